@@ -1,0 +1,196 @@
+/*
+ * CPU restatement of dpf-nets' structural-loss CUDA kernels (Chamfer NN distance
+ * and approximate EMD).  Plain C, fp32, one thread.
+ *
+ * TEST INFRASTRUCTURE -- the checker, never the thing measured or shipped.
+ * Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may load
+ * it.  Build: oracle/Makefile (gcc -O2 -ffp-contract=off).
+ *
+ * Parity status
+ *   Chamfer values:   PINNED against the reference's own pure-PyTorch
+ *                     distChamfer (lib/metrics/evaluation_metrics.py:35-45)
+ *                     imported on CPU -> tests/golden/chamfer_*.npz.
+ *   Chamfer argmin:   the reference holds no test, fixture or CPU path that
+ *                     returns indices; this file IS the index oracle
+ *                     (SURVEY.md section 8c): fp32, d=(dx*dx+dy*dy)+dz*dz with
+ *                     dx = x2 - x1, no FMA contraction, k ascending, strict '<'
+ *                     => lowest index among ties (nndistance.cu:22-26,116).
+ *   approx-EMD:       PARITY UNPINNED -- the reference has no CPU
+ *                     implementation, test or golden vector for it, and its
+ *                     kernels use __expf; this restatement follows
+ *                     approxmatch.cu line by line in fp32 with expf().
+ *
+ * The reference's .cu sources cannot be compiled here (no nvcc; CUDA-only), so
+ * there is no oracle/_ref build for them.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- Chamfer: nndistance.cu:2-128 -------------------------------------- */
+static void nn_one_direction(int b, int n, const float *xyz, int m, const float *xyz2,
+                             float *result, int *result_i) {
+    for (int i = 0; i < b; i++) {
+        const float *q = xyz + (size_t)i * n * 3;
+        const float *c = xyz2 + (size_t)i * m * 3;
+        for (int j = 0; j < n; j++) {
+            const float x1 = q[j * 3 + 0], y1 = q[j * 3 + 1], z1 = q[j * 3 + 2];
+            float best = 0.0f;
+            int best_i = 0;
+            for (int k = 0; k < m; k++) {
+                const float x2 = c[k * 3 + 0] - x1;          /* nndistance.cu:22-24 */
+                const float y2 = c[k * 3 + 1] - y1;
+                const float z2 = c[k * 3 + 2] - z1;
+                const float xx = x2 * x2, yy = y2 * y2, zz = z2 * z2;
+                const float d = (xx + yy) + zz;              /* :25, no contraction */
+                if (k == 0 || d < best) {                    /* :26 and :116: first minimum wins */
+                    best = d;
+                    best_i = k;
+                }
+            }
+            result[(size_t)i * n + j] = best;
+            result_i[(size_t)i * n + j] = best_i;
+        }
+    }
+}
+
+void oracle_nndistance(int b, int n, const float *xyz, int m, const float *xyz2,
+                       float *result, int *result_i, float *result2, int *result2_i) {
+    nn_one_direction(b, n, xyz, m, xyz2, result, result_i);      /* nndistance.cu:126 */
+    nn_one_direction(b, m, xyz2, n, xyz, result2, result2_i);    /* :127 */
+}
+
+/* nndistance.cu:129-154.  The reference scatters with float atomics (order
+ * undefined); this oracle accumulates in double and rounds once. */
+void oracle_nndistancegrad(int b, int n, const float *xyz1, int m, const float *xyz2,
+                           const float *grad_dist1, const int *idx1,
+                           const float *grad_dist2, const int *idx2,
+                           float *grad_xyz1, float *grad_xyz2) {
+    double *g1 = (double *)calloc((size_t)b * n * 3, sizeof(double));
+    double *g2 = (double *)calloc((size_t)b * m * 3, sizeof(double));
+    for (int i = 0; i < b; i++) {
+        for (int j = 0; j < n; j++) {                        /* launch 1, :152 */
+            const int j2 = idx1[(size_t)i * n + j];
+            const float g = grad_dist1[(size_t)i * n + j] * 2;
+            for (int c = 0; c < 3; c++) {
+                const float t = g * (xyz1[((size_t)i * n + j) * 3 + c] - xyz2[((size_t)i * m + j2) * 3 + c]);
+                g1[((size_t)i * n + j) * 3 + c] += t;
+                g2[((size_t)i * m + j2) * 3 + c] += -t;
+            }
+        }
+        for (int j = 0; j < m; j++) {                        /* launch 2, :153 (roles swapped) */
+            const int j2 = idx2[(size_t)i * m + j];
+            const float g = grad_dist2[(size_t)i * m + j] * 2;
+            for (int c = 0; c < 3; c++) {
+                const float t = g * (xyz2[((size_t)i * m + j) * 3 + c] - xyz1[((size_t)i * n + j2) * 3 + c]);
+                g2[((size_t)i * m + j) * 3 + c] += t;
+                g1[((size_t)i * n + j2) * 3 + c] += -t;
+            }
+        }
+    }
+    for (size_t t = 0; t < (size_t)b * n * 3; t++) grad_xyz1[t] = (float)g1[t];
+    for (size_t t = 0; t < (size_t)b * m * 3; t++) grad_xyz2[t] = (float)g2[t];
+    free(g1);
+    free(g2);
+}
+
+/* ---- approximate EMD: approxmatch.cu:3-182 ----------------------------- */
+static inline float sqd(const float *a, const float *c) {
+    /* (x2-x1)*(x2-x1)+(y2-y1)*(y2-y1)+(z2-z1)*(z2-z1), approxmatch.cu:54 */
+    const float dx = c[0] - a[0], dy = c[1] - a[1], dz = c[2] - a[2];
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+/* match: (b, m, n) with match[i][l][k]; temp: (b, 2*(n+m)) scratch laid out as
+ * remainL[n] remainR[m] ratioL[n] ratioR[m] (approxmatch.cu:4). */
+void oracle_approxmatch(int b, int n, int m, const float *xyz1, const float *xyz2,
+                        float *match, float *temp) {
+    float multiL, multiR;
+    if (n >= m) { multiL = 1; multiR = (float)(n / m); }     /* integer division, :6-12 */
+    else        { multiL = (float)(m / n); multiR = 1; }
+    for (int i = 0; i < b; i++) {
+        const float *p1 = xyz1 + (size_t)i * n * 3;
+        const float *p2 = xyz2 + (size_t)i * m * 3;
+        float *mt = match + (size_t)i * n * m;
+        float *remainL = temp + (size_t)i * (n + m) * 2;
+        float *remainR = remainL + n, *ratioL = remainR + m, *ratioR = ratioL + n;
+        memset(mt, 0, sizeof(float) * (size_t)n * m);        /* :16-17 */
+        for (int k = 0; k < n; k++) remainL[k] = multiL;
+        for (int l = 0; l < m; l++) remainR[l] = multiR;
+        for (int j = 7; j > -2; j--) {                       /* :24 (j==-2 branch is dead) */
+            const float level = -powf(4.0f, (float)j);
+            for (int k = 0; k < n; k++) {                    /* pass 1, :29-62 */
+                float suml = 1e-9f;
+                for (int l = 0; l < m; l++)
+                    suml += expf(level * sqd(p1 + k * 3, p2 + l * 3)) * remainR[l];
+                ratioL[k] = remainL[k] / suml;
+            }
+            for (int l = 0; l < m; l++) {                    /* pass 2, :78-111 */
+                float sumr = 0;
+                for (int k = 0; k < n; k++)
+                    sumr += expf(level * sqd(p1 + k * 3, p2 + l * 3)) * ratioL[k];
+                sumr *= remainR[l];
+                const float consumption = fminf(remainR[l] / (sumr + 1e-9f), 1.0f);
+                ratioR[l] = consumption * remainR[l];
+                remainR[l] = fmaxf(0.0f, remainR[l] - sumr);
+            }
+            for (int k = 0; k < n; k++) {                    /* pass 3, :130-163 */
+                float suml = 0;
+                const float rl = ratioL[k];
+                for (int l = 0; l < m; l++) {
+                    const float w = expf(level * sqd(p1 + k * 3, p2 + l * 3)) * rl * ratioR[l];
+                    mt[(size_t)l * n + k] += w;
+                    suml += w;
+                }
+                remainL[k] = fmaxf(0.0f, remainL[k] - suml);
+            }
+        }
+    }
+}
+
+/* approxmatch.cu:184-224: out[i] = sum_{l,k} match[i][l][k] * ||xyz1[k]-xyz2[l]||.
+ * The reference sums in a 512-thread strided + tree order; fp32 summation order
+ * is not part of the contract, so this accumulates in double. */
+void oracle_matchcost(int b, int n, int m, const float *xyz1, const float *xyz2,
+                      const float *match, float *out) {
+    for (int i = 0; i < b; i++) {
+        double s = 0;
+        for (int l = 0; l < m; l++)
+            for (int k = 0; k < n; k++) {
+                const float d = sqrtf(sqd(xyz1 + ((size_t)i * n + k) * 3, xyz2 + ((size_t)i * m + l) * 3));
+                s += (double)(match[(size_t)i * n * m + (size_t)l * n + k] * d);
+            }
+        out[i] = (float)s;
+    }
+}
+
+/* approxmatch.cu:229-291. */
+void oracle_matchcostgrad(int b, int n, int m, const float *xyz1, const float *xyz2,
+                          const float *match, float *grad1, float *grad2) {
+    for (int i = 0; i < b; i++) {
+        const float *p1 = xyz1 + (size_t)i * n * 3, *p2 = xyz2 + (size_t)i * m * 3;
+        const float *mt = match + (size_t)i * n * m;
+        for (int k = 0; k < n; k++) {                        /* grad1, :270-291 */
+            double gx = 0, gy = 0, gz = 0;
+            for (int l = 0; l < m; l++) {
+                const float dx = p1[k * 3] - p2[l * 3], dy = p1[k * 3 + 1] - p2[l * 3 + 1], dz = p1[k * 3 + 2] - p2[l * 3 + 2];
+                const float d = mt[(size_t)l * n + k] * (1.0f / sqrtf(fmaxf((dx * dx + dy * dy) + dz * dz, 1e-20f)));
+                gx += dx * d; gy += dy * d; gz += dz * d;
+            }
+            grad1[((size_t)i * n + k) * 3 + 0] = (float)gx;
+            grad1[((size_t)i * n + k) * 3 + 1] = (float)gy;
+            grad1[((size_t)i * n + k) * 3 + 2] = (float)gz;
+        }
+        for (int l = 0; l < m; l++) {                        /* grad2, :229-269 */
+            double gx = 0, gy = 0, gz = 0;
+            for (int k = 0; k < n; k++) {
+                const float dx = p2[l * 3] - p1[k * 3], dy = p2[l * 3 + 1] - p1[k * 3 + 1], dz = p2[l * 3 + 2] - p1[k * 3 + 2];
+                const float d = mt[(size_t)l * n + k] * (1.0f / sqrtf(fmaxf((dx * dx + dy * dy) + dz * dz, 1e-20f)));
+                gx += dx * d; gy += dy * d; gz += dz * d;
+            }
+            grad2[((size_t)i * m + l) * 3 + 0] = (float)gx;
+            grad2[((size_t)i * m + l) * 3 + 1] = (float)gy;
+            grad2[((size_t)i * m + l) * 3 + 2] = (float)gz;
+        }
+    }
+}

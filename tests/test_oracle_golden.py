@@ -1,0 +1,210 @@
+"""Pins the CPU oracle (oracle/) against golden vectors captured from the
+reference's own PyTorch modules (oracle/gen_golden.py).  CPU only."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import detrng
+from oracle import flow_oracle as FO
+from oracle import structural as S
+from oracle.gen_golden import layer_inputs, chamfer_inputs, _grad_projection
+
+RTOL, ATOL = 1e-5, 2e-6   # oracle and reference are both fp32 torch-CPU; only op association differs
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz")), json.load(open(os.path.join(golden_dir, name + ".json")))
+
+
+def test_param_spec_matches_reference_state_dict(golden_dir):
+    keys = json.load(open(os.path.join(golden_dir, "state_keys.json")))
+    for warp in ([0], [0, 1]):
+        ref = keys["CondRealNVPFlow3D_w" + "".join(map(str, warp))]
+        spec = FO.layer_param_spec(64, 128, warp)
+        assert [k for k, _, _ in ref] == [k for k, _, _ in spec]
+        assert [tuple(s) for _, s, _ in ref] == [tuple(s) for _, s, _ in spec]
+    ref = keys["LocalCondRNVPDecoder_nf2_g512"]
+    st = FO.make_decoder_state(0, 2, 64, 512)
+    assert [k for k, _, _ in ref] == list(st.keys())
+    nparam = sum(int(np.prod(s)) for k, s, _ in ref
+                 if not (k.endswith("running_mean") or k.endswith("running_var")
+                         or k.endswith("num_batches_tracked") or k.endswith("eps")))
+    assert nparam == keys["LocalCondRNVPDecoder_nf2_g512_nparams"]
+    # 157 058 / 157 060 params per layer at G=512 (pattern 0 / 1)
+    assert nparam == 3 * 157058 + 3 * 157060
+
+
+def test_coupling_layer_vs_reference(golden_dir):
+    gold, meta = _load(golden_dir, "flow_layer")
+    B, N, F, G = meta["B"], meta["N"], meta["F"], meta["G"]
+    for case in meta["cases"]:
+        tag, warp, mode, bn, seed = case["tag"], case["warp"], case["mode"], case["bn"], case["seed"]
+        st = FO.to_torch(FO.make_layer_state(seed, F, G, warp))
+        for k, v in st.items():
+            if v.dtype == torch.float32 and k != "eps" and not ("running" in k):
+                v.requires_grad_(True)
+        p, g, r1, r2, r3 = layer_inputs(seed, B, N, G)
+        tp = torch.from_numpy(p.copy()).requires_grad_(True)
+        tg = torch.from_numpy(g.copy()).requires_grad_(True)
+        stats = {}
+        p_out, mu, lv = FO.coupling_layer(st, tp, tg, mode, warp, training=(bn == "train"), stats_out=stats)
+        np.testing.assert_allclose(p_out.detach().numpy(), gold[tag + "/p_out"], rtol=RTOL, atol=ATOL, err_msg=tag)
+        np.testing.assert_allclose(mu.detach().numpy(), gold[tag + "/mu"], rtol=RTOL, atol=ATOL, err_msg=tag)
+        np.testing.assert_allclose(lv.detach().numpy(), gold[tag + "/logvar"], rtol=RTOL, atol=ATOL, err_msg=tag)
+        loss = (p_out * torch.from_numpy(r1)).sum() + (lv * torch.from_numpy(r2)).sum() + (mu * torch.from_numpy(r3)).sum()
+        loss.backward()
+        np.testing.assert_allclose(tp.grad.numpy(), gold[tag + "/grad_p"], rtol=2e-4, atol=2e-5, err_msg=tag)
+        np.testing.assert_allclose(tg.grad.numpy(), gold[tag + "/grad_g"], rtol=2e-3, atol=2e-4, err_msg=tag)
+        named = [(k, v.grad) for k, v in st.items() if v.requires_grad]
+        for k, v in _grad_projection(named, seed).items():
+            ref = gold[tag + "/gproj/" + k]
+            scale = ref[2] + 1e-6        # sum |grad|: projection error budget relative to gradient mass
+            assert abs(v[0] - ref[0]) <= 2e-4 * scale + 1e-5, (tag, k, v, ref)
+            assert abs(v[1] - ref[1]) <= 2e-4 * scale * 3 + 1e-5, (tag, k, v, ref)
+        if bn == "train":
+            for k, v in stats.items():
+                np.testing.assert_allclose(v.numpy(), gold[tag + "/stats/" + k], rtol=1e-5, atol=1e-6, err_msg=tag + k)
+            assert len(stats) == 2 * 2 * 4       # 2 branches x (sd0_bn, sd1_bn, film_w0_bn, film_b0_bn) x (mean, var)
+
+
+def test_decoder_vs_reference(golden_dir):
+    gold, meta = _load(golden_dir, "flow_decoder")
+    for case in meta["cases"]:
+        if case.get("bn") == "train":
+            continue
+        c, n_flows, B, N, G, seed, mode = (case[k] for k in ("tag", "n_flows", "B", "N", "G", "seed", "mode"))
+        st = FO.to_torch(FO.make_decoder_state(seed, n_flows, 64, G))
+        tgt, z, g = FO.synthetic_inputs(seed, B, N, G)
+        src = z if mode == "direct" else tgt
+        with torch.no_grad():
+            ps, mus, lvs = FO.decoder(st, n_flows, torch.from_numpy(src), torch.from_numpy(g), mode)
+            assert len(ps) == 3 * n_flows
+            tol = dict(rtol=5e-5, atol=5e-6) if n_flows > 5 else dict(rtol=RTOL, atol=ATOL)
+            for k in case["picks"]:
+                np.testing.assert_allclose(ps[k].numpy(), gold["%s/ps%d" % (c, k)], err_msg=c, **tol)
+                np.testing.assert_allclose(mus[k].numpy(), gold["%s/mus%d" % (c, k)], err_msg=c, **tol)
+                np.testing.assert_allclose(lvs[k].numpy(), gold["%s/logvars%d" % (c, k)], err_msg=c, **tol)
+            np.testing.assert_allclose(sum(lvs).numpy(), gold[c + "/sum_logvars"], err_msg=c, **tol)
+            pm, pl = torch.zeros(B, 3, N), torch.full((B, 3, N), -3.6)
+            smp = ps + [torch.from_numpy(src)] if mode == "inverse" else [torch.from_numpy(src)] + ps
+            nll = FO.point_flow_nll(smp, [pm] + mus, [pl] + lvs)
+            np.testing.assert_allclose(nll.numpy(), gold[c + "/nll"], rtol=2e-5)
+    # L=14 truncated stack (the BASELINE metric's layer count)
+    st = FO.to_torch(FO.make_decoder_state(7, 5, 64, 128))
+    tgt, z, g = FO.synthetic_inputs(7, 2, 128, 128)
+    with torch.no_grad():
+        ps, mus, lvs = FO.decoder(st, 5, torch.from_numpy(z), torch.from_numpy(g), "direct", n_layers=14)
+    assert len(ps) == 14
+    np.testing.assert_allclose(ps[-1].numpy(), gold["nf5_L14_direct/final"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(sum(lvs).numpy(), gold["nf5_L14_direct/sum_logvars"], rtol=RTOL, atol=ATOL)
+
+
+def test_decoder_training_step_vs_reference(golden_dir):
+    gold, meta = _load(golden_dir, "flow_decoder")
+    case = [c for c in meta["cases"] if c.get("bn") == "train"][0]
+    c, n_flows, B, N, G, seed = (case[k] for k in ("tag", "n_flows", "B", "N", "G", "seed"))
+    st = FO.to_torch(FO.make_decoder_state(seed, n_flows, 64, G))
+    for k, v in st.items():
+        if v.dtype == torch.float32 and not k.endswith("eps") and "running" not in k:
+            v.requires_grad_(True)
+    tgt, z, g = FO.synthetic_inputs(seed, B, N, G)
+    tp = torch.from_numpy(tgt.copy()).requires_grad_(True)
+    tg = torch.from_numpy(g.copy()).requires_grad_(True)
+    stats = {}
+    ps, mus, lvs = FO.decoder(st, n_flows, tp, tg, "inverse", training=True, stats_out=stats)
+    pm, pl = torch.zeros(B, 3, N), torch.full((B, 3, N), -3.6)
+    loss = FO.point_flow_nll(ps + [tp], [pm] + mus, [pl] + lvs)
+    loss.backward()
+    np.testing.assert_allclose(ps[0].detach().numpy(), gold[c + "/ps0"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(sum(lvs).detach().numpy(), gold[c + "/sum_logvars"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(loss.detach().numpy(), gold[c + "/nll"], rtol=2e-5)
+    np.testing.assert_allclose(tp.grad.numpy(), gold[c + "/grad_p"], rtol=2e-3, atol=2e-3)
+    for k, v in stats.items():
+        np.testing.assert_allclose(v.numpy(), gold[c + "/stats/" + k], rtol=1e-4, atol=1e-5, err_msg=k)
+    named = [(k, v.grad) for k, v in st.items() if v.requires_grad]
+    for k, v in _grad_projection(named, seed).items():
+        ref = gold[c + "/gproj/" + k]
+        assert abs(v[0] - ref[0]) <= 1e-3 * (ref[2] + 1e-6) + 1e-4, (k, v, ref)
+        assert abs(v[1] - ref[1]) <= 3e-3 * (ref[2] + 1e-6) + 1e-4, (k, v, ref)
+
+
+def test_chamfer_oracle_vs_reference_distChamfer(golden_dir):
+    gold = np.load(os.path.join(golden_dir, "chamfer.npz"))
+    a, b = chamfer_inputs(21, 3, 257, 257)
+    d1, i1, d2, i2 = S.nndistance(a, b)
+    # reference distChamfer returns (per-b-point, per-a-point) -- the opposite
+    # order of NNDistance
+    np.testing.assert_allclose(d1, gold["eq257/ref_per_a"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(d2, gold["eq257/ref_per_b"], rtol=1e-4, atol=2e-6)
+    for tag, (B, n, m, seed) in {"eq257": (3, 257, 257, 21), "ne": (2, 130, 515, 22)}.items():
+        a, b = chamfer_inputs(seed, B, n, m)
+        d1, i1, d2, i2 = S.nndistance(a, b)
+        np.testing.assert_allclose(d1, gold[tag + "/bf_dist1"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(d2, gold[tag + "/bf_dist2"], rtol=1e-5, atol=1e-7)
+        # indices agree with the float64 brute force wherever the best/second-best gap is resolvable in fp32
+        ok1 = gold[tag + "/bf_gap1"] > 1e-5
+        ok2 = gold[tag + "/bf_gap2"] > 1e-5
+        assert ok1.mean() > 0.9 and ok2.mean() > 0.9
+        assert np.array_equal(i1[ok1], gold[tag + "/bf_idx1"][ok1])
+        assert np.array_equal(i2[ok2], gold[tag + "/bf_idx2"][ok2])
+
+
+def test_chamfer_oracle_first_minimum_rule():
+    # integer-grid coordinates: distances are exact in fp32, ties are exact
+    B, n, m = 2, 97, 130
+    a = np.round(detrng.uniform_f32(31, (B, n, 3), -3, 3))
+    b = np.round(detrng.uniform_f32(32, (B, m, 3), -3, 3))
+    b[:, 50:60] = b[:, 10:20]              # duplicate candidates: earlier index must win
+    d1, i1, d2, i2 = S.nndistance(a, b)
+    dd = ((a[:, :, None, :] - b[:, None, :, :]) ** 2).sum(-1)
+    assert np.array_equal(i1, dd.argmin(2))        # numpy argmin = first minimum
+    assert np.array_equal(i2, dd.argmin(1))
+    assert np.array_equal(d1, dd.min(2)) and np.array_equal(d2, dd.min(1))
+    assert not np.isin(i1, np.arange(50, 60)).any()
+
+
+def test_chamfer_grad_oracle_matches_autograd():
+    B, n, m = 2, 40, 55
+    a, b = chamfer_inputs(41, B, n, m)
+    d1, i1, d2, i2 = S.nndistance(a, b)
+    gd1 = detrng.normal_f32(42, (B, n)); gd2 = detrng.normal_f32(43, (B, m))
+    g1, g2 = S.nndistancegrad(a, b, i1, i2, gd1, gd2)
+    ta = torch.from_numpy(a).double().requires_grad_(True)
+    tb = torch.from_numpy(b).double().requires_grad_(True)
+    dd = ((ta[:, :, None, :] - tb[:, None, :, :]) ** 2).sum(-1)
+    loss = (dd.min(2)[0] * torch.from_numpy(gd1).double()).sum() + (dd.min(1)[0] * torch.from_numpy(gd2).double()).sum()
+    loss.backward()
+    np.testing.assert_allclose(g1, ta.grad.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(g2, tb.grad.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_emd_oracle_invariants():
+    """approx-EMD parity is UNPINNED by the reference (no CPU path / test);
+    these are the structural invariants of approxmatch.cu's auction."""
+    for (B, n, m) in ((2, 64, 64), (2, 128, 64), (1, 48, 96)):
+        a, b = chamfer_inputs(50 + n, B, n, m)
+        match, temp = S.approxmatch(a, b)
+        multiL, multiR = (1, n // m) if n >= m else (m // n, 1)
+        assert match.shape == (B, m, n) and (match >= 0).all()
+        assert (match.sum(1) <= multiL * (1 + 1e-4)).all()       # each xyz1 point ships at most multiL
+        assert (match.sum(2) <= multiR * (1 + 1e-4)).all()       # each xyz2 point receives at most multiR
+        assert match.sum() > 0.95 * min(n * multiL, m * multiR) * B
+        cost = S.matchcost(a, b, match)
+        assert (cost > 0).all()
+        g1, g2 = S.matchcostgrad(a, b, match)
+        # d cost / d xyz with match held constant == autograd of sum(match * dist)
+        ta = torch.from_numpy(a).double().requires_grad_(True)
+        tb = torch.from_numpy(b).double().requires_grad_(True)
+        dist = ((ta[:, None, :, :] - tb[:, :, None, :]) ** 2).sum(-1).sqrt()
+        (torch.from_numpy(match).double() * dist).sum().backward()
+        np.testing.assert_allclose(g1, ta.grad.numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(g2, tb.grad.numpy(), rtol=1e-4, atol=1e-5)
+    # identical clouds: the matching is (nearly) the identity and the cost ~ 0
+    a, _ = chamfer_inputs(60, 2, 64, 64)
+    match, _ = S.approxmatch(a, a.copy())
+    assert (S.matchcost(a, a.copy(), match) < 0.05).all()
+    assert (np.diagonal(match, axis1=1, axis2=2) > 0.9).all()
