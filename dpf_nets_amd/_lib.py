@@ -1,0 +1,70 @@
+"""ctypes binding of libdpf_hip.so (include/dpf_hip.h).
+
+There is NO fallback: if the shared library is missing or a symbol cannot be
+resolved, every product entry point raises.  Build it with
+`python -c "import __graft_entry__ as g; g.build()"` or
+`make -C dpf_nets_amd/csrc`.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/dpf_hip.h declares
+SIGNATURES = {
+    "dpf_nndistance": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dpf_nndistancegrad": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dpf_approxmatch": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "dpf_matchcost": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "dpf_matchcostgrad": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dpf_flow_canon_floats": (_sz, [_i]),
+    "dpf_flow_packed_bytes": (_sz, [_i, _i]),
+    "dpf_flow_film_floats": (_sz, [_i, _i]),
+    "dpf_flow_pack": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "dpf_flow_film": (_i, [_i, _i, _i, _vp, _vp, _vp, _f, _vp]),
+    "dpf_flow_forward": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp]),
+    "dpf_version": (ctypes.c_char_p, []),
+}
+
+PREC = {"bf16": 1, "bf16x3": 2, "bf16x6": 3}
+MODE = {"direct": 0, "inverse": 1}
+
+
+def lib_path():
+    return os.path.join(_HERE, "libdpf_hip.so")
+
+
+def have_lib():
+    return os.path.exists(lib_path())
+
+
+def lib():
+    """The loaded library; raises RuntimeError (never falls back) if it is absent."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "dpf_nets_amd: %s is missing -- the HIP kernels are not built. "
+                "Run __graft_entry__.build() or `make -C dpf_nets_amd/csrc`. There is no CPU fallback." % path)
+        handle = ctypes.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = handle
+    return _LIB
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: "invalid argument", -2: "unsupported shape"}.get(rc, "hipError_t %d" % rc)
+        raise RuntimeError("dpf_hip: %s failed: %s" % (what, kind))
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,308 @@
+// Chamfer nearest-neighbour distance for gfx950 (MI355X): forward (min + first
+// argmin, bit-exact contract) and backward (scatter through the argmin).
+//
+// Replaces NmDistanceKernel / NmDistanceGradKernel of the reference
+// (lib/metrics/pytorch_structural_losses/src/nndistance.cu:2-154).
+//
+// Forward design (VALU-bound brute force, 2*B*n*m pair evaluations):
+//  * one wave owns 128 contiguous query points (two per lane, held in
+//    registers as packed f32 pairs so the distance runs on v_pk_{add,mul}_f32);
+//  * candidate points are wave-uniform, so they are fetched with SCALAR loads
+//    straight into SGPRs (no LDS, no bank conflicts, no vector-memory issue
+//    slots) and broadcast into the packed ops;
+//  * the inner loop only tracks the running MINIMUM per chunk of 8 candidates
+//    (v_min), and remembers which chunk first achieved the best value; the
+//    winning chunk is re-scanned once at the end to recover the first index.
+//    That is arithmetically identical to the reference's strict '<' scan in
+//    ascending k (nndistance.cu:26,116) but costs ~5 instead of ~8 VALU ops
+//    per pair;
+//  * small problems split the candidate range over the waves of a workgroup
+//    (KS) so the launch still fills 256 CUs x 4 SIMDs; partial results merge
+//    in LDS in ascending slice order with the same strict '<'.
+//  d = (dx*dx + dy*dy) + dz*dz, dx = candidate - query, every operation rounded
+//  separately: this file is compiled with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include "dpf_hip.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+constexpr int CH = 8;            // candidates per min-chunk
+constexpr int NWAVES = 4;        // waves per workgroup
+constexpr int QPW = 128;         // query points per wave (2 per lane)
+
+struct NNDir {
+    const float *q;   // (B, nq, 3) queries
+    const float *c;   // (B, nc, 3) candidates
+    float *dist;      // (B, nq)
+    int *idx;         // (B, nq)
+    int nq, nc;
+};
+
+struct NNArgs {
+    NNDir d[2];
+};
+
+__device__ __forceinline__ f2 pair_dist(float sx, float sy, float sz, f2 qx, f2 qy, f2 qz) {
+    const f2 dx = sx - qx, dy = sy - qy, dz = sz - qz;
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+// Candidate coordinates live in SGPR *pairs* (64-bit scalar loads); element e of
+// a chunk is the (e&1) half of pair e>>1.  v_pk_add_f32 broadcasts that half to
+// both packed lanes through op_sel, so no SGPR copies or VGPR splats are needed
+// (hipcc otherwise emits an s_mov per odd element, which also drags the
+// scalar-load wait to the top of the chunk).
+template <int HALF>
+__device__ __forceinline__ f2 bsub(unsigned long long pr, f2 q) {   // {s,s} - q
+    f2 r;
+    if constexpr (HALF == 0)
+        asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "s"(pr), "v"(q));
+    else
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "s"(pr), "v"(q));
+    return r;
+}
+
+template <int U>   // candidate U of a chunk held as 12 pairs
+__device__ __forceinline__ f2 pair_dist_sp(const unsigned long long (&pr)[CH * 3 / 2], f2 qx, f2 qy, f2 qz) {
+    const f2 dx = bsub<(3 * U + 0) & 1>(pr[(3 * U + 0) >> 1], qx);
+    const f2 dy = bsub<(3 * U + 1) & 1>(pr[(3 * U + 1) >> 1], qy);
+    const f2 dz = bsub<(3 * U + 2) & 1>(pr[(3 * U + 2) >> 1], qz);
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+template <int U>
+__device__ __forceinline__ void chunk_min_sp(const unsigned long long (&pr)[CH * 3 / 2], f2 qx, f2 qy, f2 qz, f2 &dm) {
+    if constexpr (U < CH) {
+        const f2 d = pair_dist_sp<U>(pr, qx, qy, qz);
+        dm.x = fminf(dm.x, d.x);
+        dm.y = fminf(dm.y, d.y);
+        chunk_min_sp<U + 1>(pr, qx, qy, qz, dm);
+    }
+}
+
+__device__ __forceinline__ float one_dist(float cx, float cy, float cz, float qx, float qy, float qz) {
+    const float dx = cx - qx, dy = cy - qy, dz = cz - qz;
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+template <int KS>
+__global__ __launch_bounds__(NWAVES * 64) void nn_kernel(NNArgs args) {
+    constexpr int QG = NWAVES / KS;          // query groups per workgroup
+    const NNDir A = args.d[blockIdx.z];
+    const int nq = A.nq, nc = A.nc;
+    if ((int)blockIdx.x * QG * QPW >= nq) return;   // this direction has fewer query tiles
+    const int bi = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int qg = wave / KS, ks = wave % KS;
+    const float *__restrict__ q = A.q + (size_t)bi * nq * 3;
+    const float *__restrict__ c = A.c + (size_t)bi * nc * 3;
+
+    const int j0 = (blockIdx.x * QG + qg) * QPW + lane;
+    const int j1 = j0 + 64;
+    const int j0c = min(j0, nq - 1), j1c = min(j1, nq - 1);
+    const f2 qx = {q[j0c * 3 + 0], q[j1c * 3 + 0]};
+    const f2 qy = {q[j0c * 3 + 1], q[j1c * 3 + 1]};
+    const f2 qz = {q[j0c * 3 + 2], q[j1c * 3 + 2]};
+
+    // candidate slice of this wave, aligned to whole chunks
+    const int nchunk = (nc + CH - 1) / CH;
+    const int kbeg = (int)((long)nchunk * ks / KS) * CH;
+    const int kend = min(nc, (int)((long)nchunk * (ks + 1) / KS) * CH);
+
+    const float INF = __builtin_inff();
+    f2 best = {INF, INF};
+    int bc0 = kbeg, bc1 = kbeg;
+    int k = kbeg;
+    const int nfull = (kend - kbeg) / CH;          // whole chunks in this slice
+    if (nfull > 0) {
+        // Software-pipelined scalar loads, ping-pong between two SGPR sets so
+        // that chunk i+1's 24 floats are in flight while chunk i runs on the VALU.
+        const int klast = kbeg + (nfull - 1) * CH;  // last whole chunk (prefetch clamp, never out of bounds)
+        unsigned long long bufA[CH * 3 / 2], bufB[CH * 3 / 2];
+#define DPF_LOAD_CHUNK(buf, kk)                                                  \
+        {                                                                        \
+            const unsigned long long *__restrict__ ck_ =                         \
+                (const unsigned long long *)(c + (size_t)(kk) * 3); /* uniform, 8B-aligned (kk % 8 == 0) -> s_load */ \
+            _Pragma("unroll") for (int u = 0; u < CH * 3 / 2; ++u) buf[u] = ck_[u]; \
+        }
+#define DPF_EVAL_HEAD(buf) f2 dm = pair_dist_sp<0>(buf, qx, qy, qz);
+#define DPF_EVAL_TAIL(buf, kk)                                                   \
+        chunk_min_sp<1>(buf, qx, qy, qz, dm);                                    \
+        if (dm.x < best.x) { best.x = dm.x; bc0 = (kk); }                        \
+        if (dm.y < best.y) { best.y = dm.y; bc1 = (kk); }
+        // SMEM returns out of order, so any use of loaded SGPRs waits for ALL
+        // outstanding scalar loads (lgkmcnt(0)).  Each prefetch is therefore
+        // issued right AFTER the first use of the other buffer (its wait) and
+        // has one whole chunk of VALU work to land.
+        DPF_LOAD_CHUNK(bufA, k);
+        int it = 0;
+        for (; it + 2 <= nfull; it += 2, k += 2 * CH) {
+            {
+                DPF_EVAL_HEAD(bufA);
+                __builtin_amdgcn_sched_barrier(0);
+                DPF_LOAD_CHUNK(bufB, k + CH);
+                __builtin_amdgcn_sched_barrier(0);
+                DPF_EVAL_TAIL(bufA, k);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                DPF_EVAL_HEAD(bufB);
+                __builtin_amdgcn_sched_barrier(0);
+                DPF_LOAD_CHUNK(bufA, min(k + 2 * CH, klast));
+                __builtin_amdgcn_sched_barrier(0);
+                DPF_EVAL_TAIL(bufB, k + CH);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (it < nfull) {
+            DPF_EVAL_HEAD(bufA);
+            DPF_EVAL_TAIL(bufA, k);
+            k += CH;
+        }
+#undef DPF_EVAL_HEAD
+#undef DPF_EVAL_TAIL
+#undef DPF_LOAD_CHUNK
+    }
+    if (k < kend) {   // ragged last chunk (only the last slice can have one)
+        f2 dm = {INF, INF};
+        for (int u = 0; k + u < kend; ++u) {
+            const f2 d = pair_dist(c[(k + u) * 3 + 0], c[(k + u) * 3 + 1], c[(k + u) * 3 + 2], qx, qy, qz);
+            dm.x = fminf(dm.x, d.x);
+            dm.y = fminf(dm.y, d.y);
+        }
+        if (dm.x < best.x) { best.x = dm.x; bc0 = k; }
+        if (dm.y < best.y) { best.y = dm.y; bc1 = k; }
+    }
+
+    // recover the FIRST index inside the winning chunk (descending scan, last hit wins)
+    int i0 = bc0, i1 = bc1;
+#pragma unroll
+    for (int u = CH - 1; u >= 0; --u) {
+        const int k0 = min(bc0 + u, nc - 1), k1 = min(bc1 + u, nc - 1);
+        const float d0 = one_dist(c[k0 * 3 + 0], c[k0 * 3 + 1], c[k0 * 3 + 2], qx.x, qy.x, qz.x);
+        const float d1 = one_dist(c[k1 * 3 + 0], c[k1 * 3 + 1], c[k1 * 3 + 2], qx.y, qy.y, qz.y);
+        if (d0 == best.x && bc0 + u < kend) i0 = bc0 + u;
+        if (d1 == best.y && bc1 + u < kend) i1 = bc1 + u;
+    }
+
+    if constexpr (KS > 1) {
+        __shared__ float sd[NWAVES][QPW];
+        __shared__ int si[NWAVES][QPW];
+        sd[wave][lane] = best.x; sd[wave][lane + 64] = best.y;
+        si[wave][lane] = i0;     si[wave][lane + 64] = i1;
+        __syncthreads();
+        if (ks != 0) return;
+#pragma unroll
+        for (int s = 1; s < KS; ++s) {   // ascending slices + strict '<' == global first minimum
+            const float e0 = sd[wave + s][lane], e1 = sd[wave + s][lane + 64];
+            if (e0 < best.x) { best.x = e0; i0 = si[wave + s][lane]; }
+            if (e1 < best.y) { best.y = e1; i1 = si[wave + s][lane + 64]; }
+        }
+    }
+    if (j0 < nq) { A.dist[(size_t)bi * nq + j0] = best.x; A.idx[(size_t)bi * nq + j0] = i0; }
+    if (j1 < nq) { A.dist[(size_t)bi * nq + j1] = best.y; A.idx[(size_t)bi * nq + j1] = i1; }
+}
+
+// ---- backward -------------------------------------------------------------
+// grad_xyz1[b,j] = 2*gd1[b,j]*(x1_j - x2[idx1_j])  -  sum_{l: idx2_l = j} 2*gd2[b,l]*(x2_l - x1_j)
+// (nndistance.cu:139-145, both launches of :152-153).  The first term of each
+// output has no collisions and is written with plain stores (which also
+// replaces the reference's memset); only the scattered term uses atomics.
+__global__ __launch_bounds__(256) void nn_grad_direct_kernel(int b, int n, const float *__restrict__ xyz1, int m,
+                                                             const float *__restrict__ xyz2,
+                                                             const float *__restrict__ gd1, const int *__restrict__ idx1,
+                                                             const float *__restrict__ gd2, const int *__restrict__ idx2,
+                                                             float *__restrict__ g1, float *__restrict__ g2) {
+    const long total1 = (long)b * n, total = total1 + (long)b * m;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const bool first = t < total1;
+        const long u = first ? t : t - total1;
+        const int nn = first ? n : m, mm = first ? m : n;
+        const float *xa = first ? xyz1 : xyz2, *xb = first ? xyz2 : xyz1;
+        const float *gd = first ? gd1 : gd2;
+        const int *idx = first ? idx1 : idx2;
+        float *go = first ? g1 : g2;
+        const long bi = u / nn;
+        const int j2 = idx[u];
+        const float g = gd[u] * 2;
+        const float *pa = xa + u * 3, *pb = xb + (bi * mm + j2) * 3;
+        go[u * 3 + 0] = g * (pa[0] - pb[0]);
+        go[u * 3 + 1] = g * (pa[1] - pb[1]);
+        go[u * 3 + 2] = g * (pa[2] - pb[2]);
+    }
+}
+
+__global__ __launch_bounds__(256) void nn_grad_scatter_kernel(int b, int n, const float *__restrict__ xyz1, int m,
+                                                              const float *__restrict__ xyz2,
+                                                              const float *__restrict__ gd1, const int *__restrict__ idx1,
+                                                              const float *__restrict__ gd2, const int *__restrict__ idx2,
+                                                              float *g1, float *g2) {
+    const long total1 = (long)b * n, total = total1 + (long)b * m;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const bool first = t < total1;
+        const long u = first ? t : t - total1;
+        const int nn = first ? n : m, mm = first ? m : n;
+        const float *xa = first ? xyz1 : xyz2, *xb = first ? xyz2 : xyz1;
+        const float *gd = first ? gd1 : gd2;
+        const int *idx = first ? idx1 : idx2;
+        float *go = first ? g2 : g1;          // the OTHER cloud's gradient
+        const long bi = u / nn;
+        const int j2 = idx[u];
+        const float g = gd[u] * 2;
+        const float *pa = xa + u * 3, *pb = xb + (bi * mm + j2) * 3;
+        float *dst = go + (bi * mm + j2) * 3;
+        atomicAdd(dst + 0, -(g * (pa[0] - pb[0])));
+        atomicAdd(dst + 1, -(g * (pa[1] - pb[1])));
+        atomicAdd(dst + 2, -(g * (pa[2] - pb[2])));
+    }
+}
+
+}  // namespace
+
+extern "C" int dpf_nndistance(int b, int n, const float *xyz, int m, const float *xyz2, float *result, int *result_i,
+                              float *result2, int *result2_i, dpf_stream_t stream) {
+    if (b < 0 || n <= 0 || m <= 0) return DPF_EINVAL;
+    if (b == 0) return 0;
+    if (!xyz || !xyz2 || !result || !result_i || !result2 || !result2_i) return DPF_EINVAL;
+    if ((long)n * 3 >= (1l << 31) || (long)m * 3 >= (1l << 31) || b > 65535) return DPF_ENOSUP;
+    NNArgs a;
+    a.d[0] = NNDir{xyz, xyz2, result, result_i, n, m};     // nndistance.cu:126
+    a.d[1] = NNDir{xyz2, xyz, result2, result2_i, m, n};   // nndistance.cu:127
+    const int nmax = n > m ? n : m;
+    // pick the candidate split so that the launch has >= ~2 waves per SIMD on 256 CUs
+    const long waves1 = (long)b * ((n + QPW - 1) / QPW + (m + QPW - 1) / QPW);
+    hipStream_t s = (hipStream_t)stream;
+    if (waves1 >= 2048 || (n < 64 && m < 64)) {
+        dim3 grid((nmax + NWAVES * QPW - 1) / (NWAVES * QPW), b, 2);
+        hipLaunchKernelGGL(nn_kernel<1>, grid, dim3(NWAVES * 64), 0, s, a);
+    } else if (waves1 >= 1024) {
+        dim3 grid((nmax + 2 * QPW - 1) / (2 * QPW), b, 2);
+        hipLaunchKernelGGL(nn_kernel<2>, grid, dim3(NWAVES * 64), 0, s, a);
+    } else {
+        dim3 grid((nmax + QPW - 1) / QPW, b, 2);
+        hipLaunchKernelGGL(nn_kernel<4>, grid, dim3(NWAVES * 64), 0, s, a);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int dpf_nndistancegrad(int b, int n, const float *xyz1, int m, const float *xyz2, const float *grad_dist1,
+                                  const int *idx1, const float *grad_dist2, const int *idx2, float *grad_xyz1,
+                                  float *grad_xyz2, dpf_stream_t stream) {
+    if (b < 0 || n <= 0 || m <= 0) return DPF_EINVAL;
+    if (b == 0) return 0;
+    if (!xyz1 || !xyz2 || !grad_dist1 || !idx1 || !grad_dist2 || !idx2 || !grad_xyz1 || !grad_xyz2) return DPF_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)b * (n + m);
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(nn_grad_direct_kernel, dim3(blocks), dim3(256), 0, s, b, n, xyz1, m, xyz2, grad_dist1, idx1,
+                       grad_dist2, idx2, grad_xyz1, grad_xyz2);
+    hipLaunchKernelGGL(nn_grad_scatter_kernel, dim3(blocks), dim3(256), 0, s, b, n, xyz1, m, xyz2, grad_dist1, idx1,
+                       grad_dist2, idx2, grad_xyz1, grad_xyz2);
+    return (int)hipGetLastError();
+}

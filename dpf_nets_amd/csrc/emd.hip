@@ -1,0 +1,285 @@
+// Approximate earth-mover's distance (soft auction matching) for gfx950.
+//
+// Replaces approxmatchkernel / matchcostkernel / matchcostgrad{1,2}kernel of the
+// reference (lib/metrics/pytorch_structural_losses/src/approxmatch.cu:3-326).
+//
+// The reference runs ONE 512-thread block per cloud with block barriers
+// between the 27 dependent passes (9 annealing levels x 3 passes), so B=16
+// clouds use 16 of 256 CUs.  Here every pass is its own launch over
+// (points x candidate-slices x clouds): a workgroup owns 64 points of one
+// cloud, its waves split the inner loop over the other cloud (wave-uniform
+// candidates come in through scalar loads), and partial sums merge in LDS in
+// a fixed order.  The kernel boundary is the grid-wide barrier the algorithm
+// needs between passes.  The (B, m, n) `match` tensor is the only large
+// object: pass 3 read-modify-writes it once per level (the first level writes
+// without reading, which replaces the reference's zero-fill, approxmatch.cu:16-17).
+#include <hip/hip_runtime.h>
+
+#include "dpf_hip.h"
+
+namespace {
+
+constexpr int MAXS = 16;   // max inner-loop slices (waves) per workgroup
+
+__device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, float by, float bz) {
+    const float dx = bx - ax, dy = by - ay, dz = bz - az;
+    return dx * dx + dy * dy + dz * dz;
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// remainL = multiL, remainR = multiR                       approxmatch.cu:6-12,18-21
+__global__ void emd_init_kernel(int n, int m, float multiL, float multiR, float *__restrict__ temp) {
+    float *t = temp + (size_t)blockIdx.y * (n + m) * 2;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n + m; i += gridDim.x * blockDim.x)
+        t[i] = i < n ? multiL : multiR;
+}
+
+// Passes 1 and 2 share one shape: for every point i of cloud P
+//     s_i = sum_j exp(level * |P_i - Q_j|^2) * wq[j]
+// PASS 1 (P=xyz1, Q=xyz2, wq=remainR): ratioL[i] = remainL[i] / (1e-9 + s_i)    approxmatch.cu:29-62
+// PASS 2 (P=xyz2, Q=xyz1, wq=ratioL):  sumr = s_i * remainR[i];                  approxmatch.cu:78-111
+//        ratioR[i] = min(remainR[i]/(sumr+1e-9), 1) * remainR[i]; remainR[i] = max(0, remainR[i]-sumr)
+template <int PASS>
+__global__ __launch_bounds__(1024) void emd_ratio_kernel(int n, int m, float lvl2, const float *__restrict__ xyz1,
+                                                         const float *__restrict__ xyz2, float *temp) {
+    __shared__ float part[MAXS][64];
+    const int bi = blockIdx.y;
+    const int lane = threadIdx.x, slice = __builtin_amdgcn_readfirstlane(threadIdx.y), S = blockDim.y;
+    float *t = temp + (size_t)bi * (n + m) * 2;
+    float *remainL = t, *remainR = t + n, *ratioL = t + n + m, *ratioR = t + n + m + n;
+    const int np = PASS == 1 ? n : m, nq = PASS == 1 ? m : n;
+    const float *__restrict__ P = (PASS == 1 ? xyz1 + (size_t)bi * n * 3 : xyz2 + (size_t)bi * m * 3);
+    const float *__restrict__ Q = (PASS == 1 ? xyz2 + (size_t)bi * m * 3 : xyz1 + (size_t)bi * n * 3);
+    const float *__restrict__ wq = PASS == 1 ? remainR : ratioL;
+    const int i = blockIdx.x * 64 + lane;
+    const int ic = min(i, np - 1);
+    const float px = P[ic * 3 + 0], py = P[ic * 3 + 1], pz = P[ic * 3 + 2];
+    const int jb = (int)((long)nq * slice / S), je = (int)((long)nq * (slice + 1) / S);
+    float s = 0.f;
+    int j = jb;
+    for (; j + 4 <= je; j += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float d2 = sqdist(px, py, pz, Q[(j + u) * 3 + 0], Q[(j + u) * 3 + 1], Q[(j + u) * 3 + 2]);
+            s += fast_exp2(lvl2 * d2) * wq[j + u];
+        }
+    }
+    for (; j < je; ++j) {
+        const float d2 = sqdist(px, py, pz, Q[j * 3 + 0], Q[j * 3 + 1], Q[j * 3 + 2]);
+        s += fast_exp2(lvl2 * d2) * wq[j];
+    }
+    part[slice][lane] = s;
+    __syncthreads();
+    if (slice != 0 || i >= np) return;
+    float tot = PASS == 1 ? 1e-9f : 0.f;
+    for (int u = 0; u < S; ++u) tot += part[u][lane];
+    if (PASS == 1) {
+        ratioL[i] = remainL[i] / tot;
+    } else {
+        const float rr = remainR[i];
+        const float sumr = tot * rr;
+        const float consumption = fminf(rr / (sumr + 1e-9f), 1.0f);
+        ratioR[i] = consumption * rr;
+        remainR[i] = fmaxf(0.0f, rr - sumr);
+    }
+}
+
+// PASS 3: w = exp(level*d^2) * ratioL[k] * ratioR[l]; match[l][k] += w;          approxmatch.cu:130-163
+//         remainL[k] = max(0, remainL[k] - sum_l w)
+template <bool FIRST>
+__global__ __launch_bounds__(1024) void emd_match_kernel(int n, int m, float lvl2, const float *__restrict__ xyz1,
+                                                         const float *__restrict__ xyz2, float *__restrict__ match,
+                                                         float *temp) {
+    __shared__ float part[MAXS][64];
+    const int bi = blockIdx.y;
+    const int lane = threadIdx.x, slice = __builtin_amdgcn_readfirstlane(threadIdx.y), S = blockDim.y;
+    float *t = temp + (size_t)bi * (n + m) * 2;
+    float *remainL = t;
+    const float *__restrict__ ratioL = t + n + m;
+    const float *__restrict__ ratioR = t + n + m + n;
+    const float *__restrict__ P = xyz1 + (size_t)bi * n * 3;
+    const float *__restrict__ Q = xyz2 + (size_t)bi * m * 3;
+    float *__restrict__ mt = match + (size_t)bi * n * m;
+    const int k = blockIdx.x * 64 + lane;
+    const bool live = k < n;
+    const int kc = min(k, n - 1);
+    const float px = P[kc * 3 + 0], py = P[kc * 3 + 1], pz = P[kc * 3 + 2];
+    const float rl = ratioL[kc];
+    const int lb = (int)((long)m * slice / S), le = (int)((long)m * (slice + 1) / S);
+    float suml = 0.f;
+    int l = lb;
+    for (; l + 4 <= le; l += 4) {
+        float w[4], old[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!FIRST) old[u] = live ? mt[(size_t)(l + u) * n + k] : 0.f;
+            const float d2 = sqdist(px, py, pz, Q[(l + u) * 3 + 0], Q[(l + u) * 3 + 1], Q[(l + u) * 3 + 2]);
+            w[u] = fast_exp2(lvl2 * d2) * rl * ratioR[l + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (live) mt[(size_t)(l + u) * n + k] = FIRST ? w[u] : old[u] + w[u];
+            suml += w[u];
+        }
+    }
+    for (; l < le; ++l) {
+        const float d2 = sqdist(px, py, pz, Q[l * 3 + 0], Q[l * 3 + 1], Q[l * 3 + 2]);
+        const float w = fast_exp2(lvl2 * d2) * rl * ratioR[l];
+        if (live) mt[(size_t)l * n + k] = FIRST ? w : mt[(size_t)l * n + k] + w;
+        suml += w;
+    }
+    part[slice][lane] = suml;
+    __syncthreads();
+    if (slice != 0 || !live) return;
+    float tot = 0.f;
+    for (int u = 0; u < S; ++u) tot += part[u][lane];
+    remainL[k] = fmaxf(0.0f, remainL[k] - tot);
+}
+
+// out[b] = sum_{l,k} match[b,l,k] * |xyz1[k] - xyz2[l]|                           approxmatch.cu:184-224
+__global__ __launch_bounds__(256) void emd_cost_kernel(int n, int m, const float *__restrict__ xyz1,
+                                                       const float *__restrict__ xyz2,
+                                                       const float *__restrict__ match, float *out) {
+    __shared__ float red[4];
+    const int bi = blockIdx.y;
+    const float *__restrict__ P = xyz1 + (size_t)bi * n * 3;
+    const float *__restrict__ Q = xyz2 + (size_t)bi * m * 3;
+    const float *__restrict__ mt = match + (size_t)bi * n * m;
+    const int lb = (int)((long)m * blockIdx.x / gridDim.x), le = (int)((long)m * (blockIdx.x + 1) / gridDim.x);
+    float sub = 0.f;
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        const float px = P[k * 3 + 0], py = P[k * 3 + 1], pz = P[k * 3 + 2];
+        for (int l = lb; l < le; ++l) {
+            const float d = sqrtf(sqdist(px, py, pz, Q[l * 3 + 0], Q[l * 3 + 1], Q[l * 3 + 2]));
+            sub += mt[(size_t)l * n + k] * d;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) sub += __shfl_xor(sub, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sub;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out + bi, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+// grad1[k] = sum_l match[l][k] * (x1_k - x2_l) / max(|x1_k - x2_l|, 1e-10)         approxmatch.cu:270-291
+__global__ __launch_bounds__(1024) void emd_grad1_kernel(int n, int m, const float *__restrict__ xyz1,
+                                                         const float *__restrict__ xyz2,
+                                                         const float *__restrict__ match, float *__restrict__ grad1) {
+    __shared__ float part[MAXS][3][64];
+    const int bi = blockIdx.y;
+    const int lane = threadIdx.x, slice = __builtin_amdgcn_readfirstlane(threadIdx.y), S = blockDim.y;
+    const float *__restrict__ P = xyz1 + (size_t)bi * n * 3;
+    const float *__restrict__ Q = xyz2 + (size_t)bi * m * 3;
+    const float *__restrict__ mt = match + (size_t)bi * n * m;
+    const int k = blockIdx.x * 64 + lane;
+    const bool live = k < n;
+    const int kc = min(k, n - 1);
+    const float px = P[kc * 3 + 0], py = P[kc * 3 + 1], pz = P[kc * 3 + 2];
+    const int lb = (int)((long)m * slice / S), le = (int)((long)m * (slice + 1) / S);
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    for (int l = lb; l < le; ++l) {
+        const float dx = px - Q[l * 3 + 0], dy = py - Q[l * 3 + 1], dz = pz - Q[l * 3 + 2];
+        const float d = mt[(size_t)l * n + kc] * rsqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-20f));
+        gx += dx * d; gy += dy * d; gz += dz * d;
+    }
+    part[slice][0][lane] = gx; part[slice][1][lane] = gy; part[slice][2][lane] = gz;
+    __syncthreads();
+    if (slice != 0 || !live) return;
+    float tx = 0.f, ty = 0.f, tz = 0.f;
+    for (int u = 0; u < S; ++u) { tx += part[u][0][lane]; ty += part[u][1][lane]; tz += part[u][2][lane]; }
+    float *g = grad1 + ((size_t)bi * n + k) * 3;
+    g[0] = tx; g[1] = ty; g[2] = tz;
+}
+
+// grad2[l] = sum_k match[l][k] * (x2_l - x1_k) / max(|x2_l - x1_k|, 1e-10)         approxmatch.cu:229-269
+// one wave per row l (coalesced over k), 4 rows per workgroup
+__global__ __launch_bounds__(256) void emd_grad2_kernel(int n, int m, const float *__restrict__ xyz1,
+                                                        const float *__restrict__ xyz2,
+                                                        const float *__restrict__ match, float *__restrict__ grad2) {
+    const int bi = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int l = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (l >= m) return;
+    const float *__restrict__ P = xyz1 + (size_t)bi * n * 3;
+    const float *__restrict__ Q = xyz2 + (size_t)bi * m * 3;
+    const float *__restrict__ row = match + (size_t)bi * n * m + (size_t)l * n;
+    const float qx = Q[l * 3 + 0], qy = Q[l * 3 + 1], qz = Q[l * 3 + 2];
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    for (int k = lane; k < n; k += 64) {
+        const float dx = qx - P[k * 3 + 0], dy = qy - P[k * 3 + 1], dz = qz - P[k * 3 + 2];
+        const float d = row[k] * rsqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-20f));
+        gx += dx * d; gy += dy * d; gz += dz * d;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        gx += __shfl_xor(gx, o); gy += __shfl_xor(gy, o); gz += __shfl_xor(gz, o);
+    }
+    if (lane == 0) {
+        float *g = grad2 + ((size_t)bi * m + l) * 3;
+        g[0] = gx; g[1] = gy; g[2] = gz;
+    }
+}
+
+// inner-loop slices per workgroup so that the launch has >= ~2048 waves
+int pick_slices(int b, int npoints, int ninner) {
+    const long groups = (long)b * ((npoints + 63) / 64);
+    int s = 1;
+    while (s < MAXS && groups * s < 2048 && ninner / (2 * s) >= 64) s *= 2;
+    return s;
+}
+
+}  // namespace
+
+extern "C" int dpf_approxmatch(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
+                               dpf_stream_t stream) {
+    if (b < 0 || n <= 0 || m <= 0) return DPF_EINVAL;
+    if (b == 0) return 0;
+    if (!xyz1 || !xyz2 || !match || !temp) return DPF_EINVAL;
+    if (b > 65535) return DPF_ENOSUP;
+    hipStream_t s = (hipStream_t)stream;
+    float multiL, multiR;
+    if (n >= m) { multiL = 1; multiR = (float)(n / m); }   // integer division, approxmatch.cu:6-12
+    else        { multiL = (float)(m / n); multiR = 1; }
+    hipLaunchKernelGGL(emd_init_kernel, dim3((n + m + 255) / 256, b), dim3(256), 0, s, n, m, multiL, multiR, temp);
+    const int s1 = pick_slices(b, n, m), s2 = pick_slices(b, m, n);
+    const dim3 g1((n + 63) / 64, b), g2((m + 63) / 64, b);
+    for (int j = 7; j > -2; --j) {                          // approxmatch.cu:24 (the j==-2 branch is dead)
+        const float level = -powf(4.0f, (float)j);
+        const float lvl2 = level * 1.44269504088896340736f;  // exp(x) = exp2(x*log2 e), as __expf does
+        hipLaunchKernelGGL(emd_ratio_kernel<1>, g1, dim3(64, s1), 0, s, n, m, lvl2, xyz1, xyz2, temp);
+        hipLaunchKernelGGL(emd_ratio_kernel<2>, g2, dim3(64, s2), 0, s, n, m, lvl2, xyz1, xyz2, temp);
+        if (j == 7)
+            hipLaunchKernelGGL(emd_match_kernel<true>, g1, dim3(64, s1), 0, s, n, m, lvl2, xyz1, xyz2, match, temp);
+        else
+            hipLaunchKernelGGL(emd_match_kernel<false>, g1, dim3(64, s1), 0, s, n, m, lvl2, xyz1, xyz2, match, temp);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int dpf_matchcost(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match, float *out,
+                             dpf_stream_t stream) {
+    if (b < 0 || n <= 0 || m <= 0) return DPF_EINVAL;
+    if (b == 0) return 0;
+    if (!xyz1 || !xyz2 || !match || !out) return DPF_EINVAL;
+    if (b > 65535) return DPF_ENOSUP;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * b, s);
+    if (e != hipSuccess) return (int)e;
+    int gx = (int)(2048 / b);
+    if (gx < 1) gx = 1;
+    if (gx > m) gx = m;
+    hipLaunchKernelGGL(emd_cost_kernel, dim3(gx, b), dim3(256), 0, s, n, m, xyz1, xyz2, match, out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dpf_matchcostgrad(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match,
+                                 float *grad1, float *grad2, dpf_stream_t stream) {
+    if (b < 0 || n <= 0 || m <= 0) return DPF_EINVAL;
+    if (b == 0) return 0;
+    if (!xyz1 || !xyz2 || !match || !grad1 || !grad2) return DPF_EINVAL;
+    if (b > 65535) return DPF_ENOSUP;
+    hipStream_t s = (hipStream_t)stream;
+    const int s1 = pick_slices(b, n, m);
+    hipLaunchKernelGGL(emd_grad1_kernel, dim3((n + 63) / 64, b), dim3(64, s1), 0, s, n, m, xyz1, xyz2, match, grad1);
+    hipLaunchKernelGGL(emd_grad2_kernel, dim3((m + 3) / 4, b), dim3(256), 0, s, n, m, xyz1, xyz2, match, grad2);
+    return (int)hipGetLastError();
+}

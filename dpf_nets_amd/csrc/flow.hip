@@ -1,0 +1,530 @@
+// Fused per-point conditional affine-coupling flow stack for gfx950 (MI355X).
+//
+// Replaces, for eval-mode BatchNorm, the whole of
+//   LocalCondRNVPDecoder.forward      lib/networks/decoders.py:54-72
+//   CondRealNVPFlow3DTriple.forward   lib/networks/flows.py:151-160
+//   CondRealNVPFlow3D.forward         lib/networks/flows.py:95-117
+//   SharedDot.forward                 lib/networks/layers.py:40-45
+// (~30 ATen kernels and ~7.7 KB of HBM traffic per point per layer in the
+// reference) by THREE kernels:
+//
+//   pack_kernel   once per weight version: folds BatchNorm into the SharedDot
+//                 weights, splits them into bf16 parts and lays them out in
+//                 MFMA-fragment order;
+//   film_kernel   once per batch: the per-cloud FiLM conditioner MLPs of every
+//                 layer (flows.py:33-45,68-80), folded with BN1 and the output
+//                 SharedDot into three per-cloud vectors per branch;
+//   flow_kernel   the L-layer stack.  A wave owns 32 contiguous points of one
+//                 cloud for ALL layers: the points, their running sum of
+//                 log-variances and every activation stay in registers; HBM
+//                 sees 12 B/point in, 24 B/point out (+36 B/point/layer only
+//                 if the caller asks for the per-layer lists).
+//
+// Per layer and branch, for a 32-point tile (F = 64 hidden features):
+//   h0 = relu(BN0(W0 x))      one  v_mfma_f32_32x32x16_bf16 per 32 features: the
+//                             K=16 slots hold the 3-way bf16 split of the two
+//                             inputs and of the folded weights/bias, so the
+//                             result is fp32-accurate;
+//   h1 = W1 h0                2 x 4 x {1,3,6} v_mfma_f32_32x32x16_bf16 (bf16,
+//                             bf16x3 or bf16x6 split precision), fp32 accumulate.
+//                             The accumulator starts at the folded FiLM shift.
+//   o  = W2' relu(h1 + D)     VALU on the accumulator fragment + one
+//                             cross-half swap (v_permlane32_swap).
+// Weights are the A operand (rows = output features) and points the B operand
+// (columns), so the C/D fragment of one MFMA -- lane holds 16 features of ITS
+// point -- is, after relu and a bf16 split in registers, directly the B
+// fragment of the next MFMA: the K-slot <-> feature permutation this implies
+// is applied to W1's columns at pack time.  No LDS round trip for activations.
+// LDS holds the current and the next layer's packed weights (double-buffered,
+// streamed with global_load_lds while the current layer computes).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dpf_hip.h"
+
+namespace {
+
+constexpr int F = DPF_FLOW_F;
+constexpr float BN_EPS = 1e-5f;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- canonical fp32 layout (see dpf_hip.h) --------------------------------
+constexpr int C_W0 = 0;
+constexpr int C_BN0 = 128;     // gamma, beta, rm, rv
+constexpr int C_W1 = 384;
+constexpr int C_BN1 = 4480;    // rm, rv
+constexpr int C_W2 = 4608;     // [2][64]
+constexpr int C_B2 = 4736;     // [4]
+constexpr int C_FILM = 4740;
+__host__ __device__ constexpr int c_film_floats(int G) { return 64 * G + 256 + 4096 + 64; }
+__host__ __device__ constexpr int c_branch_floats(int G) { return C_FILM + 2 * c_film_floats(G); }
+__host__ __device__ constexpr int c_layer_floats(int G) { return 2 * c_branch_floats(G); }
+
+// ---- packed layout ----------------------------------------------------------
+constexpr int P_A1_PART = 16384;                       // [br2][t2][s4][lane64][8 bf16]
+__host__ __device__ constexpr int p_a0_off(int NS) { return NS * P_A1_PART; }            // [br2][t2][lane64][8 bf16]
+__host__ __device__ constexpr int p_misc_off(int NS) { return NS * P_A1_PART + 4096; }   // b2[br][2] floats
+__host__ __device__ constexpr int p_layer_bytes(int NS) { return NS * P_A1_PART + 5120; }
+constexpr int FILM_BYTES = 2048;                       // per (layer, cloud): [br2]{D[64], Wab[64][2]} + pad
+constexpr int FILM_BR_FLOATS = 192;
+
+__device__ __forceinline__ uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ float u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
+__device__ __forceinline__ uint32_t bf16_rne(float x) {   // top-16 bits, round to nearest even
+    const uint32_t u = f2u(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+// truncation split: x = hi + rest exactly, hi has 8 significant bits
+__device__ __forceinline__ uint32_t split_hi(float x, float &rest) {
+    const uint32_t h = f2u(x) & 0xFFFF0000u;
+    rest = x - u2f(h);
+    return h;
+}
+
+// ===========================================================================
+// pack
+// ===========================================================================
+template <int NS>
+__global__ __launch_bounds__(256) void pack_kernel(int G, const float *__restrict__ canon, uint8_t *__restrict__ packed) {
+    const int l = blockIdx.x;
+    const float *cl = canon + (size_t)l * c_layer_floats(G);
+    uint8_t *out = packed + (size_t)l * p_layer_bytes(NS);
+    uint16_t *o16 = (uint16_t *)out;
+    // A1: W1 in fragment order.  Element j of lane (i, h), k-step s, M-tile t':
+    //   W1[32t'+i][feat(s, j, h)],  feat = 32*(s>>1) + (r&3) + 8*(r>>2) + 4h,  r = 8*(s&1) + j
+    // -- the feature a lane of the h0 accumulator fragment holds in register r of tile s>>1.
+    for (int idx = threadIdx.x; idx < 2 * 2 * 4 * 64 * 8; idx += blockDim.x) {
+        const int j = idx & 7, lane = (idx >> 3) & 63, s = (idx >> 9) & 3, tp = (idx >> 11) & 1, br = idx >> 12;
+        const int i = lane & 31, h = lane >> 5;
+        const int r = 8 * (s & 1) + j;
+        const int fi = 32 * (s >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float w = cl[br * c_branch_floats(G) + C_W1 + (32 * tp + i) * 64 + fi];
+        if (NS == 1) {
+            o16[idx] = (uint16_t)bf16_rne(w);
+        } else if (NS == 2) {
+            float r1;
+            o16[idx] = (uint16_t)(split_hi(w, r1) >> 16);
+            o16[P_A1_PART / 2 + idx] = (uint16_t)bf16_rne(r1);
+        } else {
+            float r1, r2;
+            o16[idx] = (uint16_t)(split_hi(w, r1) >> 16);
+            o16[P_A1_PART / 2 + idx] = (uint16_t)(split_hi(r1, r2) >> 16);
+            o16[P_A1_PART + idx] = (uint16_t)bf16_rne(r2);
+        }
+    }
+    // A0: BN0-folded first SharedDot + bias, 3-way split over the 16 K slots of one MFMA.
+    //   half h (0: keep channel a, 1: keep channel b) slots j:
+    //   A = [wh wh wm wh wm wl | T*]   B = [xh xm xh xl xm xh | 1 (1|0)]
+    //   T* = (Th, Tm) for h = 0 and (Tl, 0) for h = 1.
+    uint16_t *a0 = (uint16_t *)(out + p_a0_off(NS));
+    for (int idx = threadIdx.x; idx < 2 * 2 * 64 * 8; idx += blockDim.x) {
+        const int j = idx & 7, lane = (idx >> 3) & 63, t = (idx >> 9) & 1, br = idx >> 10;
+        const int f = 32 * t + (lane & 31), h = lane >> 5;
+        const float *cb = cl + br * c_branch_floats(G);
+        const float gamma = cb[C_BN0 + f], beta = cb[C_BN0 + 64 + f], rm = cb[C_BN0 + 128 + f], rv = cb[C_BN0 + 192 + f];
+        const float s0 = gamma / sqrtf(rv + BN_EPS);
+        const float w = s0 * cb[C_W0 + f * 2 + h];
+        const float T = beta - rm * s0;
+        float r1, r2, q1, q2, dummy;
+        const uint32_t wh = split_hi(w, r1) >> 16, wm = split_hi(r1, r2) >> 16, wl = split_hi(r2, dummy) >> 16;
+        const uint32_t Th = split_hi(T, q1) >> 16, Tm = split_hi(q1, q2) >> 16, Tl = split_hi(q2, dummy) >> 16;
+        uint32_t v;
+        switch (j) {
+            case 0: case 1: case 3: v = wh; break;
+            case 2: case 4: v = wm; break;
+            case 5: v = wl; break;
+            case 6: v = h == 0 ? Th : Tl; break;
+            default: v = h == 0 ? Tm : 0u; break;
+        }
+        a0[idx] = (uint16_t)v;
+    }
+    float *misc = (float *)(out + p_misc_off(NS));
+    for (int idx = threadIdx.x; idx < 256; idx += blockDim.x) {
+        float v = 0.f;
+        if (idx < 4) v = cl[(idx >> 1) * c_branch_floats(G) + C_B2 + (idx & 1)];
+        misc[idx] = v;
+    }
+}
+
+// ===========================================================================
+// FiLM conditioner
+// ===========================================================================
+constexpr int FILM_CLOUDS = 16;   // clouds per workgroup
+
+__global__ __launch_bounds__(256) void film_kernel(int B, int G, const float *__restrict__ canon,
+                                                   const float *__restrict__ g, float *__restrict__ film, float flow_eps) {
+    __shared__ __attribute__((aligned(16))) float Wt[64][36];
+    __shared__ __attribute__((aligned(16))) float gt[FILM_CLOUDS][32];
+    __shared__ __attribute__((aligned(16))) float hid[FILM_CLOUDS][64];
+    __shared__ __attribute__((aligned(16))) float W1t[64][68];
+    const int l = blockIdx.x >> 1, br = blockIdx.x & 1;
+    const int b0 = blockIdx.y * FILM_CLOUDS;
+    const int tid = threadIdx.x, f = tid & 63, bq = tid >> 6;
+    const float *cb = canon + (size_t)l * c_layer_floats(G) + br * c_branch_floats(G);
+    float cwb[2][4];
+    for (int sub = 0; sub < 2; ++sub) {
+        const float *cf = cb + C_FILM + sub * c_film_floats(G);
+        const float *Wf0 = cf, *bnf = cf + 64 * G, *Wf1 = bnf + 256, *bf1 = Wf1 + 4096;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int g0 = 0; g0 < G; g0 += 32) {
+            for (int e = tid; e < 64 * 8; e += 256) {          // Wf0[0:64][g0:g0+32] -> Wt
+                const int row = e >> 3, c4 = (e & 7) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (g0 + c4 < G) v = *(const f32x4 *)(Wf0 + (size_t)row * G + g0 + c4);
+                *(f32x4 *)&Wt[row][c4] = v;
+            }
+            if (tid < FILM_CLOUDS * 8) {                       // g[b0:b0+16][g0:g0+32] -> gt
+                const int row = tid >> 3, c4 = (tid & 7) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (b0 + row < B && g0 + c4 < G) v = *(const f32x4 *)(g + (size_t)(b0 + row) * G + g0 + c4);
+                *(f32x4 *)&gt[row][c4] = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int gg = 0; gg < 32; gg += 4) {
+                const f32x4 w = *(const f32x4 *)&Wt[f][gg];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f32x4 x = *(const f32x4 *)&gt[bq * 4 + c][gg];
+                    acc[c] += w.x * x.x + w.y * x.y + w.z * x.z + w.w * x.w;
+                }
+            }
+            __syncthreads();
+        }
+        // BatchNorm1d over the batch dim, eval mode (flows.py:35/42), then Swish (layers.py:9-10)
+        const float gamma = bnf[f], beta = bnf[64 + f], rm = bnf[128 + f], rv = bnf[192 + f];
+        const float sc = gamma / sqrtf(rv + BN_EPS);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float u = (acc[c] - rm) * sc + beta;
+            hid[bq * 4 + c][f] = u / (1.0f + expf(-u));
+        }
+        for (int e = tid; e < 64 * 16; e += 256) {             // Wf1 -> W1t
+            const int row = e >> 4, c4 = (e & 15) * 4;
+            *(f32x4 *)&W1t[row][c4] = *(const f32x4 *)(Wf1 + row * 64 + c4);
+        }
+        __syncthreads();
+        float v[4];
+        const float bias = bf1[f];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = bias;
+#pragma unroll 4
+        for (int k = 0; k < 64; k += 4) {
+            const f32x4 w = *(const f32x4 *)&W1t[f][k];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 x = *(const f32x4 *)&hid[bq * 4 + c][k];
+                v[c] += w.x * x.x + w.y * x.y + w.z * x.z + w.w * x.w;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cwb[sub][c] = v[c];
+        __syncthreads();
+    }
+    // fold FiLM (flows.py:100-101) with BN1 (affine=False, :30/65) and the output SharedDot (:49/84):
+    //   relu((eps+e^cw) * BN1(h1) + cb) = FA * relu(h1 + FC/FA),  FA = (eps+e^cw)/sqrt(rv1+eps_bn) > 0
+    const float s1 = 1.0f / sqrtf(cb[C_BN1 + 64 + f] + BN_EPS);
+    const float t1 = -cb[C_BN1 + f] * s1;
+    const float w2a = cb[C_W2 + f], w2b = cb[C_W2 + 64 + f];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int b = b0 + bq * 4 + c;
+        if (b >= B) continue;
+        const float a = flow_eps + expf(cwb[0][c]);
+        const float FA = a * s1, FC = a * t1 + cwb[1][c];
+        float *o = film + ((size_t)l * B + b) * (FILM_BYTES / 4) + br * FILM_BR_FLOATS;
+        o[f] = FC / FA;
+        o[64 + 2 * f] = w2a * FA;
+        o[64 + 2 * f + 1] = w2b * FA;
+    }
+}
+
+// ===========================================================================
+// the fused stack
+// ===========================================================================
+struct FlowArgs {
+    const uint8_t *packed;
+    const int *meta;
+    const float *film;
+    const float *p_in;
+    float *p_out, *sum_lv, *ps, *mus, *lvs;
+    int L, B, N, mode;
+    float eps;
+};
+
+constexpr int TILE = 32;          // points per wave (one MFMA N tile)
+constexpr int FW = 4;             // waves per workgroup
+constexpr int BLOCK_PTS = TILE * FW;
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_void;
+
+// Stream one layer (packed weights + this cloud's FiLM vectors) into an LDS
+// buffer: 1 KiB per wave-instruction, straight to LDS (no VGPR staging).
+template <int NS>
+__device__ __forceinline__ void stage_layer(const FlowArgs &a, int li, int bi, uint8_t *lds, int wave, int lane) {
+    constexpr int NP = p_layer_bytes(NS) / 1024, NC = NP + FILM_BYTES / 1024;
+    const uint8_t *wsrc = a.packed + (size_t)li * p_layer_bytes(NS);
+    const uint8_t *fsrc = (const uint8_t *)a.film + ((size_t)li * a.B + bi) * FILM_BYTES;
+    for (int c = wave; c < NC; c += FW) {
+        const uint8_t *src = (c < NP ? wsrc + c * 1024 : fsrc + (c - NP) * 1024) + lane * 16;
+        __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(lds + c * 1024), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float sel3(int c, float v0, float v1, float v2) {   // c wave-uniform
+    return c == 0 ? v0 : (c == 1 ? v1 : v2);
+}
+
+// split-precision product terms: parts are 0 = hi, 1 = mid/lo, 2 = lo
+template <int NS> struct Terms;
+template <> struct Terms<1> { static constexpr int N = 1; static constexpr int A[1] = {0}, B[1] = {0}; };
+template <> struct Terms<2> { static constexpr int N = 3; static constexpr int A[3] = {1, 0, 0}, B[3] = {0, 1, 0}; };
+template <> struct Terms<3> {
+    static constexpr int N = 6;
+    static constexpr int A[6] = {1, 2, 0, 1, 0, 0}, B[6] = {1, 0, 2, 0, 1, 0};
+};
+
+template <int NS>
+__global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int LBYTES = p_layer_bytes(NS) + FILM_BYTES;
+    constexpr int A0OFF = p_a0_off(NS), MISCOFF = p_misc_off(NS), FILMOFF = p_layer_bytes(NS);
+    typedef Terms<NS> TT;                    // product terms (A part, B part), smallest magnitude first
+    constexpr int NT = TT::N;
+
+    const int bi = blockIdx.y;
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int N = a.N, L = a.L;
+    const int n = blockIdx.x * BLOCK_PTS + wave * TILE + (lane & 31);
+    const bool valid = n < N;
+    const int nc = valid ? n : N - 1;
+    const size_t cloud = (size_t)bi * 3 * N;
+    float p0 = a.p_in[cloud + nc], p1 = a.p_in[cloud + N + nc], p2 = a.p_in[cloud + 2 * (size_t)N + nc];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;   // running sum of logvar per channel
+    const bool inverse = a.mode == DPF_MODE_INVERSE;
+    const size_t list_stride = (size_t)a.B * 3 * N;
+
+    stage_layer<NS>(a, inverse ? L - 1 : 0, bi, smem, wave, lane);
+    __syncthreads();
+
+    for (int step = 0; step < L; ++step) {
+        const int li = inverse ? L - 1 - step : step;
+        const uint8_t *lb = smem + (step & 1) * LBYTES;
+        if (step + 1 < L) stage_layer<NS>(a, inverse ? li - 1 : li + 1, bi, smem + ((step + 1) & 1) * LBYTES, wave, lane);
+
+        const int ka = a.meta[li * 4 + 0], kb = a.meta[li * 4 + 1], wa = a.meta[li * 4 + 2], wb = a.meta[li * 4 + 3];
+        // ---- B operand of the input MFMA: 3-way bf16 split of this half's input channel
+        const float xa = sel3(ka, p0, p1, p2);
+        const float xb = kb < 0 ? 0.f : sel3(kb, p0, p1, p2);
+        const float x = h ? xb : xa;
+        float r1, r2, r3;
+        const uint32_t xh = split_hi(x, r1), xm = split_hi(r1, r2), xl = split_hi(r2, r3);
+        u32x4 b0;
+        b0.x = (xh >> 16) | xm;            // e0 = xh, e1 = xm
+        b0.y = (xh >> 16) | xl;            // e2 = xh, e3 = xl
+        b0.z = (xm >> 16) | xh;            // e4 = xm, e5 = xh
+        b0.w = h ? 0x00003F80u : 0x3F803F80u;   // e6 = 1, e7 = (h == 0)
+
+        float o[2][2];
+#pragma unroll
+        for (int br = 0; br < 2; ++br) {
+            // ---- h0 = relu(BN0(W0 x)) on the matrix core, fp32-accurate
+            u32x4 bfrag[NS][4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const u32x4 a0 = *(const u32x4 *)(lb + A0OFF + ((br * 2 + t) * 64 + lane) * 16);
+                f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                acc0 = mfma(a0, b0, acc0);
+                // relu + bf16 split; accumulator register r of tile t is element j = r&7 of k-step 2t + (r>>3)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float v0 = fmaxf(acc0[r], 0.f), v1 = fmaxf(acc0[r + 1], 0.f);
+                    const int s = 2 * t + (r >> 3), d = (r & 7) >> 1;
+                    if (NS == 1) {
+                        bfrag[0][s][d] = bf16_rne(v0) | (bf16_rne(v1) << 16);
+                    } else if (NS == 2) {
+                        float l0, l1;
+                        const uint32_t h0 = split_hi(v0, l0), h1 = split_hi(v1, l1);
+                        bfrag[0][s][d] = (h0 >> 16) | h1;
+                        bfrag[1][s][d] = bf16_rne(l0) | (bf16_rne(l1) << 16);
+                    } else {
+                        float l0, l1, m0, m1;
+                        const uint32_t h0 = split_hi(v0, l0), h1 = split_hi(v1, l1);
+                        const uint32_t g0 = split_hi(l0, m0), g1 = split_hi(l1, m1);
+                        bfrag[0][s][d] = (h0 >> 16) | h1;
+                        bfrag[1][s][d] = (g0 >> 16) | g1;
+                        bfrag[2][s][d] = bf16_rne(m0) | (bf16_rne(m1) << 16);
+                    }
+                }
+            }
+            // ---- h1 = W1 h0, accumulator pre-loaded with the folded FiLM shift D
+            const float *fl = (const float *)(lb + FILMOFF) + br * FILM_BR_FLOATS;
+            f32x16 acc1[2];
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 dv = *(const f32x4 *)(fl + 32 * tp + 8 * q + 4 * h);
+                    acc1[tp][4 * q + 0] = dv.x; acc1[tp][4 * q + 1] = dv.y;
+                    acc1[tp][4 * q + 2] = dv.z; acc1[tp][4 * q + 3] = dv.w;
+                }
+#pragma unroll
+            for (int term = 0; term < NT; ++term)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int tp = 0; tp < 2; ++tp) {
+                        const u32x4 a1 = *(const u32x4 *)(lb + TT::A[term] * P_A1_PART + (((br * 2 + tp) * 4 + s) * 64 + lane) * 16);
+                        acc1[tp] = mfma(a1, bfrag[TT::B[term]][s], acc1[tp]);
+                    }
+            // ---- o = W2' relu(h1 + D): each lane reduces its 32 features, halves swap-add
+            float oa = 0.f, ob = 0.f;
+            const float *wab = fl + 64;
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int f0 = 32 * tp + 8 * q + 4 * h;
+                    const f32x4 w01 = *(const f32x4 *)(wab + 2 * f0);
+                    const f32x4 w23 = *(const f32x4 *)(wab + 2 * f0 + 4);
+                    const float v0 = fmaxf(acc1[tp][4 * q + 0], 0.f), v1 = fmaxf(acc1[tp][4 * q + 1], 0.f);
+                    const float v2 = fmaxf(acc1[tp][4 * q + 2], 0.f), v3 = fmaxf(acc1[tp][4 * q + 3], 0.f);
+                    oa += w01.x * v0; ob += w01.y * v0;
+                    oa += w01.z * v1; ob += w01.w * v1;
+                    oa += w23.x * v2; ob += w23.y * v2;
+                    oa += w23.z * v3; ob += w23.w * v3;
+                }
+            {
+                const auto ra = __builtin_amdgcn_permlane32_swap(f2u(oa), f2u(oa), false, false);
+                const auto rb = __builtin_amdgcn_permlane32_swap(f2u(ob), f2u(ob), false, false);
+                oa = u2f(ra[0]) + u2f(ra[1]);
+                ob = u2f(rb[0]) + u2f(rb[1]);
+            }
+            const float *b2 = (const float *)(lb + MISCOFF);
+            o[br][0] = oa + b2[br * 2 + 0];
+            o[br][1] = ob + b2[br * 2 + 1];
+        }
+        // ---- coupling transform (flows.py:96-115); branch 0 = logvar, 1 = mu
+        const float lva = o[0][0] * __builtin_amdgcn_rcpf(1.0f + fabsf(o[0][0]));   // softsign, :99
+        const float lvb = o[0][1] * __builtin_amdgcn_rcpf(1.0f + fabsf(o[0][1]));
+        float lv[3], mu[3], pn[3];
+        const float pin[3] = {p0, p1, p2};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            lv[c] = c == wa ? lva : (c == wb ? lvb : 0.f);
+            mu[c] = c == wa ? o[1][0] : (c == wb ? o[1][1] : 0.f);
+            const float var = a.eps + __expf(lv[c]);
+            // keep channels are scaled by sqrt(1 + eps) too, as in the reference (:113/:115)
+            pn[c] = inverse ? (pin[c] - mu[c]) * __builtin_amdgcn_rsqf(var) : __builtin_amdgcn_sqrtf(var) * pin[c] + mu[c];
+        }
+        p0 = pn[0]; p1 = pn[1]; p2 = pn[2];
+        s0 += lv[0]; s1 += lv[1]; s2 += lv[2];
+        if (a.ps != nullptr && valid) {   // per-layer lists in DIRECT order (decoders.py:61-70); halves share the rows
+            const size_t base = (size_t)li * list_stride + cloud + n;
+            float *dst[5]; float val[5];
+            dst[0] = (h ? a.mus + base + 2 * (size_t)N : a.ps + base);              val[0] = h ? mu[2] : pn[0];
+            dst[1] = (h ? a.lvs + base : a.ps + base + N);                          val[1] = h ? lv[0] : pn[1];
+            dst[2] = (h ? a.lvs + base + N : a.ps + base + 2 * (size_t)N);          val[2] = h ? lv[1] : pn[2];
+            dst[3] = (h ? a.lvs + base + 2 * (size_t)N : a.mus + base);             val[3] = h ? lv[2] : mu[0];
+            dst[4] = a.mus + base + N;                                             val[4] = mu[1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) *dst[e] = val[e];
+            if (!h) *dst[4] = val[4];
+        }
+        __syncthreads();   // next layer's weights have landed; everyone is done with this buffer
+    }
+    if (valid) {
+        if (!h) {
+            a.p_out[cloud + n] = p0; a.p_out[cloud + N + n] = p1; a.p_out[cloud + 2 * (size_t)N + n] = p2;
+        } else if (a.sum_lv != nullptr) {
+            a.sum_lv[cloud + n] = s0; a.sum_lv[cloud + N + n] = s1; a.sum_lv[cloud + 2 * (size_t)N + n] = s2;
+        }
+    }
+}
+
+int ns_of(int precision) {
+    return precision == DPF_PREC_BF16 ? 1 : precision == DPF_PREC_BF16X3 ? 2 : precision == DPF_PREC_BF16X6 ? 3 : 0;
+}
+
+}  // namespace
+
+extern "C" size_t dpf_flow_canon_floats(int G) { return (size_t)c_layer_floats(G); }
+
+extern "C" size_t dpf_flow_packed_bytes(int n_layers, int precision) {
+    const int ns = ns_of(precision);
+    return ns ? (size_t)n_layers * p_layer_bytes(ns) : 0;
+}
+
+extern "C" size_t dpf_flow_film_floats(int n_layers, int B) { return (size_t)n_layers * B * (FILM_BYTES / 4); }
+
+extern "C" int dpf_flow_pack(int n_layers, int G, int precision, const float *canon, const int *meta, void *packed,
+                             dpf_stream_t stream) {
+    (void)meta;
+    const int ns = ns_of(precision);
+    if (!ns || n_layers < 0 || G <= 0) return DPF_EINVAL;
+    if (n_layers == 0) return 0;
+    if (!canon || !packed) return DPF_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (ns == 1) hipLaunchKernelGGL(pack_kernel<1>, dim3(n_layers), dim3(256), 0, s, G, canon, (uint8_t *)packed);
+    if (ns == 2) hipLaunchKernelGGL(pack_kernel<2>, dim3(n_layers), dim3(256), 0, s, G, canon, (uint8_t *)packed);
+    if (ns == 3) hipLaunchKernelGGL(pack_kernel<3>, dim3(n_layers), dim3(256), 0, s, G, canon, (uint8_t *)packed);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dpf_flow_film(int n_layers, int B, int G, const float *canon, const float *g, float *film,
+                             float flow_eps, dpf_stream_t stream) {
+    if (n_layers < 0 || B < 0 || G <= 0) return DPF_EINVAL;
+    if (n_layers == 0 || B == 0) return 0;
+    if (!canon || !g || !film) return DPF_EINVAL;
+    if (G % 4 != 0) return DPF_ENOSUP;
+    hipLaunchKernelGGL(film_kernel, dim3(n_layers * 2, (B + FILM_CLOUDS - 1) / FILM_CLOUDS), dim3(256), 0,
+                       (hipStream_t)stream, B, G, canon, g, film, flow_eps);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dpf_flow_forward(int n_layers, int B, int N, int mode, int precision, const void *packed,
+                                const int *meta, const float *film, const float *p_in, float *p_out,
+                                float *sum_logvar, float *ps, float *mus, float *logvars, float flow_eps,
+                                dpf_stream_t stream) {
+    const int ns = ns_of(precision);
+    if (!ns || n_layers <= 0 || B < 0 || N <= 0 || (mode != DPF_MODE_DIRECT && mode != DPF_MODE_INVERSE)) return DPF_EINVAL;
+    if (B == 0) return 0;
+    if (!packed || !meta || !film || !p_in || !p_out) return DPF_EINVAL;
+    if ((ps != nullptr) != (mus != nullptr) || (ps != nullptr) != (logvars != nullptr)) return DPF_EINVAL;
+    if (B > 65535) return DPF_ENOSUP;
+    FlowArgs a;
+    a.packed = (const uint8_t *)packed; a.meta = meta; a.film = film; a.p_in = p_in;
+    a.p_out = p_out; a.sum_lv = sum_logvar; a.ps = ps; a.mus = mus; a.lvs = logvars;
+    a.L = n_layers; a.B = B; a.N = N; a.mode = mode; a.eps = flow_eps;
+    const dim3 grid((N + BLOCK_PTS - 1) / BLOCK_PTS, B), block(FW * 64);
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipSuccess;
+#define DPF_LAUNCH(NSV)                                                                                         \
+    {                                                                                                           \
+        const int lds = 2 * (p_layer_bytes(NSV) + FILM_BYTES);                                                  \
+        static bool attr_set = false;                                                                           \
+        if (!attr_set) {                                                                                        \
+            e = hipFuncSetAttribute((const void *)flow_kernel<NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            if (e != hipSuccess) return (int)e;                                                                 \
+            attr_set = true;                                                                                    \
+        }                                                                                                       \
+        hipLaunchKernelGGL(flow_kernel<NSV>, grid, block, lds, s, a);                                           \
+    }
+    if (ns == 1) DPF_LAUNCH(1)
+    if (ns == 2) DPF_LAUNCH(2)
+    if (ns == 3) DPF_LAUNCH(3)
+#undef DPF_LAUNCH
+    return (int)hipGetLastError();
+}
+
+extern "C" const char *dpf_version(void) { return "dpf_hip gfx950 r1"; }

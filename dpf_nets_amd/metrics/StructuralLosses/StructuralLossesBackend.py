@@ -1,0 +1,92 @@
+"""Same five functions the reference's pybind module exports
+(lib/metrics/pytorch_structural_losses/pybind/bind.cpp:9-15), same argument and
+return conventions as its ATen glue (src/structural_loss.cpp:22-124): the caller
+side allocates every output with torch.empty on the input's device, inputs must
+be contiguous device tensors (CHECK_INPUT, structural_loss.cpp:10-12), launches
+go to the current stream and do not synchronise.  The kernels live in
+libdpf_hip.so (csrc/chamfer.hip, csrc/emd.hip)."""
+import torch
+
+from ..._lib import lib, check, current_stream
+
+
+def _check_input(x, name, dtype=torch.float32):
+    # mirrors CHECK_CUDA / CHECK_CONTIGUOUS (AT_ASSERTM -> RuntimeError)
+    if not x.is_cuda:
+        raise RuntimeError("%s must be a CUDA tensor" % name)
+    if not x.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+    if x.dtype != dtype:
+        raise RuntimeError("%s must be %s" % (name, dtype))
+
+
+def _dims(set_d, set_q):
+    if set_d.dim() != 3 or set_q.dim() != 3 or set_d.shape[2] != 3 or set_q.shape[2] != 3 \
+            or set_d.shape[0] != set_q.shape[0]:
+        raise RuntimeError("expected (B, n, 3) and (B, m, 3) point clouds")
+    return set_d.shape[0], set_d.shape[1], set_q.shape[1]
+
+
+def NNDistance(set_d, set_q):
+    """-> [dist1 (B,n), idx1 (B,n) int32, dist2 (B,m), idx2 (B,m) int32]   structural_loss.cpp:80-99"""
+    _check_input(set_d, "set_d"); _check_input(set_q, "set_q")
+    b, n, m = _dims(set_d, set_q)
+    dev = set_d.device
+    dist1 = torch.empty((b, n), dtype=torch.float32, device=dev)
+    idx1 = torch.empty((b, n), dtype=torch.int32, device=dev)
+    dist2 = torch.empty((b, m), dtype=torch.float32, device=dev)
+    idx2 = torch.empty((b, m), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().dpf_nndistance(b, n, set_d.data_ptr(), m, set_q.data_ptr(), dist1.data_ptr(), idx1.data_ptr(),
+                                   dist2.data_ptr(), idx2.data_ptr(), current_stream()), "nndistance")
+    return [dist1, idx1, dist2, idx2]
+
+
+def NNDistanceGrad(set_d, set_q, idx1, idx2, grad_dist1, grad_dist2):
+    """-> [grad1 (B,n,3), grad2 (B,m,3)]                                    structural_loss.cpp:101-124"""
+    _check_input(set_d, "set_d"); _check_input(set_q, "set_q")
+    _check_input(idx1, "idx1", torch.int32); _check_input(idx2, "idx2", torch.int32)
+    _check_input(grad_dist1, "grad_dist1"); _check_input(grad_dist2, "grad_dist2")
+    b, n, m = _dims(set_d, set_q)
+    grad1 = torch.empty((b, n, 3), dtype=torch.float32, device=set_d.device)
+    grad2 = torch.empty((b, m, 3), dtype=torch.float32, device=set_d.device)
+    with torch.cuda.device(set_d.device):
+        check(lib().dpf_nndistancegrad(b, n, set_d.data_ptr(), m, set_q.data_ptr(), grad_dist1.data_ptr(),
+                                       idx1.data_ptr(), grad_dist2.data_ptr(), idx2.data_ptr(), grad1.data_ptr(),
+                                       grad2.data_ptr(), current_stream()), "nndistancegrad")
+    return [grad1, grad2]
+
+
+def ApproxMatch(set_d, set_q):
+    """-> [match (B,m,n), temp (B, 2(n+m))]                                 structural_loss.cpp:22-37"""
+    _check_input(set_d, "set_d"); _check_input(set_q, "set_q")
+    b, n, m = _dims(set_d, set_q)
+    match = torch.empty((b, m, n), dtype=torch.float32, device=set_d.device)
+    temp = torch.empty((b, (n + m) * 2), dtype=torch.float32, device=set_d.device)
+    with torch.cuda.device(set_d.device):
+        check(lib().dpf_approxmatch(b, n, m, set_d.data_ptr(), set_q.data_ptr(), match.data_ptr(), temp.data_ptr(),
+                                    current_stream()), "approxmatch")
+    return [match, temp]
+
+
+def MatchCost(set_d, set_q, match):
+    """-> cost (B,)                                                         structural_loss.cpp:39-52"""
+    _check_input(set_d, "set_d"); _check_input(set_q, "set_q"); _check_input(match, "match")
+    b, n, m = _dims(set_d, set_q)
+    out = torch.empty((b,), dtype=torch.float32, device=set_d.device)
+    with torch.cuda.device(set_d.device):
+        check(lib().dpf_matchcost(b, n, m, set_d.data_ptr(), set_q.data_ptr(), match.data_ptr(), out.data_ptr(),
+                                  current_stream()), "matchcost")
+    return out
+
+
+def MatchCostGrad(set_d, set_q, match):
+    """-> [grad1 (B,n,3), grad2 (B,m,3)]                                    structural_loss.cpp:54-69"""
+    _check_input(set_d, "set_d"); _check_input(set_q, "set_q"); _check_input(match, "match")
+    b, n, m = _dims(set_d, set_q)
+    grad1 = torch.empty((b, n, 3), dtype=torch.float32, device=set_d.device)
+    grad2 = torch.empty((b, m, 3), dtype=torch.float32, device=set_d.device)
+    with torch.cuda.device(set_d.device):
+        check(lib().dpf_matchcostgrad(b, n, m, set_d.data_ptr(), set_q.data_ptr(), match.data_ptr(),
+                                      grad1.data_ptr(), grad2.data_ptr(), current_stream()), "matchcostgrad")
+    return [grad1, grad2]

@@ -1,0 +1,74 @@
+"""LocalCondRNVPDecoder with the reference's constructor and forward() contract
+(lib/networks/decoders.py:41-72): forward(p, g, mode) -> (ps, mus, logvars), three
+list-likes of 3*n_flows (B,3,N) tensors in DIRECT order for both modes.
+
+Eval mode runs ALL layers in one fused HIP launch (csrc/flow.hip); the lists are
+FlowLists over three (L,B,3,N) buffers the kernel fills.  Training mode chains
+the layers' tensor-op path (decoders.py:58-70)."""
+import torch.nn as nn
+
+from .flows import CondRealNVPFlow3DTriple, _needs_autograd
+from .flowlist import FlowList
+from .engine import FlowStack
+
+
+class LocalCondRNVPDecoder(nn.Module):
+    def __init__(self, n_flows, f_n_features, g_n_features, weight_std=0.01):
+        super().__init__()
+        self.n_flows, self.f_n_features, self.g_n_features = n_flows, f_n_features, g_n_features
+        self.weight_std = weight_std
+        self.flows = nn.ModuleList([
+            CondRealNVPFlow3DTriple(f_n_features, g_n_features, weight_std=weight_std, pattern=i % 2)
+            for i in range(n_flows)])
+        object.__setattr__(self, "_stack", None)
+        self.precision = None          # None -> engine.DEFAULT_PRECISION ("bf16x3")
+        self.materialize_lists = True  # False: skip the 3 x L per-layer tensors (lists then hold the final layer only)
+        self.register_load_state_dict_post_hook(lambda m, keys: m.invalidate_packed())
+
+    def coupling_layers(self):
+        """All 3*n_flows CondRealNVPFlow3D modules in DIRECT order."""
+        return [lyr for tri in self.flows for lyr in tri.layers()]
+
+    def invalidate_packed(self):
+        if self._stack is not None:
+            self._stack.invalidate()
+
+    def train(self, mode=True):
+        if mode != self.training:
+            self.invalidate_packed()
+        return super().train(mode)
+
+    def _apply(self, fn, *a, **kw):
+        self.invalidate_packed()
+        return super()._apply(fn, *a, **kw)
+
+    def stack(self):
+        if self._stack is None:
+            object.__setattr__(self, "_stack", FlowStack(self.coupling_layers()))
+        return self._stack
+
+    def forward_torch(self, p, g, mode="direct"):
+        ps, mus, lvs = [], [], []
+        for i in range(self.n_flows):                               # decoders.py:58-70
+            if mode == "direct":
+                buf = self.flows[i](p if i == 0 else ps[-1], g, mode=mode)
+                ps, mus, lvs = ps + buf[0], mus + buf[1], lvs + buf[2]
+            else:
+                buf = self.flows[-(i + 1)](p if i == 0 else ps[0], g, mode=mode)
+                ps, mus, lvs = buf[0] + ps, buf[1] + mus, buf[2] + lvs
+        return ps, mus, lvs
+
+    def forward(self, p, g, mode="direct", n_layers=None):
+        """n_layers (extension, default all): run only the first n_layers DIRECT-order layers
+        (the BASELINE metric's 14-layer stack = first 14 layers of n_flows=5)."""
+        if mode not in ("direct", "inverse"):
+            raise ValueError(mode)
+        if self.training or _needs_autograd(p, g):
+            if n_layers is not None:
+                raise ValueError("n_layers is only supported on the fused eval path")
+            return self.forward_torch(p, g, mode)
+        p_out, sum_lv, ps, mus, lvs = self.stack().run(p, g, mode, self.precision,
+                                                       want_lists=self.materialize_lists, n_layers=n_layers)
+        if ps is None:
+            return FlowList(p_out.unsqueeze(0)), None, FlowList(sum_lv.unsqueeze(0), sum_lv)
+        return FlowList(ps), FlowList(mus), FlowList(lvs, sum_lv)

@@ -1,0 +1,147 @@
+"""Host driver of the fused HIP flow stack (csrc/flow.hip via include/dpf_hip.h).
+
+A FlowStack owns, for an ordered list of coupling layers (DIRECT order,
+lib/networks/decoders.py:58-64):
+  * the canonical fp32 parameter block the C ABI consumes (dpf_hip.h),
+  * the packed MFMA-fragment weights per precision (built by dpf_flow_pack,
+    once per weight version -- never per batch),
+and runs dpf_flow_film + dpf_flow_forward on the current stream.  torch is used
+for device buffers and the stream handle only."""
+import os
+
+import torch
+
+from .._lib import lib, check, current_stream, PREC, MODE
+
+DEFAULT_PRECISION = os.environ.get("DPF_PRECISION", "bf16x3")
+F = 64
+
+
+def _pad_cols(w, n):
+    if w.shape[1] == n:
+        return w
+    return torch.cat([w, w.new_zeros(w.shape[0], n - w.shape[1])], dim=1)
+
+
+def _pad_rows(w, n):
+    if w.shape[0] == n:
+        return w
+    return torch.cat([w, w.new_zeros(n - w.shape[0], w.shape[1])], dim=0)
+
+
+def layer_canon_pieces(layer):
+    """Flattened tensors of one CondRealNVPFlow3D in the canonical order of dpf_hip.h."""
+    out = []
+    for br in ("logvar", "mu"):
+        t0 = getattr(layer, "T_%s_0" % br)
+        sd0, bn0, sd1, bn1 = t0[0], t0[1], t0[3], t0[4]
+        sd2 = getattr(layer, "T_%s_1" % br)[1]
+        out += [_pad_cols(sd0.weight[0], 2), bn0.weight, bn0.bias, bn0.running_mean, bn0.running_var,
+                sd1.weight[0], bn1.running_mean, bn1.running_var,
+                _pad_rows(sd2.weight[0], 2), torch.cat([sd2.bias[0], sd2.bias.new_zeros(4 - sd2.bias.shape[1])])]
+        for s in ("w", "b"):
+            tc = getattr(layer, "T_%s_0_cond_%s" % (br, s))
+            lin0, bnf, lin1 = tc[0], tc[1], tc[3]
+            out += [lin0.weight, bnf.weight, bnf.bias, bnf.running_mean, bnf.running_var, lin1.weight, lin1.bias]
+    return [t.detach().reshape(-1) for t in out]
+
+
+def layer_meta(layer):
+    k = list(layer.keep_inds) + [-1] * (2 - len(layer.keep_inds))
+    w = list(layer.warp_inds) + [-1] * (2 - len(layer.warp_inds))
+    return k + w
+
+
+class FlowStack:
+    def __init__(self, layers):
+        self.layers = list(layers)
+        self._canon = None
+        self._meta = None
+        self._packed = {}
+        self._sentinels = []
+        self._sentinel_state = None
+        for lyr in (self.layers[0], self.layers[-1]):
+            self._sentinels += [lyr.T_mu_0[3].weight, lyr.T_logvar_1[1].weight]
+
+    # -- weight-version tracking -------------------------------------------------
+    def invalidate(self):
+        self._canon = None
+        self._packed = {}
+
+    def _sentinel(self):
+        return tuple((t._version, t.data_ptr()) for t in self._sentinels)
+
+    def _check_fresh(self):
+        s = self._sentinel()
+        if s != self._sentinel_state:
+            self.invalidate()
+            self._sentinel_state = s
+
+    # -- packing -----------------------------------------------------------------
+    def _ensure(self, precision, device):
+        self._check_fresh()
+        L = len(self.layers)
+        lyr0 = self.layers[0]
+        if lyr0.f_n_features != F:
+            raise RuntimeError("dpf_hip flow kernels are built for f_n_features == 64, got %d" % lyr0.f_n_features)
+        G = lyr0.g_n_features
+        if self._canon is None or self._canon.device != device:
+            pieces = []
+            for lyr in self.layers:
+                pieces += layer_canon_pieces(lyr)
+            canon = torch.cat(pieces).to(device=device, dtype=torch.float32).contiguous()
+            assert canon.numel() == L * lib().dpf_flow_canon_floats(G), (canon.numel(), L, G)
+            self._canon = canon
+            self._meta = torch.tensor([layer_meta(l) for l in self.layers], dtype=torch.int32, device=device)
+            self._packed = {}
+        if precision not in self._packed:
+            nbytes = lib().dpf_flow_packed_bytes(L, PREC[precision])
+            packed = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            check(lib().dpf_flow_pack(L, G, PREC[precision], self._canon.data_ptr(), self._meta.data_ptr(),
+                                      packed.data_ptr(), current_stream()), "flow_pack")
+            self._packed[precision] = packed
+        return self._canon, self._meta, self._packed[precision], G
+
+    # -- run ---------------------------------------------------------------------
+    def run(self, p, g, mode, precision=None, want_lists=True, n_layers=None):
+        """p (B,3,N), g (B,G) fp32 CUDA.  Returns (p_out, sum_logvar, ps, mus, logvars); the
+        last three are (L,B,3,N) buffers in DIRECT order or None."""
+        precision = precision or DEFAULT_PRECISION
+        if precision not in PREC:
+            raise ValueError("precision must be one of %s" % sorted(PREC))
+        if not p.is_cuda or not g.is_cuda:
+            raise RuntimeError("the fused flow stack runs on MI355X only (p and g must be CUDA tensors); "
+                               "there is no CPU fallback")
+        if p.dtype != torch.float32 or g.dtype != torch.float32:
+            raise RuntimeError("p and g must be float32")
+        if p.dim() != 3 or p.shape[1] != 3 or g.dim() != 2 or g.shape[0] != p.shape[0]:
+            raise RuntimeError("expected p (B,3,N) and g (B,G)")
+        p = p.contiguous()
+        g = g.contiguous()
+        B, _, N = p.shape
+        with torch.cuda.device(p.device):
+            canon, meta, packed, G = self._ensure(precision, p.device)
+            if g.shape[1] != G:
+                raise RuntimeError("g has %d features, the layers expect %d" % (g.shape[1], G))
+            L = len(self.layers) if n_layers is None else int(n_layers)
+            if not 0 < L <= len(self.layers):
+                raise ValueError("n_layers out of range")
+            dev = p.device
+            film = torch.empty(lib().dpf_flow_film_floats(L, B), dtype=torch.float32, device=dev)
+            p_out = torch.empty_like(p)
+            sum_lv = torch.empty_like(p)
+            if want_lists:
+                lists = torch.empty((3, L, B, 3, N), dtype=torch.float32, device=dev)
+                lp = [lists[i].data_ptr() for i in range(3)]
+            else:
+                lists, lp = None, [None, None, None]
+            eps = float(self.layers[0].eps_value)
+            stream = current_stream()
+            check(lib().dpf_flow_film(L, B, G, canon.data_ptr(), g.data_ptr(), film.data_ptr(), eps, stream),
+                  "flow_film")
+            check(lib().dpf_flow_forward(L, B, N, MODE[mode], PREC[precision], packed.data_ptr(), meta.data_ptr(),
+                                         film.data_ptr(), p.data_ptr(), p_out.data_ptr(), sum_lv.data_ptr(),
+                                         lp[0], lp[1], lp[2], eps, stream), "flow_forward")
+        if want_lists:
+            return p_out, sum_lv, lists[0], lists[1], lists[2]
+        return p_out, sum_lv, None, None, None

@@ -1,0 +1,138 @@
+/*
+ * dpf_hip.h -- C ABI of libdpf_hip.so: the MI355X (gfx950) implementation of
+ * dpf-nets' per-point flow decoder and structural losses.
+ *
+ * Drop-in boundary.  Every entry point takes raw DEVICE pointers, plain ints
+ * and a HIP stream (hipStream_t passed as void*); no torch / ATen types.  The
+ * caller owns every buffer (inputs, outputs and scratch); nothing here
+ * allocates, frees or synchronises.  All launches are asynchronous on
+ * `stream`.  Return value: 0 on success, otherwise the hipError_t of the failed
+ * launch, or a negative DPF_E* code for an argument the kernels do not support
+ * (the reference returned void and, for Chamfer, checked nothing:
+ * nndistance.cu:125-128).
+ *
+ * File:line citations are into the reference tree (Regenerator/dpf-nets).
+ */
+#ifndef DPF_HIP_H
+#define DPF_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *dpf_stream_t; /* hipStream_t */
+
+#define DPF_EINVAL (-1)  /* bad size / null pointer */
+#define DPF_ENOSUP (-2)  /* shape the kernels are not built for (e.g. F != 64) */
+
+/* ------------------------------------------------------------------------ *
+ * Structural losses.  Same argument order and meaning as the reference's C
+ * launchers, which lib/metrics/pytorch_structural_losses/src/structural_loss.cpp
+ * binds (:35, :50, :67, :97, :118).  Point clouds are point-major fp32
+ * (B, n, 3) contiguous; indices int32.
+ * ------------------------------------------------------------------------ */
+
+/* replaces nndistance(...)      src/nndistance.cuh:1, nndistance.cu:125-128.
+ * result[b,j]  = min_k |xyz[b,j]-xyz2[b,k]|^2, result_i = its FIRST argmin;
+ * result2/_i the same with the clouds swapped.  Bit-exact contract:
+ * d = (dx*dx + dy*dy) + dz*dz, dx = xyz2 - xyz, no FMA contraction. */
+int dpf_nndistance(int b, int n, const float *xyz, int m, const float *xyz2,
+                   float *result, int *result_i, float *result2, int *result2_i,
+                   dpf_stream_t stream);
+
+/* replaces nndistancegrad(...)  src/nndistance.cuh:2, nndistance.cu:149-154.
+ * grad_xyz1 / grad_xyz2 are fully overwritten (the zero-fill happens on
+ * `stream`, not on the null stream as at nndistance.cu:150-151). */
+int dpf_nndistancegrad(int b, int n, const float *xyz1, int m, const float *xyz2,
+                       const float *grad_dist1, const int *idx1,
+                       const float *grad_dist2, const int *idx2,
+                       float *grad_xyz1, float *grad_xyz2, dpf_stream_t stream);
+
+/* replaces approxmatch(...)     src/approxmatch.cuh:6, approxmatch.cu:299-307.
+ * match: (b, m, n) fp32, fully overwritten.  temp: (b, 2*(n+m)) fp32 scratch
+ * (remainL | remainR | ratioL | ratioR per cloud, approxmatch.cu:4). */
+int dpf_approxmatch(int b, int n, int m, const float *xyz1, const float *xyz2,
+                    float *match, float *temp, dpf_stream_t stream);
+
+/* replaces matchcost(...)       src/approxmatch.cuh:7, approxmatch.cu:309-316.
+ * out: (b,) = sum_{l,k} match[b,l,k] * |xyz1[b,k]-xyz2[b,l]|_2. */
+int dpf_matchcost(int b, int n, int m, const float *xyz1, const float *xyz2,
+                  const float *match, float *out, dpf_stream_t stream);
+
+/* replaces matchcostgrad(...)   src/approxmatch.cuh:8, approxmatch.cu:318-326. */
+int dpf_matchcostgrad(int b, int n, int m, const float *xyz1, const float *xyz2,
+                      const float *match, float *grad1, float *grad2,
+                      dpf_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * Per-point conditional affine-coupling flow (eval-mode BatchNorm), i.e.
+ * LocalCondRNVPDecoder.forward (lib/networks/decoders.py:54-72) over
+ * CondRealNVPFlow3D.forward (lib/networks/flows.py:95-117), F = 64.
+ *
+ * Weights arrive as one "canonical" fp32 block per coupling layer, layers in
+ * DIRECT order (decoders.py:58-64).  dpf_flow_canon_floats(G) floats per layer:
+ *
+ *   for br in (logvar, mu):                               offsets in floats
+ *     W0   [64][2]   sd0.weight, columns = the (up to) two keep channels,
+ *                    zero column if the layer keeps one            flows.py:26/61
+ *     BN0  gamma[64] beta[64] running_mean[64] running_var[64]     flows.py:27/62
+ *     W1   [64][64]  sd1.weight                                    flows.py:29/64
+ *     BN1  running_mean[64] running_var[64]  (affine=False)        flows.py:30/65
+ *     W2   [2][64]   sd2.weight, rows = the (up to) two warp channels,
+ *                    zero row if the layer warps one               flows.py:49/84
+ *     b2   [4]       sd2.bias in [0..1], [2..3] unused
+ *     for s in (w, b):                                             flows.py:33-45/68-80
+ *       Wf0 [64][G]  film_{s}0.weight
+ *       BNf gamma[64] beta[64] running_mean[64] running_var[64]
+ *       Wf1 [64][64] film_{s}1.weight
+ *       bf1 [64]     film_{s}1.bias
+ *
+ * meta: int32 [n_layers][4] = {keep_a, keep_b, warp_a, warp_b}, -1 = absent
+ * (keep_inds / warp_inds of flows.py:17-23), device memory.
+ * ------------------------------------------------------------------------ */
+
+#define DPF_FLOW_F 64
+
+/* precision of the 64x64 conditioner contraction on the matrix cores */
+#define DPF_PREC_BF16   1  /* one bf16 MFMA product                      ~3e-3 rel */
+#define DPF_PREC_BF16X3 2  /* hi/lo split, 3 bf16 MFMA products          ~1e-5 rel */
+#define DPF_PREC_BF16X6 3  /* hi/mid/lo split, 6 bf16 MFMA products      fp32-class */
+
+#define DPF_MODE_DIRECT  0 /* p_out = sqrt(eps+exp(logvar))*p + mu     flows.py:113 */
+#define DPF_MODE_INVERSE 1 /* p_out = (p-mu)/sqrt(eps+exp(logvar))     flows.py:115 */
+
+size_t dpf_flow_canon_floats(int G);
+size_t dpf_flow_packed_bytes(int n_layers, int precision);
+size_t dpf_flow_film_floats(int n_layers, int B);
+
+/* canonical fp32 weights -> MFMA-fragment-ordered bf16 parts with BatchNorm
+ * folded.  Run once per weight version (not per batch). */
+int dpf_flow_pack(int n_layers, int G, int precision, const float *canon,
+                  const int *meta, void *packed, dpf_stream_t stream);
+
+/* per-cloud FiLM conditioner (flows.py:33-45,68-80,100-101,105-106) for every
+ * layer at once: g (B, G) -> film (dpf_flow_film_floats floats). */
+int dpf_flow_film(int n_layers, int B, int G, const float *canon, const float *g,
+                  float *film, float flow_eps, dpf_stream_t stream);
+
+/* The fused L-layer stack.  p_in / p_out / sum_logvar: (B, 3, N) fp32
+ * channel-major as the networks use (flows.py:95).  Optional per-layer lists
+ * ps / mus / logvars: (n_layers, B, 3, N) fp32 in DIRECT layer order for both
+ * modes (decoders.py:61-70), or NULL to skip materialising them.
+ * sum_logvar = sum over layers of logvar (what sum(logvars) gives
+ * losses.py:13); may be NULL. */
+int dpf_flow_forward(int n_layers, int B, int N, int mode, int precision,
+                     const void *packed, const int *meta, const float *film, const float *p_in,
+                     float *p_out, float *sum_logvar,
+                     float *ps, float *mus, float *logvars,
+                     float flow_eps, dpf_stream_t stream);
+
+/* library identification: returns e.g. "dpf_hip gfx950 r1" */
+const char *dpf_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPF_HIP_H */

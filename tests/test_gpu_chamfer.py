@@ -1,0 +1,122 @@
+"""Chamfer parity on the GPU: HIP kernels (through the C ABI) vs the CPU oracle, bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import detrng
+from oracle import structural as S
+from oracle.gen_golden import chamfer_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from dpf_nets_amd.metrics.StructuralLosses import StructuralLossesBackend as BK
+    return BK
+
+
+def _run(BK, a, b):
+    d1, i1, d2, i2 = BK.NNDistance(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
+    torch.cuda.synchronize()
+    return d1.cpu().numpy(), i1.cpu().numpy(), d2.cpu().numpy(), i2.cpu().numpy()
+
+
+def _assert_bit_exact(got, ref, tag):
+    for g, r, name in zip(got, ref, ("dist1", "idx1", "dist2", "idx2")):
+        assert g.dtype == r.dtype and g.shape == r.shape, (tag, name)
+        if g.dtype == np.float32:
+            assert np.array_equal(g.view(np.uint32), r.view(np.uint32)), \
+                (tag, name, float(np.abs(g - r).max()), int((g != r).sum()))
+        else:
+            assert np.array_equal(g, r), (tag, name, int((g != r).sum()))
+
+
+# shapes chosen to hit every launch variant (candidate split KS = 4 / 2 / 1), ragged tails
+# (n, m not multiples of 8 / 64 / 128 / 512) and degenerate sizes
+SHAPES = [(3, 257, 257), (2, 130, 515), (1, 1, 1), (2, 7, 3), (1, 64, 8), (5, 128, 1000), (32, 1024, 1024),
+          (32, 2048, 2048), (48, 2500, 2048), (64, 2048, 2048)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_nndistance_bit_exact_vs_oracle(shape):
+    BK = _gpu()
+    B, n, m = shape
+    a, b = chamfer_inputs(1000 + n + m, B, n, m)
+    _assert_bit_exact(_run(BK, a, b), S.nndistance(a, b), shape)
+
+
+def test_nndistance_first_minimum_on_exact_ties():
+    BK = _gpu()
+    B, n, m = 2, 197, 530
+    a = np.round(detrng.uniform_f32(31, (B, n, 3), -3, 3))
+    b = np.round(detrng.uniform_f32(32, (B, m, 3), -3, 3))
+    b[:, 250:260] = b[:, 10:20]
+    b[:, 520:530] = b[:, 3:13]
+    got = _run(BK, a, b)
+    _assert_bit_exact(got, S.nndistance(a, b), "ties")
+    dd = ((a[:, :, None, :] - b[:, None, :, :]) ** 2).sum(-1)
+    assert np.array_equal(got[1], dd.argmin(2)) and np.array_equal(got[3], dd.argmin(1))
+
+
+def test_nndistance_vs_reference_golden(golden_dir):
+    BK = _gpu()
+    gold = np.load(os.path.join(golden_dir, "chamfer.npz"))
+    a, b = chamfer_inputs(21, 3, 257, 257)
+    d1, i1, d2, i2 = _run(BK, a, b)
+    np.testing.assert_allclose(d1, gold["eq257/ref_per_a"], rtol=1e-4, atol=2e-6)   # reference distChamfer
+    np.testing.assert_allclose(d2, gold["eq257/ref_per_b"], rtol=1e-4, atol=2e-6)
+    ok = gold["eq257/bf_gap1"] > 1e-5
+    assert np.array_equal(i1[ok], gold["eq257/bf_idx1"][ok])
+
+
+def test_nndistance_full_size_properties():
+    """BASELINE.json sizes (B=32, N=2048 and the N=8192 stress config) through size-independent properties."""
+    BK = _gpu()
+    for (B, n) in ((32, 2048), (4, 8192)):
+        a, b = chamfer_inputs(77, B, n, n)
+        ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+        d1, i1, d2, i2 = BK.NNDistance(ta, tb)
+        e1, j1, e2, j2 = BK.NNDistance(tb, ta)              # swapping the clouds swaps the outputs
+        assert torch.equal(d1, e2) and torch.equal(i1, j2) and torch.equal(d2, e1) and torch.equal(i2, j1)
+        assert (d1 >= 0).all() and (i1 >= 0).all() and (i1 < n).all()
+        # the reported index really attains the reported distance, and nothing is closer
+        nn = torch.gather(tb, 1, i1.long().unsqueeze(2).expand(-1, -1, 3))
+        dx = nn - ta
+        dd = (dx[..., 0] * dx[..., 0] + dx[..., 1] * dx[..., 1]) + dx[..., 2] * dx[..., 2]
+        assert torch.equal(dd, d1)
+        s1, si1, _, _ = BK.NNDistance(ta, ta.clone())      # a cloud against itself: distance 0 at its own index
+        assert (s1 == 0).all() and torch.equal(si1.long(), torch.arange(n, device="cuda").expand(B, n))
+        # permuting the candidates does not change the distances
+        perm = torch.randperm(n, device="cuda")
+        p1, _, _, _ = BK.NNDistance(ta, tb[:, perm].contiguous())
+        assert torch.equal(p1, d1)
+
+
+def test_nndistancegrad_vs_oracle_and_autograd():
+    BK = _gpu()
+    from dpf_nets_amd.metrics.StructuralLosses import nn_distance
+    for (B, n, m) in ((2, 40, 55), (3, 300, 257), (8, 2048, 2048)):
+        a, b = chamfer_inputs(41 + n, B, n, m)
+        gd1 = detrng.normal_f32(42, (B, n)); gd2 = detrng.normal_f32(43, (B, m))
+        d1, i1, d2, i2 = S.nndistance(a, b)
+        r1, r2 = S.nndistancegrad(a, b, i1, i2, gd1, gd2)
+        ta = torch.from_numpy(a).cuda().requires_grad_(True)
+        tb = torch.from_numpy(b).cuda().requires_grad_(True)
+        o1, o2 = nn_distance(ta, tb)
+        ((o1 * torch.from_numpy(gd1).cuda()).sum() + (o2 * torch.from_numpy(gd2).cuda()).sum()).backward()
+        np.testing.assert_allclose(ta.grad.cpu().numpy(), r1, rtol=1e-5, atol=1e-5)   # atomics: order-dependent rounding
+        np.testing.assert_allclose(tb.grad.cpu().numpy(), r2, rtol=1e-5, atol=1e-5)
+
+
+def test_input_checks_mirror_reference():
+    BK = _gpu()
+    a = torch.zeros(2, 8, 3)
+    with pytest.raises(RuntimeError):
+        BK.NNDistance(a, a)                                    # CPU tensor: CHECK_CUDA
+    c = torch.zeros(2, 3, 8, device="cuda").transpose(1, 2)
+    with pytest.raises(RuntimeError):
+        BK.NNDistance(c, c)                                    # non-contiguous: CHECK_CONTIGUOUS
