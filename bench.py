@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""Headline benchmark: points/s through the L-layer per-point flow + Chamfer.
+
+  python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one synthetic batch resident in HBM:
+  FiLM conditioner (all layers) -> fused L-layer coupling stack, mode 'direct',
+  eval-BN (lib/networks/decoders.py:54-72 as evaluate() runs it, evaluating.py:70)
+  -> nn_distance(out^T, target) both directions (evaluating.py:110-111)
+  -> per-cloud CD reduction (evaluating.py:112).
+Workload: BASELINE.json configs[1]: B=32 clouds x N=2048 points per GPU, L=14
+coupling layers (first 14 layers of LocalCondRNVPDecoder(n_flows=5)), F=64, G=128.
+N GPUs: one process per GPU (torchrun), every rank runs its own B=32 shard, no
+data-path collective ("weak" scaling); value = all ranks' points / max-rank time.
+
+Prints ONE JSON line (rank 0) carrying `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA peak
+FLOP_PER_POINT_LAYER = 17152   # 2 branches x (2F|K| + 2F^2 + 2|W|F)
+MFMA_PRODUCTS = {"bf16": 1, "bf16x3": 3, "bf16x6": 6}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=32, help="clouds per GPU")
+    ap.add_argument("--points", type=int, default=2048)
+    ap.add_argument("--layers", type=int, default=14)
+    ap.add_argument("--latent", type=int, default=128)
+    ap.add_argument("--precision", default=os.environ.get("DPF_PRECISION", "bf16x3"),
+                    choices=sorted(MFMA_PRODUCTS))
+    ap.add_argument("--lists", action="store_true", help="also materialise the 3 x L per-layer lists")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reps", type=int, default=6)
+    return ap.parse_args()
+
+
+def build_workload(args, device):
+    from dpf_nets_amd import synthetic as FO
+    from dpf_nets_amd.networks import LocalCondRNVPDecoder
+    n_flows = (args.layers + 2) // 3
+    state = FO.make_decoder_state(0, n_flows, 64, args.latent)
+    dec = LocalCondRNVPDecoder(n_flows, 64, args.latent)
+    dec.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in state.items()}, strict=True)
+    dec = dec.to(device).eval()
+    dec.precision = args.precision
+    dec.materialize_lists = bool(args.lists)
+    tgt, z, g = FO.synthetic_inputs(0, args.batch, args.points, args.latent)
+    z = torch.from_numpy(z).to(device)
+    g = torch.from_numpy(g).to(device)
+    tgt_pm = torch.from_numpy(np.ascontiguousarray(tgt.transpose(0, 2, 1))).to(device)   # (B,N,3), resident
+    return dec, state, n_flows, z, g, tgt, tgt_pm
+
+
+def make_step(dec, z, g, tgt_pm, L):
+    from dpf_nets_amd.metrics.StructuralLosses import StructuralLossesBackend as BK
+    from dpf_nets_amd.networks.utils import chamfer_per_cloud
+    stack = dec.stack()
+
+    def step():
+        p_out, sum_lv, ps, mus, lvs = stack.run(z, g, "direct", dec.precision, want_lists=dec.materialize_lists,
+                                                n_layers=L, want_pointmajor=True)
+        d1, i1, d2, i2 = BK.NNDistance(stack.last_pointmajor, tgt_pm)
+        cd = chamfer_per_cloud(d1, d2)
+        return p_out, d1, i1, d2, i2, cd
+    return step
+
+
+def time_kernel(fn, reps=20, rounds=5):
+    """average duration of one launch, HIP events on the launch stream, back-to-back launches"""
+    best = []
+    for _ in range(rounds):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            fn()
+        e.record()
+        e.synchronize()
+        best.append(s.elapsed_time(e) / reps * 1e3)     # us
+    return float(np.median(best))
+
+
+def kernel_timings(dec, z, g, tgt_pm, L, precision):
+    """per-kernel average launch durations (us) measured with HIP events"""
+    from dpf_nets_amd._lib import lib, PREC, MODE, current_stream
+    from dpf_nets_amd.metrics.StructuralLosses import StructuralLossesBackend as BK
+    stack = dec.stack()
+    canon, meta, packed, G = stack._ensure(precision, z.device)
+    B, _, N = z.shape
+    film = torch.empty(lib().dpf_flow_film_floats(L, B), dtype=torch.float32, device=z.device)
+    p_out, sum_lv = torch.empty_like(z), torch.empty_like(z)
+    pm = torch.empty((B, N, 3), dtype=torch.float32, device=z.device)
+    st = current_stream()
+    eps = float(stack.layers[0].eps_value)
+
+    def k_film():
+        lib().dpf_flow_film(L, B, G, canon.data_ptr(), g.data_ptr(), film.data_ptr(), eps, st)
+
+    def k_flow():
+        lib().dpf_flow_forward(L, B, N, MODE["direct"], PREC[precision], packed.data_ptr(), meta.data_ptr(),
+                               film.data_ptr(), z.data_ptr(), p_out.data_ptr(), pm.data_ptr(), sum_lv.data_ptr(),
+                               None, None, None, eps, st)
+    d1 = torch.empty((B, N), dtype=torch.float32, device=z.device); d2 = torch.empty_like(d1)
+    i1 = torch.empty((B, N), dtype=torch.int32, device=z.device); i2 = torch.empty_like(i1)
+
+    def k_nn():
+        lib().dpf_nndistance(B, N, pm.data_ptr(), N, tgt_pm.data_ptr(), d1.data_ptr(), i1.data_ptr(), d2.data_ptr(),
+                             i2.data_ptr(), st)
+    k_film(); k_flow(); k_nn()
+    torch.cuda.synchronize()
+    return {"film_kernel": time_kernel(k_film), "flow_kernel": time_kernel(k_flow), "nn_kernel": time_kernel(k_nn)}
+
+
+def cpu_baseline(args, state, n_flows, tgt):
+    """The CPU oracle (kind 'port') timed on this host on the SAME workload, bounded reps."""
+    from oracle import flow_oracle as FO
+    from oracle import structural as S
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    st = FO.to_torch(state)
+    _, z, g = FO.synthetic_inputs(0, args.batch, args.points, args.latent)
+    tz, tg = torch.from_numpy(z), torch.from_numpy(g)
+    tgt_pm = np.ascontiguousarray(tgt.transpose(0, 2, 1))
+    S.lib()
+    with torch.no_grad():
+        FO.decoder(st, n_flows, tz[:2], tg[:2], "direct", n_layers=args.layers)     # warm-up
+        t0 = time.perf_counter()
+        for _ in range(args.cpu_reps):
+            ps, _, _ = FO.decoder(st, n_flows, tz, tg, "direct", n_layers=args.layers)
+            out = np.ascontiguousarray(ps[-1].numpy().transpose(0, 2, 1))
+            d1, _, d2, _ = S.nndistance(out, tgt_pm)
+            _ = d1.mean(1) + d2.mean(1)
+        dt = time.perf_counter() - t0
+    pts = args.cpu_reps * args.batch * args.points
+    return {"value": pts / dt, "unit": "points/s", "cores": ncores, "kind": "port",
+            "sample": "%d x full workload (B=%d N=%d L=%d): torch-CPU fp32 flow oracle on %d threads + "
+                      "single-thread C Chamfer oracle, %.1f s" % (args.cpu_reps, args.batch, args.points, args.layers,
+                                                                   ncores, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    n_gpus = world if world > 1 else 1
+
+    dec, state, n_flows, z, g, tgt, tgt_pm = build_workload(args, device)
+    L = args.layers
+    step = make_step(dec, z, g, tgt_pm, L)
+
+    # first calls: pack weights, set LDS attribute -- outside any capture and outside the timed region
+    for _ in range(3):
+        out = step()
+    torch.cuda.synchronize()
+
+    run_once = step
+    graph = None
+    if not args.no_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = step()
+        run_once = graph.replay
+
+    for _ in range(args.warmup):
+        run_once()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_once()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity on the outputs of the timed path (cheap, outside the timed region)
+    p_out, d1, i1, d2, i2, cd = out
+    assert torch.isfinite(p_out).all() and torch.isfinite(cd).all() and (d1 >= 0).all()
+
+    if rank == 0:
+        pts_per_step = args.batch * args.points * n_gpus
+        ms_per_step = elapsed / args.steps * 1e3
+        kt = kernel_timings(dec, z, g, tgt_pm, L, args.precision)
+        dom = max(("flow_kernel", "nn_kernel"), key=lambda k: kt[k])
+        B, N = args.batch, args.points
+        flow_flops = FLOP_PER_POINT_LAYER * L * B * N
+        flow_ach = flow_flops / (kt["flow_kernel"] * 1e-6) / 1e12
+        nn_bytes = B * (N + N) * 20                         # 12 B in + 8 B out per point
+        nn_ach = nn_bytes / (kt["nn_kernel"] * 1e-6) / 1e9
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tj):
+            try:
+                tr = json.load(open(tj))
+                key = "%s/B%d_N%d_L%d_%s" % (dom, B, N, L, args.precision)
+                traffic = tr.get(key)
+            except Exception:
+                traffic = None
+        if dom == "flow_kernel":
+            roof = {"kernel": "flow_kernel<%s>" % args.precision, "bound": "mfma", "achieved": flow_ach,
+                    "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": flow_ach / MFMA_BF16_PEAK_TF,
+                    "traffic": traffic,
+                    "note": "algorithmic FLOPs (17152/pt/layer); the split precision issues %dx the products of "
+                            "the 64x64 contraction on the matrix cores" % MFMA_PRODUCTS[args.precision]}
+        else:
+            roof = {"kernel": "nn_kernel", "bound": "hbm", "achieved": nn_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": nn_ach / HBM_PEAK_GBS, "traffic": traffic,
+                    "note": "brute-force Chamfer is fp32-VALU bound (AI ~800 FLOP/B); HBM fraction is tiny by construction"}
+        roof["kernels_us"] = kt
+        roof["flow_algorithmic_tflops"] = flow_ach
+        roof["chamfer_algorithmic_gbs"] = nn_ach
+        roof["chamfer_pair_evals_per_s"] = 2.0 * B * N * N / (kt["nn_kernel"] * 1e-6)
+        line = {
+            "metric": "points/sec through %d-layer flow + Chamfer, B=%d N=%d" % (L, B, N),
+            "value": pts_per_step / (elapsed / args.steps), "unit": "points/s", "n_gpus": n_gpus,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.precision + " MFMA operands, fp32 accumulate/points",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: %d coupling layers (first %d of LocalCondRNVPDecoder(n_flows=%d)), "
+                                   "direct/eval-BN, + nn_distance both directions + CD reduction" % (L, L, n_flows),
+                       "clouds_per_gpu": B, "points_per_cloud": N, "hidden": 64, "latent": args.latent,
+                       "global_clouds": B * n_gpus, "per_layer_lists": bool(args.lists),
+                       "launch": "eager" if args.no_graph else "hipGraph replay", "parallelism": "clouds sharded, no collective"},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, state, n_flows, tgt)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -25,7 +25,8 @@ SIGNATURES = {
     "dpf_flow_film_floats": (_sz, [_i, _i]),
     "dpf_flow_pack": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "dpf_flow_film": (_i, [_i, _i, _i, _vp, _vp, _vp, _f, _vp]),
-    "dpf_flow_forward": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp]),
+    "dpf_flow_forward": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp]),
+    "dpf_chamfer_reduce": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "dpf_version": (ctypes.c_char_p, []),
 }
 

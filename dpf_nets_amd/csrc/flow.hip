@@ -44,7 +44,7 @@
 
 namespace {
 
-constexpr int F = DPF_FLOW_F;
+static_assert(DPF_FLOW_F == 64, "kernels are built for 64 hidden features");
 constexpr float BN_EPS = 1e-5f;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -251,7 +251,7 @@ struct FlowArgs {
     const int *meta;
     const float *film;
     const float *p_in;
-    float *p_out, *sum_lv, *ps, *mus, *lvs;
+    float *p_out, *p_out_pm, *sum_lv, *ps, *mus, *lvs;
     int L, B, N, mode;
     float eps;
 };
@@ -446,6 +446,10 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
     if (valid) {
         if (!h) {
             a.p_out[cloud + n] = p0; a.p_out[cloud + N + n] = p1; a.p_out[cloud + 2 * (size_t)N + n] = p2;
+            if (a.p_out_pm != nullptr) {   // point-major (B,N,3) copy for the structural losses (evaluating.py:110)
+                float *o = a.p_out_pm + ((size_t)bi * N + n) * 3;
+                o[0] = p0; o[1] = p1; o[2] = p2;
+            }
         } else if (a.sum_lv != nullptr) {
             a.sum_lv[cloud + n] = s0; a.sum_lv[cloud + N + n] = s1; a.sum_lv[cloud + 2 * (size_t)N + n] = s2;
         }
@@ -494,8 +498,8 @@ extern "C" int dpf_flow_film(int n_layers, int B, int G, const float *canon, con
 
 extern "C" int dpf_flow_forward(int n_layers, int B, int N, int mode, int precision, const void *packed,
                                 const int *meta, const float *film, const float *p_in, float *p_out,
-                                float *sum_logvar, float *ps, float *mus, float *logvars, float flow_eps,
-                                dpf_stream_t stream) {
+                                float *p_out_pointmajor, float *sum_logvar, float *ps, float *mus, float *logvars,
+                                float flow_eps, dpf_stream_t stream) {
     const int ns = ns_of(precision);
     if (!ns || n_layers <= 0 || B < 0 || N <= 0 || (mode != DPF_MODE_DIRECT && mode != DPF_MODE_INVERSE)) return DPF_EINVAL;
     if (B == 0) return 0;
@@ -504,7 +508,7 @@ extern "C" int dpf_flow_forward(int n_layers, int B, int N, int mode, int precis
     if (B > 65535) return DPF_ENOSUP;
     FlowArgs a;
     a.packed = (const uint8_t *)packed; a.meta = meta; a.film = film; a.p_in = p_in;
-    a.p_out = p_out; a.sum_lv = sum_logvar; a.ps = ps; a.mus = mus; a.lvs = logvars;
+    a.p_out = p_out; a.p_out_pm = p_out_pointmajor; a.sum_lv = sum_logvar; a.ps = ps; a.mus = mus; a.lvs = logvars;
     a.L = n_layers; a.B = B; a.N = N; a.mode = mode; a.eps = flow_eps;
     const dim3 grid((N + BLOCK_PTS - 1) / BLOCK_PTS, B), block(FW * 64);
     hipStream_t s = (hipStream_t)stream;

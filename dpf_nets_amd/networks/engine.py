@@ -103,9 +103,10 @@ class FlowStack:
         return self._canon, self._meta, self._packed[precision], G
 
     # -- run ---------------------------------------------------------------------
-    def run(self, p, g, mode, precision=None, want_lists=True, n_layers=None):
+    def run(self, p, g, mode, precision=None, want_lists=True, n_layers=None, want_pointmajor=False):
         """p (B,3,N), g (B,G) fp32 CUDA.  Returns (p_out, sum_logvar, ps, mus, logvars); the
-        last three are (L,B,3,N) buffers in DIRECT order or None."""
+        last three are (L,B,3,N) buffers in DIRECT order or None.  With want_pointmajor the
+        (B,N,3) copy of p_out is left in self.last_pointmajor."""
         precision = precision or DEFAULT_PRECISION
         if precision not in PREC:
             raise ValueError("precision must be one of %s" % sorted(PREC))
@@ -130,6 +131,8 @@ class FlowStack:
             film = torch.empty(lib().dpf_flow_film_floats(L, B), dtype=torch.float32, device=dev)
             p_out = torch.empty_like(p)
             sum_lv = torch.empty_like(p)
+            pm = torch.empty((B, N, 3), dtype=torch.float32, device=dev) if want_pointmajor else None
+            self.last_pointmajor = pm
             if want_lists:
                 lists = torch.empty((3, L, B, 3, N), dtype=torch.float32, device=dev)
                 lp = [lists[i].data_ptr() for i in range(3)]
@@ -140,7 +143,8 @@ class FlowStack:
             check(lib().dpf_flow_film(L, B, G, canon.data_ptr(), g.data_ptr(), film.data_ptr(), eps, stream),
                   "flow_film")
             check(lib().dpf_flow_forward(L, B, N, MODE[mode], PREC[precision], packed.data_ptr(), meta.data_ptr(),
-                                         film.data_ptr(), p.data_ptr(), p_out.data_ptr(), sum_lv.data_ptr(),
+                                         film.data_ptr(), p.data_ptr(), p_out.data_ptr(),
+                                         pm.data_ptr() if pm is not None else None, sum_lv.data_ptr(),
                                          lp[0], lp[1], lp[2], eps, stream), "flow_forward")
         if want_lists:
             return p_out, sum_lv, lists[0], lists[1], lists[2]

@@ -66,6 +66,12 @@ int dpf_matchcostgrad(int b, int n, int m, const float *xyz1, const float *xyz2,
                       const float *match, float *grad1, float *grad2,
                       dpf_stream_t stream);
 
+/* Chamfer caller reductions, lib/networks/evaluating.py:112:
+ * cd[b] = mean_j dist1[b,j] + mean_k dist2[b,k]  (the reference then takes
+ * .mean() over the batch).  Deterministic: one workgroup per cloud, fixed tree. */
+int dpf_chamfer_reduce(int b, int n, int m, const float *dist1, const float *dist2,
+                       float *cd, dpf_stream_t stream);
+
 /* ------------------------------------------------------------------------ *
  * Per-point conditional affine-coupling flow (eval-mode BatchNorm), i.e.
  * LocalCondRNVPDecoder.forward (lib/networks/decoders.py:54-72) over
@@ -122,10 +128,12 @@ int dpf_flow_film(int n_layers, int B, int G, const float *canon, const float *g
  * ps / mus / logvars: (n_layers, B, 3, N) fp32 in DIRECT layer order for both
  * modes (decoders.py:61-70), or NULL to skip materialising them.
  * sum_logvar = sum over layers of logvar (what sum(logvars) gives
- * losses.py:13); may be NULL. */
+ * losses.py:13); may be NULL.  p_out_pointmajor: optional (B, N, 3) copy of
+ * p_out in the layout the structural losses take (the
+ * `.transpose(1, 2).contiguous()` of lib/networks/evaluating.py:110), or NULL. */
 int dpf_flow_forward(int n_layers, int B, int N, int mode, int precision,
                      const void *packed, const int *meta, const float *film, const float *p_in,
-                     float *p_out, float *sum_logvar,
+                     float *p_out, float *p_out_pointmajor, float *sum_logvar,
                      float *ps, float *mus, float *logvars,
                      float flow_eps, dpf_stream_t stream);
 

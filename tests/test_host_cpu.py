@@ -1,0 +1,160 @@
+"""CPU-side checks of the product package: the C-ABI library loads and exports every symbol
+include/dpf_hip.h declares, the module mirror keeps the reference's state-dict contract, the
+training-mode tensor-op path matches the reference's golden vectors, FlowList/PointFlowNLL
+semantics.  No compute calls into the HIP library here (there is no GPU)."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import flow_oracle as FO
+from oracle.gen_golden import layer_inputs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from dpf_nets_amd import _lib
+    assert _lib.have_lib(), "libdpf_hip.so is not built (run __graft_entry__.build())"
+    header = open(os.path.join(ROOT, "include", "dpf_hip.h")).read()
+    declared = set(re.findall(r"\b(dpf_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    handle = _lib.lib()                                   # raises if any symbol is unresolved
+    assert handle.dpf_version().startswith(b"dpf_hip gfx950")
+    for G in (128, 512):                                  # size queries are host-only
+        assert handle.dpf_flow_canon_floats(G) == 2 * (4740 + 2 * (64 * G + 4416))
+    assert handle.dpf_flow_packed_bytes(14, _lib.PREC["bf16x3"]) == 14 * (2 * 16384 + 5120)
+    assert handle.dpf_flow_film_floats(14, 32) == 14 * 32 * 512
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from dpf_nets_amd import _lib
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "lib_path", lambda: "/nonexistent/libdpf_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.lib()
+
+
+def test_state_dict_contract(golden_dir):
+    from dpf_nets_amd.networks import CondRealNVPFlow3D, LocalCondRNVPDecoder, SharedDot
+    keys = json.load(open(os.path.join(golden_dir, "state_keys.json")))
+    for warp in ([0], [0, 1]):
+        ref = keys["CondRealNVPFlow3D_w" + "".join(map(str, warp))]
+        mod = CondRealNVPFlow3D(64, 128, warp_inds=warp)
+        sd = mod.state_dict()
+        assert [k for k, _, _ in ref] == list(sd.keys())
+        assert all(tuple(s) == tuple(sd[k].shape) and d == str(sd[k].dtype) for k, s, d in ref)
+        assert keys["CondRealNVPFlow3D_w" + "".join(map(str, warp)) + "_params"] == [k for k, _ in mod.named_parameters()]
+    dec = LocalCondRNVPDecoder(2, 64, 512)
+    ref = keys["LocalCondRNVPDecoder_nf2_g512"]
+    assert [k for k, _, _ in ref] == list(dec.state_dict().keys())
+    assert sum(p.numel() for p in dec.parameters()) == keys["LocalCondRNVPDecoder_nf2_g512_nparams"]
+    assert [[k, list(v.shape)] for k, v in SharedDot(3, 5, 1, bias=True).state_dict().items()] == keys["SharedDot_3_5_bias"]
+    # init statistics (flows.py:52-58, layers.py:29-38)
+    torch.manual_seed(0)
+    mod = CondRealNVPFlow3D(64, 128, weight_std=0.01, warp_inds=[0])
+    st = keys["init_stats"]
+    assert abs(float(mod.T_mu_0[0].weight.abs().max()) - st["sd0_absmax"]) < 0.02      # bound sqrt(6/(64*2))
+    assert float(mod.T_mu_0[0].weight.abs().max()) <= (6.0 / 128) ** 0.5 + 1e-6
+    assert float(mod.T_mu_0[3].weight.abs().max()) <= (6.0 / 4096) ** 0.5 + 1e-6
+    assert abs(float(mod.T_mu_1[-1].weight.std()) - 0.01) < 0.004
+    assert abs(float(mod.T_mu_0_cond_w[-1].weight.std()) - 0.01) < 0.001
+    assert float(mod.T_mu_1[-1].bias.abs().max()) == 0 and float(mod.T_mu_0_cond_b[-1].bias.abs().max()) == 0
+    assert float(mod.eps) == pytest.approx(1e-6)
+
+
+def test_training_path_matches_reference_golden(golden_dir):
+    """The tensor-op (training-mode BN) path of the mirror module == the reference module."""
+    from dpf_nets_amd.networks import CondRealNVPFlow3D
+    gold = np.load(os.path.join(golden_dir, "flow_layer.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "flow_layer.json")))
+    B, N, F, G = meta["B"], meta["N"], meta["F"], meta["G"]
+    for case in meta["cases"]:
+        if case["bn"] != "train":
+            continue
+        mod = CondRealNVPFlow3D(F, G, warp_inds=case["warp"])
+        mod.load_state_dict(FO.to_torch(FO.make_layer_state(case["seed"], F, G, case["warp"])), strict=True)
+        mod.train()
+        p, g, r1, r2, r3 = layer_inputs(case["seed"], B, N, G)
+        tp = torch.from_numpy(p.copy()).requires_grad_(True)
+        po, mu, lv = mod(tp, torch.from_numpy(g), mode=case["mode"])
+        t = case["tag"]
+        np.testing.assert_allclose(po.detach().numpy(), gold[t + "/p_out"], rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(lv.detach().numpy(), gold[t + "/logvar"], rtol=1e-5, atol=2e-6)
+        ((po * torch.from_numpy(r1)).sum() + (lv * torch.from_numpy(r2)).sum() + (mu * torch.from_numpy(r3)).sum()).backward()
+        np.testing.assert_allclose(tp.grad.numpy(), gold[t + "/grad_p"], rtol=2e-4, atol=2e-5)
+        sd = mod.state_dict()
+        for k in sd:
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                np.testing.assert_allclose(sd[k].numpy(), gold[t + "/stats/" + k], rtol=1e-5, atol=1e-6)
+
+
+def test_eval_path_refuses_cpu():
+    from dpf_nets_amd.networks import LocalCondRNVPDecoder
+    dec = LocalCondRNVPDecoder(1, 64, 128).eval()
+    with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU fallback"):
+        dec(torch.zeros(1, 3, 8), torch.zeros(1, 128))
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        from dpf_nets_amd.metrics.StructuralLosses import nn_distance
+        nn_distance(torch.zeros(1, 4, 3), torch.zeros(1, 4, 3))
+
+
+def test_flowlist_and_nll_semantics():
+    from dpf_nets_amd.networks.flowlist import FlowList
+    from dpf_nets_amd.networks.losses import PointFlowNLL, total_logvar
+    torch.manual_seed(0)
+    buf = torch.randn(5, 2, 3, 7)
+    fl = FlowList(buf, buf.sum(0))
+    assert len(fl) == 5 and torch.equal(fl[0], buf[0]) and torch.equal(fl[-1], buf[4])
+    with pytest.raises(IndexError):
+        fl[5]
+    prior = torch.randn(2, 3, 7)
+    lst = [prior] + fl                                   # models.py:169-171
+    assert isinstance(lst, list) and len(lst) == 6 and lst[1] is fl[0]
+    lst2 = [prior]
+    lst2 += fl                                           # models.py:119-122
+    assert len(lst2) == 6
+    assert isinstance(fl + [prior], list)                # models.py:168: buf_p[0] + [p_input]
+    np.testing.assert_allclose(total_logvar(lst).numpy(), sum([prior] + list(buf.unbind(0))).numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(total_logvar(lst2).numpy(), total_logvar(lst).numpy())
+    np.testing.assert_allclose(sum(fl).numpy(), buf.sum(0).numpy(), rtol=1e-6, atol=1e-6)
+    # a list that merely ENDS with a foreign tagged view must not use the fused total
+    other = FlowList(torch.randn(5, 2, 3, 7), torch.zeros(2, 3, 7))
+    mixed = [prior] + list(buf.unbind(0))[:4] + [other[4]]
+    np.testing.assert_allclose(total_logvar(mixed).numpy(), sum(mixed).numpy())
+    # PointFlowNLL == oracle formula
+    smp, mus = [torch.randn(2, 3, 7)], [torch.randn(2, 3, 7)]
+    ref = FO.point_flow_nll(smp, mus, lst)
+    np.testing.assert_allclose(float(PointFlowNLL()(smp, mus, lst)), float(ref), rtol=1e-6)
+
+
+def test_synthetic_generator_matches_oracle_streams():
+    from dpf_nets_amd import synthetic as SY
+    a, b = SY.make_decoder_state(3, 2, 64, 128), FO.make_decoder_state(3, 2, 64, 128)
+    assert list(a) == list(b) and all(np.array_equal(a[k], b[k]) for k in a)
+    assert all(np.array_equal(x, y) for x, y in zip(SY.synthetic_inputs(1, 2, 16, 8), FO.synthetic_inputs(1, 2, 16, 8)))
+
+
+def test_canonical_block_layout():
+    """engine.layer_canon_pieces follows the layout documented in include/dpf_hip.h."""
+    from dpf_nets_amd.networks import CondRealNVPFlow3D
+    from dpf_nets_amd.networks.engine import layer_canon_pieces, layer_meta
+    from dpf_nets_amd import _lib
+    for warp, G in (([1], 128), ([0, 2], 512)):
+        mod = CondRealNVPFlow3D(64, G, warp_inds=warp)
+        flat = torch.cat(layer_canon_pieces(mod))
+        assert flat.numel() == _lib.lib().dpf_flow_canon_floats(G)
+        br = flat.numel() // 2
+        nk = 3 - len(warp)
+        w0 = flat[:128].view(64, 2)                         # logvar branch first
+        assert torch.equal(w0[:, :nk], mod.T_logvar_0[0].weight[0]) and (w0[:, nk:] == 0).all()
+        assert torch.equal(flat[384:384 + 4096].view(64, 64), mod.T_logvar_0[3].weight[0])
+        w2 = flat[4608:4736].view(2, 64)
+        assert torch.equal(w2[:len(warp)], mod.T_logvar_1[1].weight[0]) and (w2[len(warp):] == 0).all()
+        assert torch.equal(flat[br + 384:br + 384 + 4096].view(64, 64), mod.T_mu_0[3].weight[0])
+        assert torch.equal(flat[4740:4740 + 64 * G].view(64, G), mod.T_logvar_0_cond_w[0].weight)
+        m = layer_meta(mod)
+        assert m[:2] == ([c for c in range(3) if c not in warp] + [-1])[:2] and m[2:] == (warp + [-1])[:2]
