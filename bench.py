@@ -101,7 +101,7 @@ def kernel_timings(dec, z, g, tgt_pm, L, precision):
     from dpf_nets_amd._lib import lib, PREC, MODE, current_stream
     from dpf_nets_amd.metrics.StructuralLosses import StructuralLossesBackend as BK
     stack = dec.stack()
-    canon, meta, packed, G = stack._ensure(precision, z.device)
+    canon, meta, packed, G = stack._ensure(precision, z.device, L)
     B, _, N = z.shape
     film = torch.empty(lib().dpf_flow_film_floats(L, B), dtype=torch.float32, device=z.device)
     p_out, sum_lv = torch.empty_like(z), torch.empty_like(z)
@@ -110,7 +110,7 @@ def kernel_timings(dec, z, g, tgt_pm, L, precision):
     eps = float(stack.layers[0].eps_value)
 
     def k_film():
-        lib().dpf_flow_film(L, B, G, canon.data_ptr(), g.data_ptr(), film.data_ptr(), eps, st)
+        lib().dpf_flow_film(L, B, G, PREC[precision], packed.data_ptr(), g.data_ptr(), film.data_ptr(), eps, st)
 
     def k_flow():
         lib().dpf_flow_forward(L, B, N, MODE["direct"], PREC[precision], packed.data_ptr(), meta.data_ptr(),
@@ -127,31 +127,38 @@ def kernel_timings(dec, z, g, tgt_pm, L, precision):
     return {"film_kernel": time_kernel(k_film), "flow_kernel": time_kernel(k_flow), "nn_kernel": time_kernel(k_nn)}
 
 
-def cpu_baseline(args, state, n_flows, tgt):
-    """The CPU oracle (kind 'port') timed on this host on the SAME workload, bounded reps."""
+def cpu_baseline(args, state, n_flows, tgt, budget_s=15.0):
+    """The CPU oracle (kind 'port') timed on this host's cores on a BOUNDED sample of the same
+    workload: whole clouds of the B x N batch, as many as fit ~budget_s of CPU work."""
     from oracle import flow_oracle as FO
     from oracle import structural as S
-    ncores = os.cpu_count() or 1
+    ncores = min(os.cpu_count() or 1, 32)       # torch-CPU on hundreds of threads thrashes on these small ops
     torch.set_num_threads(ncores)
     st = FO.to_torch(state)
     _, z, g = FO.synthetic_inputs(0, args.batch, args.points, args.latent)
-    tz, tg = torch.from_numpy(z), torch.from_numpy(g)
     tgt_pm = np.ascontiguousarray(tgt.transpose(0, 2, 1))
     S.lib()
-    with torch.no_grad():
-        FO.decoder(st, n_flows, tz[:2], tg[:2], "direct", n_layers=args.layers)     # warm-up
-        t0 = time.perf_counter()
-        for _ in range(args.cpu_reps):
+
+    def run(nb):
+        tz, tg = torch.from_numpy(z[:nb]), torch.from_numpy(g[:nb])
+        with torch.no_grad():
             ps, _, _ = FO.decoder(st, n_flows, tz, tg, "direct", n_layers=args.layers)
-            out = np.ascontiguousarray(ps[-1].numpy().transpose(0, 2, 1))
-            d1, _, d2, _ = S.nndistance(out, tgt_pm)
-            _ = d1.mean(1) + d2.mean(1)
+        out = np.ascontiguousarray(ps[-1].numpy().transpose(0, 2, 1))
+        d1, _, d2, _ = S.nndistance(out, tgt_pm[:nb])
+        return d1.mean(1) + d2.mean(1)
+    run(1)                                       # warm-up
+    t0 = time.perf_counter(); run(2); t2 = time.perf_counter() - t0          # calibration on 2 clouds
+    nb = int(max(2, min(args.batch, budget_s / max(t2 / 2, 1e-6))))
+    reps, done, t0 = 0, 0, time.perf_counter()
+    while True:
+        run(nb)
+        reps += 1; done += nb
         dt = time.perf_counter() - t0
-    pts = args.cpu_reps * args.batch * args.points
-    return {"value": pts / dt, "unit": "points/s", "cores": ncores, "kind": "port",
-            "sample": "%d x full workload (B=%d N=%d L=%d): torch-CPU fp32 flow oracle on %d threads + "
-                      "single-thread C Chamfer oracle, %.1f s" % (args.cpu_reps, args.batch, args.points, args.layers,
-                                                                   ncores, dt)}
+        if dt > budget_s or reps >= 50:
+            break
+    return {"value": done * args.points / dt, "unit": "points/s", "cores": ncores, "kind": "port",
+            "sample": "%d x %d clouds of the workload (N=%d, L=%d): torch-CPU fp32 flow oracle on %d threads + "
+                      "single-thread C Chamfer oracle, %.1f s" % (reps, nb, args.points, args.layers, ncores, dt)}
 
 
 def main():

@@ -21,10 +21,10 @@ SIGNATURES = {
     "dpf_matchcost": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dpf_matchcostgrad": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dpf_flow_canon_floats": (_sz, [_i]),
-    "dpf_flow_packed_bytes": (_sz, [_i, _i]),
+    "dpf_flow_packed_bytes": (_sz, [_i, _i, _i]),
     "dpf_flow_film_floats": (_sz, [_i, _i]),
     "dpf_flow_pack": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
-    "dpf_flow_film": (_i, [_i, _i, _i, _vp, _vp, _vp, _f, _vp]),
+    "dpf_flow_film": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _f, _vp]),
     "dpf_flow_forward": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp]),
     "dpf_chamfer_reduce": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "dpf_version": (ctypes.c_char_p, []),

@@ -39,6 +39,7 @@
 // streamed with global_load_lds while the current layer computes).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "dpf_hip.h"
 
@@ -77,6 +78,19 @@ __device__ __forceinline__ float u2f(uint32_t x) { return __builtin_bit_cast(flo
 __device__ __forceinline__ uint32_t bf16_rne(float x) {   // top-16 bits, round to nearest even
     const uint32_t u = f2u(x);
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// relu on the bit pattern: one v_max_i32 (fmaxf would add a canonicalising v_max per MFMA output)
+__device__ __forceinline__ float relu(float x) { return u2f((uint32_t)max((int)f2u(x), 0)); }
+// {bf16(a), bf16(b)} round-to-nearest-even in one v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t pack_bf16_rne(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+// {top16(a), top16(b)} (truncation) in one v_perm_b32
+__device__ __forceinline__ uint32_t pack_bf16_trunc(float a, float b) {
+    return __builtin_amdgcn_perm(f2u(b), f2u(a), 0x07060302u);
 }
 // truncation split: x = hi + rest exactly, hi has 8 significant bits
 __device__ __forceinline__ uint32_t split_hi(float x, float &rest) {
@@ -153,89 +167,112 @@ __global__ __launch_bounds__(256) void pack_kernel(int G, const float *__restric
 // ===========================================================================
 // FiLM conditioner
 // ===========================================================================
-constexpr int FILM_CLOUDS = 16;   // clouds per workgroup
+// fp32 conditioner weights, transposed at pack time so that the 64 output features are the
+// contiguous (lane) dimension: per (layer, branch, sub-net w|b):
+//   WT[G][64] | sc[64] sh[64] (eval BatchNorm folded: u*sc + sh) | W1T[64][64] | bf1[64]
+// and per (layer, branch): s1[64] t1[64] (BN1, affine=False) w2a[64] w2b[64] (output SharedDot rows).
+__host__ __device__ constexpr int fw_sub_floats(int G) { return 64 * G + 128 + 4096 + 64; }
+__host__ __device__ constexpr size_t fw_total_floats(int L, int G) { return (size_t)L * 4 * fw_sub_floats(G) + (size_t)L * 2 * 256; }
 
-__global__ __launch_bounds__(256) void film_kernel(int B, int G, const float *__restrict__ canon,
+__global__ __launch_bounds__(256) void pack_film_kernel(int L, int G, const float *__restrict__ canon, float *__restrict__ fw) {
+    const int l = blockIdx.x >> 2, br = (blockIdx.x >> 1) & 1, sub = blockIdx.x & 1;
+    const float *cb = canon + (size_t)l * c_layer_floats(G) + br * c_branch_floats(G);
+    const float *cf = cb + C_FILM + sub * c_film_floats(G);
+    const float *Wf0 = cf, *bnf = cf + 64 * G, *Wf1 = bnf + 256, *bf1 = Wf1 + 4096;
+    float *o = fw + (size_t)blockIdx.x * fw_sub_floats(G);
+    for (int idx = threadIdx.x; idx < 64 * G; idx += 256) o[idx] = Wf0[(idx & 63) * G + (idx >> 6)];
+    o += 64 * G;
+    if (threadIdx.x < 64) {
+        const int f = threadIdx.x;
+        const float sc = bnf[f] / sqrtf(bnf[192 + f] + BN_EPS);
+        o[f] = sc;
+        o[64 + f] = bnf[64 + f] - bnf[128 + f] * sc;
+        o[128 + 4096 + f] = bf1[f];
+    }
+    for (int idx = threadIdx.x; idx < 4096; idx += 256) o[128 + idx] = Wf1[(idx & 63) * 64 + (idx >> 6)];
+    if (sub == 0 && threadIdx.x < 64) {
+        const int f = threadIdx.x;
+        float *c = fw + (size_t)L * 4 * fw_sub_floats(G) + (size_t)(l * 2 + br) * 256;
+        const float s1 = 1.0f / sqrtf(cb[C_BN1 + 64 + f] + BN_EPS);
+        c[f] = s1;
+        c[64 + f] = -cb[C_BN1 + f] * s1;
+        c[128 + f] = cb[C_W2 + f];
+        c[192 + f] = cb[C_W2 + 64 + f];
+    }
+}
+
+constexpr int FILM_CLOUDS = 16;   // clouds per workgroup: 2 sub-nets x 64 features x 4 groups x 4 clouds = 512 threads
+
+__global__ __launch_bounds__(512) void film_kernel(int L, int B, int G, const float *__restrict__ fw,
                                                    const float *__restrict__ g, float *__restrict__ film, float flow_eps) {
-    __shared__ __attribute__((aligned(16))) float Wt[64][36];
-    __shared__ __attribute__((aligned(16))) float gt[FILM_CLOUDS][32];
-    __shared__ __attribute__((aligned(16))) float hid[FILM_CLOUDS][64];
-    __shared__ __attribute__((aligned(16))) float W1t[64][68];
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    float *gs = fsm;                                  // [16][G]
+    float *hid = fsm + FILM_CLOUDS * G;               // [2][16][64]
+    float *cbx = hid + 2 * FILM_CLOUDS * 64;          // [16][64]
     const int l = blockIdx.x >> 1, br = blockIdx.x & 1;
     const int b0 = blockIdx.y * FILM_CLOUDS;
-    const int tid = threadIdx.x, f = tid & 63, bq = tid >> 6;
-    const float *cb = canon + (size_t)l * c_layer_floats(G) + br * c_branch_floats(G);
-    float cwb[2][4];
-    for (int sub = 0; sub < 2; ++sub) {
-        const float *cf = cb + C_FILM + sub * c_film_floats(G);
-        const float *Wf0 = cf, *bnf = cf + 64 * G, *Wf1 = bnf + 256, *bf1 = Wf1 + 4096;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int g0 = 0; g0 < G; g0 += 32) {
-            for (int e = tid; e < 64 * 8; e += 256) {          // Wf0[0:64][g0:g0+32] -> Wt
-                const int row = e >> 3, c4 = (e & 7) * 4;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (g0 + c4 < G) v = *(const f32x4 *)(Wf0 + (size_t)row * G + g0 + c4);
-                *(f32x4 *)&Wt[row][c4] = v;
-            }
-            if (tid < FILM_CLOUDS * 8) {                       // g[b0:b0+16][g0:g0+32] -> gt
-                const int row = tid >> 3, c4 = (tid & 7) * 4;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (b0 + row < B && g0 + c4 < G) v = *(const f32x4 *)(g + (size_t)(b0 + row) * G + g0 + c4);
-                *(f32x4 *)&gt[row][c4] = v;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int gg = 0; gg < 32; gg += 4) {
-                const f32x4 w = *(const f32x4 *)&Wt[f][gg];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const f32x4 x = *(const f32x4 *)&gt[bq * 4 + c][gg];
-                    acc[c] += w.x * x.x + w.y * x.y + w.z * x.z + w.w * x.w;
-                }
-            }
-            __syncthreads();
-        }
-        // BatchNorm1d over the batch dim, eval mode (flows.py:35/42), then Swish (layers.py:9-10)
-        const float gamma = bnf[f], beta = bnf[64 + f], rm = bnf[128 + f], rv = bnf[192 + f];
-        const float sc = gamma / sqrtf(rv + BN_EPS);
+    const int tid = threadIdx.x, sub = tid >> 8, f = tid & 63, cg = (tid >> 6) & 3;
+    const float *w = fw + (size_t)((l * 2 + br) * 2 + sub) * fw_sub_floats(G);
+    const float *WT = w, *sc = w + 64 * G, *sh = sc + 64, *W1T = sh + 64, *bf1 = W1T + 4096;
+    for (int e = tid; e < FILM_CLOUDS * G / 4; e += 512) {            // g rows of this workgroup's clouds
+        const int row = e / (G / 4), c4 = (e % (G / 4)) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (b0 + row < B) v = *(const f32x4 *)(g + (size_t)(b0 + row) * G + c4);
+        *(f32x4 *)(gs + row * G + c4) = v;
+    }
+    __syncthreads();
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float *g0 = gs + (cg * 4) * G;
+#pragma unroll 4
+    for (int k = 0; k < G; k += 4) {                                  // u = g . Wf0^T        flows.py:34/41
+        const float w0 = WT[(k + 0) * 64 + f], w1 = WT[(k + 1) * 64 + f], w2 = WT[(k + 2) * 64 + f], w3 = WT[(k + 3) * 64 + f];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float u = (acc[c] - rm) * sc + beta;
-            hid[bq * 4 + c][f] = u / (1.0f + expf(-u));
+            const f32x4 x = *(const f32x4 *)(g0 + c * G + k);
+            acc[c] += w0 * x.x + w1 * x.y + w2 * x.z + w3 * x.w;
         }
-        for (int e = tid; e < 64 * 16; e += 256) {             // Wf1 -> W1t
-            const int row = e >> 4, c4 = (e & 15) * 4;
-            *(f32x4 *)&W1t[row][c4] = *(const f32x4 *)(Wf1 + row * 64 + c4);
+    }
+    {   // BatchNorm1d over the batch dim in eval mode (flows.py:35/42), then Swish (layers.py:9-10)
+        const float a = sc[f], d = sh[f];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float u = acc[c] * a + d;
+            hid[(sub * FILM_CLOUDS + cg * 4 + c) * 64 + f] = u / (1.0f + expf(-u));
         }
-        __syncthreads();
-        float v[4];
+    }
+    __syncthreads();
+    float v[4];
+    {
         const float bias = bf1[f];
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = bias;
+        const float *h0 = hid + (sub * FILM_CLOUDS + cg * 4) * 64;
 #pragma unroll 4
-        for (int k = 0; k < 64; k += 4) {
-            const f32x4 w = *(const f32x4 *)&W1t[f][k];
+        for (int k = 0; k < 64; k += 4) {                             // Linear(F, F) + bias   flows.py:37/44
+            const float w0 = W1T[(k + 0) * 64 + f], w1 = W1T[(k + 1) * 64 + f], w2 = W1T[(k + 2) * 64 + f], w3 = W1T[(k + 3) * 64 + f];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const f32x4 x = *(const f32x4 *)&hid[bq * 4 + c][k];
-                v[c] += w.x * x.x + w.y * x.y + w.z * x.z + w.w * x.w;
+                const f32x4 x = *(const f32x4 *)(h0 + c * 64 + k);
+                v[c] += w0 * x.x + w1 * x.y + w2 * x.z + w3 * x.w;
             }
         }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) cwb[sub][c] = v[c];
-        __syncthreads();
     }
+    if (sub == 1) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cbx[(cg * 4 + c) * 64 + f] = v[c];
+    }
+    __syncthreads();
+    if (sub == 1) return;
     // fold FiLM (flows.py:100-101) with BN1 (affine=False, :30/65) and the output SharedDot (:49/84):
     //   relu((eps+e^cw) * BN1(h1) + cb) = FA * relu(h1 + FC/FA),  FA = (eps+e^cw)/sqrt(rv1+eps_bn) > 0
-    const float s1 = 1.0f / sqrtf(cb[C_BN1 + 64 + f] + BN_EPS);
-    const float t1 = -cb[C_BN1 + f] * s1;
-    const float w2a = cb[C_W2 + f], w2b = cb[C_W2 + 64 + f];
+    const float *cst = fw + (size_t)L * 4 * fw_sub_floats(G) + (size_t)(l * 2 + br) * 256;
+    const float s1 = cst[f], t1 = cst[64 + f], w2a = cst[128 + f], w2b = cst[192 + f];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const int b = b0 + bq * 4 + c;
+        const int b = b0 + cg * 4 + c;
         if (b >= B) continue;
-        const float a = flow_eps + expf(cwb[0][c]);
-        const float FA = a * s1, FC = a * t1 + cwb[1][c];
+        const float a = flow_eps + expf(v[c]);
+        const float FA = a * s1, FC = a * t1 + cbx[(cg * 4 + c) * 64 + f];
         float *o = film + ((size_t)l * B + b) * (FILM_BYTES / 4) + br * FILM_BR_FLOATS;
         o[f] = FC / FA;
         o[64 + 2 * f] = w2a * FA;
@@ -257,15 +294,13 @@ struct FlowArgs {
 };
 
 constexpr int TILE = 32;          // points per wave (one MFMA N tile)
-constexpr int FW = 4;             // waves per workgroup
-constexpr int BLOCK_PTS = TILE * FW;
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
 
 // Stream one layer (packed weights + this cloud's FiLM vectors) into an LDS
 // buffer: 1 KiB per wave-instruction, straight to LDS (no VGPR staging).
-template <int NS>
+template <int NS, int FW>
 __device__ __forceinline__ void stage_layer(const FlowArgs &a, int li, int bi, uint8_t *lds, int wave, int lane) {
     constexpr int NP = p_layer_bytes(NS) / 1024, NC = NP + FILM_BYTES / 1024;
     const uint8_t *wsrc = a.packed + (size_t)li * p_layer_bytes(NS);
@@ -293,8 +328,11 @@ template <> struct Terms<3> {
     static constexpr int A[6] = {1, 2, 0, 1, 0, 0}, B[6] = {1, 0, 2, 0, 1, 0};
 };
 
-template <int NS>
-__global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
+// FW = waves per workgroup (each wave one 32-point tile).  Every workgroup streams the
+// layer weights through its own LDS, so larger workgroups halve the L2->LDS traffic per point.
+template <int NS, int FW>
+__global__ __launch_bounds__(FW * 64, FW == 4 ? 2 : 2) void flow_kernel(FlowArgs a) {
+    constexpr int BLOCK_PTS = TILE * FW;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int LBYTES = p_layer_bytes(NS) + FILM_BYTES;
     constexpr int A0OFF = p_a0_off(NS), MISCOFF = p_misc_off(NS), FILMOFF = p_layer_bytes(NS);
@@ -314,13 +352,13 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
     const bool inverse = a.mode == DPF_MODE_INVERSE;
     const size_t list_stride = (size_t)a.B * 3 * N;
 
-    stage_layer<NS>(a, inverse ? L - 1 : 0, bi, smem, wave, lane);
+    stage_layer<NS, FW>(a, inverse ? L - 1 : 0, bi, smem, wave, lane);
     __syncthreads();
 
     for (int step = 0; step < L; ++step) {
         const int li = inverse ? L - 1 - step : step;
         const uint8_t *lb = smem + (step & 1) * LBYTES;
-        if (step + 1 < L) stage_layer<NS>(a, inverse ? li - 1 : li + 1, bi, smem + ((step + 1) & 1) * LBYTES, wave, lane);
+        if (step + 1 < L) stage_layer<NS, FW>(a, inverse ? li - 1 : li + 1, bi, smem + ((step + 1) & 1) * LBYTES, wave, lane);
 
         const int ka = a.meta[li * 4 + 0], kb = a.meta[li * 4 + 1], wa = a.meta[li * 4 + 2], wb = a.meta[li * 4 + 3];
         // ---- B operand of the input MFMA: 3-way bf16 split of this half's input channel
@@ -348,22 +386,22 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
                 // relu + bf16 split; accumulator register r of tile t is element j = r&7 of k-step 2t + (r>>3)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    const float v0 = fmaxf(acc0[r], 0.f), v1 = fmaxf(acc0[r + 1], 0.f);
+                    const float v0 = relu(acc0[r]), v1 = relu(acc0[r + 1]);
                     const int s = 2 * t + (r >> 3), d = (r & 7) >> 1;
                     if (NS == 1) {
-                        bfrag[0][s][d] = bf16_rne(v0) | (bf16_rne(v1) << 16);
+                        bfrag[0][s][d] = pack_bf16_rne(v0, v1);
                     } else if (NS == 2) {
                         float l0, l1;
-                        const uint32_t h0 = split_hi(v0, l0), h1 = split_hi(v1, l1);
-                        bfrag[0][s][d] = (h0 >> 16) | h1;
-                        bfrag[1][s][d] = bf16_rne(l0) | (bf16_rne(l1) << 16);
+                        split_hi(v0, l0); split_hi(v1, l1);
+                        bfrag[0][s][d] = pack_bf16_trunc(v0, v1);
+                        bfrag[1][s][d] = pack_bf16_rne(l0, l1);
                     } else {
                         float l0, l1, m0, m1;
-                        const uint32_t h0 = split_hi(v0, l0), h1 = split_hi(v1, l1);
-                        const uint32_t g0 = split_hi(l0, m0), g1 = split_hi(l1, m1);
-                        bfrag[0][s][d] = (h0 >> 16) | h1;
-                        bfrag[1][s][d] = (g0 >> 16) | g1;
-                        bfrag[2][s][d] = bf16_rne(m0) | (bf16_rne(m1) << 16);
+                        split_hi(v0, l0); split_hi(v1, l1);
+                        split_hi(l0, m0); split_hi(l1, m1);
+                        bfrag[0][s][d] = pack_bf16_trunc(v0, v1);
+                        bfrag[1][s][d] = pack_bf16_trunc(l0, l1);
+                        bfrag[2][s][d] = pack_bf16_rne(m0, m1);
                     }
                 }
             }
@@ -397,8 +435,8 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
                     const int f0 = 32 * tp + 8 * q + 4 * h;
                     const f32x4 w01 = *(const f32x4 *)(wab + 2 * f0);
                     const f32x4 w23 = *(const f32x4 *)(wab + 2 * f0 + 4);
-                    const float v0 = fmaxf(acc1[tp][4 * q + 0], 0.f), v1 = fmaxf(acc1[tp][4 * q + 1], 0.f);
-                    const float v2 = fmaxf(acc1[tp][4 * q + 2], 0.f), v3 = fmaxf(acc1[tp][4 * q + 3], 0.f);
+                    const float v0 = relu(acc1[tp][4 * q + 0]), v1 = relu(acc1[tp][4 * q + 1]);
+                    const float v2 = relu(acc1[tp][4 * q + 2]), v3 = relu(acc1[tp][4 * q + 3]);
                     oa += w01.x * v0; ob += w01.y * v0;
                     oa += w01.z * v1; ob += w01.w * v1;
                     oa += w23.x * v2; ob += w23.y * v2;
@@ -464,9 +502,9 @@ int ns_of(int precision) {
 
 extern "C" size_t dpf_flow_canon_floats(int G) { return (size_t)c_layer_floats(G); }
 
-extern "C" size_t dpf_flow_packed_bytes(int n_layers, int precision) {
+extern "C" size_t dpf_flow_packed_bytes(int n_layers, int G, int precision) {
     const int ns = ns_of(precision);
-    return ns ? (size_t)n_layers * p_layer_bytes(ns) : 0;
+    return ns ? (size_t)n_layers * p_layer_bytes(ns) + fw_total_floats(n_layers, G) * sizeof(float) : 0;
 }
 
 extern "C" size_t dpf_flow_film_floats(int n_layers, int B) { return (size_t)n_layers * B * (FILM_BYTES / 4); }
@@ -482,17 +520,28 @@ extern "C" int dpf_flow_pack(int n_layers, int G, int precision, const float *ca
     if (ns == 1) hipLaunchKernelGGL(pack_kernel<1>, dim3(n_layers), dim3(256), 0, s, G, canon, (uint8_t *)packed);
     if (ns == 2) hipLaunchKernelGGL(pack_kernel<2>, dim3(n_layers), dim3(256), 0, s, G, canon, (uint8_t *)packed);
     if (ns == 3) hipLaunchKernelGGL(pack_kernel<3>, dim3(n_layers), dim3(256), 0, s, G, canon, (uint8_t *)packed);
+    float *fw = (float *)((uint8_t *)packed + (size_t)n_layers * p_layer_bytes(ns));
+    hipLaunchKernelGGL(pack_film_kernel, dim3(n_layers * 4), dim3(256), 0, s, n_layers, G, canon, fw);
     return (int)hipGetLastError();
 }
 
-extern "C" int dpf_flow_film(int n_layers, int B, int G, const float *canon, const float *g, float *film,
-                             float flow_eps, dpf_stream_t stream) {
-    if (n_layers < 0 || B < 0 || G <= 0) return DPF_EINVAL;
+extern "C" int dpf_flow_film(int n_layers, int B, int G, int precision, const void *packed, const float *g,
+                             float *film, float flow_eps, dpf_stream_t stream) {
+    const int ns = ns_of(precision);
+    if (!ns || n_layers < 0 || B < 0 || G <= 0) return DPF_EINVAL;
     if (n_layers == 0 || B == 0) return 0;
-    if (!canon || !g || !film) return DPF_EINVAL;
-    if (G % 4 != 0) return DPF_ENOSUP;
-    hipLaunchKernelGGL(film_kernel, dim3(n_layers * 2, (B + FILM_CLOUDS - 1) / FILM_CLOUDS), dim3(256), 0,
-                       (hipStream_t)stream, B, G, canon, g, film, flow_eps);
+    if (!packed || !g || !film) return DPF_EINVAL;
+    if (G % 4 != 0 || G > 2048) return DPF_ENOSUP;
+    const float *fw = (const float *)((const uint8_t *)packed + (size_t)n_layers * p_layer_bytes(ns));
+    const int lds = (FILM_CLOUDS * G + 3 * FILM_CLOUDS * 64) * (int)sizeof(float);
+    static int attr_lds = 0;
+    if (lds > 65536 && lds > attr_lds) {
+        hipError_t e = hipFuncSetAttribute((const void *)film_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL(film_kernel, dim3(n_layers * 2, (B + FILM_CLOUDS - 1) / FILM_CLOUDS), dim3(512), lds,
+                       (hipStream_t)stream, n_layers, B, G, fw, g, film, flow_eps);
     return (int)hipGetLastError();
 }
 
@@ -510,23 +559,32 @@ extern "C" int dpf_flow_forward(int n_layers, int B, int N, int mode, int precis
     a.packed = (const uint8_t *)packed; a.meta = meta; a.film = film; a.p_in = p_in;
     a.p_out = p_out; a.p_out_pm = p_out_pointmajor; a.sum_lv = sum_logvar; a.ps = ps; a.mus = mus; a.lvs = logvars;
     a.L = n_layers; a.B = B; a.N = N; a.mode = mode; a.eps = flow_eps;
-    const dim3 grid((N + BLOCK_PTS - 1) / BLOCK_PTS, B), block(FW * 64);
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipSuccess;
-#define DPF_LAUNCH(NSV)                                                                                         \
+    // 8-wave workgroups (256 points) when a cloud is big enough to still give every CU a workgroup
+    static const int force_fw = getenv("DPF_FLOW_WAVES") ? atoi(getenv("DPF_FLOW_WAVES")) : 0;
+    const int fw = force_fw ? force_fw : (((long)B * ((N + 255) / 256) >= 256) ? 8 : 4);
+#define DPF_LAUNCH(NSV, FWV)                                                                                    \
     {                                                                                                           \
         const int lds = 2 * (p_layer_bytes(NSV) + FILM_BYTES);                                                  \
         static bool attr_set = false;                                                                           \
         if (!attr_set) {                                                                                        \
-            e = hipFuncSetAttribute((const void *)flow_kernel<NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            e = hipFuncSetAttribute((const void *)flow_kernel<NSV, FWV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
             if (e != hipSuccess) return (int)e;                                                                 \
             attr_set = true;                                                                                    \
         }                                                                                                       \
-        hipLaunchKernelGGL(flow_kernel<NSV>, grid, block, lds, s, a);                                           \
+        const dim3 grid((N + TILE * FWV - 1) / (TILE * FWV), B), block(FWV * 64);                               \
+        hipLaunchKernelGGL((flow_kernel<NSV, FWV>), grid, block, lds, s, a);                                    \
     }
-    if (ns == 1) DPF_LAUNCH(1)
-    if (ns == 2) DPF_LAUNCH(2)
-    if (ns == 3) DPF_LAUNCH(3)
+    if (fw == 8) {
+        if (ns == 1) DPF_LAUNCH(1, 8)
+        if (ns == 2) DPF_LAUNCH(2, 8)
+        if (ns == 3) DPF_LAUNCH(3, 8)
+    } else {
+        if (ns == 1) DPF_LAUNCH(1, 4)
+        if (ns == 2) DPF_LAUNCH(2, 4)
+        if (ns == 3) DPF_LAUNCH(3, 4)
+    }
 #undef DPF_LAUNCH
     return (int)hipGetLastError();
 }

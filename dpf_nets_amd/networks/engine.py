@@ -78,9 +78,11 @@ class FlowStack:
             self._sentinel_state = s
 
     # -- packing -----------------------------------------------------------------
-    def _ensure(self, precision, device):
+    def _ensure(self, precision, device, L=None):
+        """canon block, meta and the packed weights of the first L layers (default: all)."""
         self._check_fresh()
-        L = len(self.layers)
+        nl = len(self.layers)
+        L = nl if L is None else L
         lyr0 = self.layers[0]
         if lyr0.f_n_features != F:
             raise RuntimeError("dpf_hip flow kernels are built for f_n_features == 64, got %d" % lyr0.f_n_features)
@@ -90,17 +92,18 @@ class FlowStack:
             for lyr in self.layers:
                 pieces += layer_canon_pieces(lyr)
             canon = torch.cat(pieces).to(device=device, dtype=torch.float32).contiguous()
-            assert canon.numel() == L * lib().dpf_flow_canon_floats(G), (canon.numel(), L, G)
+            assert canon.numel() == nl * lib().dpf_flow_canon_floats(G), (canon.numel(), nl, G)
             self._canon = canon
             self._meta = torch.tensor([layer_meta(l) for l in self.layers], dtype=torch.int32, device=device)
             self._packed = {}
-        if precision not in self._packed:
-            nbytes = lib().dpf_flow_packed_bytes(L, PREC[precision])
+        key = (precision, L)
+        if key not in self._packed:
+            nbytes = lib().dpf_flow_packed_bytes(L, G, PREC[precision])
             packed = torch.empty(nbytes, dtype=torch.uint8, device=device)
             check(lib().dpf_flow_pack(L, G, PREC[precision], self._canon.data_ptr(), self._meta.data_ptr(),
                                       packed.data_ptr(), current_stream()), "flow_pack")
-            self._packed[precision] = packed
-        return self._canon, self._meta, self._packed[precision], G
+            self._packed[key] = packed
+        return self._canon, self._meta, self._packed[key], G
 
     # -- run ---------------------------------------------------------------------
     def run(self, p, g, mode, precision=None, want_lists=True, n_layers=None, want_pointmajor=False):
@@ -121,12 +124,12 @@ class FlowStack:
         g = g.contiguous()
         B, _, N = p.shape
         with torch.cuda.device(p.device):
-            canon, meta, packed, G = self._ensure(precision, p.device)
-            if g.shape[1] != G:
-                raise RuntimeError("g has %d features, the layers expect %d" % (g.shape[1], G))
             L = len(self.layers) if n_layers is None else int(n_layers)
             if not 0 < L <= len(self.layers):
                 raise ValueError("n_layers out of range")
+            canon, meta, packed, G = self._ensure(precision, p.device, L)
+            if g.shape[1] != G:
+                raise RuntimeError("g has %d features, the layers expect %d" % (g.shape[1], G))
             dev = p.device
             film = torch.empty(lib().dpf_flow_film_floats(L, B), dtype=torch.float32, device=dev)
             p_out = torch.empty_like(p)
@@ -140,8 +143,8 @@ class FlowStack:
                 lists, lp = None, [None, None, None]
             eps = float(self.layers[0].eps_value)
             stream = current_stream()
-            check(lib().dpf_flow_film(L, B, G, canon.data_ptr(), g.data_ptr(), film.data_ptr(), eps, stream),
-                  "flow_film")
+            check(lib().dpf_flow_film(L, B, G, PREC[precision], packed.data_ptr(), g.data_ptr(), film.data_ptr(), eps,
+                                      stream), "flow_film")
             check(lib().dpf_flow_forward(L, B, N, MODE[mode], PREC[precision], packed.data_ptr(), meta.data_ptr(),
                                          film.data_ptr(), p.data_ptr(), p_out.data_ptr(),
                                          pm.data_ptr() if pm is not None else None, sum_lv.data_ptr(),

@@ -110,18 +110,22 @@ int dpf_chamfer_reduce(int b, int n, int m, const float *dist1, const float *dis
 #define DPF_MODE_INVERSE 1 /* p_out = (p-mu)/sqrt(eps+exp(logvar))     flows.py:115 */
 
 size_t dpf_flow_canon_floats(int G);
-size_t dpf_flow_packed_bytes(int n_layers, int precision);
+size_t dpf_flow_packed_bytes(int n_layers, int G, int precision);
 size_t dpf_flow_film_floats(int n_layers, int B);
 
-/* canonical fp32 weights -> MFMA-fragment-ordered bf16 parts with BatchNorm
- * folded.  Run once per weight version (not per batch). */
+/* canonical fp32 weights -> `packed`: MFMA-fragment-ordered bf16 parts with
+ * BatchNorm folded (dpf_flow_forward), followed by the transposed fp32
+ * conditioner weights (dpf_flow_film).  Run once per weight version (not per
+ * batch).  The film weights of the n_layers-layer prefix of a longer packed
+ * buffer are NOT at the prefix's offset: pack a stack with the n_layers it
+ * will be run with. */
 int dpf_flow_pack(int n_layers, int G, int precision, const float *canon,
                   const int *meta, void *packed, dpf_stream_t stream);
 
 /* per-cloud FiLM conditioner (flows.py:33-45,68-80,100-101,105-106) for every
  * layer at once: g (B, G) -> film (dpf_flow_film_floats floats). */
-int dpf_flow_film(int n_layers, int B, int G, const float *canon, const float *g,
-                  float *film, float flow_eps, dpf_stream_t stream);
+int dpf_flow_film(int n_layers, int B, int G, int precision, const void *packed,
+                  const float *g, float *film, float flow_eps, dpf_stream_t stream);
 
 /* The fused L-layer stack.  p_in / p_out / sum_logvar: (B, 3, N) fp32
  * channel-major as the networks use (flows.py:95).  Optional per-layer lists
