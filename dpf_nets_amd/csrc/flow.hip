@@ -68,10 +68,10 @@ __host__ __device__ constexpr int c_layer_floats(int G) { return 2 * c_branch_fl
 // ---- packed layout ----------------------------------------------------------
 constexpr int P_A1_PART = 16384;                       // [br2][t2][s4][lane64][8 bf16]
 __host__ __device__ constexpr int p_a0_off(int NS) { return NS * P_A1_PART; }            // [br2][t2][lane64][8 bf16]
-__host__ __device__ constexpr int p_misc_off(int NS) { return NS * P_A1_PART + 4096; }   // b2[br][2] floats
-__host__ __device__ constexpr int p_layer_bytes(int NS) { return NS * P_A1_PART + 5120; }
-constexpr int FILM_BYTES = 2048;                       // per (layer, cloud): [br2]{D[64], Wab[64][2]} + pad
+__host__ __device__ constexpr int p_layer_bytes(int NS) { return NS * P_A1_PART + 4096; }
+constexpr int FILM_BYTES = 2048;                       // per (layer, cloud): [br2]{D[64], Wab[64][2]}, b2[br2][2], pad
 constexpr int FILM_BR_FLOATS = 192;
+constexpr int FILM_B2_OFF = 384;                       // floats
 
 __device__ __forceinline__ uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
 __device__ __forceinline__ float u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
@@ -156,12 +156,6 @@ __global__ __launch_bounds__(256) void pack_kernel(int G, const float *__restric
         }
         a0[idx] = (uint16_t)v;
     }
-    float *misc = (float *)(out + p_misc_off(NS));
-    for (int idx = threadIdx.x; idx < 256; idx += blockDim.x) {
-        float v = 0.f;
-        if (idx < 4) v = cl[(idx >> 1) * c_branch_floats(G) + C_B2 + (idx & 1)];
-        misc[idx] = v;
-    }
 }
 
 // ===========================================================================
@@ -172,7 +166,7 @@ __global__ __launch_bounds__(256) void pack_kernel(int G, const float *__restric
 //   WT[G][64] | sc[64] sh[64] (eval BatchNorm folded: u*sc + sh) | W1T[64][64] | bf1[64]
 // and per (layer, branch): s1[64] t1[64] (BN1, affine=False) w2a[64] w2b[64] (output SharedDot rows).
 __host__ __device__ constexpr int fw_sub_floats(int G) { return 64 * G + 128 + 4096 + 64; }
-__host__ __device__ constexpr size_t fw_total_floats(int L, int G) { return (size_t)L * 4 * fw_sub_floats(G) + (size_t)L * 2 * 256; }
+__host__ __device__ constexpr size_t fw_total_floats(int L, int G) { return (size_t)L * 4 * fw_sub_floats(G) + (size_t)L * 2 * 320; }
 
 __global__ __launch_bounds__(256) void pack_film_kernel(int L, int G, const float *__restrict__ canon, float *__restrict__ fw) {
     const int l = blockIdx.x >> 2, br = (blockIdx.x >> 1) & 1, sub = blockIdx.x & 1;
@@ -192,12 +186,13 @@ __global__ __launch_bounds__(256) void pack_film_kernel(int L, int G, const floa
     for (int idx = threadIdx.x; idx < 4096; idx += 256) o[128 + idx] = Wf1[(idx & 63) * 64 + (idx >> 6)];
     if (sub == 0 && threadIdx.x < 64) {
         const int f = threadIdx.x;
-        float *c = fw + (size_t)L * 4 * fw_sub_floats(G) + (size_t)(l * 2 + br) * 256;
+        float *c = fw + (size_t)L * 4 * fw_sub_floats(G) + (size_t)(l * 2 + br) * 320;
         const float s1 = 1.0f / sqrtf(cb[C_BN1 + 64 + f] + BN_EPS);
         c[f] = s1;
         c[64 + f] = -cb[C_BN1 + f] * s1;
         c[128 + f] = cb[C_W2 + f];
         c[192 + f] = cb[C_W2 + 64 + f];
+        if (f < 2) c[256 + f] = cb[C_B2 + f];
     }
 }
 
@@ -265,7 +260,7 @@ __global__ __launch_bounds__(512) void film_kernel(int L, int B, int G, const fl
     if (sub == 1) return;
     // fold FiLM (flows.py:100-101) with BN1 (affine=False, :30/65) and the output SharedDot (:49/84):
     //   relu((eps+e^cw) * BN1(h1) + cb) = FA * relu(h1 + FC/FA),  FA = (eps+e^cw)/sqrt(rv1+eps_bn) > 0
-    const float *cst = fw + (size_t)L * 4 * fw_sub_floats(G) + (size_t)(l * 2 + br) * 256;
+    const float *cst = fw + (size_t)L * 4 * fw_sub_floats(G) + (size_t)(l * 2 + br) * 320;
     const float s1 = cst[f], t1 = cst[64 + f], w2a = cst[128 + f], w2b = cst[192 + f];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -277,6 +272,7 @@ __global__ __launch_bounds__(512) void film_kernel(int L, int B, int G, const fl
         o[f] = FC / FA;
         o[64 + 2 * f] = w2a * FA;
         o[64 + 2 * f + 1] = w2b * FA;
+        if (f < 2) film[((size_t)l * B + b) * (FILM_BYTES / 4) + FILM_B2_OFF + br * 2 + f] = cst[256 + f];
     }
 }
 
@@ -293,7 +289,7 @@ struct FlowArgs {
     float eps;
 };
 
-constexpr int TILE = 32;          // points per wave (one MFMA N tile)
+constexpr int TILE = 32;          // points per tile (one MFMA N tile)
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
@@ -328,22 +324,102 @@ template <> struct Terms<3> {
     static constexpr int A[6] = {1, 2, 0, 1, 0, 0}, B[6] = {1, 0, 2, 0, 1, 0};
 };
 
-// FW = waves per workgroup (each wave one 32-point tile).  Every workgroup streams the
-// layer weights through its own LDS, so larger workgroups halve the L2->LDS traffic per point.
+// One conditioner branch (logvar or mu) of one layer for one 32-point tile:
+// returns the two pre-activation outputs o_a, o_b of the branch (sum over this
+// lane-half's 32 features; the caller adds the other half).
+template <int NS, bool TWO>
+__device__ __forceinline__ void branch_tile(const uint8_t *lb, int br, int lane, int h, u32x4 b0, float &oa, float &ob) {
+    constexpr int A0OFF = p_a0_off(NS), FILMOFF = p_layer_bytes(NS);
+    typedef Terms<NS> TT;
+    // ---- h0 = relu(BN0(W0 x)) on the matrix core, fp32-accurate
+    u32x4 bfrag[NS][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const u32x4 a0 = *(const u32x4 *)(lb + A0OFF + ((br * 2 + t) * 64 + lane) * 16);
+        f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc0 = mfma(a0, b0, acc0);
+        // relu + bf16 split; accumulator register r of tile t is element j = r&7 of k-step 2t + (r>>3)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const float v0 = relu(acc0[r]), v1 = relu(acc0[r + 1]);
+            const int s = 2 * t + (r >> 3), d = (r & 7) >> 1;
+            if (NS == 1) {
+                bfrag[0][s][d] = pack_bf16_rne(v0, v1);
+            } else if (NS == 2) {
+                float l0, l1;
+                split_hi(v0, l0); split_hi(v1, l1);
+                bfrag[0][s][d] = pack_bf16_trunc(v0, v1);
+                bfrag[1][s][d] = pack_bf16_rne(l0, l1);
+            } else {
+                float l0, l1, m0, m1;
+                split_hi(v0, l0); split_hi(v1, l1);
+                split_hi(l0, m0); split_hi(l1, m1);
+                bfrag[0][s][d] = pack_bf16_trunc(v0, v1);
+                bfrag[1][s][d] = pack_bf16_trunc(l0, l1);
+                bfrag[2][s][d] = pack_bf16_rne(m0, m1);
+            }
+        }
+    }
+    // ---- h1 = W1 h0, accumulator pre-loaded with the folded FiLM shift D
+    const float *fl = (const float *)(lb + FILMOFF) + br * FILM_BR_FLOATS;
+    f32x16 acc1[2];
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 dv = *(const f32x4 *)(fl + 32 * tp + 8 * q + 4 * h);
+            acc1[tp][4 * q + 0] = dv.x; acc1[tp][4 * q + 1] = dv.y;
+            acc1[tp][4 * q + 2] = dv.z; acc1[tp][4 * q + 3] = dv.w;
+        }
+#pragma unroll
+    for (int term = 0; term < TT::N; ++term)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp) {
+                const u32x4 a1 = *(const u32x4 *)(lb + TT::A[term] * P_A1_PART + (((br * 2 + tp) * 4 + s) * 64 + lane) * 16);
+                acc1[tp] = mfma(a1, bfrag[TT::B[term]][s], acc1[tp]);
+            }
+    // ---- o = W2' relu(h1 + D): each lane reduces its 32 features
+    oa = 0.f; ob = 0.f;
+    const float *wab = fl + 64;
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int f0 = 32 * tp + 8 * q + 4 * h;
+            const f32x4 w01 = *(const f32x4 *)(wab + 2 * f0);
+            const f32x4 w23 = *(const f32x4 *)(wab + 2 * f0 + 4);
+            const float v0 = relu(acc1[tp][4 * q + 0]), v1 = relu(acc1[tp][4 * q + 1]);
+            const float v2 = relu(acc1[tp][4 * q + 2]), v3 = relu(acc1[tp][4 * q + 3]);
+            oa += w01.x * v0; oa += w01.z * v1; oa += w23.x * v2; oa += w23.z * v3;
+            if (TWO) { ob += w01.y * v0; ob += w01.w * v1; ob += w23.y * v2; ob += w23.w * v3; }
+        }
+}
+
+__device__ __forceinline__ float half_sum(float x) {   // x(lane) + x(lane ^ 32)
+    const auto r = __builtin_amdgcn_permlane32_swap(f2u(x), f2u(x), false, false);
+    return u2f(r[0]) + u2f(r[1]);
+}
+
+// The fused L-layer stack.  FW waves per workgroup = FW/2 tiles of 32 points of ONE cloud; the
+// two waves of a tile each run one conditioner branch (even wave: logvar, odd wave: mu) and
+// swap their two outputs per point through LDS at the layer's single barrier -- twice the waves
+// per SIMD for latency hiding at the price of duplicating the (cheap) per-point transform.
 template <int NS, int FW>
-__global__ __launch_bounds__(FW * 64, FW == 4 ? 2 : 2) void flow_kernel(FlowArgs a) {
-    constexpr int BLOCK_PTS = TILE * FW;
+__global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int LBYTES = p_layer_bytes(NS) + FILM_BYTES;
-    constexpr int A0OFF = p_a0_off(NS), MISCOFF = p_misc_off(NS), FILMOFF = p_layer_bytes(NS);
-    typedef Terms<NS> TT;                    // product terms (A part, B part), smallest magnitude first
-    constexpr int NT = TT::N;
+    constexpr int FILMOFF = p_layer_bytes(NS);
+    constexpr int TPB = FW / 2;                       // tiles per workgroup
+    float *xch = (float *)(smem + 2 * LBYTES);        // [parity 2][tile TPB][4][32]
 
     const int bi = blockIdx.y;
-    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int lane = threadIdx.x & 63, h = lane >> 5, pl = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = wave >> 1, br = wave & 1;
     const int N = a.N, L = a.L;
-    const int n = blockIdx.x * BLOCK_PTS + wave * TILE + (lane & 31);
+    const int n = (blockIdx.x * TPB + tile) * TILE + pl;
     const bool valid = n < N;
     const int nc = valid ? n : N - 1;
     const size_t cloud = (size_t)bi * 3 * N;
@@ -373,123 +449,58 @@ __global__ __launch_bounds__(FW * 64, FW == 4 ? 2 : 2) void flow_kernel(FlowArgs
         b0.z = (xm >> 16) | xh;            // e4 = xm, e5 = xh
         b0.w = h ? 0x00003F80u : 0x3F803F80u;   // e6 = 1, e7 = (h == 0)
 
-        float o[2][2];
-#pragma unroll
-        for (int br = 0; br < 2; ++br) {
-            // ---- h0 = relu(BN0(W0 x)) on the matrix core, fp32-accurate
-            u32x4 bfrag[NS][4];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const u32x4 a0 = *(const u32x4 *)(lb + A0OFF + ((br * 2 + t) * 64 + lane) * 16);
-                f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                acc0 = mfma(a0, b0, acc0);
-                // relu + bf16 split; accumulator register r of tile t is element j = r&7 of k-step 2t + (r>>3)
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const float v0 = relu(acc0[r]), v1 = relu(acc0[r + 1]);
-                    const int s = 2 * t + (r >> 3), d = (r & 7) >> 1;
-                    if (NS == 1) {
-                        bfrag[0][s][d] = pack_bf16_rne(v0, v1);
-                    } else if (NS == 2) {
-                        float l0, l1;
-                        split_hi(v0, l0); split_hi(v1, l1);
-                        bfrag[0][s][d] = pack_bf16_trunc(v0, v1);
-                        bfrag[1][s][d] = pack_bf16_rne(l0, l1);
-                    } else {
-                        float l0, l1, m0, m1;
-                        split_hi(v0, l0); split_hi(v1, l1);
-                        split_hi(l0, m0); split_hi(l1, m1);
-                        bfrag[0][s][d] = pack_bf16_trunc(v0, v1);
-                        bfrag[1][s][d] = pack_bf16_trunc(l0, l1);
-                        bfrag[2][s][d] = pack_bf16_rne(m0, m1);
-                    }
-                }
-            }
-            // ---- h1 = W1 h0, accumulator pre-loaded with the folded FiLM shift D
-            const float *fl = (const float *)(lb + FILMOFF) + br * FILM_BR_FLOATS;
-            f32x16 acc1[2];
-#pragma unroll
-            for (int tp = 0; tp < 2; ++tp)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 dv = *(const f32x4 *)(fl + 32 * tp + 8 * q + 4 * h);
-                    acc1[tp][4 * q + 0] = dv.x; acc1[tp][4 * q + 1] = dv.y;
-                    acc1[tp][4 * q + 2] = dv.z; acc1[tp][4 * q + 3] = dv.w;
-                }
-#pragma unroll
-            for (int term = 0; term < NT; ++term)
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int tp = 0; tp < 2; ++tp) {
-                        const u32x4 a1 = *(const u32x4 *)(lb + TT::A[term] * P_A1_PART + (((br * 2 + tp) * 4 + s) * 64 + lane) * 16);
-                        acc1[tp] = mfma(a1, bfrag[TT::B[term]][s], acc1[tp]);
-                    }
-            // ---- o = W2' relu(h1 + D): each lane reduces its 32 features, halves swap-add
-            float oa = 0.f, ob = 0.f;
-            const float *wab = fl + 64;
-#pragma unroll
-            for (int tp = 0; tp < 2; ++tp)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int f0 = 32 * tp + 8 * q + 4 * h;
-                    const f32x4 w01 = *(const f32x4 *)(wab + 2 * f0);
-                    const f32x4 w23 = *(const f32x4 *)(wab + 2 * f0 + 4);
-                    const float v0 = relu(acc1[tp][4 * q + 0]), v1 = relu(acc1[tp][4 * q + 1]);
-                    const float v2 = relu(acc1[tp][4 * q + 2]), v3 = relu(acc1[tp][4 * q + 3]);
-                    oa += w01.x * v0; ob += w01.y * v0;
-                    oa += w01.z * v1; ob += w01.w * v1;
-                    oa += w23.x * v2; ob += w23.y * v2;
-                    oa += w23.z * v3; ob += w23.w * v3;
-                }
-            {
-                const auto ra = __builtin_amdgcn_permlane32_swap(f2u(oa), f2u(oa), false, false);
-                const auto rb = __builtin_amdgcn_permlane32_swap(f2u(ob), f2u(ob), false, false);
-                oa = u2f(ra[0]) + u2f(ra[1]);
-                ob = u2f(rb[0]) + u2f(rb[1]);
-            }
-            const float *b2 = (const float *)(lb + MISCOFF);
-            o[br][0] = oa + b2[br * 2 + 0];
-            o[br][1] = ob + b2[br * 2 + 1];
+        float oa, ob;
+        if (wb < 0) branch_tile<NS, false>(lb, br, lane, h, b0, oa, ob);   // layer warps one channel
+        else        branch_tile<NS, true>(lb, br, lane, h, b0, oa, ob);
+        const float *b2 = (const float *)(lb + FILMOFF) + FILM_B2_OFF;
+        oa = half_sum(oa) + b2[br * 2 + 0];
+        ob = half_sum(ob) + b2[br * 2 + 1];
+        if (br == 0) {                                                        // softsign, flows.py:99
+            oa = oa * __builtin_amdgcn_rcpf(1.0f + fabsf(oa));
+            ob = ob * __builtin_amdgcn_rcpf(1.0f + fabsf(ob));
         }
-        // ---- coupling transform (flows.py:96-115); branch 0 = logvar, 1 = mu
-        const float lva = o[0][0] * __builtin_amdgcn_rcpf(1.0f + fabsf(o[0][0]));   // softsign, :99
-        const float lvb = o[0][1] * __builtin_amdgcn_rcpf(1.0f + fabsf(o[0][1]));
+        // ---- swap branch outputs with the partner wave at the layer's barrier
+        float *xw = xch + (((step & 1) * TPB + tile) * 4 + br * 2) * 32;
+        if (!h) { xw[pl] = oa; xw[32 + pl] = ob; }
+        __syncthreads();   // partner's outputs visible; next layer's weights landed; this buffer is free
+        const float *xr = xch + (((step & 1) * TPB + tile) * 4 + (br ^ 1) * 2) * 32;
+        const float qa = xr[pl], qb = xr[32 + pl];
+        const float lva = br ? qa : oa, lvb = br ? qb : ob, mua = br ? oa : qa, mub = br ? ob : qb;
+        // ---- coupling transform (flows.py:96-115)
         float lv[3], mu[3], pn[3];
         const float pin[3] = {p0, p1, p2};
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             lv[c] = c == wa ? lva : (c == wb ? lvb : 0.f);
-            mu[c] = c == wa ? o[1][0] : (c == wb ? o[1][1] : 0.f);
+            mu[c] = c == wa ? mua : (c == wb ? mub : 0.f);
             const float var = a.eps + __expf(lv[c]);
             // keep channels are scaled by sqrt(1 + eps) too, as in the reference (:113/:115)
             pn[c] = inverse ? (pin[c] - mu[c]) * __builtin_amdgcn_rsqf(var) : __builtin_amdgcn_sqrtf(var) * pin[c] + mu[c];
         }
         p0 = pn[0]; p1 = pn[1]; p2 = pn[2];
         s0 += lv[0]; s1 += lv[1]; s2 += lv[2];
-        if (a.ps != nullptr && valid) {   // per-layer lists in DIRECT order (decoders.py:61-70); halves share the rows
+        if (a.ps != nullptr && valid) {
+            // per-layer lists in DIRECT order (decoders.py:61-70): 9 rows of 32 floats, shared by the
+            // four lane-halves of the tile's two waves
             const size_t base = (size_t)li * list_stride + cloud + n;
-            float *dst[5]; float val[5];
-            dst[0] = (h ? a.mus + base + 2 * (size_t)N : a.ps + base);              val[0] = h ? mu[2] : pn[0];
-            dst[1] = (h ? a.lvs + base : a.ps + base + N);                          val[1] = h ? lv[0] : pn[1];
-            dst[2] = (h ? a.lvs + base + N : a.ps + base + 2 * (size_t)N);          val[2] = h ? lv[1] : pn[2];
-            dst[3] = (h ? a.lvs + base + 2 * (size_t)N : a.mus + base);             val[3] = h ? lv[2] : mu[0];
-            dst[4] = a.mus + base + N;                                             val[4] = mu[1];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) *dst[e] = val[e];
-            if (!h) *dst[4] = val[4];
+            const int who = br * 2 + h;
+            float *d0, *d1, *d2; float v0, v1, v2; bool third = true;
+            if (who == 0)      { d0 = a.ps + base;  v0 = pn[0]; d1 = a.ps + base + N;  v1 = pn[1]; d2 = a.ps + base + 2 * (size_t)N;  v2 = pn[2]; }
+            else if (who == 1) { d0 = a.lvs + base; v0 = lv[0]; d1 = a.lvs + base + N; v1 = lv[1]; d2 = a.lvs + base + 2 * (size_t)N; v2 = lv[2]; }
+            else if (who == 2) { d0 = a.mus + base; v0 = mu[0]; d1 = a.mus + base + N; v1 = mu[1]; d2 = a.mus + base + 2 * (size_t)N; v2 = mu[2]; }
+            else               { d0 = d1 = d2 = nullptr; v0 = v1 = v2 = 0.f; third = false; }
+            if (third) { *d0 = v0; *d1 = v1; *d2 = v2; }
         }
-        __syncthreads();   // next layer's weights have landed; everyone is done with this buffer
     }
     if (valid) {
-        if (!h) {
+        if (br == 0 && !h) {
             a.p_out[cloud + n] = p0; a.p_out[cloud + N + n] = p1; a.p_out[cloud + 2 * (size_t)N + n] = p2;
-            if (a.p_out_pm != nullptr) {   // point-major (B,N,3) copy for the structural losses (evaluating.py:110)
-                float *o = a.p_out_pm + ((size_t)bi * N + n) * 3;
-                o[0] = p0; o[1] = p1; o[2] = p2;
-            }
-        } else if (a.sum_lv != nullptr) {
+        } else if (br == 0 && h && a.sum_lv != nullptr) {
             a.sum_lv[cloud + n] = s0; a.sum_lv[cloud + N + n] = s1; a.sum_lv[cloud + 2 * (size_t)N + n] = s2;
+        } else if (br == 1 && !h && a.p_out_pm != nullptr) {
+            // point-major (B,N,3) copy for the structural losses (evaluating.py:110)
+            float *o = a.p_out_pm + ((size_t)bi * N + n) * 3;
+            o[0] = p0; o[1] = p1; o[2] = p2;
         }
     }
 }
@@ -561,19 +572,19 @@ extern "C" int dpf_flow_forward(int n_layers, int B, int N, int mode, int precis
     a.L = n_layers; a.B = B; a.N = N; a.mode = mode; a.eps = flow_eps;
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipSuccess;
-    // 8-wave workgroups (256 points) when a cloud is big enough to still give every CU a workgroup
+    // 8-wave workgroups: 4 tiles x 2 branch-waves = 128 points of one cloud
     static const int force_fw = getenv("DPF_FLOW_WAVES") ? atoi(getenv("DPF_FLOW_WAVES")) : 0;
-    const int fw = force_fw ? force_fw : (((long)B * ((N + 255) / 256) >= 256) ? 8 : 4);
+    const int fw = force_fw ? force_fw : 8;
 #define DPF_LAUNCH(NSV, FWV)                                                                                    \
     {                                                                                                           \
-        const int lds = 2 * (p_layer_bytes(NSV) + FILM_BYTES);                                                  \
+        const int lds = 2 * (p_layer_bytes(NSV) + FILM_BYTES) + 2 * (FWV / 2) * 4 * 32 * 4;                     \
         static bool attr_set = false;                                                                           \
         if (!attr_set) {                                                                                        \
             e = hipFuncSetAttribute((const void *)flow_kernel<NSV, FWV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
             if (e != hipSuccess) return (int)e;                                                                 \
             attr_set = true;                                                                                    \
         }                                                                                                       \
-        const dim3 grid((N + TILE * FWV - 1) / (TILE * FWV), B), block(FWV * 64);                               \
+        const dim3 grid((N + TILE * (FWV / 2) - 1) / (TILE * (FWV / 2)), B), block(FWV * 64);                   \
         hipLaunchKernelGGL((flow_kernel<NSV, FWV>), grid, block, lds, s, a);                                    \
     }
     if (fw == 8) {

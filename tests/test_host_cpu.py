@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     assert handle.dpf_version().startswith(b"dpf_hip gfx950")
     for G in (128, 512):                                  # size queries are host-only
         assert handle.dpf_flow_canon_floats(G) == 2 * (4740 + 2 * (64 * G + 4416))
-    assert handle.dpf_flow_packed_bytes(14, 128, _lib.PREC["bf16x3"]) == 14 * (2 * 16384 + 5120) + 4 * (14 * 4 * (64 * 128 + 4288) + 14 * 2 * 256)
+    assert handle.dpf_flow_packed_bytes(14, 128, _lib.PREC["bf16x3"]) == 14 * (2 * 16384 + 4096) + 4 * (14 * 4 * (64 * 128 + 4288) + 14 * 2 * 320)
     assert handle.dpf_flow_film_floats(14, 32) == 14 * 32 * 512
 
 
