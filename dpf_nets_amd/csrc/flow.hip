@@ -360,7 +360,10 @@ __device__ __forceinline__ void branch_tile(const uint8_t *lb, int br, int lane,
             }
         }
     }
-    // ---- h1 = W1 h0, accumulator pre-loaded with the folded FiLM shift D
+    // ---- h1 = W1 h0, accumulator pre-loaded with the folded FiLM shift D.
+    // The A fragments stream from LDS in batches of 4 (two k-steps x two M tiles), one batch
+    // ahead of the MFMAs that consume them (hipcc otherwise reuses ONE fragment register and
+    // waits for each ds_read before each MFMA).
     const float *fl = (const float *)(lb + FILMOFF) + br * FILM_BR_FLOATS;
     f32x16 acc1[2];
 #pragma unroll
@@ -371,29 +374,51 @@ __device__ __forceinline__ void branch_tile(const uint8_t *lb, int br, int lane,
             acc1[tp][4 * q + 0] = dv.x; acc1[tp][4 * q + 1] = dv.y;
             acc1[tp][4 * q + 2] = dv.z; acc1[tp][4 * q + 3] = dv.w;
         }
+    constexpr int NB = TT::N * 2;                 // batches: (term, k-step pair)
+    u32x4 af[2][4];
+    auto load_batch = [&](int bt, u32x4 (&dst)[4]) {
+        const int term = bt >> 1, s0 = (bt & 1) * 2;
 #pragma unroll
-    for (int term = 0; term < TT::N; ++term)
+        for (int e = 0; e < 4; ++e) {
+            const int s = s0 + (e >> 1), tp = e & 1;
+            dst[e] = *(const u32x4 *)(lb + TT::A[term] * P_A1_PART + (((br * 2 + tp) * 4 + s) * 64 + lane) * 16);
+        }
+    };
+    load_batch(0, af[0]);
+    const float *wab = fl + 64;
+    f32x4 w01[2][4], w23[2][4];                    // epilogue weights, one M tile at a time
+    auto load_w = [&](int tp, f32x4 (&d01)[4], f32x4 (&d23)[4]) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int q = 0; q < 4; ++q) {
+            const int f0 = 32 * tp + 8 * q + 4 * h;
+            d01[q] = *(const f32x4 *)(wab + 2 * f0);
+            d23[q] = *(const f32x4 *)(wab + 2 * f0 + 4);
+        }
+    };
 #pragma unroll
-            for (int tp = 0; tp < 2; ++tp) {
-                const u32x4 a1 = *(const u32x4 *)(lb + TT::A[term] * P_A1_PART + (((br * 2 + tp) * 4 + s) * 64 + lane) * 16);
-                acc1[tp] = mfma(a1, bfrag[TT::B[term]][s], acc1[tp]);
-            }
+    for (int bt = 0; bt < NB; ++bt) {
+        if (bt + 1 < NB) load_batch(bt + 1, af[(bt + 1) & 1]);
+        else load_w(0, w01[0], w23[0]);            // rides under the last batch of MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        const int term = bt >> 1, s0 = (bt & 1) * 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int s = s0 + (e >> 1), tp = e & 1;
+            acc1[tp] = mfma(af[bt & 1][e], bfrag[TT::B[term]][s], acc1[tp]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     // ---- o = W2' relu(h1 + D): each lane reduces its 32 features
     oa = 0.f; ob = 0.f;
-    const float *wab = fl + 64;
+    load_w(1, w01[1], w23[1]);
 #pragma unroll
     for (int tp = 0; tp < 2; ++tp)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int f0 = 32 * tp + 8 * q + 4 * h;
-            const f32x4 w01 = *(const f32x4 *)(wab + 2 * f0);
-            const f32x4 w23 = *(const f32x4 *)(wab + 2 * f0 + 4);
             const float v0 = relu(acc1[tp][4 * q + 0]), v1 = relu(acc1[tp][4 * q + 1]);
             const float v2 = relu(acc1[tp][4 * q + 2]), v3 = relu(acc1[tp][4 * q + 3]);
-            oa += w01.x * v0; oa += w01.z * v1; oa += w23.x * v2; oa += w23.z * v3;
-            if (TWO) { ob += w01.y * v0; ob += w01.w * v1; ob += w23.y * v2; ob += w23.w * v3; }
+            oa += w01[tp][q].x * v0; oa += w01[tp][q].z * v1; oa += w23[tp][q].x * v2; oa += w23[tp][q].z * v3;
+            if (TWO) { ob += w01[tp][q].y * v0; ob += w01[tp][q].w * v1; ob += w23[tp][q].y * v2; ob += w23[tp][q].w * v3; }
         }
 }
 
@@ -407,7 +432,7 @@ __device__ __forceinline__ float half_sum(float x) {   // x(lane) + x(lane ^ 32)
 // swap their two outputs per point through LDS at the layer's single barrier -- twice the waves
 // per SIMD for latency hiding at the price of duplicating the (cheap) per-point transform.
 template <int NS, int FW>
-__global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
+__global__ __launch_bounds__(FW * 64, NS <= 2 ? 4 : 2) void flow_kernel(FlowArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int LBYTES = p_layer_bytes(NS) + FILM_BYTES;
     constexpr int FILMOFF = p_layer_bytes(NS);
