@@ -196,7 +196,8 @@ __global__ __launch_bounds__(256) void pack_film_kernel(int L, int G, const floa
     }
 }
 
-constexpr int FILM_CLOUDS = 16;   // clouds per workgroup: 2 sub-nets x 64 features x 4 groups x 4 clouds = 512 threads
+constexpr int FILM_CLOUDS = 8;    // clouds per workgroup: 2 sub-nets x 64 features x 4 groups x 2 clouds = 512 threads
+constexpr int FILM_CPT = FILM_CLOUDS / 4;   // clouds per thread
 
 __global__ __launch_bounds__(512) void film_kernel(int L, int B, int G, const float *__restrict__ fw,
                                                    const float *__restrict__ g, float *__restrict__ film, float flow_eps) {
@@ -216,13 +217,15 @@ __global__ __launch_bounds__(512) void film_kernel(int L, int B, int G, const fl
         *(f32x4 *)(gs + row * G + c4) = v;
     }
     __syncthreads();
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    const float *g0 = gs + (cg * 4) * G;
-#pragma unroll 4
+    float acc[FILM_CPT];
+#pragma unroll
+    for (int c = 0; c < FILM_CPT; ++c) acc[c] = 0.f;
+    const float *g0 = gs + (cg * FILM_CPT) * G;
+#pragma unroll 8
     for (int k = 0; k < G; k += 4) {                                  // u = g . Wf0^T        flows.py:34/41
         const float w0 = WT[(k + 0) * 64 + f], w1 = WT[(k + 1) * 64 + f], w2 = WT[(k + 2) * 64 + f], w3 = WT[(k + 3) * 64 + f];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < FILM_CPT; ++c) {
             const f32x4 x = *(const f32x4 *)(g0 + c * G + k);
             acc[c] += w0 * x.x + w1 * x.y + w2 * x.z + w3 * x.w;
         }
@@ -230,23 +233,23 @@ __global__ __launch_bounds__(512) void film_kernel(int L, int B, int G, const fl
     {   // BatchNorm1d over the batch dim in eval mode (flows.py:35/42), then Swish (layers.py:9-10)
         const float a = sc[f], d = sh[f];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < FILM_CPT; ++c) {
             const float u = acc[c] * a + d;
-            hid[(sub * FILM_CLOUDS + cg * 4 + c) * 64 + f] = u / (1.0f + expf(-u));
+            hid[(sub * FILM_CLOUDS + cg * FILM_CPT + c) * 64 + f] = u / (1.0f + expf(-u));
         }
     }
     __syncthreads();
-    float v[4];
+    float v[FILM_CPT];
     {
         const float bias = bf1[f];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = bias;
-        const float *h0 = hid + (sub * FILM_CLOUDS + cg * 4) * 64;
-#pragma unroll 4
+        for (int c = 0; c < FILM_CPT; ++c) v[c] = bias;
+        const float *h0 = hid + (sub * FILM_CLOUDS + cg * FILM_CPT) * 64;
+#pragma unroll 16
         for (int k = 0; k < 64; k += 4) {                             // Linear(F, F) + bias   flows.py:37/44
             const float w0 = W1T[(k + 0) * 64 + f], w1 = W1T[(k + 1) * 64 + f], w2 = W1T[(k + 2) * 64 + f], w3 = W1T[(k + 3) * 64 + f];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < FILM_CPT; ++c) {
                 const f32x4 x = *(const f32x4 *)(h0 + c * 64 + k);
                 v[c] += w0 * x.x + w1 * x.y + w2 * x.z + w3 * x.w;
             }
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(512) void film_kernel(int L, int B, int G, const fl
     }
     if (sub == 1) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) cbx[(cg * 4 + c) * 64 + f] = v[c];
+        for (int c = 0; c < FILM_CPT; ++c) cbx[(cg * FILM_CPT + c) * 64 + f] = v[c];
     }
     __syncthreads();
     if (sub == 1) return;
@@ -263,11 +266,11 @@ __global__ __launch_bounds__(512) void film_kernel(int L, int B, int G, const fl
     const float *cst = fw + (size_t)L * 4 * fw_sub_floats(G) + (size_t)(l * 2 + br) * 320;
     const float s1 = cst[f], t1 = cst[64 + f], w2a = cst[128 + f], w2b = cst[192 + f];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int b = b0 + cg * 4 + c;
+    for (int c = 0; c < FILM_CPT; ++c) {
+        const int b = b0 + cg * FILM_CPT + c;
         if (b >= B) continue;
         const float a = flow_eps + expf(v[c]);
-        const float FA = a * s1, FC = a * t1 + cbx[(cg * 4 + c) * 64 + f];
+        const float FA = a * s1, FC = a * t1 + cbx[(cg * FILM_CPT + c) * 64 + f];
         float *o = film + ((size_t)l * B + b) * (FILM_BYTES / 4) + br * FILM_BR_FLOATS;
         o[f] = FC / FA;
         o[64 + 2 * f] = w2a * FA;
@@ -287,6 +290,9 @@ struct FlowArgs {
     float *p_out, *p_out_pm, *sum_lv, *ps, *mus, *lvs;
     int L, B, N, mode;
     float eps;
+#ifdef DPF_PROFILE
+    unsigned long long *prof;
+#endif
 };
 
 constexpr int TILE = 32;          // points per tile (one MFMA N tile)
@@ -327,8 +333,13 @@ template <> struct Terms<3> {
 // One conditioner branch (logvar or mu) of one layer for one 32-point tile:
 // returns the two pre-activation outputs o_a, o_b of the branch (sum over this
 // lane-half's 32 features; the caller adds the other half).
+#ifdef DPF_PROFILE
+#define DPF_T(i) { __builtin_amdgcn_sched_barrier(0); tt[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define DPF_T(i)
+#endif
 template <int NS, bool TWO>
-__device__ __forceinline__ void branch_tile(const uint8_t *lb, int br, int lane, int h, u32x4 b0, float &oa, float &ob) {
+__device__ __forceinline__ void branch_tile(const uint8_t *lb, int br, int lane, int h, u32x4 b0, float &oa, float &ob, unsigned long long *tt) {
     constexpr int A0OFF = p_a0_off(NS), FILMOFF = p_layer_bytes(NS);
     typedef Terms<NS> TT;
     // ---- h0 = relu(BN0(W0 x)) on the matrix core, fp32-accurate
@@ -360,6 +371,7 @@ __device__ __forceinline__ void branch_tile(const uint8_t *lb, int br, int lane,
             }
         }
     }
+    DPF_T(1)
     // ---- h1 = W1 h0, accumulator pre-loaded with the folded FiLM shift D.
     // The A fragments stream from LDS in batches of 4 (two k-steps x two M tiles), one batch
     // ahead of the MFMAs that consume them (hipcc otherwise reuses ONE fragment register and
@@ -408,6 +420,7 @@ __device__ __forceinline__ void branch_tile(const uint8_t *lb, int br, int lane,
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    DPF_T(2)
     // ---- o = W2' relu(h1 + D): each lane reduces its 32 features
     oa = 0.f; ob = 0.f;
     load_w(1, w01[1], w23[1]);
@@ -427,24 +440,20 @@ __device__ __forceinline__ float half_sum(float x) {   // x(lane) + x(lane ^ 32)
     return u2f(r[0]) + u2f(r[1]);
 }
 
-// The fused L-layer stack.  FW waves per workgroup = FW/2 tiles of 32 points of ONE cloud; the
-// two waves of a tile each run one conditioner branch (even wave: logvar, odd wave: mu) and
-// swap their two outputs per point through LDS at the layer's single barrier -- twice the waves
-// per SIMD for latency hiding at the price of duplicating the (cheap) per-point transform.
+// The fused L-layer stack.  FW waves per workgroup, each wave owns one 32-point tile of ONE
+// cloud for all layers (both conditioner branches).  Every workgroup streams the layer weights
+// through its own LDS, so bigger workgroups mean less L2->LDS traffic per point.
 template <int NS, int FW>
-__global__ __launch_bounds__(FW * 64, NS <= 2 ? 4 : 2) void flow_kernel(FlowArgs a) {
+__global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int LBYTES = p_layer_bytes(NS) + FILM_BYTES;
     constexpr int FILMOFF = p_layer_bytes(NS);
-    constexpr int TPB = FW / 2;                       // tiles per workgroup
-    float *xch = (float *)(smem + 2 * LBYTES);        // [parity 2][tile TPB][4][32]
 
     const int bi = blockIdx.y;
     const int lane = threadIdx.x & 63, h = lane >> 5, pl = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile = wave >> 1, br = wave & 1;
     const int N = a.N, L = a.L;
-    const int n = (blockIdx.x * TPB + tile) * TILE + pl;
+    const int n = (blockIdx.x * FW + wave) * TILE + pl;
     const bool valid = n < N;
     const int nc = valid ? n : N - 1;
     const size_t cloud = (size_t)bi * 3 * N;
@@ -453,15 +462,20 @@ __global__ __launch_bounds__(FW * 64, NS <= 2 ? 4 : 2) void flow_kernel(FlowArgs
     const bool inverse = a.mode == DPF_MODE_INVERSE;
     const size_t list_stride = (size_t)a.B * 3 * N;
 
-    stage_layer<NS, FW>(a, inverse ? L - 1 : 0, bi, smem, wave, lane);
+    const int lfirst = inverse ? L - 1 : 0;
+    stage_layer<NS, FW>(a, lfirst, bi, smem, wave, lane);
+    // layer descriptors (keep/warp channels) ride one layer ahead in SGPRs
+    int ka = a.meta[lfirst * 4 + 0], kb = a.meta[lfirst * 4 + 1], wa = a.meta[lfirst * 4 + 2], wb = a.meta[lfirst * 4 + 3];
     __syncthreads();
 
     for (int step = 0; step < L; ++step) {
         const int li = inverse ? L - 1 - step : step;
+        const int ln = inverse ? (li > 0 ? li - 1 : 0) : (li + 1 < L ? li + 1 : li);
         const uint8_t *lb = smem + (step & 1) * LBYTES;
-        if (step + 1 < L) stage_layer<NS, FW>(a, inverse ? li - 1 : li + 1, bi, smem + ((step + 1) & 1) * LBYTES, wave, lane);
-
-        const int ka = a.meta[li * 4 + 0], kb = a.meta[li * 4 + 1], wa = a.meta[li * 4 + 2], wb = a.meta[li * 4 + 3];
+        if (step + 1 < L) stage_layer<NS, FW>(a, ln, bi, smem + ((step + 1) & 1) * LBYTES, wave, lane);
+        const int nka = a.meta[ln * 4 + 0], nkb = a.meta[ln * 4 + 1], nwa = a.meta[ln * 4 + 2], nwb = a.meta[ln * 4 + 3];
+        unsigned long long tt[8];
+        DPF_T(0)
         // ---- B operand of the input MFMA: 3-way bf16 split of this half's input channel
         const float xa = sel3(ka, p0, p1, p2);
         const float xb = kb < 0 ? 0.f : sel3(kb, p0, p1, p2);
@@ -474,62 +488,75 @@ __global__ __launch_bounds__(FW * 64, NS <= 2 ? 4 : 2) void flow_kernel(FlowArgs
         b0.z = (xm >> 16) | xh;            // e4 = xm, e5 = xh
         b0.w = h ? 0x00003F80u : 0x3F803F80u;   // e6 = 1, e7 = (h == 0)
 
-        float oa, ob;
-        if (wb < 0) branch_tile<NS, false>(lb, br, lane, h, b0, oa, ob);   // layer warps one channel
-        else        branch_tile<NS, true>(lb, br, lane, h, b0, oa, ob);
-        const float *b2 = (const float *)(lb + FILMOFF) + FILM_B2_OFF;
-        oa = half_sum(oa) + b2[br * 2 + 0];
-        ob = half_sum(ob) + b2[br * 2 + 1];
-        if (br == 0) {                                                        // softsign, flows.py:99
-            oa = oa * __builtin_amdgcn_rcpf(1.0f + fabsf(oa));
-            ob = ob * __builtin_amdgcn_rcpf(1.0f + fabsf(ob));
+        float o[2][2];
+        if (wb < 0) {                                       // layer warps one channel
+            branch_tile<NS, false>(lb, 0, lane, h, b0, o[0][0], o[0][1], tt);
+            branch_tile<NS, false>(lb, 1, lane, h, b0, o[1][0], o[1][1], tt);
+        } else {
+            branch_tile<NS, true>(lb, 0, lane, h, b0, o[0][0], o[0][1], tt);
+            branch_tile<NS, true>(lb, 1, lane, h, b0, o[1][0], o[1][1], tt);
         }
-        // ---- swap branch outputs with the partner wave at the layer's barrier
-        float *xw = xch + (((step & 1) * TPB + tile) * 4 + br * 2) * 32;
-        if (!h) { xw[pl] = oa; xw[32 + pl] = ob; }
-        __syncthreads();   // partner's outputs visible; next layer's weights landed; this buffer is free
-        const float *xr = xch + (((step & 1) * TPB + tile) * 4 + (br ^ 1) * 2) * 32;
-        const float qa = xr[pl], qb = xr[32 + pl];
-        const float lva = br ? qa : oa, lvb = br ? qb : ob, mua = br ? oa : qa, mub = br ? ob : qb;
-        // ---- coupling transform (flows.py:96-115)
+        DPF_T(3)
+        const float *b2 = (const float *)(lb + FILMOFF) + FILM_B2_OFF;
+#pragma unroll
+        for (int br = 0; br < 2; ++br)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) o[br][e] = half_sum(o[br][e]) + b2[br * 2 + e];
+        // ---- coupling transform (flows.py:96-115); branch 0 = logvar, 1 = mu
+        const float lva = o[0][0] * __builtin_amdgcn_rcpf(1.0f + fabsf(o[0][0]));   // softsign, :99
+        const float lvb = o[0][1] * __builtin_amdgcn_rcpf(1.0f + fabsf(o[0][1]));
         float lv[3], mu[3], pn[3];
         const float pin[3] = {p0, p1, p2};
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             lv[c] = c == wa ? lva : (c == wb ? lvb : 0.f);
-            mu[c] = c == wa ? mua : (c == wb ? mub : 0.f);
+            mu[c] = c == wa ? o[1][0] : (c == wb ? o[1][1] : 0.f);
             const float var = a.eps + __expf(lv[c]);
             // keep channels are scaled by sqrt(1 + eps) too, as in the reference (:113/:115)
             pn[c] = inverse ? (pin[c] - mu[c]) * __builtin_amdgcn_rsqf(var) : __builtin_amdgcn_sqrtf(var) * pin[c] + mu[c];
         }
         p0 = pn[0]; p1 = pn[1]; p2 = pn[2];
         s0 += lv[0]; s1 += lv[1]; s2 += lv[2];
-        if (a.ps != nullptr && valid) {
-            // per-layer lists in DIRECT order (decoders.py:61-70): 9 rows of 32 floats, shared by the
-            // four lane-halves of the tile's two waves
+        if (a.ps != nullptr && valid) {   // per-layer lists in DIRECT order (decoders.py:61-70); halves share the rows
             const size_t base = (size_t)li * list_stride + cloud + n;
-            const int who = br * 2 + h;
-            float *d0, *d1, *d2; float v0, v1, v2; bool third = true;
-            if (who == 0)      { d0 = a.ps + base;  v0 = pn[0]; d1 = a.ps + base + N;  v1 = pn[1]; d2 = a.ps + base + 2 * (size_t)N;  v2 = pn[2]; }
-            else if (who == 1) { d0 = a.lvs + base; v0 = lv[0]; d1 = a.lvs + base + N; v1 = lv[1]; d2 = a.lvs + base + 2 * (size_t)N; v2 = lv[2]; }
-            else if (who == 2) { d0 = a.mus + base; v0 = mu[0]; d1 = a.mus + base + N; v1 = mu[1]; d2 = a.mus + base + 2 * (size_t)N; v2 = mu[2]; }
-            else               { d0 = d1 = d2 = nullptr; v0 = v1 = v2 = 0.f; third = false; }
-            if (third) { *d0 = v0; *d1 = v1; *d2 = v2; }
+            float *dst[5]; float val[5];
+            dst[0] = (h ? a.mus + base + 2 * (size_t)N : a.ps + base);              val[0] = h ? mu[2] : pn[0];
+            dst[1] = (h ? a.lvs + base : a.ps + base + N);                          val[1] = h ? lv[0] : pn[1];
+            dst[2] = (h ? a.lvs + base + N : a.ps + base + 2 * (size_t)N);          val[2] = h ? lv[1] : pn[2];
+            dst[3] = (h ? a.lvs + base + 2 * (size_t)N : a.mus + base);             val[3] = h ? lv[2] : mu[0];
+            dst[4] = a.mus + base + N;                                             val[4] = mu[1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) *dst[e] = val[e];
+            if (!h) *dst[4] = val[4];
         }
+        ka = nka; kb = nkb; wa = nwa; wb = nwb;
+        DPF_T(4)
+        __syncthreads();   // next layer's weights have landed; everyone is done with this buffer
+        DPF_T(5)
+#ifdef DPF_PROFILE
+        DPF_T(6)
+        if (a.prof != nullptr && lane == 0 && blockIdx.x < 2 && blockIdx.y == 0) {
+            unsigned long long *o2 = a.prof + (((size_t)(blockIdx.x * FW + wave)) * L + step) * 8;
+            for (int i = 0; i < 7; ++i) o2[i] = tt[i];
+        }
+#endif
     }
     if (valid) {
-        if (br == 0 && !h) {
+        if (!h) {
             a.p_out[cloud + n] = p0; a.p_out[cloud + N + n] = p1; a.p_out[cloud + 2 * (size_t)N + n] = p2;
-        } else if (br == 0 && h && a.sum_lv != nullptr) {
+            if (a.p_out_pm != nullptr) {   // point-major (B,N,3) copy for the structural losses (evaluating.py:110)
+                float *o2 = a.p_out_pm + ((size_t)bi * N + n) * 3;
+                o2[0] = p0; o2[1] = p1; o2[2] = p2;
+            }
+        } else if (a.sum_lv != nullptr) {
             a.sum_lv[cloud + n] = s0; a.sum_lv[cloud + N + n] = s1; a.sum_lv[cloud + 2 * (size_t)N + n] = s2;
-        } else if (br == 1 && !h && a.p_out_pm != nullptr) {
-            // point-major (B,N,3) copy for the structural losses (evaluating.py:110)
-            float *o = a.p_out_pm + ((size_t)bi * N + n) * 3;
-            o[0] = p0; o[1] = p1; o[2] = p2;
         }
     }
 }
 
+#ifdef DPF_PROFILE
+unsigned long long *g_prof = nullptr;
+#endif
 int ns_of(int precision) {
     return precision == DPF_PREC_BF16 ? 1 : precision == DPF_PREC_BF16X3 ? 2 : precision == DPF_PREC_BF16X6 ? 3 : 0;
 }
@@ -595,21 +622,24 @@ extern "C" int dpf_flow_forward(int n_layers, int B, int N, int mode, int precis
     a.packed = (const uint8_t *)packed; a.meta = meta; a.film = film; a.p_in = p_in;
     a.p_out = p_out; a.p_out_pm = p_out_pointmajor; a.sum_lv = sum_logvar; a.ps = ps; a.mus = mus; a.lvs = logvars;
     a.L = n_layers; a.B = B; a.N = N; a.mode = mode; a.eps = flow_eps;
+#ifdef DPF_PROFILE
+    a.prof = g_prof;
+#endif
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipSuccess;
-    // 8-wave workgroups: 4 tiles x 2 branch-waves = 128 points of one cloud
+    // 8-wave workgroups (256 points of one cloud) unless that leaves CUs without a workgroup
     static const int force_fw = getenv("DPF_FLOW_WAVES") ? atoi(getenv("DPF_FLOW_WAVES")) : 0;
-    const int fw = force_fw ? force_fw : 8;
+    const int fw = force_fw ? force_fw : (((long)B * ((N + 255) / 256) >= 200) ? 8 : 4);
 #define DPF_LAUNCH(NSV, FWV)                                                                                    \
     {                                                                                                           \
-        const int lds = 2 * (p_layer_bytes(NSV) + FILM_BYTES) + 2 * (FWV / 2) * 4 * 32 * 4;                     \
+        const int lds = 2 * (p_layer_bytes(NSV) + FILM_BYTES);                                                  \
         static bool attr_set = false;                                                                           \
         if (!attr_set) {                                                                                        \
             e = hipFuncSetAttribute((const void *)flow_kernel<NSV, FWV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
             if (e != hipSuccess) return (int)e;                                                                 \
             attr_set = true;                                                                                    \
         }                                                                                                       \
-        const dim3 grid((N + TILE * (FWV / 2) - 1) / (TILE * (FWV / 2)), B), block(FWV * 64);                   \
+        const dim3 grid((N + TILE * FWV - 1) / (TILE * FWV), B), block(FWV * 64);                               \
         hipLaunchKernelGGL((flow_kernel<NSV, FWV>), grid, block, lds, s, a);                                    \
     }
     if (fw == 8) {
@@ -625,4 +655,7 @@ extern "C" int dpf_flow_forward(int n_layers, int B, int N, int mode, int precis
     return (int)hipGetLastError();
 }
 
+#ifdef DPF_PROFILE
+extern "C" void dpf_debug_set_prof(void *p) { g_prof = (unsigned long long *)p; }
+#endif
 extern "C" const char *dpf_version(void) { return "dpf_hip gfx950 r1"; }
