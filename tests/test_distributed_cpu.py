@@ -1,0 +1,84 @@
+"""world_size-2 gloo tests of the data-parallel wrapper (runs on CPU)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import flow_oracle as FO
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dpf_nets_amd import distributed as D
+        from dpf_nets_amd.networks import LocalCondRNVPDecoder, PointFlowNLL
+        torch.manual_seed(0)
+        torch.set_num_threads(2)
+        B, N, G = 6, 40, 128
+        dec = LocalCondRNVPDecoder(1, 64, G)
+        dec.load_state_dict(FO.to_torch(FO.make_decoder_state(1, 1, 64, G)))
+        dec.train()
+        tgt, z, g = FO.synthetic_inputs(1, B, N, G)
+        # shard the batch by cloud: contiguous, exhaustive, disjoint
+        lo, hi = D.shard_bounds(B)
+        p_loc, g_loc = D.shard(torch.from_numpy(tgt), torch.from_numpy(g))
+        assert p_loc.shape[0] == hi - lo
+        ps, mus, lvs = dec(p_loc, g_loc, mode="inverse")                # training path (tensor ops)
+        pm, pl = torch.zeros_like(p_loc), torch.full_like(p_loc, -3.6)
+        loss = PointFlowNLL()(ps + [p_loc], [pm] + mus, [pl] + lvs)
+        loss.backward()
+        local = torch.cat([p.grad.reshape(-1) for p in dec.parameters()]).clone()
+        n = D.allreduce_gradients(dec.parameters())                    # ONE collective
+        after = torch.cat([p.grad.reshape(-1) for p in dec.parameters()])
+        gathered = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        expect = sum(gathered) / world
+        ok = torch.allclose(after, expect, rtol=1e-6, atol=1e-7) and n == local.numel()
+        # per-cloud results gathered back in batch order
+        ids = torch.arange(lo, hi, dtype=torch.float32)
+        allids = D.gather_clouds(ids)
+        ok = ok and torch.equal(allids, torch.arange(B, dtype=torch.float32))
+        D.broadcast_buffers(dec)
+        q.put((rank, bool(ok), (lo, hi), float(loss)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_allreduce_gather_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+    assert res[0][2] == (0, 3) and res[1][2] == (3, 6)
+
+
+def test_shard_bounds_cover_batch():
+    from dpf_nets_amd.distributed import shard_bounds
+    for n in (1, 7, 32, 33, 64):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
