@@ -5,9 +5,14 @@ side allocates every output with torch.empty on the input's device, inputs must
 be contiguous device tensors (CHECK_INPUT, structural_loss.cpp:10-12), launches
 go to the current stream and do not synchronise.  The kernels live in
 libdpf_hip.so (csrc/chamfer.hip, csrc/emd.hip)."""
+import os
+
 import torch
 
 from ..._lib import lib, check, current_stream
+
+
+BRUTE_FORCE = bool(int(os.environ.get("DPF_CHAMFER_BRUTE", "0")))   # 1: O(n*m) kernel only
 
 
 def _check_input(x, name, dtype=torch.float32):
@@ -37,8 +42,16 @@ def NNDistance(set_d, set_q):
     dist2 = torch.empty((b, m), dtype=torch.float32, device=dev)
     idx2 = torch.empty((b, m), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        check(lib().dpf_nndistance(b, n, set_d.data_ptr(), m, set_q.data_ptr(), dist1.data_ptr(), idx1.data_ptr(),
-                                   dist2.data_ptr(), idx2.data_ptr(), current_stream()), "nndistance")
+        if BRUTE_FORCE:
+            check(lib().dpf_nndistance(b, n, set_d.data_ptr(), m, set_q.data_ptr(), dist1.data_ptr(),
+                                       idx1.data_ptr(), dist2.data_ptr(), idx2.data_ptr(), current_stream()),
+                  "nndistance")
+        else:   # same bits, pruned search; scratch is caller-owned like every other buffer
+            nbytes = lib().dpf_nndistance_workspace_bytes(b, n, m)
+            ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
+            check(lib().dpf_nndistance_ws(b, n, set_d.data_ptr(), m, set_q.data_ptr(), dist1.data_ptr(),
+                                          idx1.data_ptr(), dist2.data_ptr(), idx2.data_ptr(), ws.data_ptr(), nbytes,
+                                          current_stream()), "nndistance_ws")
     return [dist1, idx1, dist2, idx2]
 
 

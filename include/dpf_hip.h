@@ -42,6 +42,17 @@ int dpf_nndistance(int b, int n, const float *xyz, int m, const float *xyz2,
                    float *result, int *result_i, float *result2, int *result2_i,
                    dpf_stream_t stream);
 
+/* Same results as dpf_nndistance, bit for bit (distances AND first-minimum
+ * indices), but prunes: clouds are sorted by x once and every query wave scans
+ * only the sorted candidates that can still win or tie.  `workspace` is
+ * caller-owned scratch of dpf_nndistance_workspace_bytes(b, n, m) bytes
+ * (16 B per point).  Falls back to the brute-force kernel when n or m is
+ * outside [64, 8192] or the workspace is NULL / too small. */
+size_t dpf_nndistance_workspace_bytes(int b, int n, int m);
+int dpf_nndistance_ws(int b, int n, const float *xyz, int m, const float *xyz2,
+                      float *result, int *result_i, float *result2, int *result2_i,
+                      void *workspace, size_t workspace_bytes, dpf_stream_t stream);
+
 /* replaces nndistancegrad(...)  src/nndistance.cuh:2, nndistance.cu:149-154.
  * grad_xyz1 / grad_xyz2 are fully overwritten (the zero-fill happens on
  * `stream`, not on the null stream as at nndistance.cu:150-151). */
