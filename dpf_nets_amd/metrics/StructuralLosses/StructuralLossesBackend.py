@@ -12,7 +12,11 @@ import torch
 from ..._lib import lib, check, current_stream
 
 
-BRUTE_FORCE = bool(int(os.environ.get("DPF_CHAMFER_BRUTE", "0")))   # 1: O(n*m) kernel only
+# The O(n*m) brute-force kernel is the default: it runs at ~75 % of its VALU issue bound and its
+# cost does not depend on the data.  DPF_CHAMFER_PRUNED=1 selects the x-sorted pruned search
+# (bit-identical results; pays off only when both clouds cover the same region -- r01 measurement on
+# the synthetic benchmark clouds: 170 us vs 50 us).
+BRUTE_FORCE = not bool(int(os.environ.get("DPF_CHAMFER_PRUNED", "0")))
 
 
 def _check_input(x, name, dtype=torch.float32):
