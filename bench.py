@@ -243,7 +243,7 @@ def main():
             try:
                 tr = json.load(open(tj))
                 key = "%s/B%d_N%d_L%d_%s" % (dom, B, N, L, args.precision)
-                traffic = tr.get(key)
+                traffic = (tr.get(key) or {}).get("hbm_bytes")
             except Exception:
                 traffic = None
         if dom == "flow_kernel":

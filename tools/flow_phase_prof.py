@@ -36,7 +36,7 @@ def main():
         handle.dpf_debug_set_prof(None)
         t = prof.cpu().numpy().astype(np.int64)
         d = np.diff(t[:, :, :7], axis=2)            # phases 0..5
-        names = ["br0: mfma0+split (T0-T1, br1 overwrites)", "mfma1 chain (br1)", "epilogue (br1)", "transform+stores", "barrier", "-"]
+        names = ["A+B: input mfma + split br0", "C: chain br0 | split br1", "D: chain br1 | epi br0", "E: epi br1", "reduce+transform+stores", "barrier"]
         print("== %s: cycles per layer (median over waves/layers) | per-wave layer period" % prec)
         for i, nme in enumerate(names):
             print("   %-14s median %7.0f  p90 %7.0f" % (nme, np.median(d[:, 1:, i]), np.percentile(d[:, 1:, i], 90)))

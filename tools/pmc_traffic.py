@@ -1,0 +1,44 @@
+"""Turn the FETCH_SIZE / WRITE_SIZE passes of tools/pmc_run.sh into profiles/traffic.json:
+HBM bytes per launch for each of our kernels, corrected as MI355X_MICROARCH.md prescribes
+(FETCH_SIZE counts 64 B per 128-B request on gfx950 -> x2 for wide coalesced reads; both
+counters are in KiB)."""
+import json
+import os
+import re
+import sys
+
+
+def parse(path):
+    out = {}
+    for line in open(path):
+        m = re.match(r"(\S+)\s+(FETCH_SIZE|WRITE_SIZE)\s+([0-9.]+)", line)
+        if m:
+            out[(m.group(1), m.group(2))] = float(m.group(3))
+    return out
+
+
+def main(pmc_dir, tag, out_json):
+    vals = {}
+    for f in sorted(os.listdir(pmc_dir)):
+        if f.endswith(".txt"):
+            vals.update(parse(os.path.join(pmc_dir, f)))
+    res = json.load(open(out_json)) if os.path.exists(out_json) else {}
+    names = {"flow_kernel": "flow_kernel", "nn_kernel": "nn_kernel", "film_kernel": "film_kernel"}
+    for (k, c), v in vals.items():
+        for short in names:
+            if short in k:
+                e = res.setdefault("%s/%s" % (short, tag), {})
+                if c == "FETCH_SIZE":
+                    e["fetch_bytes_raw"] = v * 1024
+                    e["fetch_bytes"] = v * 1024 * 2          # gfx950: 128-B requests tallied at 64 B
+                else:
+                    e["write_bytes"] = v * 1024
+    for e in res.values():
+        if isinstance(e, dict) and "fetch_bytes" in e and "write_bytes" in e:
+            e["hbm_bytes"] = e["fetch_bytes"] + e["write_bytes"]
+    json.dump(res, open(out_json, "w"), indent=1, sort_keys=True)
+    print(json.dumps(res, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], sys.argv[3])

@@ -19,6 +19,8 @@ __global__ void k(float *out, int iters, float seed, unsigned long long *ticks) 
     for (int i = 0; i < 8; ++i) p[i] = f2{seed + i, seed - i};
     f32x16 acc = {0};
     f32x16 acc2 = {0};
+    f32x16 acc3 = {0};
+    f32x16 acc4 = {0};
     bf16x8 ab = {1, 2, 3, 4, 5, 6, 7, 8};
     uint32_t u[8];
     for (int i = 0; i < 8; ++i) u[i] = threadIdx.x * 2654435761u + i;
@@ -41,13 +43,33 @@ __global__ void k(float *out, int iters, float seed, unsigned long long *ticks) 
                 acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, ab, acc2, 0, 0, 0);
                 for (int i = 0; i < 8; ++i) a[i] = __builtin_fmaf(a[i], 1.0001f, 0.5f);
             }
+        } else if (KIND == 6) { // 16 MFMA + 128 integer VALU (and/max)
+            for (int r = 0; r < 8; ++r) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, ab, acc, 0, 0, 0);
+                for (int i = 0; i < 8; ++i) u[i] = (uint32_t)max((int)(u[i] ^ 0x5bd1e995u), (int)i);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, ab, acc2, 0, 0, 0);
+                for (int i = 0; i < 8; ++i) u[i] = (uint32_t)max((int)(u[i] ^ 0x5bd1e995u), (int)i);
+            }
+        } else if (KIND == 7) { // 256 integer VALU only (xor + max)
+            REP16(for (int i = 0; i < 8; ++i) u[i] = (uint32_t)max((int)(u[i] ^ 0x5bd1e995u), (int)i);)
+        } else if (KIND == 8) { // 16 MFMA on 4 accumulators + 128 fma
+            for (int r = 0; r < 4; ++r) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, ab, acc, 0, 0, 0);
+                for (int i = 0; i < 8; ++i) a[i] = __builtin_fmaf(a[i], 1.0001f, 0.5f);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, ab, acc2, 0, 0, 0);
+                for (int i = 0; i < 8; ++i) a[i] = __builtin_fmaf(a[i], 1.0001f, 0.5f);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, ab, acc3, 0, 0, 0);
+                for (int i = 0; i < 8; ++i) a[i] = __builtin_fmaf(a[i], 1.0001f, 0.5f);
+                acc4 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, ab, acc4, 0, 0, 0);
+                for (int i = 0; i < 8; ++i) a[i] = __builtin_fmaf(a[i], 1.0001f, 0.5f);
+            }
         } else if (KIND == 5) { // v_perm + cvt_pk mix (128)
             REP16(for (int i = 0; i < 8; ++i) u[i] = __builtin_amdgcn_perm(u[i], u[(i + 1) & 7], 0x07060302u);)
         }
     }
     float s = 0;
     for (int i = 0; i < 8; ++i) s += a[i] + p[i].x + p[i].y + (float)u[i];
-    for (int i = 0; i < 16; ++i) s += acc[i] + acc2[i];
+    for (int i = 0; i < 16; ++i) s += acc[i] + acc2[i] + acc3[i] + acc4[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if (ticks && blockIdx.x == 0 && threadIdx.x == 0) ticks[0] = __builtin_amdgcn_s_memtime() - t0;
 }
@@ -84,5 +106,8 @@ int main() {
     run<5>("v_perm_b32", 128);
     run<3>("mfma32x32x16", 16);
     run<4>("mfma + 8 fma each", 16 + 128);
+    run<8>("mfma(4 acc) + 8 fma", 16 + 128);
+    run<7>("xor+max_i32 only", 256);
+    run<6>("mfma + 8x(xor,max)", 16 + 256);
     return 0;
 }
