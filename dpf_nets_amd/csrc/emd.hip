@@ -40,14 +40,17 @@ __global__ void emd_init_kernel(int n, int m, float multiL, float multiR, float 
 // PASS 1 (P=xyz1, Q=xyz2, wq=remainR): ratioL[i] = remainL[i] / (1e-9 + s_i)    approxmatch.cu:29-62
 // PASS 2 (P=xyz2, Q=xyz1, wq=ratioL):  sumr = s_i * remainR[i];                  approxmatch.cu:78-111
 //        ratioR[i] = min(remainR[i]/(sumr+1e-9), 1) * remainR[i]; remainR[i] = max(0, remainR[i]-sumr)
+// ratio vectors live at rbase + bi*rstride: [ratioL(n) | ratioR(m)] -- either inside `temp`
+// (reference layout, approxmatch.cu:4) or in a per-level slot of the caller's workspace
 template <int PASS>
 __global__ __launch_bounds__(1024) void emd_ratio_kernel(int n, int m, float lvl2, const float *__restrict__ xyz1,
-                                                         const float *__restrict__ xyz2, float *temp) {
+                                                         const float *__restrict__ xyz2, float *temp, float *rbase,
+                                                         size_t rstride) {
     __shared__ float part[MAXS][64];
     const int bi = blockIdx.y;
     const int lane = threadIdx.x, slice = __builtin_amdgcn_readfirstlane(threadIdx.y), S = blockDim.y;
     float *t = temp + (size_t)bi * (n + m) * 2;
-    float *remainL = t, *remainR = t + n, *ratioL = t + n + m, *ratioR = t + n + m + n;
+    float *remainL = t, *remainR = t + n, *ratioL = rbase + (size_t)bi * rstride, *ratioR = ratioL + n;
     const int np = PASS == 1 ? n : m, nq = PASS == 1 ? m : n;
     const float *__restrict__ P = (PASS == 1 ? xyz1 + (size_t)bi * n * 3 : xyz2 + (size_t)bi * m * 3);
     const float *__restrict__ Q = (PASS == 1 ? xyz2 + (size_t)bi * m * 3 : xyz1 + (size_t)bi * n * 3);
@@ -87,17 +90,19 @@ __global__ __launch_bounds__(1024) void emd_ratio_kernel(int n, int m, float lvl
 
 // PASS 3: w = exp(level*d^2) * ratioL[k] * ratioR[l]; match[l][k] += w;          approxmatch.cu:130-163
 //         remainL[k] = max(0, remainL[k] - sum_l w)
-template <bool FIRST>
+// MODE 0: match = w (first level), 1: match += w, 2: no match traffic (deferred materialisation)
+template <int MODE>
 __global__ __launch_bounds__(1024) void emd_match_kernel(int n, int m, float lvl2, const float *__restrict__ xyz1,
                                                          const float *__restrict__ xyz2, float *__restrict__ match,
-                                                         float *temp) {
+                                                         float *temp, const float *rbase, size_t rstride) {
+    constexpr bool FIRST = MODE == 0;
     __shared__ float part[MAXS][64];
     const int bi = blockIdx.y;
     const int lane = threadIdx.x, slice = __builtin_amdgcn_readfirstlane(threadIdx.y), S = blockDim.y;
     float *t = temp + (size_t)bi * (n + m) * 2;
     float *remainL = t;
-    const float *__restrict__ ratioL = t + n + m;
-    const float *__restrict__ ratioR = t + n + m + n;
+    const float *__restrict__ ratioL = rbase + (size_t)bi * rstride;
+    const float *__restrict__ ratioR = ratioL + n;
     const float *__restrict__ P = xyz1 + (size_t)bi * n * 3;
     const float *__restrict__ Q = xyz2 + (size_t)bi * m * 3;
     float *__restrict__ mt = match + (size_t)bi * n * m;
@@ -113,20 +118,20 @@ __global__ __launch_bounds__(1024) void emd_match_kernel(int n, int m, float lvl
         float w[4], old[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (!FIRST) old[u] = live ? mt[(size_t)(l + u) * n + k] : 0.f;
+            if (MODE == 1) old[u] = live ? mt[(size_t)(l + u) * n + k] : 0.f;
             const float d2 = sqdist(px, py, pz, Q[(l + u) * 3 + 0], Q[(l + u) * 3 + 1], Q[(l + u) * 3 + 2]);
             w[u] = fast_exp2(lvl2 * d2) * rl * ratioR[l + u];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (live) mt[(size_t)(l + u) * n + k] = FIRST ? w[u] : old[u] + w[u];
+            if (MODE != 2 && live) mt[(size_t)(l + u) * n + k] = FIRST ? w[u] : old[u] + w[u];
             suml += w[u];
         }
     }
     for (; l < le; ++l) {
         const float d2 = sqdist(px, py, pz, Q[l * 3 + 0], Q[l * 3 + 1], Q[l * 3 + 2]);
         const float w = fast_exp2(lvl2 * d2) * rl * ratioR[l];
-        if (live) mt[(size_t)l * n + k] = FIRST ? w : mt[(size_t)l * n + k] + w;
+        if (MODE != 2 && live) mt[(size_t)l * n + k] = FIRST ? w : mt[(size_t)l * n + k] + w;
         suml += w;
     }
     part[slice][lane] = suml;
@@ -135,6 +140,42 @@ __global__ __launch_bounds__(1024) void emd_match_kernel(int n, int m, float lvl
     float tot = 0.f;
     for (int u = 0; u < S; ++u) tot += part[u][lane];
     remainL[k] = fmaxf(0.0f, remainL[k] - tot);
+}
+
+// Deferred materialisation: match[l][k] = sum over the 9 levels (in level order, so the fp32
+// association equals the reference's repeated `match += w`, approxmatch.cu:155) of
+// exp(level*d^2) * ratioL_level[k] * ratioR_level[l].  One 4-byte write per pair instead of a
+// read-modify-write per level: HBM traffic 4*n*m instead of 68*n*m bytes per cloud.
+constexpr int NLEVEL = 9;
+struct Levels { float lvl2[NLEVEL]; };
+
+__global__ __launch_bounds__(1024) void emd_materialize_kernel(int n, int m, Levels lv, const float *__restrict__ xyz1,
+                                                               const float *__restrict__ xyz2,
+                                                               float *__restrict__ match, const float *__restrict__ ws,
+                                                               size_t lstride, size_t rstride) {
+    const int bi = blockIdx.y;
+    const int lane = threadIdx.x, slice = __builtin_amdgcn_readfirstlane(threadIdx.y), S = blockDim.y;
+    const float *__restrict__ P = xyz1 + (size_t)bi * n * 3;
+    const float *__restrict__ Q = xyz2 + (size_t)bi * m * 3;
+    float *__restrict__ mt = match + (size_t)bi * n * m;
+    const int k = blockIdx.x * 64 + lane;
+    const bool live = k < n;
+    const int kc = min(k, n - 1);
+    const float px = P[kc * 3 + 0], py = P[kc * 3 + 1], pz = P[kc * 3 + 2];
+    float rl[NLEVEL];
+#pragma unroll
+    for (int j = 0; j < NLEVEL; ++j) rl[j] = ws[j * lstride + (size_t)bi * rstride + kc];
+    const int lb = (int)((long)m * slice / S), le = (int)((long)m * (slice + 1) / S);
+    for (int l = lb; l < le; ++l) {
+        const float d2 = sqdist(px, py, pz, Q[l * 3 + 0], Q[l * 3 + 1], Q[l * 3 + 2]);
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < NLEVEL; ++j) {
+            const float w = fast_exp2(lv.lvl2[j] * d2) * rl[j] * ws[j * lstride + (size_t)bi * rstride + n + l];
+            acc = j == 0 ? w : acc + w;
+        }
+        if (live) mt[(size_t)l * n + k] = acc;
+    }
 }
 
 // out[b] = sum_{l,k} match[b,l,k] * |xyz1[k] - xyz2[l]|                           approxmatch.cu:184-224
@@ -229,12 +270,18 @@ int pick_slices(int b, int npoints, int ninner) {
 
 }  // namespace
 
-extern "C" int dpf_approxmatch(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
-                               dpf_stream_t stream) {
+extern "C" size_t dpf_approxmatch_workspace_bytes(int b, int n, int m) {
+    if (b <= 0 || n <= 0 || m <= 0) return 0;
+    return (size_t)b * NLEVEL * ((size_t)n + m) * sizeof(float);
+}
+
+extern "C" int dpf_approxmatch_ws(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
+                                  void *workspace, size_t workspace_bytes, dpf_stream_t stream) {
     if (b < 0 || n <= 0 || m <= 0) return DPF_EINVAL;
     if (b == 0) return 0;
     if (!xyz1 || !xyz2 || !match || !temp) return DPF_EINVAL;
     if (b > 65535) return DPF_ENOSUP;
+    const bool deferred = workspace != nullptr && workspace_bytes >= dpf_approxmatch_workspace_bytes(b, n, m);
     hipStream_t s = (hipStream_t)stream;
     float multiL, multiR;
     if (n >= m) { multiL = 1; multiR = (float)(n / m); }   // integer division, approxmatch.cu:6-12
@@ -242,17 +289,33 @@ extern "C" int dpf_approxmatch(int b, int n, int m, const float *xyz1, const flo
     hipLaunchKernelGGL(emd_init_kernel, dim3((n + m + 255) / 256, b), dim3(256), 0, s, n, m, multiL, multiR, temp);
     const int s1 = pick_slices(b, n, m), s2 = pick_slices(b, m, n);
     const dim3 g1((n + 63) / 64, b), g2((m + 63) / 64, b);
-    for (int j = 7; j > -2; --j) {                          // approxmatch.cu:24 (the j==-2 branch is dead)
+    const size_t rstride = deferred ? (size_t)(n + m) : (size_t)(n + m) * 2;     // per-cloud stride of a ratio slot
+    const size_t lstride = (size_t)b * (n + m);                                   // per-level stride in the workspace
+    Levels lv;
+    int li = 0;
+    for (int j = 7; j > -2; --j, ++li) {                    // approxmatch.cu:24 (the j==-2 branch is dead)
         const float level = -powf(4.0f, (float)j);
         const float lvl2 = level * 1.44269504088896340736f;  // exp(x) = exp2(x*log2 e), as __expf does
-        hipLaunchKernelGGL(emd_ratio_kernel<1>, g1, dim3(64, s1), 0, s, n, m, lvl2, xyz1, xyz2, temp);
-        hipLaunchKernelGGL(emd_ratio_kernel<2>, g2, dim3(64, s2), 0, s, n, m, lvl2, xyz1, xyz2, temp);
-        if (j == 7)
-            hipLaunchKernelGGL(emd_match_kernel<true>, g1, dim3(64, s1), 0, s, n, m, lvl2, xyz1, xyz2, match, temp);
+        lv.lvl2[li] = lvl2;
+        float *rb = deferred ? (float *)workspace + li * lstride : temp + (size_t)(n + m);
+        hipLaunchKernelGGL(emd_ratio_kernel<1>, g1, dim3(64, s1), 0, s, n, m, lvl2, xyz1, xyz2, temp, rb, rstride);
+        hipLaunchKernelGGL(emd_ratio_kernel<2>, g2, dim3(64, s2), 0, s, n, m, lvl2, xyz1, xyz2, temp, rb, rstride);
+        if (deferred)
+            hipLaunchKernelGGL(emd_match_kernel<2>, g1, dim3(64, s1), 0, s, n, m, lvl2, xyz1, xyz2, match, temp, rb, rstride);
+        else if (j == 7)
+            hipLaunchKernelGGL(emd_match_kernel<0>, g1, dim3(64, s1), 0, s, n, m, lvl2, xyz1, xyz2, match, temp, rb, rstride);
         else
-            hipLaunchKernelGGL(emd_match_kernel<false>, g1, dim3(64, s1), 0, s, n, m, lvl2, xyz1, xyz2, match, temp);
+            hipLaunchKernelGGL(emd_match_kernel<1>, g1, dim3(64, s1), 0, s, n, m, lvl2, xyz1, xyz2, match, temp, rb, rstride);
     }
+    if (deferred)
+        hipLaunchKernelGGL(emd_materialize_kernel, g1, dim3(64, s1), 0, s, n, m, lv, xyz1, xyz2, match,
+                           (const float *)workspace, lstride, rstride);
     return (int)hipGetLastError();
+}
+
+extern "C" int dpf_approxmatch(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
+                               dpf_stream_t stream) {
+    return dpf_approxmatch_ws(b, n, m, xyz1, xyz2, match, temp, nullptr, 0, stream);
 }
 
 extern "C" int dpf_matchcost(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match, float *out,

@@ -26,7 +26,7 @@ def main(pmc_dir, tag, out_json):
     names = {"flow_kernel": "flow_kernel", "nn_kernel": "nn_kernel", "film_kernel": "film_kernel"}
     for (k, c), v in vals.items():
         for short in names:
-            if short in k:
+            if short in k and "pack_" not in k:
                 e = res.setdefault("%s/%s" % (short, tag), {})
                 if c == "FETCH_SIZE":
                     e["fetch_bytes_raw"] = v * 1024
