@@ -19,6 +19,9 @@ from ..._lib import lib, check, current_stream
 BRUTE_FORCE = not bool(int(os.environ.get("DPF_CHAMFER_PRUNED", "0")))
 
 
+EMD_RMW = bool(int(os.environ.get("DPF_EMD_RMW", "0")))   # 1: the reference's per-level read-modify-write of `match`
+
+
 def _check_input(x, name, dtype=torch.float32):
     # mirrors CHECK_CUDA / CHECK_CONTIGUOUS (AT_ASSERTM -> RuntimeError)
     if not x.is_cuda:
@@ -81,8 +84,14 @@ def ApproxMatch(set_d, set_q):
     match = torch.empty((b, m, n), dtype=torch.float32, device=set_d.device)
     temp = torch.empty((b, (n + m) * 2), dtype=torch.float32, device=set_d.device)
     with torch.cuda.device(set_d.device):
-        check(lib().dpf_approxmatch(b, n, m, set_d.data_ptr(), set_q.data_ptr(), match.data_ptr(), temp.data_ptr(),
-                                    current_stream()), "approxmatch")
+        if EMD_RMW:
+            check(lib().dpf_approxmatch(b, n, m, set_d.data_ptr(), set_q.data_ptr(), match.data_ptr(),
+                                        temp.data_ptr(), current_stream()), "approxmatch")
+        else:   # bit-identical, `match` written once (scratch for the per-level ratio vectors is caller-owned)
+            nbytes = lib().dpf_approxmatch_workspace_bytes(b, n, m)
+            ws = torch.empty((nbytes,), dtype=torch.uint8, device=set_d.device)
+            check(lib().dpf_approxmatch_ws(b, n, m, set_d.data_ptr(), set_q.data_ptr(), match.data_ptr(),
+                                           temp.data_ptr(), ws.data_ptr(), nbytes, current_stream()), "approxmatch_ws")
     return [match, temp]
 
 

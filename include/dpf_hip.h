@@ -67,6 +67,16 @@ int dpf_nndistancegrad(int b, int n, const float *xyz1, int m, const float *xyz2
 int dpf_approxmatch(int b, int n, int m, const float *xyz1, const float *xyz2,
                     float *match, float *temp, dpf_stream_t stream);
 
+/* Same results as dpf_approxmatch, bit for bit, with `match` written ONCE: the
+ * nine levels' ratio vectors are kept in `workspace`
+ * (dpf_approxmatch_workspace_bytes = 36*(n+m) bytes per cloud) and the matching
+ * is materialised by a final pass (4*n*m instead of 68*n*m bytes of HBM traffic
+ * per cloud).  NULL / short workspace -> the read-modify-write path. */
+size_t dpf_approxmatch_workspace_bytes(int b, int n, int m);
+int dpf_approxmatch_ws(int b, int n, int m, const float *xyz1, const float *xyz2,
+                       float *match, float *temp, void *workspace, size_t workspace_bytes,
+                       dpf_stream_t stream);
+
 /* replaces matchcost(...)       src/approxmatch.cuh:7, approxmatch.cu:309-316.
  * out: (b,) = sum_{l,k} match[b,l,k] * |xyz1[b,k]-xyz2[b,l]|_2. */
 int dpf_matchcost(int b, int n, int m, const float *xyz1, const float *xyz2,

@@ -45,6 +45,21 @@ def test_approxmatch_matchcost_vs_oracle(shape):
     np.testing.assert_allclose(g2.cpu().numpy(), r2, rtol=1e-4, atol=1e-5)
 
 
+def test_deferred_materialisation_is_bit_identical_to_rmw():
+    BK = _gpu()
+    for (B, n, m) in ((2, 64, 64), (3, 300, 257), (2, 1024, 2048)):
+        a, b = chamfer_inputs(700 + n, B, n, m)
+        ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+        BK.EMD_RMW = True
+        try:
+            m_rmw, t_rmw = BK.ApproxMatch(ta, tb)
+        finally:
+            BK.EMD_RMW = False
+        m_def, t_def = BK.ApproxMatch(ta, tb)
+        assert torch.equal(m_rmw, m_def)
+        assert torch.equal(t_rmw[:, :n + m], t_def[:, :n + m])        # remainL / remainR
+
+
 def test_emd_full_size_invariants_and_autograd():
     BK = _gpu()
     from dpf_nets_amd.networks.utils import emd_approx
