@@ -21,9 +21,58 @@ namespace {
 
 constexpr int MAXS = 16;   // max inner-loop slices (waves) per workgroup
 
+// Explicit fma / rn intrinsics: the read-modify-write and the deferred paths of approxmatch
+// must produce the same bits, so nothing here is left to the compiler's contraction heuristics.
 __device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, float by, float bz) {
     const float dx = bx - ax, dy = by - ay, dz = bz - az;
-    return dx * dx + dy * dy + dz * dz;
+    return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
+}
+
+__device__ __forceinline__ float bcast(float v, int lane) {   // lane wave-uniform -> v_readlane_b32 into an SGPR
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// Stream the wave-uniform candidates [jb, je) of cloud Q (with NW per-candidate weight arrays
+// w[0..NW), each indexed by candidate) past the lanes' own points: each lane loads ONE candidate
+// of a 64-tile with coalesced vector loads (next tile in flight while the current one is used) and
+// the tile is replayed by broadcasting lane u's registers (v_readlane -> SGPR operands).  No
+// memory latency inside the 64-candidate loop, no LDS.
+template <int NW, class F>
+__device__ __forceinline__ void stream_candidates(const float *__restrict__ Q, const float *const (&w)[NW > 0 ? NW : 1],
+                                                  int jb, int je, int lane, F &&f) {
+    if (jb >= je) return;
+    float cx, cy, cz, cw[NW > 0 ? NW : 1];
+    auto load = [&](int j0, float &x, float &y, float &z, float (&ww)[NW > 0 ? NW : 1]) {
+        const int jj = min(j0 + lane, je - 1);
+        x = Q[jj * 3 + 0]; y = Q[jj * 3 + 1]; z = Q[jj * 3 + 2];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) ww[i] = w[i][jj];
+    };
+    load(jb, cx, cy, cz, cw);
+    for (int j0 = jb; j0 < je; j0 += 64) {
+        float nx = 0.f, ny = 0.f, nz = 0.f, nw[NW > 0 ? NW : 1];
+        if (j0 + 64 < je) load(j0 + 64, nx, ny, nz, nw);
+        const int cnt = min(64, je - j0);
+        if (cnt == 64) {
+#pragma unroll 16
+            for (int u = 0; u < 64; ++u) {
+                float ww[NW > 0 ? NW : 1];
+#pragma unroll
+                for (int i = 0; i < NW; ++i) ww[i] = bcast(cw[i], u);
+                f(j0 + u, bcast(cx, u), bcast(cy, u), bcast(cz, u), ww);
+            }
+        } else {
+            for (int u = 0; u < cnt; ++u) {
+                float ww[NW > 0 ? NW : 1];
+#pragma unroll
+                for (int i = 0; i < NW; ++i) ww[i] = bcast(cw[i], u);
+                f(j0 + u, bcast(cx, u), bcast(cy, u), bcast(cz, u), ww);
+            }
+        }
+        cx = nx; cy = ny; cz = nz;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) cw[i] = nw[i];
+    }
 }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -60,18 +109,10 @@ __global__ __launch_bounds__(1024) void emd_ratio_kernel(int n, int m, float lvl
     const float px = P[ic * 3 + 0], py = P[ic * 3 + 1], pz = P[ic * 3 + 2];
     const int jb = (int)((long)nq * slice / S), je = (int)((long)nq * (slice + 1) / S);
     float s = 0.f;
-    int j = jb;
-    for (; j + 4 <= je; j += 4) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float d2 = sqdist(px, py, pz, Q[(j + u) * 3 + 0], Q[(j + u) * 3 + 1], Q[(j + u) * 3 + 2]);
-            s += fast_exp2(lvl2 * d2) * wq[j + u];
-        }
-    }
-    for (; j < je; ++j) {
-        const float d2 = sqdist(px, py, pz, Q[j * 3 + 0], Q[j * 3 + 1], Q[j * 3 + 2]);
-        s += fast_exp2(lvl2 * d2) * wq[j];
-    }
+    const float *const wl[1] = {wq};
+    stream_candidates<1>(Q, wl, jb, je, lane, [&](int, float qx, float qy, float qz, const float (&ww)[1]) {
+        s = __fmaf_rn(fast_exp2(__fmul_rn(lvl2, sqdist(px, py, pz, qx, qy, qz))), ww[0], s);
+    });
     part[slice][lane] = s;
     __syncthreads();
     if (slice != 0 || i >= np) return;
@@ -113,27 +154,15 @@ __global__ __launch_bounds__(1024) void emd_match_kernel(int n, int m, float lvl
     const float rl = ratioL[kc];
     const int lb = (int)((long)m * slice / S), le = (int)((long)m * (slice + 1) / S);
     float suml = 0.f;
-    int l = lb;
-    for (; l + 4 <= le; l += 4) {
-        float w[4], old[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (MODE == 1) old[u] = live ? mt[(size_t)(l + u) * n + k] : 0.f;
-            const float d2 = sqdist(px, py, pz, Q[(l + u) * 3 + 0], Q[(l + u) * 3 + 1], Q[(l + u) * 3 + 2]);
-            w[u] = fast_exp2(lvl2 * d2) * rl * ratioR[l + u];
+    const float *const wl[1] = {ratioR};
+    stream_candidates<1>(Q, wl, lb, le, lane, [&](int l, float qx, float qy, float qz, const float (&ww)[1]) {
+        const float w = __fmul_rn(__fmul_rn(fast_exp2(__fmul_rn(lvl2, sqdist(px, py, pz, qx, qy, qz))), rl), ww[0]);
+        if (MODE != 2 && live) {
+            float *dst = mt + (size_t)l * n + k;
+            *dst = FIRST ? w : __fadd_rn(*dst, w);
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (MODE != 2 && live) mt[(size_t)(l + u) * n + k] = FIRST ? w[u] : old[u] + w[u];
-            suml += w[u];
-        }
-    }
-    for (; l < le; ++l) {
-        const float d2 = sqdist(px, py, pz, Q[l * 3 + 0], Q[l * 3 + 1], Q[l * 3 + 2]);
-        const float w = fast_exp2(lvl2 * d2) * rl * ratioR[l];
-        if (MODE != 2 && live) mt[(size_t)l * n + k] = FIRST ? w : mt[(size_t)l * n + k] + w;
-        suml += w;
-    }
+        suml = __fadd_rn(suml, w);
+    });
     part[slice][lane] = suml;
     __syncthreads();
     if (slice != 0 || !live) return;
@@ -166,16 +195,20 @@ __global__ __launch_bounds__(1024) void emd_materialize_kernel(int n, int m, Lev
 #pragma unroll
     for (int j = 0; j < NLEVEL; ++j) rl[j] = ws[j * lstride + (size_t)bi * rstride + kc];
     const int lb = (int)((long)m * slice / S), le = (int)((long)m * (slice + 1) / S);
-    for (int l = lb; l < le; ++l) {
-        const float d2 = sqdist(px, py, pz, Q[l * 3 + 0], Q[l * 3 + 1], Q[l * 3 + 2]);
+    const float *wl[NLEVEL];
+#pragma unroll
+    for (int j = 0; j < NLEVEL; ++j) wl[j] = ws + j * lstride + (size_t)bi * rstride + n;
+    const float *const (&wlr)[NLEVEL] = wl;
+    stream_candidates<NLEVEL>(Q, wlr, lb, le, lane, [&](int l, float qx, float qy, float qz, const float (&ww)[NLEVEL]) {
+        const float d2 = sqdist(px, py, pz, qx, qy, qz);
         float acc = 0.f;
 #pragma unroll
         for (int j = 0; j < NLEVEL; ++j) {
-            const float w = fast_exp2(lv.lvl2[j] * d2) * rl[j] * ws[j * lstride + (size_t)bi * rstride + n + l];
-            acc = j == 0 ? w : acc + w;
+            const float w = __fmul_rn(__fmul_rn(fast_exp2(__fmul_rn(lv.lvl2[j], d2)), rl[j]), ww[j]);
+            acc = j == 0 ? w : __fadd_rn(acc, w);
         }
         if (live) mt[(size_t)l * n + k] = acc;
-    }
+    });
 }
 
 // out[b] = sum_{l,k} match[b,l,k] * |xyz1[k] - xyz2[l]|                           approxmatch.cu:184-224
@@ -218,11 +251,12 @@ __global__ __launch_bounds__(1024) void emd_grad1_kernel(int n, int m, const flo
     const float px = P[kc * 3 + 0], py = P[kc * 3 + 1], pz = P[kc * 3 + 2];
     const int lb = (int)((long)m * slice / S), le = (int)((long)m * (slice + 1) / S);
     float gx = 0.f, gy = 0.f, gz = 0.f;
-    for (int l = lb; l < le; ++l) {
-        const float dx = px - Q[l * 3 + 0], dy = py - Q[l * 3 + 1], dz = pz - Q[l * 3 + 2];
+    const float *const nowl[1] = {nullptr};
+    stream_candidates<0>(Q, nowl, lb, le, lane, [&](int l, float qx, float qy, float qz, const float (&)[1]) {
+        const float dx = px - qx, dy = py - qy, dz = pz - qz;
         const float d = mt[(size_t)l * n + kc] * rsqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-20f));
         gx += dx * d; gy += dy * d; gz += dz * d;
-    }
+    });
     part[slice][0][lane] = gx; part[slice][1][lane] = gy; part[slice][2][lane] = gz;
     __syncthreads();
     if (slice != 0 || !live) return;
