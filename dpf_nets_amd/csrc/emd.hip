@@ -17,6 +17,8 @@
 
 #include "dpf_hip.h"
 
+#pragma clang fp contract(off)
+
 namespace {
 
 constexpr int MAXS = 16;   // max inner-loop slices (waves) per workgroup
@@ -25,8 +27,11 @@ constexpr int MAXS = 16;   // max inner-loop slices (waves) per workgroup
 // must produce the same bits, so nothing here is left to the compiler's contraction heuristics.
 __device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, float by, float bz) {
     const float dx = bx - ax, dy = by - ay, dz = bz - az;
-    return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
 }
+
+__device__ __forceinline__ float fmul(float a, float b) { return a * b; }   // never contracted (file is contract(off))
+__device__ __forceinline__ float fadd(float a, float b) { return a + b; }
 
 __device__ __forceinline__ float bcast(float v, int lane) {   // lane wave-uniform -> v_readlane_b32 into an SGPR
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(1024) void emd_ratio_kernel(int n, int m, float lvl
     float s = 0.f;
     const float *const wl[1] = {wq};
     stream_candidates<1>(Q, wl, jb, je, lane, [&](int, float qx, float qy, float qz, const float (&ww)[1]) {
-        s = __fmaf_rn(fast_exp2(__fmul_rn(lvl2, sqdist(px, py, pz, qx, qy, qz))), ww[0], s);
+        s = __builtin_fmaf(fast_exp2(fmul(lvl2, sqdist(px, py, pz, qx, qy, qz))), ww[0], s);
     });
     part[slice][lane] = s;
     __syncthreads();
@@ -156,12 +161,12 @@ __global__ __launch_bounds__(1024) void emd_match_kernel(int n, int m, float lvl
     float suml = 0.f;
     const float *const wl[1] = {ratioR};
     stream_candidates<1>(Q, wl, lb, le, lane, [&](int l, float qx, float qy, float qz, const float (&ww)[1]) {
-        const float w = __fmul_rn(__fmul_rn(fast_exp2(__fmul_rn(lvl2, sqdist(px, py, pz, qx, qy, qz))), rl), ww[0]);
+        const float w = fmul(fmul(fast_exp2(fmul(lvl2, sqdist(px, py, pz, qx, qy, qz))), rl), ww[0]);
         if (MODE != 2 && live) {
             float *dst = mt + (size_t)l * n + k;
-            *dst = FIRST ? w : __fadd_rn(*dst, w);
+            *dst = FIRST ? w : fadd(*dst, w);
         }
-        suml = __fadd_rn(suml, w);
+        suml = fadd(suml, w);
     });
     part[slice][lane] = suml;
     __syncthreads();
@@ -204,8 +209,8 @@ __global__ __launch_bounds__(1024) void emd_materialize_kernel(int n, int m, Lev
         float acc = 0.f;
 #pragma unroll
         for (int j = 0; j < NLEVEL; ++j) {
-            const float w = __fmul_rn(__fmul_rn(fast_exp2(__fmul_rn(lv.lvl2[j], d2)), rl[j]), ww[j]);
-            acc = j == 0 ? w : __fadd_rn(acc, w);
+            const float w = fmul(fmul(fast_exp2(fmul(lv.lvl2[j], d2)), rl[j]), ww[j]);
+            acc = j == 0 ? w : fadd(acc, w);
         }
         if (live) mt[(size_t)l * n + k] = acc;
     });
