@@ -41,6 +41,7 @@ struct NNDir {
     float *dist;      // (B, nq)
     int *idx;         // (B, nq)
     int nq, nc;
+    long qstride, cstride;   // floats between consecutive clouds (0 = one cloud broadcast over the batch)
 };
 
 struct NNArgs {
@@ -100,8 +101,8 @@ __global__ __launch_bounds__(NWAVES * 64) void nn_kernel(NNArgs args) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int qg = wave / KS, ks = wave % KS;
-    const float *__restrict__ q = A.q + (size_t)bi * nq * 3;
-    const float *__restrict__ c = A.c + (size_t)bi * nc * 3;
+    const float *__restrict__ q = A.q + (size_t)bi * A.qstride;
+    const float *__restrict__ c = A.c + (size_t)bi * A.cstride;
 
     const int j0 = (blockIdx.x * QG + qg) * QPW + lane;
     const int j1 = j0 + 64;
@@ -300,15 +301,19 @@ extern "C" int dpf_chamfer_reduce(int b, int n, int m, const float *dist1, const
     return (int)hipGetLastError();
 }
 
-extern "C" int dpf_nndistance(int b, int n, const float *xyz, int m, const float *xyz2, float *result, int *result_i,
-                              float *result2, int *result2_i, dpf_stream_t stream) {
-    if (b < 0 || n <= 0 || m <= 0) return DPF_EINVAL;
+// nndistance with explicit per-cloud strides (in floats): stride 0 broadcasts ONE cloud against a
+// whole batch, which is what pairwise_CD needs (lib/networks/utils.py:104-107 expands and copies
+// cloud i N2 times before every call).
+extern "C" int dpf_nndistance_strided(int b, int n, const float *xyz, long xyz_stride, int m, const float *xyz2,
+                                      long xyz2_stride, float *result, int *result_i, float *result2, int *result2_i,
+                                      dpf_stream_t stream) {
+    if (b < 0 || n <= 0 || m <= 0 || xyz_stride < 0 || xyz2_stride < 0) return DPF_EINVAL;
     if (b == 0) return 0;
     if (!xyz || !xyz2 || !result || !result_i || !result2 || !result2_i) return DPF_EINVAL;
     if ((long)n * 3 >= (1l << 31) || (long)m * 3 >= (1l << 31) || b > 65535) return DPF_ENOSUP;
     NNArgs a;
-    a.d[0] = NNDir{xyz, xyz2, result, result_i, n, m};     // nndistance.cu:126
-    a.d[1] = NNDir{xyz2, xyz, result2, result2_i, m, n};   // nndistance.cu:127
+    a.d[0] = NNDir{xyz, xyz2, result, result_i, n, m, xyz_stride, xyz2_stride};     // nndistance.cu:126
+    a.d[1] = NNDir{xyz2, xyz, result2, result2_i, m, n, xyz2_stride, xyz_stride};   // nndistance.cu:127
     const int nmax = n > m ? n : m;
     // pick the candidate split so that the launch has >= ~2 waves per SIMD on 256 CUs
     const long waves1 = (long)b * ((n + QPW - 1) / QPW + (m + QPW - 1) / QPW);
@@ -324,6 +329,12 @@ extern "C" int dpf_nndistance(int b, int n, const float *xyz, int m, const float
         hipLaunchKernelGGL(nn_kernel<4>, grid, dim3(NWAVES * 64), 0, s, a);
     }
     return (int)hipGetLastError();
+}
+
+extern "C" int dpf_nndistance(int b, int n, const float *xyz, int m, const float *xyz2, float *result, int *result_i,
+                              float *result2, int *result2_i, dpf_stream_t stream) {
+    return dpf_nndistance_strided(b, n, xyz, (long)n * 3, m, xyz2, (long)m * 3, result, result_i, result2, result2_i,
+                                  stream);
 }
 
 extern "C" int dpf_nndistancegrad(int b, int n, const float *xyz1, int m, const float *xyz2, const float *grad_dist1,

@@ -196,18 +196,21 @@ __global__ __launch_bounds__(256) void pack_film_kernel(int L, int G, const floa
     }
 }
 
-constexpr int FILM_CLOUDS = 8;    // clouds per workgroup: 2 sub-nets x 64 features x 4 groups x 2 clouds = 512 threads
-constexpr int FILM_CPT = FILM_CLOUDS / 4;   // clouds per thread
+constexpr int FILM_CLOUDS = 8;    // clouds per workgroup
 
+// 512 threads = 2 sub-nets (w, b) x 64 output features x 4 K-quarters.  Each thread reduces ONE
+// quarter of the contraction for all 8 clouds, so its weight loads (coalesced: feature = lane)
+// are all issued up front -- the kernel is two global round trips and two LDS reductions deep.
 __global__ __launch_bounds__(512) void film_kernel(int L, int B, int G, const float *__restrict__ fw,
                                                    const float *__restrict__ g, float *__restrict__ film, float flow_eps) {
     extern __shared__ __attribute__((aligned(16))) float fsm[];
-    float *gs = fsm;                                  // [16][G]
-    float *hid = fsm + FILM_CLOUDS * G;               // [2][16][64]
-    float *cbx = hid + 2 * FILM_CLOUDS * 64;          // [16][64]
+    float *gs = fsm;                                  // [8][G]
+    float *part = fsm + FILM_CLOUDS * G;              // [2 sub][4 kq][8 clouds][64]
+    float *hid = part + 2 * 4 * FILM_CLOUDS * 64;     // [2][8][64]
+    float *cbx = hid + 2 * FILM_CLOUDS * 64;          // [8][64]
     const int l = blockIdx.x >> 1, br = blockIdx.x & 1;
     const int b0 = blockIdx.y * FILM_CLOUDS;
-    const int tid = threadIdx.x, sub = tid >> 8, f = tid & 63, cg = (tid >> 6) & 3;
+    const int tid = threadIdx.x, sub = tid >> 8, f = tid & 63, kq = (tid >> 6) & 3;
     const float *w = fw + (size_t)((l * 2 + br) * 2 + sub) * fw_sub_floats(G);
     const float *WT = w, *sc = w + 64 * G, *sh = sc + 64, *W1T = sh + 64, *bf1 = W1T + 4096;
     for (int e = tid; e < FILM_CLOUDS * G / 4; e += 512) {            // g rows of this workgroup's clouds
@@ -216,48 +219,72 @@ __global__ __launch_bounds__(512) void film_kernel(int L, int B, int G, const fl
         if (b0 + row < B) v = *(const f32x4 *)(g + (size_t)(b0 + row) * G + c4);
         *(f32x4 *)(gs + row * G + c4) = v;
     }
-    __syncthreads();
-    float acc[FILM_CPT];
+    float acc[FILM_CLOUDS];
 #pragma unroll
-    for (int c = 0; c < FILM_CPT; ++c) acc[c] = 0.f;
-    const float *g0 = gs + (cg * FILM_CPT) * G;
-#pragma unroll 8
-    for (int k = 0; k < G; k += 4) {                                  // u = g . Wf0^T        flows.py:34/41
-        const float w0 = WT[(k + 0) * 64 + f], w1 = WT[(k + 1) * 64 + f], w2 = WT[(k + 2) * 64 + f], w3 = WT[(k + 3) * 64 + f];
+    for (int c = 0; c < FILM_CLOUDS; ++c) acc[c] = 0.f;
+    const int kspan = G / 4, k0 = kq * kspan;                         // G % 16 == 0
+    for (int kk = 0; kk < kspan; kk += 32) {                          // u = g . Wf0^T        flows.py:34/41
+        float wv[32];
 #pragma unroll
-        for (int c = 0; c < FILM_CPT; ++c) {
-            const f32x4 x = *(const f32x4 *)(g0 + c * G + k);
-            acc[c] += w0 * x.x + w1 * x.y + w2 * x.z + w3 * x.w;
-        }
-    }
-    {   // BatchNorm1d over the batch dim in eval mode (flows.py:35/42), then Swish (layers.py:9-10)
-        const float a = sc[f], d = sh[f];
+        for (int i = 0; i < 32; ++i) wv[i] = kk + i < kspan ? WT[(size_t)(k0 + kk + i) * 64 + f] : 0.f;
+        if (kk == 0) __syncthreads();                                 // gs visible (loads above already in flight)
 #pragma unroll
-        for (int c = 0; c < FILM_CPT; ++c) {
-            const float u = acc[c] * a + d;
-            hid[(sub * FILM_CLOUDS + cg * FILM_CPT + c) * 64 + f] = u / (1.0f + expf(-u));
-        }
-    }
-    __syncthreads();
-    float v[FILM_CPT];
-    {
-        const float bias = bf1[f];
+        for (int i = 0; i < 32; i += 4) {
+            if (kk + i < kspan) {
 #pragma unroll
-        for (int c = 0; c < FILM_CPT; ++c) v[c] = bias;
-        const float *h0 = hid + (sub * FILM_CLOUDS + cg * FILM_CPT) * 64;
-#pragma unroll 16
-        for (int k = 0; k < 64; k += 4) {                             // Linear(F, F) + bias   flows.py:37/44
-            const float w0 = W1T[(k + 0) * 64 + f], w1 = W1T[(k + 1) * 64 + f], w2 = W1T[(k + 2) * 64 + f], w3 = W1T[(k + 3) * 64 + f];
-#pragma unroll
-            for (int c = 0; c < FILM_CPT; ++c) {
-                const f32x4 x = *(const f32x4 *)(h0 + c * 64 + k);
-                v[c] += w0 * x.x + w1 * x.y + w2 * x.z + w3 * x.w;
+                for (int c = 0; c < FILM_CLOUDS; ++c) {
+                    const f32x4 x = *(const f32x4 *)(gs + c * G + k0 + kk + i);
+                    acc[c] += wv[i] * x.x + wv[i + 1] * x.y + wv[i + 2] * x.z + wv[i + 3] * x.w;
+                }
             }
         }
     }
-    if (sub == 1) {
+    float w1[16];
 #pragma unroll
-        for (int c = 0; c < FILM_CPT; ++c) cbx[(cg * FILM_CPT + c) * 64 + f] = v[c];
+    for (int i = 0; i < 16; ++i) w1[i] = W1T[(kq * 16 + i) * 64 + f];  // second layer's weights: in flight early
+#pragma unroll
+    for (int c = 0; c < FILM_CLOUDS; ++c) part[((sub * 4 + kq) * FILM_CLOUDS + c) * 64 + f] = acc[c];
+    __syncthreads();
+    {   // BatchNorm1d over the batch dim in eval mode (flows.py:35/42), then Swish (layers.py:9-10)
+        const float a = sc[f], d = sh[f];
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const int c = kq * 2 + cc;
+            float u = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) u += part[((sub * 4 + q) * FILM_CLOUDS + c) * 64 + f];
+            u = u * a + d;
+            hid[(sub * FILM_CLOUDS + c) * 64 + f] = u / (1.0f + expf(-u));
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < FILM_CLOUDS; ++c) {                           // Linear(F, F)          flows.py:37/44
+        const float *h0 = hid + (sub * FILM_CLOUDS + c) * 64 + kq * 16;
+        float a2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; i += 4) {
+            const f32x4 x = *(const f32x4 *)(h0 + i);
+            a2 += w1[i] * x.x + w1[i + 1] * x.y + w1[i + 2] * x.z + w1[i + 3] * x.w;
+        }
+        acc[c] = a2;
+    }
+    __syncthreads();                                                  // everyone is done reading part (phase 1)
+#pragma unroll
+    for (int c = 0; c < FILM_CLOUDS; ++c) part[((sub * 4 + kq) * FILM_CLOUDS + c) * 64 + f] = acc[c];
+    __syncthreads();
+    float v[2];
+    {
+        const float bias = bf1[f];
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const int c = kq * 2 + cc;
+            float t = bias;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t += part[((sub * 4 + q) * FILM_CLOUDS + c) * 64 + f];
+            v[cc] = t;
+            if (sub == 1) cbx[c * 64 + f] = t;
+        }
     }
     __syncthreads();
     if (sub == 1) return;
@@ -266,11 +293,11 @@ __global__ __launch_bounds__(512) void film_kernel(int L, int B, int G, const fl
     const float *cst = fw + (size_t)L * 4 * fw_sub_floats(G) + (size_t)(l * 2 + br) * 320;
     const float s1 = cst[f], t1 = cst[64 + f], w2a = cst[128 + f], w2b = cst[192 + f];
 #pragma unroll
-    for (int c = 0; c < FILM_CPT; ++c) {
-        const int b = b0 + cg * FILM_CPT + c;
+    for (int cc = 0; cc < 2; ++cc) {
+        const int c = kq * 2 + cc, b = b0 + c;
         if (b >= B) continue;
-        const float a = flow_eps + expf(v[c]);
-        const float FA = a * s1, FC = a * t1 + cbx[(cg * FILM_CPT + c) * 64 + f];
+        const float a = flow_eps + expf(v[cc]);
+        const float FA = a * s1, FC = a * t1 + cbx[c * 64 + f];
         float *o = film + ((size_t)l * B + b) * (FILM_BYTES / 4) + br * FILM_BR_FLOATS;
         o[f] = FC / FA;
         o[64 + 2 * f] = w2a * FA;
@@ -594,9 +621,9 @@ extern "C" int dpf_flow_film(int n_layers, int B, int G, int precision, const vo
     if (!ns || n_layers < 0 || B < 0 || G <= 0) return DPF_EINVAL;
     if (n_layers == 0 || B == 0) return 0;
     if (!packed || !g || !film) return DPF_EINVAL;
-    if (G % 4 != 0 || G > 2048) return DPF_ENOSUP;
+    if (G % 16 != 0 || G > 2048) return DPF_ENOSUP;
     const float *fw = (const float *)((const uint8_t *)packed + (size_t)n_layers * p_layer_bytes(ns));
-    const int lds = (FILM_CLOUDS * G + 3 * FILM_CLOUDS * 64) * (int)sizeof(float);
+    const int lds = (FILM_CLOUDS * G + (2 * 4 + 2 + 1) * FILM_CLOUDS * 64) * (int)sizeof(float);
     static int attr_lds = 0;
     if (lds > 65536 && lds > attr_lds) {
         hipError_t e = hipFuncSetAttribute((const void *)film_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

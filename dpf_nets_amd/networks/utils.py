@@ -37,15 +37,33 @@ def f_score(predicted_clouds, true_clouds, threshold=0.001):
 
 
 def pairwise_CD(clouds1, clouds2, bs=2048):
-    """(N1, N2) matrix of Chamfer distances; row i = cloud1[i] against every cloud2."""
-    N1, N2 = clouds1.shape[0], clouds2.shape[0]
-    cds = torch.zeros((N1, N2), dtype=torch.float32, device=clouds1.device)
-    for i in range(N1):
-        for j_l in range(0, N2, bs):
-            j_u = min(N2, j_l + bs)
-            c1 = clouds1[i].unsqueeze(0).expand(j_u - j_l, -1, -1).contiguous()
-            dl, dr = distChamferCUDA(c1, clouds2[j_l:j_u].contiguous())
-            cds[i, j_l:j_u] = dl.mean(dim=1) + dr.mean(dim=1)
+    """(N1, N2) matrix of Chamfer distances, cds[i, j] = CD(clouds1[i], clouds2[j])
+    (lib/networks/utils.py:90-117).  Row i is ONE strided Chamfer launch -- cloud i is broadcast
+    against the batch by a zero stride instead of being expanded and copied N2 times -- plus one
+    reduction launch; results are those of the reference's expand-and-call loop."""
+    from .._lib import lib, check, current_stream
+    if not (clouds1.is_cuda and clouds2.is_cuda):
+        raise RuntimeError("pairwise_CD needs CUDA tensors")
+    clouds1, clouds2 = clouds1.contiguous(), clouds2.contiguous()
+    N1, n = clouds1.shape[0], clouds1.shape[1]
+    N2, m = clouds2.shape[0], clouds2.shape[1]
+    dev = clouds1.device
+    cds = torch.empty((N1, N2), dtype=torch.float32, device=dev)
+    bs = max(1, min(bs, N2))
+    d1 = torch.empty((bs, n), dtype=torch.float32, device=dev)
+    d2 = torch.empty((bs, m), dtype=torch.float32, device=dev)
+    i1 = torch.empty((bs, n), dtype=torch.int32, device=dev)
+    i2 = torch.empty((bs, m), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        st = current_stream()
+        for i in range(N1):
+            for j_l in range(0, N2, bs):
+                nb = min(N2, j_l + bs) - j_l
+                check(lib().dpf_nndistance_strided(nb, n, clouds1[i].data_ptr(), 0, m, clouds2[j_l].data_ptr(), m * 3,
+                                                   d1.data_ptr(), i1.data_ptr(), d2.data_ptr(), i2.data_ptr(), st),
+                      "nndistance_strided")
+                check(lib().dpf_chamfer_reduce(nb, n, m, d1.data_ptr(), d2.data_ptr(),
+                                               cds[i, j_l:j_l + nb].data_ptr(), st), "chamfer_reduce")
     return cds
 
 

@@ -42,6 +42,13 @@ int dpf_nndistance(int b, int n, const float *xyz, int m, const float *xyz2,
                    float *result, int *result_i, float *result2, int *result2_i,
                    dpf_stream_t stream);
 
+/* dpf_nndistance with explicit strides (in floats) between consecutive clouds of
+ * each set; stride 0 broadcasts one cloud over the batch -- the "expand +
+ * contiguous" copy of pairwise_CD (lib/networks/utils.py:104-107) disappears. */
+int dpf_nndistance_strided(int b, int n, const float *xyz, long xyz_stride, int m,
+                           const float *xyz2, long xyz2_stride, float *result, int *result_i,
+                           float *result2, int *result2_i, dpf_stream_t stream);
+
 /* Same results as dpf_nndistance, bit for bit (distances AND first-minimum
  * indices), but prunes: clouds are sorted by x once and every query wave scans
  * only the sorted candidates that can still win or tie.  `workspace` is

@@ -148,3 +148,28 @@ def test_input_checks_mirror_reference():
     c = torch.zeros(2, 3, 8, device="cuda").transpose(1, 2)
     with pytest.raises(RuntimeError):
         BK.NNDistance(c, c)                                    # non-contiguous: CHECK_CONTIGUOUS
+
+
+def test_pairwise_cd_and_fscore_match_the_expand_and_call_form():
+    """utils.py:38-42 (f_score) and :90-117 (pairwise_CD) against the reference's own formulation
+    evaluated with the oracle."""
+    _gpu()
+    from dpf_nets_amd.networks.utils import pairwise_CD, f_score, chamfer_distance
+    N1, N2, n, m = 5, 7, 130, 200
+    a, _ = chamfer_inputs(301, N1, n, n)
+    b, _ = chamfer_inputs(302, N2, m, m)
+    cds = pairwise_CD(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), bs=4).cpu().numpy()
+    ref = np.zeros((N1, N2), np.float32)
+    for i in range(N1):
+        ai = np.ascontiguousarray(np.broadcast_to(a[i], (N2, n, 3)))       # utils.py:104-105
+        d1, _, d2, _ = S.nndistance(ai, b)
+        ref[i] = d1.mean(1) + d2.mean(1)
+    np.testing.assert_allclose(cds, ref, rtol=2e-6)
+    p, t = chamfer_inputs(303, 4, 300, 300)
+    p = (t + 0.01 * p).astype(np.float32)
+    f1 = f_score(torch.from_numpy(p).cuda(), torch.from_numpy(t).cuda(), threshold=0.001).cpu().numpy()
+    ld, _, rd, _ = S.nndistance(p, t)
+    prec, rec = 100.0 * (rd < 0.001).mean(1), 100.0 * (ld < 0.001).mean(1)
+    np.testing.assert_allclose(f1, 2 * prec * rec / (prec + rec + 1e-7), rtol=1e-5)
+    cd = chamfer_distance(torch.from_numpy(p).cuda(), torch.from_numpy(t).cuda())
+    np.testing.assert_allclose(float(cd), float((ld.mean(1) + rd.mean(1)).mean()), rtol=1e-5)
