@@ -234,7 +234,8 @@ __global__ __launch_bounds__(512) void film_kernel(int L, int B, int G, const fl
 #pragma unroll
                 for (int c = 0; c < FILM_CLOUDS; ++c) {
                     const f32x4 x = *(const f32x4 *)(gs + c * G + k0 + kk + i);
-                    acc[c] += wv[i] * x.x + wv[i + 1] * x.y + wv[i + 2] * x.z + wv[i + 3] * x.w;
+                    // explicit fma chain: the same bits for a cloud wherever it sits in the batch
+                    acc[c] = __builtin_fmaf(wv[i + 3], x.w, __builtin_fmaf(wv[i + 2], x.z, __builtin_fmaf(wv[i + 1], x.y, __builtin_fmaf(wv[i], x.x, acc[c]))));
                 }
             }
         }
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(512) void film_kernel(int L, int B, int G, const fl
 #pragma unroll
         for (int i = 0; i < 16; i += 4) {
             const f32x4 x = *(const f32x4 *)(h0 + i);
-            a2 += w1[i] * x.x + w1[i + 1] * x.y + w1[i + 2] * x.z + w1[i + 3] * x.w;
+            a2 = __builtin_fmaf(w1[i + 3], x.w, __builtin_fmaf(w1[i + 2], x.z, __builtin_fmaf(w1[i + 1], x.y, __builtin_fmaf(w1[i], x.x, a2))));
         }
         acc[c] = a2;
     }
