@@ -657,7 +657,13 @@ extern "C" int dpf_flow_forward(int n_layers, int B, int N, int mode, int precis
     hipError_t e = hipSuccess;
     // 8-wave workgroups (256 points of one cloud) unless that leaves CUs without a workgroup
     static const int force_fw = getenv("DPF_FLOW_WAVES") ? atoi(getenv("DPF_FLOW_WAVES")) : 0;
-    const int fw = force_fw ? force_fw : (((long)B * ((N + 255) / 256) >= 200) ? 8 : 4);
+    // waves (32-point tiles) per workgroup: as many as possible (each workgroup streams the layer
+    // weights through its own LDS) while the launch still has a workgroup for every CU
+    int fw = force_fw;
+    if (!fw) {
+        fw = 8;
+        while (fw > 1 && (long)B * ((N + TILE * fw - 1) / (TILE * fw)) < 224) fw >>= 1;
+    }
 #define DPF_LAUNCH(NSV, FWV)                                                                                    \
     {                                                                                                           \
         const int lds = 2 * (p_layer_bytes(NSV) + FILM_BYTES);                                                  \
@@ -670,15 +676,17 @@ extern "C" int dpf_flow_forward(int n_layers, int B, int N, int mode, int precis
         const dim3 grid((N + TILE * FWV - 1) / (TILE * FWV), B), block(FWV * 64);                               \
         hipLaunchKernelGGL((flow_kernel<NSV, FWV>), grid, block, lds, s, a);                                    \
     }
-    if (fw == 8) {
-        if (ns == 1) DPF_LAUNCH(1, 8)
-        if (ns == 2) DPF_LAUNCH(2, 8)
-        if (ns == 3) DPF_LAUNCH(3, 8)
-    } else {
-        if (ns == 1) DPF_LAUNCH(1, 4)
-        if (ns == 2) DPF_LAUNCH(2, 4)
-        if (ns == 3) DPF_LAUNCH(3, 4)
+#define DPF_LAUNCH_FW(FWV)                 \
+    {                                      \
+        if (ns == 1) DPF_LAUNCH(1, FWV)    \
+        if (ns == 2) DPF_LAUNCH(2, FWV)    \
+        if (ns == 3) DPF_LAUNCH(3, FWV)    \
     }
+    if (fw >= 8) DPF_LAUNCH_FW(8)
+    else if (fw >= 4) DPF_LAUNCH_FW(4)
+    else if (fw >= 2) DPF_LAUNCH_FW(2)
+    else DPF_LAUNCH_FW(1)
+#undef DPF_LAUNCH_FW
 #undef DPF_LAUNCH
     return (int)hipGetLastError();
 }
