@@ -659,10 +659,14 @@ extern "C" int dpf_flow_forward(int n_layers, int B, int N, int mode, int precis
     static const int force_fw = getenv("DPF_FLOW_WAVES") ? atoi(getenv("DPF_FLOW_WAVES")) : 0;
     // waves (32-point tiles) per workgroup: as many as possible (each workgroup streams the layer
     // weights through its own LDS) while the launch still has a workgroup for every CU
+    // (measured r01: below 4 waves the LDS-DMA fill of a layer, ~1.5 us for 38 KB on one CU, is no
+    // longer hidden, so 2- and 1-wave workgroups are only for clouds of <= 64 / <= 32 points)
     int fw = force_fw;
     if (!fw) {
         fw = 8;
-        while (fw > 1 && (long)B * ((N + TILE * fw - 1) / (TILE * fw)) < 224) fw >>= 1;
+        if ((long)B * ((N + 255) / 256) < 224) fw = 4;
+        if (N <= 64) fw = 2;
+        if (N <= 32) fw = 1;
     }
 #define DPF_LAUNCH(NSV, FWV)                                                                                    \
     {                                                                                                           \
