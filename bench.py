@@ -119,16 +119,19 @@ def kernel_timings(dec, z, g, tgt_pm, L, precision):
     d1 = torch.empty((B, N), dtype=torch.float32, device=z.device); d2 = torch.empty_like(d1)
     i1 = torch.empty((B, N), dtype=torch.int32, device=z.device); i2 = torch.empty_like(i1)
 
-    nws = lib().dpf_nndistance_workspace_bytes(B, N, N)
+    impl = BK.NN_IMPL
+    sized, fn = {"mfma": (lib().dpf_nndistance_mfma_workspace_bytes, lib().dpf_nndistance_mfma),
+                 "sorted": (lib().dpf_nndistance_workspace_bytes, lib().dpf_nndistance_ws)}.get(impl, (None, None))
+    nws = sized(B, N, N) if sized else 0
     ws = torch.empty((max(nws, 16),), dtype=torch.uint8, device=z.device)
 
     def k_nn():
-        if BK.BRUTE_FORCE:
+        if impl == "brute":
             lib().dpf_nndistance(B, N, pm.data_ptr(), N, tgt_pm.data_ptr(), d1.data_ptr(), i1.data_ptr(),
                                  d2.data_ptr(), i2.data_ptr(), st)
         else:
-            lib().dpf_nndistance_ws(B, N, pm.data_ptr(), N, tgt_pm.data_ptr(), d1.data_ptr(), i1.data_ptr(),
-                                    d2.data_ptr(), i2.data_ptr(), ws.data_ptr(), nws, st)
+            fn(B, N, pm.data_ptr(), N, tgt_pm.data_ptr(), d1.data_ptr(), i1.data_ptr(), d2.data_ptr(), i2.data_ptr(),
+               ws.data_ptr(), nws, st)
     k_film(); k_flow(); k_nn()
     torch.cuda.synchronize()
     return {"film_kernel": time_kernel(k_film), "flow_kernel": time_kernel(k_flow), "nn_kernel": time_kernel(k_nn)}

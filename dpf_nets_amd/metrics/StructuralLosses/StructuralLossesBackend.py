@@ -12,13 +12,11 @@ import torch
 from ..._lib import lib, check, current_stream
 
 
-# The O(n*m) brute-force kernel is the default: it runs at ~75 % of its VALU issue bound and its
-# cost does not depend on the data.  DPF_CHAMFER_PRUNED=1 selects the x-sorted pruned search
-# (bit-identical results; pays off only when both clouds cover the same region -- r01 measurement on
-# the synthetic benchmark clouds: 170 us vs 50 us).
-BRUTE_FORCE = not bool(int(os.environ.get("DPF_CHAMFER_PRUNED", "0")))
-
-
+# Chamfer forward implementation; all three return identical bits (tests/test_gpu_chamfer.py):
+#   "mfma"   matrix-core filter + exact verification of the few candidates that can win (default)
+#   "brute"  O(n*m) exact VALU scan, data-independent cost
+#   "sorted" x-sorted pruned exact scan (pays off only when both clouds cover the same region)
+NN_IMPL = os.environ.get("DPF_CHAMFER_IMPL", "mfma")
 EMD_RMW = bool(int(os.environ.get("DPF_EMD_RMW", "0")))   # 1: the reference's per-level read-modify-write of `match`
 
 
@@ -49,16 +47,16 @@ def NNDistance(set_d, set_q):
     dist2 = torch.empty((b, m), dtype=torch.float32, device=dev)
     idx2 = torch.empty((b, m), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        if BRUTE_FORCE:
-            check(lib().dpf_nndistance(b, n, set_d.data_ptr(), m, set_q.data_ptr(), dist1.data_ptr(),
-                                       idx1.data_ptr(), dist2.data_ptr(), idx2.data_ptr(), current_stream()),
-                  "nndistance")
-        else:   # same bits, pruned search; scratch is caller-owned like every other buffer
-            nbytes = lib().dpf_nndistance_workspace_bytes(b, n, m)
+        args = (b, n, set_d.data_ptr(), m, set_q.data_ptr(), dist1.data_ptr(), idx1.data_ptr(), dist2.data_ptr(),
+                idx2.data_ptr())
+        if NN_IMPL == "brute":
+            check(lib().dpf_nndistance(*args, current_stream()), "nndistance")
+        else:   # same bits; scratch is caller-owned like every other buffer
+            sized, fn = ((lib().dpf_nndistance_mfma_workspace_bytes, lib().dpf_nndistance_mfma) if NN_IMPL == "mfma"
+                         else (lib().dpf_nndistance_workspace_bytes, lib().dpf_nndistance_ws))
+            nbytes = sized(b, n, m)
             ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
-            check(lib().dpf_nndistance_ws(b, n, set_d.data_ptr(), m, set_q.data_ptr(), dist1.data_ptr(),
-                                          idx1.data_ptr(), dist2.data_ptr(), idx2.data_ptr(), ws.data_ptr(), nbytes,
-                                          current_stream()), "nndistance_ws")
+            check(fn(*args, ws.data_ptr(), nbytes, current_stream()), "nndistance_" + NN_IMPL)
     return [dist1, idx1, dist2, idx2]
 
 

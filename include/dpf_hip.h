@@ -60,6 +60,17 @@ int dpf_nndistance_ws(int b, int n, const float *xyz, int m, const float *xyz2,
                       float *result, int *result_i, float *result2, int *result2_i,
                       void *workspace, size_t workspace_bytes, dpf_stream_t stream);
 
+/* Same results as dpf_nndistance, bit for bit, matrix-core filtered: one bf16
+ * MFMA per 32x32 pairs bounds every distance to within 2^-14*R2, and only the
+ * candidates that can still be the fp32-exact minimiser (or tie with it) are
+ * evaluated with the exact formula.  `workspace`: caller-owned scratch of
+ * dpf_nndistance_mfma_workspace_bytes(b, n, m) bytes (64 B per point).  NULL /
+ * short workspace, or both clouds under 32 points -> the brute-force kernel. */
+size_t dpf_nndistance_mfma_workspace_bytes(int b, int n, int m);
+int dpf_nndistance_mfma(int b, int n, const float *xyz, int m, const float *xyz2,
+                        float *result, int *result_i, float *result2, int *result2_i,
+                        void *workspace, size_t workspace_bytes, dpf_stream_t stream);
+
 /* replaces nndistancegrad(...)  src/nndistance.cuh:2, nndistance.cu:149-154.
  * grad_xyz1 / grad_xyz2 are fully overwritten (the zero-fill happens on
  * `stream`, not on the null stream as at nndistance.cu:150-151). */

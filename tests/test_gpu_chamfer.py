@@ -19,13 +19,16 @@ def _gpu():
     return BK
 
 
-def _run(BK, a, b, brute=False):
-    old = BK.BRUTE_FORCE
-    BK.BRUTE_FORCE = brute
+IMPLS = ["mfma", "brute", "sorted"]
+
+
+def _run(BK, a, b, impl=None):
+    old = BK.NN_IMPL
+    BK.NN_IMPL = impl or old
     try:
         d1, i1, d2, i2 = BK.NNDistance(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
     finally:
-        BK.BRUTE_FORCE = old
+        BK.NN_IMPL = old
     torch.cuda.synchronize()
     return d1.cpu().numpy(), i1.cpu().numpy(), d2.cpu().numpy(), i2.cpu().numpy()
 
@@ -46,17 +49,19 @@ SHAPES = [(3, 257, 257), (2, 130, 515), (1, 1, 1), (2, 7, 3), (1, 64, 8), (5, 12
           (32, 2048, 2048), (48, 2500, 2048), (64, 2048, 2048)]
 
 
-@pytest.mark.parametrize("brute", [False, True], ids=["pruned", "brute"])
+@pytest.mark.parametrize("impl", IMPLS)
 @pytest.mark.parametrize("shape", SHAPES)
-def test_nndistance_bit_exact_vs_oracle(shape, brute):
+def test_nndistance_bit_exact_vs_oracle(shape, impl):
     BK = _gpu()
     B, n, m = shape
     a, b = chamfer_inputs(1000 + n + m, B, n, m)
-    _assert_bit_exact(_run(BK, a, b, brute), S.nndistance(a, b), shape)
+    _assert_bit_exact(_run(BK, a, b, impl), S.nndistance(a, b), shape)
 
 
-@pytest.mark.parametrize("kind", ["same_x", "two_planes", "line", "clustered", "surface"])
-def test_pruned_search_adversarial_distributions(kind):
+@pytest.mark.parametrize("impl", ["mfma", "sorted"])
+@pytest.mark.parametrize("kind", ["same_x", "two_planes", "line", "clustered", "surface", "far_offset", "all_equal",
+                                  "big_coords"])
+def test_pruned_search_adversarial_distributions(kind, impl):
     """Distributions that stress the x-sorted pruning: identical x (no pruning possible, must still
     be exact), duplicated planes (massive exact ties in dx), clusters, a thin surface."""
     BK = _gpu()
@@ -73,7 +78,13 @@ def test_pruned_search_adversarial_distributions(kind):
         a = (np.round(a * 4) / 4 + a * 0.01).astype(np.float32); b = (np.round(b * 4) / 4 + b * 0.01).astype(np.float32)
     elif kind == "surface":
         a[..., 2] = np.sin(a[..., 0] * 9) * 0.1; b[..., 2] = np.sin(b[..., 0] * 9) * 0.1
-    _assert_bit_exact(_run(BK, a, b), S.nndistance(a, b), kind)
+    elif kind == "far_offset":          # clouds far from the origin: |p|^2 >> d, the filter's window is wide
+        a += np.float32(37.0); b += np.float32(37.0)
+    elif kind == "all_equal":           # every candidate ties: queue overflow -> exact rescan path
+        b[:] = b[:, :1]
+    elif kind == "big_coords":
+        a *= np.float32(1000.0); b *= np.float32(1000.0)
+    _assert_bit_exact(_run(BK, a, b, impl), S.nndistance(a, b), kind)
 
 
 def test_nndistance_first_minimum_on_exact_ties():
@@ -85,7 +96,8 @@ def test_nndistance_first_minimum_on_exact_ties():
     b[:, 520:530] = b[:, 3:13]
     got = _run(BK, a, b)
     _assert_bit_exact(got, S.nndistance(a, b), "ties")
-    _assert_bit_exact(_run(BK, a, b, brute=True), S.nndistance(a, b), "ties-brute")
+    for impl in IMPLS:
+        _assert_bit_exact(_run(BK, a, b, impl), S.nndistance(a, b), "ties-" + impl)
     dd = ((a[:, :, None, :] - b[:, None, :, :]) ** 2).sum(-1)
     assert np.array_equal(got[1], dd.argmin(2)) and np.array_equal(got[3], dd.argmin(1))
 
