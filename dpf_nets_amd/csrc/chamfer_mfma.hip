@@ -12,13 +12,16 @@
 // terms per coordinate) and a 3-way split of |c|^2 against 1.  s differs from
 // the true distance by at most E = 2^-14 * R2 (R2 = largest squared norm of the
 // two clouds; derivation in DESIGN.md 4.3), so the fp32-exact minimiser -- and
-// every exact tie -- has s <= s_min + tau with tau = 2^-12 * R2.  Two sweeps:
-//   1. s_min per query (v_min3 over the accumulator fragment: 0.5 VALU op/pair);
-//   2. candidates tiles whose tile minimum is <= s_min + tau are queued per lane
-//      (a handful per query) and only THOSE are evaluated with the exact formula
-//      and the (d, index) lexicographic rule.
-// A queue overflow (pathological data: thousands of near-ties) makes the wave
-// rescan everything exactly, so the result is exact for any finite input.
+// every exact tie -- has s <= s_min + tau with tau = 2^-12 * R2.  ONE sweep over
+// the candidate tiles: per tile one MFMA and a v_min3 tree over the accumulator
+// fragment (0.5 VALU op per pair); a tile whose minimum is within tau of the
+// RUNNING minimum is queued per lane (the running minimum only decreases, so the
+// queue is a superset of what the final threshold selects: ~ln(#tiles) record
+// lows plus near-ties).  Afterwards the queue is filtered with the final s_min
+// and only those few tiles are evaluated with the exact formula and the
+// (d, index) lexicographic rule.  A queue overflow (pathological data: thousands
+// of near-ties) makes the wave rescan everything exactly, so the result is exact
+// for any finite input.
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <stdint.h>
@@ -35,7 +38,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int QW = 8;            // waves per workgroup, 32 queries each
 constexpr int CHUNK = 16;        // candidate tiles (of 32) staged in LDS per step
-constexpr int QCAP = 12;         // queued candidate tiles per lane before the exact-rescan fallback
+constexpr int QCAP = 16;         // queued candidate tiles per lane before the exact-rescan fallback
 
 __device__ __forceinline__ uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
 __device__ __forceinline__ float u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
@@ -59,9 +62,11 @@ __host__ __device__ inline int tiles_of(int n) { return (n + 31) / 32; }
 struct PrepSet {
     const float *xyz;   // (B, n, 3)
     uint4 *fa, *fb;     // (B, ntiles, 64)
+    float *tmax;        // (B, ntiles) largest |p|^2 of each tile
+    float4 *pts;        // (B, ntiles*32) points as (x, y, z, 0): one 16-byte load per exact evaluation
     int n;
 };
-struct PrepArgs { PrepSet s[2]; unsigned *r2bits; };   // r2bits: (B,) max |p|^2 over both clouds, float bits
+struct PrepArgs { PrepSet s[2]; };
 
 __global__ __launch_bounds__(256) void nnm_prep_kernel(PrepArgs args) {
     const PrepSet S = args.s[blockIdx.z];
@@ -106,20 +111,21 @@ __global__ __launch_bounds__(256) void nnm_prep_kernel(PrepArgs args) {
     const size_t off = ((size_t)bi * tiles_of(n) + tile) * 64 + lane;
     S.fa[off] = oa;
     S.fb[off] = ob;
-    // cloud-pair bound R2 (non-negative floats order like their bit patterns)
     float m = live ? w : 0.f;
     for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
-    if (lane == 0) atomicMax(args.r2bits + bi, f2u(m));
+    if (lane == 0) S.tmax[(size_t)bi * tiles_of(n) + tile] = m;
+    if (h == 0) S.pts[((size_t)bi * tiles_of(n) + tile) * 32 + i] = make_float4(x, y, z, 0.f);
 }
 
 struct MDir {
-    const float *q, *c;        // original clouds (B, nq, 3), (B, nc, 3)
+    const float4 *qp, *cp;     // packed points of the query / candidate cloud
     const uint4 *qfb, *cfa;    // query fragments (role B), candidate fragments (role A)
+    const float *qtmax, *ctmax;
     float *dist;
     int *idx;
     int nq, nc;
 };
-struct MArgs { MDir d[2]; const unsigned *r2bits; };
+struct MArgs { MDir d[2]; };
 
 __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b) {
     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -137,25 +143,30 @@ __device__ __forceinline__ float dist3(float cx, float cy, float cz, float qx, f
     return (dx * dx + dy * dy) + dz * dz;
 }
 // exact evaluation of the 16 candidates this lane half sees in candidate tile `t`
-__device__ __forceinline__ void exact_tile(const float *__restrict__ c, int nc, int t, int h, float qx, float qy, float qz,
+// (accumulator rows (r&3) + 8(r>>2) + 4h); ascending k, so ties keep the lowest index
+__device__ __forceinline__ void exact_tile(const float4 *__restrict__ cp, int nc, int t, int h, float qx, float qy, float qz,
                                            float &best, int &bidx) {
+    float4 v[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * g + e] = cp[(size_t)t * 32 + 8 * g + 4 * h + e];     // padded: always in range
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int k = t * 32 + 8 * g + 4 * h + e;          // accumulator row (r&3) + 8(r>>2) + 4h
-            if (k < nc) {
-                const float d = dist3(c[(size_t)k * 3 + 0], c[(size_t)k * 3 + 1], c[(size_t)k * 3 + 2], qx, qy, qz);
-                const bool better = d < best || (d == best && k < bidx);
-                best = better ? d : best;
-                bidx = better ? k : bidx;
-            }
+            const int k = t * 32 + 8 * g + 4 * h + e;
+            const float d = dist3(v[4 * g + e].x, v[4 * g + e].y, v[4 * g + e].z, qx, qy, qz);
+            const bool better = k < nc && (d < best || (d == best && k < bidx));
+            best = better ? d : best;
+            bidx = better ? k : bidx;
         }
 }
 
 __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
     __shared__ __attribute__((aligned(16))) uint4 stage[2][CHUNK * 64];      // 2 x 16 KB of candidate fragments
-    __shared__ int queue[QW][QCAP][64];
+    __shared__ int qtile[QW][QCAP][64];
+    __shared__ float qmin[QW][QCAP][64];
     const MDir A = args.d[blockIdx.z];
     const int bi = blockIdx.y;
     const int nq = A.nq, nc = A.nc;
@@ -165,14 +176,18 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
     const int qt = blockIdx.x * QW + wave;                                   // query tile of this wave
     const int nqt = tiles_of(nq), nct = tiles_of(nc);
     const bool wave_live = qt < nqt;
-    const float *__restrict__ q = A.q + (size_t)bi * nq * 3;
-    const float *__restrict__ c = A.c + (size_t)bi * nc * 3;
+    const float4 *__restrict__ cp = A.cp + (size_t)bi * nct * 32;
     const uint4 *__restrict__ cfa = A.cfa + (size_t)bi * nct * 64;
     const int j = qt * 32 + (lane & 31);
-    const int jc = min(j, nq - 1);
-    const float qx = q[jc * 3 + 0], qy = q[jc * 3 + 1], qz = q[jc * 3 + 2];
+    const float4 qv = A.qp[(size_t)bi * nqt * 32 + min(qt, nqt - 1) * 32 + (lane & 31)];
+    const float qx = qv.x, qy = qv.y, qz = qv.z;
     const uint4 bq = A.qfb[((size_t)bi * nqt + min(qt, nqt - 1)) * 64 + lane];
-    const float tau = u2f(args.r2bits[bi]) * 2.44140625e-4f;                  // 2^-12 * R2
+    // R2 = largest |p|^2 of the two clouds (per-tile maxima from the prep kernel)
+    float r2 = 0.f;
+    for (int t = lane; t < nqt; t += 64) r2 = fmaxf(r2, A.qtmax[(size_t)bi * nqt + t]);
+    for (int t = lane; t < nct; t += 64) r2 = fmaxf(r2, A.ctmax[(size_t)bi * nct + t]);
+    for (int d = 32; d > 0; d >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, d));
+    const float tau = r2 * 2.44140625e-4f;                                    // 2^-12 * R2
 
     const int nchunk = (nct + CHUNK - 1) / CHUNK;
     auto stage_chunk = [&](int ch, int buf) {                                // all 512 threads copy 16 KB
@@ -185,50 +200,51 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
     };
     float smin = __builtin_inff();
     int qcount = 0;
-    bool overflow = false;
-    // sweep 0: minimum of the surrogate; sweep 1: queue the tiles that can hold the exact minimiser
-    for (int sweep = 0; sweep < 2; ++sweep) {
-        float thr = 0.f;
-        if (sweep == 1) {
-            const auto sw = __builtin_amdgcn_permlane32_swap(f2u(smin), f2u(smin), false, false);
-            smin = fminf(u2f(sw[0]), u2f(sw[1]));                             // both halves of a query
-            thr = smin + tau;
-        }
-        stage_chunk(0, 0);
-        __syncthreads();
-        for (int ch = 0; ch < nchunk; ++ch) {
-            if (ch + 1 < nchunk) stage_chunk(ch + 1, (ch + 1) & 1);
-            const uint4 *sb = stage[ch & 1];
-            const int tcount = min(CHUNK, nct - ch * CHUNK);
-            if (wave_live) {
-#pragma unroll 4
-                for (int t = 0; t < tcount; ++t) {
-                    const f32x16 s = mfma(sb[t * 64 + lane], bq);
-                    const float m = tile_min(s);
-                    if (sweep == 0) {
-                        smin = fminf(smin, m);
-                    } else if (m <= thr) {
-                        if (qcount < QCAP) queue[wave][qcount][lane] = ch * CHUNK + t;
-                        else overflow = true;
-                        ++qcount;
-                    }
+    stage_chunk(0, 0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ++ch) {
+        if (ch + 1 < nchunk) stage_chunk(ch + 1, (ch + 1) & 1);
+        const uint4 *sb = stage[ch & 1];
+        const int tcount = min(CHUNK, nct - ch * CHUNK);
+        if (wave_live) {
+            auto visit = [&](int t, float m) {
+                if (m <= smin + tau) {                                        // record low or near-tie of the running minimum
+                    if (qcount < QCAP) { qtile[wave][qcount][lane] = ch * CHUNK + t; qmin[wave][qcount][lane] = m; }
+                    ++qcount;
                 }
+                smin = fminf(smin, m);
+            };
+            int t = 0;
+            for (; t + 4 <= tcount; t += 4) {                                 // four independent MFMAs in flight
+                const f32x16 s0 = mfma(sb[(t + 0) * 64 + lane], bq), s1 = mfma(sb[(t + 1) * 64 + lane], bq);
+                const f32x16 s2 = mfma(sb[(t + 2) * 64 + lane], bq), s3 = mfma(sb[(t + 3) * 64 + lane], bq);
+                const float m0 = tile_min(s0), m1 = tile_min(s1), m2 = tile_min(s2), m3 = tile_min(s3);
+                visit(t + 0, m0); visit(t + 1, m1); visit(t + 2, m2); visit(t + 3, m3);
             }
-            __syncthreads();
+            for (; t < tcount; ++t) visit(t, tile_min(mfma(sb[t * 64 + lane], bq)));
         }
+        __syncthreads();
     }
     if (!wave_live) return;
-    // exact evaluation of the queued tiles (d, index) lexicographic; both halves then merge
+    // final threshold from both halves of each query, then exact evaluation of the surviving tiles
+    smin = fminf(smin, __shfl_xor(smin, 32));
+    const float thr = smin + tau;
     float best = __builtin_inff();
     int bidx = INT_MAX;
-    if (__builtin_amdgcn_ballot_w64(overflow) != 0) {
-        for (int t = 0; t < nct; ++t) exact_tile(c, nc, t, h, qx, qy, qz, best, bidx);
+    if (__builtin_amdgcn_ballot_w64(qcount > QCAP) != 0) {
+        for (int t = 0; t < nct; ++t) exact_tile(cp, nc, t, h, qx, qy, qz, best, bidx);
     } else {
         int qmax = qcount;
         for (int d = 32; d > 0; d >>= 1) qmax = max(qmax, __shfl_xor(qmax, d));
         qmax = __builtin_amdgcn_readfirstlane(qmax);
         for (int e = 0; e < qmax; ++e) {
-            if (e < qcount) exact_tile(c, nc, queue[wave][e][lane], h, qx, qy, qz, best, bidx);
+            const bool take = e < qcount && qmin[wave][e][lane] <= thr;
+            if (__builtin_amdgcn_ballot_w64(take) != 0) {
+                const int t = take ? qtile[wave][e][lane] : 0;
+                float b2 = best; int i2 = bidx;
+                exact_tile(cp, nc, t, h, qx, qy, qz, b2, i2);
+                if (take) { best = b2; bidx = i2; }
+            }
         }
     }
     // merge the two lane halves of each query
@@ -245,7 +261,8 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
 
 extern "C" size_t dpf_nndistance_mfma_workspace_bytes(int b, int n, int m) {
     if (b <= 0 || n <= 0 || m <= 0) return 0;
-    return (size_t)b * ((size_t)tiles_of(n) + tiles_of(m)) * 64 * 16 * 2 + (size_t)b * 4 + 256;
+    const size_t t = (size_t)tiles_of(n) + tiles_of(m);
+    return (size_t)b * t * (64 * 16 * 2 + 32 * 16 + 4) + 256;
 }
 
 extern "C" int dpf_nndistance_mfma(int b, int n, const float *xyz, int m, const float *xyz2, float *result,
@@ -257,24 +274,23 @@ extern "C" int dpf_nndistance_mfma(int b, int n, const float *xyz, int m, const 
     if (b > 65535 || !workspace || workspace_bytes < dpf_nndistance_mfma_workspace_bytes(b, n, m) || (n < 32 && m < 32))
         return dpf_nndistance(b, n, xyz, m, xyz2, result, result_i, result2, result2_i, stream);
     hipStream_t s = (hipStream_t)stream;
-    const int nt = tiles_of(n), mt = tiles_of(m);
+    const size_t nt = tiles_of(n), mt = tiles_of(m);
     uint4 *fa1 = (uint4 *)workspace;
     uint4 *fb1 = fa1 + (size_t)b * nt * 64;
     uint4 *fa2 = fb1 + (size_t)b * nt * 64;
     uint4 *fb2 = fa2 + (size_t)b * mt * 64;
-    unsigned *r2 = (unsigned *)(fb2 + (size_t)b * mt * 64);
-    hipError_t e = hipMemsetAsync(r2, 0, sizeof(unsigned) * b, s);
-    if (e != hipSuccess) return (int)e;
+    float4 *p1 = (float4 *)(fb2 + (size_t)b * mt * 64);
+    float4 *p2 = p1 + (size_t)b * nt * 32;
+    float *tm1 = (float *)(p2 + (size_t)b * mt * 32);
+    float *tm2 = tm1 + (size_t)b * nt;
     PrepArgs pa;
-    pa.s[0] = PrepSet{xyz, fa1, fb1, n};
-    pa.s[1] = PrepSet{xyz2, fa2, fb2, m};
-    pa.r2bits = r2;
-    const int tmax = nt > mt ? nt : mt;
+    pa.s[0] = PrepSet{xyz, fa1, fb1, tm1, p1, n};
+    pa.s[1] = PrepSet{xyz2, fa2, fb2, tm2, p2, m};
+    const int tmax = (int)(nt > mt ? nt : mt);
     hipLaunchKernelGGL(nnm_prep_kernel, dim3((tmax * 64 + 255) / 256, b, 2), dim3(256), 0, s, pa);
     MArgs ma;
-    ma.d[0] = MDir{xyz, xyz2, fb1, fa2, result, result_i, n, m};      // nndistance.cu:126
-    ma.d[1] = MDir{xyz2, xyz, fb2, fa1, result2, result2_i, m, n};    // nndistance.cu:127
-    ma.r2bits = r2;
+    ma.d[0] = MDir{p1, p2, fb1, fa2, tm1, tm2, result, result_i, n, m};      // nndistance.cu:126
+    ma.d[1] = MDir{p2, p1, fb2, fa1, tm2, tm1, result2, result2_i, m, n};    // nndistance.cu:127
     const int nmax = n > m ? n : m;
     hipLaunchKernelGGL(nnm_kernel, dim3((nmax + QW * 32 - 1) / (QW * 32), b, 2), dim3(QW * 64), 0, s, ma);
     return (int)hipGetLastError();
