@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "dpf_hip.h"
 
@@ -36,9 +37,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int QW = 8;            // waves per workgroup, 32 queries each
-constexpr int CHUNK = 16;        // candidate tiles (of 32) staged in LDS per step
-constexpr int QCAP = 16;         // queued candidate tiles per lane before the exact-rescan fallback
+constexpr int QW = 16;           // waves per workgroup, 32 queries each
+constexpr int CT = 64;           // candidate tiles resident in LDS at a time (64 KiB of fragments + 32 KiB of points)
+constexpr int QCAP = 8;          // queued candidate tiles per lane (compacted when full)
 
 __device__ __forceinline__ uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
 __device__ __forceinline__ float u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void nnm_prep_kernel(PrepArgs args) {
     float m = live ? w : 0.f;
     for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
     if (lane == 0) S.tmax[(size_t)bi * tiles_of(n) + tile] = m;
-    if (h == 0) S.pts[((size_t)bi * tiles_of(n) + tile) * 32 + i] = make_float4(x, y, z, 0.f);
+    if (h == 0) S.pts[((size_t)bi * (tiles_of(n) + 1) + tile) * 32 + i] = make_float4(x, y, z, 0.f);   // +1 tile of slack per cloud
 }
 
 struct MDir {
@@ -125,7 +126,7 @@ struct MDir {
     int *idx;
     int nq, nc;
 };
-struct MArgs { MDir d[2]; };
+struct MArgs { MDir d[2]; int debug; };
 
 __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b) {
     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -144,13 +145,14 @@ __device__ __forceinline__ float dist3(float cx, float cy, float cz, float qx, f
 }
 // exact evaluation of the 16 candidates this lane half sees in candidate tile `t`
 // (accumulator rows (r&3) + 8(r>>2) + 4h); ascending k, so ties keep the lowest index
-__device__ __forceinline__ void exact_tile(const float4 *__restrict__ cp, int nc, int t, int h, float qx, float qy, float qz,
-                                           float &best, int &bidx) {
+template <class P>
+__device__ __forceinline__ void exact_tile(P cp, int nc, int t, int tl, int h, float qx, float qy, float qz,
+                                           float &best, int &bidx) {   // tl = tile index inside cp, t = global tile
     float4 v[16];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[4 * g + e] = cp[(size_t)t * 32 + 8 * g + 4 * h + e];     // padded: always in range
+        for (int e = 0; e < 4; ++e) v[4 * g + e] = cp[(size_t)tl * 32 + 8 * g + 4 * h + e];    // padded: always in range
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -163,10 +165,18 @@ __device__ __forceinline__ void exact_tile(const float4 *__restrict__ cp, int nc
         }
 }
 
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_void;
+
+// A workgroup = 16 waves x 32 queries of one cloud.  The candidate cloud's MFMA fragments and
+// packed points are DMA'd into LDS once (global_load_lds, 64 tiles = 96 KiB per pass) and shared
+// by all 16 waves; per tile a wave issues one ds_read_b128, one MFMA and a v_min3 tree.
 __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
-    __shared__ __attribute__((aligned(16))) uint4 stage[2][CHUNK * 64];      // 2 x 16 KB of candidate fragments
-    __shared__ int qtile[QW][QCAP][64];
-    __shared__ float qmin[QW][QCAP][64];
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint4 *sfrag = (uint4 *)lds;                                  // [CT][64]
+    float4 *spts = (float4 *)(lds + CT * 1024);                    // [CT][32]
+    unsigned short *qtile = (unsigned short *)(lds + CT * 1536);   // [QW][QCAP][64]
+    float *qmin = (float *)(lds + CT * 1536 + QW * QCAP * 64 * 2); // [QW][QCAP][64]
     const MDir A = args.d[blockIdx.z];
     const int bi = blockIdx.y;
     const int nq = A.nq, nc = A.nc;
@@ -176,10 +186,10 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
     const int qt = blockIdx.x * QW + wave;                                   // query tile of this wave
     const int nqt = tiles_of(nq), nct = tiles_of(nc);
     const bool wave_live = qt < nqt;
-    const float4 *__restrict__ cp = A.cp + (size_t)bi * nct * 32;
+    const float4 *__restrict__ cp = A.cp + (size_t)bi * (nct + 1) * 32;
     const uint4 *__restrict__ cfa = A.cfa + (size_t)bi * nct * 64;
     const int j = qt * 32 + (lane & 31);
-    const float4 qv = A.qp[(size_t)bi * nqt * 32 + min(qt, nqt - 1) * 32 + (lane & 31)];
+    const float4 qv = A.qp[(size_t)bi * (nqt + 1) * 32 + min(qt, nqt - 1) * 32 + (lane & 31)];
     const float qx = qv.x, qy = qv.y, qz = qv.z;
     const uint4 bq = A.qfb[((size_t)bi * nqt + min(qt, nqt - 1)) * 64 + lane];
     // R2 = largest |p|^2 of the two clouds (per-tile maxima from the prep kernel)
@@ -189,64 +199,72 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
     for (int d = 32; d > 0; d >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, d));
     const float tau = r2 * 2.44140625e-4f;                                    // 2^-12 * R2
 
-    const int nchunk = (nct + CHUNK - 1) / CHUNK;
-    auto stage_chunk = [&](int ch, int buf) {                                // all 512 threads copy 16 KB
-        for (int e = tid; e < CHUNK * 64; e += QW * 64) {
-            const int t = ch * CHUNK + (e >> 6);
-            uint4 v = {0u, 0u, 0u, 0u};
-            if (t < nct) v = cfa[(size_t)t * 64 + (e & 63)];
-            stage[buf][e] = v;
-        }
-    };
+    unsigned short *myq = qtile + (size_t)wave * QCAP * 64;
+    float *mym = qmin + (size_t)wave * QCAP * 64;
     float smin = __builtin_inff();
     int qcount = 0;
-    stage_chunk(0, 0);
-    __syncthreads();
-    for (int ch = 0; ch < nchunk; ++ch) {
-        if (ch + 1 < nchunk) stage_chunk(ch + 1, (ch + 1) & 1);
-        const uint4 *sb = stage[ch & 1];
-        const int tcount = min(CHUNK, nct - ch * CHUNK);
+    float best = __builtin_inff();
+    int bidx = INT_MAX;
+    const int npass = (nct + CT - 1) / CT;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int t0 = pass * CT, tn = min(CT, nct - t0);
+        if (pass > 0) __syncthreads();                                        // everyone is done with the previous pass
+        // DMA: fragments (1 KiB per tile) and packed points (512 B per tile, two tiles per wave-instruction)
+        for (int t = wave; t < tn; t += QW)
+            __builtin_amdgcn_global_load_lds((glb_void *)(cfa + (size_t)(t0 + t) * 64 + lane), (lds_void *)(sfrag + t * 64), 16, 0, 0);
+        for (int t = wave * 2; t < tn; t += QW * 2)
+            __builtin_amdgcn_global_load_lds((glb_void *)(cp + (size_t)(t0 + t) * 32 + lane), (lds_void *)(spts + t * 32), 16, 0, 0);
+        __syncthreads();                                                      // drains the DMA (vmcnt) and publishes it
         if (wave_live) {
             auto visit = [&](int t, float m) {
                 if (m <= smin + tau) {                                        // record low or near-tie of the running minimum
-                    if (qcount < QCAP) { qtile[wave][qcount][lane] = ch * CHUNK + t; qmin[wave][qcount][lane] = m; }
-                    ++qcount;
+                    if (qcount == QCAP) {
+                        // full: drop what the CURRENT threshold already excludes (the final one is no larger)
+                        const float cur = fminf(smin, m) + tau;
+                        int keep = 0;
+                        for (int e = 0; e < QCAP; ++e) {
+                            const float v = mym[e * 64 + lane];
+                            if (v <= cur) { myq[keep * 64 + lane] = myq[e * 64 + lane]; mym[keep * 64 + lane] = v; ++keep; }
+                        }
+                        qcount = keep;
+                    }
+                    if (qcount < QCAP) { myq[qcount * 64 + lane] = (unsigned short)t; mym[qcount * 64 + lane] = m; ++qcount; }
+                    else qcount = QCAP + 1;                                   // still full of near-ties: exact rescan
                 }
                 smin = fminf(smin, m);
             };
             int t = 0;
-            for (; t + 4 <= tcount; t += 4) {                                 // four independent MFMAs in flight
-                const f32x16 s0 = mfma(sb[(t + 0) * 64 + lane], bq), s1 = mfma(sb[(t + 1) * 64 + lane], bq);
-                const f32x16 s2 = mfma(sb[(t + 2) * 64 + lane], bq), s3 = mfma(sb[(t + 3) * 64 + lane], bq);
+            for (; t + 4 <= tn; t += 4) {                                     // four independent MFMAs in flight
+                const f32x16 s0 = mfma(sfrag[(t + 0) * 64 + lane], bq), s1 = mfma(sfrag[(t + 1) * 64 + lane], bq);
+                const f32x16 s2 = mfma(sfrag[(t + 2) * 64 + lane], bq), s3 = mfma(sfrag[(t + 3) * 64 + lane], bq);
                 const float m0 = tile_min(s0), m1 = tile_min(s1), m2 = tile_min(s2), m3 = tile_min(s3);
                 visit(t + 0, m0); visit(t + 1, m1); visit(t + 2, m2); visit(t + 3, m3);
             }
-            for (; t < tcount; ++t) visit(t, tile_min(mfma(sb[t * 64 + lane], bq)));
+            for (; t < tn; ++t) visit(t, tile_min(mfma(sfrag[t * 64 + lane], bq)));
+            // exact evaluation of this pass's surviving tiles against the pass-local threshold (the
+            // global minimum can only be lower, so this is a superset; extra exact evaluations are harmless)
+            const float thr = fminf(smin, __shfl_xor(smin, 32)) + tau;
+            if (__builtin_amdgcn_ballot_w64(qcount > QCAP) != 0) {
+                for (int tt = 0; tt < tn; ++tt) exact_tile(spts, nc, t0 + tt, tt, h, qx, qy, qz, best, bidx);
+            } else {
+                int nsurv = 0;
+                for (int e = 0; e < QCAP; ++e)
+                    if (e < qcount && mym[e * 64 + lane] <= thr) { myq[nsurv * 64 + lane] = myq[e * 64 + lane]; ++nsurv; }
+                int smax = nsurv;
+                for (int d = 32; d > 0; d >>= 1) smax = max(smax, __shfl_xor(smax, d));
+                smax = __builtin_amdgcn_readfirstlane(smax);
+                for (int e = 0; e < smax; ++e) {
+                    const bool take = e < nsurv;
+                    const int tl = take ? myq[e * 64 + lane] : 0;
+                    float b2 = best; int i2 = bidx;
+                    exact_tile(spts, nc, t0 + tl, tl, h, qx, qy, qz, b2, i2);
+                    if (take) { best = b2; bidx = i2; }
+                }
+            }
+            qcount = 0;                                                       // the queue is per pass; smin carries over
         }
-        __syncthreads();
     }
     if (!wave_live) return;
-    // final threshold from both halves of each query, then exact evaluation of the surviving tiles
-    smin = fminf(smin, __shfl_xor(smin, 32));
-    const float thr = smin + tau;
-    float best = __builtin_inff();
-    int bidx = INT_MAX;
-    if (__builtin_amdgcn_ballot_w64(qcount > QCAP) != 0) {
-        for (int t = 0; t < nct; ++t) exact_tile(cp, nc, t, h, qx, qy, qz, best, bidx);
-    } else {
-        int qmax = qcount;
-        for (int d = 32; d > 0; d >>= 1) qmax = max(qmax, __shfl_xor(qmax, d));
-        qmax = __builtin_amdgcn_readfirstlane(qmax);
-        for (int e = 0; e < qmax; ++e) {
-            const bool take = e < qcount && qmin[wave][e][lane] <= thr;
-            if (__builtin_amdgcn_ballot_w64(take) != 0) {
-                const int t = take ? qtile[wave][e][lane] : 0;
-                float b2 = best; int i2 = bidx;
-                exact_tile(cp, nc, t, h, qx, qy, qz, b2, i2);
-                if (take) { best = b2; bidx = i2; }
-            }
-        }
-    }
     // merge the two lane halves of each query
     const float od = __shfl_xor(best, 32);
     const int oi = __shfl_xor(bidx, 32);
@@ -262,7 +280,7 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
 extern "C" size_t dpf_nndistance_mfma_workspace_bytes(int b, int n, int m) {
     if (b <= 0 || n <= 0 || m <= 0) return 0;
     const size_t t = (size_t)tiles_of(n) + tiles_of(m);
-    return (size_t)b * t * (64 * 16 * 2 + 32 * 16 + 4) + 256;
+    return (size_t)b * t * (64 * 16 * 2 + 32 * 16 + 4) + (size_t)b * 2 * 32 * 16 + 256;
 }
 
 extern "C" int dpf_nndistance_mfma(int b, int n, const float *xyz, int m, const float *xyz2, float *result,
@@ -271,7 +289,8 @@ extern "C" int dpf_nndistance_mfma(int b, int n, const float *xyz, int m, const 
     if (b < 0 || n <= 0 || m <= 0) return DPF_EINVAL;
     if (b == 0) return 0;
     if (!xyz || !xyz2 || !result || !result_i || !result2 || !result2_i) return DPF_EINVAL;
-    if (b > 65535 || !workspace || workspace_bytes < dpf_nndistance_mfma_workspace_bytes(b, n, m) || (n < 32 && m < 32))
+    if (b > 65535 || n > 65535 * 32 || m > 65535 * 32 || !workspace ||
+        workspace_bytes < dpf_nndistance_mfma_workspace_bytes(b, n, m) || (n < 32 && m < 32))
         return dpf_nndistance(b, n, xyz, m, xyz2, result, result_i, result2, result2_i, stream);
     hipStream_t s = (hipStream_t)stream;
     const size_t nt = tiles_of(n), mt = tiles_of(m);
@@ -280,8 +299,8 @@ extern "C" int dpf_nndistance_mfma(int b, int n, const float *xyz, int m, const 
     uint4 *fa2 = fb1 + (size_t)b * nt * 64;
     uint4 *fb2 = fa2 + (size_t)b * mt * 64;
     float4 *p1 = (float4 *)(fb2 + (size_t)b * mt * 64);
-    float4 *p2 = p1 + (size_t)b * nt * 32;
-    float *tm1 = (float *)(p2 + (size_t)b * mt * 32);
+    float4 *p2 = p1 + (size_t)b * (nt + 1) * 32;
+    float *tm1 = (float *)(p2 + (size_t)b * (mt + 1) * 32);
     float *tm2 = tm1 + (size_t)b * nt;
     PrepArgs pa;
     pa.s[0] = PrepSet{xyz, fa1, fb1, tm1, p1, n};
@@ -291,7 +310,15 @@ extern "C" int dpf_nndistance_mfma(int b, int n, const float *xyz, int m, const 
     MArgs ma;
     ma.d[0] = MDir{p1, p2, fb1, fa2, tm1, tm2, result, result_i, n, m};      // nndistance.cu:126
     ma.d[1] = MDir{p2, p1, fb2, fa1, tm2, tm1, result2, result2_i, m, n};    // nndistance.cu:127
+    ma.debug = 0;
     const int nmax = n > m ? n : m;
-    hipLaunchKernelGGL(nnm_kernel, dim3((nmax + QW * 32 - 1) / (QW * 32), b, 2), dim3(QW * 64), 0, s, ma);
+    const int lds = CT * 1536 + QW * QCAP * 64 * 6;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)nnm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(nnm_kernel, dim3((nmax + QW * 32 - 1) / (QW * 32), b, 2), dim3(QW * 64), lds, s, ma);
     return (int)hipGetLastError();
 }
