@@ -62,7 +62,7 @@ __host__ __device__ inline int tiles_of(int n) { return (n + 31) / 32; }
 //   role B (query):     coord -> (qh, ql, qh, ql) of -2q,  norm -> (1, 1, 1)
 struct PrepSet {
     const float *xyz;   // (B, n, 3)
-    uint4 *fa;          // (B, ntiles, 64) candidate-role fragments
+    uint4 *fa, *fb;     // (B, ntiles, 64)
     float *tmax;        // (B, ntiles) largest |p|^2 of each tile
     float4 *pts;        // (B, ntiles*32) points as (x, y, z, 0): one 16-byte load per exact evaluation
     int n;
@@ -83,13 +83,15 @@ __global__ __launch_bounds__(256) void nnm_prep_kernel(PrepArgs args) {
         x = src[0]; y = src[1]; z = src[2];
     }
     const float w = (x * x + y * y) + z * z;
-    uint32_t sa[16];
+    uint32_t sa[16], sb[16];
     const float c3[3] = {x, y, z};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        uint32_t ch, cl;
+        uint32_t ch, cl, qh, ql;
         split2(c3[c], ch, cl);
+        split2(-2.0f * c3[c], qh, ql);
         sa[4 * c + 0] = ch; sa[4 * c + 1] = ch; sa[4 * c + 2] = cl; sa[4 * c + 3] = cl;
+        sb[4 * c + 0] = qh; sb[4 * c + 1] = ql; sb[4 * c + 2] = qh; sb[4 * c + 3] = ql;
     }
     {
         // padding rows of the last tile: +big surrogate so they never reach a minimum
@@ -99,12 +101,17 @@ __global__ __launch_bounds__(256) void nnm_prep_kernel(PrepArgs args) {
         const uint32_t wm = f2u(r1) & 0xFFFF0000u;
         const float r2 = r1 - u2f(wm);
         sa[12] = wh >> 16; sa[13] = live ? (wm >> 16) : 0u; sa[14] = live ? bf16_rne(r2) : 0u; sa[15] = 0u;
+        sb[12] = 0x3F80u; sb[13] = 0x3F80u; sb[14] = 0x3F80u; sb[15] = 0u;
     }
-    uint4 oa;
+    uint4 oa, ob;
     const int o = 8 * h;
     oa.x = sa[o + 0] | (sa[o + 1] << 16); oa.y = sa[o + 2] | (sa[o + 3] << 16);
     oa.z = sa[o + 4] | (sa[o + 5] << 16); oa.w = sa[o + 6] | (sa[o + 7] << 16);
-    S.fa[((size_t)bi * tiles_of(n) + tile) * 64 + lane] = oa;
+    ob.x = sb[o + 0] | (sb[o + 1] << 16); ob.y = sb[o + 2] | (sb[o + 3] << 16);
+    ob.z = sb[o + 4] | (sb[o + 5] << 16); ob.w = sb[o + 6] | (sb[o + 7] << 16);
+    const size_t off = ((size_t)bi * tiles_of(n) + tile) * 64 + lane;
+    S.fa[off] = oa;
+    S.fb[off] = ob;
     float m = live ? w : 0.f;
     for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
     if (lane == 0) S.tmax[(size_t)bi * tiles_of(n) + tile] = m;
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(256) void nnm_prep_kernel(PrepArgs args) {
 
 struct MDir {
     const float4 *qp, *cp;     // packed points of the query / candidate cloud
-    const uint4 *cfa;          // candidate fragments (role A)
+    const uint4 *qfb, *cfa;    // query fragments (role B), candidate fragments (role A)
     const float *qtmax, *ctmax;
     float *dist;
     int *idx;
@@ -125,11 +132,12 @@ __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b) {
     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), z, 0, 0, 0);
 }
-// minima of the four row groups (4 accumulator registers = 4 consecutive candidates each) and of the tile
-__device__ __forceinline__ float tile_min(const f32x16 &s, float (&g)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) g[i] = fminf(fminf(fminf(s[4 * i], s[4 * i + 1]), s[4 * i + 2]), s[4 * i + 3]);
-    return fminf(fminf(fminf(g[0], g[1]), g[2]), g[3]);
+__device__ __forceinline__ float tile_min(const f32x16 &s) {
+    float m = fminf(fminf(s[0], s[1]), s[2]);
+    m = fminf(fminf(m, s[3]), s[4]);   m = fminf(fminf(m, s[5]), s[6]);
+    m = fminf(fminf(m, s[7]), s[8]);   m = fminf(fminf(m, s[9]), s[10]);
+    m = fminf(fminf(m, s[11]), s[12]); m = fminf(fminf(m, s[13]), s[14]);
+    return fminf(m, s[15]);
 }
 __device__ __forceinline__ float dist3(float cx, float cy, float cz, float qx, float qy, float qz) {
     const float dx = cx - qx, dy = cy - qy, dz = cz - qz;
@@ -137,26 +145,24 @@ __device__ __forceinline__ float dist3(float cx, float cy, float cz, float qx, f
 }
 // exact evaluation of the 16 candidates this lane half sees in candidate tile `t`
 // (accumulator rows (r&3) + 8(r>>2) + 4h); ascending k, so ties keep the lowest index
-// exact evaluation of the row groups `mask` (bit g = rows 8g+4h .. 8g+4h+3) this lane half sees in
-// candidate tile `t`; ascending k inside the call
 template <class P>
-__device__ __forceinline__ void exact_tile(P cp, int nc, int t, int tl, unsigned mask, int h, float qx, float qy, float qz,
+__device__ __forceinline__ void exact_tile(P cp, int nc, int t, int tl, int h, float qx, float qy, float qz,
                                            float &best, int &bidx) {   // tl = tile index inside cp, t = global tile
+    float4 v[16];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        if (__builtin_amdgcn_ballot_w64((mask >> g) & 1u) == 0) continue;     // no lane needs this group
-        float4 v[4];
+    for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = cp[(size_t)tl * 32 + 8 * g + 4 * h + e];    // padded: always in range
+        for (int e = 0; e < 4; ++e) v[4 * g + e] = cp[(size_t)tl * 32 + 8 * g + 4 * h + e];    // padded: always in range
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int k = t * 32 + 8 * g + 4 * h + e;
-            const float d = dist3(v[e].x, v[e].y, v[e].z, qx, qy, qz);
-            const bool better = ((mask >> g) & 1u) && k < nc && (d < best || (d == best && k < bidx));
+            const float d = dist3(v[4 * g + e].x, v[4 * g + e].y, v[4 * g + e].z, qx, qy, qz);
+            const bool better = k < nc && (d < best || (d == best && k < bidx));
             best = better ? d : best;
             bidx = better ? k : bidx;
         }
-    }
 }
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -185,21 +191,7 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
     const int j = qt * 32 + (lane & 31);
     const float4 qv = A.qp[(size_t)bi * (nqt + 1) * 32 + min(qt, nqt - 1) * 32 + (lane & 31)];
     const float qx = qv.x, qy = qv.y, qz = qv.z;
-    uint4 bq;                                                                // this wave's query fragment (role B)
-    {
-        uint32_t sb[16];
-        const float c3[3] = {qx, qy, qz};
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            uint32_t qh, ql;
-            split2(-2.0f * c3[c], qh, ql);
-            sb[4 * c + 0] = qh; sb[4 * c + 1] = ql; sb[4 * c + 2] = qh; sb[4 * c + 3] = ql;
-        }
-        sb[12] = 0x3F80u; sb[13] = 0x3F80u; sb[14] = 0x3F80u; sb[15] = 0u;
-        const int o = 8 * h;
-        bq.x = sb[o + 0] | (sb[o + 1] << 16); bq.y = sb[o + 2] | (sb[o + 3] << 16);
-        bq.z = sb[o + 4] | (sb[o + 5] << 16); bq.w = sb[o + 6] | (sb[o + 7] << 16);
-    }
+    const uint4 bq = A.qfb[((size_t)bi * nqt + min(qt, nqt - 1)) * 64 + lane];
     // R2 = largest |p|^2 of the two clouds (per-tile maxima from the prep kernel)
     float r2 = 0.f;
     for (int t = lane; t < nqt; t += 64) r2 = fmaxf(r2, A.qtmax[(size_t)bi * nqt + t]);
@@ -214,20 +206,17 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
     float best = __builtin_inff();
     int bidx = INT_MAX;
     const int npass = (nct + CT - 1) / CT;
-    unsigned long long tc[4] = {0, 0, 0, 0};
-    tc[0] = __builtin_amdgcn_s_memtime();
     for (int pass = 0; pass < npass; ++pass) {
         const int t0 = pass * CT, tn = min(CT, nct - t0);
         if (pass > 0) __syncthreads();                                        // everyone is done with the previous pass
         // DMA: fragments (1 KiB per tile) and packed points (512 B per tile, two tiles per wave-instruction)
         for (int t = wave; t < tn; t += QW)
             __builtin_amdgcn_global_load_lds((glb_void *)(cfa + (size_t)(t0 + t) * 64 + lane), (lds_void *)(sfrag + t * 64), 16, 0, 0);
-        __syncthreads();                                                      // drains the fragment DMA (vmcnt) and publishes it
-        for (int t = wave * 2; t < tn; t += QW * 2)                           // points: needed only after the sweep
+        for (int t = wave * 2; t < tn; t += QW * 2)
             __builtin_amdgcn_global_load_lds((glb_void *)(cp + (size_t)(t0 + t) * 32 + lane), (lds_void *)(spts + t * 32), 16, 0, 0);
-        tc[1] = __builtin_amdgcn_s_memtime();
+        __syncthreads();                                                      // drains the DMA (vmcnt) and publishes it
         if (wave_live) {
-            auto visit = [&](int t, float m, const float (&g)[4]) {
+            auto visit = [&](int t, float m) {
                 if (m <= smin + tau) {                                        // record low or near-tie of the running minimum
                     if (qcount == QCAP) {
                         // full: drop what the CURRENT threshold already excludes (the final one is no larger)
@@ -239,10 +228,7 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
                         }
                         qcount = keep;
                     }
-                    // row groups that are within tau of the running minimum (superset of the final selection)
-                    const float lim = smin + tau;
-                    const unsigned gm = (g[0] <= lim ? 1u : 0u) | (g[1] <= lim ? 2u : 0u) | (g[2] <= lim ? 4u : 0u) | (g[3] <= lim ? 8u : 0u);
-                    if (qcount < QCAP) { myq[qcount * 64 + lane] = (unsigned short)(t | (gm << 12)); mym[qcount * 64 + lane] = m; ++qcount; }
+                    if (qcount < QCAP) { myq[qcount * 64 + lane] = (unsigned short)t; mym[qcount * 64 + lane] = m; ++qcount; }
                     else qcount = QCAP + 1;                                   // still full of near-ties: exact rescan
                 }
                 smin = fminf(smin, m);
@@ -251,20 +237,15 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
             for (; t + 4 <= tn; t += 4) {                                     // four independent MFMAs in flight
                 const f32x16 s0 = mfma(sfrag[(t + 0) * 64 + lane], bq), s1 = mfma(sfrag[(t + 1) * 64 + lane], bq);
                 const f32x16 s2 = mfma(sfrag[(t + 2) * 64 + lane], bq), s3 = mfma(sfrag[(t + 3) * 64 + lane], bq);
-                float g0[4], g1[4], g2[4], g3[4];
-                const float m0 = tile_min(s0, g0), m1 = tile_min(s1, g1), m2 = tile_min(s2, g2), m3 = tile_min(s3, g3);
-                visit(t + 0, m0, g0); visit(t + 1, m1, g1); visit(t + 2, m2, g2); visit(t + 3, m3, g3);
+                const float m0 = tile_min(s0), m1 = tile_min(s1), m2 = tile_min(s2), m3 = tile_min(s3);
+                visit(t + 0, m0); visit(t + 1, m1); visit(t + 2, m2); visit(t + 3, m3);
             }
-            for (; t < tn; ++t) { float gg[4]; const float mm = tile_min(mfma(sfrag[t * 64 + lane], bq), gg); visit(t, mm, gg); }
-            tc[2] = __builtin_amdgcn_s_memtime();
-        }
-        __syncthreads();                                                      // points have landed (vmcnt drained) for every wave
-        if (wave_live) {
+            for (; t < tn; ++t) visit(t, tile_min(mfma(sfrag[t * 64 + lane], bq)));
             // exact evaluation of this pass's surviving tiles against the pass-local threshold (the
             // global minimum can only be lower, so this is a superset; extra exact evaluations are harmless)
             const float thr = fminf(smin, __shfl_xor(smin, 32)) + tau;
             if (__builtin_amdgcn_ballot_w64(qcount > QCAP) != 0) {
-                for (int tt = 0; tt < tn; ++tt) exact_tile(spts, nc, t0 + tt, tt, 15u, h, qx, qy, qz, best, bidx);
+                for (int tt = 0; tt < tn; ++tt) exact_tile(spts, nc, t0 + tt, tt, h, qx, qy, qz, best, bidx);
             } else {
                 int nsurv = 0;
                 for (int e = 0; e < QCAP; ++e)
@@ -274,23 +255,16 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
                 smax = __builtin_amdgcn_readfirstlane(smax);
                 for (int e = 0; e < smax; ++e) {
                     const bool take = e < nsurv;
-                    const unsigned ent = take ? myq[e * 64 + lane] : 0u;
-                    const int tl = ent & 0xFFF;
-                    exact_tile(spts, nc, t0 + tl, tl, take ? (ent >> 12) : 0u, h, qx, qy, qz, best, bidx);
+                    const int tl = take ? myq[e * 64 + lane] : 0;
+                    float b2 = best; int i2 = bidx;
+                    exact_tile(spts, nc, t0 + tl, tl, h, qx, qy, qz, b2, i2);
+                    if (take) { best = b2; bidx = i2; }
                 }
             }
             qcount = 0;                                                       // the queue is per pass; smin carries over
         }
     }
     if (!wave_live) return;
-    tc[3] = __builtin_amdgcn_s_memtime();
-    if (args.debug == 2) {
-        if (j < nq && h == 0) {
-            A.dist[(size_t)bi * nq + j] = (float)(tc[1] - tc[0]) + 1e-6f * 0;
-            A.idx[(size_t)bi * nq + j] = (int)(((tc[2] - tc[1]) & 0xFFFF) << 16 | ((tc[3] - tc[2]) & 0xFFFF));
-        }
-        return;
-    }
     // merge the two lane halves of each query
     const float od = __shfl_xor(best, 32);
     const int oi = __shfl_xor(bidx, 32);
@@ -306,7 +280,7 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
 extern "C" size_t dpf_nndistance_mfma_workspace_bytes(int b, int n, int m) {
     if (b <= 0 || n <= 0 || m <= 0) return 0;
     const size_t t = (size_t)tiles_of(n) + tiles_of(m);
-    return (size_t)b * t * (64 * 16 + 32 * 16 + 4) + (size_t)b * 2 * 32 * 16 + 256;
+    return (size_t)b * t * (64 * 16 * 2 + 32 * 16 + 4) + (size_t)b * 2 * 32 * 16 + 256;
 }
 
 extern "C" int dpf_nndistance_mfma(int b, int n, const float *xyz, int m, const float *xyz2, float *result,
@@ -321,20 +295,22 @@ extern "C" int dpf_nndistance_mfma(int b, int n, const float *xyz, int m, const 
     hipStream_t s = (hipStream_t)stream;
     const size_t nt = tiles_of(n), mt = tiles_of(m);
     uint4 *fa1 = (uint4 *)workspace;
-    uint4 *fa2 = fa1 + (size_t)b * nt * 64;
-    float4 *p1 = (float4 *)(fa2 + (size_t)b * mt * 64);
+    uint4 *fb1 = fa1 + (size_t)b * nt * 64;
+    uint4 *fa2 = fb1 + (size_t)b * nt * 64;
+    uint4 *fb2 = fa2 + (size_t)b * mt * 64;
+    float4 *p1 = (float4 *)(fb2 + (size_t)b * mt * 64);
     float4 *p2 = p1 + (size_t)b * (nt + 1) * 32;
     float *tm1 = (float *)(p2 + (size_t)b * (mt + 1) * 32);
     float *tm2 = tm1 + (size_t)b * nt;
     PrepArgs pa;
-    pa.s[0] = PrepSet{xyz, fa1, tm1, p1, n};
-    pa.s[1] = PrepSet{xyz2, fa2, tm2, p2, m};
+    pa.s[0] = PrepSet{xyz, fa1, fb1, tm1, p1, n};
+    pa.s[1] = PrepSet{xyz2, fa2, fb2, tm2, p2, m};
     const int tmax = (int)(nt > mt ? nt : mt);
     hipLaunchKernelGGL(nnm_prep_kernel, dim3((tmax * 64 + 255) / 256, b, 2), dim3(256), 0, s, pa);
     MArgs ma;
-    ma.d[0] = MDir{p1, p2, fa2, tm1, tm2, result, result_i, n, m};      // nndistance.cu:126
-    ma.d[1] = MDir{p2, p1, fa1, tm2, tm1, result2, result2_i, m, n};    // nndistance.cu:127
-    ma.debug = getenv("DPF_NNM_DEBUG") ? atoi(getenv("DPF_NNM_DEBUG")) : 0;
+    ma.d[0] = MDir{p1, p2, fb1, fa2, tm1, tm2, result, result_i, n, m};      // nndistance.cu:126
+    ma.d[1] = MDir{p2, p1, fb2, fa1, tm2, tm1, result2, result2_i, m, n};    // nndistance.cu:127
+    ma.debug = 0;
     const int nmax = n > m ? n : m;
     const int lds = CT * 1536 + QW * QCAP * 64 * 6;
     static bool attr_set = false;

@@ -13,10 +13,11 @@ from ..._lib import lib, check, current_stream
 
 
 # Chamfer forward implementation; all three return identical bits (tests/test_gpu_chamfer.py):
-#   "mfma"   matrix-core filter + exact verification of the few candidates that can win (default)
-#   "brute"  O(n*m) exact VALU scan, data-independent cost
+#   "brute"  O(n*m) exact VALU scan at ~75 % of its issue bound, data-independent cost (default)
+#   "mfma"   matrix-core filter (one bf16 MFMA per 32x32 pairs) + exact verification of the few
+#            candidates that can win; r01: 35 + 10 us vs 50 us brute on cfg-2 -- not yet a clear win
 #   "sorted" x-sorted pruned exact scan (pays off only when both clouds cover the same region)
-NN_IMPL = os.environ.get("DPF_CHAMFER_IMPL", "mfma")
+NN_IMPL = os.environ.get("DPF_CHAMFER_IMPL", "brute")
 EMD_RMW = bool(int(os.environ.get("DPF_EMD_RMW", "0")))   # 1: the reference's per-level read-modify-write of `match`
 
 
