@@ -37,21 +37,11 @@
 // is applied to W1's columns at pack time.  No LDS round trip for activations.
 // LDS holds the current and the next layer's packed weights (double-buffered,
 // streamed with global_load_lds while the current layer computes).
-#include <hip/hip_runtime.h>
-#include <stdint.h>
 #include <stdlib.h>
 
-#include "dpf_hip.h"
+#include "flow_common.h"
 
 namespace {
-
-static_assert(DPF_FLOW_F == 64, "kernels are built for 64 hidden features");
-constexpr float BN_EPS = 1e-5f;
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // ---- canonical fp32 layout (see dpf_hip.h) --------------------------------
 constexpr int C_W0 = 0;
@@ -64,40 +54,6 @@ constexpr int C_FILM = 4740;
 __host__ __device__ constexpr int c_film_floats(int G) { return 64 * G + 256 + 4096 + 64; }
 __host__ __device__ constexpr int c_branch_floats(int G) { return C_FILM + 2 * c_film_floats(G); }
 __host__ __device__ constexpr int c_layer_floats(int G) { return 2 * c_branch_floats(G); }
-
-// ---- packed layout ----------------------------------------------------------
-constexpr int P_A1_PART = 16384;                       // [br2][t2][s4][lane64][8 bf16]
-__host__ __device__ constexpr int p_a0_off(int NS) { return NS * P_A1_PART; }            // [br2][t2][lane64][8 bf16]
-__host__ __device__ constexpr int p_layer_bytes(int NS) { return NS * P_A1_PART + 4096; }
-constexpr int FILM_BYTES = 2048;                       // per (layer, cloud): [br2]{D[64], Wab[64][2]}, b2[br2][2], pad
-constexpr int FILM_BR_FLOATS = 192;
-constexpr int FILM_B2_OFF = 384;                       // floats
-
-__device__ __forceinline__ uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
-__device__ __forceinline__ float u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
-__device__ __forceinline__ uint32_t bf16_rne(float x) {   // top-16 bits, round to nearest even
-    const uint32_t u = f2u(x);
-    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-// relu on the bit pattern: one v_max_i32 (fmaxf would add a canonicalising v_max per MFMA output)
-__device__ __forceinline__ float relu(float x) { return u2f((uint32_t)max((int)f2u(x), 0)); }
-// {bf16(a), bf16(b)} round-to-nearest-even in one v_cvt_pk_bf16_f32
-__device__ __forceinline__ uint32_t pack_bf16_rne(float a, float b) {
-    const f32x2 v = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-}
-// {top16(a), top16(b)} (truncation) in one v_perm_b32
-__device__ __forceinline__ uint32_t pack_bf16_trunc(float a, float b) {
-    return __builtin_amdgcn_perm(f2u(b), f2u(a), 0x07060302u);
-}
-// truncation split: x = hi + rest exactly, hi has 8 significant bits
-__device__ __forceinline__ uint32_t split_hi(float x, float &rest) {
-    const uint32_t h = f2u(x) & 0xFFFF0000u;
-    rest = x - u2f(h);
-    return h;
-}
 
 // ===========================================================================
 // pack
@@ -143,17 +99,7 @@ __global__ __launch_bounds__(256) void pack_kernel(int G, const float *__restric
         const float s0 = gamma / sqrtf(rv + BN_EPS);
         const float w = s0 * cb[C_W0 + f * 2 + h];
         const float T = beta - rm * s0;
-        float r1, r2, q1, q2, dummy;
-        const uint32_t wh = split_hi(w, r1) >> 16, wm = split_hi(r1, r2) >> 16, wl = split_hi(r2, dummy) >> 16;
-        const uint32_t Th = split_hi(T, q1) >> 16, Tm = split_hi(q1, q2) >> 16, Tl = split_hi(q2, dummy) >> 16;
-        uint32_t v;
-        switch (j) {
-            case 0: case 1: case 3: v = wh; break;
-            case 2: case 4: v = wm; break;
-            case 5: v = wl; break;
-            case 6: v = h == 0 ? Th : Tl; break;
-            default: v = h == 0 ? Tm : 0u; break;
-        }
+        const uint32_t v = input_weight_slot(w, T, h, j);
         a0[idx] = (uint16_t)v;
     }
 }
@@ -323,11 +269,6 @@ struct FlowArgs {
 #endif
 };
 
-constexpr int TILE = 32;          // points per tile (one MFMA N tile)
-
-typedef __attribute__((address_space(3))) void lds_void;
-typedef __attribute__((address_space(1))) const void glb_void;
-
 // Stream one layer (packed weights + this cloud's FiLM vectors) into an LDS
 // buffer: 1 KiB per wave-instruction, straight to LDS (no VGPR staging).
 template <int NS, int FW>
@@ -341,26 +282,6 @@ __device__ __forceinline__ void stage_layer(const FlowArgs &a, int li, int bi, u
     }
 }
 
-__device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-__device__ __forceinline__ float sel3(int c, float v0, float v1, float v2) {   // c wave-uniform
-    return c == 0 ? v0 : (c == 1 ? v1 : v2);
-}
-
-// split-precision product terms: parts are 0 = hi, 1 = mid/lo, 2 = lo
-template <int NS> struct Terms;
-template <> struct Terms<1> { static constexpr int N = 1; static constexpr int A[1] = {0}, B[1] = {0}; };
-template <> struct Terms<2> { static constexpr int N = 3; static constexpr int A[3] = {1, 0, 0}, B[3] = {0, 1, 0}; };
-template <> struct Terms<3> {
-    static constexpr int N = 6;
-    static constexpr int A[6] = {1, 2, 0, 1, 0, 0}, B[6] = {1, 0, 2, 0, 1, 0};
-};
-
-// One conditioner branch (logvar or mu) of one layer for one 32-point tile:
-// returns the two pre-activation outputs o_a, o_b of the branch (sum over this
-// lane-half's 32 features; the caller adds the other half).
 #ifdef DPF_PROFILE
 #define DPF_T(i) { __builtin_amdgcn_sched_barrier(0); tt[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
 #else
@@ -508,13 +429,7 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
         const float xa = sel3(ka, p0, p1, p2);
         const float xb = kb < 0 ? 0.f : sel3(kb, p0, p1, p2);
         const float x = h ? xb : xa;
-        float r1, r2, r3;
-        const uint32_t xh = split_hi(x, r1), xm = split_hi(r1, r2), xl = split_hi(r2, r3);
-        u32x4 b0;
-        b0.x = (xh >> 16) | xm;            // e0 = xh, e1 = xm
-        b0.y = (xh >> 16) | xl;            // e2 = xh, e3 = xl
-        b0.z = (xm >> 16) | xh;            // e4 = xm, e5 = xh
-        b0.w = h ? 0x00003F80u : 0x3F803F80u;   // e6 = 1, e7 = (h == 0)
+        const u32x4 b0 = input_fragment(x, h);
 
         float o[2][2];
         if (wb < 0) {                                       // layer warps one channel

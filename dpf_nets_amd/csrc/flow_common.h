@@ -1,0 +1,115 @@
+// Shared device helpers of the flow kernels (csrc/flow.hip: eval-mode fused stack;
+// csrc/flow_train.hip: training-mode per-layer forward/backward).  Everything is in an
+// anonymous namespace: each translation unit gets its own copy.
+#ifndef DPF_FLOW_COMMON_H
+#define DPF_FLOW_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dpf_hip.h"
+
+namespace {
+
+static_assert(DPF_FLOW_F == 64, "kernels are built for 64 hidden features");
+constexpr float BN_EPS = 1e-5f;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- packed layout ----------------------------------------------------------
+constexpr int P_A1_PART = 16384;                       // [br2][t2][s4][lane64][8 bf16]
+__host__ __device__ constexpr int p_a0_off(int NS) { return NS * P_A1_PART; }            // [br2][t2][lane64][8 bf16]
+__host__ __device__ constexpr int p_layer_bytes(int NS) { return NS * P_A1_PART + 4096; }
+constexpr int FILM_BYTES = 2048;                       // per (layer, cloud): [br2]{D[64], Wab[64][2]}, b2[br2][2], pad
+constexpr int FILM_BR_FLOATS = 192;
+constexpr int FILM_B2_OFF = 384;                       // floats
+
+__device__ __forceinline__ uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ float u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
+__device__ __forceinline__ uint32_t bf16_rne(float x) {   // top-16 bits, round to nearest even
+    const uint32_t u = f2u(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// relu on the bit pattern: one v_max_i32 (fmaxf would add a canonicalising v_max per MFMA output)
+__device__ __forceinline__ float relu(float x) { return u2f((uint32_t)max((int)f2u(x), 0)); }
+// {bf16(a), bf16(b)} round-to-nearest-even in one v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t pack_bf16_rne(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+// {top16(a), top16(b)} (truncation) in one v_perm_b32
+__device__ __forceinline__ uint32_t pack_bf16_trunc(float a, float b) {
+    return __builtin_amdgcn_perm(f2u(b), f2u(a), 0x07060302u);
+}
+// truncation split: x = hi + rest exactly, hi has 8 significant bits
+__device__ __forceinline__ uint32_t split_hi(float x, float &rest) {
+    const uint32_t h = f2u(x) & 0xFFFF0000u;
+    rest = x - u2f(h);
+    return h;
+}
+
+constexpr int TILE = 32;          // points per tile (one MFMA N tile)
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_void;
+
+
+__device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float sel3(int c, float v0, float v1, float v2) {   // c wave-uniform
+    return c == 0 ? v0 : (c == 1 ? v1 : v2);
+}
+
+// split-precision product terms: parts are 0 = hi, 1 = mid/lo, 2 = lo
+template <int NS> struct Terms;
+template <> struct Terms<1> { static constexpr int N = 1; static constexpr int A[1] = {0}, B[1] = {0}; };
+template <> struct Terms<2> { static constexpr int N = 3; static constexpr int A[3] = {1, 0, 0}, B[3] = {0, 1, 0}; };
+template <> struct Terms<3> {
+    static constexpr int N = 6;
+    static constexpr int A[6] = {1, 2, 0, 1, 0, 0}, B[6] = {1, 0, 2, 0, 1, 0};
+};
+
+// One conditioner branch (logvar or mu) of one layer for one 32-point tile:
+// returns the two pre-activation outputs o_a, o_b of the branch (sum over this
+// lane-half's 32 features; the caller adds the other half).
+
+// B operand of the input MFMA (see pack_kernel's A0 layout): lane half h carries the 3-way bf16
+// split of ITS input channel (h = 0: keep channel a, h = 1: keep channel b)
+__device__ __forceinline__ u32x4 input_fragment(float x, int h) {
+    float r1, r2, r3;
+    const uint32_t xh = split_hi(x, r1), xm = split_hi(r1, r2), xl = split_hi(r2, r3);
+    u32x4 b0;
+    b0.x = (xh >> 16) | xm;                 // e0 = xh, e1 = xm
+    b0.y = (xh >> 16) | xl;                 // e2 = xh, e3 = xl
+    b0.z = (xm >> 16) | xh;                 // e4 = xm, e5 = xh
+    b0.w = h ? 0x00003F80u : 0x3F803F80u;   // e6 = 1, e7 = (h == 0)
+    return b0;
+}
+
+// A operand of the input MFMA for (folded weight w of this half's channel, folded bias T):
+// slots [wh wh wm wh wm wl | T*], T* = (Th, Tm) for h = 0 and (Tl, 0) for h = 1; returns slot j
+__device__ __forceinline__ uint32_t input_weight_slot(float w, float T, int h, int j) {
+    float r1, r2, q1, q2, dummy;
+    const uint32_t wh = split_hi(w, r1) >> 16, wm = split_hi(r1, r2) >> 16, wl = split_hi(r2, dummy) >> 16;
+    const uint32_t Th = split_hi(T, q1) >> 16, Tm = split_hi(q1, q2) >> 16, Tl = split_hi(q2, dummy) >> 16;
+    switch (j) {
+        case 0: case 1: case 3: return wh;
+        case 2: case 4: return wm;
+        case 5: return wl;
+        case 6: return h == 0 ? Th : Tl;
+        default: return h == 0 ? Tm : 0u;
+    }
+}
+
+// feature held by accumulator register r (0..15) of M tile t in lane half h
+__device__ __forceinline__ constexpr int acc_feature(int t, int r, int h) { return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+}  // namespace
+#endif  // DPF_FLOW_COMMON_H
