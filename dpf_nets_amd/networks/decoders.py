@@ -3,11 +3,13 @@
 list-likes of 3*n_flows (B,3,N) tensors in DIRECT order for both modes.
 
 Eval mode runs ALL layers in one fused HIP launch (csrc/flow.hip); the lists are
-FlowLists over three (L,B,3,N) buffers the kernel fills.  Training mode chains
-the layers' tensor-op path (decoders.py:58-70)."""
+FlowLists over three (L,B,3,N) buffers the kernel fills.  Training mode on CUDA
+tensors runs the HIP training kernels for the whole stack as one autograd node
+(networks/train_engine.py); `forward_torch` chains the layers' tensor-op path
+(decoders.py:58-70) for CPU tensors / DPF_TRAIN_IMPL=torch."""
 import torch.nn as nn
 
-from .flows import CondRealNVPFlow3DTriple, _needs_autograd
+from .flows import CondRealNVPFlow3DTriple, _needs_autograd, use_hip_training
 from .flowlist import FlowList
 from .engine import FlowStack
 
@@ -63,6 +65,13 @@ class LocalCondRNVPDecoder(nn.Module):
         (the BASELINE metric's 14-layer stack = first 14 layers of n_flows=5)."""
         if mode not in ("direct", "inverse"):
             raise ValueError(mode)
+        if use_hip_training(self, p):
+            from .train_engine import run_training_stack
+            layers = self.coupling_layers()
+            if n_layers is not None:
+                layers = layers[:int(n_layers)]
+            ps, mus, lvs = run_training_stack(layers, p, g, mode)
+            return list(ps.unbind(0)), list(mus.unbind(0)), list(lvs.unbind(0))
         if self.training or _needs_autograd(p, g):
             if n_layers is not None:
                 raise ValueError("n_layers is only supported on the fused eval path")

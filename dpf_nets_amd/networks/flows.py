@@ -5,9 +5,14 @@ reference checkpoints load unchanged.
 forward(p, g, mode) -> (p_out, mu, logvar), p (B,3,N), g (B,G):
   * eval mode (BatchNorm frozen, the per-point map of evaluate()/inference):
     the fused HIP stack (csrc/flow.hip) -- no torch ops on the path;
-  * training mode (BatchNorm batch statistics + autograd): the op sequence of
-    flows.py:95-117 on PyTorch-ROCm tensor ops.  [Round-1 status: not yet HIP.]
+  * training mode (BatchNorm batch statistics + autograd) on CUDA tensors: the HIP
+    training kernels (csrc/flow_train.hip via networks/train_engine.py), forward and
+    backward; DPF_TRAIN_IMPL=torch selects the tensor-op restatement of
+    flows.py:95-117 instead (`forward_torch`, also what CPU tensors get: the
+    reference-shaped module the CPU tests check against the golden vectors).
 """
+import os
+
 from collections import OrderedDict
 
 import torch
@@ -15,6 +20,12 @@ import torch.nn as nn
 
 from .layers import SharedDot, Swish
 from .engine import FlowStack
+
+TRAIN_IMPL = os.environ.get("DPF_TRAIN_IMPL", "hip")
+
+
+def use_hip_training(module, p):
+    return module.training and p.is_cuda and TRAIN_IMPL == "hip"
 
 
 def _needs_autograd(*tensors):
@@ -101,6 +112,10 @@ class CondRealNVPFlow3D(nn.Module):
     def forward(self, p, g, mode="direct"):
         if mode not in ("direct", "inverse"):
             raise ValueError(mode)
+        if use_hip_training(self, p):
+            from .train_engine import run_training_stack
+            ps, mus, lvs = run_training_stack([self], p, g, mode)
+            return ps[0], mus[0], lvs[0]
         if self.training or _needs_autograd(p, g):
             return self.forward_torch(p, g, mode)
         if self._stack is None:

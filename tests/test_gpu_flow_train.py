@@ -1,0 +1,176 @@
+"""Parity of the HIP TRAINING path (csrc/flow_train.hip through the C ABI: batch-statistics
+BatchNorm forward + the whole backward pass) against
+
+  * the golden vectors captured from the reference's PyTorch modules in train() mode
+    (outputs, d/dp, d/dg, projections of every parameter gradient, BatchNorm running statistics),
+  * the tensor-op restatement of flows.py:95-117 (`forward_torch`) run on the same GPU with
+    autograd, at sizes with ragged tiles and many workgroups.
+
+Tolerance: outputs rel <= 1e-4 of the tensor's scale (north star); gradients rel <= 1e-3 of the
+gradient tensor's scale (they pass through two BatchNorm backward reductions over all B*N points
+and a single-bf16 outer product for dW1, see flow_train.hip header)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import flow_oracle as FO
+from oracle.gen_golden import layer_inputs, _grad_projection
+
+pytestmark = pytest.mark.gpu
+
+OUT_REL = 1e-4
+GRAD_REL = 1e-3
+
+
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from dpf_nets_amd import networks
+    return networks
+
+
+def rel(got, ref):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else got
+    ref = ref.detach().cpu().numpy() if torch.is_tensor(ref) else ref
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    return float(np.abs(got.astype(np.float64) - ref).max() / (np.abs(ref).max() + 1e-30))
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz")), json.load(open(os.path.join(golden_dir, name + ".json")))
+
+
+def _check_gproj(named_grads, gold, prefix, seed, tol=3e-3):
+    for k, v in _grad_projection(named_grads, seed).items():
+        ref = gold[prefix + "/gproj/" + k]
+        assert abs(v[0] - ref[0]) <= tol * (ref[2] + 1e-6) + 1e-4, (k, v, ref)
+        assert abs(v[1] - ref[1]) <= tol * (ref[2] + 1e-6) + 1e-4, (k, v, ref)
+        assert abs(v[2] - ref[2]) <= tol * (ref[2] + 1e-6) + 1e-4, (k, v, ref)
+
+
+def test_single_layer_training_vs_reference_golden(golden_dir):
+    nets = _gpu()
+    gold, meta = _load(golden_dir, "flow_layer")
+    B, N, F, G = meta["B"], meta["N"], meta["F"], meta["G"]
+    for case in meta["cases"]:
+        if case["bn"] != "train":
+            continue
+        mod = nets.CondRealNVPFlow3D(F, G, warp_inds=case["warp"])
+        mod.load_state_dict(FO.to_torch(FO.make_layer_state(case["seed"], F, G, case["warp"])), strict=True)
+        mod = mod.cuda().train()
+        p, g, r1, r2, r3 = layer_inputs(case["seed"], B, N, G)
+        tp = torch.from_numpy(p.copy()).cuda().requires_grad_(True)
+        tg = torch.from_numpy(g.copy()).cuda().requires_grad_(True)
+        po, mu, lv = mod(tp, tg, mode=case["mode"])
+        t = case["tag"]
+        for name, got in (("p_out", po), ("mu", mu), ("logvar", lv)):
+            r = rel(got, gold[t + "/" + name])
+            assert r <= OUT_REL, (t, name, r)
+        loss = (po * torch.from_numpy(r1).cuda()).sum() + (lv * torch.from_numpy(r2).cuda()).sum() \
+            + (mu * torch.from_numpy(r3).cuda()).sum()
+        loss.backward()
+        assert rel(tp.grad, gold[t + "/grad_p"]) <= GRAD_REL, (t, rel(tp.grad, gold[t + "/grad_p"]))
+        assert rel(tg.grad, gold[t + "/grad_g"]) <= GRAD_REL, (t, rel(tg.grad, gold[t + "/grad_g"]))
+        _check_gproj([(k, v.grad.cpu()) for k, v in mod.named_parameters()], gold, t, case["seed"])
+        sd = mod.state_dict()
+        for k in sd:
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                np.testing.assert_allclose(sd[k].cpu().numpy(), gold[t + "/stats/" + k], rtol=1e-4, atol=1e-5, err_msg=t + k)
+
+
+def test_decoder_training_step_vs_reference_golden(golden_dir):
+    """training.py:37-55: inverse flow + PointFlowNLL + backward, n_flows = 2 (6 coupling layers)."""
+    nets = _gpu()
+    gold, meta = _load(golden_dir, "flow_decoder")
+    case = [c for c in meta["cases"] if c.get("bn") == "train"][0]
+    c, n_flows, B, N, G, seed = (case[k] for k in ("tag", "n_flows", "B", "N", "G", "seed"))
+    dec = nets.LocalCondRNVPDecoder(n_flows, 64, G, weight_std=0.01)
+    dec.load_state_dict(FO.to_torch(FO.make_decoder_state(seed, n_flows, 64, G)), strict=True)
+    dec = dec.cuda().train()
+    tgt, z, g = FO.synthetic_inputs(seed, B, N, G)
+    tp = torch.from_numpy(tgt.copy()).cuda().requires_grad_(True)
+    tg = torch.from_numpy(g.copy()).cuda().requires_grad_(True)
+    ps, mus, lvs = dec(tp, tg, mode="inverse")
+    assert isinstance(ps, list) and len(ps) == len(mus) == len(lvs) == 3 * n_flows
+    pm, pl = torch.zeros(B, 3, N).cuda(), torch.full((B, 3, N), -3.6).cuda()
+    loss = nets.PointFlowNLL()(ps + [tp], [pm] + mus, [pl] + lvs)
+    loss.backward()
+    assert rel(ps[0], gold[c + "/ps0"]) <= OUT_REL
+    assert rel(sum(lvs), gold[c + "/sum_logvars"]) <= OUT_REL
+    np.testing.assert_allclose(float(loss), float(gold[c + "/nll"]), rtol=5e-5)
+    assert rel(tp.grad, gold[c + "/grad_p"]) <= 2e-3, rel(tp.grad, gold[c + "/grad_p"])
+    assert rel(tg.grad, gold[c + "/grad_g"]) <= 2e-3, rel(tg.grad, gold[c + "/grad_g"])
+    _check_gproj([(k, v.grad.cpu()) for k, v in dec.named_parameters()], gold, c, seed)
+    sd = dec.state_dict()
+    for k in sd:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            np.testing.assert_allclose(sd[k].cpu().numpy(), gold[c + "/stats/" + k], rtol=1e-4, atol=1e-5, err_msg=k)
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == 1, k
+
+
+@pytest.mark.parametrize("B,N,mode", [(3, 1000, "inverse"), (8, 2048, "direct"), (2, 40, "inverse")])
+def test_training_hip_vs_tensor_op_path(B, N, mode):
+    """Same module, same inputs: HIP kernels vs forward_torch + autograd (PyTorch-ROCm fp32 ops) on
+    the GPU -- every output, every input gradient, every parameter gradient elementwise."""
+    nets = _gpu()
+    n_flows, G, seed = 2, 128, 31
+    sd = FO.to_torch(FO.make_decoder_state(seed, n_flows, 64, G))
+    tgt, z, g = FO.synthetic_inputs(seed, B, N, G)
+    src = tgt if mode == "inverse" else z
+    res = {}
+    for impl in ("hip", "torch"):
+        dec = nets.LocalCondRNVPDecoder(n_flows, 64, G, weight_std=0.01)
+        dec.load_state_dict(sd, strict=True)
+        dec = dec.cuda().train()
+        tp = torch.from_numpy(src.copy()).cuda().requires_grad_(True)
+        tg = torch.from_numpy(g.copy()).cuda().requires_grad_(True)
+        if impl == "hip":
+            ps, mus, lvs = dec(tp, tg, mode=mode)
+        else:
+            ps, mus, lvs = dec.forward_torch(tp, tg, mode=mode)
+        pm, pl = torch.zeros(B, 3, N).cuda(), torch.full((B, 3, N), -3.6).cuda()
+        smp = ps + [tp] if mode == "inverse" else [tp] + ps
+        loss = nets.PointFlowNLL()(smp, [pm] + mus, [pl] + lvs) + 0.1 * (ps[2] * mus[4]).mean()
+        loss.backward()
+        res[impl] = dict(ps=[x.detach() for x in ps], mus=[x.detach() for x in mus], lvs=[x.detach() for x in lvs],
+                         loss=float(loss), gp=tp.grad, gg=tg.grad,
+                         grads={k: v.grad for k, v in dec.named_parameters()},
+                         stats={k: v for k, v in dec.state_dict().items() if "running" in k})
+    h, t = res["hip"], res["torch"]
+    for key in ("ps", "mus", "lvs"):
+        for i, (a, b) in enumerate(zip(h[key], t[key])):
+            assert rel(a, b) <= OUT_REL or float(b.abs().max()) == 0.0, (key, i, rel(a, b))
+    assert abs(h["loss"] - t["loss"]) <= 5e-5 * abs(t["loss"])
+    assert rel(h["gp"], t["gp"]) <= GRAD_REL, rel(h["gp"], t["gp"])
+    assert rel(h["gg"], t["gg"]) <= GRAD_REL, rel(h["gg"], t["gg"])
+    for k in t["grads"]:
+        assert h["grads"][k] is not None, k
+        r = rel(h["grads"][k], t["grads"][k])
+        assert r <= 2 * GRAD_REL, (k, r)
+    for k in t["stats"]:
+        np.testing.assert_allclose(h["stats"][k].cpu().numpy(), t["stats"][k].cpu().numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+def test_training_path_uses_hip_and_repeats(monkeypatch):
+    nets = _gpu()
+    from dpf_nets_amd.networks import flows
+    assert flows.TRAIN_IMPL == "hip"
+
+    def boom(*a, **k):
+        raise AssertionError("tensor-op path used on a CUDA training step")
+    monkeypatch.setattr(flows.CondRealNVPFlow3D, "forward_torch", boom)
+    dec = nets.LocalCondRNVPDecoder(1, 64, 128).cuda().train()
+    tgt, z, g = FO.synthetic_inputs(5, 4, 300, 128)
+    outs = []
+    for _ in range(2):
+        dec.zero_grad()
+        tp = torch.from_numpy(tgt.copy()).cuda().requires_grad_(True)
+        ps, mus, lvs = dec(tp, torch.from_numpy(g).cuda(), mode="inverse")
+        (ps[0].square().mean() + sum(lvs).mean()).backward()
+        outs.append((ps[0].detach().clone(), tp.grad.clone(), dec.flows[0].nvp1.T_mu_0[3].weight.grad.clone()))
+    for a, b in zip(*outs):
+        assert rel(a, b) <= 1e-5
