@@ -25,8 +25,12 @@
 // accumulator-fragment dumps.  The per-cloud FiLM conditioner nets (B x 64 tensors) stay on
 // PyTorch-ROCm, batched over all layers; they enter here as the tensor `fm` and leave as `dfm`.
 //
-// Split precision is fixed to bf16x3 (hi/lo) for every per-point contraction; the dW1 outer
-// product over points uses single bf16 products (unbiased rounding averages out over B*N points).
+// Precision: the forward contraction h1 = W1 relu(h0) -- and its recomputation in the backward passes,
+// which decides every ReLU mask -- runs at the precision the caller asks for: bf16x3 (hi/lo split,
+// ~1e-5) or bf16x6 (hi/mid/lo, fp32-class; the default of the host side, because a ReLU whose
+// pre-activation is within the forward error of zero switches the other way and moves that point's
+// gradient to the other subgradient: at 1e-5 that happens to ~1e-5 of all ReLUs).  The gradient
+// contractions themselves (dh0 = W1^T dh1, dW1 = dh1 h0^T) use hi/lo splits (3 products).
 #include <stdlib.h>
 
 #include "flow_common.h"
@@ -46,12 +50,12 @@ constexpr int T_B2 = 4480;     // [4]      sd2.bias
 constexpr int T_BR = 4484;
 constexpr int T_LAYER = 2 * T_BR;
 
-// ---- packed per-layer training block (bytes); the first 36864 bytes are the eval layer format ---
-constexpr int PT_A1 = 0;                 // W1 fragments, hi | lo                      2 x 16384
-constexpr int PT_A0 = 32768;             // input MFMA, folded gamma*rstd0 / beta      4096
-constexpr int PT_A0N = 36864;            // input MFMA, folded to the NORMALISED h0    4096
-constexpr int PT_A1T = 40960;            // W1^T fragments, hi | lo                    2 x 16384
-constexpr int PT_BYTES = 73728;
+// ---- packed per-layer training block (bytes); its head is the eval layer format of precision NS ---
+constexpr int PT_A1 = 0;                                                   // W1 fragments, NS parts x 16384
+__host__ __device__ constexpr int pt_a0(int NS) { return NS * P_A1_PART; }           // input MFMA, gamma*rstd0 / beta
+__host__ __device__ constexpr int pt_a0n(int NS) { return pt_a0(NS) + 4096; }        // input MFMA -> NORMALISED h0
+__host__ __device__ constexpr int pt_a1t(int NS) { return pt_a0(NS) + 8192; }        // W1^T fragments, hi | lo
+__host__ __device__ constexpr int pt_bytes(int NS) { return pt_a1t(NS) + 2 * P_A1_PART; }
 
 // ---- per-layer saved statistics (floats) ---------------------------------------------------------
 // stats[br][k][64]: k = 0 mean0, 1 rstd0, 2 mean1, 3 rstd1, 4 batch var0 (unbiased), 5 batch var1 (unbiased)
@@ -70,20 +74,26 @@ __device__ __forceinline__ f32x16 zero16() {
 // ===================================================================================================
 // pack: W1 and W1^T fragments for every layer (once per optimizer step)
 // ===================================================================================================
+template <int NS>
 __global__ __launch_bounds__(256) void tpack_kernel(const float *__restrict__ tcanon, uint8_t *__restrict__ packed) {
     const int l = blockIdx.x;
     const float *cl = tcanon + (size_t)l * T_LAYER;
-    uint16_t *o1 = (uint16_t *)(packed + (size_t)l * PT_BYTES + PT_A1);
-    uint16_t *oT = (uint16_t *)(packed + (size_t)l * PT_BYTES + PT_A1T);
+    uint16_t *o1 = (uint16_t *)(packed + (size_t)l * pt_bytes(NS) + PT_A1);
+    uint16_t *oT = (uint16_t *)(packed + (size_t)l * pt_bytes(NS) + pt_a1t(NS));
     for (int idx = threadIdx.x; idx < 2 * 2 * 4 * 64 * 8; idx += blockDim.x) {
         const int j = idx & 7, lane = (idx >> 3) & 63, s = (idx >> 9) & 3, tp = (idx >> 11) & 1, br = idx >> 12;
         const int i = lane & 31, h = lane >> 5;
         const int fk = acc_feature(s >> 1, 8 * (s & 1) + j, h);     // feature carried by K slot (s, j, h)
         const float *W1 = cl + br * T_BR + T_W1;
-        float r1;
+        float r1, r2;
         const float w = W1[(32 * tp + i) * 64 + fk];                // forward: rows = out feature, K = in feature
         o1[idx] = (uint16_t)(split_hi(w, r1) >> 16);
-        o1[P_A1_PART / 2 + idx] = (uint16_t)bf16_rne(r1);
+        if (NS == 2) {
+            o1[P_A1_PART / 2 + idx] = (uint16_t)bf16_rne(r1);
+        } else {
+            o1[P_A1_PART / 2 + idx] = (uint16_t)(split_hi(r1, r2) >> 16);
+            o1[P_A1_PART + idx] = (uint16_t)bf16_rne(r2);
+        }
         const float wt = W1[fk * 64 + (32 * tp + i)];               // transposed: rows = in feature, K = out feature
         oT[idx] = (uint16_t)(split_hi(wt, r1) >> 16);
         oT[P_A1_PART / 2 + idx] = (uint16_t)bf16_rne(r1);
@@ -120,7 +130,7 @@ __global__ __launch_bounds__(256) void tstats_x_kernel(int N, int ka, int kb, co
 // BN0 batch statistics (analytic: h0 = W0 x is linear in x) and the two folded input-MFMA fragment
 // sets of the layer.  One workgroup, thread = (branch, feature).
 __global__ __launch_bounds__(128) void tbn0_kernel(int nblk, double count, const double *__restrict__ part,
-                                                   const float *__restrict__ tcanon_l, uint8_t *__restrict__ packed_l,
+                                                   const float *__restrict__ tcanon_l, uint8_t *__restrict__ packed_a0,
                                                    float *__restrict__ stats_l) {
     __shared__ double mom[5];
     __shared__ float fold[2][64][4];     // per (branch, feature): w_a', w_b', T'  |  and normalised variants share the loop
@@ -149,7 +159,7 @@ __global__ __launch_bounds__(128) void tbn0_kernel(int nblk, double count, const
     fold[br][f][0] = s0 * (float)wa; fold[br][f][1] = s0 * (float)wb; fold[br][f][2] = beta - (float)mean * s0;
     foldn[br][f][0] = rstd * (float)wa; foldn[br][f][1] = rstd * (float)wb; foldn[br][f][2] = -(float)mean * rstd;
     __syncthreads();
-    uint16_t *a0 = (uint16_t *)(packed_l + PT_A0), *a0n = (uint16_t *)(packed_l + PT_A0N);
+    uint16_t *a0 = (uint16_t *)packed_a0, *a0n = (uint16_t *)(packed_a0 + 4096);
     for (int idx = threadIdx.x; idx < 2 * 2 * 64 * 8; idx += blockDim.x) {
         const int j = idx & 7, lane = (idx >> 3) & 63, t = (idx >> 9) & 1, b2 = idx >> 10;
         const int ff = 32 * t + (lane & 31), h = lane >> 5;
@@ -173,10 +183,12 @@ __device__ __forceinline__ void input_mfma(const uint8_t *a0, int br, int lane, 
         acc[t] = mfma(*(const u32x4 *)(a0 + ((br * 2 + t) * 64 + lane) * 16), b0, zero16());
 }
 
-// hi/lo bf16 split of an accumulator fragment pair into the B fragments of the next contraction
-// (register r of M tile t = element j = r&7 of k-step 2t + (r>>3)); RELU = clamp at zero first
-template <bool RELU>
-__device__ __forceinline__ void split_fragment(const f32x16 (&v)[2], u32x4 (&bf)[2][4]) {
+// bf16 split (NS parts) of an accumulator fragment pair into the B fragments of the next contraction
+// (register r of M tile t = element j = r&7 of k-step 2t + (r>>3)); RELU = clamp at zero first.
+// Same arithmetic as branch_tile in csrc/flow.hip: the recomputed activations are bit-identical to
+// the forward kernel's.
+template <bool RELU, int NS>
+__device__ __forceinline__ void split_fragment(const f32x16 (&v)[2], u32x4 (&bf)[NS][4]) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -186,23 +198,31 @@ __device__ __forceinline__ void split_fragment(const f32x16 (&v)[2], u32x4 (&bf)
             float l0, l1;
             split_hi(v0, l0); split_hi(v1, l1);
             bf[0][s][d] = pack_bf16_trunc(v0, v1);
-            bf[1][s][d] = pack_bf16_rne(l0, l1);
+            if constexpr (NS == 2) {
+                bf[1][s][d] = pack_bf16_rne(l0, l1);
+            } else {
+                float m0, m1;
+                split_hi(l0, m0); split_hi(l1, m1);
+                bf[1][s][d] = pack_bf16_trunc(l0, l1);
+                bf[2][s][d] = pack_bf16_rne(m0, m1);
+            }
         }
 }
 
-// acc[tp] += A1[br] . B  with the three split terms (lo*hi, hi*lo, hi*hi); a1 = base of [part][br][tp][s][lane]
-__device__ __forceinline__ void chain_mfma(const uint8_t *a1, int br, int lane, const u32x4 (&bf)[2][4], f32x16 (&acc)[2]) {
-    constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};
+// acc[tp] += A1[br] . B  with the split terms of Terms<NS>; a1 = base of [part][br][tp][s][lane]
+template <int NS>
+__device__ __forceinline__ void chain_mfma(const uint8_t *a1, int br, int lane, const u32x4 (&bf)[NS][4], f32x16 (&acc)[2]) {
+    using TT = Terms<NS>;
 #pragma unroll
-    for (int term = 0; term < 3; ++term)
+    for (int term = 0; term < TT::N; ++term)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             u32x4 af[2];
 #pragma unroll
             for (int tp = 0; tp < 2; ++tp)
-                af[tp] = *(const u32x4 *)(a1 + TA[term] * P_A1_PART + (((br * 2 + tp) * 4 + s) * 64 + lane) * 16);
+                af[tp] = *(const u32x4 *)(a1 + TT::A[term] * P_A1_PART + (((br * 2 + tp) * 4 + s) * 64 + lane) * 16);
 #pragma unroll
-            for (int tp = 0; tp < 2; ++tp) acc[tp] = mfma(af[tp], bf[TB[term]][s], acc[tp]);
+            for (int tp = 0; tp < 2; ++tp) acc[tp] = mfma(af[tp], bf[TT::B[term]][s], acc[tp]);
         }
 }
 
@@ -263,18 +283,19 @@ struct TArgs {
     const float *filmb_l;        // (B, FB_CLOUD) backward FiLM blocks
     const float *stats_l;        // ST_LAYER
     const float *p_in;           // (B, 3, N)
-    int B, N, ka, kb, wa, wb, mode;
+    int B, N, ka, kb, wa, wb, mode, a0_off;
     float eps;
 };
 
 // h1 = W1 relu(BN0(W0 x)) for every point; per-workgroup partial sums and sums of squares
 //   part[blk][br][2][64]
+template <int NS>
 __global__ __launch_bounds__(TW * 64) void tstats_h1_kernel(TArgs a, float *__restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ float acc_s[2][2][64];
     const int bi = blockIdx.y, lane = threadIdx.x & 63, h = lane >> 5, pl = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    stage_bytes(a.packed_l, smem, PT_A0N, wave, lane);                    // A1 (32 KB) + A0 (4 KB)
+    stage_bytes(a.packed_l, smem, pt_a0n(NS), wave, lane);                // A1 + A0
     if (threadIdx.x < 256) ((float *)acc_s)[threadIdx.x] = 0.f;
     const int N = a.N, n = (blockIdx.x * TW + wave) * TILE + pl;
     const bool valid = n < N;
@@ -286,10 +307,10 @@ __global__ __launch_bounds__(TW * 64) void tstats_h1_kernel(TArgs a, float *__re
 #pragma unroll
     for (int br = 0; br < 2; ++br) {
         f32x16 acc0[2], acc1[2] = {zero16(), zero16()}, sq[2];
-        u32x4 bf[2][4];
-        input_mfma(smem + PT_A0, br, lane, b0, acc0);
-        split_fragment<true>(acc0, bf);
-        chain_mfma(smem + PT_A1, br, lane, bf, acc1);
+        u32x4 bf[NS][4];
+        input_mfma(smem + pt_a0(NS), br, lane, b0, acc0);
+        split_fragment<true, NS>(acc0, bf);
+        chain_mfma<NS>(smem + PT_A1, br, lane, bf, acc1);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -350,23 +371,26 @@ __global__ __launch_bounds__(128) void tfilm_fold_kernel(int nblk, float count, 
 // backward
 // ===================================================================================================
 // LDS map of the backward kernels (bytes)
-constexpr int L_PACK = 0;                       // packed layer block (PT_BYTES)
-constexpr int L_FILM = PT_BYTES;                // eval FiLM block of this cloud (2048)
-constexpr int L_FILMB = L_FILM + 2048;          // backward FiLM block (2048)
-constexpr int L_RED = L_FILMB + 2048;           // workgroup reduction scratch
+constexpr int L_PACK = 0;                                                  // packed layer block (pt_bytes)
+__host__ __device__ constexpr int l_film(int NS) { return pt_bytes(NS); }            // eval FiLM block of this cloud (2048)
+__host__ __device__ constexpr int l_filmb(int NS) { return l_film(NS) + 2048; }      // backward FiLM block (2048)
+__host__ __device__ constexpr int l_red(int NS) { return l_filmb(NS) + 2048; }       // workgroup reduction scratch
+constexpr int XY_WAVE = 2 * 64 * 32;                                       // bf16 elements of one wave's X | Y tiles
 
 // Pass 1: recompute the layer to h2, differentiate the coupling transform and the output SharedDot.
 //   stores  dh2a fragments (scratch)         dp_in <- direct term  g * d(p_out)/d(p)
 //   partial sums per workgroup: part1[blk][br][k][64], k = 0 dW2a, 1 dW2b, 2 da, 3 dc;  part1b[blk][br][2] = db2
+template <int NS>
 __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__restrict__ g_p, const float *__restrict__ g_mu,
                                                         const float *__restrict__ g_lv, float *__restrict__ dp_in,
                                                         float *__restrict__ scratch, float *__restrict__ part1,
                                                         float *__restrict__ part1b) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int L_FILM = l_film(NS), L_FILMB = l_filmb(NS), L_RED = l_red(NS);
     float *red = (float *)(smem + L_RED);                                  // [2 br][4][64] + [2][2]
     const int bi = blockIdx.y, lane = threadIdx.x & 63, h = lane >> 5, pl = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    stage_bytes(a.packed_l, smem + L_PACK, PT_A0N, wave, lane);
+    stage_bytes(a.packed_l, smem + L_PACK, pt_a0n(NS), wave, lane);
     stage_bytes((const uint8_t *)(a.film_l + (size_t)bi * 512), smem + L_FILM, 2048, wave, lane);
     stage_bytes((const uint8_t *)(a.filmb_l + (size_t)bi * FB_CLOUD), smem + L_FILMB, 2048, wave, lane);
     for (int i = threadIdx.x; i < 2 * 4 * 64 + 4; i += TW * 64) red[i] = 0.f;
@@ -393,11 +417,11 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
 #pragma unroll
     for (int br = 0; br < 2; ++br) {
         f32x16 acc0[2];
-        u32x4 bf[2][4];
-        input_mfma(smem + L_PACK + PT_A0, br, lane, b0, acc0);
-        split_fragment<true>(acc0, bf);
+        u32x4 bf[NS][4];
+        input_mfma(smem + L_PACK + pt_a0(NS), br, lane, b0, acc0);
+        split_fragment<true, NS>(acc0, bf);
         load_features(film + br * FILM_BR_FLOATS, h, pre[br]);             // accumulator starts at D
-        chain_mfma(smem + L_PACK + PT_A1, br, lane, bf, pre[br]);
+        chain_mfma<NS>(smem + L_PACK + PT_A1, br, lane, bf, pre[br]);
         float oa = 0.f, ob = 0.f;
         const float *wab = film + br * FILM_BR_FLOATS + 64;
 #pragma unroll
@@ -536,15 +560,17 @@ __global__ __launch_bounds__(128) void tbwd1_finish_kernel(int B, int nb, float 
 // Pass 2: BN1 backward, dh0 = W1^T dh1 (matrix cores), dW1 = dh1 h0^T (matrix cores, contraction over the
 // tile's 32 points through an LDS transpose), relu backward; stores dh0a; partials of d gamma0 / d beta0.
 //   part2[blk][br][4224]: [0..63] d gamma0, [64..127] d beta0, [128..4223] dW1 (row = out feature)
+template <int NS>
 __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__restrict__ s12, float *__restrict__ scratch,
                                                         float *__restrict__ scratch2, float *__restrict__ part2) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int L_FILM = l_film(NS), L_FILMB = l_filmb(NS), L_RED = l_red(NS);
     float *red = (float *)(smem + L_RED);                                  // [128] d gamma0 | d beta0 of the branch
-    uint16_t *tr = (uint16_t *)(smem + L_RED + 512);                       // per wave: X[64][40], Y[64][40] bf16
+    uint16_t *tr = (uint16_t *)(smem + L_RED + 512);                       // per wave: X[64][32], Y[64][32] bf16, swizzled
     float *redw = (float *)(smem + L_RED + 512);                           // [4096] dW1, ALIASES tr once the MFMAs are done
     const int bi = blockIdx.y, lane = threadIdx.x & 63, h = lane >> 5, pl = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    stage_bytes(a.packed_l, smem + L_PACK, PT_BYTES, wave, lane);
+    stage_bytes(a.packed_l, smem + L_PACK, pt_bytes(NS), wave, lane);
     stage_bytes((const uint8_t *)(a.film_l + (size_t)bi * 512), smem + L_FILM, 2048, wave, lane);
     stage_bytes((const uint8_t *)(a.filmb_l + (size_t)bi * FB_CLOUD), smem + L_FILMB, 2048, wave, lane);
     const int N = a.N, n = (blockIdx.x * TW + wave) * TILE + pl;
@@ -557,18 +583,21 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
     const float *filmb = (const float *)(smem + L_FILMB);
     const size_t tile = ((size_t)bi * gridDim.x + blockIdx.x) * TW + wave;
     const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-    uint16_t *X = tr + wave * (2 * 64 * 40), *Y = X + 64 * 40;
+    uint16_t *X = tr + wave * XY_WAVE, *Y = X + 64 * 32;
+    // tile element (row f, point q) lives at f*32 + ((q>>3) ^ ((f>>2)&3))*8 + (q&7): the 16-byte chunks of a
+    // row are XOR-swizzled so that the 16 rows a ds_read_b128 group touches hit 16 distinct bank quads
+    auto xy_off = [](int f, int chunk) { return f * 32 + ((chunk ^ ((f >> 2) & 3)) << 3); };
     for (int br = 0; br < 2; ++br) {
         __syncthreads();                                                   // staging landed / previous branch flushed
         if (threadIdx.x < 128) red[threadIdx.x] = 0.f;
         __syncthreads();
         f32x16 h0a[2], h0n[2], pre[2], g2[2];
-        u32x4 bf[2][4];
-        input_mfma(smem + L_PACK + PT_A0, br, lane, b0, h0a);              // gamma*h0n + beta
-        input_mfma(smem + L_PACK + PT_A0N, br, lane, b0, h0n);             // normalised
-        split_fragment<true>(h0a, bf);
+        u32x4 bf[NS][4];
+        input_mfma(smem + L_PACK + pt_a0(NS), br, lane, b0, h0a);          // gamma*h0n + beta
+        input_mfma(smem + L_PACK + pt_a0n(NS), br, lane, b0, h0n);         // normalised
+        split_fragment<true, NS>(h0a, bf);
         load_features(film + br * FILM_BR_FLOATS, h, pre);
-        chain_mfma(smem + L_PACK + PT_A1, br, lane, bf, pre);              // pre = h1 + D
+        chain_mfma<NS>(smem + L_PACK + PT_A1, br, lane, bf, pre);          // pre = h1 + D
         load_fragment(scratch, tile, br, lane, g2);                        // dh2a from pass 1
         const float *fb = filmb + br * FB_BR;
         // dh1 = rstd1 * (dh1n - mean(dh1n) - h1n * mean(dh1n*h1n)),  dh1n = a*dh2a,  h1n = pre*rstd1 - c/a
@@ -587,8 +616,8 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
         // ---- dh0 = W1^T dh1
         u32x4 bg[2][4];
         f32x16 dh0[2] = {zero16(), zero16()};
-        split_fragment<false>(dh1, bg);
-        chain_mfma(smem + L_PACK + PT_A1T, br, lane, bg, dh0);
+        split_fragment<false, 2>(dh1, bg);
+        chain_mfma<2>(smem + L_PACK + pt_a1t(NS), br, lane, bg, dh0);
         f32x16 dh0a[2], tg[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -605,32 +634,44 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
             atomicAdd(&red[f], r0);
             atomicAdd(&red[64 + f], r1);
         }
-        // ---- dW1[fo][fi] += sum_points dh1[fo][pt] * h0[fi][pt]: transpose both fragments through LDS so that
-        // the 32 points become the K dimension (2 k-steps of 16), single bf16 products
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int f = acc_feature(t, r, 0) + 4 * h;
-                X[f * 40 + pl] = (uint16_t)bf16_rne(dh1[t][r]);
-                Y[f * 40 + pl] = (uint16_t)bf16_rne(relu(h0a[t][r]));
-            }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        // ---- dW1[fo][fi] += sum_points dh1[fo][pt] * h0[fi][pt]: both fragments are transposed through LDS so
+        // that the tile's 32 points become the K dimension (2 k-steps of 16).  hi/lo split like every other
+        // contraction: three rounds (hi.hi, hi.lo, lo.hi) over the same two LDS tiles.
         f32x16 dw[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};     // [fo tile][fi tile]
+        auto put = [&](uint16_t *dst, const f32x16 (&v)[2], bool clamp, bool lo) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            u32x4 fa[2], fbb[2];
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                fa[mt] = *(const u32x4 *)(X + (32 * mt + pl) * 40 + 16 * ks + 8 * h);     // row fo, 8 consecutive points
-                fbb[mt] = *(const u32x4 *)(Y + (32 * mt + pl) * 40 + 16 * ks + 8 * h);    // col fi, same points
+                for (int r = 0; r < 16; ++r) {
+                    const int f = acc_feature(t, r, 0) + 4 * h;
+                    const float x = clamp ? relu(v[t][r]) : v[t][r];
+                    float rest;
+                    const uint32_t hi = split_hi(x, rest);
+                    dst[xy_off(f, pl >> 3) + (pl & 7)] = lo ? (uint16_t)bf16_rne(rest) : (uint16_t)(hi >> 16);
+                }
+        };
+        auto outer = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 fa[2], fbb[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    fa[mt] = *(const u32x4 *)(X + xy_off(32 * mt + pl, 2 * ks + h));     // row fo, 8 consecutive points
+                    fbb[mt] = *(const u32x4 *)(Y + xy_off(32 * mt + pl, 2 * ks + h));    // col fi, same points
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) dw[mt][nt] = mfma(fa[mt], fbb[nt], dw[mt][nt]);
             }
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) dw[mt][nt] = mfma(fa[mt], fbb[nt], dw[mt][nt]);
-        }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
+        put(X, dh1, false, false); put(Y, h0a, true, false); outer();       // hi . hi
+        put(Y, h0a, true, true); outer();                                   // hi . lo
+        put(X, dh1, false, true); put(Y, h0a, true, false); outer();        // lo . hi
         __syncthreads();                                                   // every wave is done with its X / Y
         for (int i = threadIdx.x; i < 4096; i += TW * 64) redw[i] = 0.f;
         __syncthreads();
@@ -660,7 +701,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd3_kernel(TArgs a, float count, co
     float *red = (float *)(smem + 8192);                                   // [2 br][128]
     const int bi = blockIdx.y, lane = threadIdx.x & 63, h = lane >> 5, pl = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    stage_bytes(a.packed_l + PT_A0, smem, 8192, wave, lane);               // A0 and A0N only
+    stage_bytes(a.packed_l + a.a0_off, smem, 8192, wave, lane);            // A0 and A0N only
     for (int i = threadIdx.x; i < 256; i += TW * 64) red[i] = 0.f;
     const int N = a.N, n = (blockIdx.x * TW + wave) * TILE + pl;
     const bool valid = n < N;
@@ -674,7 +715,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd3_kernel(TArgs a, float count, co
 #pragma unroll
     for (int br = 0; br < 2; ++br) {
         f32x16 h0n[2], g[2], ta[2], tb[2];
-        input_mfma(smem + (PT_A0N - PT_A0), br, lane, b0, h0n);
+        input_mfma(smem + 4096, br, lane, b0, h0n);
         load_fragment(scratch2, tile, br, lane, g);                        // dh0a from pass 2
         const float *cb = a.tcanon_l + br * T_BR;
         const float *st = a.stats_l + br * ST_BR;
@@ -726,8 +767,12 @@ hipError_t set_lds(const void *fn, int bytes) {
 
 }  // namespace
 
+static inline int t_ns(int precision) { return precision == DPF_PREC_BF16X3 ? 2 : (precision == DPF_PREC_BF16X6 ? 3 : 0); }
+
 extern "C" size_t dpf_flow_train_canon_floats(void) { return (size_t)T_LAYER; }
-extern "C" size_t dpf_flow_train_packed_bytes(int n_layers) { return (size_t)n_layers * PT_BYTES; }
+extern "C" size_t dpf_flow_train_packed_bytes(int n_layers, int precision) {
+    return t_ns(precision) ? (size_t)n_layers * pt_bytes(t_ns(precision)) : 0;
+}
 extern "C" size_t dpf_flow_train_stats_floats(void) { return (size_t)ST_LAYER; }
 extern "C" size_t dpf_flow_train_film_floats(int B) { return (size_t)B * (512 + FB_CLOUD); }
 
@@ -749,9 +794,12 @@ extern "C" size_t dpf_flow_train_workspace_bytes(int B, int N) {
 // the two fragment scratch buffers (dh2a, dh0a): floats
 extern "C" size_t dpf_flow_train_scratch_floats(int B, int N) { return (size_t)t_nblk(B, N) * TW * 2 * 32 * 64; }
 
-extern "C" int dpf_flow_train_pack(int n_layers, const float *tcanon, void *packed, dpf_stream_t stream) {
+extern "C" int dpf_flow_train_pack(int n_layers, int precision, const float *tcanon, void *packed, dpf_stream_t stream) {
+    const int ns = t_ns(precision);
     if (n_layers <= 0 || !tcanon || !packed) return DPF_EINVAL;
-    hipLaunchKernelGGL(tpack_kernel, dim3(n_layers), dim3(256), 0, (hipStream_t)stream, tcanon, (uint8_t *)packed);
+    if (!ns) return DPF_ENOSUP;
+    if (ns == 2) hipLaunchKernelGGL(tpack_kernel<2>, dim3(n_layers), dim3(256), 0, (hipStream_t)stream, tcanon, (uint8_t *)packed);
+    else hipLaunchKernelGGL(tpack_kernel<3>, dim3(n_layers), dim3(256), 0, (hipStream_t)stream, tcanon, (uint8_t *)packed);
     return (int)hipGetLastError();
 }
 
@@ -772,37 +820,81 @@ static TWork carve(void *ws, int B, int N) {
     return w;
 }
 
-// Forward statistics + folds of ONE layer; afterwards dpf_flow_forward(n_layers = 1, packed = packed_l,
-// film = film_l) runs the layer itself.  stats_l receives the batch statistics (for the running-stat update).
-extern "C" int dpf_flow_train_prepare_layer(int B, int N, int ka, int kb, const float *tcanon_l, void *packed_l,
-                                            const float *fm_l, const float *p_in, float *stats_l, float *film_l,
-                                            float flow_eps, void *workspace, dpf_stream_t stream) {
-    if (B <= 0 || N <= 0 || !tcanon_l || !packed_l || !fm_l || !p_in || !stats_l || !film_l || !workspace) return DPF_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
+template <int NS>
+static int prepare_layer(int B, int N, int ka, int kb, const float *tcanon_l, void *packed_l, const float *fm_l,
+                         const float *p_in, float *stats_l, float *film_l, float flow_eps, void *workspace, hipStream_t s) {
     TWork w = carve(workspace, B, N);
     const int nbx = (N + 255) / 256;
     const double count = (double)B * N;
     hipLaunchKernelGGL(tstats_x_kernel, dim3(nbx, B), dim3(256), 0, s, N, ka, kb, p_in, w.xpart);
-    hipLaunchKernelGGL(tbn0_kernel, dim3(1), dim3(128), 0, s, nbx * B, count, w.xpart, tcanon_l, (uint8_t *)packed_l, stats_l);
+    hipLaunchKernelGGL(tbn0_kernel, dim3(1), dim3(128), 0, s, nbx * B, count, w.xpart, tcanon_l,
+                       (uint8_t *)packed_l + pt_a0(NS), stats_l);
     TArgs a;
     a.packed_l = (const uint8_t *)packed_l; a.tcanon_l = tcanon_l; a.film_l = film_l; a.filmb_l = film_l + (size_t)B * 512;
-    a.stats_l = stats_l; a.p_in = p_in; a.B = B; a.N = N; a.ka = ka; a.kb = kb; a.wa = 0; a.wb = 0; a.mode = 0; a.eps = flow_eps;
+    a.stats_l = stats_l; a.p_in = p_in; a.B = B; a.N = N; a.ka = ka; a.kb = kb; a.wa = 0; a.wb = 0; a.mode = 0;
+    a.a0_off = pt_a0(NS); a.eps = flow_eps;
     static bool attr = false;
     if (!attr) {
-        hipError_t e = set_lds((const void *)tstats_h1_kernel, PT_A0N);
+        hipError_t e = set_lds((const void *)tstats_h1_kernel<NS>, pt_a0n(NS));
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
     const dim3 grid((N + TBLK - 1) / TBLK, B);
-    hipLaunchKernelGGL(tstats_h1_kernel, grid, dim3(TW * 64), PT_A0N, s, a, w.part1);
+    hipLaunchKernelGGL(tstats_h1_kernel<NS>, grid, dim3(TW * 64), pt_a0n(NS), s, a, w.part1);
     hipLaunchKernelGGL(tfilm_fold_kernel, dim3(B), dim3(128), 0, s, (int)(grid.x * grid.y), (float)count, w.part1, tcanon_l,
                        fm_l, B, flow_eps, stats_l, film_l, film_l + (size_t)B * 512);
     return (int)hipGetLastError();
 }
 
+// Forward statistics + folds of ONE layer; afterwards dpf_flow_forward(n_layers = 1, precision, packed = packed_l,
+// film = film_l) runs the layer itself.  stats_l receives the batch statistics (for the running-stat update).
+extern "C" int dpf_flow_train_prepare_layer(int B, int N, int precision, int ka, int kb, const float *tcanon_l, void *packed_l,
+                                            const float *fm_l, const float *p_in, float *stats_l, float *film_l,
+                                            float flow_eps, void *workspace, dpf_stream_t stream) {
+    if (B <= 0 || N <= 0 || !tcanon_l || !packed_l || !fm_l || !p_in || !stats_l || !film_l || !workspace) return DPF_EINVAL;
+    if (B > 65535) return DPF_ENOSUP;
+    switch (t_ns(precision)) {
+        case 2: return prepare_layer<2>(B, N, ka, kb, tcanon_l, packed_l, fm_l, p_in, stats_l, film_l, flow_eps, workspace, (hipStream_t)stream);
+        case 3: return prepare_layer<3>(B, N, ka, kb, tcanon_l, packed_l, fm_l, p_in, stats_l, film_l, flow_eps, workspace, (hipStream_t)stream);
+        default: return DPF_ENOSUP;
+    }
+}
+
+template <int NS>
+static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb, const float *tcanon_l, const void *packed_l,
+                          const float *film_l, const float *stats_l, const float *p_in, const float *g_p, const float *g_mu,
+                          const float *g_lv, float *dp_in, float *dcanon_l, float *dfm_l, float *scratch_a, float *scratch_b,
+                          float flow_eps, void *workspace, hipStream_t s) {
+    TWork w = carve(workspace, B, N);
+    TArgs a;
+    a.packed_l = (const uint8_t *)packed_l; a.tcanon_l = tcanon_l; a.film_l = film_l; a.filmb_l = film_l + (size_t)B * 512;
+    a.stats_l = stats_l; a.p_in = p_in; a.B = B; a.N = N; a.ka = ka; a.kb = kb; a.wa = wa; a.wb = wb; a.mode = mode;
+    a.a0_off = pt_a0(NS); a.eps = flow_eps;
+    const dim3 grid((N + TBLK - 1) / TBLK, B);
+    const int nblk = grid.x * grid.y, nb = grid.x;
+    const float count = (float)((double)B * N);
+    const int lds1 = l_red(NS) + (512 + 4) * 4, lds2 = l_red(NS) + 512 + TW * XY_WAVE * 2, lds3 = 8192 + 256 * 4;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = set_lds((const void *)tbwd1_kernel<NS>, lds1);
+        if (e == hipSuccess) e = set_lds((const void *)tbwd2_kernel<NS>, lds2);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(tbwd1_kernel<NS>, grid, dim3(TW * 64), lds1, s, a, g_p, g_mu, g_lv, dp_in, scratch_a, w.part1, w.part1b);
+    hipLaunchKernelGGL(treduce_cloud_kernel, dim3(2, B), dim3(256), 0, s, nb, 512, w.part1, w.pc);
+    hipLaunchKernelGGL(tbwd1_finish_kernel, dim3(1), dim3(128), 0, s, B, nb, count, w.pc, w.part1b, nblk, a.filmb_l, flow_eps,
+                       dfm_l, w.s12, dcanon_l);
+    hipLaunchKernelGGL(tbwd2_kernel<NS>, grid, dim3(TW * 64), lds2, s, a, w.s12, scratch_a, scratch_b, w.part2);
+    hipLaunchKernelGGL(treduce_to_canon_kernel, dim3((4224 + 255) / 256, 2), dim3(256), 0, s, nblk, 4224, T_G0, w.part2, dcanon_l);
+    hipLaunchKernelGGL(tbwd3_kernel, grid, dim3(TW * 64), lds3, s, a, count, dcanon_l, scratch_b, dp_in, w.part3);
+    hipLaunchKernelGGL(treduce_to_canon_kernel, dim3(1, 2), dim3(256), 0, s, nblk, 128, T_W0, w.part3, dcanon_l);
+    return (int)hipGetLastError();
+}
+
 // Backward of ONE layer.  g_p / g_mu / g_lv: gradients w.r.t. the layer's outputs (g_mu, g_lv may be NULL);
 // dp_in (B,3,N), dcanon_l (T_LAYER) and dfm_l ([br][sub][B][64]) are fully overwritten.
-extern "C" int dpf_flow_train_backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb,
+extern "C" int dpf_flow_train_backward_layer(int B, int N, int mode, int precision, int ka, int kb, int wa, int wb,
                                              const float *tcanon_l, const void *packed_l, const float *film_l,
                                              const float *stats_l, const float *p_in, const float *g_p, const float *g_mu,
                                              const float *g_lv, float *dp_in, float *dcanon_l, float *dfm_l,
@@ -811,29 +903,14 @@ extern "C" int dpf_flow_train_backward_layer(int B, int N, int mode, int ka, int
     if (B <= 0 || N <= 0 || !tcanon_l || !packed_l || !film_l || !stats_l || !p_in || !g_p || !dp_in || !dcanon_l || !dfm_l ||
         !scratch_a || !scratch_b || !workspace)
         return DPF_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
-    TWork w = carve(workspace, B, N);
-    TArgs a;
-    a.packed_l = (const uint8_t *)packed_l; a.tcanon_l = tcanon_l; a.film_l = film_l; a.filmb_l = film_l + (size_t)B * 512;
-    a.stats_l = stats_l; a.p_in = p_in; a.B = B; a.N = N; a.ka = ka; a.kb = kb; a.wa = wa; a.wb = wb; a.mode = mode; a.eps = flow_eps;
-    const dim3 grid((N + TBLK - 1) / TBLK, B);
-    const int nblk = grid.x * grid.y, nb = grid.x;
-    const float count = (float)((double)B * N);
-    const int lds1 = L_RED + (512 + 4) * 4, lds2 = L_RED + 512 + TW * 2 * 64 * 40 * 2, lds3 = 8192 + 256 * 4;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = set_lds((const void *)tbwd1_kernel, lds1);
-        if (e == hipSuccess) e = set_lds((const void *)tbwd2_kernel, lds2);
-        if (e != hipSuccess) return (int)e;
-        attr = true;
+    if (B > 65535) return DPF_ENOSUP;
+#define DPF_BWD(NSV)                                                                                                       \
+    return backward_layer<NSV>(B, N, mode, ka, kb, wa, wb, tcanon_l, packed_l, film_l, stats_l, p_in, g_p, g_mu, g_lv, dp_in, \
+                               dcanon_l, dfm_l, scratch_a, scratch_b, flow_eps, workspace, (hipStream_t)stream);
+    switch (t_ns(precision)) {
+        case 2: DPF_BWD(2)
+        case 3: DPF_BWD(3)
+        default: return DPF_ENOSUP;
     }
-    hipLaunchKernelGGL(tbwd1_kernel, grid, dim3(TW * 64), lds1, s, a, g_p, g_mu, g_lv, dp_in, scratch_a, w.part1, w.part1b);
-    hipLaunchKernelGGL(treduce_cloud_kernel, dim3(2, B), dim3(256), 0, s, nb, 512, w.part1, w.pc);
-    hipLaunchKernelGGL(tbwd1_finish_kernel, dim3(1), dim3(128), 0, s, B, nb, count, w.pc, w.part1b, nblk, a.filmb_l, flow_eps,
-                       dfm_l, w.s12, dcanon_l);
-    hipLaunchKernelGGL(tbwd2_kernel, grid, dim3(TW * 64), lds2, s, a, w.s12, scratch_a, scratch_b, w.part2);
-    hipLaunchKernelGGL(treduce_to_canon_kernel, dim3((4224 + 255) / 256, 2), dim3(256), 0, s, nblk, 4224, T_G0, w.part2, dcanon_l);
-    hipLaunchKernelGGL(tbwd3_kernel, grid, dim3(TW * 64), lds3, s, a, count, dcanon_l, scratch_b, dp_in, w.part3);
-    hipLaunchKernelGGL(treduce_to_canon_kernel, dim3(1, 2), dim3(256), 0, s, nblk, 128, T_W0, w.part3, dcanon_l);
-    return (int)hipGetLastError();
+#undef DPF_BWD
 }

@@ -53,10 +53,10 @@ class LocalCondRNVPDecoder(nn.Module):
         ps, mus, lvs = [], [], []
         for i in range(self.n_flows):                               # decoders.py:58-70
             if mode == "direct":
-                buf = self.flows[i](p if i == 0 else ps[-1], g, mode=mode)
+                buf = self.flows[i].forward_torch(p if i == 0 else ps[-1], g, mode=mode)
                 ps, mus, lvs = ps + buf[0], mus + buf[1], lvs + buf[2]
             else:
-                buf = self.flows[-(i + 1)](p if i == 0 else ps[0], g, mode=mode)
+                buf = self.flows[-(i + 1)].forward_torch(p if i == 0 else ps[0], g, mode=mode)
                 ps, mus, lvs = buf[0] + ps, buf[1] + mus, buf[2] + lvs
         return ps, mus, lvs
 

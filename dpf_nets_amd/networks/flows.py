@@ -139,15 +139,27 @@ class CondRealNVPFlow3DTriple(nn.Module):
     def layers(self):
         return [self.nvp1, self.nvp2, self.nvp3]
 
-    def forward(self, p, g, mode="direct"):                        # flows.py:151-160
+    def _chain(self, p, g, mode, call):                            # flows.py:151-160
         if mode == "direct":
-            p1, mu1, lv1 = self.nvp1(p, g, mode=mode)
-            p2, mu2, lv2 = self.nvp2(p1, g, mode=mode)
-            p3, mu3, lv3 = self.nvp3(p2, g, mode=mode)
+            p1, mu1, lv1 = call(self.nvp1, p, g, mode)
+            p2, mu2, lv2 = call(self.nvp2, p1, g, mode)
+            p3, mu3, lv3 = call(self.nvp3, p2, g, mode)
         elif mode == "inverse":
-            p3, mu3, lv3 = self.nvp3(p, g, mode=mode)
-            p2, mu2, lv2 = self.nvp2(p3, g, mode=mode)
-            p1, mu1, lv1 = self.nvp1(p2, g, mode=mode)
+            p3, mu3, lv3 = call(self.nvp3, p, g, mode)
+            p2, mu2, lv2 = call(self.nvp2, p3, g, mode)
+            p1, mu1, lv1 = call(self.nvp1, p2, g, mode)
         else:
             raise ValueError(mode)
         return [p1, p2, p3], [mu1, mu2, mu3], [lv1, lv2, lv3]
+
+    def forward_torch(self, p, g, mode="direct"):
+        return self._chain(p, g, mode, lambda lyr, pp, gg, mm: lyr.forward_torch(pp, gg, mm))
+
+    def forward(self, p, g, mode="direct"):
+        if mode not in ("direct", "inverse"):
+            raise ValueError(mode)
+        if use_hip_training(self, p):                              # the three layers as one autograd node
+            from .train_engine import run_training_stack
+            ps, mus, lvs = run_training_stack(self.layers(), p, g, mode)
+            return list(ps.unbind(0)), list(mus.unbind(0)), list(lvs.unbind(0))
+        return self._chain(p, g, mode, lambda lyr, pp, gg, mm: lyr(pp, gg, mode=mm))

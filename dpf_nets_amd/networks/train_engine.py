@@ -15,12 +15,17 @@ kernels; torch is the plumbing around them:
     dpf_flow_train_prepare_layer + dpf_flow_forward(n_layers=1); backward = per layer
     dpf_flow_train_backward_layer in reverse order.
 """
+import os
+
 import torch
 
 from .._lib import lib, check, current_stream, PREC, MODE
 from .engine import layer_meta, _pad_cols, _pad_rows
 
 F = 64
+# precision of the forward contraction and of its recomputation in the backward passes (which fixes
+# every ReLU mask): bf16x6 is fp32-class; bf16x3 (~1e-5) is ~25 % faster and flips ~1e-5 of the ReLUs
+TRAIN_PRECISION = os.environ.get("DPF_TRAIN_PRECISION", "bf16x6")
 BRANCHES = ("logvar", "mu")
 SUBS = ("w", "b")
 
@@ -86,7 +91,7 @@ def _update_running(bns, means, uvars):
 
 class _FlowStackTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, p, tcanon, fm, metas, mode, eps):
+    def forward(ctx, p, tcanon, fm, metas, mode, eps, prec):
         L = tcanon.shape[0]
         B, _, N = p.shape
         dev = p.device
@@ -95,9 +100,9 @@ class _FlowStackTrain(torch.autograd.Function):
         p = p.contiguous()
         tcanon = tcanon.contiguous()
         fm = fm.contiguous()
-        packed = torch.empty(L_.dpf_flow_train_packed_bytes(L), dtype=torch.uint8, device=dev)
-        check(L_.dpf_flow_train_pack(L, tcanon.data_ptr(), packed.data_ptr(), stream), "flow_train_pack")
-        pbytes = L_.dpf_flow_train_packed_bytes(1)
+        packed = torch.empty(L_.dpf_flow_train_packed_bytes(L, prec), dtype=torch.uint8, device=dev)
+        check(L_.dpf_flow_train_pack(L, prec, tcanon.data_ptr(), packed.data_ptr(), stream), "flow_train_pack")
+        pbytes = L_.dpf_flow_train_packed_bytes(1, prec)
         film = torch.empty((L, L_.dpf_flow_train_film_floats(B)), dtype=torch.float32, device=dev)
         stats = torch.empty((L, L_.dpf_flow_train_stats_floats()), dtype=torch.float32, device=dev)
         ws = torch.empty(L_.dpf_flow_train_workspace_bytes(B, N), dtype=torch.uint8, device=dev)
@@ -108,16 +113,16 @@ class _FlowStackTrain(torch.autograd.Function):
         for l in order:
             ka, kb, wa, wb = metas[l]
             pk = packed.data_ptr() + l * pbytes
-            check(L_.dpf_flow_train_prepare_layer(B, N, ka, kb, tcanon[l].data_ptr(), pk, fm[l].data_ptr(),
+            check(L_.dpf_flow_train_prepare_layer(B, N, prec, ka, kb, tcanon[l].data_ptr(), pk, fm[l].data_ptr(),
                                                   cur.data_ptr(), stats[l].data_ptr(), film[l].data_ptr(), eps,
                                                   ws.data_ptr(), stream), "flow_train_prepare_layer")
-            check(L_.dpf_flow_forward(1, B, N, MODE[mode], PREC["bf16x3"], pk, meta_dev[l].data_ptr(),
+            check(L_.dpf_flow_forward(1, B, N, MODE[mode], prec, pk, meta_dev[l].data_ptr(),
                                       film[l].data_ptr(), cur.data_ptr(), ps[l].data_ptr(), None, None,
                                       ps[l].data_ptr(), mus[l].data_ptr(), lvs[l].data_ptr(), eps, stream),
                   "flow_forward")
             cur = ps[l]
         ctx.save_for_backward(p, tcanon, packed, film, stats, ps)
-        ctx.metas, ctx.mode, ctx.eps, ctx.order = metas, mode, eps, order
+        ctx.metas, ctx.mode, ctx.eps, ctx.order, ctx.prec = metas, mode, eps, order, prec
         ctx.mark_non_differentiable(stats)
         return ps, mus, lvs, stats
 
@@ -129,7 +134,7 @@ class _FlowStackTrain(torch.autograd.Function):
         dev = p.device
         L_ = lib()
         stream = current_stream()
-        pbytes = L_.dpf_flow_train_packed_bytes(1)
+        pbytes = L_.dpf_flow_train_packed_bytes(1, ctx.prec)
         ws = torch.empty(L_.dpf_flow_train_workspace_bytes(B, N), dtype=torch.uint8, device=dev)
         nscr = L_.dpf_flow_train_scratch_floats(B, N)
         scr = torch.empty((2, nscr), dtype=torch.float32, device=dev)
@@ -151,17 +156,17 @@ class _FlowStackTrain(torch.autograd.Function):
             ka, kb, wa, wb = ctx.metas[l]
             out = dp[step & 1]
             check(L_.dpf_flow_train_backward_layer(
-                B, N, MODE[ctx.mode], ka, kb, wa, wb, tcanon[l].data_ptr(), packed.data_ptr() + l * pbytes,
+                B, N, MODE[ctx.mode], ctx.prec, ka, kb, wa, wb, tcanon[l].data_ptr(), packed.data_ptr() + l * pbytes,
                 film[l].data_ptr(), stats[l].data_ptr(), p_in.data_ptr(), gp.data_ptr(),
                 g_mus[l].data_ptr() if g_mus is not None else None,
                 g_lvs[l].data_ptr() if g_lvs is not None else None,
                 out.data_ptr(), dcanon[l].data_ptr(), dfm[l].data_ptr(), scr[0].data_ptr(), scr[1].data_ptr(),
                 ctx.eps, ws.data_ptr(), stream), "flow_train_backward_layer")
             chain = out
-        return chain, dcanon, dfm, None, None, None
+        return chain, dcanon, dfm, None, None, None, None
 
 
-def run_training_stack(layers, p, g, mode):
+def run_training_stack(layers, p, g, mode, precision=None):
     """Training-mode forward of `layers` (DIRECT order) on the HIP path.  Returns (ps, mus, lvs):
     three (L,B,3,N) tensors in DIRECT order, attached to autograd; updates the BatchNorm running
     statistics as nn.BatchNorm1d would."""
@@ -175,11 +180,15 @@ def run_training_stack(layers, p, g, mode):
         raise RuntimeError("dpf_hip flow kernels are built for f_n_features == 64")
     if p.shape[0] * p.shape[2] < 2:
         raise ValueError("Expected more than 1 value per channel when training")
+    precision = precision or TRAIN_PRECISION
+    if precision not in ("bf16x3", "bf16x6"):
+        raise ValueError("training precision must be bf16x3 or bf16x6")
     with torch.cuda.device(p.device):
         tcanon = stack_parameters(layers)
         fm = film_vectors(layers, g)
         metas = tuple(tuple(layer_meta(l)) for l in layers)
-        ps, mus, lvs, stats = _FlowStackTrain.apply(p, tcanon, fm, metas, mode, float(layers[0].eps_value))
+        ps, mus, lvs, stats = _FlowStackTrain.apply(p, tcanon, fm, metas, mode, float(layers[0].eps_value),
+                                                      PREC[precision])
         with torch.no_grad():
             st = stats.view(len(layers), 2, 6, F)
             bns, means, uvars = [], [], []

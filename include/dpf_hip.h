@@ -184,7 +184,9 @@ int dpf_flow_forward(int n_layers, int B, int N, int mode, int precision,
  * Training mode (model.train()) of one coupling layer: batch-statistics
  * BatchNorm in both conditioner SharedDot stacks (flows.py:27,30,62,65), and the
  * backward pass autograd derives from CondRealNVPFlow3D.forward (flows.py:95-117;
- * lib/networks/training.py:55 calls loss.backward()).  bf16x3 only.
+ * lib/networks/training.py:55 calls loss.backward()).  precision: DPF_PREC_BF16X3 or
+ * DPF_PREC_BF16X6 (of the forward contraction and its recomputation; see
+ * csrc/flow_train.hip).
  *
  * tcanon, per layer dpf_flow_train_canon_floats() floats, per branch
  * (logvar, mu) 4484 floats:
@@ -199,24 +201,27 @@ int dpf_flow_forward(int n_layers, int B, int N, int mode, int precision,
  * those nets (B x 64 tensors) stay with the caller.
  *
  * film_l: dpf_flow_train_film_floats(B) floats; its first B*512 floats are the
- * block dpf_flow_forward(n_layers = 1, packed = packed_l, film = film_l) takes.
+ * block dpf_flow_forward(n_layers = 1, precision, packed = packed_l, film = film_l)
+ * takes.
  * stats_l: dpf_flow_train_stats_floats() floats, [branch][6][64] =
  * mean0, rstd0, mean1, rstd1, unbiased batch var0, unbiased batch var1 (what
  * BatchNorm1d feeds its running statistics with).
  * ------------------------------------------------------------------------ */
 size_t dpf_flow_train_canon_floats(void);
-size_t dpf_flow_train_packed_bytes(int n_layers);
+size_t dpf_flow_train_packed_bytes(int n_layers, int precision);
 size_t dpf_flow_train_stats_floats(void);
 size_t dpf_flow_train_film_floats(int B);
 size_t dpf_flow_train_workspace_bytes(int B, int N);
 size_t dpf_flow_train_scratch_floats(int B, int N);
 
 /* W1 / W1^T MFMA fragments of every layer (once per optimizer step) */
-int dpf_flow_train_pack(int n_layers, const float *tcanon, void *packed, dpf_stream_t stream);
+int dpf_flow_train_pack(int n_layers, int precision, const float *tcanon, void *packed,
+                        dpf_stream_t stream);
 
 /* batch statistics and folds of ONE layer for the batch p_in (B,3,N); completes
  * packed_l (input-layer fragments), writes stats_l and film_l */
-int dpf_flow_train_prepare_layer(int B, int N, int keep_a, int keep_b, const float *tcanon_l,
+int dpf_flow_train_prepare_layer(int B, int N, int precision, int keep_a, int keep_b,
+                                 const float *tcanon_l,
                                  void *packed_l, const float *fm_l, const float *p_in,
                                  float *stats_l, float *film_l, float flow_eps,
                                  void *workspace, dpf_stream_t stream);
@@ -224,8 +229,8 @@ int dpf_flow_train_prepare_layer(int B, int N, int keep_a, int keep_b, const flo
 /* backward of ONE layer.  g_p / g_mu / g_lv: gradients w.r.t. the layer's three
  * outputs (g_mu, g_lv may be NULL = zero).  Overwrites dp_in (B,3,N), dcanon_l
  * and dfm_l.  scratch_a / scratch_b: dpf_flow_train_scratch_floats floats each. */
-int dpf_flow_train_backward_layer(int B, int N, int mode, int keep_a, int keep_b, int warp_a,
-                                  int warp_b, const float *tcanon_l, const void *packed_l,
+int dpf_flow_train_backward_layer(int B, int N, int mode, int precision, int keep_a, int keep_b,
+                                  int warp_a, int warp_b, const float *tcanon_l, const void *packed_l,
                                   const float *film_l, const float *stats_l, const float *p_in,
                                   const float *g_p, const float *g_mu, const float *g_lv,
                                   float *dp_in, float *dcanon_l, float *dfm_l,
