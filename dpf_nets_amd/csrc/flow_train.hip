@@ -5,25 +5,30 @@
 // what autograd derives from it (lib/networks/training.py:55).  In training mode the layer is
 // NOT a per-point map: both BatchNorm1d layers of each conditioner branch normalise with
 // statistics over all B*N points (flows.py:27,30,62,65), which puts two grid-wide reductions in
-// the forward pass and three in the backward pass.  Each reduction is a kernel boundary:
+// the forward pass and two in the backward pass.  Each reduction is a kernel boundary:
 //
 //  forward   tstats_x      moments of the (<=2) kept coordinates       -> BN0 batch stats are an
 //            tbn0          analytic function of them (h0 = W0 x is linear): folded input-MFMA
 //                          fragments with the BATCH statistics
 //            tstats_h1     h1 = W1 relu(BN0(W0 x)) on the matrix cores, sum / sum of squares
+//            tcolsum       per-workgroup partials -> totals (fixed order, no global atomics)
 //            tfilm_fold    BN1 batch stats + this step's FiLM vectors  -> the per-cloud block the
 //                          eval kernel consumes
 //            flow_kernel   (csrc/flow.hip, L = 1) the layer itself
-//  backward  tbwd1         recompute to h2; d(out) -> dW2, db2, d FiLM(a, c), dh2a (stored)
+//  backward  tbwd1         recompute to h2; d(outputs) -> d(o) (4 floats/point, stored), dW2, db2,
+//                          per-cloud d FiLM(a, c)
+//            tfinish1      FiLM gradients, BN1 backward sums
 //            tbwd2         recompute; BN1 backward; dh0 = W1^T dh1 and dW1 = dh1 h0^T on the
-//                          matrix cores; dh0a (stored); d gamma0, d beta0
-//            tbwd3         BN0 backward; dW0; d(input points)
-//            treduce       per-workgroup partial sums -> gradients (deterministic, no atomics)
+//                          matrix cores; per point u_k = sum_f c_fk dh0a[f] (2 floats, stored);
+//                          per feature sums of dh0a * {1, h0n, x_a, x_b}
+//            tcolsum + tfinish2   d gamma0, d beta0, dW1, dW0 (BN0 backward in closed form: h0n is
+//                          linear in x, so its sums over points follow from the x moments)
+//            tbwd3         d(input) = direct term + u_k - affine(x): elementwise
 //
-// Activations are RECOMPUTED from the layer input in every backward pass (MFMA work is cheap);
-// only the two (B*N, 128) gradient fragments that cross a grid-wide reduction are stored, as raw
-// accumulator-fragment dumps.  The per-cloud FiLM conditioner nets (B x 64 tensors) stay on
-// PyTorch-ROCm, batched over all layers; they enter here as the tensor `fm` and leave as `dfm`.
+// Activations are RECOMPUTED from the layer input in both backward passes (MFMA work is cheap);
+// nothing of size (B*N, 64) ever goes to HBM -- between the passes travel 4 + 2 floats per point.
+// The per-cloud FiLM conditioner nets (B x 64 tensors) stay on PyTorch-ROCm, batched over all
+// layers; they enter here as the tensor `fm` and leave as `dfm`.
 //
 // Precision: the forward contraction h1 = W1 relu(h0) -- and its recomputation in the backward passes,
 // which decides every ReLU mask -- runs at the precision the caller asks for: bf16x3 (hi/lo split,
@@ -59,8 +64,10 @@ __host__ __device__ constexpr int pt_bytes(int NS) { return pt_a1t(NS) + 2 * P_A
 
 // ---- per-layer saved statistics (floats) ---------------------------------------------------------
 // stats[br][k][64]: k = 0 mean0, 1 rstd0, 2 mean1, 3 rstd1, 4 batch var0 (unbiased), 5 batch var1 (unbiased)
+// then the moments of the kept coordinates: E[xa], E[xb], cov aa, bb, ab
 constexpr int ST_BR = 6 * 64;
-constexpr int ST_LAYER = 2 * ST_BR;
+constexpr int ST_MOM = 2 * ST_BR;
+constexpr int ST_LAYER = ST_MOM + 8;
 
 // ---- backward FiLM block per (layer, cloud) (floats): [br][k][64], k = 0 a, 1 c, 2 rstd1, 3 c/a ---
 constexpr int FB_BR = 4 * 64;
@@ -132,20 +139,31 @@ __global__ __launch_bounds__(256) void tstats_x_kernel(int N, int ka, int kb, co
 __global__ __launch_bounds__(128) void tbn0_kernel(int nblk, double count, const double *__restrict__ part,
                                                    const float *__restrict__ tcanon_l, uint8_t *__restrict__ packed_a0,
                                                    float *__restrict__ stats_l) {
-    __shared__ double mom[5];
-    __shared__ float fold[2][64][4];     // per (branch, feature): w_a', w_b', T'  |  and normalised variants share the loop
+    __shared__ double mom[5], wsum[2][5];
+    __shared__ float fold[2][64][4];
     __shared__ float foldn[2][64][4];
-    if (threadIdx.x < 5) {
-        double s = 0;
-        for (int b = 0; b < nblk; ++b) s += part[(size_t)b * 8 + threadIdx.x];
-        mom[threadIdx.x] = s / count;
+    {   // fixed-order tree over the per-workgroup partials
+        double v[5] = {0, 0, 0, 0, 0};
+        for (int b = threadIdx.x; b < nblk; b += 128)
+            for (int i = 0; i < 5; ++i) v[i] += part[(size_t)b * 8 + i];
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
+        if ((threadIdx.x & 63) == 0)
+            for (int i = 0; i < 5; ++i) wsum[threadIdx.x >> 6][i] = v[i];
+        __syncthreads();
+        if (threadIdx.x < 5) mom[threadIdx.x] = (wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) / count;
+        __syncthreads();
     }
-    __syncthreads();
     const int br = threadIdx.x >> 6, f = threadIdx.x & 63;
     const float *cb = tcanon_l + br * T_BR;
     const double wa = cb[T_W0 + f * 2 + 0], wb = cb[T_W0 + f * 2 + 1];
     const double ea = mom[0], eb = mom[1];
     const double caa = mom[2] - ea * ea, cbb = mom[3] - eb * eb, cab = mom[4] - ea * eb;
+    if (threadIdx.x == 0) {
+        float *m = stats_l + ST_MOM;
+        m[0] = (float)ea; m[1] = (float)eb; m[2] = (float)caa; m[3] = (float)cbb; m[4] = (float)cab;
+    }
     const double mean = wa * ea + wb * eb;
     double var = wa * wa * caa + wb * wb * cbb + 2.0 * wa * wb * cab;     // biased, as BatchNorm normalises with
     if (var < 0) var = 0;
@@ -165,6 +183,25 @@ __global__ __launch_bounds__(128) void tbn0_kernel(int nblk, double count, const
         const int ff = 32 * t + (lane & 31), h = lane >> 5;
         a0[idx] = (uint16_t)input_weight_slot(fold[b2][ff][h], fold[b2][ff][2], h, j);
         a0n[idx] = (uint16_t)input_weight_slot(foldn[b2][ff][h], foldn[b2][ff][2], h, j);
+    }
+}
+
+// column sums of a (nrows, J) fp32 matrix of per-workgroup partials, in a fixed order, as doubles.
+// workgroup = 32 columns x 32 row groups
+__global__ __launch_bounds__(1024) void tcolsum_kernel(int nrows, int J, const float *__restrict__ part, double *__restrict__ out) {
+    __shared__ double acc[32][33];
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + c;
+    double s = 0;
+    if (j < J)
+        for (int r = rg; r < nrows; r += 32) s += part[(size_t)r * J + j];
+    acc[rg][c] = s;
+    __syncthreads();
+    if (rg == 0 && j < J) {
+        double t = 0;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) t += acc[r][c];
+        out[j] = t;
     }
 }
 
@@ -242,8 +279,8 @@ __device__ __forceinline__ void load_features(const float *vec, int h, f32x16 (&
 // total of register index R(pl) = b0*16 + b1*8 + b2*4 + b3*2 + b4 (b_k = bit k of pl), i.e. of
 // feature acc_feature(R >> 4, R & 15, h).
 template <int K>
-__device__ __forceinline__ void reduce_stage(float (&w)[32], int pl) {
-    constexpr int n2 = 16 >> K;
+__device__ __forceinline__ void reduce_stage(float (&w)[16], int pl) {
+    constexpr int n2 = 8 >> (K - 1);
     const bool up = (pl >> K) & 1;
 #pragma unroll
     for (int i = 0; i < n2; ++i) {
@@ -252,38 +289,39 @@ __device__ __forceinline__ void reduce_stage(float (&w)[32], int pl) {
         w[i] = keep + __shfl_xor(send, 1 << K);
     }
 }
-__device__ __forceinline__ float reduce_points(const f32x16 (&v)[2], int pl) {
-    float w[32];
+// gen(i), i = 0..31: element of accumulator register i (tile i >> 4, register i & 15); elements are
+// produced on the fly so that a product like dh * x never exists as 32 live registers
+template <typename Gen>
+__device__ __forceinline__ float reduce_points_gen(Gen gen, int pl) {
+    float w[16];
+    const bool up = pl & 1;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) w[i] = v[i >> 4][i & 15];
-    reduce_stage<0>(w, pl); reduce_stage<1>(w, pl); reduce_stage<2>(w, pl); reduce_stage<3>(w, pl); reduce_stage<4>(w, pl);
+    for (int i = 0; i < 16; ++i) {
+        const float lo = gen(i), hi = gen(i + 16);
+        const float keep = up ? hi : lo, send = up ? lo : hi;
+        w[i] = keep + __shfl_xor(send, 1);
+    }
+    reduce_stage<1>(w, pl); reduce_stage<2>(w, pl); reduce_stage<3>(w, pl); reduce_stage<4>(w, pl);
+    __builtin_amdgcn_sched_barrier(0);       // keep consecutive reductions from interleaving (register pressure)
     return w[0];
+}
+__device__ __forceinline__ float reduce_points(const f32x16 (&v)[2], int pl) {
+    return reduce_points_gen([&](int i) { return v[i >> 4][i & 15]; }, pl);
 }
 __device__ __forceinline__ int reduced_feature(int pl, int h) {
     const int R = ((pl & 1) << 4) | ((pl & 2) << 2) | (pl & 4) | ((pl & 8) >> 2) | ((pl & 16) >> 4);
     return acc_feature(R >> 4, R & 15, h);
 }
 
-// raw dump / reload of an accumulator fragment pair (gradients that cross a grid-wide reduction)
-__device__ __forceinline__ void dump_fragment(float *buf, size_t tile, int br, int lane, const f32x16 (&v)[2]) {
-    float *o = buf + ((tile * 2 + br) * 32) * 64 + lane;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) o[i * 64] = v[i >> 4][i & 15];
-}
-__device__ __forceinline__ void load_fragment(const float *buf, size_t tile, int br, int lane, f32x16 (&v)[2]) {
-    const float *o = buf + ((tile * 2 + br) * 32) * 64 + lane;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) v[i >> 4][i & 15] = o[i * 64];
-}
 
 struct TArgs {
-    const uint8_t *packed_l;     // PT_BYTES of this layer
+    const uint8_t *packed_l;     // pt_bytes(NS) of this layer
     const float *tcanon_l;       // T_LAYER floats
     const float *film_l;         // (B, 512) eval FiLM blocks of this layer
     const float *filmb_l;        // (B, FB_CLOUD) backward FiLM blocks
     const float *stats_l;        // ST_LAYER
     const float *p_in;           // (B, 3, N)
-    int B, N, ka, kb, wa, wb, mode, a0_off;
+    int B, N, ka, kb, wa, wb, mode;
     float eps;
 };
 
@@ -292,11 +330,10 @@ struct TArgs {
 template <int NS>
 __global__ __launch_bounds__(TW * 64) void tstats_h1_kernel(TArgs a, float *__restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    __shared__ float acc_s[2][2][64];
+    __shared__ float acc_s[TW][2][2][64];                                 // per-wave slots (LDS float atomics are slow)
     const int bi = blockIdx.y, lane = threadIdx.x & 63, h = lane >> 5, pl = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     stage_bytes(a.packed_l, smem, pt_a0n(NS), wave, lane);                // A1 + A0
-    if (threadIdx.x < 256) ((float *)acc_s)[threadIdx.x] = 0.f;
     const int N = a.N, n = (blockIdx.x * TW + wave) * TILE + pl;
     const bool valid = n < N;
     const float *pc = a.p_in + (size_t)bi * 3 * N;
@@ -306,7 +343,7 @@ __global__ __launch_bounds__(TW * 64) void tstats_h1_kernel(TArgs a, float *__re
     __syncthreads();
 #pragma unroll
     for (int br = 0; br < 2; ++br) {
-        f32x16 acc0[2], acc1[2] = {zero16(), zero16()}, sq[2];
+        f32x16 acc0[2], acc1[2] = {zero16(), zero16()};
         u32x4 bf[NS][4];
         input_mfma(smem + pt_a0(NS), br, lane, b0, acc0);
         split_fragment<true, NS>(acc0, bf);
@@ -316,33 +353,33 @@ __global__ __launch_bounds__(TW * 64) void tstats_h1_kernel(TArgs a, float *__re
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 acc1[t][r] = valid ? acc1[t][r] : 0.f;                   // padding lanes do not count
-                sq[t][r] = acc1[t][r] * acc1[t][r];
             }
-        const float s1 = reduce_points(acc1, pl), s2 = reduce_points(sq, pl);
+        const float s1 = reduce_points(acc1, pl);
+        const float s2 = reduce_points_gen([&](int i) { return acc1[i >> 4][i & 15] * acc1[i >> 4][i & 15]; }, pl);
         const int f = reduced_feature(pl, h);
-        atomicAdd(&acc_s[br][0][f], s1);                                  // LDS atomics: 8 waves per address
-        atomicAdd(&acc_s[br][1][f], s2);
+        acc_s[wave][br][0][f] = s1;
+        acc_s[wave][br][1][f] = s2;
     }
     __syncthreads();
-    if (threadIdx.x < 256) part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x] = ((float *)acc_s)[threadIdx.x];
+    if (threadIdx.x < 256) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < TW; ++w) t += ((const float *)acc_s)[w * 256 + threadIdx.x];
+        part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x] = t;
+    }
 }
 
-// BN1 batch statistics from the partial sums, then this step's FiLM fold for one cloud:
+// BN1 batch statistics from the column sums, then this step's FiLM fold for one cloud:
 //   eval block  (csrc/flow.hip film layout): D = FC/FA, W2' = W2*FA, b2
 //   bwd block   a = eps + e^cw, c = cb, rstd1, c/a
-// fm_l: [br][sub(w,b)][B][64]
-__global__ __launch_bounds__(128) void tfilm_fold_kernel(int nblk, float count, const float *__restrict__ part,
+// sums: [br][2][64] doubles;  fm_l: [br][sub(w,b)][B][64]
+__global__ __launch_bounds__(128) void tfilm_fold_kernel(double count, const double *__restrict__ sums,
                                                          const float *__restrict__ tcanon_l, const float *__restrict__ fm_l,
                                                          int B, float eps, float *__restrict__ stats_l,
                                                          float *__restrict__ film_l, float *__restrict__ filmb_l) {
     const int b = blockIdx.x, br = threadIdx.x >> 6, f = threadIdx.x & 63;
-    double s1 = 0, s2 = 0;
-    for (int k = 0; k < nblk; ++k) {
-        s1 += part[(size_t)k * 256 + (br * 2 + 0) * 64 + f];
-        s2 += part[(size_t)k * 256 + (br * 2 + 1) * 64 + f];
-    }
-    const double mean = s1 / count;
-    double var = s2 / count - mean * mean;
+    const double mean = sums[(br * 2 + 0) * 64 + f] / count;
+    double var = sums[(br * 2 + 1) * 64 + f] / count - mean * mean;
     if (var < 0) var = 0;
     const float rstd = (float)(1.0 / sqrt(var + (double)BN_EPS));
     if (b == 0) {
@@ -377,23 +414,33 @@ __host__ __device__ constexpr int l_filmb(int NS) { return l_film(NS) + 2048; } 
 __host__ __device__ constexpr int l_red(int NS) { return l_filmb(NS) + 2048; }       // workgroup reduction scratch
 constexpr int XY_WAVE = 2 * 64 * 32;                                       // bf16 elements of one wave's X | Y tiles
 
+// d(o) of one branch from d(h2a): the per-feature part shared by passes 1 and 2 (same arithmetic in
+// both, so the sums of pass 1 describe exactly the dh2a pass 2 works with)
+__device__ __forceinline__ float dh2a_of(float pre, float w2a, float w2b, float doa, float dob) {
+    return pre > 0.f ? w2a * doa + w2b * dob : 0.f;
+}
+
 // Pass 1: recompute the layer to h2, differentiate the coupling transform and the output SharedDot.
-//   stores  dh2a fragments (scratch)         dp_in <- direct term  g * d(p_out)/d(p)
-//   partial sums per workgroup: part1[blk][br][k][64], k = 0 dW2a, 1 dW2b, 2 da, 3 dc;  part1b[blk][br][2] = db2
+//   stores  dout (B,4,N) = d(o_logvar a,b), d(o_mu a,b)         dp_in <- direct term  g * d(p_out)/d(p)
+//   partial sums per workgroup: part1[blk][br][k][64], k = 0 dW2a, 1 dW2b, 2 da, 3 dc;  part1[blk][512 + br*2 + w] = db2
+// the gradient w.r.t. p_out is g_p + g_p2 (g_p2 may be NULL)
 template <int NS>
-__global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__restrict__ g_p, const float *__restrict__ g_mu,
-                                                        const float *__restrict__ g_lv, float *__restrict__ dp_in,
-                                                        float *__restrict__ scratch, float *__restrict__ part1,
-                                                        float *__restrict__ part1b) {
+__global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__restrict__ g_p, const float *__restrict__ g_p2,
+                                                        const float *__restrict__ g_mu, const float *__restrict__ g_lv,
+                                                        float *__restrict__ dp_in, float *__restrict__ dout,
+                                                        float *__restrict__ part1) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    constexpr int L_FILM = l_film(NS), L_FILMB = l_filmb(NS), L_RED = l_red(NS);
-    float *red = (float *)(smem + L_RED);                                  // [2 br][4][64] + [2][2]
+    constexpr int L_FILM = pt_a0n(NS), L_FILMB = L_FILM + 2048, L_RED = L_FILMB + 2048;
+    float *red = (float *)(smem + L_RED);                                  // per wave [2 br][4][64] + [2][2] (+4 pad)
     const int bi = blockIdx.y, lane = threadIdx.x & 63, h = lane >> 5, pl = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int h4 = 4 * h;                   // opaque to the optimiser: feature offsets stay "lane base + immediate"
+    asm volatile("" : "+v"(h4));      // (as known bits they become OR-ed constants, one live register each)
     stage_bytes(a.packed_l, smem + L_PACK, pt_a0n(NS), wave, lane);
     stage_bytes((const uint8_t *)(a.film_l + (size_t)bi * 512), smem + L_FILM, 2048, wave, lane);
     stage_bytes((const uint8_t *)(a.filmb_l + (size_t)bi * FB_CLOUD), smem + L_FILMB, 2048, wave, lane);
-    for (int i = threadIdx.x; i < 2 * 4 * 64 + 4; i += TW * 64) red[i] = 0.f;
+    float *w2s = red + TW * 520;                                                // [2 br][2][64] raw sd2.weight
+    if (threadIdx.x < 256) w2s[threadIdx.x] = a.tcanon_l[(threadIdx.x >> 7) * T_BR + T_W2 + (threadIdx.x & 127)];
     const int N = a.N, n = (blockIdx.x * TW + wave) * TILE + pl;
     const bool valid = n < N;
     const int nc = valid ? n : N - 1;
@@ -401,10 +448,11 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
     float p[3], gp[3], gm[3], gl[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        p[c] = a.p_in[cloud + (size_t)c * N + nc];
-        gp[c] = valid ? g_p[cloud + (size_t)c * N + nc] : 0.f;
-        gm[c] = valid && g_mu ? g_mu[cloud + (size_t)c * N + nc] : 0.f;
-        gl[c] = valid && g_lv ? g_lv[cloud + (size_t)c * N + nc] : 0.f;
+        const size_t o = cloud + (size_t)c * N + nc;
+        p[c] = a.p_in[o];
+        gp[c] = valid ? g_p[o] + (g_p2 ? g_p2[o] : 0.f) : 0.f;
+        gm[c] = valid && g_mu ? g_mu[o] : 0.f;
+        gl[c] = valid && g_lv ? g_lv[o] : 0.f;
     }
     const float xa = sel3(a.ka, p[0], p[1], p[2]), xb = a.kb >= 0 ? sel3(a.kb, p[0], p[1], p[2]) : 0.f;
     const u32x4 b0 = input_fragment(h ? xb : xa, h);
@@ -423,14 +471,14 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
         load_features(film + br * FILM_BR_FLOATS, h, pre[br]);             // accumulator starts at D
         chain_mfma<NS>(smem + L_PACK + PT_A1, br, lane, bf, pre[br]);
         float oa = 0.f, ob = 0.f;
-        const float *wab = film + br * FILM_BR_FLOATS + 64;
+        const float *wab = film + br * FILM_BR_FLOATS + 64 + 2 * h4;       // lane base; feature offsets are immediates
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int f = acc_feature(t, r, 0) + 4 * h;
+                const int F0 = acc_feature(t, r, 0);
                 const float v = relu(pre[br][t][r]);
-                oa += wab[2 * f] * v; ob += wab[2 * f + 1] * v;
+                oa += wab[2 * F0] * v; ob += wab[2 * F0 + 1] * v;
             }
         oa += __shfl_xor(oa, 32); ob += __shfl_xor(ob, 32);
         o[br][0] = oa + film[FILM_B2_OFF + br * 2 + 0];
@@ -463,191 +511,241 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
         if (isa) { dmu_w[0] = dmu; dlv_w[0] = dlv * dsoft; }
         if (isb) { dmu_w[1] = dmu; dlv_w[1] = dlv * dsoft; }
     }
+    if (valid) {                                                           // half 0 stores the logvar pair, half 1 the mu pair
+        float *d = dout + ((size_t)bi * 4 + 2 * h) * N + n;
+        d[0] = h ? dmu_w[0] : dlv_w[0];
+        d[N] = h ? dmu_w[1] : dlv_w[1];
+    }
     // ---- output SharedDot backward, FiLM backward, per-feature sums
-    const size_t tile = ((size_t)bi * gridDim.x + blockIdx.x) * TW + wave;
 #pragma unroll
     for (int br = 0; br < 2; ++br) {
         const float doa = br == 0 ? dlv_w[0] : dmu_w[0], dob = br == 0 ? dlv_w[1] : dmu_w[1];
-        const float *wab = film + br * FILM_BR_FLOATS + 64;
-        const float *fb = filmb + br * FB_BR;
-        f32x16 dh2a[2], tW2a[2], tW2b[2], tda[2];
+        const float *w2 = w2s + br * 128 + h4;                             // lane bases; feature offsets are immediates
+        const float *fb = filmb + br * FB_BR + h4;
+        f32x16 dh2a[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int f = acc_feature(t, r, 0) + 4 * h;
-                const float pa = pre[br][t][r];
-                const bool on = pa > 0.f;
-                // h2 = FA*relu(pa); W2' = W2*FA  ->  dh2a = sum_w W2[w]*do_w * [on] = (W2'[w]/FA)*do_w ; dW2[w] = do_w*h2
-                const float FA = fb[0 * 64 + f] * fb[2 * 64 + f];                  // a * rstd1
-                const float g2 = on ? (wab[2 * f] * doa + wab[2 * f + 1] * dob) / FA : 0.f;    // d/d(h2a)
-                dh2a[t][r] = g2;
-                const float h2 = on ? FA * pa : 0.f;
-                tW2a[t][r] = doa * h2;
-                tW2b[t][r] = dob * h2;
-                // h1n = pa*rstd1 - c/a
-                tda[t][r] = g2 * (pa * fb[2 * 64 + f] - fb[3 * 64 + f]);
+                const int F0 = acc_feature(t, r, 0);
+                dh2a[t][r] = dh2a_of(pre[br][t][r], w2[F0], w2[64 + F0], doa, dob);   // [pa > 0] sum_w W2[w]*do_w
             }
-        dump_fragment(scratch, tile, br, lane, dh2a);
         const int f = reduced_feature(pl, h);
-        const float r0 = reduce_points(tW2a, pl), r1 = reduce_points(tW2b, pl), r2 = reduce_points(tda, pl),
-                    r3 = reduce_points(dh2a, pl);
-        atomicAdd(&red[(br * 4 + 0) * 64 + f], r0);
-        atomicAdd(&red[(br * 4 + 1) * 64 + f], r1);
-        atomicAdd(&red[(br * 4 + 2) * 64 + f], r2);
-        atomicAdd(&red[(br * 4 + 3) * 64 + f], r3);
+        // dW2[w] = sum do_w * h2,  h2 = FA * relu(pa)
+        auto h2 = [&](int i) {
+            const int F0 = acc_feature(i >> 4, i & 15, 0);
+            return relu(pre[br][i >> 4][i & 15]) * (fb[0 * 64 + F0] * fb[2 * 64 + F0]);
+        };
+        const float r0 = reduce_points_gen([&](int i) { return doa * h2(i); }, pl);
+        const float r1 = reduce_points_gen([&](int i) { return dob * h2(i); }, pl);
+        // da = sum dh2a * h1n,  h1n = pa*rstd1 - c/a
+        const float r2 = reduce_points_gen([&](int i) {
+            const int F0 = acc_feature(i >> 4, i & 15, 0);
+            return dh2a[i >> 4][i & 15] * (pre[br][i >> 4][i & 15] * fb[2 * 64 + F0] - fb[3 * 64 + F0]);
+        }, pl);
+        const float r3 = reduce_points(dh2a, pl);
+        float *rw = red + wave * 520;
+        rw[(br * 4 + 0) * 64 + f] = r0;
+        rw[(br * 4 + 1) * 64 + f] = r1;
+        rw[(br * 4 + 2) * 64 + f] = r2;
+        rw[(br * 4 + 3) * 64 + f] = r3;
         float sa = h == 0 ? doa : 0.f, sb = h == 0 ? dob : 0.f;                   // db2: each point once
         for (int q = 32; q > 0; q >>= 1) { sa += __shfl_xor(sa, q); sb += __shfl_xor(sb, q); }
-        if (lane == 0) { atomicAdd(&red[512 + br * 2 + 0], sa); atomicAdd(&red[512 + br * 2 + 1], sb); }
+        if (lane == 0) { rw[512 + br * 2 + 0] = sa; rw[512 + br * 2 + 1] = sb; }
     }
     __syncthreads();
     const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-    for (int i = threadIdx.x; i < 512; i += TW * 64) part1[blk * 512 + i] = red[i];
-    if (threadIdx.x < 4) part1b[blk * 4 + threadIdx.x] = red[512 + threadIdx.x];
+    for (int i = threadIdx.x; i < 516; i += TW * 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < TW; ++w) t += red[w * 520 + i];
+        part1[blk * 520 + i] = t;
+    }
 }
 
-// reduce per-workgroup partials: out[j] = scale * sum_k part[k*J + j]   (deterministic)
-__global__ __launch_bounds__(256) void treduce_kernel(int nblk, int J, const float *__restrict__ part, float *__restrict__ out,
-                                                      float scale) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= J) return;
-    double s = 0;
-    for (int k = 0; k < nblk; ++k) s += part[(size_t)k * J + j];
-    out[j] = (float)(s * scale);
-}
-
-// per-cloud reduce: out[b][j] = sum over the nb workgroups of cloud b
-__global__ __launch_bounds__(256) void treduce_cloud_kernel(int nb, int J, const float *__restrict__ part, float *__restrict__ out) {
-    const int j = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (j >= J) return;
+// Per-cloud totals of pass 1: pc[b][520]; and the FiLM gradients of the cloud
+//   dfm_l[br][sub][b][64] = (da * e^cw, dc)
+__global__ __launch_bounds__(520) void tcloudsum_kernel(int nb, int B, const float *__restrict__ part1, const float *__restrict__ filmb_l,
+                                                        float eps, float *__restrict__ pc, float *__restrict__ dfm_l) {
+    const int b = blockIdx.x, j = threadIdx.x;
     float s = 0;
-    for (int k = 0; k < nb; ++k) s += part[((size_t)b * nb + k) * J + j];
-    out[(size_t)b * J + j] = s;
+    for (int k = 0; k < nb; ++k) s += part1[((size_t)b * nb + k) * 520 + j];
+    pc[(size_t)b * 520 + j] = s;
+    if (j < 512) {
+        const int br = j >> 8, k = (j >> 6) & 3, f = j & 63;
+        if (k == 2) dfm_l[((size_t)(br * 2 + 0) * B + b) * 64 + f] = s * (filmb_l[(size_t)b * FB_CLOUD + br * FB_BR + f] - eps);
+        if (k == 3) dfm_l[((size_t)(br * 2 + 1) * B + b) * 64 + f] = s;
+    }
 }
 
-// Finish pass 1 on the host side of the reductions: the FiLM gradients and the BN1 sums.
-//   part1 totals per cloud pc[b][br][k][64] (k: 0 dW2a 1 dW2b 2 da 3 dc)
-//   -> dfm_l[br][sub][b][64] = (da * e^cw, dc);  s12[br][2][64] = (sum dh1n, sum dh1n*h1n) / P
-//   -> dW2, db2 into dcanon_l
-__global__ __launch_bounds__(128) void tbwd1_finish_kernel(int B, int nb, float count, const float *__restrict__ pc,
-                                                           const float *__restrict__ part1b, int nblk,
-                                                           const float *__restrict__ filmb_l, float eps,
-                                                           float *__restrict__ dfm_l, float *__restrict__ s12,
-                                                           float *__restrict__ dcanon_l) {
+// BN1 backward sums and the output SharedDot's parameter gradients from the per-cloud totals:
+//   s12[br][2][64] = (sum dh1n, sum dh1n*h1n) / P,  dh1n = a * dh2a;   dW2, db2 -> dcanon_l
+__global__ __launch_bounds__(128) void tfinish1_kernel(int B, double count, const float *__restrict__ pc,
+                                                       const float *__restrict__ filmb_l, float *__restrict__ s12,
+                                                       float *__restrict__ dcanon_l) {
     const int br = threadIdx.x >> 6, f = threadIdx.x & 63;
-    double S1 = 0, S2 = 0, w2a = 0, w2b = 0;
+    double S1 = 0, S2 = 0, w2a = 0, w2b = 0, bb = 0;
     for (int b = 0; b < B; ++b) {
-        const float *q = pc + ((size_t)b * 2 + br) * 256;
-        const float da = q[2 * 64 + f], dc = q[3 * 64 + f];
-        const float av = filmb_l[(size_t)b * FB_CLOUD + br * FB_BR + f];
-        dfm_l[((size_t)(br * 2 + 0) * B + b) * 64 + f] = da * (av - eps);       // d cw = da * e^cw
-        dfm_l[((size_t)(br * 2 + 1) * B + b) * 64 + f] = dc;
-        S1 += (double)av * dc;                                                   // dh1n = a * dh2a
-        S2 += (double)av * da;                                                   // dh1n * h1n
+        const float *q = pc + (size_t)b * 520 + br * 256;
+        const double av = filmb_l[(size_t)b * FB_CLOUD + br * FB_BR + f];
+        S1 += av * q[3 * 64 + f];                                                // dh1n = a * dh2a
+        S2 += av * q[2 * 64 + f];                                                // dh1n * h1n
         w2a += q[0 * 64 + f]; w2b += q[1 * 64 + f];
+        if (f < 2) bb += pc[(size_t)b * 520 + 512 + br * 2 + f];
     }
     s12[(br * 2 + 0) * 64 + f] = (float)(S1 / count);
     s12[(br * 2 + 1) * 64 + f] = (float)(S2 / count);
     dcanon_l[br * T_BR + T_W2 + f] = (float)w2a;
     dcanon_l[br * T_BR + T_W2 + 64 + f] = (float)w2b;
-    if (f < 4) {
-        double s = 0;
-        if (f < 2) for (int k = 0; k < nblk; ++k) s += part1b[(size_t)k * 4 + br * 2 + f];
-        dcanon_l[br * T_BR + T_B2 + f] = (float)s;
-    }
+    if (f < 4) dcanon_l[br * T_BR + T_B2 + f] = (float)bb;
 }
 
 // Pass 2: BN1 backward, dh0 = W1^T dh1 (matrix cores), dW1 = dh1 h0^T (matrix cores, contraction over the
-// tile's 32 points through an LDS transpose), relu backward; stores dh0a; partials of d gamma0 / d beta0.
-//   part2[blk][br][4224]: [0..63] d gamma0, [64..127] d beta0, [128..4223] dW1 (row = out feature)
+// tile's 32 points through an LDS transpose), relu backward.
+//   part2[blk][br][P2_J]: [0..63] sum dh0a*h0n (d gamma0), [64..127] sum dh0a (d beta0), [128..4223] dW1
+//                         (row = out feature), [4224..4287] sum dh0a*x_a, [4288..4351] sum dh0a*x_b
+//   ubuf (B,2,N): u_k = sum over both branches and all features of W0[f][k]*rstd0*gamma0 * dh0a[f]
+constexpr int P2_J = 4352;
+#ifdef DPF_PROFILE
+__device__ unsigned long long *g_tprof = nullptr;
+#define TP(i) { __builtin_amdgcn_sched_barrier(0); if (br == 0) tt[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define TP(i)
+#endif
 template <int NS>
-__global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__restrict__ s12, float *__restrict__ scratch,
-                                                        float *__restrict__ scratch2, float *__restrict__ part2) {
+__global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__restrict__ s12, const float *__restrict__ dout,
+                                                        float *__restrict__ ubuf, float *__restrict__ part2) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int L_FILM = l_film(NS), L_FILMB = l_filmb(NS), L_RED = l_red(NS);
-    float *red = (float *)(smem + L_RED);                                  // [128] d gamma0 | d beta0 of the branch
-    uint16_t *tr = (uint16_t *)(smem + L_RED + 512);                       // per wave: X[64][32], Y[64][32] bf16, swizzled
-    float *redw = (float *)(smem + L_RED + 512);                           // [4096] dW1, ALIASES tr once the MFMAs are done
+    float *cf = (float *)(smem + L_RED) + 256;                             // c_fk [2 br][2][64]   (first 1 KB of the region: spare)
+    uint16_t *tr = (uint16_t *)(smem + L_RED + 4096);                      // per wave: X[64][32], Y[64][32] bf16, swizzled
+    float *redw = (float *)(smem + L_RED + 4096);                          // per-wave slots of the workgroup reduction, ALIAS tr once the MFMAs are done
     const int bi = blockIdx.y, lane = threadIdx.x & 63, h = lane >> 5, pl = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int h4 = 4 * h;                   // opaque to the optimiser: feature offsets stay "lane base + immediate"
+    asm volatile("" : "+v"(h4));      // (as known bits they become OR-ed constants, one live register each)
     stage_bytes(a.packed_l, smem + L_PACK, pt_bytes(NS), wave, lane);
     stage_bytes((const uint8_t *)(a.film_l + (size_t)bi * 512), smem + L_FILM, 2048, wave, lane);
     stage_bytes((const uint8_t *)(a.filmb_l + (size_t)bi * FB_CLOUD), smem + L_FILMB, 2048, wave, lane);
+    if (threadIdx.x < 256) {                                               // c_fk = W0[f][k] * rstd0_f * gamma0_f
+        const int br = threadIdx.x >> 7, k = (threadIdx.x >> 6) & 1, f = threadIdx.x & 63;
+        const float *cb = a.tcanon_l + br * T_BR;
+        cf[threadIdx.x] = cb[T_W0 + f * 2 + k] * a.stats_l[br * ST_BR + 64 + f] * cb[T_G0 + f];
+    }
     const int N = a.N, n = (blockIdx.x * TW + wave) * TILE + pl;
     const bool valid = n < N;
     const int nc = valid ? n : N - 1;
     const float *pc = a.p_in + (size_t)bi * 3 * N;
     const float xa = pc[(size_t)a.ka * N + nc], xb = a.kb >= 0 ? pc[(size_t)a.kb * N + nc] : 0.f;
+    const float *dq = dout + (size_t)bi * 4 * N + nc;
+    const float dov[2][2] = {{dq[0], dq[N]}, {dq[2 * (size_t)N], dq[3 * (size_t)N]}};
     const u32x4 b0 = input_fragment(h ? xb : xa, h);
     const float *film = (const float *)(smem + L_FILM);
     const float *filmb = (const float *)(smem + L_FILMB);
-    const size_t tile = ((size_t)bi * gridDim.x + blockIdx.x) * TW + wave;
     const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
     uint16_t *X = tr + wave * XY_WAVE, *Y = X + 64 * 32;
     // tile element (row f, point q) lives at f*32 + ((q>>3) ^ ((f>>2)&3))*8 + (q&7): the 16-byte chunks of a
-    // row are XOR-swizzled so that the 16 rows a ds_read_b128 group touches hit 16 distinct bank quads
-    auto xy_off = [](int f, int chunk) { return f * 32 + ((chunk ^ ((f >> 2) & 3)) << 3); };
+    // row are XOR-swizzled so that the 16 rows a ds_read_b128 group touches hit 16 distinct bank quads.
+    // Writes: row f = F0 + 4h with F0 a compile-time constant per register, (f>>2)&3 = (2q + h)&3 with
+    // q = bit 2 of the register index  ->  two lane-dependent bases; reads likewise (two k-steps).
+    const int wbase0 = 128 * h + (pl & 7) + ((((pl >> 3) ^ h) & 3) << 3);
+    const int wbase[2] = {wbase0, wbase0 ^ 16};
+    const int rbase0 = pl * 32 + (((h ^ (pl >> 2)) & 3) << 3);
+    const int rbase[2] = {rbase0, rbase0 ^ 16};
+    float *s12s = cf + 256;                                                // [2 br][2][64] BN1 backward means
+    float *w2s = s12s + 256;                                               // [2 br][2][64] raw sd2.weight
+    if (threadIdx.x >= 256) {
+        const int i = threadIdx.x - 256;
+        s12s[i] = s12[i];
+        w2s[i] = a.tcanon_l[(i >> 7) * T_BR + T_W2 + (i & 127)];
+    }
+    float ua = 0.f, ub = 0.f;
+#ifdef DPF_PROFILE
+    unsigned long long tt[12];
+    tt[11] = __builtin_amdgcn_s_memtime();
+#endif
     for (int br = 0; br < 2; ++br) {
+        TP(0)
         __syncthreads();                                                   // staging landed / previous branch flushed
-        if (threadIdx.x < 128) red[threadIdx.x] = 0.f;
-        __syncthreads();
-        f32x16 h0a[2], h0n[2], pre[2], g2[2];
-        u32x4 bf[NS][4];
-        input_mfma(smem + L_PACK + pt_a0(NS), br, lane, b0, h0a);          // gamma*h0n + beta
-        input_mfma(smem + L_PACK + pt_a0n(NS), br, lane, b0, h0n);         // normalised
-        split_fragment<true, NS>(h0a, bf);
-        load_features(film + br * FILM_BR_FLOATS, h, pre);
-        chain_mfma<NS>(smem + L_PACK + PT_A1, br, lane, bf, pre);          // pre = h1 + D
-        load_fragment(scratch, tile, br, lane, g2);                        // dh2a from pass 1
-        const float *fb = filmb + br * FB_BR;
+        TP(1)
+        f32x16 h0a[2], pre[2];
+        {
+            u32x4 bf[NS][4];
+            input_mfma(smem + L_PACK + pt_a0(NS), br, lane, b0, h0a);      // gamma*h0n + beta
+            split_fragment<true, NS>(h0a, bf);
+            load_features(film + br * FILM_BR_FLOATS, h, pre);
+            chain_mfma<NS>(smem + L_PACK + PT_A1, br, lane, bf, pre);      // pre = h1 + D
+        }
+        TP(2)
+        const float *fb = filmb + br * FB_BR + h4;                         // lane bases; feature offsets are immediates
+        const float *w2 = w2s + br * 128 + h4;
+        const float *s12h = s12s + br * 128 + h4;
+        const float doa = dov[br][0], dob = dov[br][1];
         // dh1 = rstd1 * (dh1n - mean(dh1n) - h1n * mean(dh1n*h1n)),  dh1n = a*dh2a,  h1n = pre*rstd1 - c/a
         f32x16 dh1[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int f = acc_feature(t, r, 0) + 4 * h;
-                const float rstd1 = fb[2 * 64 + f];
-                const float h1n = pre[t][r] * rstd1 - fb[3 * 64 + f];
-                const float dh1n = fb[0 * 64 + f] * g2[t][r];
-                const float v = rstd1 * (dh1n - s12[(br * 2 + 0) * 64 + f] - h1n * s12[(br * 2 + 1) * 64 + f]);
+                const int F0 = acc_feature(t, r, 0);
+                const float av = fb[0 * 64 + F0], rstd1 = fb[2 * 64 + F0];
+                const float g2 = dh2a_of(pre[t][r], w2[F0], w2[64 + F0], doa, dob);
+                const float h1n = pre[t][r] * rstd1 - fb[3 * 64 + F0];
+                const float v = rstd1 * (av * g2 - s12h[F0] - h1n * s12h[64 + F0]);
                 dh1[t][r] = valid ? v : 0.f;
             }
-        // ---- dh0 = W1^T dh1
-        u32x4 bg[2][4];
-        f32x16 dh0[2] = {zero16(), zero16()};
-        split_fragment<false, 2>(dh1, bg);
-        chain_mfma<2>(smem + L_PACK + pt_a1t(NS), br, lane, bg, dh0);
-        f32x16 dh0a[2], tg[2];
+        TP(3)
+        // ---- dh0 = W1^T dh1, relu backward
+        f32x16 dh0a[2] = {zero16(), zero16()};
+        {
+            u32x4 bg[2][4];
+            split_fragment<false, 2>(dh1, bg);
+            chain_mfma<2>(smem + L_PACK + pt_a1t(NS), br, lane, bg, dh0a);
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = h0a[t][r] > 0.f ? dh0[t][r] : 0.f;
-                dh0a[t][r] = v;
-                tg[t][r] = v * h0n[t][r];
-            }
-        dump_fragment(scratch2, tile, br, lane, dh0a);
+            for (int r = 0; r < 16; ++r) dh0a[t][r] = h0a[t][r] > 0.f ? dh0a[t][r] : 0.f;
+        // ---- per-point u_k and the per-feature sums of dh0a * {h0n, 1, x_a, x_b}
+        float rsum[4];
+        int rfeat;
+        __builtin_amdgcn_sched_barrier(0);
+        TP(4)
         {
+            const float *c0 = cf + br * 128 + h4;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int F0 = acc_feature(t, r, 0);
+                    ua += c0[F0] * dh0a[t][r]; ub += c0[64 + F0] * dh0a[t][r];
+                }
             const int f = reduced_feature(pl, h);
-            const float r0 = reduce_points(tg, pl), r1 = reduce_points(dh0a, pl);
-            atomicAdd(&red[f], r0);
-            atomicAdd(&red[64 + f], r1);
+            const float r1 = reduce_points(dh0a, pl);
+            const float r2 = reduce_points_gen([&](int i) { return dh0a[i >> 4][i & 15] * xa; }, pl);
+            const float r3 = reduce_points_gen([&](int i) { return dh0a[i >> 4][i & 15] * xb; }, pl);
+            f32x16 h0n[2];
+            input_mfma(smem + L_PACK + pt_a0n(NS), br, lane, b0, h0n);     // normalised h0
+            const float r0 = reduce_points_gen([&](int i) { return dh0a[i >> 4][i & 15] * h0n[i >> 4][i & 15]; }, pl);
+            rsum[0] = r0; rsum[1] = r1; rsum[2] = r2; rsum[3] = r3; rfeat = f;
         }
+        __builtin_amdgcn_sched_barrier(0);
         // ---- dW1[fo][fi] += sum_points dh1[fo][pt] * h0[fi][pt]: both fragments are transposed through LDS so
         // that the tile's 32 points become the K dimension (2 k-steps of 16).  hi/lo split like every other
         // contraction: three rounds (hi.hi, hi.lo, lo.hi) over the same two LDS tiles.
+        TP(5)
         f32x16 dw[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};     // [fo tile][fi tile]
         auto put = [&](uint16_t *dst, const f32x16 (&v)[2], bool clamp, bool lo) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int f = acc_feature(t, r, 0) + 4 * h;
-                    const float x = clamp ? relu(v[t][r]) : v[t][r];
+                    float x = v[t][r];
+                    asm volatile("" : "+v"(x));      // no CSE with the forward split: keep h0a live, not 3 copies of it
+                    x = clamp ? relu(x) : x;
                     float rest;
                     const uint32_t hi = split_hi(x, rest);
-                    dst[xy_off(f, pl >> 3) + (pl & 7)] = lo ? (uint16_t)bf16_rne(rest) : (uint16_t)(hi >> 16);
+                    (dst + wbase[(r >> 2) & 1])[acc_feature(t, r, 0) * 32] = lo ? (uint16_t)bf16_rne(rest) : (uint16_t)(hi >> 16);
                 }
         };
         auto outer = [&]() {
@@ -658,8 +756,8 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
                 u32x4 fa[2], fbb[2];
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
-                    fa[mt] = *(const u32x4 *)(X + xy_off(32 * mt + pl, 2 * ks + h));     // row fo, 8 consecutive points
-                    fbb[mt] = *(const u32x4 *)(Y + xy_off(32 * mt + pl, 2 * ks + h));    // col fi, same points
+                    fa[mt] = *(const u32x4 *)((X + rbase[ks]) + mt * 1024);     // row fo = 32mt + pl, 8 consecutive points
+                    fbb[mt] = *(const u32x4 *)((Y + rbase[ks]) + mt * 1024);    // col fi, same points
                 }
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
@@ -672,94 +770,122 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
         put(X, dh1, false, false); put(Y, h0a, true, false); outer();       // hi . hi
         put(Y, h0a, true, true); outer();                                   // hi . lo
         put(X, dh1, false, true); put(Y, h0a, true, false); outer();        // lo . hi
-        __syncthreads();                                                   // every wave is done with its X / Y
-        for (int i = threadIdx.x; i < 4096; i += TW * 64) redw[i] = 0.f;
-        __syncthreads();
+        TP(6)
+        // ---- workgroup reduction through per-wave LDS slots (plain stores: LDS float atomics are ~1000 cycles
+        // per wave instruction), two rounds of 32 accumulator registers, then the four per-feature sums
+        float *o = part2 + (blk * 2 + br) * P2_J;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt) {
+            __syncthreads();                                               // X / Y (or the previous round) are free
+            float *slot = redw + wave * 2048 + lane;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int fo = acc_feature(mt, r, 0) + 4 * h, fi = 32 * nt + pl;
-                    atomicAdd(&redw[fo * 64 + fi], dw[mt][nt][r]);
-                }
-        __syncthreads();
-        float *o = part2 + (blk * 2 + br) * 4224;
-        if (threadIdx.x < 128) o[threadIdx.x] = red[threadIdx.x];
-        for (int i = threadIdx.x; i < 4096; i += TW * 64) o[128 + i] = redw[i];
-    }
-}
-
-// Pass 3: BN0 backward (batch statistics), dW0, and the conditioner path of d(input points).
-//   tot[br][0..63] = sum dh0a*h0n (d gamma0), [64..127] = sum dh0a (d beta0)   (already reduced, from dcanon_l)
-//   part3[blk][br][128]: dW0 [64][2]
-__global__ __launch_bounds__(TW * 64) void tbwd3_kernel(TArgs a, float count, const float *__restrict__ dcanon_l,
-                                                        const float *__restrict__ scratch2, float *__restrict__ dp_in,
-                                                        float *__restrict__ part3) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    float *red = (float *)(smem + 8192);                                   // [2 br][128]
-    const int bi = blockIdx.y, lane = threadIdx.x & 63, h = lane >> 5, pl = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    stage_bytes(a.packed_l + a.a0_off, smem, 8192, wave, lane);            // A0 and A0N only
-    for (int i = threadIdx.x; i < 256; i += TW * 64) red[i] = 0.f;
-    const int N = a.N, n = (blockIdx.x * TW + wave) * TILE + pl;
-    const bool valid = n < N;
-    const int nc = valid ? n : N - 1;
-    const float *pc = a.p_in + (size_t)bi * 3 * N;
-    const float xa = pc[(size_t)a.ka * N + nc], xb = a.kb >= 0 ? pc[(size_t)a.kb * N + nc] : 0.f;
-    const u32x4 b0 = input_fragment(h ? xb : xa, h);
-    const size_t tile = ((size_t)bi * gridDim.x + blockIdx.x) * TW + wave;
-    __syncthreads();
-    float dxa = 0.f, dxb = 0.f;
+                for (int r = 0; r < 16; ++r) slot[(16 * nt + r) * 64] = dw[mt][nt][r];
+            __syncthreads();
 #pragma unroll
-    for (int br = 0; br < 2; ++br) {
-        f32x16 h0n[2], g[2], ta[2], tb[2];
-        input_mfma(smem + 4096, br, lane, b0, h0n);
-        load_fragment(scratch2, tile, br, lane, g);                        // dh0a from pass 2
-        const float *cb = a.tcanon_l + br * T_BR;
-        const float *st = a.stats_l + br * ST_BR;
-        const float *dg = dcanon_l + br * T_BR;
+            for (int k = 0; k < 4; ++k) {
+                const int e = threadIdx.x + 512 * k;                       // (nt, r, lane) of the fragment element
+                float t = 0.f;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int f = acc_feature(t, r, 0) + 4 * h;
-                const float gamma = cb[T_G0 + f], rstd0 = st[1 * 64 + f];
-                // dh0n = gamma*dh0a; mean(dh0n) = gamma*dbeta/P; mean(dh0n*h0n) = gamma*dgamma/P
-                const float v = rstd0 * gamma * (g[t][r] - dg[T_B0 + f] / count - h0n[t][r] * dg[T_G0 + f] / count);
-                const float dpre = valid ? v : 0.f;                        // d h0pre
-                ta[t][r] = dpre * xa;
-                tb[t][r] = dpre * xb;
-                dxa += cb[T_W0 + f * 2 + 0] * dpre;
-                dxb += cb[T_W0 + f * 2 + 1] * dpre;
+                for (int w = 0; w < TW; ++w) t += redw[w * 2048 + e];
+                const int ln = e & 63, rr = (e >> 6) & 15, nt = e >> 10;
+                const int fo = 32 * mt + (rr & 3) + 8 * (rr >> 2) + 4 * (ln >> 5), fi = 32 * nt + (ln & 31);
+                o[128 + fo * 64 + fi] = t;
             }
-        const int f = reduced_feature(pl, h);
-        const float r0 = reduce_points(ta, pl), r1 = reduce_points(tb, pl);
-        atomicAdd(&red[br * 128 + f * 2 + 0], r0);
-        atomicAdd(&red[br * 128 + f * 2 + 1], r1);
+        }
+        TP(7)
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) redw[wave * 256 + k * 64 + rfeat] = rsum[k];
+        TP(8)
+        __syncthreads();
+        TP(9)
+        if (threadIdx.x < 256) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < TW; ++w) t += redw[w * 256 + threadIdx.x];
+            o[threadIdx.x < 128 ? threadIdx.x : 4224 - 128 + threadIdx.x] = t;
+        }
+        TP(10)
     }
-    dxa += __shfl_xor(dxa, 32); dxb += __shfl_xor(dxb, 32);
+#ifdef DPF_PROFILE
+    if (g_tprof != nullptr && lane == 0 && blk < 2)
+        for (int i = 0; i < 12; ++i) g_tprof[(blk * TW + wave) * 12 + i] = tt[i];
+#endif
+    ua += __shfl_xor(ua, 32); ub += __shfl_xor(ub, 32);
     if (valid && h == 0) {
-        float *d = dp_in + (size_t)bi * 3 * N;
-        d[(size_t)a.ka * N + n] += dxa;
-        if (a.kb >= 0) d[(size_t)a.kb * N + n] += dxb;
+        ubuf[((size_t)bi * 2 + 0) * N + n] = ua;
+        ubuf[((size_t)bi * 2 + 1) * N + n] = ub;
     }
-    __syncthreads();
-    const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-    for (int i = threadIdx.x; i < 256; i += TW * 64) part3[blk * 256 + i] = red[i];
 }
 
-// strided copy helper for the reduce outputs: part2 totals [br][4224] -> dcanon (gamma0, beta0, W1 are contiguous
-// at T_G0 .. T_W2), part3 totals [br][128] -> dcanon T_W0
-__global__ __launch_bounds__(256) void treduce_to_canon_kernel(int nblk, int J, int dst_off, const float *__restrict__ part,
-                                                               float *__restrict__ dcanon_l) {
-    const int j = blockIdx.x * 256 + threadIdx.x, br = blockIdx.y;
-    if (j >= J) return;
-    double s = 0;
-    for (int k = 0; k < nblk; ++k) s += part[((size_t)k * 2 + br) * J + j];
-    dcanon_l[br * T_BR + dst_off + j] = (float)s;
+// Totals of pass 2 -> d gamma0, d beta0, dW1, dW0 and the coefficients of the input gradient.
+//   tot[br][P2_J] doubles.  BN0 backward:  dh0pre = rstd0*gamma0*(dh0a - A - h0n*Bc),  A = S/P,  Bc = Sg/P
+//   dW0[f][k] = sum_pt dh0pre * x_k = rstd0*gamma0*(Sk - A*sum x_k - Bc * sum h0n*x_k), and h0n is linear in x:
+//   sum_pt h0n_f x_k / P = rstd0_f (w_fa cov(a,k) + w_fb cov(b,k)) + (mean of h0n = 0) * E[x_k]
+//   dx_k[pt] = u_k[pt] - C_k - (alpha_k x_a + beta_k x_b - delta_k):  coef[k] = {C_k - delta_k, alpha_k, beta_k}
+__global__ __launch_bounds__(128) void tfinish2_kernel(double count, const double *__restrict__ tot, const float *__restrict__ tcanon_l,
+                                                       const float *__restrict__ stats_l, float *__restrict__ dcanon_l,
+                                                       float *__restrict__ coef) {
+    __shared__ double acc[2][4][128];
+    const int br = threadIdx.x >> 6, f = threadIdx.x & 63;
+    const double *t = tot + (size_t)br * P2_J;
+    const float *cb = tcanon_l + br * T_BR;
+    const double Sg = t[f], S = t[64 + f], Sa = t[4224 + f], Sb = t[4288 + f];
+    dcanon_l[br * T_BR + T_G0 + f] = (float)Sg;
+    dcanon_l[br * T_BR + T_B0 + f] = (float)S;
+    const float *m = stats_l + ST_MOM;
+    const double ea = m[0], eb = m[1], caa = m[2], cbb = m[3], cab = m[4];
+    const double wa = cb[T_W0 + f * 2 + 0], wb = cb[T_W0 + f * 2 + 1], gamma = cb[T_G0 + f];
+    const double rstd0 = stats_l[br * ST_BR + 64 + f], mean0 = stats_l[br * ST_BR + f];
+    const double A = S / count, Bc = Sg / count;
+    const double hxa = rstd0 * (wa * caa + wb * cab), hxb = rstd0 * (wa * cab + wb * cbb);     // E[h0n x_k]
+    const double sc = rstd0 * gamma;
+    dcanon_l[br * T_BR + T_W0 + f * 2 + 0] = (float)(sc * (Sa - A * ea * count - Bc * hxa * count));
+    dcanon_l[br * T_BR + T_W0 + f * 2 + 1] = (float)(sc * (Sb - A * eb * count - Bc * hxb * count));
+    // input-gradient coefficients: sum over all 128 (branch, feature) rows
+    const double ck[2] = {wa * sc, wb * sc};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        acc[k][0][threadIdx.x] = ck[k] * A;
+        acc[k][1][threadIdx.x] = ck[k] * Bc * rstd0 * wa;
+        acc[k][2][threadIdx.x] = ck[k] * Bc * rstd0 * wb;
+        acc[k][3][threadIdx.x] = ck[k] * Bc * rstd0 * mean0;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const int k = threadIdx.x >> 2, q = threadIdx.x & 3;
+        double s = 0;
+        for (int i = 0; i < 128; ++i) s += acc[k][q][i];
+        acc[k][q][0] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const int k = threadIdx.x;
+        coef[k * 4 + 0] = (float)(acc[k][0][0] - acc[k][3][0]);
+        coef[k * 4 + 1] = (float)acc[k][1][0];
+        coef[k * 4 + 2] = (float)acc[k][2][0];
+    }
+    // dW1 rows of this branch
+    for (int i = f; i < 4096; i += 64) dcanon_l[br * T_BR + T_W1 + i] = (float)t[128 + i];
 }
+
+// Pass 3: the conditioner path of d(input points), elementwise
+__global__ __launch_bounds__(256) void tbwd3_kernel(int N, int ka, int kb, const float *__restrict__ p_in, const float *__restrict__ ubuf,
+                                                    const float *__restrict__ coef, float *__restrict__ dp_in) {
+    const int bi = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const float *pc = p_in + (size_t)bi * 3 * N;
+    float *d = dp_in + (size_t)bi * 3 * N;
+    const float xa = pc[(size_t)ka * N + n], xb = kb >= 0 ? pc[(size_t)kb * N + n] : 0.f;
+    d[(size_t)ka * N + n] += ubuf[((size_t)bi * 2 + 0) * N + n] - coef[0] - coef[1] * xa - coef[2] * xb;
+    if (kb >= 0) d[(size_t)kb * N + n] += ubuf[((size_t)bi * 2 + 1) * N + n] - coef[4] - coef[5] * xa - coef[6] * xb;
+}
+
+#ifdef DPF_PROFILE
+__global__ void tprof_set_kernel(unsigned long long *p) { g_tprof = p; }
+#endif
 
 hipError_t set_lds(const void *fn, int bytes) {
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -778,21 +904,36 @@ extern "C" size_t dpf_flow_train_film_floats(int B) { return (size_t)B * (512 + 
 
 static inline int t_nblk(int B, int N) { return B * ((N + TBLK - 1) / TBLK); }
 
-// workspace (floats) for one layer call, forward or backward
-extern "C" size_t dpf_flow_train_workspace_bytes(int B, int N) {
+struct TWork {
+    double *xpart, *sums, *tot2;
+    float *part1, *pc, *s12, *part2, *dout, *ubuf, *coef;
+};
+static size_t carve(void *ws, int B, int N, TWork *w) {
     const size_t nblk = (size_t)t_nblk(B, N), nbx = (size_t)B * ((N + 255) / 256);
-    size_t f = 0;
-    f += nbx * 8 * 2;                 // x-moment partials (double)
-    f += nblk * 512;                  // h1 / pass-1 partials
-    f += nblk * 4;                    // db2 partials
-    f += (size_t)B * 512;             // per-cloud totals of pass 1
-    f += 256;                         // s12
-    f += nblk * 2 * 4224;             // pass-2 partials
-    f += nblk * 256;                  // pass-3 partials
-    return f * sizeof(float) + 1024;
+    uint8_t *p = (uint8_t *)ws;
+    auto take = [&](size_t bytes) { uint8_t *q = p; p += (bytes + 255) / 256 * 256; return q; };
+    uint8_t *xpart = take(nbx * 8 * sizeof(double));
+    uint8_t *sums = take(256 * sizeof(double));
+    uint8_t *tot2 = take(2 * P2_J * sizeof(double));
+    uint8_t *part1 = take(nblk * 520 * 4);
+    uint8_t *pc = take((size_t)B * 520 * 4);
+    uint8_t *s12 = take(256 * 4);
+    uint8_t *part2 = take(nblk * 2 * P2_J * 4);
+    uint8_t *dout = take((size_t)B * 4 * N * 4);
+    uint8_t *ubuf = take((size_t)B * 2 * N * 4);
+    uint8_t *coef = take(8 * 4);
+    if (w) {
+        w->xpart = (double *)xpart; w->sums = (double *)sums; w->tot2 = (double *)tot2; w->part1 = (float *)part1;
+        w->pc = (float *)pc; w->s12 = (float *)s12; w->part2 = (float *)part2; w->dout = (float *)dout;
+        w->ubuf = (float *)ubuf; w->coef = (float *)coef;
+    }
+    return (size_t)(p - (uint8_t *)ws);
 }
-// the two fragment scratch buffers (dh2a, dh0a): floats
-extern "C" size_t dpf_flow_train_scratch_floats(int B, int N) { return (size_t)t_nblk(B, N) * TW * 2 * 32 * 64; }
+// workspace for one layer call, forward or backward (contents do not survive the call)
+extern "C" size_t dpf_flow_train_workspace_bytes(int B, int N) {
+    if (B <= 0 || N <= 0) return 0;
+    return carve(nullptr, B, N, nullptr) + 256;
+}
 
 extern "C" int dpf_flow_train_pack(int n_layers, int precision, const float *tcanon, void *packed, dpf_stream_t stream) {
     const int ns = t_ns(precision);
@@ -803,27 +944,11 @@ extern "C" int dpf_flow_train_pack(int n_layers, int precision, const float *tca
     return (int)hipGetLastError();
 }
 
-struct TWork {
-    double *xpart; float *part1, *part1b, *pc, *s12, *part2, *part3;
-};
-static TWork carve(void *ws, int B, int N) {
-    const size_t nblk = (size_t)t_nblk(B, N), nbx = (size_t)B * ((N + 255) / 256);
-    TWork w;
-    uint8_t *p = (uint8_t *)ws;
-    w.xpart = (double *)p; p += nbx * 8 * sizeof(double);
-    w.part1 = (float *)p; p += nblk * 512 * 4;
-    w.part1b = (float *)p; p += nblk * 4 * 4;
-    w.pc = (float *)p; p += (size_t)B * 512 * 4;
-    w.s12 = (float *)p; p += 256 * 4;
-    w.part2 = (float *)p; p += nblk * 2 * 4224 * 4;
-    w.part3 = (float *)p;
-    return w;
-}
-
 template <int NS>
 static int prepare_layer(int B, int N, int ka, int kb, const float *tcanon_l, void *packed_l, const float *fm_l,
                          const float *p_in, float *stats_l, float *film_l, float flow_eps, void *workspace, hipStream_t s) {
-    TWork w = carve(workspace, B, N);
+    TWork w;
+    carve(workspace, B, N, &w);
     const int nbx = (N + 255) / 256;
     const double count = (double)B * N;
     hipLaunchKernelGGL(tstats_x_kernel, dim3(nbx, B), dim3(256), 0, s, N, ka, kb, p_in, w.xpart);
@@ -832,7 +957,7 @@ static int prepare_layer(int B, int N, int ka, int kb, const float *tcanon_l, vo
     TArgs a;
     a.packed_l = (const uint8_t *)packed_l; a.tcanon_l = tcanon_l; a.film_l = film_l; a.filmb_l = film_l + (size_t)B * 512;
     a.stats_l = stats_l; a.p_in = p_in; a.B = B; a.N = N; a.ka = ka; a.kb = kb; a.wa = 0; a.wb = 0; a.mode = 0;
-    a.a0_off = pt_a0(NS); a.eps = flow_eps;
+    a.eps = flow_eps;
     static bool attr = false;
     if (!attr) {
         hipError_t e = set_lds((const void *)tstats_h1_kernel<NS>, pt_a0n(NS));
@@ -841,8 +966,9 @@ static int prepare_layer(int B, int N, int ka, int kb, const float *tcanon_l, vo
     }
     const dim3 grid((N + TBLK - 1) / TBLK, B);
     hipLaunchKernelGGL(tstats_h1_kernel<NS>, grid, dim3(TW * 64), pt_a0n(NS), s, a, w.part1);
-    hipLaunchKernelGGL(tfilm_fold_kernel, dim3(B), dim3(128), 0, s, (int)(grid.x * grid.y), (float)count, w.part1, tcanon_l,
-                       fm_l, B, flow_eps, stats_l, film_l, film_l + (size_t)B * 512);
+    hipLaunchKernelGGL(tcolsum_kernel, dim3(8), dim3(1024), 0, s, (int)(grid.x * grid.y), 256, w.part1, w.sums);
+    hipLaunchKernelGGL(tfilm_fold_kernel, dim3(B), dim3(128), 0, s, count, w.sums, tcanon_l, fm_l, B, flow_eps, stats_l, film_l,
+                       film_l + (size_t)B * 512);
     return (int)hipGetLastError();
 }
 
@@ -862,18 +988,19 @@ extern "C" int dpf_flow_train_prepare_layer(int B, int N, int precision, int ka,
 
 template <int NS>
 static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb, const float *tcanon_l, const void *packed_l,
-                          const float *film_l, const float *stats_l, const float *p_in, const float *g_p, const float *g_mu,
-                          const float *g_lv, float *dp_in, float *dcanon_l, float *dfm_l, float *scratch_a, float *scratch_b,
-                          float flow_eps, void *workspace, hipStream_t s) {
-    TWork w = carve(workspace, B, N);
+                          const float *film_l, const float *stats_l, const float *p_in, const float *g_p, const float *g_p2,
+                          const float *g_mu, const float *g_lv, float *dp_in, float *dcanon_l, float *dfm_l, float flow_eps,
+                          void *workspace, hipStream_t s) {
+    TWork w;
+    carve(workspace, B, N, &w);
     TArgs a;
     a.packed_l = (const uint8_t *)packed_l; a.tcanon_l = tcanon_l; a.film_l = film_l; a.filmb_l = film_l + (size_t)B * 512;
     a.stats_l = stats_l; a.p_in = p_in; a.B = B; a.N = N; a.ka = ka; a.kb = kb; a.wa = wa; a.wb = wb; a.mode = mode;
-    a.a0_off = pt_a0(NS); a.eps = flow_eps;
+    a.eps = flow_eps;
     const dim3 grid((N + TBLK - 1) / TBLK, B);
     const int nblk = grid.x * grid.y, nb = grid.x;
-    const float count = (float)((double)B * N);
-    const int lds1 = l_red(NS) + (512 + 4) * 4, lds2 = l_red(NS) + 512 + TW * XY_WAVE * 2, lds3 = 8192 + 256 * 4;
+    const double count = (double)B * N;
+    const int lds1 = pt_a0n(NS) + 4096 + (TW * 520 + 256) * 4, lds2 = l_red(NS) + 4096 + TW * XY_WAVE * 2;
     static bool attr = false;
     if (!attr) {
         hipError_t e = set_lds((const void *)tbwd1_kernel<NS>, lds1);
@@ -881,32 +1008,31 @@ static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
-    hipLaunchKernelGGL(tbwd1_kernel<NS>, grid, dim3(TW * 64), lds1, s, a, g_p, g_mu, g_lv, dp_in, scratch_a, w.part1, w.part1b);
-    hipLaunchKernelGGL(treduce_cloud_kernel, dim3(2, B), dim3(256), 0, s, nb, 512, w.part1, w.pc);
-    hipLaunchKernelGGL(tbwd1_finish_kernel, dim3(1), dim3(128), 0, s, B, nb, count, w.pc, w.part1b, nblk, a.filmb_l, flow_eps,
-                       dfm_l, w.s12, dcanon_l);
-    hipLaunchKernelGGL(tbwd2_kernel<NS>, grid, dim3(TW * 64), lds2, s, a, w.s12, scratch_a, scratch_b, w.part2);
-    hipLaunchKernelGGL(treduce_to_canon_kernel, dim3((4224 + 255) / 256, 2), dim3(256), 0, s, nblk, 4224, T_G0, w.part2, dcanon_l);
-    hipLaunchKernelGGL(tbwd3_kernel, grid, dim3(TW * 64), lds3, s, a, count, dcanon_l, scratch_b, dp_in, w.part3);
-    hipLaunchKernelGGL(treduce_to_canon_kernel, dim3(1, 2), dim3(256), 0, s, nblk, 128, T_W0, w.part3, dcanon_l);
+    hipLaunchKernelGGL(tbwd1_kernel<NS>, grid, dim3(TW * 64), lds1, s, a, g_p, g_p2, g_mu, g_lv, dp_in, w.dout, w.part1);
+    hipLaunchKernelGGL(tcloudsum_kernel, dim3(B), dim3(520), 0, s, nb, B, w.part1, a.filmb_l, flow_eps, w.pc, dfm_l);
+    hipLaunchKernelGGL(tfinish1_kernel, dim3(1), dim3(128), 0, s, B, count, w.pc, a.filmb_l, w.s12, dcanon_l);
+    hipLaunchKernelGGL(tbwd2_kernel<NS>, grid, dim3(TW * 64), lds2, s, a, w.s12, w.dout, w.ubuf, w.part2);
+    hipLaunchKernelGGL(tcolsum_kernel, dim3((2 * P2_J + 31) / 32), dim3(1024), 0, s, nblk, 2 * P2_J, w.part2, w.tot2);
+    hipLaunchKernelGGL(tfinish2_kernel, dim3(1), dim3(128), 0, s, count, w.tot2, tcanon_l, stats_l, dcanon_l, w.coef);
+    hipLaunchKernelGGL(tbwd3_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, N, ka, kb, p_in, w.ubuf, w.coef, dp_in);
     return (int)hipGetLastError();
 }
 
-// Backward of ONE layer.  g_p / g_mu / g_lv: gradients w.r.t. the layer's outputs (g_mu, g_lv may be NULL);
+// Backward of ONE layer.  The gradient w.r.t. the layer's p_out is g_p + g_p2 (g_p2 may be NULL: the chain
+// from the next layer plus the loss's own term); g_mu / g_lv: gradients w.r.t. mu / logvar (may be NULL).
 // dp_in (B,3,N), dcanon_l (T_LAYER) and dfm_l ([br][sub][B][64]) are fully overwritten.
 extern "C" int dpf_flow_train_backward_layer(int B, int N, int mode, int precision, int ka, int kb, int wa, int wb,
                                              const float *tcanon_l, const void *packed_l, const float *film_l,
-                                             const float *stats_l, const float *p_in, const float *g_p, const float *g_mu,
-                                             const float *g_lv, float *dp_in, float *dcanon_l, float *dfm_l,
-                                             float *scratch_a, float *scratch_b, float flow_eps, void *workspace,
-                                             dpf_stream_t stream) {
+                                             const float *stats_l, const float *p_in, const float *g_p, const float *g_p2,
+                                             const float *g_mu, const float *g_lv, float *dp_in, float *dcanon_l,
+                                             float *dfm_l, float flow_eps, void *workspace, dpf_stream_t stream) {
     if (B <= 0 || N <= 0 || !tcanon_l || !packed_l || !film_l || !stats_l || !p_in || !g_p || !dp_in || !dcanon_l || !dfm_l ||
-        !scratch_a || !scratch_b || !workspace)
+        !workspace)
         return DPF_EINVAL;
     if (B > 65535) return DPF_ENOSUP;
-#define DPF_BWD(NSV)                                                                                                       \
-    return backward_layer<NSV>(B, N, mode, ka, kb, wa, wb, tcanon_l, packed_l, film_l, stats_l, p_in, g_p, g_mu, g_lv, dp_in, \
-                               dcanon_l, dfm_l, scratch_a, scratch_b, flow_eps, workspace, (hipStream_t)stream);
+#define DPF_BWD(NSV)                                                                                                          \
+    return backward_layer<NSV>(B, N, mode, ka, kb, wa, wb, tcanon_l, packed_l, film_l, stats_l, p_in, g_p, g_p2, g_mu, g_lv,  \
+                               dp_in, dcanon_l, dfm_l, flow_eps, workspace, (hipStream_t)stream);
     switch (t_ns(precision)) {
         case 2: DPF_BWD(2)
         case 3: DPF_BWD(3)
@@ -914,3 +1040,10 @@ extern "C" int dpf_flow_train_backward_layer(int B, int N, int mode, int precisi
     }
 #undef DPF_BWD
 }
+
+#ifdef DPF_PROFILE
+extern "C" void dpf_debug_set_tprof(void *p) {
+    hipLaunchKernelGGL(tprof_set_kernel, dim3(1), dim3(1), 0, 0, (unsigned long long *)p);
+    hipDeviceSynchronize();
+}
+#endif

@@ -136,32 +136,23 @@ class _FlowStackTrain(torch.autograd.Function):
         stream = current_stream()
         pbytes = L_.dpf_flow_train_packed_bytes(1, ctx.prec)
         ws = torch.empty(L_.dpf_flow_train_workspace_bytes(B, N), dtype=torch.uint8, device=dev)
-        nscr = L_.dpf_flow_train_scratch_floats(B, N)
-        scr = torch.empty((2, nscr), dtype=torch.float32, device=dev)
         dcanon = torch.empty_like(tcanon)
         dfm = torch.empty((L, 2, 2, B, F), dtype=torch.float32, device=dev)
-        g_ps = g_ps.contiguous() if g_ps is not None else None
-        g_mus = g_mus.contiguous() if g_mus is not None else None
-        g_lvs = g_lvs.contiguous() if g_lvs is not None else None
+        g_ps, g_mus, g_lvs = g_ps.contiguous(), g_mus.contiguous(), g_lvs.contiguous()
         dp = [torch.empty_like(p), torch.empty_like(p)]
         chain = None
         order = ctx.order
         for step in range(L - 1, -1, -1):
             l = order[step]
             p_in = p if step == 0 else ps[order[step - 1]]
-            if chain is None:
-                gp = g_ps[l] if g_ps is not None else torch.zeros_like(p)
-            else:
-                gp = chain + g_ps[l] if g_ps is not None else chain
             ka, kb, wa, wb = ctx.metas[l]
             out = dp[step & 1]
             check(L_.dpf_flow_train_backward_layer(
                 B, N, MODE[ctx.mode], ctx.prec, ka, kb, wa, wb, tcanon[l].data_ptr(), packed.data_ptr() + l * pbytes,
-                film[l].data_ptr(), stats[l].data_ptr(), p_in.data_ptr(), gp.data_ptr(),
-                g_mus[l].data_ptr() if g_mus is not None else None,
-                g_lvs[l].data_ptr() if g_lvs is not None else None,
-                out.data_ptr(), dcanon[l].data_ptr(), dfm[l].data_ptr(), scr[0].data_ptr(), scr[1].data_ptr(),
-                ctx.eps, ws.data_ptr(), stream), "flow_train_backward_layer")
+                film[l].data_ptr(), stats[l].data_ptr(), p_in.data_ptr(), g_ps[l].data_ptr(),
+                chain.data_ptr() if chain is not None else None, g_mus[l].data_ptr(), g_lvs[l].data_ptr(),
+                out.data_ptr(), dcanon[l].data_ptr(), dfm[l].data_ptr(), ctx.eps, ws.data_ptr(), stream),
+                "flow_train_backward_layer")
             chain = out
         return chain, dcanon, dfm, None, None, None, None
 
@@ -190,7 +181,7 @@ def run_training_stack(layers, p, g, mode, precision=None):
         ps, mus, lvs, stats = _FlowStackTrain.apply(p, tcanon, fm, metas, mode, float(layers[0].eps_value),
                                                       PREC[precision])
         with torch.no_grad():
-            st = stats.view(len(layers), 2, 6, F)
+            st = stats[:, :2 * 6 * F].view(len(layers), 2, 6, F)
             bns, means, uvars = [], [], []
             for li, lyr in enumerate(layers):
                 for bi, br in enumerate(BRANCHES):

@@ -205,14 +205,13 @@ int dpf_flow_forward(int n_layers, int B, int N, int mode, int precision,
  * takes.
  * stats_l: dpf_flow_train_stats_floats() floats, [branch][6][64] =
  * mean0, rstd0, mean1, rstd1, unbiased batch var0, unbiased batch var1 (what
- * BatchNorm1d feeds its running statistics with).
+ * BatchNorm1d feeds its running statistics with), then 8 floats of input moments.
  * ------------------------------------------------------------------------ */
 size_t dpf_flow_train_canon_floats(void);
 size_t dpf_flow_train_packed_bytes(int n_layers, int precision);
 size_t dpf_flow_train_stats_floats(void);
 size_t dpf_flow_train_film_floats(int B);
 size_t dpf_flow_train_workspace_bytes(int B, int N);
-size_t dpf_flow_train_scratch_floats(int B, int N);
 
 /* W1 / W1^T MFMA fragments of every layer (once per optimizer step) */
 int dpf_flow_train_pack(int n_layers, int precision, const float *tcanon, void *packed,
@@ -226,16 +225,16 @@ int dpf_flow_train_prepare_layer(int B, int N, int precision, int keep_a, int ke
                                  float *stats_l, float *film_l, float flow_eps,
                                  void *workspace, dpf_stream_t stream);
 
-/* backward of ONE layer.  g_p / g_mu / g_lv: gradients w.r.t. the layer's three
- * outputs (g_mu, g_lv may be NULL = zero).  Overwrites dp_in (B,3,N), dcanon_l
- * and dfm_l.  scratch_a / scratch_b: dpf_flow_train_scratch_floats floats each. */
+/* backward of ONE layer.  The gradient w.r.t. the layer's p_out is g_p + g_p2
+ * (g_p2 may be NULL); g_mu / g_lv: gradients w.r.t. its mu / logvar outputs (may
+ * be NULL = zero).  Overwrites dp_in (B,3,N), dcanon_l and dfm_l. */
 int dpf_flow_train_backward_layer(int B, int N, int mode, int precision, int keep_a, int keep_b,
-                                  int warp_a, int warp_b, const float *tcanon_l, const void *packed_l,
-                                  const float *film_l, const float *stats_l, const float *p_in,
-                                  const float *g_p, const float *g_mu, const float *g_lv,
-                                  float *dp_in, float *dcanon_l, float *dfm_l,
-                                  float *scratch_a, float *scratch_b, float flow_eps,
-                                  void *workspace, dpf_stream_t stream);
+                                  int warp_a, int warp_b, const float *tcanon_l,
+                                  const void *packed_l, const float *film_l, const float *stats_l,
+                                  const float *p_in, const float *g_p, const float *g_p2,
+                                  const float *g_mu, const float *g_lv, float *dp_in,
+                                  float *dcanon_l, float *dfm_l, float flow_eps, void *workspace,
+                                  dpf_stream_t stream);
 
 /* library identification: returns e.g. "dpf_hip gfx950 r1" */
 const char *dpf_version(void);

@@ -144,8 +144,11 @@ def test_decoder_training_step_vs_reference_golden(golden_dir, prec):
 
 @pytest.mark.parametrize("B,N,mode", [(3, 1000, "inverse"), (8, 2048, "direct"), (2, 40, "inverse")])
 def test_training_hip_vs_tensor_op_path(B, N, mode, prec):
-    """Same module, same inputs: HIP kernels vs forward_torch + autograd (PyTorch-ROCm fp32 ops) on
-    the GPU -- every output, every input gradient, every parameter gradient elementwise."""
+    """Same module, same inputs: HIP kernels vs forward_torch + autograd on the GPU, in float64 (the
+    yardstick) and in fp32 (PyTorch-ROCm ops) -- every output, every input gradient, every parameter
+    gradient elementwise.  A parameter gradient that is a heavily cancelling sum over all points (a
+    bias of the last layers: 16384 terms of both signs) is held to what fp32 summation itself achieves:
+    tolerance = max(stated tolerance, 4 x error of the fp32 tensor-op path against float64)."""
     nets = _gpu()
     kf, loose = (2e-4, 1.0) if prec == "bf16x6" else (1e-2, 10.0)
     n_flows, G, seed = 2, 128, 31
@@ -153,17 +156,21 @@ def test_training_hip_vs_tensor_op_path(B, N, mode, prec):
     tgt, z, g = FO.synthetic_inputs(seed, B, N, G)
     src = tgt if mode == "inverse" else z
     res = {}
-    for impl in ("hip", "torch"):
+    for impl in ("hip", "torch", "torch64"):
         dec = nets.LocalCondRNVPDecoder(n_flows, 64, G, weight_std=0.01)
         dec.load_state_dict(sd, strict=True)
         dec = dec.cuda().train()
-        tp = torch.from_numpy(src.copy()).cuda().requires_grad_(True)
-        tg = torch.from_numpy(g.copy()).cuda().requires_grad_(True)
+        tp = torch.from_numpy(src.copy()).cuda()
+        tg = torch.from_numpy(g.copy()).cuda()
+        if impl == "torch64":
+            dec, tp, tg = dec.double(), tp.double(), tg.double()
+        tp.requires_grad_(True)
+        tg.requires_grad_(True)
         if impl == "hip":
             ps, mus, lvs = dec(tp, tg, mode=mode)
         else:
             ps, mus, lvs = dec.forward_torch(tp, tg, mode=mode)
-        pm, pl = torch.zeros(B, 3, N).cuda(), torch.full((B, 3, N), -3.6).cuda()
+        pm, pl = torch.zeros(B, 3, N).cuda().to(tp.dtype), torch.full((B, 3, N), -3.6).cuda().to(tp.dtype)
         smp = ps + [tp] if mode == "inverse" else [tp] + ps
         loss = nets.PointFlowNLL()(smp, [pm] + mus, [pl] + lvs) + 0.1 * (ps[2] * mus[4]).mean()
         loss.backward()
@@ -171,7 +178,7 @@ def test_training_hip_vs_tensor_op_path(B, N, mode, prec):
                          loss=float(loss), gp=tp.grad, gg=tg.grad,
                          grads={k: v.grad for k, v in dec.named_parameters()},
                          stats={k: v for k, v in dec.state_dict().items() if "running" in k})
-    h, t = res["hip"], res["torch"]
+    h, t, t32 = res["hip"], res["torch64"], res["torch"]
     for key in ("ps", "mus", "lvs"):
         for i, (a, b) in enumerate(zip(h[key], t[key])):
             assert rel(a, b) <= STACK_OUT_REL or float(b.abs().max()) == 0.0, (key, i, rel(a, b))
@@ -183,8 +190,8 @@ def test_training_hip_vs_tensor_op_path(B, N, mode, prec):
             assert h["grads"][k] is None or float(h["grads"][k].abs().max()) == 0.0, k
             continue
         assert h["grads"][k] is not None, k
-        r = rel(h["grads"][k], t["grads"][k])
-        assert r <= 2 * loose * STACK_GRAD_REL, (k, r)
+        r, r32 = rel(h["grads"][k], t["grads"][k]), rel(t32["grads"][k], t["grads"][k])
+        assert r <= max(2 * loose * STACK_GRAD_REL, 4 * r32), (k, r, r32)
     for k in t["stats"]:
         np.testing.assert_allclose(h["stats"][k].cpu().numpy(), t["stats"][k].cpu().numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
 

@@ -1,0 +1,31 @@
+"""Per-phase s_memtime profile of tbwd2 (needs libdpf_hip_prof.so: make -C dpf_nets_amd/csrc prof)."""
+import ctypes, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dpf_nets_amd import _lib
+_lib.lib_path = lambda: os.path.join(ROOT, "dpf_nets_amd", "libdpf_hip_prof.so")
+from dpf_nets_amd import networks as nets, synthetic as SY
+from dpf_nets_amd.networks import train_engine
+B, N, G = 32, 2048, 128
+h = _lib.lib()
+h.dpf_debug_set_tprof.argtypes = [ctypes.c_void_p]
+dec = nets.LocalCondRNVPDecoder(1, 64, G).cuda().train()
+tgt, z, g = SY.synthetic_inputs(3, B, N, G)
+names = ["loop top", "sync+zero", "fwd recompute", "dh1", "T chain + mask", "reductions", "dW1 rounds", "sync+zero redw",
+         "LDS atomics", "sync", "write out"]
+for prec in ("bf16x3", "bf16x6"):
+    train_engine.TRAIN_PRECISION = prec
+    prof = torch.zeros((16, 12), dtype=torch.int64, device="cuda")
+    for it in range(3):
+        if it == 2: h.dpf_debug_set_tprof(prof.data_ptr())
+        x = torch.from_numpy(tgt).cuda().requires_grad_(True)
+        ps, mus, lvs = dec(x, torch.from_numpy(g).cuda(), mode="inverse")
+        (ps[0].square().mean() + sum(lvs).mean()).backward()
+    torch.cuda.synchronize()
+    h.dpf_debug_set_tprof(None)
+    t = prof.cpu().numpy()
+    d = np.diff(t[:, :11], axis=1)
+    print(prec, "entry->loop:", np.median(t[:, 0] - t[:, 11]))
+    for i in range(10):
+        print("   %-16s median %8.0f  max %8.0f" % (names[i + 1], np.median(d[:, i]), d[:, i].max()))
