@@ -39,9 +39,9 @@ SIGNATURES = {
     "dpf_flow_train_film_floats": (_sz, [_i]),
     "dpf_flow_train_workspace_bytes": (_sz, [_i, _i]),
     "dpf_flow_train_pack": (_i, [_i, _i, _vp, _vp, _vp]),
-    "dpf_flow_train_prepare_layer": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
-    "dpf_flow_train_backward_layer": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                           _vp, _vp, _vp, _f, _vp, _vp]),
+    "dpf_flow_train_forward": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
+    "dpf_flow_train_backward": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                     _vp, _f, _vp, _vp]),
     "dpf_chamfer_reduce": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "dpf_version": (ctypes.c_char_p, []),
 }

@@ -46,7 +46,7 @@ constexpr int TW = 8;                    // waves per workgroup (256 points of o
 constexpr int TBLK = TW * TILE;
 
 // ---- compact per-layer parameter block `tcanon` (floats), branch order (logvar, mu) ----------
-constexpr int T_W0 = 0;        // [64][2]  sd0.weight, columns = keep channels (zero column if one)
+constexpr int T_W0 = 0;        // [64][nk] sd0.weight as stored (nk = 1 or 2 keep channels), then zeros up to 128
 constexpr int T_G0 = 128;      // [64]     sd0_bn.weight
 constexpr int T_B0 = 192;      // [64]     sd0_bn.bias
 constexpr int T_W1 = 256;      // [64][64] sd1.weight
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void tstats_x_kernel(int N, int ka, int kb, co
 
 // BN0 batch statistics (analytic: h0 = W0 x is linear in x) and the two folded input-MFMA fragment
 // sets of the layer.  One workgroup, thread = (branch, feature).
-__global__ __launch_bounds__(128) void tbn0_kernel(int nblk, double count, const double *__restrict__ part,
+__global__ __launch_bounds__(128) void tbn0_kernel(int nblk, int nk, double count, const double *__restrict__ part,
                                                    const float *__restrict__ tcanon_l, uint8_t *__restrict__ packed_a0,
                                                    float *__restrict__ stats_l) {
     __shared__ double mom[5], wsum[2][5];
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(128) void tbn0_kernel(int nblk, double count, const
     }
     const int br = threadIdx.x >> 6, f = threadIdx.x & 63;
     const float *cb = tcanon_l + br * T_BR;
-    const double wa = cb[T_W0 + f * 2 + 0], wb = cb[T_W0 + f * 2 + 1];
+    const double wa = cb[T_W0 + f * nk], wb = nk == 2 ? cb[T_W0 + f * 2 + 1] : 0.0;
     const double ea = mom[0], eb = mom[1];
     const double caa = mom[2] - ea * ea, cbb = mom[3] - eb * eb, cab = mom[4] - ea * eb;
     if (threadIdx.x == 0) {
@@ -630,7 +630,8 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
     if (threadIdx.x < 256) {                                               // c_fk = W0[f][k] * rstd0_f * gamma0_f
         const int br = threadIdx.x >> 7, k = (threadIdx.x >> 6) & 1, f = threadIdx.x & 63;
         const float *cb = a.tcanon_l + br * T_BR;
-        cf[threadIdx.x] = cb[T_W0 + f * 2 + k] * a.stats_l[br * ST_BR + 64 + f] * cb[T_G0 + f];
+        const int nk = a.kb >= 0 ? 2 : 1;
+        cf[threadIdx.x] = (k < nk ? cb[T_W0 + f * nk + k] : 0.f) * a.stats_l[br * ST_BR + 64 + f] * cb[T_G0 + f];
     }
     const int N = a.N, n = (blockIdx.x * TW + wave) * TILE + pl;
     const bool valid = n < N;
@@ -825,7 +826,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
 //   dW0[f][k] = sum_pt dh0pre * x_k = rstd0*gamma0*(Sk - A*sum x_k - Bc * sum h0n*x_k), and h0n is linear in x:
 //   sum_pt h0n_f x_k / P = rstd0_f (w_fa cov(a,k) + w_fb cov(b,k)) + (mean of h0n = 0) * E[x_k]
 //   dx_k[pt] = u_k[pt] - C_k - (alpha_k x_a + beta_k x_b - delta_k):  coef[k] = {C_k - delta_k, alpha_k, beta_k}
-__global__ __launch_bounds__(128) void tfinish2_kernel(double count, const double *__restrict__ tot, const float *__restrict__ tcanon_l,
+__global__ __launch_bounds__(128) void tfinish2_kernel(int nk, double count, const double *__restrict__ tot, const float *__restrict__ tcanon_l,
                                                        const float *__restrict__ stats_l, float *__restrict__ dcanon_l,
                                                        float *__restrict__ coef) {
     __shared__ double acc[2][4][128];
@@ -837,13 +838,14 @@ __global__ __launch_bounds__(128) void tfinish2_kernel(double count, const doubl
     dcanon_l[br * T_BR + T_B0 + f] = (float)S;
     const float *m = stats_l + ST_MOM;
     const double ea = m[0], eb = m[1], caa = m[2], cbb = m[3], cab = m[4];
-    const double wa = cb[T_W0 + f * 2 + 0], wb = cb[T_W0 + f * 2 + 1], gamma = cb[T_G0 + f];
+    const double wa = cb[T_W0 + f * nk], wb = nk == 2 ? cb[T_W0 + f * 2 + 1] : 0.0, gamma = cb[T_G0 + f];
     const double rstd0 = stats_l[br * ST_BR + 64 + f], mean0 = stats_l[br * ST_BR + f];
     const double A = S / count, Bc = Sg / count;
     const double hxa = rstd0 * (wa * caa + wb * cab), hxb = rstd0 * (wa * cab + wb * cbb);     // E[h0n x_k]
     const double sc = rstd0 * gamma;
-    dcanon_l[br * T_BR + T_W0 + f * 2 + 0] = (float)(sc * (Sa - A * ea * count - Bc * hxa * count));
-    dcanon_l[br * T_BR + T_W0 + f * 2 + 1] = (float)(sc * (Sb - A * eb * count - Bc * hxb * count));
+    dcanon_l[br * T_BR + T_W0 + f * nk] = (float)(sc * (Sa - A * ea * count - Bc * hxa * count));
+    if (nk == 2) dcanon_l[br * T_BR + T_W0 + f * 2 + 1] = (float)(sc * (Sb - A * eb * count - Bc * hxb * count));
+    else dcanon_l[br * T_BR + T_W0 + 64 + f] = 0.f;
     // input-gradient coefficients: sum over all 128 (branch, feature) rows
     const double ck[2] = {wa * sc, wb * sc};
 #pragma unroll
@@ -952,7 +954,7 @@ static int prepare_layer(int B, int N, int ka, int kb, const float *tcanon_l, vo
     const int nbx = (N + 255) / 256;
     const double count = (double)B * N;
     hipLaunchKernelGGL(tstats_x_kernel, dim3(nbx, B), dim3(256), 0, s, N, ka, kb, p_in, w.xpart);
-    hipLaunchKernelGGL(tbn0_kernel, dim3(1), dim3(128), 0, s, nbx * B, count, w.xpart, tcanon_l,
+    hipLaunchKernelGGL(tbn0_kernel, dim3(1), dim3(128), 0, s, nbx * B, kb >= 0 ? 2 : 1, count, w.xpart, tcanon_l,
                        (uint8_t *)packed_l + pt_a0(NS), stats_l);
     TArgs a;
     a.packed_l = (const uint8_t *)packed_l; a.tcanon_l = tcanon_l; a.film_l = film_l; a.filmb_l = film_l + (size_t)B * 512;
@@ -972,18 +974,36 @@ static int prepare_layer(int B, int N, int ka, int kb, const float *tcanon_l, vo
     return (int)hipGetLastError();
 }
 
-// Forward statistics + folds of ONE layer; afterwards dpf_flow_forward(n_layers = 1, precision, packed = packed_l,
-// film = film_l) runs the layer itself.  stats_l receives the batch statistics (for the running-stat update).
-extern "C" int dpf_flow_train_prepare_layer(int B, int N, int precision, int ka, int kb, const float *tcanon_l, void *packed_l,
-                                            const float *fm_l, const float *p_in, float *stats_l, float *film_l,
-                                            float flow_eps, void *workspace, dpf_stream_t stream) {
-    if (B <= 0 || N <= 0 || !tcanon_l || !packed_l || !fm_l || !p_in || !stats_l || !film_l || !workspace) return DPF_EINVAL;
-    if (B > 65535) return DPF_ENOSUP;
-    switch (t_ns(precision)) {
-        case 2: return prepare_layer<2>(B, N, ka, kb, tcanon_l, packed_l, fm_l, p_in, stats_l, film_l, flow_eps, workspace, (hipStream_t)stream);
-        case 3: return prepare_layer<3>(B, N, ka, kb, tcanon_l, packed_l, fm_l, p_in, stats_l, film_l, flow_eps, workspace, (hipStream_t)stream);
-        default: return DPF_ENOSUP;
+// Training-mode forward of an L-layer stack: per layer (in the order the mode prescribes) the batch statistics
+// and folds, then the layer itself through dpf_flow_forward(n_layers = 1).
+extern "C" int dpf_flow_train_forward(int n_layers, int B, int N, int mode, int precision, const int *meta_host,
+                                      const int *meta_dev, const float *tcanon, void *packed, const float *fm,
+                                      const float *p_in, float *ps, float *mus, float *logvars, float *stats, float *film,
+                                      float flow_eps, void *workspace, dpf_stream_t stream) {
+    if (n_layers <= 0 || B <= 0 || N <= 0 || !meta_host || !meta_dev || !tcanon || !packed || !fm || !p_in || !ps || !mus ||
+        !logvars || !stats || !film || !workspace)
+        return DPF_EINVAL;
+    if (mode != DPF_MODE_DIRECT && mode != DPF_MODE_INVERSE) return DPF_EINVAL;
+    const int ns = t_ns(precision);
+    if (!ns || B > 65535) return DPF_ENOSUP;
+    const size_t lst = (size_t)B * 3 * N, fls = dpf_flow_train_film_floats(B), fms = (size_t)4 * B * DPF_FLOW_F;
+    const float *cur = p_in;
+    for (int step = 0; step < n_layers; ++step) {
+        const int l = mode == DPF_MODE_DIRECT ? step : n_layers - 1 - step;
+        const int *m = meta_host + 4 * l;
+        uint8_t *pk = (uint8_t *)packed + (size_t)l * pt_bytes(ns);
+        float *film_l = film + l * fls;
+        int rc = ns == 2 ? prepare_layer<2>(B, N, m[0], m[1], tcanon + (size_t)l * T_LAYER, pk, fm + l * fms, cur,
+                                            stats + (size_t)l * ST_LAYER, film_l, flow_eps, workspace, (hipStream_t)stream)
+                         : prepare_layer<3>(B, N, m[0], m[1], tcanon + (size_t)l * T_LAYER, pk, fm + l * fms, cur,
+                                            stats + (size_t)l * ST_LAYER, film_l, flow_eps, workspace, (hipStream_t)stream);
+        if (rc) return rc;
+        rc = dpf_flow_forward(1, B, N, mode, precision, pk, meta_dev + 4 * l, film_l, cur, ps + l * lst, nullptr, nullptr,
+                              ps + l * lst, mus + l * lst, logvars + l * lst, flow_eps, stream);
+        if (rc) return rc;
+        cur = ps + l * lst;
     }
+    return 0;
 }
 
 template <int NS>
@@ -1013,32 +1033,45 @@ static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb
     hipLaunchKernelGGL(tfinish1_kernel, dim3(1), dim3(128), 0, s, B, count, w.pc, a.filmb_l, w.s12, dcanon_l);
     hipLaunchKernelGGL(tbwd2_kernel<NS>, grid, dim3(TW * 64), lds2, s, a, w.s12, w.dout, w.ubuf, w.part2);
     hipLaunchKernelGGL(tcolsum_kernel, dim3((2 * P2_J + 31) / 32), dim3(1024), 0, s, nblk, 2 * P2_J, w.part2, w.tot2);
-    hipLaunchKernelGGL(tfinish2_kernel, dim3(1), dim3(128), 0, s, count, w.tot2, tcanon_l, stats_l, dcanon_l, w.coef);
+    hipLaunchKernelGGL(tfinish2_kernel, dim3(1), dim3(128), 0, s, kb >= 0 ? 2 : 1, count, w.tot2, tcanon_l, stats_l, dcanon_l, w.coef);
     hipLaunchKernelGGL(tbwd3_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, N, ka, kb, p_in, w.ubuf, w.coef, dp_in);
     return (int)hipGetLastError();
 }
 
-// Backward of ONE layer.  The gradient w.r.t. the layer's p_out is g_p + g_p2 (g_p2 may be NULL: the chain
-// from the next layer plus the loss's own term); g_mu / g_lv: gradients w.r.t. mu / logvar (may be NULL).
-// dp_in (B,3,N), dcanon_l (T_LAYER) and dfm_l ([br][sub][B][64]) are fully overwritten.
-extern "C" int dpf_flow_train_backward_layer(int B, int N, int mode, int precision, int ka, int kb, int wa, int wb,
-                                             const float *tcanon_l, const void *packed_l, const float *film_l,
-                                             const float *stats_l, const float *p_in, const float *g_p, const float *g_p2,
-                                             const float *g_mu, const float *g_lv, float *dp_in, float *dcanon_l,
-                                             float *dfm_l, float flow_eps, void *workspace, dpf_stream_t stream) {
-    if (B <= 0 || N <= 0 || !tcanon_l || !packed_l || !film_l || !stats_l || !p_in || !g_p || !dp_in || !dcanon_l || !dfm_l ||
-        !workspace)
+// Backward of the stack, layers in the reverse of the forward order.  g_ps / g_mus / g_lvs: (L,B,3,N) gradients
+// w.r.t. the three output lists; the gradient that reaches layer l's p_out is g_ps[l] plus what the next layer
+// passes down.  dp_in (B,3,N), dcanon (L, T_LAYER) and dfm (L,[br][sub][B][64]) are fully overwritten; dp_tmp is a
+// (B,3,N) scratch buffer.
+extern "C" int dpf_flow_train_backward(int n_layers, int B, int N, int mode, int precision, const int *meta_host,
+                                       const float *tcanon, const void *packed, const float *film, const float *stats,
+                                       const float *p_in, const float *ps, const float *g_ps, const float *g_mus,
+                                       const float *g_lvs, float *dp_in, float *dp_tmp, float *dcanon, float *dfm,
+                                       float flow_eps, void *workspace, dpf_stream_t stream) {
+    if (n_layers <= 0 || B <= 0 || N <= 0 || !meta_host || !tcanon || !packed || !film || !stats || !p_in || !ps || !g_ps ||
+        !dp_in || !dp_tmp || !dcanon || !dfm || !workspace)
         return DPF_EINVAL;
-    if (B > 65535) return DPF_ENOSUP;
-#define DPF_BWD(NSV)                                                                                                          \
-    return backward_layer<NSV>(B, N, mode, ka, kb, wa, wb, tcanon_l, packed_l, film_l, stats_l, p_in, g_p, g_p2, g_mu, g_lv,  \
-                               dp_in, dcanon_l, dfm_l, flow_eps, workspace, (hipStream_t)stream);
-    switch (t_ns(precision)) {
-        case 2: DPF_BWD(2)
-        case 3: DPF_BWD(3)
-        default: return DPF_ENOSUP;
-    }
+    if (mode != DPF_MODE_DIRECT && mode != DPF_MODE_INVERSE) return DPF_EINVAL;
+    const int ns = t_ns(precision);
+    if (!ns || B > 65535) return DPF_ENOSUP;
+    const size_t lst = (size_t)B * 3 * N, fls = dpf_flow_train_film_floats(B), fms = (size_t)4 * B * DPF_FLOW_F;
+    const float *chain = nullptr;
+    for (int step = n_layers - 1; step >= 0; --step) {
+        const int l = mode == DPF_MODE_DIRECT ? step : n_layers - 1 - step;
+        const int lprev = mode == DPF_MODE_DIRECT ? step - 1 : n_layers - step;       // layer whose output fed layer l
+        const float *pin = step == 0 ? p_in : ps + lprev * lst;
+        float *out = (step & 1) ? dp_tmp : dp_in;                                      // step 0 writes dp_in
+        const int *m = meta_host + 4 * l;
+#define DPF_BWD(NSV)                                                                                                      \
+    backward_layer<NSV>(B, N, mode, m[0], m[1], m[2], m[3], tcanon + (size_t)l * T_LAYER,                               \
+                        (const uint8_t *)packed + (size_t)l * pt_bytes(NSV), film + l * fls, stats + (size_t)l * ST_LAYER, pin, \
+                        g_ps + l * lst, chain, g_mus ? g_mus + l * lst : nullptr, g_lvs ? g_lvs + l * lst : nullptr, out,      \
+                        dcanon + (size_t)l * T_LAYER, dfm + l * fms, flow_eps, workspace, (hipStream_t)stream)
+        const int rc = ns == 2 ? DPF_BWD(2) : DPF_BWD(3);
 #undef DPF_BWD
+        if (rc) return rc;
+        chain = out;
+    }
+    return 0;
 }
 
 #ifdef DPF_PROFILE

@@ -9,7 +9,7 @@ tensors runs the HIP training kernels for the whole stack as one autograd node
 (decoders.py:58-70) for CPU tensors / DPF_TRAIN_IMPL=torch."""
 import torch.nn as nn
 
-from .flows import CondRealNVPFlow3DTriple, _needs_autograd, use_hip_training
+from .flows import CondRealNVPFlow3DTriple, _needs_autograd, use_hip_training, train_stack
 from .flowlist import FlowList
 from .engine import FlowStack
 
@@ -66,11 +66,10 @@ class LocalCondRNVPDecoder(nn.Module):
         if mode not in ("direct", "inverse"):
             raise ValueError(mode)
         if use_hip_training(self, p):
-            from .train_engine import run_training_stack
             layers = self.coupling_layers()
             if n_layers is not None:
                 layers = layers[:int(n_layers)]
-            ps, mus, lvs = run_training_stack(layers, p, g, mode)
+            ps, mus, lvs = train_stack(self, layers, p, g, mode)
             return list(ps.unbind(0)), list(mus.unbind(0)), list(lvs.unbind(0))
         if self.training or _needs_autograd(p, g):
             if n_layers is not None:

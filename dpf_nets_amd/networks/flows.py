@@ -28,6 +28,17 @@ def use_hip_training(module, p):
     return module.training and p.is_cuda and TRAIN_IMPL == "hip"
 
 
+def train_stack(owner, layers, p, g, mode):
+    """Run `layers` (DIRECT order) through the HIP training path; the static layout description is
+    cached on `owner` per number of layers."""
+    from .train_engine import StackSpec, run_training_stack
+    cache = owner.__dict__.setdefault("_train_specs", {})
+    spec = cache.get(len(layers))
+    if spec is None:
+        spec = cache[len(layers)] = StackSpec(layers)
+    return run_training_stack(spec, p, g, mode)
+
+
 def _needs_autograd(*tensors):
     return torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
 
@@ -113,8 +124,7 @@ class CondRealNVPFlow3D(nn.Module):
         if mode not in ("direct", "inverse"):
             raise ValueError(mode)
         if use_hip_training(self, p):
-            from .train_engine import run_training_stack
-            ps, mus, lvs = run_training_stack([self], p, g, mode)
+            ps, mus, lvs = train_stack(self, [self], p, g, mode)
             return ps[0], mus[0], lvs[0]
         if self.training or _needs_autograd(p, g):
             return self.forward_torch(p, g, mode)
@@ -159,7 +169,6 @@ class CondRealNVPFlow3DTriple(nn.Module):
         if mode not in ("direct", "inverse"):
             raise ValueError(mode)
         if use_hip_training(self, p):                              # the three layers as one autograd node
-            from .train_engine import run_training_stack
-            ps, mus, lvs = run_training_stack(self.layers(), p, g, mode)
+            ps, mus, lvs = train_stack(self, self.layers(), p, g, mode)
             return list(ps.unbind(0)), list(mus.unbind(0)), list(lvs.unbind(0))
         return self._chain(p, g, mode, lambda lyr, pp, gg, mm: lyr(pp, gg, mode=mm))

