@@ -580,19 +580,26 @@ __global__ __launch_bounds__(520) void tcloudsum_kernel(int nb, int B, const flo
 
 // BN1 backward sums and the output SharedDot's parameter gradients from the per-cloud totals:
 //   s12[br][2][64] = (sum dh1n, sum dh1n*h1n) / P,  dh1n = a * dh2a;   dW2, db2 -> dcanon_l
-__global__ __launch_bounds__(128) void tfinish1_kernel(int B, double count, const float *__restrict__ pc,
-                                                       const float *__restrict__ filmb_l, float *__restrict__ s12,
-                                                       float *__restrict__ dcanon_l) {
-    const int br = threadIdx.x >> 6, f = threadIdx.x & 63;
+__global__ __launch_bounds__(1024) void tfinish1_kernel(int B, double count, const float *__restrict__ pc,
+                                                        const float *__restrict__ filmb_l, float *__restrict__ s12,
+                                                        float *__restrict__ dcanon_l) {
+    __shared__ double acc[8][5][128];
+    const int q = threadIdx.x & 127, grp = threadIdx.x >> 7, br = q >> 6, f = q & 63;
     double S1 = 0, S2 = 0, w2a = 0, w2b = 0, bb = 0;
-    for (int b = 0; b < B; ++b) {
-        const float *q = pc + (size_t)b * 520 + br * 256;
+    for (int b = grp; b < B; b += 8) {
+        const float *qq = pc + (size_t)b * 520 + br * 256;
         const double av = filmb_l[(size_t)b * FB_CLOUD + br * FB_BR + f];
-        S1 += av * q[3 * 64 + f];                                                // dh1n = a * dh2a
-        S2 += av * q[2 * 64 + f];                                                // dh1n * h1n
-        w2a += q[0 * 64 + f]; w2b += q[1 * 64 + f];
+        S1 += av * qq[3 * 64 + f];                                               // dh1n = a * dh2a
+        S2 += av * qq[2 * 64 + f];                                               // dh1n * h1n
+        w2a += qq[0 * 64 + f]; w2b += qq[1 * 64 + f];
         if (f < 2) bb += pc[(size_t)b * 520 + 512 + br * 2 + f];
     }
+    acc[grp][0][q] = S1; acc[grp][1][q] = S2; acc[grp][2][q] = w2a; acc[grp][3][q] = w2b; acc[grp][4][q] = bb;
+    __syncthreads();
+    if (grp != 0) return;
+    S1 = S2 = w2a = w2b = bb = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { S1 += acc[k][0][q]; S2 += acc[k][1][q]; w2a += acc[k][2][q]; w2b += acc[k][3][q]; bb += acc[k][4][q]; }
     s12[(br * 2 + 0) * 64 + f] = (float)(S1 / count);
     s12[(br * 2 + 1) * 64 + f] = (float)(S2 / count);
     dcanon_l[br * T_BR + T_W2 + f] = (float)w2a;
@@ -830,6 +837,12 @@ __global__ __launch_bounds__(128) void tfinish2_kernel(int nk, double count, con
                                                        const float *__restrict__ stats_l, float *__restrict__ dcanon_l,
                                                        float *__restrict__ coef) {
     __shared__ double acc[2][4][128];
+    if (blockIdx.x > 0) {                                                  // dW1: (2, 4096) totals -> dcanon
+        const int i = (blockIdx.x - 1) * 128 + threadIdx.x;                // 64 workgroups x 128
+        const int b2 = i >> 12, j = i & 4095;
+        dcanon_l[b2 * T_BR + T_W1 + j] = (float)tot[(size_t)b2 * P2_J + 128 + j];
+        return;
+    }
     const int br = threadIdx.x >> 6, f = threadIdx.x & 63;
     const double *t = tot + (size_t)br * P2_J;
     const float *cb = tcanon_l + br * T_BR;
@@ -869,8 +882,6 @@ __global__ __launch_bounds__(128) void tfinish2_kernel(int nk, double count, con
         coef[k * 4 + 1] = (float)acc[k][1][0];
         coef[k * 4 + 2] = (float)acc[k][2][0];
     }
-    // dW1 rows of this branch
-    for (int i = f; i < 4096; i += 64) dcanon_l[br * T_BR + T_W1 + i] = (float)t[128 + i];
 }
 
 // Pass 3: the conditioner path of d(input points), elementwise
@@ -1030,10 +1041,10 @@ static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb
     }
     hipLaunchKernelGGL(tbwd1_kernel<NS>, grid, dim3(TW * 64), lds1, s, a, g_p, g_p2, g_mu, g_lv, dp_in, w.dout, w.part1);
     hipLaunchKernelGGL(tcloudsum_kernel, dim3(B), dim3(520), 0, s, nb, B, w.part1, a.filmb_l, flow_eps, w.pc, dfm_l);
-    hipLaunchKernelGGL(tfinish1_kernel, dim3(1), dim3(128), 0, s, B, count, w.pc, a.filmb_l, w.s12, dcanon_l);
+    hipLaunchKernelGGL(tfinish1_kernel, dim3(1), dim3(1024), 0, s, B, count, w.pc, a.filmb_l, w.s12, dcanon_l);
     hipLaunchKernelGGL(tbwd2_kernel<NS>, grid, dim3(TW * 64), lds2, s, a, w.s12, w.dout, w.ubuf, w.part2);
     hipLaunchKernelGGL(tcolsum_kernel, dim3((2 * P2_J + 31) / 32), dim3(1024), 0, s, nblk, 2 * P2_J, w.part2, w.tot2);
-    hipLaunchKernelGGL(tfinish2_kernel, dim3(1), dim3(128), 0, s, kb >= 0 ? 2 : 1, count, w.tot2, tcanon_l, stats_l, dcanon_l, w.coef);
+    hipLaunchKernelGGL(tfinish2_kernel, dim3(65), dim3(128), 0, s, kb >= 0 ? 2 : 1, count, w.tot2, tcanon_l, stats_l, dcanon_l, w.coef);
     hipLaunchKernelGGL(tbwd3_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, N, ka, kb, p_in, w.ubuf, w.coef, dp_in);
     return (int)hipGetLastError();
 }
