@@ -63,6 +63,25 @@ __global__ void k(float *out, int iters, float seed, unsigned long long *ticks) 
                 acc4 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, ab, acc4, 0, 0, 0);
                 for (int i = 0; i < 8; ++i) a[i] = __builtin_fmaf(a[i], 1.0001f, 0.5f);
             }
+        } else if (KIND == 9) { // wave-specialised: waves 0-3 of each 8 do 16 MFMA, waves 4-7 do 128 fma
+            if (((threadIdx.x >> 6) >> 2) & 1) {
+                REP16(for (int i = 0; i < 8; ++i) a[i] = __builtin_fmaf(a[i], 1.0001f, 0.5f);)
+            } else {
+                for (int r = 0; r < 8; ++r) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, ab, acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, ab, acc2, 0, 0, 0);
+                }
+            }
+        } else if (KIND == 10) { // 16 MFMA (4 acc) then 128 fma, NOT interleaved in program order
+            for (int r = 0; r < 4; ++r) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, ab, acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, ab, acc2, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, ab, acc3, 0, 0, 0);
+                acc4 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, ab, acc4, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            REP16(for (int i = 0; i < 8; ++i) a[i] = __builtin_fmaf(a[i], 1.0001f, 0.5f);)
+            __builtin_amdgcn_sched_barrier(0);
         } else if (KIND == 5) { // v_perm + cvt_pk mix (128)
             REP16(for (int i = 0; i < 8; ++i) u[i] = __builtin_amdgcn_perm(u[i], u[(i + 1) & 7], 0x07060302u);)
         }
@@ -109,5 +128,7 @@ int main() {
     run<8>("mfma(4 acc) + 8 fma", 16 + 128);
     run<7>("xor+max_i32 only", 256);
     run<6>("mfma + 8x(xor,max)", 16 + 256);
+    run<9>("specialised waves (per pair: 16 mfma | 128 fma)", 72);
+    run<10>("16 mfma then 128 fma", 16 + 128);
     return 0;
 }
