@@ -120,8 +120,7 @@ def kernel_timings(dec, z, g, tgt_pm, L, precision):
     i1 = torch.empty((B, N), dtype=torch.int32, device=z.device); i2 = torch.empty_like(i1)
 
     impl = BK.NN_IMPL
-    sized, fn = {"mfma": (lib().dpf_nndistance_mfma_workspace_bytes, lib().dpf_nndistance_mfma),
-                 "sorted": (lib().dpf_nndistance_workspace_bytes, lib().dpf_nndistance_ws)}.get(impl, (None, None))
+    sized, fn = BK.nn_impl_entry(impl) if impl != "brute" else (None, None)
     nws = sized(B, N, N) if sized else 0
     ws = torch.empty((max(nws, 16),), dtype=torch.uint8, device=z.device)
 

@@ -17,8 +17,18 @@ from ..._lib import lib, check, current_stream
 #   "mfma"   matrix-core filter (one bf16 MFMA per 32x32 pairs) + exact verification of the few
 #            candidates that can win; r01: 35 + 10 us vs 50 us brute on cfg-2 -- not yet a clear win
 #   "sorted" x-sorted pruned exact scan (pays off only when both clouds cover the same region)
+#   "grid"   quantile 3-D grid in LDS, per-lane cell walk + exact bound (csrc/chamfer_grid.hip): 41 vs 53 us on
+#            uniform cubes, 2-5x SLOWER on surfaces / Gaussian blobs (measured numbers in the file header)
 NN_IMPL = os.environ.get("DPF_CHAMFER_IMPL", "brute")
 EMD_RMW = bool(int(os.environ.get("DPF_EMD_RMW", "0")))   # 1: the reference's per-level read-modify-write of `match`
+
+
+def nn_impl_entry(impl):
+    """(workspace_bytes, launcher) of a workspace-taking Chamfer implementation"""
+    L = lib()
+    return {"mfma": (L.dpf_nndistance_mfma_workspace_bytes, L.dpf_nndistance_mfma),
+            "sorted": (L.dpf_nndistance_workspace_bytes, L.dpf_nndistance_ws),
+            "grid": (L.dpf_nndistance_grid_workspace_bytes, L.dpf_nndistance_grid)}[impl]
 
 
 def _check_input(x, name, dtype=torch.float32):
@@ -53,8 +63,7 @@ def NNDistance(set_d, set_q):
         if NN_IMPL == "brute":
             check(lib().dpf_nndistance(*args, current_stream()), "nndistance")
         else:   # same bits; scratch is caller-owned like every other buffer
-            sized, fn = ((lib().dpf_nndistance_mfma_workspace_bytes, lib().dpf_nndistance_mfma) if NN_IMPL == "mfma"
-                         else (lib().dpf_nndistance_workspace_bytes, lib().dpf_nndistance_ws))
+            sized, fn = nn_impl_entry(NN_IMPL)
             nbytes = sized(b, n, m)
             ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
             check(fn(*args, ws.data_ptr(), nbytes, current_stream()), "nndistance_" + NN_IMPL)

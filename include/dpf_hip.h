@@ -71,6 +71,18 @@ int dpf_nndistance_mfma(int b, int n, const float *xyz, int m, const float *xyz2
                         float *result, int *result_i, float *result2, int *result2_i,
                         void *workspace, size_t workspace_bytes, dpf_stream_t stream);
 
+/* Same results as dpf_nndistance, bit for bit, evaluating only the candidates that
+ * can still win: both clouds are counting-sorted into a uniform G^3 grid
+ * (G ~ cbrt(n/4) <= 16) and each wave scans the cell rows of a growing box
+ * around its 64 spatially coherent queries until no unscanned point can be
+ * closer or tie (csrc/chamfer_grid.hip).  Data-dependent cost; degenerates to the
+ * full scan, never to a wrong answer.  NULL / short workspace or clouds of
+ * < 256 points -> dpf_nndistance. */
+size_t dpf_nndistance_grid_workspace_bytes(int b, int n, int m);
+int dpf_nndistance_grid(int b, int n, const float *xyz, int m, const float *xyz2,
+                        float *result, int *result_i, float *result2, int *result2_i,
+                        void *workspace, size_t workspace_bytes, dpf_stream_t stream);
+
 /* replaces nndistancegrad(...)  src/nndistance.cuh:2, nndistance.cu:149-154.
  * grad_xyz1 / grad_xyz2 are fully overwritten (the zero-fill happens on
  * `stream`, not on the null stream as at nndistance.cu:150-151). */
