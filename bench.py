@@ -275,7 +275,7 @@ def main():
                        "launch": "eager" if args.no_graph else "hipGraph replay", "parallelism": "clouds sharded, no collective"},
             "roofline": roof,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and n_gpus == 1:      # the CPU oracle is timed at N = 1 only
             line["cpu_baseline"] = cpu_baseline(args, state, n_flows, tgt)
         else:
             line["cpu_baseline"] = None
