@@ -413,8 +413,21 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
 
     const int lfirst = inverse ? L - 1 : 0;
     stage_layer<NS, FW>(a, lfirst, bi, smem, wave, lane);
-    // layer descriptors (keep/warp channels) ride one layer ahead in SGPRs
-    int ka = a.meta[lfirst * 4 + 0], kb = a.meta[lfirst * 4 + 1], wa = a.meta[lfirst * 4 + 2], wb = a.meta[lfirst * 4 + 3];
+    // Layer descriptors (keep/warp channels): lane l of every wave holds the rows of layers l and 64 + l, a
+    // layer's row comes out with v_readlane.  (Loading them inside the loop puts a vector-memory wait at the top of every
+    // layer, and vmcnt retires in order: it waited for the whole next-layer DMA issued just before -- r01
+    // profile: ~3000 of the 9700 cycles per layer.)
+    const int4 meta_lo = ((const int4 *)a.meta)[min(lane, L - 1)], meta_hi = ((const int4 *)a.meta)[min(64 + lane, L - 1)];
+    auto layer_meta = [&](int l, int &k0, int &k1, int &w0, int &w1) {      // L <= 128 (checked by the launcher)
+        const int s = l & 63;
+        const bool hi = l >= 64;
+        k0 = hi ? __builtin_amdgcn_readlane(meta_hi.x, s) : __builtin_amdgcn_readlane(meta_lo.x, s);
+        k1 = hi ? __builtin_amdgcn_readlane(meta_hi.y, s) : __builtin_amdgcn_readlane(meta_lo.y, s);
+        w0 = hi ? __builtin_amdgcn_readlane(meta_hi.z, s) : __builtin_amdgcn_readlane(meta_lo.z, s);
+        w1 = hi ? __builtin_amdgcn_readlane(meta_hi.w, s) : __builtin_amdgcn_readlane(meta_lo.w, s);
+    };
+    int ka, kb, wa, wb;
+    layer_meta(lfirst, ka, kb, wa, wb);
     __syncthreads();
 
     for (int step = 0; step < L; ++step) {
@@ -422,7 +435,8 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
         const int ln = inverse ? (li > 0 ? li - 1 : 0) : (li + 1 < L ? li + 1 : li);
         const uint8_t *lb = smem + (step & 1) * LBYTES;
         if (step + 1 < L) stage_layer<NS, FW>(a, ln, bi, smem + ((step + 1) & 1) * LBYTES, wave, lane);
-        const int nka = a.meta[ln * 4 + 0], nkb = a.meta[ln * 4 + 1], nwa = a.meta[ln * 4 + 2], nwb = a.meta[ln * 4 + 3];
+        int nka, nkb, nwa, nwb;
+        layer_meta(ln, nka, nkb, nwa, nwb);
         unsigned long long tt[8];
         DPF_T(0)
         // ---- B operand of the input MFMA: 3-way bf16 split of this half's input channel
@@ -560,7 +574,7 @@ extern "C" int dpf_flow_forward(int n_layers, int B, int N, int mode, int precis
     if (B == 0) return 0;
     if (!packed || !meta || !film || !p_in || !p_out) return DPF_EINVAL;
     if ((ps != nullptr) != (mus != nullptr) || (ps != nullptr) != (logvars != nullptr)) return DPF_EINVAL;
-    if (B > 65535) return DPF_ENOSUP;
+    if (B > 65535 || n_layers > 128) return DPF_ENOSUP;
     FlowArgs a;
     a.packed = (const uint8_t *)packed; a.meta = meta; a.film = film; a.p_in = p_in;
     a.p_out = p_out; a.p_out_pm = p_out_pointmajor; a.sum_lv = sum_logvar; a.ps = ps; a.mus = mus; a.lvs = logvars;

@@ -16,13 +16,14 @@ import bench  # noqa: E402
 
 
 def main():
-    sys.argv = ["bench.py"]
+    extra = sys.argv[1:]
+    sys.argv = ["bench.py"] + extra          # e.g. --batch 16: one wave per SIMD
     args = bench.parse()
     dev = torch.device("cuda", 0)
     handle = _lib.lib()
     handle.dpf_debug_set_prof.argtypes = [ctypes.c_void_p]
     FW = 8
-    for prec in ("bf16", "bf16x3", "bf16x6"):
+    for prec in ("bf16x3",):
         args.precision = prec
         L = args.layers
         dec, state, n_flows, z, g, tgt, tgt_pm = bench.build_workload(args, dev)
@@ -36,10 +37,12 @@ def main():
         handle.dpf_debug_set_prof(None)
         t = prof.cpu().numpy().astype(np.int64)
         d = np.diff(t[:, :, :7], axis=2)            # phases 0..5
-        names = ["A+B: input mfma + split br0", "C: chain br0 | split br1", "D: chain br1 | epi br0", "E: epi br1", "reduce+transform+stores", "barrier"]
+        # stamps 1 and 2 are taken inside branch_tile, which runs twice per layer: the second call (branch mu) overwrites them
+        names = ["branch 0 (all) + branch 1 input/split", "branch 1 chain", "branch 1 epilogue", "transform + list stores",
+                 "end-of-layer DMA wait + barrier", "-"]
         print("== %s: cycles per layer (median over waves/layers) | per-wave layer period" % prec)
         for i, nme in enumerate(names):
-            print("   %-14s median %7.0f  p90 %7.0f" % (nme, np.median(d[:, 1:, i]), np.percentile(d[:, 1:, i], 90)))
+            print("   %-38s median %7.0f  p90 %7.0f" % (nme, np.median(d[:, 1:, i]), np.percentile(d[:, 1:, i], 90)))
         period = np.diff(t[:, :, 0], axis=1)
         print("   layer period   median %7.0f  (total/layer incl. staging issue + B0 build)" % np.median(period))
         print("   wave0 first 3 layers raw deltas:", d[0, :3].tolist())
