@@ -28,6 +28,8 @@ SIGNATURES = {
     "dpf_approxmatch_workspace_bytes": (_sz, [_i, _i, _i]),
     "dpf_approxmatch_ws": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpf_matchcost": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "dpf_matchcostgrad_workspace_bytes": (_sz, [_i, _i, _i]),
+    "dpf_matchcostgrad_ws": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpf_matchcostgrad": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dpf_flow_canon_floats": (_sz, [_i]),
     "dpf_flow_packed_bytes": (_sz, [_i, _i, _i]),

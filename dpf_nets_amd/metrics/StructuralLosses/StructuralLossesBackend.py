@@ -20,6 +20,7 @@ from ..._lib import lib, check, current_stream
 #   "grid"   quantile 3-D grid in LDS, per-lane cell walk + exact bound (csrc/chamfer_grid.hip): 41 vs 53 us on
 #            uniform cubes, 2-5x SLOWER on surfaces / Gaussian blobs (measured numbers in the file header)
 NN_IMPL = os.environ.get("DPF_CHAMFER_IMPL", "brute")
+EMD_GRAD_TWO_PASS = bool(int(os.environ.get("DPF_EMD_GRAD_TWO_PASS", "0")))   # 1: separate grad1 / grad2 kernels
 EMD_RMW = bool(int(os.environ.get("DPF_EMD_RMW", "0")))   # 1: the reference's per-level read-modify-write of `match`
 
 
@@ -121,6 +122,13 @@ def MatchCostGrad(set_d, set_q, match):
     grad1 = torch.empty((b, n, 3), dtype=torch.float32, device=set_d.device)
     grad2 = torch.empty((b, m, 3), dtype=torch.float32, device=set_d.device)
     with torch.cuda.device(set_d.device):
-        check(lib().dpf_matchcostgrad(b, n, m, set_d.data_ptr(), set_q.data_ptr(), match.data_ptr(),
-                                      grad1.data_ptr(), grad2.data_ptr(), current_stream()), "matchcostgrad")
+        if EMD_GRAD_TWO_PASS:
+            check(lib().dpf_matchcostgrad(b, n, m, set_d.data_ptr(), set_q.data_ptr(), match.data_ptr(),
+                                          grad1.data_ptr(), grad2.data_ptr(), current_stream()), "matchcostgrad")
+        else:   # `match` read once; partial sums in caller-owned scratch
+            nbytes = lib().dpf_matchcostgrad_workspace_bytes(b, n, m)
+            ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=set_d.device)
+            check(lib().dpf_matchcostgrad_ws(b, n, m, set_d.data_ptr(), set_q.data_ptr(), match.data_ptr(),
+                                             grad1.data_ptr(), grad2.data_ptr(), ws.data_ptr(), nbytes,
+                                             current_stream()), "matchcostgrad_ws")
     return [grad1, grad2]

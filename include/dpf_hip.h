@@ -117,6 +117,15 @@ int dpf_matchcostgrad(int b, int n, int m, const float *xyz1, const float *xyz2,
                       const float *match, float *grad1, float *grad2,
                       dpf_stream_t stream);
 
+/* The same two gradients with `match` read ONCE instead of twice (one workgroup per
+ * 256 columns walks all rows; per-row lane sums by a halving butterfly; partials in
+ * `workspace`, added in a fixed order).  Deterministic; agrees with
+ * dpf_matchcostgrad to fp32 summation order.  NULL / short workspace -> that. */
+size_t dpf_matchcostgrad_workspace_bytes(int b, int n, int m);
+int dpf_matchcostgrad_ws(int b, int n, int m, const float *xyz1, const float *xyz2,
+                         const float *match, float *grad1, float *grad2,
+                         void *workspace, size_t workspace_bytes, dpf_stream_t stream);
+
 /* Chamfer caller reductions, lib/networks/evaluating.py:112:
  * cd[b] = mean_j dist1[b,j] + mean_k dist2[b,k]  (the reference then takes
  * .mean() over the batch).  Deterministic: one workgroup per cloud, fixed tree. */

@@ -77,3 +77,24 @@ def test_emd_full_size_invariants_and_autograd():
     assert torch.isfinite(ta.grad).all() and ta.grad.abs().sum() > 0
     same = emd_approx(tb, tb.clone())
     assert (same < 0.1 * emd.detach()).all()                   # a cloud matched with itself costs ~nothing
+
+
+def test_one_pass_gradients_match_two_pass():
+    """dpf_matchcostgrad_ws (match read once) vs dpf_matchcostgrad (two kernels): same sums in a different order."""
+    BK = _gpu()
+    for (B, n, m) in ((2, 64, 64), (3, 300, 257), (64, 1024, 500), (40, 2048, 700), (300, 200, 129)):
+        a, b = chamfer_inputs(900 + n, B, n, m)
+        ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+        match, _ = BK.ApproxMatch(ta, tb)
+        g1, g2 = BK.MatchCostGrad(ta, tb, match)
+        assert torch.equal(g1, BK.MatchCostGrad(ta, tb, match)[0])          # deterministic
+        BK.EMD_GRAD_TWO_PASS = True
+        try:
+            h1, h2 = BK.MatchCostGrad(ta, tb, match)
+        finally:
+            BK.EMD_GRAD_TWO_PASS = False
+        np.testing.assert_allclose(g1.cpu().numpy(), h1.cpu().numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(g2.cpu().numpy(), h2.cpu().numpy(), rtol=1e-4, atol=1e-5)
+        r1, r2 = S.matchcostgrad(a, b, match.cpu().numpy())
+        np.testing.assert_allclose(g1.cpu().numpy(), r1, rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(g2.cpu().numpy(), r2, rtol=1e-4, atol=1e-5)
