@@ -265,29 +265,26 @@ __global__ __launch_bounds__(256) void nn_grad_scatter_kernel(int b, int n, cons
 }
 
 // cd[b] = mean(dist1[b]) + mean(dist2[b])                          lib/networks/evaluating.py:112
-// one 1024-thread workgroup per cloud, every load of a cloud in flight at once, fixed-order tree
-__global__ __launch_bounds__(1024) void chamfer_reduce_kernel(int n, int m, const float *__restrict__ d1,
-                                                              const float *__restrict__ d2, float *__restrict__ cd) {
-    __shared__ float red[2][16];
+// one 256-thread workgroup per cloud, every load of a cloud in flight at once, fixed-order tree
+constexpr int RT = 256;
+__global__ __launch_bounds__(RT) void chamfer_reduce_kernel(int n, int m, const float *__restrict__ d1,
+                                                            const float *__restrict__ d2, float *__restrict__ cd) {
+    __shared__ float red[2][RT / 64];
     const int bi = blockIdx.x, tid = threadIdx.x;
     const float *a = d1 + (size_t)bi * n, *b = d2 + (size_t)bi * m;
     float s1 = 0.f, s2 = 0.f;
     if (((n | m) & 3) == 0) {
-        for (int j = tid * 4; j < n; j += 4096) { const float4 v = *(const float4 *)(a + j); s1 += (v.x + v.y) + (v.z + v.w); }
-        for (int j = tid * 4; j < m; j += 4096) { const float4 v = *(const float4 *)(b + j); s2 += (v.x + v.y) + (v.z + v.w); }
+        for (int j = tid * 4; j < n; j += 4 * RT) { const float4 v = *(const float4 *)(a + j); s1 += (v.x + v.y) + (v.z + v.w); }
+        for (int j = tid * 4; j < m; j += 4 * RT) { const float4 v = *(const float4 *)(b + j); s2 += (v.x + v.y) + (v.z + v.w); }
     } else {
-        for (int j = tid; j < n; j += 1024) s1 += a[j];
-        for (int j = tid; j < m; j += 1024) s2 += b[j];
+        for (int j = tid; j < n; j += RT) s1 += a[j];
+        for (int j = tid; j < m; j += RT) s2 += b[j];
     }
     for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
     if ((tid & 63) == 0) { red[0][tid >> 6] = s1; red[1][tid >> 6] = s2; }
     __syncthreads();
-    if (tid < 64) {
-        s1 = tid < 16 ? red[0][tid] : 0.f;
-        s2 = tid < 16 ? red[1][tid] : 0.f;
-        for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-        if (tid == 0) cd[bi] = s1 / (float)n + s2 / (float)m;
-    }
+    if (tid == 0)
+        cd[bi] = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)n + ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)m;
 }
 
 }  // namespace
@@ -297,7 +294,7 @@ extern "C" int dpf_chamfer_reduce(int b, int n, int m, const float *dist1, const
     if (b < 0 || n <= 0 || m <= 0) return DPF_EINVAL;
     if (b == 0) return 0;
     if (!dist1 || !dist2 || !cd) return DPF_EINVAL;
-    hipLaunchKernelGGL(chamfer_reduce_kernel, dim3(b), dim3(1024), 0, (hipStream_t)stream, n, m, dist1, dist2, cd);
+    hipLaunchKernelGGL(chamfer_reduce_kernel, dim3(b), dim3(RT), 0, (hipStream_t)stream, n, m, dist1, dist2, cd);
     return (int)hipGetLastError();
 }
 

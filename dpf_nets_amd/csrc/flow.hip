@@ -165,6 +165,10 @@ __global__ __launch_bounds__(512) void film_kernel(int L, int B, int G, const fl
         if (b0 + row < B) v = *(const f32x4 *)(g + (size_t)(b0 + row) * G + c4);
         *(f32x4 *)(gs + row * G + c4) = v;
     }
+    // every small per-feature constant is requested now: nothing below waits on a fresh global round trip
+    const float *cst = fw + (size_t)L * 4 * fw_sub_floats(G) + (size_t)(l * 2 + br) * 320;
+    const float bn_a = sc[f], bn_d = sh[f], bias1 = bf1[f];
+    const float s1 = cst[f], t1 = cst[64 + f], w2a = cst[128 + f], w2b = cst[192 + f], b2v = cst[256 + (f & 1)];
     float acc[FILM_CLOUDS];
 #pragma unroll
     for (int c = 0; c < FILM_CLOUDS; ++c) acc[c] = 0.f;
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(512) void film_kernel(int L, int B, int G, const fl
     for (int c = 0; c < FILM_CLOUDS; ++c) part[((sub * 4 + kq) * FILM_CLOUDS + c) * 64 + f] = acc[c];
     __syncthreads();
     {   // BatchNorm1d over the batch dim in eval mode (flows.py:35/42), then Swish (layers.py:9-10)
-        const float a = sc[f], d = sh[f];
+        const float a = bn_a, d = bn_d;
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
             const int c = kq * 2 + cc;
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(512) void film_kernel(int L, int B, int G, const fl
     __syncthreads();
     float v[2];
     {
-        const float bias = bf1[f];
+        const float bias = bias1;
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
             const int c = kq * 2 + cc;
@@ -237,8 +241,6 @@ __global__ __launch_bounds__(512) void film_kernel(int L, int B, int G, const fl
     if (sub == 1) return;
     // fold FiLM (flows.py:100-101) with BN1 (affine=False, :30/65) and the output SharedDot (:49/84):
     //   relu((eps+e^cw) * BN1(h1) + cb) = FA * relu(h1 + FC/FA),  FA = (eps+e^cw)/sqrt(rv1+eps_bn) > 0
-    const float *cst = fw + (size_t)L * 4 * fw_sub_floats(G) + (size_t)(l * 2 + br) * 320;
-    const float s1 = cst[f], t1 = cst[64 + f], w2a = cst[128 + f], w2b = cst[192 + f];
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
         const int c = kq * 2 + cc, b = b0 + c;
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(512) void film_kernel(int L, int B, int G, const fl
         o[f] = FC / FA;
         o[64 + 2 * f] = w2a * FA;
         o[64 + 2 * f + 1] = w2b * FA;
-        if (f < 2) film[((size_t)l * B + b) * (FILM_BYTES / 4) + FILM_B2_OFF + br * 2 + f] = cst[256 + f];
+        if (f < 2) film[((size_t)l * B + b) * (FILM_BYTES / 4) + FILM_B2_OFF + br * 2 + f] = b2v;
     }
 }
 
