@@ -249,8 +249,8 @@ __global__ __launch_bounds__(512) void film_kernel(int L, int B, int G, const fl
         const float FA = a * s1, FC = a * t1 + cbx[c * 64 + f];
         float *o = film + ((size_t)l * B + b) * (FILM_BYTES / 4) + br * FILM_BR_FLOATS;
         o[f] = FC / FA;
-        o[64 + 2 * f] = w2a * FA;
-        o[64 + 2 * f + 1] = w2b * FA;
+        o[64 + f] = w2a * FA;
+        o[128 + f] = w2b * FA;
         if (f < 2) film[((size_t)l * B + b) * (FILM_BYTES / 4) + FILM_B2_OFF + br * 2 + f] = b2v;
     }
 }
@@ -337,52 +337,53 @@ __device__ __forceinline__ void branch_tile(const uint8_t *lb, int br, int lane,
             acc1[tp][4 * q + 0] = dv.x; acc1[tp][4 * q + 1] = dv.y;
             acc1[tp][4 * q + 2] = dv.z; acc1[tp][4 * q + 3] = dv.w;
         }
-    constexpr int NB = TT::N * 2;                 // batches: (term, k-step pair)
-    u32x4 af[2][4];
-    auto load_batch = [&](int bt, u32x4 (&dst)[4]) {
-        const int term = bt >> 1, s0 = (bt & 1) * 2;
+    // One batch = the NS parts of both M tiles of ONE k-step (2*NS fragments); every fragment feeds all the
+    // product terms that use its part (bf16x3: the hi part twice) -- an LDS->VGPR fragment load costs the SIMD
+    // ~18 cycles next to the 32 of an MFMA (tools/ubench/lds_mfma.hip), so loads are not repeated per term.
+    // Batches run one ahead of the MFMAs that consume them.
+    u32x4 af[2][2 * NS];
+    auto load_batch = [&](int ks, u32x4 (&dst)[2 * NS]) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int s = s0 + (e >> 1), tp = e & 1;
-            dst[e] = *(const u32x4 *)(lb + TT::A[term] * P_A1_PART + (((br * 2 + tp) * 4 + s) * 64 + lane) * 16);
-        }
+        for (int part = 0; part < NS; ++part)
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp)
+                dst[part * 2 + tp] = *(const u32x4 *)(lb + part * P_A1_PART + (((br * 2 + tp) * 4 + ks) * 64 + lane) * 16);
     };
     load_batch(0, af[0]);
-    const float *wab = fl + 64;
-    f32x4 w01[2][4], w23[2][4];                    // epilogue weights, one M tile at a time
-    auto load_w = [&](int tp, f32x4 (&d01)[4], f32x4 (&d23)[4]) {
+    const float *wa = fl + 64, *wb2 = fl + 128;
+    f32x4 wva[2][4], wvb[2][4];                    // epilogue weights, one M tile at a time
+    auto load_w = [&](int tp, f32x4 (&da)[4], f32x4 (&db)[4]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int f0 = 32 * tp + 8 * q + 4 * h;
-            d01[q] = *(const f32x4 *)(wab + 2 * f0);
-            d23[q] = *(const f32x4 *)(wab + 2 * f0 + 4);
+            da[q] = *(const f32x4 *)(wa + f0);
+            if (TWO) db[q] = *(const f32x4 *)(wb2 + f0);
         }
     };
 #pragma unroll
-    for (int bt = 0; bt < NB; ++bt) {
-        if (bt + 1 < NB) load_batch(bt + 1, af[(bt + 1) & 1]);
-        else load_w(0, w01[0], w23[0]);            // rides under the last batch of MFMAs
+    for (int ks = 0; ks < 4; ++ks) {
+        if (ks + 1 < 4) load_batch(ks + 1, af[(ks + 1) & 1]);
+        else load_w(0, wva[0], wvb[0]);            // rides under the last batch of MFMAs
         __builtin_amdgcn_sched_barrier(0);
-        const int term = bt >> 1, s0 = (bt & 1) * 2;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int s = s0 + (e >> 1), tp = e & 1;
-            acc1[tp] = mfma(af[bt & 1][e], bfrag[TT::B[term]][s], acc1[tp]);
-        }
+        for (int term = 0; term < TT::N; ++term)
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp)
+                acc1[tp] = mfma(af[ks & 1][TT::A[term] * 2 + tp], bfrag[TT::B[term]][ks], acc1[tp]);
         __builtin_amdgcn_sched_barrier(0);
     }
     DPF_T(2)
     // ---- o = W2' relu(h1 + D): each lane reduces its 32 features
     oa = 0.f; ob = 0.f;
-    load_w(1, w01[1], w23[1]);
+    load_w(1, wva[1], wvb[1]);
 #pragma unroll
     for (int tp = 0; tp < 2; ++tp)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float v0 = relu(acc1[tp][4 * q + 0]), v1 = relu(acc1[tp][4 * q + 1]);
             const float v2 = relu(acc1[tp][4 * q + 2]), v3 = relu(acc1[tp][4 * q + 3]);
-            oa += w01[tp][q].x * v0; oa += w01[tp][q].z * v1; oa += w23[tp][q].x * v2; oa += w23[tp][q].z * v3;
-            if (TWO) { ob += w01[tp][q].y * v0; ob += w01[tp][q].w * v1; ob += w23[tp][q].y * v2; ob += w23[tp][q].w * v3; }
+            oa += wva[tp][q].x * v0; oa += wva[tp][q].y * v1; oa += wva[tp][q].z * v2; oa += wva[tp][q].w * v3;
+            if (TWO) { ob += wvb[tp][q].x * v0; ob += wvb[tp][q].y * v1; ob += wvb[tp][q].z * v2; ob += wvb[tp][q].w * v3; }
         }
 }
 

@@ -23,7 +23,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int P_A1_PART = 16384;                       // [br2][t2][s4][lane64][8 bf16]
 __host__ __device__ constexpr int p_a0_off(int NS) { return NS * P_A1_PART; }            // [br2][t2][lane64][8 bf16]
 __host__ __device__ constexpr int p_layer_bytes(int NS) { return NS * P_A1_PART + 4096; }
-constexpr int FILM_BYTES = 2048;                       // per (layer, cloud): [br2]{D[64], Wab[64][2]}, b2[br2][2], pad
+constexpr int FILM_BYTES = 2048;                       // per (layer, cloud): [br2]{D[64], Wa[64], Wb[64]}, b2[br2][2], pad
 constexpr int FILM_BR_FLOATS = 192;
 constexpr int FILM_B2_OFF = 384;                       // floats
 

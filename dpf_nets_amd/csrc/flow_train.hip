@@ -246,21 +246,25 @@ __device__ __forceinline__ void split_fragment(const f32x16 (&v)[2], u32x4 (&bf)
         }
 }
 
-// acc[tp] += A1[br] . B  with the split terms of Terms<NS>; a1 = base of [part][br][tp][s][lane]
+// acc[tp] += A1[br] . B  with the split terms of Terms<NS>; a1 = base of [part][br][tp][s][lane].  Same order as
+// branch_tile in csrc/flow.hip (k-step major; the fragment of each part is loaded once and feeds every term that
+// uses it): the recomputed pre-activations are bit-identical to the forward kernel's.
 template <int NS>
 __device__ __forceinline__ void chain_mfma(const uint8_t *a1, int br, int lane, const u32x4 (&bf)[NS][4], f32x16 (&acc)[2]) {
     using TT = Terms<NS>;
 #pragma unroll
-    for (int term = 0; term < TT::N; ++term)
+    for (int s = 0; s < 4; ++s) {
+        u32x4 af[NS][2];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            u32x4 af[2];
+        for (int part = 0; part < NS; ++part)
 #pragma unroll
             for (int tp = 0; tp < 2; ++tp)
-                af[tp] = *(const u32x4 *)(a1 + TT::A[term] * P_A1_PART + (((br * 2 + tp) * 4 + s) * 64 + lane) * 16);
+                af[part][tp] = *(const u32x4 *)(a1 + part * P_A1_PART + (((br * 2 + tp) * 4 + s) * 64 + lane) * 16);
 #pragma unroll
-            for (int tp = 0; tp < 2; ++tp) acc[tp] = mfma(af[tp], bf[TT::B[term]][s], acc[tp]);
-        }
+        for (int term = 0; term < TT::N; ++term)
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp) acc[tp] = mfma(af[TT::A[term]][tp], bf[TT::B[term]][s], acc[tp]);
+    }
 }
 
 // per-lane vector of a per-feature LDS array for the features this lane holds: out[t][r]
@@ -394,8 +398,8 @@ __global__ __launch_bounds__(128) void tfilm_fold_kernel(double count, const dou
     const float *cbp = tcanon_l + br * T_BR;
     float *o = film_l + (size_t)b * (FILM_BYTES / 4) + br * FILM_BR_FLOATS;
     o[f] = FC / FA;
-    o[64 + 2 * f] = cbp[T_W2 + f] * FA;
-    o[64 + 2 * f + 1] = cbp[T_W2 + 64 + f] * FA;
+    o[64 + f] = cbp[T_W2 + f] * FA;
+    o[128 + f] = cbp[T_W2 + 64 + f] * FA;
     if (f < 2) film_l[(size_t)b * (FILM_BYTES / 4) + FILM_B2_OFF + br * 2 + f] = cbp[T_B2 + f];
     float *ob = filmb_l + (size_t)b * FB_CLOUD + br * FB_BR;
     ob[0 * 64 + f] = av;
@@ -471,14 +475,14 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
         load_features(film + br * FILM_BR_FLOATS, h, pre[br]);             // accumulator starts at D
         chain_mfma<NS>(smem + L_PACK + PT_A1, br, lane, bf, pre[br]);
         float oa = 0.f, ob = 0.f;
-        const float *wab = film + br * FILM_BR_FLOATS + 64 + 2 * h4;       // lane base; feature offsets are immediates
+        const float *wab = film + br * FILM_BR_FLOATS + 64 + h4;           // lane base; feature offsets are immediates
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int F0 = acc_feature(t, r, 0);
                 const float v = relu(pre[br][t][r]);
-                oa += wab[2 * F0] * v; ob += wab[2 * F0 + 1] * v;
+                oa += wab[F0] * v; ob += wab[64 + F0] * v;
             }
         oa += __shfl_xor(oa, 32); ob += __shfl_xor(ob, 32);
         o[br][0] = oa + film[FILM_B2_OFF + br * 2 + 0];
