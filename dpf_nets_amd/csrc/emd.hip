@@ -80,6 +80,15 @@ __device__ __forceinline__ void stream_candidates(const float *__restrict__ Q, c
     }
 }
 
+// Variant for kernels with no per-candidate weights: the wave-uniform candidates come through SCALAR loads
+// (s_load -> SGPR operands), no v_readlane.  Measured r01: emd_grad1_kernel 2x faster with it, the ratio / match
+// kernels (which also broadcast a weight per candidate and run at 8 waves/SIMD) 5 % slower.
+template <class F>
+__device__ __forceinline__ void stream_candidates_scalar(const float *__restrict__ Q, int jb, int je, F &&f) {
+#pragma unroll 8
+    for (int j = jb; j < je; ++j) f(j, Q[j * 3 + 0], Q[j * 3 + 1], Q[j * 3 + 2]);
+}
+
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // remainL = multiL, remainR = multiR                       approxmatch.cu:6-12,18-21
@@ -256,8 +265,7 @@ __global__ __launch_bounds__(1024) void emd_grad1_kernel(int n, int m, const flo
     const float px = P[kc * 3 + 0], py = P[kc * 3 + 1], pz = P[kc * 3 + 2];
     const int lb = (int)((long)m * slice / S), le = (int)((long)m * (slice + 1) / S);
     float gx = 0.f, gy = 0.f, gz = 0.f;
-    const float *const nowl[1] = {nullptr};
-    stream_candidates<0>(Q, nowl, lb, le, lane, [&](int l, float qx, float qy, float qz, const float (&)[1]) {
+    stream_candidates_scalar(Q, lb, le, [&](int l, float qx, float qy, float qz) {
         const float dx = px - qx, dy = py - qy, dz = pz - qz;
         const float d = mt[(size_t)l * n + kc] * rsqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-20f));
         gx += dx * d; gy += dy * d; gz += dz * d;
@@ -494,8 +502,9 @@ extern "C" int dpf_matchcostgrad_ws(int b, int n, int m, const float *xyz1, cons
     if (b > 65535) return DPF_ENOSUP;
     const int nkb = (n + 255) / 256;
     // one workgroup per 256 columns and cloud: with fewer than one per CU the row-parallel two-pass kernels win
-    // (measured r01: B=2, N=8192: 1.39 ms vs 0.58 ms; B=16: 1.53 vs 4.76 ms; B=32, N=2048: 0.37 vs 0.60 ms)
-    if (!workspace || workspace_bytes < dpf_matchcostgrad_workspace_bytes(b, n, m) || (long)b * nkb < 256)
+    // (measured r01, one pass vs two kernels: B=2, N=8192: 0.58 vs 0.29 ms; B=32, N=2048: 0.37 vs 0.30 ms;
+    // B=16, N=8192: 1.52 vs 2.26 ms)
+    if (!workspace || workspace_bytes < dpf_matchcostgrad_workspace_bytes(b, n, m) || (long)b * nkb < 512)
         return dpf_matchcostgrad(b, n, m, xyz1, xyz2, match, grad1, grad2, stream);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(emd_grad_fused_kernel, dim3(nkb, b), dim3(256), 0, s, n, m, xyz1, xyz2, match, grad1, (float *)workspace);
