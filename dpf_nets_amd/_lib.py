@@ -21,6 +21,8 @@ SIGNATURES = {
     "dpf_nndistance_ws": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpf_nndistance_mfma_workspace_bytes": (_sz, [_i, _i, _i]),
     "dpf_nndistance_mfma": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dpf_nndistance_sym_workspace_bytes": (_sz, [_i, _i, _i]),
+    "dpf_nndistance_sym": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpf_nndistance_grid_workspace_bytes": (_sz, [_i, _i, _i]),
     "dpf_nndistance_grid": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpf_nndistancegrad": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -71,6 +71,17 @@ int dpf_nndistance_mfma(int b, int n, const float *xyz, int m, const float *xyz2
                         float *result, int *result_i, float *result2, int *result2_i,
                         void *workspace, size_t workspace_bytes, dpf_stream_t stream);
 
+/* Same results as dpf_nndistance, bit for bit, from ONE evaluation of every pair:
+ * (b - a) and (a - b) square to the same bits, so the row minima (direction 1) and
+ * the column minima (direction 2) come out of the same pass (csrc/chamfer_sym.hip).
+ * cd (optional, may be NULL): b floats, mean(dist1[b]) + mean(dist2[b]) as
+ * dpf_chamfer_reduce computes it (evaluating.py:112), emitted by the merge launch.
+ * NULL / short workspace -> dpf_nndistance (+ dpf_chamfer_reduce). */
+size_t dpf_nndistance_sym_workspace_bytes(int b, int n, int m);
+int dpf_nndistance_sym(int b, int n, const float *xyz, int m, const float *xyz2,
+                       float *result, int *result_i, float *result2, int *result2_i,
+                       float *cd, void *workspace, size_t workspace_bytes, dpf_stream_t stream);
+
 /* Same results as dpf_nndistance, bit for bit, evaluating only the candidates that
  * can still win: both clouds are counting-sorted into a uniform G^3 grid
  * (G ~ cbrt(n/4) <= 16) and each wave scans the cell rows of a growing box

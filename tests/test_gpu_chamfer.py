@@ -19,7 +19,7 @@ def _gpu():
     return BK
 
 
-IMPLS = ["mfma", "brute", "sorted", "grid"]
+IMPLS = ["mfma", "brute", "sorted", "grid", "sym"]
 
 
 def _run(BK, a, b, impl=None):
@@ -58,7 +58,7 @@ def test_nndistance_bit_exact_vs_oracle(shape, impl):
     _assert_bit_exact(_run(BK, a, b, impl), S.nndistance(a, b), shape)
 
 
-@pytest.mark.parametrize("impl", ["mfma", "sorted", "grid"])
+@pytest.mark.parametrize("impl", ["mfma", "sorted", "grid", "sym"])
 @pytest.mark.parametrize("kind", ["same_x", "two_planes", "line", "clustered", "surface", "far_offset", "all_equal",
                                   "big_coords"])
 def test_pruned_search_adversarial_distributions(kind, impl):
