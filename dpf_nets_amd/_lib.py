@@ -73,6 +73,10 @@ def lib():
             raise RuntimeError(
                 "dpf_nets_amd: %s is missing -- the HIP kernels are not built. "
                 "Run __graft_entry__.build() or `make -C dpf_nets_amd/csrc`. There is no CPU fallback." % path)
+        # PyTorch-ROCm ships its own copy of the HIP runtime (torch/lib/libamdhip64.so, same soname as
+        # /opt/rocm's).  It must be the one resident when libdpf_hip.so is loaded, or the process ends up with
+        # two runtimes and every launch on torch's streams fails with hipErrorNoDevice: import torch first.
+        import torch  # noqa: F401
         handle = ctypes.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)          # AttributeError if the symbol is not exported
