@@ -158,3 +158,32 @@ def test_canonical_block_layout():
         assert torch.equal(flat[4740:4740 + 64 * G].view(64, G), mod.T_logvar_0_cond_w[0].weight)
         m = layer_meta(mod)
         assert m[:2] == ([c for c in range(3) if c not in warp] + [-1])[:2] and m[2:] == (warp + [-1])[:2]
+
+
+def test_training_stack_spec_layout_matches_c_abi():
+    """The (L, 8968) parameter block the training C ABI takes is ONE concatenation of the parameters as stored
+    (+ zero pads): check every offset of include/dpf_hip.h against a hand-built block, for both warp patterns."""
+    from dpf_nets_amd.networks import LocalCondRNVPDecoder
+    from dpf_nets_amd.networks.train_engine import StackSpec
+    torch.manual_seed(3)
+    dec = LocalCondRNVPDecoder(2, 64, 128)            # pattern 0 (1 warp channel) and pattern 1 (2 warp channels)
+    layers = dec.coupling_layers()
+    spec = StackSpec(layers)
+    cp = spec.canon_params()
+    zeros = torch.zeros(64)
+    block = torch.cat([cp[i].reshape(-1) if kind == "p" else zeros[:i] for kind, i in spec.cat_plan]).view(spec.L, 8968)
+    assert len(spec.all_params()) == 32 * spec.L and spec.all_params()[0] is layers[0].T_logvar_0[0].weight
+    for li, lyr in enumerate(layers):
+        nk, nw = len(lyr.keep_inds), len(lyr.warp_inds)
+        assert spec.metas[li] == tuple(list(lyr.keep_inds) + [-1] * (2 - nk) + list(lyr.warp_inds) + [-1] * (2 - nw))
+        for bi, br in enumerate(("logvar", "mu")):
+            row = block[li, bi * 4484:(bi + 1) * 4484]
+            t0, sd2 = getattr(lyr, "T_%s_0" % br), getattr(lyr, "T_%s_1" % br)[1]
+            assert torch.equal(row[0:64 * nk], t0[0].weight.reshape(-1)) and float(row[64 * nk:128].abs().max() if nk < 2 else 0) == 0
+            assert torch.equal(row[128:192], t0[1].weight) and torch.equal(row[192:256], t0[1].bias)
+            assert torch.equal(row[256:4352], t0[3].weight.reshape(-1))
+            assert torch.equal(row[4352:4352 + 64 * nw], sd2.weight.reshape(-1))
+            assert torch.equal(row[4480:4480 + nw], sd2.bias.reshape(-1)) and float(row[4480 + nw:4484].abs().max()) == 0
+    # gradient slices map back one-to-one
+    covered = sum(n for _, n in spec.canon_slots)
+    assert covered == sum(p.numel() for p in cp)
