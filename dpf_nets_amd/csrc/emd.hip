@@ -14,6 +14,8 @@
 // object: pass 3 read-modify-writes it once per level (the first level writes
 // without reading, which replaces the reference's zero-fill, approxmatch.cu:16-17).
 #include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
 
 #include "dpf_hip.h"
 
@@ -90,6 +92,112 @@ __device__ __forceinline__ void stream_candidates_scalar(const float *__restrict
 }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// ---- deferred path: two points per lane, packed fp32 math, candidates as SGPR operands ----------------------
+// Measured on gfx950 (tools/ubench/valu_rate.hip): a VALU instruction with an SGPR source issues at ~1.7 ns per
+// wave (vs 1.0 ns for fp32 add/mul/fma on VGPRs only), v_readlane 1.75 ns, v_exp_f32 3.5 ns -- and a packed-f32
+// instruction also 1.75 ns, SGPR source or not.  With ONE point per lane and the wave-uniform candidate in SGPRs a
+// ratio step is 5 SGPR-source ops + 3 plain + exp = 16.8 ns per 64 pairs (measured, = the kernel's rate).  With TWO
+// points per lane the same step is 8 v_pk_* + 2 exp = 21 ns per 128 pairs.  The candidates are (x, y, z, weight)
+// records read by scalar loads as 64-bit pairs (x,y), (z,w); op_sel broadcasts one half of a pair to both packed
+// lanes, so there is no SGPR->VGPR copy at all.  Every arithmetic step is the same IEEE operation as in the
+// one-point kernels (v_pk_fma = fma per element), so the two paths stay bit-identical.
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef unsigned long long u64;
+
+template <int HALF>
+__device__ __forceinline__ f2 bsub(u64 pr, f2 q) {   // {s,s} - q,  s = HALF-th float of the SGPR pair
+    f2 r;
+    if constexpr (HALF == 0)
+        asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "s"(pr), "v"(q));
+    else
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "s"(pr), "v"(q));
+    return r;
+}
+template <int HALF>
+__device__ __forceinline__ f2 bmul(u64 pr, f2 v) {   // {s,s} * v
+    f2 r;
+    if constexpr (HALF == 0)
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "s"(pr), "v"(v));
+    else
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "s"(pr), "v"(v));
+    return r;
+}
+__device__ __forceinline__ f2 bfma_hi(u64 pr, f2 e, f2 acc) {   // fma({s.hi,s.hi}, e, acc)
+    f2 r;
+    // `e` comes straight from v_exp_f32: a transcendental result needs one wait state before a VALU use, and the
+    // compiler's hazard recogniser does not look into inline asm (without the s_nop the second packed lane read a
+    // stale register)
+    asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0]" : "=v"(r) : "s"(pr), "v"(e), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 exp2_2(f2 x) { return f2{fast_exp2(x.x), fast_exp2(x.y)}; }
+// |{q,q} - p|^2 with sqdist's association; q = (xy.lo, xy.hi, zw.lo)
+__device__ __forceinline__ f2 sqdist2(f2 px, f2 py, f2 pz, u64 xy, u64 zw) {
+    const f2 dx = bsub<0>(xy, px), dy = bsub<1>(xy, py), dz = bsub<0>(zw, pz);
+    return fma2(dz, dz, fma2(dy, dy, dx * dx));
+}
+
+// Stream records of NP 64-bit pairs each, [jb, je) of C, through scalar loads: chunks of CHK records ping-pong
+// between two SGPR sets; scalar loads return out of order (any use waits for ALL outstanding ones), so the next
+// chunk is requested right after the first use of the current one and has the rest of it to land.
+template <int NP, int CHK, class F>
+__device__ __forceinline__ void stream_records(const u64 *__restrict__ C, int jb, int je, F &&f) {
+    constexpr int W = NP * CHK;
+    int j = jb;
+    const int nfull = (je - jb) / CHK;
+    auto use = [&](const u64 (&buf)[W], int jj, int u) { f(jj + u, &buf[u * NP]); };
+    if (nfull > 0) {
+        const int jlast = jb + (nfull - 1) * CHK;
+        u64 bufA[W], bufB[W];
+#define RC_LOAD(buf, jj)                                                                   \
+        {                                                                                  \
+            const u64 *__restrict__ cp_ = C + (size_t)(jj) * NP;   /* wave-uniform */      \
+            _Pragma("unroll") for (int u = 0; u < W; ++u) buf[u] = cp_[u];                 \
+        }
+#define RC_REST(buf, jj) _Pragma("unroll") for (int u = 1; u < CHK; ++u) use(buf, jj, u);
+        RC_LOAD(bufA, j);
+        int it = 0;
+        for (; it + 2 <= nfull; it += 2, j += 2 * CHK) {
+            use(bufA, j, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            RC_LOAD(bufB, j + CHK);
+            __builtin_amdgcn_sched_barrier(0);
+            RC_REST(bufA, j)
+            __builtin_amdgcn_sched_barrier(0);
+            use(bufB, j + CHK, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            RC_LOAD(bufA, min(j + 2 * CHK, jlast));
+            __builtin_amdgcn_sched_barrier(0);
+            RC_REST(bufB, j + CHK)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (it < nfull) {
+            use(bufA, j, 0);
+            RC_REST(bufA, j)
+            j += CHK;
+        }
+#undef RC_REST
+#undef RC_LOAD
+    }
+    for (; j < je; ++j) {
+        u64 one[NP];
+#pragma unroll
+        for (int u = 0; u < NP; ++u) one[u] = C[(size_t)j * NP + u];
+        f(j, &one[0]);
+    }
+}
+
+constexpr int PPW = 128;   // points per wave in the deferred kernels
+
+// (xyz2, multiR) records for the first ratio pass
+__global__ void emd_pack_init_kernel(int m, float multiR, const float *__restrict__ xyz2, float4 *__restrict__ c2a, size_t pstride) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const float *q = xyz2 + ((size_t)blockIdx.y * m + j) * 3;
+    c2a[(size_t)blockIdx.y * pstride + j] = make_float4(q[0], q[1], q[2], multiR);
+}
 
 // remainL = multiL, remainR = multiR                       approxmatch.cu:6-12,18-21
 __global__ void emd_init_kernel(int n, int m, float multiL, float multiR, float *__restrict__ temp) {
@@ -192,36 +300,146 @@ __global__ __launch_bounds__(1024) void emd_match_kernel(int n, int m, float lvl
 constexpr int NLEVEL = 9;
 struct Levels { float lvl2[NLEVEL]; };
 
-__global__ __launch_bounds__(1024) void emd_materialize_kernel(int n, int m, Levels lv, const float *__restrict__ xyz1,
-                                                               const float *__restrict__ xyz2,
-                                                               float *__restrict__ match, const float *__restrict__ ws,
-                                                               size_t lstride, size_t rstride) {
+// ---- the deferred path's kernels (two points per lane; see the note above bsub) -------------------------------
+// Packed records per cloud, pk + bi*pstride float4's: [C1 (n) | C2a (m) | C2b (m)] =
+// (xyz1, ratioL) | (xyz2, remainR) | (xyz2, ratioR); each pass writes the record the next pass streams.
+// Same slices and the same per-lane candidate order as emd_ratio_kernel / emd_match_kernel => same bits.
+template <int PASS>
+__global__ __launch_bounds__(1024) void emd_ratio2_kernel(int n, int m, float lvl2, const float *__restrict__ xyz1,
+                                                          const float *__restrict__ xyz2, float *temp, float *rbase,
+                                                          size_t rstride, float4 *pk, size_t pstride) {
+    __shared__ float part[MAXS][PPW];
+    const int bi = blockIdx.y;
+    const int lane = threadIdx.x, slice = __builtin_amdgcn_readfirstlane(threadIdx.y), S = blockDim.y;
+    float *t = temp + (size_t)bi * (n + m) * 2;
+    float *remainL = t, *remainR = t + n, *ratioL = rbase + (size_t)bi * rstride, *ratioR = ratioL + n;
+    const int np = PASS == 1 ? n : m, nq = PASS == 1 ? m : n;
+    const float *__restrict__ P = (PASS == 1 ? xyz1 + (size_t)bi * n * 3 : xyz2 + (size_t)bi * m * 3);
+    float4 *c1 = pk + (size_t)bi * pstride, *c2a = c1 + n, *c2b = c2a + m;
+    const int i0 = blockIdx.x * PPW + lane, i1 = i0 + 64;
+    const int a0 = min(i0, np - 1), a1 = min(i1, np - 1);
+    const f2 px = {P[a0 * 3 + 0], P[a1 * 3 + 0]}, py = {P[a0 * 3 + 1], P[a1 * 3 + 1]}, pz = {P[a0 * 3 + 2], P[a1 * 3 + 2]};
+    const int jb = (int)((long)nq * slice / S), je = (int)((long)nq * (slice + 1) / S);
+    const u64 lv = ((u64)__float_as_uint(lvl2) << 32) | __float_as_uint(lvl2);
+    f2 s = {0.f, 0.f};
+    stream_records<2, 8>((const u64 *)(PASS == 1 ? c2a : c1), jb, je, [&](int, const u64 *r) {
+        const f2 e = exp2_2(bmul<0>(lv, sqdist2(px, py, pz, r[0], r[1])));
+        s = bfma_hi(r[1], e, s);
+    });
+    part[slice][lane] = s.x;
+    part[slice][lane + 64] = s.y;
+    __syncthreads();
+    if (slice != 0) return;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int i = h ? i1 : i0;
+        if (i >= np) continue;
+        const float qx = h ? px.y : px.x, qy = h ? py.y : py.x, qz = h ? pz.y : pz.x;
+        float tot = PASS == 1 ? 1e-9f : 0.f;
+        for (int u = 0; u < S; ++u) tot += part[u][lane + 64 * h];
+        if (PASS == 1) {
+            const float r = remainL[i] / tot;
+            ratioL[i] = r;
+            c1[i] = make_float4(qx, qy, qz, r);
+        } else {
+            const float rr = remainR[i];
+            const float sumr = tot * rr;
+            const float consumption = fminf(rr / (sumr + 1e-9f), 1.0f);
+            const float r = consumption * rr, rem = fmaxf(0.0f, rr - sumr);
+            ratioR[i] = r;
+            remainR[i] = rem;
+            c2b[i] = make_float4(qx, qy, qz, r);
+            c2a[i] = make_float4(qx, qy, qz, rem);
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void emd_match2_kernel(int n, int m, float lvl2, const float *__restrict__ xyz1,
+                                                          float *temp, const float *rbase, size_t rstride,
+                                                          const float4 *pk, size_t pstride) {
+    __shared__ float part[MAXS][PPW];
+    const int bi = blockIdx.y;
+    const int lane = threadIdx.x, slice = __builtin_amdgcn_readfirstlane(threadIdx.y), S = blockDim.y;
+    float *remainL = temp + (size_t)bi * (n + m) * 2;
+    const float *__restrict__ ratioL = rbase + (size_t)bi * rstride;
+    const float *__restrict__ P = xyz1 + (size_t)bi * n * 3;
+    const int k0 = blockIdx.x * PPW + lane, k1 = k0 + 64;
+    const int a0 = min(k0, n - 1), a1 = min(k1, n - 1);
+    const f2 px = {P[a0 * 3 + 0], P[a1 * 3 + 0]}, py = {P[a0 * 3 + 1], P[a1 * 3 + 1]}, pz = {P[a0 * 3 + 2], P[a1 * 3 + 2]};
+    const f2 rl = {ratioL[a0], ratioL[a1]};
+    const int lb = (int)((long)m * slice / S), le = (int)((long)m * (slice + 1) / S);
+    const u64 lv = ((u64)__float_as_uint(lvl2) << 32) | __float_as_uint(lvl2);
+    f2 suml = {0.f, 0.f};
+    stream_records<2, 8>((const u64 *)(pk + (size_t)bi * pstride + n + m), lb, le, [&](int, const u64 *r) {
+        const f2 e = exp2_2(bmul<0>(lv, sqdist2(px, py, pz, r[0], r[1])));
+        suml = suml + bmul<1>(r[1], e * rl);
+    });
+    part[slice][lane] = suml.x;
+    part[slice][lane + 64] = suml.y;
+    __syncthreads();
+    if (slice != 0) return;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int k = h ? k1 : k0;
+        if (k >= n) continue;
+        float tot = 0.f;
+        for (int u = 0; u < S; ++u) tot += part[u][lane + 64 * h];
+        remainL[k] = fmaxf(0.0f, remainL[k] - tot);
+    }
+}
+
+// (xyz2_l, ratioR_level0..8[l]) records of 12 floats for the materialisation
+__global__ void emd_pack_levels_kernel(int n, int m, const float *__restrict__ xyz2, const float *__restrict__ ws,
+                                       size_t lstride, size_t rstride, float *__restrict__ rec) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= m) return;
+    const int bi = blockIdx.y;
+    const float *q = xyz2 + ((size_t)bi * m + l) * 3;
+    float4 *o = (float4 *)(rec + ((size_t)bi * m + l) * 12);
+    float w[NLEVEL];
+#pragma unroll
+    for (int j = 0; j < NLEVEL; ++j) w[j] = ws[j * lstride + (size_t)bi * rstride + n + l];
+    o[0] = make_float4(q[0], q[1], q[2], w[0]);
+    o[1] = make_float4(w[1], w[2], w[3], w[4]);
+    o[2] = make_float4(w[5], w[6], w[7], w[8]);
+}
+
+struct LevelPairs { u64 p[(NLEVEL + 1) / 2]; };   // lvl2[2i] | lvl2[2i+1] << 32
+
+template <int J>
+__device__ __forceinline__ f2 level_term(const LevelPairs &lv, const u64 *r, const f2 (&rl)[NLEVEL], f2 d2) {
+    // record floats: 0..2 xyz, 3+J the level's weight -> pair (3+J)>>1, half (3+J)&1
+    const f2 e = exp2_2(bmul<J & 1>(lv.p[J >> 1], d2));
+    return bmul<(3 + J) & 1>(r[(3 + J) >> 1], e * rl[J]);
+}
+template <int J>
+__device__ __forceinline__ f2 level_sum(const LevelPairs &lv, const u64 *r, const f2 (&rl)[NLEVEL], f2 d2) {
+    if constexpr (J == 0) return level_term<0>(lv, r, rl, d2);
+    else return level_sum<J - 1>(lv, r, rl, d2) + level_term<J>(lv, r, rl, d2);
+}
+
+__global__ __launch_bounds__(1024) void emd_materialize2_kernel(int n, int m, LevelPairs lv, const float *__restrict__ xyz1,
+                                                                const float *__restrict__ rec, float *__restrict__ match,
+                                                                const float *__restrict__ ws, size_t lstride, size_t rstride) {
     const int bi = blockIdx.y;
     const int lane = threadIdx.x, slice = __builtin_amdgcn_readfirstlane(threadIdx.y), S = blockDim.y;
     const float *__restrict__ P = xyz1 + (size_t)bi * n * 3;
-    const float *__restrict__ Q = xyz2 + (size_t)bi * m * 3;
     float *__restrict__ mt = match + (size_t)bi * n * m;
-    const int k = blockIdx.x * 64 + lane;
-    const bool live = k < n;
-    const int kc = min(k, n - 1);
-    const float px = P[kc * 3 + 0], py = P[kc * 3 + 1], pz = P[kc * 3 + 2];
-    float rl[NLEVEL];
+    const int k0 = blockIdx.x * PPW + lane, k1 = k0 + 64;
+    const int a0 = min(k0, n - 1), a1 = min(k1, n - 1);
+    const f2 px = {P[a0 * 3 + 0], P[a1 * 3 + 0]}, py = {P[a0 * 3 + 1], P[a1 * 3 + 1]}, pz = {P[a0 * 3 + 2], P[a1 * 3 + 2]};
+    f2 rl[NLEVEL];
 #pragma unroll
-    for (int j = 0; j < NLEVEL; ++j) rl[j] = ws[j * lstride + (size_t)bi * rstride + kc];
+    for (int j = 0; j < NLEVEL; ++j) {
+        const float *r = ws + j * lstride + (size_t)bi * rstride;
+        rl[j] = f2{r[a0], r[a1]};
+    }
     const int lb = (int)((long)m * slice / S), le = (int)((long)m * (slice + 1) / S);
-    const float *wl[NLEVEL];
-#pragma unroll
-    for (int j = 0; j < NLEVEL; ++j) wl[j] = ws + j * lstride + (size_t)bi * rstride + n;
-    const float *const (&wlr)[NLEVEL] = wl;
-    stream_candidates<NLEVEL>(Q, wlr, lb, le, lane, [&](int l, float qx, float qy, float qz, const float (&ww)[NLEVEL]) {
-        const float d2 = sqdist(px, py, pz, qx, qy, qz);
-        float acc = 0.f;
-#pragma unroll
-        for (int j = 0; j < NLEVEL; ++j) {
-            const float w = fmul(fmul(fast_exp2(fmul(lv.lvl2[j], d2)), rl[j]), ww[j]);
-            acc = j == 0 ? w : fadd(acc, w);
-        }
-        if (live) mt[(size_t)l * n + k] = acc;
+    stream_records<6, 2>((const u64 *)(rec + (size_t)bi * m * 12), lb, le, [&](int l, const u64 *r) {
+        const f2 acc = level_sum<NLEVEL - 1>(lv, r, rl, sqdist2(px, py, pz, r[0], r[1]));
+        float *row = mt + (size_t)l * n;
+        if (k0 < n) row[k0] = acc.x;
+        if (k1 < n) row[k1] = acc.y;
     });
 }
 
@@ -400,6 +618,15 @@ __global__ __launch_bounds__(256) void emd_grad2_sum_kernel(int m, int nkb, cons
 }
 
 // inner-loop slices per workgroup so that the launch has >= ~2048 waves
+// slices for the approxmatch passes (both paths use the same ones, so their sums associate identically): enough
+// that the deferred kernels (128 points per wave) put ~4 waves on every SIMD
+int pick_match_slices(int b, int npoints, int ninner) {
+    const long groups = (long)b * ((npoints + PPW - 1) / PPW);
+    int s = 1;
+    while (s < MAXS && groups * s < 4096 && ninner / (2 * s) >= 64) s *= 2;
+    return s;
+}
+
 int pick_slices(int b, int npoints, int ninner) {
     const long groups = (long)b * ((npoints + 63) / 64);
     int s = 1;
@@ -411,7 +638,9 @@ int pick_slices(int b, int npoints, int ninner) {
 
 extern "C" size_t dpf_approxmatch_workspace_bytes(int b, int n, int m) {
     if (b <= 0 || n <= 0 || m <= 0) return 0;
-    return (size_t)b * NLEVEL * ((size_t)n + m) * sizeof(float);
+    // NLEVEL ratio slots | 16 B alignment slack | (x,y,z,w) records of the passes | 12-float records of the materialisation
+    return (size_t)b * NLEVEL * ((size_t)n + m) * sizeof(float) + 16 + (size_t)b * ((size_t)n + 2 * (size_t)m) * sizeof(float4) +
+           (size_t)b * m * 12 * sizeof(float);
 }
 
 extern "C" int dpf_approxmatch_ws(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
@@ -426,10 +655,17 @@ extern "C" int dpf_approxmatch_ws(int b, int n, int m, const float *xyz1, const 
     if (n >= m) { multiL = 1; multiR = (float)(n / m); }   // integer division, approxmatch.cu:6-12
     else        { multiL = (float)(m / n); multiR = 1; }
     hipLaunchKernelGGL(emd_init_kernel, dim3((n + m + 255) / 256, b), dim3(256), 0, s, n, m, multiL, multiR, temp);
-    const int s1 = pick_slices(b, n, m), s2 = pick_slices(b, m, n);
+    const int s1 = pick_match_slices(b, n, m), s2 = pick_match_slices(b, m, n);
     const dim3 g1((n + 63) / 64, b), g2((m + 63) / 64, b);
+    const dim3 h1((n + PPW - 1) / PPW, b), h2((m + PPW - 1) / PPW, b);               // deferred kernels: 128 points per wave
     const size_t rstride = deferred ? (size_t)(n + m) : (size_t)(n + m) * 2;     // per-cloud stride of a ratio slot
     const size_t lstride = (size_t)b * (n + m);                                   // per-level stride in the workspace
+    // packed records of the deferred path, after the NLEVEL ratio slots
+    const size_t pstride = (size_t)n + 2 * (size_t)m;
+    float4 *pk = deferred ? (float4 *)(((uintptr_t)((float *)workspace + NLEVEL * lstride) + 15) & ~(uintptr_t)15) : nullptr;
+    float *rec = deferred ? (float *)(pk + (size_t)b * pstride) : nullptr;
+    if (deferred)
+        hipLaunchKernelGGL(emd_pack_init_kernel, dim3((m + 255) / 256, b), dim3(256), 0, s, m, multiR, xyz2, pk + n, pstride);
     Levels lv;
     int li = 0;
     for (int j = 7; j > -2; --j, ++li) {                    // approxmatch.cu:24 (the j==-2 branch is dead)
@@ -437,18 +673,32 @@ extern "C" int dpf_approxmatch_ws(int b, int n, int m, const float *xyz1, const 
         const float lvl2 = level * 1.44269504088896340736f;  // exp(x) = exp2(x*log2 e), as __expf does
         lv.lvl2[li] = lvl2;
         float *rb = deferred ? (float *)workspace + li * lstride : temp + (size_t)(n + m);
+        if (deferred) {
+            hipLaunchKernelGGL(emd_ratio2_kernel<1>, h1, dim3(64, s1), 0, s, n, m, lvl2, xyz1, xyz2, temp, rb, rstride, pk, pstride);
+            hipLaunchKernelGGL(emd_ratio2_kernel<2>, h2, dim3(64, s2), 0, s, n, m, lvl2, xyz1, xyz2, temp, rb, rstride, pk, pstride);
+            hipLaunchKernelGGL(emd_match2_kernel, h1, dim3(64, s1), 0, s, n, m, lvl2, xyz1, temp, rb, rstride, (const float4 *)pk, pstride);
+            continue;
+        }
         hipLaunchKernelGGL(emd_ratio_kernel<1>, g1, dim3(64, s1), 0, s, n, m, lvl2, xyz1, xyz2, temp, rb, rstride);
         hipLaunchKernelGGL(emd_ratio_kernel<2>, g2, dim3(64, s2), 0, s, n, m, lvl2, xyz1, xyz2, temp, rb, rstride);
-        if (deferred)
-            hipLaunchKernelGGL(emd_match_kernel<2>, g1, dim3(64, s1), 0, s, n, m, lvl2, xyz1, xyz2, match, temp, rb, rstride);
-        else if (j == 7)
+        if (j == 7)
             hipLaunchKernelGGL(emd_match_kernel<0>, g1, dim3(64, s1), 0, s, n, m, lvl2, xyz1, xyz2, match, temp, rb, rstride);
         else
             hipLaunchKernelGGL(emd_match_kernel<1>, g1, dim3(64, s1), 0, s, n, m, lvl2, xyz1, xyz2, match, temp, rb, rstride);
     }
-    if (deferred)
-        hipLaunchKernelGGL(emd_materialize_kernel, g1, dim3(64, s1), 0, s, n, m, lv, xyz1, xyz2, match,
+    if (deferred) {
+        LevelPairs lp;
+        for (int i = 0; i < (NLEVEL + 1) / 2; ++i) {
+            uint32_t lo, hi = 0;
+            memcpy(&lo, &lv.lvl2[2 * i], 4);
+            if (2 * i + 1 < NLEVEL) memcpy(&hi, &lv.lvl2[2 * i + 1], 4);
+            lp.p[i] = (u64)lo | ((u64)hi << 32);
+        }
+        hipLaunchKernelGGL(emd_pack_levels_kernel, dim3((m + 255) / 256, b), dim3(256), 0, s, n, m, xyz2,
+                           (const float *)workspace, lstride, rstride, rec);
+        hipLaunchKernelGGL(emd_materialize2_kernel, h1, dim3(64, s1), 0, s, n, m, lp, xyz1, (const float *)rec, match,
                            (const float *)workspace, lstride, rstride);
+    }
     return (int)hipGetLastError();
 }
 

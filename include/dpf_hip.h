@@ -109,10 +109,12 @@ int dpf_approxmatch(int b, int n, int m, const float *xyz1, const float *xyz2,
                     float *match, float *temp, dpf_stream_t stream);
 
 /* Same results as dpf_approxmatch, bit for bit, with `match` written ONCE: the
- * nine levels' ratio vectors are kept in `workspace`
- * (dpf_approxmatch_workspace_bytes = 36*(n+m) bytes per cloud) and the matching
- * is materialised by a final pass (4*n*m instead of 68*n*m bytes of HBM traffic
- * per cloud).  NULL / short workspace -> the read-modify-write path. */
+ * nine levels' ratio vectors and the packed (x, y, z, weight) candidate records
+ * the passes stream through scalar loads are kept in `workspace`
+ * (dpf_approxmatch_workspace_bytes = 36*(n+m) + 16*(n+2m) + 48*m (+16) bytes per
+ * cloud) and the matching is materialised by a final pass (4*n*m instead of
+ * 68*n*m bytes of HBM traffic per cloud).  NULL / short workspace -> the
+ * read-modify-write path. */
 size_t dpf_approxmatch_workspace_bytes(int b, int n, int m);
 int dpf_approxmatch_ws(int b, int n, int m, const float *xyz1, const float *xyz2,
                        float *match, float *temp, void *workspace, size_t workspace_bytes,

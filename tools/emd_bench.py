@@ -35,7 +35,7 @@ def main():
         nm = float(B) * N * N
         print("B=%d N=%d  approxmatch %.2f ms (%.0f GB/s of the 76*n*m RMW model, %.2e exp/s)  matchcost %.3f ms (%.0f GB/s)  "
               "grad one-pass %.3f ms (%.0f GB/s of 4*n*m) | two-pass %.3f ms" %
-              (B, N, t_match, 76 * nm / t_match / 1e6, 27 * nm / t_match * 1e3, t_cost, 4 * nm / t_cost / 1e6, t_grad,
+              (B, N, t_match, 76 * nm / t_match / 1e6, 36 * nm / t_match * 1e3, t_cost, 4 * nm / t_cost / 1e6, t_grad,
                4 * nm / t_grad / 1e6, t_grad2), flush=True)
 
 
