@@ -72,6 +72,20 @@ def allreduce_gradients(parameters, average=True):
     return flat.numel()
 
 
+def allreduce_flat_gradients(store, average=True):
+    """The same single collective for a decoder whose parameters live in a FlatStore
+    (LocalCondRNVPDecoder.flatten_parameters): the gradient buffer IS flat, so there is nothing to
+    gather or scatter -- one all-reduce of `store.flat_g` in place."""
+    rank, w = world()
+    if w == 1:
+        return 0
+    store.attach_grads()
+    dist.all_reduce(store.flat_g, op=dist.ReduceOp.SUM)
+    if average:
+        store.flat_g.div_(w)
+    return store.flat_g.numel()
+
+
 def broadcast_buffers(module, src=0):
     """BatchNorm running statistics diverge across replicas (no SyncBN); broadcast rank `src`'s
     before a checkpoint so that every rank saves the same state dict."""

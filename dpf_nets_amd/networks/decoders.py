@@ -9,7 +9,7 @@ tensors runs the HIP training kernels for the whole stack as one autograd node
 (decoders.py:58-70) for CPU tensors / DPF_TRAIN_IMPL=torch."""
 import torch.nn as nn
 
-from .flows import CondRealNVPFlow3DTriple, _needs_autograd, use_hip_training, train_stack
+from .flows import CondRealNVPFlow3DTriple, _needs_autograd, use_hip_training, train_stack, stack_spec
 from .flowlist import FlowList
 from .engine import FlowStack
 
@@ -49,6 +49,24 @@ class LocalCondRNVPDecoder(nn.Module):
             object.__setattr__(self, "_stack", FlowStack(self.coupling_layers()))
         return self._stack
 
+    def flatten_parameters(self):
+        """Opt-in (extension; DPF_TRAIN_FLAT=1 does it on the first training step): move every parameter and
+        BatchNorm buffer of the coupling layers into ONE flat buffer laid out as the HIP training path consumes it,
+        with `.grad` as views of a twin gradient buffer (train_engine.FlatStore).  Names, shapes, state dicts and
+        optimizers are unaffected; the training step loses the per-parameter gather, scatter and AccumulateGrad
+        work (2016 tensors at n_flows=21).  Call it after the module is on its GPU.  Returns the store
+        (`.flat_p`, `.flat_g`, `.zero_grad()`); data-parallel runs reduce `.flat_g` with
+        dpf_nets_amd.distributed.allreduce_flat_gradients instead of DistributedDataParallel hooks."""
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("flatten_parameters: move the decoder to its GPU first")
+        return stack_spec(self, self.coupling_layers()).flatten(dev)
+
+    def flat_store(self):
+        """The FlatStore of the full stack, or None."""
+        spec = self.__dict__.get("_train_specs", {}).get(len(self.coupling_layers()))
+        return None if spec is None else spec.flat
+
     def forward_torch(self, p, g, mode="direct"):
         ps, mus, lvs = [], [], []
         for i in range(self.n_flows):                               # decoders.py:58-70
@@ -69,7 +87,7 @@ class LocalCondRNVPDecoder(nn.Module):
             layers = self.coupling_layers()
             if n_layers is not None:
                 layers = layers[:int(n_layers)]
-            ps, mus, lvs = train_stack(self, layers, p, g, mode)
+            ps, mus, lvs = train_stack(self, layers, p, g, mode, allow_flat=n_layers is None)
             return list(ps.unbind(0)), list(mus.unbind(0)), list(lvs.unbind(0))
         if self.training or _needs_autograd(p, g):
             if n_layers is not None:

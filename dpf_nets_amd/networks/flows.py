@@ -28,14 +28,26 @@ def use_hip_training(module, p):
     return module.training and p.is_cuda and TRAIN_IMPL == "hip"
 
 
-def train_stack(owner, layers, p, g, mode):
-    """Run `layers` (DIRECT order) through the HIP training path; the static layout description is
-    cached on `owner` per number of layers."""
-    from .train_engine import StackSpec, run_training_stack
+TRAIN_FLAT = os.environ.get("DPF_TRAIN_FLAT", "0") == "1"
+
+
+def stack_spec(owner, layers):
+    """The static layout description of `layers`, cached on `owner` per number of layers."""
+    from .train_engine import StackSpec
     cache = owner.__dict__.setdefault("_train_specs", {})
     spec = cache.get(len(layers))
     if spec is None:
         spec = cache[len(layers)] = StackSpec(layers)
+    return spec
+
+
+def train_stack(owner, layers, p, g, mode, allow_flat=False):
+    """Run `layers` (DIRECT order) through the HIP training path.  allow_flat: DPF_TRAIN_FLAT=1 may move the
+    parameters into a flat store on first use (the decoder passes it for its full stack only)."""
+    from .train_engine import run_training_stack
+    spec = stack_spec(owner, layers)
+    if allow_flat and TRAIN_FLAT and spec.flat is None:
+        spec.flatten(p.device)
     return run_training_stack(spec, p, g, mode)
 
 

@@ -48,6 +48,7 @@ class StackSpec:
         self.eps = float(self.layers[0].eps_value)
         self._dev_cache = {}
         self._params = None
+        self.flat = None               # FlatStore once flatten() was called
         self.meta_host = (ctypes.c_int * (4 * self.L))(*[v for m in self.metas for v in m])
         self.canon_slots = []          # (offset, numel) per parameter, in canon_params() order
         pads = []                      # (offset, numel) of the zero padding between them
@@ -70,6 +71,12 @@ class StackSpec:
             pos += n
         assert pos == self.L * 2 * _T_BR
         self.cat_plan = [what for _, _, what in order]
+
+    def flatten(self, dev):
+        """Move the parameters and BatchNorm buffers of the layers into one FlatStore (idempotent)."""
+        if self.flat is None or not self.flat.attached():
+            self.flat = FlatStore(self, dev)
+        return self.flat
 
     def meta_on(self, dev):
         """int32 (L,4) keep/warp table on the device (cached: a host->device copy synchronises)."""
@@ -139,14 +146,92 @@ def _scatter(shapes_like, flat_views):
     return outs
 
 
+def _forward_core(p, g, spec, mode, prec, tcanon, W0, gam, bet, W1, b1, flat=None):
+    """Forward of the stack given the (L, 2*T_BR) conditioner block and the batched FiLM-net weights.
+    Returns (ps, mus, lvs) and the tensors the backward needs."""
+    L, G = spec.L, spec.G
+    B, _, N = p.shape
+    dev = p.device
+    L_ = lib()
+    stream = current_stream()
+    K = 4 * L
+    if B < 2:
+        raise ValueError("Expected more than 1 value per channel when training")      # as nn.BatchNorm1d
+    mods = spec.film_modules()
+    # ---- FiLM conditioner nets, batched over the K = 4L nets (flows.py:33-45, 68-80)
+    u = torch.matmul(g.unsqueeze(0), W0.transpose(1, 2))               # (K, B, F)
+    var, mean = torch.var_mean(u, dim=1, unbiased=False, keepdim=True)
+    rstd = torch.rsqrt(var + mods[0][1].eps)
+    xhat = (u - mean) * rstd
+    y = xhat * gam + bet
+    sig = torch.sigmoid(y)
+    sw = y * sig
+    fm = torch.baddbmm(b1, sw, W1.transpose(1, 2)).view(L, 2, 2, B, F).contiguous()
+    film_mean, film_uvar = mean.view(K, F), var.view(K, F) * (B / (B - 1.0))
+    # ---- the layers
+    packed = torch.empty(L_.dpf_flow_train_packed_bytes(L, prec), dtype=torch.uint8, device=dev)
+    check(L_.dpf_flow_train_pack(L, prec, tcanon.data_ptr(), packed.data_ptr(), stream), "flow_train_pack")
+    film = torch.empty((L, L_.dpf_flow_train_film_floats(B)), dtype=torch.float32, device=dev)
+    stats = torch.empty((L, L_.dpf_flow_train_stats_floats()), dtype=torch.float32, device=dev)
+    ws = torch.empty(L_.dpf_flow_train_workspace_bytes(B, N), dtype=torch.uint8, device=dev)
+    meta_dev = spec.meta_on(dev)
+    ps, mus, lvs = (torch.empty((L, B, 3, N), dtype=torch.float32, device=dev) for _ in range(3))
+    check(L_.dpf_flow_train_forward(L, B, N, MODE[mode], prec, spec.meta_host, meta_dev.data_ptr(), tcanon.data_ptr(),
+                                    packed.data_ptr(), fm.data_ptr(), p.data_ptr(), ps.data_ptr(), mus.data_ptr(),
+                                    lvs.data_ptr(), stats.data_ptr(), film.data_ptr(), spec.eps, ws.data_ptr(), stream),
+          "flow_train_forward")
+    # ---- BatchNorm running statistics: FiLM nets, then the conditioner stacks
+    sv = stats[:, :2 * 6 * F].view(L, 2, 6, F)
+    flow_mean, flow_uvar = sv[:, :, (0, 2)].reshape(4 * L, F), sv[:, :, (4, 5)].reshape(4 * L, F)
+    if flat is not None:
+        flat.update_running(film_mean, film_uvar, flow_mean, flow_uvar, mods[0][1].momentum)
+    else:
+        _update_running([m[1] for m in mods], list(film_mean.unbind(0)), list(film_uvar.unbind(0)))
+        _update_running(spec.flow_bns(), list(flow_mean.unbind(0)), list(flow_uvar.unbind(0)))
+    return (ps, mus, lvs), (p, g, tcanon, packed, film, stats, ps, W0, gam, W1, xhat, rstd, y, sig, sw)
+
+
+def _backward_core(spec, mode, prec, saved, g_ps, g_mus, g_lvs, need_dg):
+    """(dL/dp, dL/dg, d canon block, dW0, dgamma, dbeta, dW1, db1) -- the last five batched over the K FiLM nets."""
+    p, g, tcanon, packed, film, stats, ps, W0, gam, W1, xhat, rstd, y, sig, sw = saved
+    L, G = spec.L, spec.G
+    B, _, N = p.shape
+    dev = p.device
+    L_ = lib()
+    stream = current_stream()
+    ws = torch.empty(L_.dpf_flow_train_workspace_bytes(B, N), dtype=torch.uint8, device=dev)
+    dcanon = torch.empty_like(tcanon)
+    dfm = torch.empty((L, 2, 2, B, F), dtype=torch.float32, device=dev)
+    g_ps, g_mus, g_lvs = g_ps.contiguous(), g_mus.contiguous(), g_lvs.contiguous()
+    chain, dp_tmp = torch.empty_like(p), torch.empty_like(p)
+    check(L_.dpf_flow_train_backward(L, B, N, MODE[mode], prec, spec.meta_host, tcanon.data_ptr(), packed.data_ptr(),
+                                     film.data_ptr(), stats.data_ptr(), p.data_ptr(), ps.data_ptr(), g_ps.data_ptr(),
+                                     g_mus.data_ptr(), g_lvs.data_ptr(), chain.data_ptr(), dp_tmp.data_ptr(),
+                                     dcanon.data_ptr(), dfm.data_ptr(), spec.eps, ws.data_ptr(), stream),
+          "flow_train_backward")
+    # ---- FiLM nets backward (batched)
+    K = 4 * L
+    dout = dfm.view(K, B, F)
+    db1 = dout.sum(1)
+    dW1 = torch.matmul(dout.transpose(1, 2), sw)                       # (K, F, F)
+    dsw = torch.matmul(dout, W1)
+    dy = dsw * (sig * (1.0 + y * (1.0 - sig)))
+    dgam = (dy * xhat).sum(1)
+    dbet = dy.sum(1)
+    dxh = dy * gam
+    du = rstd * (dxh - dxh.mean(1, keepdim=True) - xhat * (dxh * xhat).mean(1, keepdim=True))
+    dW0 = torch.matmul(du.transpose(1, 2), g.unsqueeze(0))             # (K, F, G)
+    dg = torch.matmul(du.permute(1, 0, 2).reshape(B, K * F), W0.reshape(K * F, G)) if need_dg else None
+    return chain, dg, dcanon, dW0, dgam, dbet, dW1, db1
+
+
 class _FlowStackTrain(torch.autograd.Function):
+    """The stack as one node whose inputs are p, g and all 32*L parameters."""
+
     @staticmethod
     def forward(ctx, p, g, spec, mode, prec, *params):
         L, G = spec.L, spec.G
-        B, _, N = p.shape
         dev = p.device
-        L_ = lib()
-        stream = current_stream()
         p = p.contiguous()
         g = g.contiguous()
         ncanon = len(spec.canon_slots)
@@ -154,86 +239,158 @@ class _FlowStackTrain(torch.autograd.Function):
         # ---- gather the conditioner parameters (one cat; zero pads come from one shared buffer)
         zeros = spec.zeros_on(dev)
         tcanon = torch.cat([cparams[i].reshape(-1) if kind == "p" else zeros[:i] for kind, i in spec.cat_plan]).view(L, 2 * _T_BR)
-        # ---- FiLM conditioner nets, batched over the K = 4L nets (flows.py:33-45, 68-80)
         K = 4 * L
         W0 = torch.cat([t.reshape(-1) for t in fparams[0::5]]).view(K, F, G)
         gam = torch.cat(fparams[1::5]).view(K, 1, F)
         bet = torch.cat(fparams[2::5]).view(K, 1, F)
         W1 = torch.cat([t.reshape(-1) for t in fparams[3::5]]).view(K, F, F)
         b1 = torch.cat(fparams[4::5]).view(K, 1, F)
-        if B < 2:
-            raise ValueError("Expected more than 1 value per channel when training")      # as nn.BatchNorm1d
-        mods = spec.film_modules()
-        u = torch.matmul(g.unsqueeze(0), W0.transpose(1, 2))               # (K, B, F)
-        var, mean = torch.var_mean(u, dim=1, unbiased=False, keepdim=True)
-        rstd = torch.rsqrt(var + mods[0][1].eps)
-        xhat = (u - mean) * rstd
-        y = xhat * gam + bet
-        sig = torch.sigmoid(y)
-        sw = y * sig
-        fm = torch.baddbmm(b1, sw, W1.transpose(1, 2)).view(L, 2, 2, B, F).contiguous()
-        _update_running([m[1] for m in mods], list(mean.view(K, F).unbind(0)),
-                        list((var.view(K, F) * (B / (B - 1.0))).unbind(0)))
-        # ---- the layers
-        packed = torch.empty(L_.dpf_flow_train_packed_bytes(L, prec), dtype=torch.uint8, device=dev)
-        check(L_.dpf_flow_train_pack(L, prec, tcanon.data_ptr(), packed.data_ptr(), stream), "flow_train_pack")
-        film = torch.empty((L, L_.dpf_flow_train_film_floats(B)), dtype=torch.float32, device=dev)
-        stats = torch.empty((L, L_.dpf_flow_train_stats_floats()), dtype=torch.float32, device=dev)
-        ws = torch.empty(L_.dpf_flow_train_workspace_bytes(B, N), dtype=torch.uint8, device=dev)
-        meta_dev = spec.meta_on(dev)
-        ps, mus, lvs = (torch.empty((L, B, 3, N), dtype=torch.float32, device=dev) for _ in range(3))
-        check(L_.dpf_flow_train_forward(L, B, N, MODE[mode], prec, spec.meta_host, meta_dev.data_ptr(), tcanon.data_ptr(),
-                                        packed.data_ptr(), fm.data_ptr(), p.data_ptr(), ps.data_ptr(), mus.data_ptr(),
-                                        lvs.data_ptr(), stats.data_ptr(), film.data_ptr(), spec.eps, ws.data_ptr(), stream),
-              "flow_train_forward")
-        # BatchNorm running statistics of the conditioner stacks
-        sv = stats[:, :2 * 6 * F].view(L, 2, 6, F)
-        _update_running(spec.flow_bns(), list(sv[:, :, (0, 2)].reshape(4 * L, F).unbind(0)),
-                        list(sv[:, :, (4, 5)].reshape(4 * L, F).unbind(0)))
-        ctx.save_for_backward(p, g, tcanon, packed, film, stats, ps, W0, gam, W1, xhat, rstd, y, sig, sw, *params)
+        outs, saved = _forward_core(p, g, spec, mode, prec, tcanon, W0, gam, bet, W1, b1)
+        ctx.save_for_backward(*saved, *params)
         ctx.spec, ctx.prec, ctx.mode = spec, prec, mode
-        return ps, mus, lvs
+        return outs
 
     @staticmethod
     def backward(ctx, g_ps, g_mus, g_lvs):
-        p, g, tcanon, packed, film, stats, ps, W0, gam, W1, xhat, rstd, y, sig, sw = ctx.saved_tensors[:15]
-        params = ctx.saved_tensors[15:]
-        spec, prec = ctx.spec, ctx.prec
-        L, G = spec.L, spec.G
-        B, _, N = p.shape
-        dev = p.device
-        L_ = lib()
-        stream = current_stream()
-        ws = torch.empty(L_.dpf_flow_train_workspace_bytes(B, N), dtype=torch.uint8, device=dev)
-        dcanon = torch.empty_like(tcanon)
-        dfm = torch.empty((L, 2, 2, B, F), dtype=torch.float32, device=dev)
-        g_ps, g_mus, g_lvs = g_ps.contiguous(), g_mus.contiguous(), g_lvs.contiguous()
-        chain, dp_tmp = torch.empty_like(p), torch.empty_like(p)
-        check(L_.dpf_flow_train_backward(L, B, N, MODE[ctx.mode], prec, spec.meta_host, tcanon.data_ptr(), packed.data_ptr(),
-                                         film.data_ptr(), stats.data_ptr(), p.data_ptr(), ps.data_ptr(), g_ps.data_ptr(),
-                                         g_mus.data_ptr(), g_lvs.data_ptr(), chain.data_ptr(), dp_tmp.data_ptr(),
-                                         dcanon.data_ptr(), dfm.data_ptr(), spec.eps, ws.data_ptr(), stream),
-              "flow_train_backward")
-        # ---- FiLM nets backward (batched)
-        K = 4 * L
-        dout = dfm.view(K, B, F)
-        db1 = dout.sum(1)
-        dW1 = torch.matmul(dout.transpose(1, 2), sw)                       # (K, F, F)
-        dsw = torch.matmul(dout, W1)
-        dy = dsw * (sig * (1.0 + y * (1.0 - sig)))
-        dgam = (dy * xhat).sum(1)
-        dbet = dy.sum(1)
-        dxh = dy * gam
-        du = rstd * (dxh - dxh.mean(1, keepdim=True) - xhat * (dxh * xhat).mean(1, keepdim=True))
-        dW0 = torch.matmul(du.transpose(1, 2), g.unsqueeze(0))             # (K, F, G)
-        dg = torch.matmul(du.permute(1, 0, 2).reshape(B, K * F), W0.view(K * F, G)) if ctx.needs_input_grad[1] else None
+        saved, params = ctx.saved_tensors[:15], ctx.saved_tensors[15:]
+        spec = ctx.spec
+        chain, dg, dcanon, dW0, dgam, dbet, dW1, db1 = _backward_core(spec, ctx.mode, ctx.prec, saved, g_ps, g_mus, g_lvs,
+                                                                      ctx.needs_input_grad[1])
         # ---- hand every parameter its gradient: slices of the blocks, one multi-tensor copy
         flat = dcanon.view(-1)
         views = [flat[o:o + n] for o, n in spec.canon_slots]
-        for k in range(K):
+        for k in range(4 * spec.L):
             views += [dW0[k], dgam[k], dbet[k], dW1[k], db1[k]]
         grads = _scatter(params, views)
         return (chain if ctx.needs_input_grad[0] else None, dg, None, None, None, *grads)
+
+
+class FlatStore:
+    """ONE fp32 buffer that owns the storage of every parameter of the stack, laid out as the kernels and the batched
+    FiLM ops consume it -- [conditioner block (L, 2*T_BR) | W0 (K,F,G) | gamma (K,F) | beta (K,F) | W1 (K,F,F) | b1 (K,F)] --
+    a twin buffer for the gradients, and (8L, F) blocks for the BatchNorm running statistics.  Every nn.Parameter /
+    buffer of the layers keeps its identity, name and shape (state dicts and optimizers are unaffected); its `.data`
+    becomes a view of the flat buffer and its `.grad` a view of the gradient buffer.
+
+    What it buys (n_flows=21: 2016 parameters, 504 BatchNorm buffers): the forward needs no gather, the backward adds
+    its result blocks into the gradient buffer with six tensor ops instead of handing 2016 tensors to 2016
+    AccumulateGrad nodes, and the data-parallel gradient exchange is one all-reduce of `flat_g`.
+
+    Gradients are written by the node itself (autograd sees only p, g and a token), so per-parameter autograd hooks
+    (and with them DistributedDataParallel's reducer) do not fire for these parameters: use
+    dpf_nets_amd.distributed.allreduce_flat_gradients.  `optimizer.zero_grad()` may set the grads to None; the next
+    backward re-attaches the views (zeroed) -- `FlatStore.zero_grad()` avoids that per-parameter pass."""
+
+    def __init__(self, spec, dev):
+        L, G = spec.L, spec.G
+        K = 4 * L
+        cp, fp = spec.canon_params(), spec.film_params()
+        sizes = [L * 2 * _T_BR, K * F * G, K * F, K * F, K * F * F, K * F]
+        shapes = [(L, 2 * _T_BR), (K, F, G), (K, 1, F), (K, 1, F), (K, F, F), (K, 1, F)]
+        self.flat_p = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros_like(self.flat_p)
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + n)
+        self.blocks = [self.flat_p[offs[i]:offs[i + 1]].view(shapes[i]) for i in range(6)]
+        self.gblocks = [self.flat_g[offs[i]:offs[i + 1]].view(shapes[i]) for i in range(6)]
+        # element range of every parameter inside the flat buffers, in spec.all_params() order
+        ranges = [(o, n) for o, n in spec.canon_slots]
+        for k in range(K):
+            ranges += [(offs[1] + k * F * G, F * G), (offs[2] + k * F, F), (offs[3] + k * F, F),
+                       (offs[4] + k * F * F, F * F), (offs[5] + k * F, F)]
+        self.params = cp + fp
+        with torch.no_grad():
+            torch._foreach_copy_([self.flat_p[o:o + n] for o, n in ranges], [t.detach().reshape(-1).to(dev) for t in self.params])
+        self.pviews = [self.flat_p[o:o + n].view(t.shape) for (o, n), t in zip(ranges, self.params)]
+        self.gviews = [self.flat_g[o:o + n].view(t.shape) for (o, n), t in zip(ranges, self.params)]
+        for t, pv, gv in zip(self.params, self.pviews, self.gviews):
+            if t.grad is not None:
+                gv.copy_(t.grad)
+            t.data = pv
+            t.grad = gv
+        # BatchNorm running statistics: [FiLM nets (4L) | conditioner stacks (4L)]
+        self.bns = [m[1] for m in spec.film_modules()] + spec.flow_bns()
+        nb = len(self.bns)
+        self.rm = torch.stack([b.running_mean.detach().to(dev) for b in self.bns])
+        self.rv = torch.stack([b.running_var.detach().to(dev) for b in self.bns])
+        self.nbt = torch.stack([b.num_batches_tracked.detach().to(dev) for b in self.bns])
+        for i, b in enumerate(self.bns):
+            b.running_mean.data = self.rm[i]
+            b.running_var.data = self.rv[i]
+            b.num_batches_tracked.data = self.nbt[i]
+        self.nfilm = nb // 2
+        self.token = torch.zeros(1, dtype=torch.float32, device=dev, requires_grad=True)
+
+    def attached(self):
+        """The aliasing survives in-place updates, load_state_dict and optimizer steps; module.to()/.cuda()/.float()
+        re-assign `.data` and break it (the decoder then builds a new store)."""
+        a, b, pv, bn = self.params[0], self.params[-1], self.pviews, self.bns[-1]
+        return (a.data_ptr() == pv[0].data_ptr() and b.data_ptr() == pv[-1].data_ptr() and
+                bn.running_var.data_ptr() == self.rv[-1].data_ptr() and a.device == self.flat_p.device)
+
+    def update_running(self, film_mean, film_uvar, flow_mean, flow_uvar, momentum):
+        n = self.nfilm
+        self.rm.mul_(1.0 - momentum)
+        self.rv.mul_(1.0 - momentum)
+        self.rm[:n].add_(film_mean, alpha=momentum)
+        self.rm[n:].add_(flow_mean, alpha=momentum)
+        self.rv[:n].add_(film_uvar, alpha=momentum)
+        self.rv[n:].add_(flow_uvar, alpha=momentum)
+        self.nbt.add_(1)
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+        self.attach_grads(zeroed=True)
+
+    def attach_grads(self, zeroed=False, full=False):
+        """Make every parameter's .grad the view of flat_g again: after optimizer.zero_grad(set_to_none=True) the views
+        come back zeroed; a .grad that was replaced by another tensor is copied in.  The per-step check looks at
+        three sentinel parameters only (first, middle, last); full=True examines all of them."""
+        ps, gv = self.params, self.gviews
+        if not full and ps[0].grad is gv[0] and ps[-1].grad is gv[-1] and ps[len(ps) // 2].grad is gv[len(ps) // 2]:
+            return
+        if not zeroed:
+            if all(t.grad is None for t in ps):
+                self.flat_g.zero_()
+            else:
+                for t, v in zip(ps, gv):
+                    if t.grad is None:
+                        v.zero_()
+                    elif t.grad is not v:
+                        v.copy_(t.grad)
+        for t, v in zip(ps, gv):
+            t.grad = v
+
+    def accumulate(self, dcanon, dW0, dgam, dbet, dW1, db1):
+        self.attach_grads()
+        gb = self.gblocks
+        gb[0].add_(dcanon)
+        gb[1].add_(dW0)
+        gb[2].add_(dgam.unsqueeze(1))
+        gb[3].add_(dbet.unsqueeze(1))
+        gb[4].add_(dW1)
+        gb[5].add_(db1.unsqueeze(1))
+
+
+class _FlowStackTrainFlat(torch.autograd.Function):
+    """The stack over a FlatStore: autograd sees p, g and a token; parameter gradients go straight to flat_g."""
+
+    @staticmethod
+    def forward(ctx, p, g, token, spec, mode, prec):
+        fs = spec.flat
+        outs, saved = _forward_core(p.contiguous(), g.contiguous(), spec, mode, prec, *fs.blocks, flat=fs)
+        ctx.save_for_backward(*saved)
+        ctx.spec, ctx.prec, ctx.mode = spec, prec, mode
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_ps, g_mus, g_lvs):
+        spec = ctx.spec
+        chain, dg, *dparams = _backward_core(spec, ctx.mode, ctx.prec, ctx.saved_tensors, g_ps, g_mus, g_lvs,
+                                             ctx.needs_input_grad[1])
+        spec.flat.accumulate(*dparams)
+        return (chain if ctx.needs_input_grad[0] else None, dg, None, None, None, None)
 
 
 def run_training_stack(spec, p, g, mode, precision=None):
@@ -256,4 +413,8 @@ def run_training_stack(spec, p, g, mode, precision=None):
     if precision not in ("bf16x3", "bf16x6"):
         raise ValueError("training precision must be bf16x3 or bf16x6")
     with torch.cuda.device(p.device):
+        if spec.flat is not None:
+            if not spec.flat.attached():
+                spec.flat = FlatStore(spec, p.device)            # .to()/.cuda() re-assigned the parameters' data
+            return _FlowStackTrainFlat.apply(p, g, spec.flat.token, spec, mode, PREC[precision])
         return _FlowStackTrain.apply(p, g, spec, mode, PREC[precision], *spec.all_params())

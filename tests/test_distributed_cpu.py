@@ -53,6 +53,18 @@ def _worker(rank, world, port, q):
         allids = D.gather_clouds(ids)
         ok = ok and torch.equal(allids, torch.arange(B, dtype=torch.float32))
         D.broadcast_buffers(dec)
+        # the same single collective over a flat parameter store: nothing to gather or scatter
+        from dpf_nets_amd.networks.flows import stack_spec
+        fs = stack_spec(dec, dec.coupling_layers()).flatten(torch.device("cpu"))
+        carried = torch.cat([p.grad.reshape(-1) for p in dec.parameters()])
+        ok = ok and torch.equal(carried, after)                        # flattening keeps existing gradients
+        ramp = torch.arange(fs.flat_g.numel(), dtype=torch.float32)
+        fs.flat_g.copy_(ramp * (rank + 1))
+        n2 = D.allreduce_flat_gradients(fs)
+        w = dec.flows[0].nvp1.T_mu_0[3].weight
+        off = (w.grad.data_ptr() - fs.flat_g.data_ptr()) // 4
+        ok = ok and n2 == ramp.numel() and torch.allclose(fs.flat_g, ramp * ((1 + world) / 2.0))
+        ok = ok and 0 <= off < ramp.numel() and torch.allclose(w.grad.reshape(-1), ramp[off:off + w.numel()] * ((1 + world) / 2.0))
         q.put((rank, bool(ok), (lo, hi), float(loss)))
     finally:
         dist.destroy_process_group()

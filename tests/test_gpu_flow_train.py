@@ -260,3 +260,58 @@ def test_training_loop_with_optimizer_and_eval_switch():
         a = dec(tz, tg, mode="direct")[0][-1]
         b = dec.forward_torch(tz, tg, mode="direct")[0][-1]
     assert rel(a, b) <= OUT_REL, rel(a, b)
+
+
+def test_flat_parameter_store_matches_per_parameter_path():
+    """LocalCondRNVPDecoder.flatten_parameters(): same kernels on the same numbers, so an optimizer loop (the
+    reference's `optimizer.zero_grad(); loss.backward(); optimizer.step()`, training.py:54-56, incl. the default
+    set_to_none) must leave BITWISE the same parameters, BatchNorm statistics and outputs as the path that hands
+    every parameter to autograd; the decoder is called twice per step so gradients accumulate."""
+    nets = _gpu()
+    import copy
+    torch.manual_seed(1)
+    B, N, G = 6, 700, 128
+    ref = nets.LocalCondRNVPDecoder(2, 64, G).cuda().train()
+    flat = copy.deepcopy(ref)
+    store = flat.flatten_parameters()
+    assert flat.flat_store() is store and store.attached()
+    names = [k for k, _ in ref.named_parameters()]
+    assert names == [k for k, _ in flat.named_parameters()]
+    assert all(torch.equal(a, b) for a, b in zip(ref.state_dict().values(), flat.state_dict().values()))
+    n_flat = sum(p.numel() for p in flat.parameters())
+    assert store.flat_p.numel() >= n_flat                      # + the zero pads of the conditioner block
+    tgt, z, g = FO.synthetic_inputs(43, B, N, G)
+    tp, tz = torch.from_numpy(tgt).cuda(), torch.from_numpy(z).cuda()
+    nll = nets.PointFlowNLL()
+    pm, pl = torch.zeros(B, 3, N).cuda(), torch.full((B, 3, N), -3.6).cuda()
+    outs = []
+    for dec in (ref, flat):
+        opt = torch.optim.Adam(dec.parameters(), lr=1e-3)
+        tg = torch.from_numpy(g).cuda().requires_grad_(True)
+        for it in range(4):
+            if it == 2 and dec is flat:
+                store.zero_grad()                               # the one-op variant
+            else:
+                opt.zero_grad()
+            tg.grad = None
+            ps, mus, lvs = dec(tp, tg, mode="inverse")
+            loss = nll(ps + [tp], [pm] + mus, [pl] + lvs) / (3 * N)
+            loss = loss + dec(tz, tg, mode="direct")[0][-1].square().mean()
+            loss.backward()
+            opt.step()
+        outs.append((loss.detach().clone(), tg.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for (k, a), b in zip(ref.state_dict().items(), flat.state_dict().values()):
+        assert torch.equal(a, b), k
+    for (k, a), (_, b) in zip(ref.named_parameters(), flat.named_parameters()):
+        assert torch.equal(a.grad, b.grad), k
+    assert store.attached() and flat.flows[0].nvp1.T_mu_0[3].weight.grad.data_ptr() >= store.flat_g.data_ptr()
+    # a state dict loads in place and keeps the aliasing; .float()/.cuda() would break it and the next step re-flattens
+    flat.load_state_dict(ref.state_dict())
+    assert store.attached()
+    flat._apply(lambda t: t.clone())
+    assert not store.attached()
+    ps, _, _ = flat(tp, torch.from_numpy(g).cuda(), mode="inverse")
+    assert flat.flat_store() is not store and flat.flat_store().attached()
+    ps2, _, _ = ref(tp, torch.from_numpy(g).cuda(), mode="inverse")
+    assert torch.equal(ps[0], ps2[0])

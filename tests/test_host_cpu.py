@@ -187,3 +187,62 @@ def test_training_stack_spec_layout_matches_c_abi():
     # gradient slices map back one-to-one
     covered = sum(n for _, n in spec.canon_slots)
     assert covered == sum(p.numel() for p in cp)
+
+
+def test_flat_store_aliases_parameters_and_survives_zero_grad():
+    """train_engine.FlatStore on CPU tensors (no kernels involved): every parameter / BatchNorm buffer becomes a
+    view of the flat buffers, keeps its values, name and shape; optimizer.zero_grad(set_to_none=True) is repaired by
+    attach_grads(); accumulate() adds the result blocks where the per-parameter path would scatter them."""
+    import torch
+    from dpf_nets_amd import networks as nets
+    from dpf_nets_amd.networks.train_engine import StackSpec, FlatStore, _T_BR
+    torch.manual_seed(3)
+    dec = nets.LocalCondRNVPDecoder(1, 64, 16)
+    for p in dec.parameters():
+        p.data.normal_()
+    before = {k: v.clone() for k, v in dec.state_dict().items()}
+    layers = dec.coupling_layers()
+    spec = StackSpec(layers)
+    fs = spec.flatten(torch.device("cpu"))
+    assert isinstance(fs, FlatStore) and spec.flatten(torch.device("cpu")) is fs and fs.attached()
+    after = dec.state_dict()
+    assert list(before) == list(after) and all(torch.equal(before[k], after[k]) for k in before)
+    lo, hi = fs.flat_p.data_ptr(), fs.flat_p.data_ptr() + 4 * fs.flat_p.numel()
+    assert all(lo <= p.data_ptr() < hi for p in spec.all_params())
+    assert fs.flat_p.numel() == len(layers) * 2 * _T_BR + sum(p.numel() for p in spec.film_params())
+    # the conditioner block is exactly what the per-parameter path gathers
+    zeros = spec.zeros_on(torch.device("cpu"))
+    cp = spec.canon_params()
+    gathered = torch.cat([cp[i].reshape(-1) if kind == "p" else zeros[:i] for kind, i in spec.cat_plan])
+    assert torch.equal(gathered, fs.blocks[0].reshape(-1))
+    # in-place updates go through
+    with torch.no_grad():
+        layers[0].T_mu_0[3].weight.add_(1.0)
+    where = lambda t: next(i for i, q in enumerate(spec.all_params()) if q is t)   # noqa: E731
+    assert torch.equal(fs.pviews[where(layers[0].T_mu_0[3].weight)], layers[0].T_mu_0[3].weight)
+    # gradients: views of flat_g, repaired after set_to_none, accumulated blockwise
+    opt = torch.optim.SGD(dec.parameters(), lr=0.1)
+    opt.zero_grad(set_to_none=True)
+    assert all(p.grad is None for p in spec.all_params())
+    blocks = [torch.randn_like(b) for b in fs.gblocks]
+    fs.flat_g.fill_(7.0)                                        # stale content must not leak into the new gradients
+    fs.accumulate(blocks[0], blocks[1], blocks[2].squeeze(1), blocks[3].squeeze(1), blocks[4], blocks[5].squeeze(1))
+    fs.accumulate(blocks[0], blocks[1], blocks[2].squeeze(1), blocks[3].squeeze(1), blocks[4], blocks[5].squeeze(1))
+    assert all(torch.equal(g, 2 * b) for g, b in zip(fs.gblocks, blocks))
+    w = layers[0].T_logvar_0_cond_w[3].weight
+    k = next(i for i, m in enumerate(spec.film_modules()) if m is layers[0].T_logvar_0_cond_w)
+    assert w.grad is not None and torch.equal(w.grad, 2 * blocks[4][k])
+    o, n = spec.canon_slots[3]                                  # first branch's W1
+    assert torch.equal(cp[3].grad.reshape(-1), 2 * blocks[0].reshape(-1)[o:o + n])
+    # a replaced .grad tensor is folded in, not lost
+    w.grad = torch.ones_like(w)
+    fs.attach_grads(full=True)
+    assert w.grad.data_ptr() == fs.gviews[where(w)].data_ptr() and bool((w.grad == 1).all())
+    # running statistics live in (8L, F) blocks
+    bn = layers[0].T_mu_0[1]
+    fs.update_running(torch.ones(fs.nfilm, 64), torch.ones(fs.nfilm, 64), torch.full((fs.nfilm, 64), 2.0),
+                      torch.full((fs.nfilm, 64), 3.0), 0.1)
+    assert torch.allclose(bn.running_mean, torch.full((64,), 0.2)) and int(bn.num_batches_tracked) == 1
+    assert torch.allclose(bn.running_var, torch.full((64,), 0.9 + 0.3))
+    opt.step()                                                  # parameters still alias the flat buffer afterwards
+    assert fs.attached()
