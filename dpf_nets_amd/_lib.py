@@ -48,6 +48,8 @@ SIGNATURES = {
     "dpf_flow_train_forward": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
     "dpf_flow_train_backward": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _vp, _f, _vp, _vp]),
+    "dpf_flow_train_backward_lists": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                           _vp, _f, _vp, _vp]),
     "dpf_chamfer_reduce": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "dpf_version": (ctypes.c_char_p, []),
 }

@@ -427,7 +427,7 @@ __device__ __forceinline__ float dh2a_of(float pre, float w2a, float w2b, float 
 // Pass 1: recompute the layer to h2, differentiate the coupling transform and the output SharedDot.
 //   stores  dout (B,4,N) = d(o_logvar a,b), d(o_mu a,b)         dp_in <- direct term  g * d(p_out)/d(p)
 //   partial sums per workgroup: part1[blk][br][k][64], k = 0 dW2a, 1 dW2b, 2 da, 3 dc;  part1[blk][512 + br*2 + w] = db2
-// the gradient w.r.t. p_out is g_p + g_p2 (g_p2 may be NULL)
+// the gradient w.r.t. p_out is g_p + g_p2 (either may be NULL = zero, like g_mu and g_lv)
 template <int NS>
 __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__restrict__ g_p, const float *__restrict__ g_p2,
                                                         const float *__restrict__ g_mu, const float *__restrict__ g_lv,
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
     for (int c = 0; c < 3; ++c) {
         const size_t o = cloud + (size_t)c * N + nc;
         p[c] = a.p_in[o];
-        gp[c] = valid ? g_p[o] + (g_p2 ? g_p2[o] : 0.f) : 0.f;
+        gp[c] = valid ? (g_p ? g_p[o] : 0.f) + (g_p2 ? g_p2[o] : 0.f) : 0.f;
         gm[c] = valid && g_mu ? g_mu[o] : 0.f;
         gl[c] = valid && g_lv ? g_lv[o] : 0.f;
     }
@@ -1053,16 +1053,15 @@ static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb
     return (int)hipGetLastError();
 }
 
-// Backward of the stack, layers in the reverse of the forward order.  g_ps / g_mus / g_lvs: (L,B,3,N) gradients
-// w.r.t. the three output lists; the gradient that reaches layer l's p_out is g_ps[l] plus what the next layer
-// passes down.  dp_in (B,3,N), dcanon (L, T_LAYER) and dfm (L,[br][sub][B][64]) are fully overwritten; dp_tmp is a
-// (B,3,N) scratch buffer.
-extern "C" int dpf_flow_train_backward(int n_layers, int B, int N, int mode, int precision, const int *meta_host,
-                                       const float *tcanon, const void *packed, const float *film, const float *stats,
-                                       const float *p_in, const float *ps, const float *g_ps, const float *g_mus,
-                                       const float *g_lvs, float *dp_in, float *dp_tmp, float *dcanon, float *dfm,
-                                       float flow_eps, void *workspace, dpf_stream_t stream) {
-    if (n_layers <= 0 || B <= 0 || N <= 0 || !meta_host || !tcanon || !packed || !film || !stats || !p_in || !ps || !g_ps ||
+// Backward of the stack, layers in the reverse of the forward order.  The gradient that reaches layer l's p_out is
+// g_p(l) plus what the next layer passes down; g_p / g_mu / g_lv of a layer may be NULL (zero).  dp_in (B,3,N),
+// dcanon (L, T_LAYER) and dfm (L,[br][sub][B][64]) are fully overwritten; dp_tmp is a (B,3,N) scratch buffer.
+template <class GP>
+static int backward_stack(int n_layers, int B, int N, int mode, int precision, const int *meta_host, const float *tcanon,
+                          const void *packed, const float *film, const float *stats, const float *p_in, const float *ps,
+                          GP &&grad_of, float *dp_in, float *dp_tmp, float *dcanon, float *dfm, float flow_eps,
+                          void *workspace, dpf_stream_t stream) {
+    if (n_layers <= 0 || B <= 0 || N <= 0 || !meta_host || !tcanon || !packed || !film || !stats || !p_in || !ps ||
         !dp_in || !dp_tmp || !dcanon || !dfm || !workspace)
         return DPF_EINVAL;
     if (mode != DPF_MODE_DIRECT && mode != DPF_MODE_INVERSE) return DPF_EINVAL;
@@ -1079,7 +1078,7 @@ extern "C" int dpf_flow_train_backward(int n_layers, int B, int N, int mode, int
 #define DPF_BWD(NSV)                                                                                                      \
     backward_layer<NSV>(B, N, mode, m[0], m[1], m[2], m[3], tcanon + (size_t)l * T_LAYER,                               \
                         (const uint8_t *)packed + (size_t)l * pt_bytes(NSV), film + l * fls, stats + (size_t)l * ST_LAYER, pin, \
-                        g_ps + l * lst, chain, g_mus ? g_mus + l * lst : nullptr, g_lvs ? g_lvs + l * lst : nullptr, out,      \
+                        grad_of(0, l), chain, grad_of(1, l), grad_of(2, l), out,                                         \
                         dcanon + (size_t)l * T_LAYER, dfm + l * fms, flow_eps, workspace, (hipStream_t)stream)
         const int rc = ns == 2 ? DPF_BWD(2) : DPF_BWD(3);
 #undef DPF_BWD
@@ -1087,6 +1086,35 @@ extern "C" int dpf_flow_train_backward(int n_layers, int B, int N, int mode, int
         chain = out;
     }
     return 0;
+}
+
+// g_ps / g_mus / g_lvs: (L,B,3,N) gradients w.r.t. the three output lists (g_mus / g_lvs may be NULL)
+extern "C" int dpf_flow_train_backward(int n_layers, int B, int N, int mode, int precision, const int *meta_host,
+                                       const float *tcanon, const void *packed, const float *film, const float *stats,
+                                       const float *p_in, const float *ps, const float *g_ps, const float *g_mus,
+                                       const float *g_lvs, float *dp_in, float *dp_tmp, float *dcanon, float *dfm,
+                                       float flow_eps, void *workspace, dpf_stream_t stream) {
+    if (!g_ps) return DPF_EINVAL;
+    const size_t lst = (size_t)(B > 0 ? B : 0) * 3 * (N > 0 ? N : 0);
+    const float *base[3] = {g_ps, g_mus, g_lvs};
+    return backward_stack(n_layers, B, N, mode, precision, meta_host, tcanon, packed, film, stats, p_in, ps,
+                          [&](int which, int l) { return base[which] ? base[which] + l * lst : nullptr; }, dp_in, dp_tmp, dcanon,
+                          dfm, flow_eps, workspace, stream);
+}
+
+// The same with one (B,3,N) gradient pointer per layer and list: autograd hands the node a gradient per output
+// tensor (training.py's loss touches ps[0], mus[0] and every logvar), so nothing has to be stacked into (L,B,3,N)
+// blocks and the layers whose outputs are unused read nothing.  Any table, and any entry, may be NULL (zero).
+extern "C" int dpf_flow_train_backward_lists(int n_layers, int B, int N, int mode, int precision, const int *meta_host,
+                                             const float *tcanon, const void *packed, const float *film, const float *stats,
+                                             const float *p_in, const float *ps, const float *const *g_ps,
+                                             const float *const *g_mus, const float *const *g_lvs, float *dp_in,
+                                             float *dp_tmp, float *dcanon, float *dfm, float flow_eps, void *workspace,
+                                             dpf_stream_t stream) {
+    const float *const *tab[3] = {g_ps, g_mus, g_lvs};
+    return backward_stack(n_layers, B, N, mode, precision, meta_host, tcanon, packed, film, stats, p_in, ps,
+                          [&](int which, int l) { return tab[which] ? tab[which][l] : nullptr; }, dp_in, dp_tmp, dcanon, dfm,
+                          flow_eps, workspace, stream);
 }
 
 #ifdef DPF_PROFILE

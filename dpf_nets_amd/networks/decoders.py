@@ -88,7 +88,7 @@ class LocalCondRNVPDecoder(nn.Module):
             if n_layers is not None:
                 layers = layers[:int(n_layers)]
             ps, mus, lvs = train_stack(self, layers, p, g, mode, allow_flat=n_layers is None)
-            return list(ps.unbind(0)), list(mus.unbind(0)), list(lvs.unbind(0))
+            return ps, mus, lvs
         if self.training or _needs_autograd(p, g):
             if n_layers is not None:
                 raise ValueError("n_layers is only supported on the fused eval path")

@@ -182,5 +182,5 @@ class CondRealNVPFlow3DTriple(nn.Module):
             raise ValueError(mode)
         if use_hip_training(self, p):                              # the three layers as one autograd node
             ps, mus, lvs = train_stack(self, self.layers(), p, g, mode)
-            return list(ps.unbind(0)), list(mus.unbind(0)), list(lvs.unbind(0))
+            return ps, mus, lvs
         return self._chain(p, g, mode, lambda lyr, pp, gg, mm: lyr(pp, gg, mode=mm))

@@ -188,11 +188,34 @@ def _forward_core(p, g, spec, mode, prec, tcanon, W0, gam, bet, W1, b1, flat=Non
     else:
         _update_running([m[1] for m in mods], list(film_mean.unbind(0)), list(film_uvar.unbind(0)))
         _update_running(spec.flow_bns(), list(flow_mean.unbind(0)), list(flow_uvar.unbind(0)))
-    return (ps, mus, lvs), (p, g, tcanon, packed, film, stats, ps, W0, gam, W1, xhat, rstd, y, sig, sw)
+    outs = ps.unbind(0) + mus.unbind(0) + lvs.unbind(0)            # 3L output tensors: autograd hands back one gradient each
+    return outs, (p, g, tcanon, packed, film, stats, ps, W0, gam, W1, xhat, rstd, y, sig, sw)
 
 
-def _backward_core(spec, mode, prec, saved, g_ps, g_mus, g_lvs, need_dg):
-    """(dL/dp, dL/dg, d canon block, dW0, dgamma, dbeta, dW1, db1) -- the last five batched over the K FiLM nets."""
+def _grad_table(grads, shape, keep):
+    """Host table of device pointers for L per-layer gradients (None -> NULL).  Non-contiguous gradients (the
+    stride-0 expansion of a reduced loss, shared by every logvar) are materialised once per distinct tensor."""
+    if all(t is None for t in grads):
+        return None
+    ptrs = []
+    for t in grads:
+        if t is None:
+            ptrs.append(None)
+            continue
+        if not t.is_contiguous() or t.dtype != torch.float32:
+            c = keep.get(id(t))
+            if c is None:
+                c = keep[id(t)] = t.to(torch.float32).contiguous()
+            t = c
+        assert tuple(t.shape) == shape
+        keep.setdefault(("ref", id(t)), t)
+        ptrs.append(t.data_ptr())
+    return (ctypes.c_void_p * len(ptrs))(*ptrs)
+
+
+def _backward_core(spec, mode, prec, saved, grads, need_dg):
+    """grads: the 3L gradients of (ps, mus, lvs), None where an output is unused.
+    -> (dL/dp, dL/dg, d canon block, dW0, dgamma, dbeta, dW1, db1), the last five batched over the K FiLM nets."""
     p, g, tcanon, packed, film, stats, ps, W0, gam, W1, xhat, rstd, y, sig, sw = saved
     L, G = spec.L, spec.G
     B, _, N = p.shape
@@ -202,13 +225,15 @@ def _backward_core(spec, mode, prec, saved, g_ps, g_mus, g_lvs, need_dg):
     ws = torch.empty(L_.dpf_flow_train_workspace_bytes(B, N), dtype=torch.uint8, device=dev)
     dcanon = torch.empty_like(tcanon)
     dfm = torch.empty((L, 2, 2, B, F), dtype=torch.float32, device=dev)
-    g_ps, g_mus, g_lvs = g_ps.contiguous(), g_mus.contiguous(), g_lvs.contiguous()
+    keep = {}
+    t_ps, t_mus, t_lvs = (_grad_table(grads[i * L:(i + 1) * L], tuple(p.shape), keep) for i in range(3))
     chain, dp_tmp = torch.empty_like(p), torch.empty_like(p)
-    check(L_.dpf_flow_train_backward(L, B, N, MODE[mode], prec, spec.meta_host, tcanon.data_ptr(), packed.data_ptr(),
-                                     film.data_ptr(), stats.data_ptr(), p.data_ptr(), ps.data_ptr(), g_ps.data_ptr(),
-                                     g_mus.data_ptr(), g_lvs.data_ptr(), chain.data_ptr(), dp_tmp.data_ptr(),
-                                     dcanon.data_ptr(), dfm.data_ptr(), spec.eps, ws.data_ptr(), stream),
-          "flow_train_backward")
+    check(L_.dpf_flow_train_backward_lists(L, B, N, MODE[mode], prec, spec.meta_host, tcanon.data_ptr(), packed.data_ptr(),
+                                           film.data_ptr(), stats.data_ptr(), p.data_ptr(), ps.data_ptr(), t_ps, t_mus, t_lvs,
+                                           chain.data_ptr(), dp_tmp.data_ptr(), dcanon.data_ptr(), dfm.data_ptr(), spec.eps,
+                                           ws.data_ptr(), stream),
+          "flow_train_backward_lists")
+    del keep
     # ---- FiLM nets backward (batched)
     K = 4 * L
     dout = dfm.view(K, B, F)
@@ -248,13 +273,14 @@ class _FlowStackTrain(torch.autograd.Function):
         outs, saved = _forward_core(p, g, spec, mode, prec, tcanon, W0, gam, bet, W1, b1)
         ctx.save_for_backward(*saved, *params)
         ctx.spec, ctx.prec, ctx.mode = spec, prec, mode
+        ctx.set_materialize_grads(False)
         return outs
 
     @staticmethod
-    def backward(ctx, g_ps, g_mus, g_lvs):
+    def backward(ctx, *grads):
         saved, params = ctx.saved_tensors[:15], ctx.saved_tensors[15:]
         spec = ctx.spec
-        chain, dg, dcanon, dW0, dgam, dbet, dW1, db1 = _backward_core(spec, ctx.mode, ctx.prec, saved, g_ps, g_mus, g_lvs,
+        chain, dg, dcanon, dW0, dgam, dbet, dW1, db1 = _backward_core(spec, ctx.mode, ctx.prec, saved, grads,
                                                                       ctx.needs_input_grad[1])
         # ---- hand every parameter its gradient: slices of the blocks, one multi-tensor copy
         flat = dcanon.view(-1)
@@ -382,21 +408,21 @@ class _FlowStackTrainFlat(torch.autograd.Function):
         outs, saved = _forward_core(p.contiguous(), g.contiguous(), spec, mode, prec, *fs.blocks, flat=fs)
         ctx.save_for_backward(*saved)
         ctx.spec, ctx.prec, ctx.mode = spec, prec, mode
+        ctx.set_materialize_grads(False)
         return outs
 
     @staticmethod
-    def backward(ctx, g_ps, g_mus, g_lvs):
+    def backward(ctx, *grads):
         spec = ctx.spec
-        chain, dg, *dparams = _backward_core(spec, ctx.mode, ctx.prec, ctx.saved_tensors, g_ps, g_mus, g_lvs,
-                                             ctx.needs_input_grad[1])
+        chain, dg, *dparams = _backward_core(spec, ctx.mode, ctx.prec, ctx.saved_tensors, grads, ctx.needs_input_grad[1])
         spec.flat.accumulate(*dparams)
         return (chain if ctx.needs_input_grad[0] else None, dg, None, None, None, None)
 
 
 def run_training_stack(spec, p, g, mode, precision=None):
     """Training-mode forward of the layers of `spec` (DIRECT order) on the HIP path.  Returns
-    (ps, mus, lvs): three (L,B,3,N) tensors in DIRECT order, attached to autograd; updates the
-    BatchNorm running statistics as nn.BatchNorm1d would."""
+    (ps, mus, lvs): three lists of L (B,3,N) tensors in DIRECT order (views of three (L,B,3,N) blocks),
+    attached to autograd; updates the BatchNorm running statistics as nn.BatchNorm1d would."""
     if not p.is_cuda or not g.is_cuda:
         raise RuntimeError("the HIP training path runs on MI355X only (p and g must be CUDA tensors)")
     if p.dtype != torch.float32 or g.dtype != torch.float32:
@@ -416,5 +442,8 @@ def run_training_stack(spec, p, g, mode, precision=None):
         if spec.flat is not None:
             if not spec.flat.attached():
                 spec.flat = FlatStore(spec, p.device)            # .to()/.cuda() re-assigned the parameters' data
-            return _FlowStackTrainFlat.apply(p, g, spec.flat.token, spec, mode, PREC[precision])
-        return _FlowStackTrain.apply(p, g, spec, mode, PREC[precision], *spec.all_params())
+            outs = _FlowStackTrainFlat.apply(p, g, spec.flat.token, spec, mode, PREC[precision])
+        else:
+            outs = _FlowStackTrain.apply(p, g, spec, mode, PREC[precision], *spec.all_params())
+    L = spec.L
+    return list(outs[:L]), list(outs[L:2 * L]), list(outs[2 * L:])

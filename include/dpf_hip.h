@@ -275,6 +275,18 @@ int dpf_flow_train_backward(int n_layers, int B, int N, int mode, int precision,
                             const float *g_lvs, float *dp_in, float *dp_tmp, float *dcanon,
                             float *dfm, float flow_eps, void *workspace, dpf_stream_t stream);
 
+/* The same with ONE (B,3,N) gradient pointer per layer and output list (host arrays of n_layers
+ * device pointers): autograd produces a gradient per output tensor, and training.py's loss only
+ * touches ps[0], mus[0] and the logvars, so nothing is stacked into (L,B,3,N) blocks and unused
+ * outputs cost no memory traffic.  Any table, and any entry, may be NULL (zero gradient). */
+int dpf_flow_train_backward_lists(int n_layers, int B, int N, int mode, int precision,
+                                  const int *meta_host, const float *tcanon, const void *packed,
+                                  const float *film, const float *stats, const float *p_in,
+                                  const float *ps, const float *const *g_ps,
+                                  const float *const *g_mus, const float *const *g_lvs,
+                                  float *dp_in, float *dp_tmp, float *dcanon, float *dfm,
+                                  float flow_eps, void *workspace, dpf_stream_t stream);
+
 /* library identification: returns e.g. "dpf_hip gfx950 r1" */
 const char *dpf_version(void);
 
