@@ -1,7 +1,7 @@
 """debug: per-layer error growth of the HIP training path vs the tensor-op path (decoder golden config)"""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import flow_oracle as FO
 from dpf_nets_amd import networks as nets
 def rel(a, b):

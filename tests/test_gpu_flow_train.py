@@ -10,7 +10,7 @@ Tolerance: ONE layer: outputs rel <= 1e-4 of the tensor's scale (north star; mea
 gradients rel <= 1e-3 of the gradient tensor's scale (measured ~2e-5; they pass through two BatchNorm
 backward reductions over all B*N points).  A STACK of training-mode layers amplifies any perturbation
 of a layer's output by ~1.3x per layer -- fp32 itself goes from 5e-7 after one layer to 2.3e-6 after
-six against float64 (tools/train_dbg2.py) -- so the 6-layer stacks are held to 5e-4 on outputs and
+six against float64 (tests/diag/train_dbg2.py) -- so the 6-layer stacks are held to 5e-4 on outputs and
 2e-3 on gradients."""
 import json
 import os
