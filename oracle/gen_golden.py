@@ -18,6 +18,7 @@ import torch
 
 from . import detrng
 from . import flow_oracle as FO
+from . import encoder_oracle as EO
 
 REF = os.environ.get("DPF_REFERENCE", "/root/reference")
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
@@ -234,6 +235,39 @@ def gen_chamfer(evaluation_metrics):
     np.savez_compressed(os.path.join(OUT, "chamfer.npz"), **out)
 
 
+def gen_encoder():
+    """PointNetCloudEncoder (encoders.py:9-28) + the models' max over the points (models.py:85), eval and train mode.
+    Shapes: a ragged N (not a multiple of 32 or 256) and a multi-workgroup one."""
+    from lib.networks import encoders
+    out = {}
+    for case, (seed, B, N) in {"a": (11, 2, 300), "b": (12, 3, 1000)}.items():
+        st = EO.make_encoder_state(seed)
+        x = torch.from_numpy(EO.encoder_inputs(seed, B, N))
+        for training in (False, True):
+            enc = encoders.PointNetCloudEncoder(3, 64, [128, 256, 512])
+            enc.load_state_dict(FO.to_torch(st), strict=True)
+            enc.train(training)
+            xin = x.clone().requires_grad_(training)
+            feat = enc(xin)
+            gmax, gidx = torch.max(feat, dim=2)
+            tag = "%s_%s" % (case, "train" if training else "eval")
+            out[tag + "_max"] = gmax.detach().numpy()
+            out[tag + "_feat_sub"] = feat.detach()[:, ::37, ::29].contiguous().numpy()     # a lattice of the per-point features
+            if training:
+                r = torch.from_numpy(detrng.normal_f32(detrng.key(seed, "enc_r"), tuple(gmax.shape)))
+                (gmax * r).sum().backward()
+                out[tag + "_dx"] = xin.grad.numpy()
+                for k, v in _grad_projection([(k, p.grad) for k, p in enc.named_parameters()], seed).items():
+                    out[tag + "_gproj_" + k] = v
+                for k, v in enc.state_dict().items():
+                    if "running" in k:
+                        out[tag + "_stat_" + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "encoder.npz"), **out)
+    with open(os.path.join(OUT, "encoder.json"), "w") as f:
+        json.dump({"cases": {"a": [11, 2, 300], "b": [12, 3, 1000]}, "feat_lattice": [37, 29],
+                   "keys": list(enc.state_dict().keys())}, f, indent=1)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -242,6 +276,7 @@ def main():
     gen_layer(flows)
     gen_decoder(decoders, losses)
     gen_chamfer(evaluation_metrics)
+    gen_encoder()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -208,3 +208,36 @@ def test_emd_oracle_invariants():
     match, _ = S.approxmatch(a, a.copy())
     assert (S.matchcost(a, a.copy(), match) < 0.05).all()
     assert (np.diagonal(match, axis1=1, axis2=2) > 0.9).all()
+
+
+def test_encoder_oracle_vs_reference_golden(golden_dir):
+    """oracle/encoder_oracle.py against PointNetCloudEncoder + torch.max captured from the reference
+    (encoders.py:9-28, models.py:85): eval and train mode outputs, running statistics, d/dx and every parameter
+    gradient (projections) through autograd on the restatement."""
+    from oracle import encoder_oracle as EO
+    gold, meta = _load(golden_dir, "encoder")
+    assert meta["keys"] == list(EO.make_encoder_state(0).keys())
+    sa, sb = meta["feat_lattice"]
+    for case, (seed, B, N) in meta["cases"].items():
+        x = torch.from_numpy(EO.encoder_inputs(seed, B, N))
+        for training in (False, True):
+            tag = "%s_%s" % (case, "train" if training else "eval")
+            st = FO.to_torch(EO.make_encoder_state(seed))
+            params = {k: v.requires_grad_(True) for k, v in st.items() if v.dtype == torch.float32 and "running" not in k}
+            st.update(params)
+            xin = x.clone().requires_grad_(training)
+            stats = {}
+            feat = EO.encoder_features(st, xin, training, stats)
+            gmax = torch.max(feat, dim=2)[0]
+            np.testing.assert_allclose(gmax.detach().numpy(), gold[tag + "_max"], rtol=RTOL, atol=ATOL)
+            np.testing.assert_allclose(feat.detach()[:, ::sa, ::sb].numpy(), gold[tag + "_feat_sub"], rtol=RTOL, atol=ATOL)
+            if training:
+                r = torch.from_numpy(detrng.normal_f32(detrng.key(seed, "enc_r"), tuple(gmax.shape)))
+                (gmax * r).sum().backward()
+                np.testing.assert_allclose(xin.grad.numpy(), gold[tag + "_dx"], rtol=1e-4, atol=2e-5)   # values O(1)
+                proj = _grad_projection([(k, v.grad) for k, v in params.items()], seed)
+                for k, v in proj.items():
+                    ref = gold[tag + "_gproj_" + k]
+                    np.testing.assert_allclose(v, ref, rtol=2e-4, atol=2e-5 * max(1.0, float(ref[2])), err_msg=k)
+                for k, v in stats.items():
+                    np.testing.assert_allclose(v.numpy(), gold[tag + "_stat_" + k], rtol=RTOL, atol=ATOL, err_msg=k)
