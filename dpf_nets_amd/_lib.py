@@ -51,6 +51,10 @@ SIGNATURES = {
     "dpf_flow_train_backward_lists": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                            _vp, _f, _vp, _vp]),
     "dpf_chamfer_reduce": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "dpf_encoder_canon_floats": (_sz, []),
+    "dpf_encoder_packed_bytes": (_sz, [_i]),
+    "dpf_encoder_pack": (_i, [_i, _vp, _vp, _vp]),
+    "dpf_encoder_forward": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dpf_version": (ctypes.c_char_p, []),
 }
 

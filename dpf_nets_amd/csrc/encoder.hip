@@ -1,0 +1,366 @@
+// Fused PointNet cloud encoder + max over the points for gfx950 (MI355X), eval-mode BatchNorm.
+//
+// Replaces
+//   PointNetCloudEncoder.forward           lib/networks/encoders.py:27-28
+//     features = [SharedDot(no bias) . BatchNorm1d . ReLU] x 4,  3 -> 64 -> 128 -> 256 -> 512   (encoders.py:15-25)
+//   torch.max(features, dim=2)[0]          lib/networks/models.py:85,131,175
+// (12 ATen kernels writing and re-reading (B,C,N) activations: (64+128+256+512) * 4 B = 3.8 KB per point per pass,
+// ~1 GB of HBM traffic at B=32, N=2048) by ONE kernel that reads 12 B per point and writes B*512 floats: the
+// activations never leave the register file.
+//
+// A wave owns a tile of 32 points; a workgroup = 8 waves = 256 points of one cloud.  Per layer the weights are the
+// MFMA A operand (rows = output features) and the points the B operand, so the accumulator fragment of one
+// v_mfma_f32_32x32x16_bf16 -- each lane holds 16 features of ITS point -- becomes, after ReLU and a bf16 hi/lo split
+// in registers, the B fragment of the next layer (the K-slot <-> feature permutation this implies is applied to the
+// next layer's columns at pack time; same trick as csrc/flow.hip).  The LAST layer swaps the operands (activations
+// = A, weights = B): then a lane holds 16 POINTS of its feature and the max over the tile is 8 v_max3 in-lane plus
+// one cross-half swap, instead of a 5-step cross-lane butterfly per accumulator register.
+//
+// Split precision (bf16x3 default): products hi*hi + hi*lo + lo*hi of the bf16 hi/lo parts, fp32 accumulate.
+// BatchNorm (running statistics) is folded: scale into the weight rows before the split, shift as the accumulator's
+// initial value (layer 0: a constant-1 K slot of the input MFMA, whose 16 K slots hold the 3-way split of x, y, z).
+//
+// The 672 KiB (bf16x3) of layer 1-3 fragments stream through LDS in 21 chunks of NS*16 KiB (double-buffered,
+// global_load_lds, one workgroup barrier per chunk): chunk 0 = layer 1, chunks 1-4 = layer 2 (two M tiles each),
+// chunks 5-20 = layer 3 (one N tile of 32 output features each).
+#include "flow_common.h"
+
+namespace {
+
+constexpr int EC0 = 3, EC1 = 64, EC2 = 128, EC3 = 256, EC4 = 512;
+// canonical fp32 block (dpf_hip.h): per layer W[cout][cin], gamma, beta, running_mean, running_var
+__host__ __device__ constexpr int e_layer_off(int l) {
+    return l == 0 ? 0 : l == 1 ? EC1 * EC0 + 4 * EC1 : l == 2 ? EC1 * EC0 + 4 * EC1 + EC2 * EC1 + 4 * EC2
+                                                              : EC1 * EC0 + 4 * EC1 + EC2 * EC1 + 4 * EC2 + EC3 * EC2 + 4 * EC3;
+}
+__host__ __device__ constexpr int e_cin(int l) { return l == 0 ? EC0 : l == 1 ? EC1 : l == 2 ? EC2 : EC3; }
+__host__ __device__ constexpr int e_cout(int l) { return l == 0 ? EC1 : l == 1 ? EC2 : l == 2 ? EC3 : EC4; }
+constexpr int E_CANON = e_layer_off(3) + EC4 * EC3 + 4 * EC4;      // 176 064 floats
+
+// packed: [A0 4 KiB: [t2][ks2][lane64][8] | bias 4 KiB: b1acc[4][2][16] b2acc[8][2][16] b3[512] pad | 21 chunks]
+constexpr int EP_A0 = 0, EP_BIAS = 4096, EP_CHUNKS = 8192, E_NCHUNK = 21;
+constexpr int EB_1 = 0, EB_2 = 128, EB_3 = 384;                      // float offsets inside the bias block
+__host__ __device__ constexpr int ep_chunk_bytes(int NS) { return NS * 16384; }
+__host__ __device__ constexpr size_t ep_bytes(int NS) { return EP_CHUNKS + (size_t)E_NCHUNK * ep_chunk_bytes(NS); }
+
+// waves (tiles) per workgroup: 8 = two per SIMD with 256 VGPRs each; bf16x6 keeps 192 VGPRs of layer-3 operand
+// fragments and runs one wave per SIMD (4 waves, 512 VGPRs)
+__host__ __device__ constexpr int e_waves(int NS) { return NS == 3 ? 4 : 8; }
+
+// K index held by element j of lane-half kg in k-step ks = the feature that register 8*(ks&1)+j of accumulator
+// tile ks>>1 holds in lane-half kg (acc_feature)
+__host__ __device__ constexpr int k_feature(int ks, int j, int kg) { return acc_feature(ks >> 1, 8 * (ks & 1) + j, kg); }
+
+template <int NS>
+__global__ __launch_bounds__(256) void enc_pack_kernel(const float *__restrict__ canon, uint8_t *__restrict__ packed) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    auto scale_shift = [&](int l, int f, float &s, float &t) {
+        const float *c = canon + e_layer_off(l) + e_cout(l) * e_cin(l);
+        const int co = e_cout(l);
+        s = c[f] / sqrtf(c[3 * co + f] + BN_EPS);
+        t = c[co + f] - c[2 * co + f] * s;
+    };
+    // A0: the three input channels over two k-steps (x, y + shift | z)
+    uint16_t *a0 = (uint16_t *)(packed + EP_A0);
+    for (int idx = tid; idx < 2 * 2 * 64 * 8; idx += nth) {
+        const int j = idx & 7, lane = (idx >> 3) & 63, ks = (idx >> 9) & 1, t = idx >> 10;
+        const int f = 32 * t + (lane & 31), h = lane >> 5;
+        float s, sh;
+        scale_shift(0, f, s, sh);
+        const float *w = canon + e_layer_off(0) + f * EC0;
+        uint32_t v;
+        if (ks == 0) v = input_weight_slot(s * w[h], sh, h, j);
+        else v = h == 0 ? input_weight_slot(s * w[2], 0.f, 0, j) : 0u;
+        a0[idx] = (uint16_t)v;
+    }
+    float *bias = (float *)(packed + EP_BIAS);
+    for (int idx = tid; idx < 1024; idx += nth) {
+        float s, sh = 0.f;
+        if (idx < EB_2) {                       // layer 1, accumulator order [mt4][h2][r16]
+            scale_shift(1, acc_feature(idx >> 5, idx & 15, (idx >> 4) & 1), s, sh);
+        } else if (idx < EB_3) {
+            const int i = idx - EB_2;
+            scale_shift(2, acc_feature(i >> 5, i & 15, (i >> 4) & 1), s, sh);
+        } else if (idx < EB_3 + EC4) {
+            scale_shift(3, idx - EB_3, s, sh);
+        }
+        bias[idx] = sh;
+    }
+    // chunks: [part][slot16][lane64][8]; slot = (row tile within the chunk) * K + ks
+    uint16_t *ch = (uint16_t *)(packed + EP_CHUNKS);
+    const int per_chunk = 16 * 64 * 8;          // elements per part
+    for (int idx = tid; idx < E_NCHUNK * per_chunk; idx += nth) {
+        const int c = idx / per_chunk, e = idx % per_chunk;
+        const int j = e & 7, lane = (e >> 3) & 63, slot = e >> 9;
+        int l, rt, ks;
+        if (c == 0) { l = 1; rt = slot >> 2; ks = slot & 3; }
+        else if (c < 5) { l = 2; rt = 2 * (c - 1) + (slot >> 3); ks = slot & 7; }
+        else { l = 3; rt = c - 5; ks = slot; }
+        const int row = 32 * rt + (lane & 31), col = k_feature(ks, j, lane >> 5);
+        float s, sh;
+        scale_shift(l, row, s, sh);
+        const float w = s * canon[e_layer_off(l) + row * e_cin(l) + col];
+        uint16_t *o = ch + (size_t)c * NS * per_chunk + e;
+        if (NS == 1) {
+            o[0] = (uint16_t)bf16_rne(w);
+        } else if (NS == 2) {
+            float r1;
+            o[0] = (uint16_t)(split_hi(w, r1) >> 16);
+            o[per_chunk] = (uint16_t)bf16_rne(r1);
+        } else {
+            float r1, r2;
+            o[0] = (uint16_t)(split_hi(w, r1) >> 16);
+            o[per_chunk] = (uint16_t)(split_hi(r1, r2) >> 16);
+            o[2 * per_chunk] = (uint16_t)bf16_rne(r2);
+        }
+    }
+}
+
+struct EncArgs {
+    const uint8_t *packed;
+    const float *x;        // (B,3,N)
+    float *gmax;           // (B,512), zero-initialised by the launcher; updated with integer atomicMax (values >= 0)
+    float *feat;           // (B,512,N) or NULL
+    int B, N;
+};
+
+// relu + split of one accumulator tile into the two k-steps 2t, 2t+1 of the next layer's fragments
+template <int NS>
+__device__ __forceinline__ void relu_split(const f32x16 &acc, u32x4 (&dst)[NS][16], int t) {
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const float v0 = relu(acc[r]), v1 = relu(acc[r + 1]);
+        const int s = 2 * t + (r >> 3), d = (r & 7) >> 1;
+        if (NS == 1) {
+            dst[0][s][d] = pack_bf16_rne(v0, v1);
+        } else if (NS == 2) {
+            float l0, l1;
+            split_hi(v0, l0); split_hi(v1, l1);
+            dst[0][s][d] = pack_bf16_trunc(v0, v1);
+            dst[1][s][d] = pack_bf16_rne(l0, l1);
+        } else {
+            float l0, l1, m0, m1;
+            split_hi(v0, l0); split_hi(v1, l1);
+            split_hi(l0, m0); split_hi(l1, m1);
+            dst[0][s][d] = pack_bf16_trunc(v0, v1);
+            dst[1][s][d] = pack_bf16_trunc(l0, l1);
+            dst[2][s][d] = pack_bf16_rne(m0, m1);
+        }
+    }
+}
+
+template <int NS>
+__device__ __forceinline__ void stage_chunk(const uint8_t *packed, int c, uint8_t *lds, int wave, int lane) {
+    constexpr int NI = ep_chunk_bytes(NS) / 1024, EW = e_waves(NS);     // wave-instructions of 1 KiB
+    const uint8_t *src = packed + EP_CHUNKS + (size_t)c * ep_chunk_bytes(NS);
+#pragma unroll
+    for (int i = 0; i < NI / EW; ++i) {
+        const int k = wave + i * EW;
+        __builtin_amdgcn_global_load_lds((glb_void *)(src + k * 1024 + lane * 16), (lds_void *)(lds + k * 1024), 16, 0, 0);
+    }
+}
+
+// One output tile: K k-steps of fragments at chunk slots [slot0, slot0 + K), two accumulators (even / odd k-steps)
+// so that consecutive MFMAs are independent.  SWAP: the activations are the A operand and the weights the B operand.
+template <int NS, int K, bool SWAP>
+__device__ __forceinline__ f32x16 tile_gemm(const uint8_t *cb, int slot0, int lane, const u32x4 (&act)[NS][16], f32x16 init) {
+    typedef Terms<NS> TT;
+    f32x16 acc[2];
+    acc[0] = init;
+    acc[1] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    u32x4 wf[2][NS];
+    auto load = [&](int ks, u32x4 (&dst)[NS]) {
+#pragma unroll
+        for (int part = 0; part < NS; ++part)
+            dst[part] = *(const u32x4 *)(cb + part * 16384 + ((slot0 + ks) * 64 + lane) * 16);
+    };
+    load(0, wf[0]);
+#pragma unroll
+    for (int ks = 0; ks < K; ++ks) {
+        if (ks + 1 < K) load(ks + 1, wf[(ks + 1) & 1]);
+#pragma unroll
+        for (int term = 0; term < TT::N; ++term) {
+            const u32x4 w = wf[ks & 1][TT::A[term]], x = act[TT::B[term]][ks];
+            acc[ks & 1] = SWAP ? mfma(x, w, acc[ks & 1]) : mfma(w, x, acc[ks & 1]);
+        }
+    }
+    return acc[0] + acc[1];
+}
+
+__device__ __forceinline__ float half_max(float x) {   // max(x(lane), x(lane ^ 32))
+    const auto r = __builtin_amdgcn_permlane32_swap(f2u(x), f2u(x), false, false);
+    return fmaxf(u2f(r[0]), u2f(r[1]));
+}
+
+template <int NS>
+__global__ __launch_bounds__(e_waves(NS) * 64) void enc_kernel(EncArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int CHB = ep_chunk_bytes(NS), EW = e_waves(NS);
+    uint8_t *l_a0 = smem, *l_bias = smem + 4096, *l_buf = smem + 8192;
+    float *l_wmax = (float *)(smem + 8192 + 2 * CHB);             // [EW][512]
+
+    const int bi = blockIdx.y;
+    const int lane = threadIdx.x & 63, h = lane >> 5, pl = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int N = a.N;
+    const int tile0 = (blockIdx.x * EW + wave) * TILE;            // first point of this wave's tile
+    const int n = tile0 + pl;
+    const int nc = min(n, N - 1);
+    const float *xc = a.x + (size_t)bi * 3 * N;
+    const float px = xc[nc], py = xc[N + nc], pz = xc[2 * (size_t)N + nc];
+
+    // A0 + bias block (8 KiB) and chunk 0
+#pragma unroll
+    for (int k = wave; k < 8; k += EW)
+        __builtin_amdgcn_global_load_lds((glb_void *)(a.packed + k * 1024 + lane * 16), (lds_void *)(smem + k * 1024), 16, 0, 0);
+    stage_chunk<NS>(a.packed, 0, l_buf, wave, lane);
+    __syncthreads();
+
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // ---- layer 0: 3 -> 64 on the matrix core, fp32-accurate (3-way split of x, y | z)
+    u32x4 f1[NS][16];        // only k-steps 0..3 are used
+    {
+        const u32x4 b0 = input_fragment(h ? py : px, h);
+        u32x4 b1 = input_fragment(pz, 0);
+        if (h) b1 = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const u32x4 a00 = *(const u32x4 *)(l_a0 + ((t * 2 + 0) * 64 + lane) * 16);
+            const u32x4 a01 = *(const u32x4 *)(l_a0 + ((t * 2 + 1) * 64 + lane) * 16);
+            f32x16 acc = mfma(a00, b0, zero16);
+            acc = mfma(a01, b1, acc);
+            relu_split<NS>(acc, f1, t);
+        }
+    }
+    auto bias_tile = [&](int off, int mt) {       // accumulator-order shift of M tile mt
+        const float *bp = (const float *)l_bias + off + (mt * 2 + h) * 16;
+        f32x16 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *(const f32x4 *)(bp + 4 * q);
+            v[4 * q + 0] = b.x; v[4 * q + 1] = b.y; v[4 * q + 2] = b.z; v[4 * q + 3] = b.w;
+        }
+        return v;
+    };
+    // ---- layer 1: 64 -> 128 (chunk 0 in buffer 0)
+    stage_chunk<NS>(a.packed, 1, l_buf + CHB, wave, lane);
+    u32x4 f2[NS][16];        // k-steps 0..7
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const f32x16 acc = tile_gemm<NS, 4, false>(l_buf, mt * 4, lane, f1, bias_tile(EB_1, mt));
+        relu_split<NS>(acc, f2, mt);
+    }
+    __syncthreads();
+    // ---- layer 2: 128 -> 256 (chunks 1..4)
+    u32x4 f3[NS][16];
+#pragma unroll
+    for (int c = 1; c < 5; ++c) {
+        const uint8_t *cb = l_buf + (c & 1) * CHB;
+        stage_chunk<NS>(a.packed, c + 1, l_buf + ((c + 1) & 1) * CHB, wave, lane);
+#pragma unroll
+        for (int mtl = 0; mtl < 2; ++mtl) {
+            const int mt = 2 * (c - 1) + mtl;
+            const f32x16 acc = tile_gemm<NS, 8, false>(cb, mtl * 8, lane, f2, bias_tile(EB_2, mt));
+            relu_split<NS>(acc, f3, mt);
+        }
+        __syncthreads();
+    }
+    // ---- layer 3: 256 -> 512, operands swapped: accumulator register r = point (r&3) + 8*(r>>2) + 4h of the tile,
+    //      lane column = output feature.  Chunks 5..20, one 32-feature tile each.
+    const bool ragged = tile0 + TILE > N;
+    for (int nt = 0; nt < 16; ++nt) {
+        const int c = 5 + nt;
+        const uint8_t *cb = l_buf + (c & 1) * CHB;
+        if (c + 1 < E_NCHUNK) stage_chunk<NS>(a.packed, c + 1, l_buf + ((c + 1) & 1) * CHB, wave, lane);
+        f32x16 acc = tile_gemm<NS, 16, true>(cb, 0, lane, f3, zero16);
+        const float shift = ((const float *)l_bias)[EB_3 + 32 * nt + pl];
+        if (a.feat != nullptr) {       // optional (B,512,N) output: 4 consecutive points per 16-byte store
+            float *fo = a.feat + ((size_t)bi * EC4 + 32 * nt + pl) * N + tile0 + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int p0 = tile0 + 4 * h + 8 * q;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[4 * q + e] + shift, 0.f);
+                if (p0 + 3 < N && (N & 3) == 0) {
+                    *(f32x4 *)(fo + 8 * q) = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (p0 + e < N) fo[8 * q + e] = v[e];
+                }
+            }
+        }
+        if (ragged) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (tile0 + (r & 3) + 8 * (r >> 2) + 4 * h >= N) acc[r] = -__builtin_inff();
+        }
+        float m = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, acc[r]), acc[r + 1]);
+        m = fmaxf(m, acc[15]);
+        m = half_max(m);
+        // max_p relu(x_p + shift) = relu(max_p x_p + shift): fp32 addition is monotonic
+        if (!h) l_wmax[wave * EC4 + 32 * nt + pl] = tile0 < N ? fmaxf(m + shift, 0.f) : 0.f;
+        __syncthreads();
+    }
+    // ---- combine the waves, one integer atomicMax per feature (all values are >= 0, so the bit patterns order)
+    for (int f = threadIdx.x; f < EC4; f += EW * 64) {
+        float m = l_wmax[f];
+#pragma unroll
+        for (int w = 1; w < EW; ++w) m = fmaxf(m, l_wmax[w * EC4 + f]);
+        atomicMax((int *)(a.gmax + (size_t)bi * EC4 + f), (int)f2u(m));
+    }
+}
+
+int e_ns_of(int precision) {
+    return precision == DPF_PREC_BF16 ? 1 : precision == DPF_PREC_BF16X3 ? 2 : precision == DPF_PREC_BF16X6 ? 3 : 0;
+}
+
+template <int NS>
+int launch_enc(const EncArgs &a, hipStream_t s) {
+    constexpr int EW = e_waves(NS), EWG_POINTS = EW * TILE;
+    const int lds = 8192 + 2 * ep_chunk_bytes(NS) + EW * EC4 * 4;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void *)enc_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(enc_kernel<NS>, dim3((a.N + EWG_POINTS - 1) / EWG_POINTS, a.B), dim3(EW * 64), lds, s, a);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" size_t dpf_encoder_canon_floats(void) { return (size_t)E_CANON; }
+
+extern "C" size_t dpf_encoder_packed_bytes(int precision) {
+    const int ns = e_ns_of(precision);
+    return ns ? ep_bytes(ns) : 0;
+}
+
+extern "C" int dpf_encoder_pack(int precision, const float *canon, void *packed, dpf_stream_t stream) {
+    const int ns = e_ns_of(precision);
+    if (!ns || !canon || !packed) return DPF_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (ns == 1) hipLaunchKernelGGL(enc_pack_kernel<1>, dim3(256), dim3(256), 0, s, canon, (uint8_t *)packed);
+    if (ns == 2) hipLaunchKernelGGL(enc_pack_kernel<2>, dim3(256), dim3(256), 0, s, canon, (uint8_t *)packed);
+    if (ns == 3) hipLaunchKernelGGL(enc_pack_kernel<3>, dim3(256), dim3(256), 0, s, canon, (uint8_t *)packed);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dpf_encoder_forward(int B, int N, int precision, const void *packed, const float *x, float *gmax, float *feat,
+                                   dpf_stream_t stream) {
+    const int ns = e_ns_of(precision);
+    if (!ns || B < 0 || N <= 0) return DPF_EINVAL;
+    if (B == 0) return 0;
+    if (!packed || !x || !gmax) return DPF_EINVAL;
+    if (B > 65535) return DPF_ENOSUP;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(gmax, 0, sizeof(float) * (size_t)B * EC4, s);
+    if (e != hipSuccess) return (int)e;
+    EncArgs a{(const uint8_t *)packed, x, gmax, feat, B, N};
+    return ns == 1 ? launch_enc<1>(a, s) : ns == 2 ? launch_enc<2>(a, s) : launch_enc<3>(a, s);
+}

@@ -1,7 +1,8 @@
 """Host-side mirror of the reference's lib.networks surface for the per-point flow
-decoder: same class names, constructor signatures, parameter/buffer names and
+decoder and the PointNet cloud encoder: same class names, constructor signatures, parameter/buffer names and
 return structures (lib/networks/{layers,flows,decoders,losses,utils}.py)."""
 from .layers import SharedDot, Swish  # noqa: F401
 from .flows import CondRealNVPFlow3D, CondRealNVPFlow3DTriple  # noqa: F401
 from .decoders import LocalCondRNVPDecoder  # noqa: F401
 from .losses import PointFlowNLL  # noqa: F401
+from .encoders import PointNetCloudEncoder, PointFeatures  # noqa: F401

@@ -290,6 +290,24 @@ int dpf_flow_train_backward_lists(int n_layers, int B, int N, int mode, int prec
 /* library identification: returns e.g. "dpf_hip gfx950 r1" */
 const char *dpf_version(void);
 
+/* ---- PointNet cloud encoder + max over the points (eval-mode BatchNorm) ---------------------
+ * replaces PointNetCloudEncoder.forward (lib/networks/encoders.py:27-28) for the architecture
+ * every config uses, SharedDot(no bias).BatchNorm1d.ReLU x 4 over 3 -> 64 -> 128 -> 256 -> 512
+ * (encoders.py:15-25, configs pc_enc_*), together with the torch.max(features, dim=2)[0] the
+ * models apply to it (lib/networks/models.py:85,131,175).
+ *
+ * canon: dpf_encoder_canon_floats() = 176 064 fp32, per layer l = 0..3
+ *   W[cout][cin] (SharedDot.weight[0]) | bn.weight | bn.bias | bn.running_mean | bn.running_var.
+ * dpf_encoder_pack folds BatchNorm and lays the weights out as bf16 MFMA fragments (once per weight
+ * version and precision) into `packed` (dpf_encoder_packed_bytes(precision)).
+ * dpf_encoder_forward: x (B,3,N) channel-major -> gmax (B,512) fully overwritten; feat, when not
+ * NULL, also receives the per-point features (B,512,N) (what the module's forward returns). */
+size_t dpf_encoder_canon_floats(void);
+size_t dpf_encoder_packed_bytes(int precision);
+int dpf_encoder_pack(int precision, const float *canon, void *packed, dpf_stream_t stream);
+int dpf_encoder_forward(int B, int N, int precision, const void *packed, const float *x,
+                        float *gmax, float *feat, dpf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

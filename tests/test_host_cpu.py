@@ -246,3 +246,26 @@ def test_flat_store_aliases_parameters_and_survives_zero_grad():
     assert torch.allclose(bn.running_var, torch.full((64,), 0.9 + 0.3))
     opt.step()                                                  # parameters still alias the flat buffer afterwards
     assert fs.attached()
+
+
+def test_encoder_state_dict_contract(golden_dir):
+    """PointNetCloudEncoder: the reference's state-dict keys, shapes (encoders.py:15-25) and init; CPU eval raises."""
+    import json
+    import os
+    import pytest
+    import torch
+    from dpf_nets_amd import networks as nets
+    from oracle import encoder_oracle as EO, flow_oracle as FO
+    meta = json.load(open(os.path.join(golden_dir, "encoder.json")))
+    enc = nets.PointNetCloudEncoder(3, 64, [128, 256, 512])
+    assert list(enc.state_dict().keys()) == meta["keys"]
+    enc.load_state_dict(FO.to_torch(EO.make_encoder_state(3)), strict=True)
+    assert enc.features.sd2.weight.shape == (1, 512, 256) and enc.hip_supported()
+    x = torch.from_numpy(EO.encoder_inputs(3, 2, 40))
+    enc.train()
+    st = FO.to_torch(EO.make_encoder_state(3))
+    ref = EO.encoder_features(st, x, training=True)
+    assert torch.allclose(enc(x), ref, rtol=1e-4, atol=1e-5)            # the tensor-op path = the reference's ops
+    enc.eval()
+    with pytest.raises(RuntimeError):
+        enc(x)
