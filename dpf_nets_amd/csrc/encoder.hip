@@ -20,9 +20,8 @@
 // BatchNorm (running statistics) is folded: scale into the weight rows before the split, shift as the accumulator's
 // initial value (layer 0: a constant-1 K slot of the input MFMA, whose 16 K slots hold the 3-way split of x, y, z).
 //
-// The 672 KiB (bf16x3) of layer 1-3 fragments stream through LDS in 21 chunks of NS*16 KiB (double-buffered,
-// global_load_lds, one workgroup barrier per chunk): chunk 0 = layer 1, chunks 1-4 = layer 2 (two M tiles each),
-// chunks 5-20 = layer 3 (one N tile of 32 output features each).
+// The 672 KiB (bf16x3) of layer 1-3 fragments stream through LDS in 11 chunks of 64 KiB (double-buffered,
+// global_load_lds, one workgroup barrier per chunk).
 #include "flow_common.h"
 
 namespace {
@@ -37,11 +36,18 @@ __host__ __device__ constexpr int e_cin(int l) { return l == 0 ? EC0 : l == 1 ? 
 __host__ __device__ constexpr int e_cout(int l) { return l == 0 ? EC1 : l == 1 ? EC2 : l == 2 ? EC3 : EC4; }
 constexpr int E_CANON = e_layer_off(3) + EC4 * EC3 + 4 * EC4;      // 176 064 floats
 
-// packed: [A0 4 KiB: [t2][ks2][lane64][8] | bias 4 KiB: b1acc[4][2][16] b2acc[8][2][16] b3[512] pad | 21 chunks]
-constexpr int EP_A0 = 0, EP_BIAS = 4096, EP_CHUNKS = 8192, E_NCHUNK = 21;
+// packed: [A0 4 KiB: [t2][ks2][lane64][8] | bias 4 KiB: b1acc[4][2][16] b2acc[8][2][16] b3[512] pad | chunks]
+// The fragments of layers 1-3 form one stream of 336 slots (a slot = the NS parts of one 1 KiB fragment):
+// layer 1: 4 M tiles x 4 k-steps at slot 0, layer 2: 8 x 8 at slot 16, layer 3: 16 N tiles x 16 at slot 80; a tile's
+// k-steps are consecutive and never straddle a chunk of e_slots(NS) slots.  Chunk: [part][slot][lane64][8].
+constexpr int EP_A0 = 0, EP_BIAS = 4096, EP_CHUNKS = 8192;
 constexpr int EB_1 = 0, EB_2 = 128, EB_3 = 384;                      // float offsets inside the bias block
-__host__ __device__ constexpr int ep_chunk_bytes(int NS) { return NS * 16384; }
-__host__ __device__ constexpr size_t ep_bytes(int NS) { return EP_CHUNKS + (size_t)E_NCHUNK * ep_chunk_bytes(NS); }
+constexpr int ES_L1 = 0, ES_L2 = 16, ES_L3 = 80, ES_TOTAL = 336;
+// slots per chunk: 32 (two 64 KiB buffers at bf16x3) halves the number of workgroup barriers; bf16x6 keeps 16
+__host__ __device__ constexpr int e_slots(int NS) { return NS == 3 ? 16 : 32; }
+__host__ __device__ constexpr int e_nchunk(int NS) { return (ES_TOTAL + e_slots(NS) - 1) / e_slots(NS); }
+__host__ __device__ constexpr int ep_chunk_bytes(int NS) { return NS * e_slots(NS) * 1024; }
+__host__ __device__ constexpr size_t ep_bytes(int NS) { return EP_CHUNKS + (size_t)e_nchunk(NS) * ep_chunk_bytes(NS); }
 
 // waves (tiles) per workgroup: 8 = two per SIMD with 256 VGPRs each; bf16x6 keeps 192 VGPRs of layer-3 operand
 // fragments and runs one wave per SIMD (4 waves, 512 VGPRs)
@@ -86,21 +92,25 @@ __global__ __launch_bounds__(256) void enc_pack_kernel(const float *__restrict__
         }
         bias[idx] = sh;
     }
-    // chunks: [part][slot16][lane64][8]; slot = (row tile within the chunk) * K + ks
     uint16_t *ch = (uint16_t *)(packed + EP_CHUNKS);
-    const int per_chunk = 16 * 64 * 8;          // elements per part
-    for (int idx = tid; idx < E_NCHUNK * per_chunk; idx += nth) {
+    constexpr int S = e_slots(NS);
+    const int per_chunk = S * 64 * 8;           // elements per part
+    for (int idx = tid; idx < e_nchunk(NS) * per_chunk; idx += nth) {
         const int c = idx / per_chunk, e = idx % per_chunk;
-        const int j = e & 7, lane = (e >> 3) & 63, slot = e >> 9;
+        const int j = e & 7, lane = (e >> 3) & 63, slot = c * S + (e >> 9);
+        uint16_t *o = ch + (size_t)c * NS * per_chunk + e;
+        if (slot >= ES_TOTAL) {                 // padding of the last chunk
+            for (int part = 0; part < NS; ++part) o[part * per_chunk] = 0;
+            continue;
+        }
         int l, rt, ks;
-        if (c == 0) { l = 1; rt = slot >> 2; ks = slot & 3; }
-        else if (c < 5) { l = 2; rt = 2 * (c - 1) + (slot >> 3); ks = slot & 7; }
-        else { l = 3; rt = c - 5; ks = slot; }
+        if (slot < ES_L2) { l = 1; rt = slot >> 2; ks = slot & 3; }
+        else if (slot < ES_L3) { l = 2; rt = (slot - ES_L2) >> 3; ks = (slot - ES_L2) & 7; }
+        else { l = 3; rt = (slot - ES_L3) >> 4; ks = (slot - ES_L3) & 15; }
         const int row = 32 * rt + (lane & 31), col = k_feature(ks, j, lane >> 5);
         float s, sh;
         scale_shift(l, row, s, sh);
         const float w = s * canon[e_layer_off(l) + row * e_cin(l) + col];
-        uint16_t *o = ch + (size_t)c * NS * per_chunk + e;
         if (NS == 1) {
             o[0] = (uint16_t)bf16_rne(w);
         } else if (NS == 2) {
@@ -160,19 +170,23 @@ __device__ __forceinline__ void stage_chunk(const uint8_t *packed, int c, uint8_
     }
 }
 
-// One output tile: K k-steps of fragments at chunk slots [slot0, slot0 + K), two accumulators (even / odd k-steps)
+// One output tile: K k-steps of fragments at slots [slot0, slot0 + K) of the chunk at cb, two accumulators (even / odd k-steps)
 // so that consecutive MFMAs are independent.  SWAP: the activations are the A operand and the weights the B operand.
 template <int NS, int K, bool SWAP>
 __device__ __forceinline__ f32x16 tile_gemm(const uint8_t *cb, int slot0, int lane, const u32x4 (&act)[NS][16], f32x16 init) {
     typedef Terms<NS> TT;
-    f32x16 acc[2];
+    // bf16 / bf16x3 (two waves per SIMD, 256 VGPRs): two accumulators only in the operand-swapped last layer --
+    // layers 1-2 hold both their input and their output fragments (192 VGPRs at bf16x3) and have no registers to
+    // spare; the other wave of the SIMD fills the gaps between dependent MFMAs
+    constexpr int NA = (SWAP || NS == 3) ? 2 : 1;
+    f32x16 acc[NA];
     acc[0] = init;
-    acc[1] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (NA == 2) acc[NA - 1] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     u32x4 wf[2][NS];
     auto load = [&](int ks, u32x4 (&dst)[NS]) {
 #pragma unroll
         for (int part = 0; part < NS; ++part)
-            dst[part] = *(const u32x4 *)(cb + part * 16384 + ((slot0 + ks) * 64 + lane) * 16);
+            dst[part] = *(const u32x4 *)(cb + part * (e_slots(NS) * 1024) + ((slot0 + ks) * 64 + lane) * 16);
     };
     load(0, wf[0]);
 #pragma unroll
@@ -181,10 +195,12 @@ __device__ __forceinline__ f32x16 tile_gemm(const uint8_t *cb, int slot0, int la
 #pragma unroll
         for (int term = 0; term < TT::N; ++term) {
             const u32x4 w = wf[ks & 1][TT::A[term]], x = act[TT::B[term]][ks];
-            acc[ks & 1] = SWAP ? mfma(x, w, acc[ks & 1]) : mfma(w, x, acc[ks & 1]);
+            f32x16 &d = acc[ks & (NA - 1)];
+            d = SWAP ? mfma(x, w, d) : mfma(w, x, d);
         }
     }
-    return acc[0] + acc[1];
+    if (NA == 2) return acc[0] + acc[NA - 1];
+    return acc[0];
 }
 
 __device__ __forceinline__ float half_max(float x) {   // max(x(lane), x(lane ^ 32))
@@ -242,37 +258,45 @@ __global__ __launch_bounds__(e_waves(NS) * 64) void enc_kernel(EncArgs a) {
         }
         return v;
     };
-    // ---- layer 1: 64 -> 128 (chunk 0 in buffer 0)
+    // Chunk `cur` is resident in buffer cur & 1 and chunk cur + 1 is on its way into the other one.  Moving on to the
+    // next chunk is one barrier (it has landed; everybody is done with the buffer the one after it will overwrite).
+    constexpr int S = e_slots(NS), NCH = e_nchunk(NS);
+    int cur = 0;
     stage_chunk<NS>(a.packed, 1, l_buf + CHB, wave, lane);
+    auto chunk_of = [&](int slot) -> const uint8_t * {       // slot: wave-uniform
+        const int c = slot / S;
+        if (c != cur) {
+            __syncthreads();
+            cur = c;
+            if (c + 1 < NCH) stage_chunk<NS>(a.packed, c + 1, l_buf + ((c + 1) & 1) * CHB, wave, lane);
+        }
+        return l_buf + (c & 1) * CHB;
+    };
+    // ---- layer 1: 64 -> 128
     u32x4 f2[NS][16];        // k-steps 0..7
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-        const f32x16 acc = tile_gemm<NS, 4, false>(l_buf, mt * 4, lane, f1, bias_tile(EB_1, mt));
+        const int slot = ES_L1 + 4 * mt;
+        const uint8_t *cb = chunk_of(slot);
+        const f32x16 acc = tile_gemm<NS, 4, false>(cb, slot % S, lane, f1, bias_tile(EB_1, mt));
         relu_split<NS>(acc, f2, mt);
     }
-    __syncthreads();
-    // ---- layer 2: 128 -> 256 (chunks 1..4)
+    // ---- layer 2: 128 -> 256
     u32x4 f3[NS][16];
 #pragma unroll
-    for (int c = 1; c < 5; ++c) {
-        const uint8_t *cb = l_buf + (c & 1) * CHB;
-        stage_chunk<NS>(a.packed, c + 1, l_buf + ((c + 1) & 1) * CHB, wave, lane);
-#pragma unroll
-        for (int mtl = 0; mtl < 2; ++mtl) {
-            const int mt = 2 * (c - 1) + mtl;
-            const f32x16 acc = tile_gemm<NS, 8, false>(cb, mtl * 8, lane, f2, bias_tile(EB_2, mt));
-            relu_split<NS>(acc, f3, mt);
-        }
-        __syncthreads();
+    for (int mt = 0; mt < 8; ++mt) {
+        const int slot = ES_L2 + 8 * mt;
+        const uint8_t *cb = chunk_of(slot);
+        const f32x16 acc = tile_gemm<NS, 8, false>(cb, slot % S, lane, f2, bias_tile(EB_2, mt));
+        relu_split<NS>(acc, f3, mt);
     }
     // ---- layer 3: 256 -> 512, operands swapped: accumulator register r = point (r&3) + 8*(r>>2) + 4h of the tile,
-    //      lane column = output feature.  Chunks 5..20, one 32-feature tile each.
+    //      lane column = output feature; one 32-feature tile at a time.
     const bool ragged = tile0 + TILE > N;
     for (int nt = 0; nt < 16; ++nt) {
-        const int c = 5 + nt;
-        const uint8_t *cb = l_buf + (c & 1) * CHB;
-        if (c + 1 < E_NCHUNK) stage_chunk<NS>(a.packed, c + 1, l_buf + ((c + 1) & 1) * CHB, wave, lane);
-        f32x16 acc = tile_gemm<NS, 16, true>(cb, 0, lane, f3, zero16);
+        const int slot = ES_L3 + 16 * nt;
+        const uint8_t *cb = chunk_of(slot);
+        f32x16 acc = tile_gemm<NS, 16, true>(cb, slot % S, lane, f3, zero16);
         const float shift = ((const float *)l_bias)[EB_3 + 32 * nt + pl];
         if (a.feat != nullptr) {       // optional (B,512,N) output: 4 consecutive points per 16-byte store
             float *fo = a.feat + ((size_t)bi * EC4 + 32 * nt + pl) * N + tile0 + 4 * h;
@@ -303,8 +327,8 @@ __global__ __launch_bounds__(e_waves(NS) * 64) void enc_kernel(EncArgs a) {
         m = half_max(m);
         // max_p relu(x_p + shift) = relu(max_p x_p + shift): fp32 addition is monotonic
         if (!h) l_wmax[wave * EC4 + 32 * nt + pl] = tile0 < N ? fmaxf(m + shift, 0.f) : 0.f;
-        __syncthreads();
     }
+    __syncthreads();
     // ---- combine the waves, one integer atomicMax per feature (all values are >= 0, so the bit patterns order)
     for (int f = threadIdx.x; f < EC4; f += EW * 64) {
         float m = l_wmax[f];
