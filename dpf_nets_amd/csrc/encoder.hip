@@ -49,9 +49,17 @@ __host__ __device__ constexpr int e_nchunk(int NS) { return (ES_TOTAL + e_slots(
 __host__ __device__ constexpr int ep_chunk_bytes(int NS) { return NS * e_slots(NS) * 1024; }
 __host__ __device__ constexpr size_t ep_bytes(int NS) { return EP_CHUNKS + (size_t)e_nchunk(NS) * ep_chunk_bytes(NS); }
 
-// waves (tiles) per workgroup: 8 = two per SIMD with 256 VGPRs each; bf16x6 keeps 192 VGPRs of layer-3 operand
-// fragments and runs one wave per SIMD (4 waves, 512 VGPRs)
-__host__ __device__ constexpr int e_waves(int NS) { return NS == 3 ? 4 : 8; }
+// A workgroup covers 8 tiles (256 points) of one cloud.  TP = tiles per wave:
+//   TP = 1 (default): 8 waves, two per SIMD with 256 VGPRs each (bf16x6: 4 waves, one per SIMD -- it keeps 192 VGPRs
+//          of layer-3 operand fragments);
+//   TP = 2 (-DDPF_ENC_TP=2; bf16, bf16x3): 4 waves, one per SIMD with 484 VGPRs; every weight fragment read from
+//          LDS feeds the MFMAs of both tiles, halving the LDS->VGPR traffic.  Measured r01 at cfg-2: 56.1 us vs
+//          50.5 us for TP = 1 -- a lone wave per SIMD does not hide its own LDS and MFMA latencies.
+#ifndef DPF_ENC_TP
+#define DPF_ENC_TP 1
+#endif
+__host__ __device__ constexpr int e_tp(int NS) { return NS == 3 ? 1 : DPF_ENC_TP; }
+__host__ __device__ constexpr int e_waves(int NS) { return NS == 3 ? 4 : 8 / e_tp(NS); }
 
 // K index held by element j of lane-half kg in k-step ks = the feature that register 8*(ks&1)+j of accumulator
 // tile ks>>1 holds in lane-half kg (acc_feature)
@@ -170,18 +178,19 @@ __device__ __forceinline__ void stage_chunk(const uint8_t *packed, int c, uint8_
     }
 }
 
-// One output tile: K k-steps of fragments at slots [slot0, slot0 + K) of the chunk at cb, two accumulators (even / odd k-steps)
-// so that consecutive MFMAs are independent.  SWAP: the activations are the A operand and the weights the B operand.
-template <int NS, int K, bool SWAP>
-__device__ __forceinline__ f32x16 tile_gemm(const uint8_t *cb, int slot0, int lane, const u32x4 (&act)[NS][16], f32x16 init) {
+// One output tile for each of the wave's TP point tiles: K k-steps of fragments at slots [slot0, slot0 + K) of the
+// chunk at cb; every fragment read feeds the MFMAs of all TP tiles.  SWAP: the activations are the A operand and the
+// weights the B operand.  NA accumulators per tile (even / odd k-steps) keep consecutive MFMAs independent.
+template <int NS, int K, bool SWAP, int TP, int NA>
+__device__ __forceinline__ void tile_gemm(const uint8_t *cb, int slot0, int lane, const u32x4 (&act)[TP][NS][16],
+                                          f32x16 (&out)[TP]) {     // out: in = initial value, out = result
     typedef Terms<NS> TT;
-    // bf16 / bf16x3 (two waves per SIMD, 256 VGPRs): two accumulators only in the operand-swapped last layer --
-    // layers 1-2 hold both their input and their output fragments (192 VGPRs at bf16x3) and have no registers to
-    // spare; the other wave of the SIMD fills the gaps between dependent MFMAs
-    constexpr int NA = (SWAP || NS == 3) ? 2 : 1;
-    f32x16 acc[NA];
-    acc[0] = init;
-    if (NA == 2) acc[NA - 1] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 acc[TP][NA];
+#pragma unroll
+    for (int q = 0; q < TP; ++q) {
+        acc[q][0] = out[q];
+        if (NA == 2) acc[q][NA - 1] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    }
     u32x4 wf[2][NS];
     auto load = [&](int ks, u32x4 (&dst)[NS]) {
 #pragma unroll
@@ -193,14 +202,16 @@ __device__ __forceinline__ f32x16 tile_gemm(const uint8_t *cb, int slot0, int la
     for (int ks = 0; ks < K; ++ks) {
         if (ks + 1 < K) load(ks + 1, wf[(ks + 1) & 1]);
 #pragma unroll
-        for (int term = 0; term < TT::N; ++term) {
-            const u32x4 w = wf[ks & 1][TT::A[term]], x = act[TT::B[term]][ks];
-            f32x16 &d = acc[ks & (NA - 1)];
-            d = SWAP ? mfma(x, w, d) : mfma(w, x, d);
-        }
+        for (int term = 0; term < TT::N; ++term)
+#pragma unroll
+            for (int q = 0; q < TP; ++q) {
+                const u32x4 w = wf[ks & 1][TT::A[term]], x = act[q][TT::B[term]][ks];
+                f32x16 &d = acc[q][ks & (NA - 1)];
+                d = SWAP ? mfma(x, w, d) : mfma(w, x, d);
+            }
     }
-    if (NA == 2) return acc[0] + acc[NA - 1];
-    return acc[0];
+#pragma unroll
+    for (int q = 0; q < TP; ++q) out[q] = NA == 2 ? acc[q][0] + acc[q][NA - 1] : acc[q][0];
 }
 
 __device__ __forceinline__ float half_max(float x) {   // max(x(lane), x(lane ^ 32))
@@ -211,7 +222,10 @@ __device__ __forceinline__ float half_max(float x) {   // max(x(lane), x(lane ^ 
 template <int NS>
 __global__ __launch_bounds__(e_waves(NS) * 64) void enc_kernel(EncArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    constexpr int CHB = ep_chunk_bytes(NS), EW = e_waves(NS);
+    constexpr int CHB = ep_chunk_bytes(NS), EW = e_waves(NS), TP = e_tp(NS);
+    // accumulators per tile and layer: two where the registers allow it (one wave per SIMD has nobody else to fill
+    // the gap between dependent MFMAs)
+    constexpr int NA12 = (EW == 4 && TP == 1) ? 2 : 1, NA3 = TP == 2 ? 1 : 2;
     uint8_t *l_a0 = smem, *l_bias = smem + 4096, *l_buf = smem + 8192;
     float *l_wmax = (float *)(smem + 8192 + 2 * CHB);             // [EW][512]
 
@@ -219,11 +233,15 @@ __global__ __launch_bounds__(e_waves(NS) * 64) void enc_kernel(EncArgs a) {
     const int lane = threadIdx.x & 63, h = lane >> 5, pl = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int N = a.N;
-    const int tile0 = (blockIdx.x * EW + wave) * TILE;            // first point of this wave's tile
-    const int n = tile0 + pl;
-    const int nc = min(n, N - 1);
     const float *xc = a.x + (size_t)bi * 3 * N;
-    const float px = xc[nc], py = xc[N + nc], pz = xc[2 * (size_t)N + nc];
+    int tile0[TP];                                                // first point of each of this wave's tiles
+    float px[TP], py[TP], pz[TP];
+#pragma unroll
+    for (int q = 0; q < TP; ++q) {
+        tile0[q] = ((blockIdx.x * EW + wave) * TP + q) * TILE;
+        const int nc = min(tile0[q] + pl, N - 1);
+        px[q] = xc[nc]; py[q] = xc[N + nc]; pz[q] = xc[2 * (size_t)N + nc];
+    }
 
     // A0 + bias block (8 KiB) and chunk 0
 #pragma unroll
@@ -234,10 +252,11 @@ __global__ __launch_bounds__(e_waves(NS) * 64) void enc_kernel(EncArgs a) {
 
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // ---- layer 0: 3 -> 64 on the matrix core, fp32-accurate (3-way split of x, y | z)
-    u32x4 f1[NS][16];        // only k-steps 0..3 are used
-    {
-        const u32x4 b0 = input_fragment(h ? py : px, h);
-        u32x4 b1 = input_fragment(pz, 0);
+    u32x4 f1[TP][NS][16];        // only k-steps 0..3 are used
+#pragma unroll
+    for (int q = 0; q < TP; ++q) {
+        const u32x4 b0 = input_fragment(h ? py[q] : px[q], h);
+        u32x4 b1 = input_fragment(pz[q], 0);
         if (h) b1 = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -245,7 +264,7 @@ __global__ __launch_bounds__(e_waves(NS) * 64) void enc_kernel(EncArgs a) {
             const u32x4 a01 = *(const u32x4 *)(l_a0 + ((t * 2 + 1) * 64 + lane) * 16);
             f32x16 acc = mfma(a00, b0, zero16);
             acc = mfma(a01, b1, acc);
-            relu_split<NS>(acc, f1, t);
+            relu_split<NS>(acc, f1[q], t);
         }
     }
     auto bias_tile = [&](int off, int mt) {       // accumulator-order shift of M tile mt
@@ -273,60 +292,74 @@ __global__ __launch_bounds__(e_waves(NS) * 64) void enc_kernel(EncArgs a) {
         return l_buf + (c & 1) * CHB;
     };
     // ---- layer 1: 64 -> 128
-    u32x4 f2[NS][16];        // k-steps 0..7
+    u32x4 f2[TP][NS][16];        // k-steps 0..7
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const int slot = ES_L1 + 4 * mt;
         const uint8_t *cb = chunk_of(slot);
-        const f32x16 acc = tile_gemm<NS, 4, false>(cb, slot % S, lane, f1, bias_tile(EB_1, mt));
-        relu_split<NS>(acc, f2, mt);
+        f32x16 acc[TP];
+#pragma unroll
+        for (int q = 0; q < TP; ++q) acc[q] = bias_tile(EB_1, mt);
+        tile_gemm<NS, 4, false, TP, NA12>(cb, slot % S, lane, f1, acc);
+#pragma unroll
+        for (int q = 0; q < TP; ++q) relu_split<NS>(acc[q], f2[q], mt);
     }
     // ---- layer 2: 128 -> 256
-    u32x4 f3[NS][16];
+    u32x4 f3[TP][NS][16];
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
         const int slot = ES_L2 + 8 * mt;
         const uint8_t *cb = chunk_of(slot);
-        const f32x16 acc = tile_gemm<NS, 8, false>(cb, slot % S, lane, f2, bias_tile(EB_2, mt));
-        relu_split<NS>(acc, f3, mt);
+        f32x16 acc[TP];
+#pragma unroll
+        for (int q = 0; q < TP; ++q) acc[q] = bias_tile(EB_2, mt);
+        tile_gemm<NS, 8, false, TP, NA12>(cb, slot % S, lane, f2, acc);
+#pragma unroll
+        for (int q = 0; q < TP; ++q) relu_split<NS>(acc[q], f3[q], mt);
     }
     // ---- layer 3: 256 -> 512, operands swapped: accumulator register r = point (r&3) + 8*(r>>2) + 4h of the tile,
     //      lane column = output feature; one 32-feature tile at a time.
-    const bool ragged = tile0 + TILE > N;
     for (int nt = 0; nt < 16; ++nt) {
         const int slot = ES_L3 + 16 * nt;
         const uint8_t *cb = chunk_of(slot);
-        f32x16 acc = tile_gemm<NS, 16, true>(cb, slot % S, lane, f3, zero16);
+        f32x16 acc[TP];
+#pragma unroll
+        for (int q = 0; q < TP; ++q) acc[q] = zero16;
+        tile_gemm<NS, 16, true, TP, NA3>(cb, slot % S, lane, f3, acc);
         const float shift = ((const float *)l_bias)[EB_3 + 32 * nt + pl];
-        if (a.feat != nullptr) {       // optional (B,512,N) output: 4 consecutive points per 16-byte store
-            float *fo = a.feat + ((size_t)bi * EC4 + 32 * nt + pl) * N + tile0 + 4 * h;
+        float best = -__builtin_inff();
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int p0 = tile0 + 4 * h + 8 * q;
-                float v[4];
+        for (int q = 0; q < TP; ++q) {
+            if (a.feat != nullptr) {       // optional (B,512,N) output: 4 consecutive points per 16-byte store
+                float *fo = a.feat + ((size_t)bi * EC4 + 32 * nt + pl) * N + tile0[q] + 4 * h;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[4 * q + e] + shift, 0.f);
-                if (p0 + 3 < N && (N & 3) == 0) {
-                    *(f32x4 *)(fo + 8 * q) = f32x4{v[0], v[1], v[2], v[3]};
-                } else {
+                for (int g = 0; g < 4; ++g) {
+                    const int p0 = tile0[q] + 4 * h + 8 * g;
+                    float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (p0 + e < N) fo[8 * q + e] = v[e];
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[q][4 * g + e] + shift, 0.f);
+                    if (p0 + 3 < N && (N & 3) == 0) {
+                        *(f32x4 *)(fo + 8 * g) = f32x4{v[0], v[1], v[2], v[3]};
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (p0 + e < N) fo[8 * g + e] = v[e];
+                    }
                 }
             }
-        }
-        if (ragged) {
+            if (tile0[q] + TILE > N) {     // ragged or empty tile: its missing points do not take part in the max
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (tile0 + (r & 3) + 8 * (r >> 2) + 4 * h >= N) acc[r] = -__builtin_inff();
-        }
-        float m = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+                for (int r = 0; r < 16; ++r)
+                    if (tile0[q] + (r & 3) + 8 * (r >> 2) + 4 * h >= N) acc[q][r] = -__builtin_inff();
+            }
+            float m = fmaxf(fmaxf(acc[q][0], acc[q][1]), acc[q][2]);
 #pragma unroll
-        for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, acc[r]), acc[r + 1]);
-        m = fmaxf(m, acc[15]);
-        m = half_max(m);
-        // max_p relu(x_p + shift) = relu(max_p x_p + shift): fp32 addition is monotonic
-        if (!h) l_wmax[wave * EC4 + 32 * nt + pl] = tile0 < N ? fmaxf(m + shift, 0.f) : 0.f;
+            for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, acc[q][r]), acc[q][r + 1]);
+            best = fmaxf(best, fmaxf(m, acc[q][15]));
+        }
+        best = half_max(best);
+        // max_p relu(x_p + shift) = relu(max_p x_p + shift): fp32 addition is monotonic; an all-empty wave gives 0
+        if (!h) l_wmax[wave * EC4 + 32 * nt + pl] = fmaxf(best + shift, 0.f);
     }
     __syncthreads();
     // ---- combine the waves, one integer atomicMax per feature (all values are >= 0, so the bit patterns order)
@@ -344,7 +377,7 @@ int e_ns_of(int precision) {
 
 template <int NS>
 int launch_enc(const EncArgs &a, hipStream_t s) {
-    constexpr int EW = e_waves(NS), EWG_POINTS = EW * TILE;
+    constexpr int EW = e_waves(NS), EWG_POINTS = EW * e_tp(NS) * TILE;
     const int lds = 8192 + 2 * ep_chunk_bytes(NS) + EW * EC4 * 4;
     static bool attr = false;
     if (!attr) {
