@@ -142,14 +142,15 @@ def kernel_timings(dec, z, g, tgt_pm, L, precision):
         def fn(b, n, a, m, c, r1, j1, r2, j2, w, nw, st_):
             return lib().dpf_nndistance_sym(b, n, a, m, c, r1, j1, r2, j2, cdb.data_ptr(), w, nw, st_)
     else:
-        sized, fn = BK.nn_impl_entry(impl) if impl != "brute" else (None, None)
+        sized, fn = BK.nn_impl_entry(impl) if impl not in ("brute", "auto") else (None, None)
     nws = sized(B, N, N) if sized else 0
     ws = torch.empty((max(nws, 16),), dtype=torch.uint8, device=z.device)
 
     def k_nn():
-        if impl == "brute":
-            lib().dpf_nndistance(B, N, pm.data_ptr(), N, tgt_pm.data_ptr(), d1.data_ptr(), i1.data_ptr(),
-                                 d2.data_ptr(), i2.data_ptr(), current_stream())
+        if impl in ("brute", "auto"):
+            (lib().dpf_nndistance if impl == "brute" else lib().dpf_nndistance_auto)(
+                B, N, pm.data_ptr(), N, tgt_pm.data_ptr(), d1.data_ptr(), i1.data_ptr(), d2.data_ptr(), i2.data_ptr(),
+                current_stream())
         else:
             fn(B, N, pm.data_ptr(), N, tgt_pm.data_ptr(), d1.data_ptr(), i1.data_ptr(), d2.data_ptr(), i2.data_ptr(),
                ws.data_ptr(), nws, current_stream())

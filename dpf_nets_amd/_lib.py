@@ -16,6 +16,7 @@ _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_
 # name -> (restype, argtypes); must list every symbol include/dpf_hip.h declares
 SIGNATURES = {
     "dpf_nndistance": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dpf_nndistance_auto": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dpf_nndistance_strided": (_i, [_i, _i, _vp, ctypes.c_long, _i, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _vp]),
     "dpf_nndistance_workspace_bytes": (_sz, [_i, _i, _i]),
     "dpf_nndistance_ws": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -19,9 +19,11 @@
 // queue is a superset of what the final threshold selects: ~ln(#tiles) record
 // lows plus near-ties).  Afterwards the queue is filtered with the final s_min
 // and only those few tiles are evaluated with the exact formula and the
-// (d, index) lexicographic rule.  A queue overflow (pathological data: thousands
-// of near-ties) makes the wave rescan everything exactly, so the result is exact
-// for any finite input.
+// (d, index) lexicographic rule.  When a lane's queue is full of genuine near-ties
+// (duplicate points, lattice data) its oldest entry is settled exactly on the spot,
+// so the result is exact for any finite input and the cost degrades gracefully.
+// The surrogate works on coordinates translated to the mean of the first 64
+// candidates: tau then scales with the extent of the data, not with its offset.
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <stdint.h>
@@ -55,73 +57,46 @@ __device__ __forceinline__ void split2(float x, uint32_t &hi, uint32_t &lo) {   
 
 __host__ __device__ inline int tiles_of(int n) { return (n + 31) / 32; }
 
-// ---- prep: per cloud, the MFMA fragments of its points in both roles + the cloud's max |p|^2 ----
+// ---- MFMA fragments of a point, built in the kernel itself (a separate pre-pass kernel cost 10 us at cfg-2) ----
 // fragment of a 32-point tile: lane (i = point in tile, h) holds K slots 8h..8h+7 (16 bytes)
 //   slots: [x:0-3] [y:4-7] [z:8-11] [norm:12-14] [15: 0]
 //   role A (candidate): coord -> (ch, ch, cl, cl),   norm -> (wh, wm, wl)      w = (x*x + y*y) + z*z
 //   role B (query):     coord -> (qh, ql, qh, ql) of -2q,  norm -> (1, 1, 1)
-struct PrepSet {
-    const float *xyz;   // (B, n, 3)
-    uint4 *fa, *fb;     // (B, ntiles, 64)
-    float *tmax;        // (B, ntiles) largest |p|^2 of each tile
-    float4 *pts;        // (B, ntiles*32) points as (x, y, z, 0): one 16-byte load per exact evaluation
-    int n;
-};
-struct PrepArgs { PrepSet s[2]; };
-
-__global__ __launch_bounds__(256) void nnm_prep_kernel(PrepArgs args) {
-    const PrepSet S = args.s[blockIdx.z];
-    const int bi = blockIdx.y, n = S.n;
-    const int gid = blockIdx.x * 256 + threadIdx.x;            // one thread per (tile, lane)
-    const int tile = gid >> 6, lane = gid & 63, i = lane & 31, h = lane >> 5;
-    if (tile >= tiles_of(n)) return;
-    const int p = tile * 32 + i;
-    float x = 0.f, y = 0.f, z = 0.f;
-    const bool live = p < n;
-    if (live) {
-        const float *src = S.xyz + ((size_t)bi * n + p) * 3;
-        x = src[0]; y = src[1]; z = src[2];
-    }
+__device__ __forceinline__ uint32_t cand_pair_hi(float c) { uint32_t hi, lo; split2(c, hi, lo); return hi | (hi << 16); }
+__device__ __forceinline__ void cand_coord(float c, uint32_t &w0, uint32_t &w1) {      // (ch, ch), (cl, cl)
+    uint32_t hi, lo;
+    split2(c, hi, lo);
+    w0 = hi | (hi << 16);
+    w1 = lo | (lo << 16);
+}
+// both halves of a candidate's fragment row; live = false: padding row with a huge surrogate (never a minimum)
+__device__ __forceinline__ void cand_fragment(float x, float y, float z, bool live, uint4 &h0, uint4 &h1) {
+    cand_coord(x, h0.x, h0.y);
+    cand_coord(y, h0.z, h0.w);
+    cand_coord(z, h1.x, h1.y);
     const float w = (x * x + y * y) + z * z;
-    uint32_t sa[16], sb[16];
-    const float c3[3] = {x, y, z};
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        uint32_t ch, cl, qh, ql;
-        split2(c3[c], ch, cl);
-        split2(-2.0f * c3[c], qh, ql);
-        sa[4 * c + 0] = ch; sa[4 * c + 1] = ch; sa[4 * c + 2] = cl; sa[4 * c + 3] = cl;
-        sb[4 * c + 0] = qh; sb[4 * c + 1] = ql; sb[4 * c + 2] = qh; sb[4 * c + 3] = ql;
-    }
-    {
-        // padding rows of the last tile: +big surrogate so they never reach a minimum
-        const float ww = live ? w : 3.0e38f;
-        const uint32_t wh = f2u(ww) & 0xFFFF0000u;
-        const float r1 = ww - u2f(wh);
-        const uint32_t wm = f2u(r1) & 0xFFFF0000u;
-        const float r2 = r1 - u2f(wm);
-        sa[12] = wh >> 16; sa[13] = live ? (wm >> 16) : 0u; sa[14] = live ? bf16_rne(r2) : 0u; sa[15] = 0u;
-        sb[12] = 0x3F80u; sb[13] = 0x3F80u; sb[14] = 0x3F80u; sb[15] = 0u;
-    }
-    uint4 oa, ob;
-    const int o = 8 * h;
-    oa.x = sa[o + 0] | (sa[o + 1] << 16); oa.y = sa[o + 2] | (sa[o + 3] << 16);
-    oa.z = sa[o + 4] | (sa[o + 5] << 16); oa.w = sa[o + 6] | (sa[o + 7] << 16);
-    ob.x = sb[o + 0] | (sb[o + 1] << 16); ob.y = sb[o + 2] | (sb[o + 3] << 16);
-    ob.z = sb[o + 4] | (sb[o + 5] << 16); ob.w = sb[o + 6] | (sb[o + 7] << 16);
-    const size_t off = ((size_t)bi * tiles_of(n) + tile) * 64 + lane;
-    S.fa[off] = oa;
-    S.fb[off] = ob;
-    float m = live ? w : 0.f;
-    for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
-    if (lane == 0) S.tmax[(size_t)bi * tiles_of(n) + tile] = m;
-    if (h == 0) S.pts[((size_t)bi * (tiles_of(n) + 1) + tile) * 32 + i] = make_float4(x, y, z, 0.f);   // +1 tile of slack per cloud
+    const float ww = live ? w : 3.0e38f;
+    const uint32_t wh = f2u(ww) & 0xFFFF0000u;
+    const float r1 = ww - u2f(wh);
+    const uint32_t wm = f2u(r1) & 0xFFFF0000u;
+    const float r2 = r1 - u2f(wm);
+    h1.z = (wh >> 16) | (live ? wm : 0u);                    // slots 12 (wh), 13 (wm)
+    h1.w = live ? bf16_rne(r2) : 0u;                          // slot 14 (wl), slot 15 = 0
+}
+// the half h of a query's fragment column
+__device__ __forceinline__ uint4 query_fragment(float x, float y, float z, int h) {
+    uint32_t ah, al, bh, bl;
+    split2(-2.0f * (h ? z : x), ah, al);
+    split2(-2.0f * y, bh, bl);
+    uint4 o;
+    o.x = ah | (al << 16); o.y = o.x;                         // (qh, ql, qh, ql)
+    o.z = h ? 0x3F803F80u : (bh | (bl << 16));                // h = 1: (1, 1 | 1, 0)
+    o.w = h ? 0x00003F80u : o.z;
+    return o;
 }
 
 struct MDir {
-    const float4 *qp, *cp;     // packed points of the query / candidate cloud
-    const uint4 *qfb, *cfa;    // query fragments (role B), candidate fragments (role A)
-    const float *qtmax, *ctmax;
+    const float *q, *c;        // (B, nq, 3) queries, (B, nc, 3) candidates
     float *dist;
     int *idx;
     int nq, nc;
@@ -148,35 +123,36 @@ __device__ __forceinline__ float dist3(float cx, float cy, float cz, float qx, f
 template <class P>
 __device__ __forceinline__ void exact_tile(P cp, int nc, int t, int tl, int h, float qx, float qy, float qz,
                                            float &best, int &bidx) {   // tl = tile index inside cp, t = global tile
-    float4 v[16];
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < 4; ++g) {                       // four points at a time: 16 live registers, not 64
+        float4 v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[4 * g + e] = cp[(size_t)tl * 32 + 8 * g + 4 * h + e];    // padded: always in range
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
+        for (int e = 0; e < 4; ++e) v[e] = cp[(size_t)tl * 32 + 8 * g + 4 * h + e];    // padded: always in range
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int k = t * 32 + 8 * g + 4 * h + e;
-            const float d = dist3(v[4 * g + e].x, v[4 * g + e].y, v[4 * g + e].z, qx, qy, qz);
+            const float d = dist3(v[e].x, v[e].y, v[e].z, qx, qy, qz);
             const bool better = k < nc && (d < best || (d == best && k < bidx));
             best = better ? d : best;
             bidx = better ? k : bidx;
         }
+    }
 }
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
 
-// A workgroup = 16 waves x 32 queries of one cloud.  The candidate cloud's MFMA fragments and
-// packed points are DMA'd into LDS once (global_load_lds, 64 tiles = 96 KiB per pass) and shared
-// by all 16 waves; per tile a wave issues one ds_read_b128, one MFMA and a v_min3 tree.
+// A workgroup = 16 waves x 32 queries of one cloud.  Per pass of 64 candidate tiles the workgroup builds the
+// candidates' MFMA fragments and packed points in LDS (96 KiB; two points per thread) and all 16 waves share them;
+// per tile a wave issues one ds_read_b128, one MFMA and a v_min3 tree.  R2 is taken over ALL candidates and over
+// the queries of THIS workgroup: the surrogate's error bound is per pair.
 __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint4 *sfrag = (uint4 *)lds;                                  // [CT][64]
     float4 *spts = (float4 *)(lds + CT * 1024);                    // [CT][32]
     unsigned short *qtile = (unsigned short *)(lds + CT * 1536);   // [QW][QCAP][64]
     float *qmin = (float *)(lds + CT * 1536 + QW * QCAP * 64 * 2); // [QW][QCAP][64]
+    __shared__ float s_r2[QW];
     const MDir A = args.d[blockIdx.z];
     const int bi = blockIdx.y;
     const int nq = A.nq, nc = A.nc;
@@ -186,18 +162,35 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
     const int qt = blockIdx.x * QW + wave;                                   // query tile of this wave
     const int nqt = tiles_of(nq), nct = tiles_of(nc);
     const bool wave_live = qt < nqt;
-    const float4 *__restrict__ cp = A.cp + (size_t)bi * (nct + 1) * 32;
-    const uint4 *__restrict__ cfa = A.cfa + (size_t)bi * nct * 64;
+    const float *__restrict__ cpts = A.c + (size_t)bi * nc * 3;
     const int j = qt * 32 + (lane & 31);
-    const float4 qv = A.qp[(size_t)bi * (nqt + 1) * 32 + min(qt, nqt - 1) * 32 + (lane & 31)];
-    const float qx = qv.x, qy = qv.y, qz = qv.z;
-    const uint4 bq = A.qfb[((size_t)bi * nqt + min(qt, nqt - 1)) * 64 + lane];
-    // R2 = largest |p|^2 of the two clouds (per-tile maxima from the prep kernel)
-    float r2 = 0.f;
-    for (int t = lane; t < nqt; t += 64) r2 = fmaxf(r2, A.qtmax[(size_t)bi * nqt + t]);
-    for (int t = lane; t < nct; t += 64) r2 = fmaxf(r2, A.ctmax[(size_t)bi * nct + t]);
-    for (int d = 32; d > 0; d >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, d));
-    const float tau = r2 * 2.44140625e-4f;                                    // 2^-12 * R2
+    const float *qsrc = A.q + ((size_t)bi * nq + min(j, nq - 1)) * 3;
+    const float qx = qsrc[0], qy = qsrc[1], qz = qsrc[2];
+    // The surrogate is evaluated on coordinates translated by mu = the mean of the first 64 candidates (every wave
+    // computes the same value: no barrier), so that R2 -- and with it the filter's tolerance tau -- scales with the
+    // extent of the data, not with its distance from the origin (an uncentred cloud made every pair a "near tie").
+    // Distances are translation invariant and fl(c - mu) is accurate to 2^-24 of ITSELF, which adds < 2^-21 * R2 to
+    // the surrogate's error; the exact evaluation keeps using the original coordinates.
+    float mux, muy, muz;
+    {
+        const float *src = cpts + (size_t)min(lane, nc - 1) * 3;
+        mux = src[0]; muy = src[1]; muz = src[2];
+        for (int d = 32; d > 0; d >>= 1) { mux += __shfl_xor(mux, d); muy += __shfl_xor(muy, d); muz += __shfl_xor(muz, d); }
+        mux *= 0.015625f; muy *= 0.015625f; muz *= 0.015625f;
+    }
+    const float qcx = qx - mux, qcy = qy - muy, qcz = qz - muz;
+    const uint4 bq = query_fragment(qcx, qcy, qcz, h);
+    // R2 >= |c - mu|^2 of every candidate and |q - mu|^2 of this workgroup's queries (the surrogate's error bound is
+    // per pair): the queries now, the candidates while their fragments are built (the first pass covers them all
+    // when nc <= 2048; otherwise a pre-scan)
+    float r2 = j < nq ? (qcx * qcx + qcy * qcy) + qcz * qcz : 0.f;
+    if (nct > CT)
+        for (int p = tid; p < nc; p += QW * 64) {
+            const float *src = cpts + (size_t)p * 3;
+            const float x = src[0] - mux, y = src[1] - muy, z = src[2] - muz;
+            r2 = fmaxf(r2, (x * x + y * y) + z * z);
+        }
+    float tau = 0.f;
 
     unsigned short *myq = qtile + (size_t)wave * QCAP * 64;
     float *mym = qmin + (size_t)wave * QCAP * 64;
@@ -209,12 +202,33 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
     for (int pass = 0; pass < npass; ++pass) {
         const int t0 = pass * CT, tn = min(CT, nct - t0);
         if (pass > 0) __syncthreads();                                        // everyone is done with the previous pass
-        // DMA: fragments (1 KiB per tile) and packed points (512 B per tile, two tiles per wave-instruction)
-        for (int t = wave; t < tn; t += QW)
-            __builtin_amdgcn_global_load_lds((glb_void *)(cfa + (size_t)(t0 + t) * 64 + lane), (lds_void *)(sfrag + t * 64), 16, 0, 0);
-        for (int t = wave * 2; t < tn; t += QW * 2)
-            __builtin_amdgcn_global_load_lds((glb_void *)(cp + (size_t)(t0 + t) * 32 + lane), (lds_void *)(spts + t * 32), 16, 0, 0);
-        __syncthreads();                                                      // drains the DMA (vmcnt) and publishes it
+#pragma unroll
+        for (int k = 0; k < CT * 32 / (QW * 64); ++k) {                       // two candidates per thread
+            const int pl = tid + k * QW * 64, t = pl >> 5, i = pl & 31, p = t0 * 32 + pl;
+            if (t < tn) {
+                const bool live = p < nc;
+                float x = 0.f, y = 0.f, z = 0.f;
+                if (live) { const float *src = cpts + (size_t)p * 3; x = src[0]; y = src[1]; z = src[2]; }
+                uint4 f0, f1;
+                const float cx = live ? x - mux : 0.f, cy = live ? y - muy : 0.f, cz = live ? z - muz : 0.f;
+                cand_fragment(cx, cy, cz, live, f0, f1);
+                sfrag[t * 64 + i] = f0;
+                sfrag[t * 64 + 32 + i] = f1;
+                spts[t * 32 + i] = make_float4(x, y, z, 0.f);                 // original coordinates: exact evaluation
+                if (pass == 0) r2 = fmaxf(r2, (cx * cx + cy * cy) + cz * cz);
+            }
+        }
+        if (pass == 0) {
+            for (int d = 32; d > 0; d >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, d));
+            if (lane == 0) s_r2[wave] = r2;
+        }
+        __syncthreads();                                                      // fragments and points are published
+        if (pass == 0) {
+            float m = s_r2[0];
+#pragma unroll
+            for (int w = 1; w < QW; ++w) m = fmaxf(m, s_r2[w]);
+            tau = m * 2.44140625e-4f;                                         // 2^-12 * R2
+        }
         if (wave_live) {
             auto visit = [&](int t, float m) {
                 if (m <= smin + tau) {                                        // record low or near-tie of the running minimum
@@ -228,8 +242,16 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
                         }
                         qcount = keep;
                     }
-                    if (qcount < QCAP) { myq[qcount * 64 + lane] = (unsigned short)t; mym[qcount * 64 + lane] = m; ++qcount; }
-                    else qcount = QCAP + 1;                                   // still full of near-ties: exact rescan
+                    if (qcount < QCAP) {
+                        myq[qcount * 64 + lane] = (unsigned short)t; mym[qcount * 64 + lane] = m; ++qcount;
+                    } else {
+                        // still full of near-ties (duplicate points, lattice data): settle the oldest entry exactly
+                        // now -- evaluation order does not matter for the (d, index) rule -- and reuse its slot
+                        const int tl = myq[lane];
+                        exact_tile(spts, nc, t0 + tl, tl, h, qx, qy, qz, best, bidx);
+                        for (int e = 0; e + 1 < QCAP; ++e) { myq[e * 64 + lane] = myq[(e + 1) * 64 + lane]; mym[e * 64 + lane] = mym[(e + 1) * 64 + lane]; }
+                        myq[(QCAP - 1) * 64 + lane] = (unsigned short)t; mym[(QCAP - 1) * 64 + lane] = m;
+                    }
                 }
                 smin = fminf(smin, m);
             };
@@ -244,9 +266,7 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
             // exact evaluation of this pass's surviving tiles against the pass-local threshold (the
             // global minimum can only be lower, so this is a superset; extra exact evaluations are harmless)
             const float thr = fminf(smin, __shfl_xor(smin, 32)) + tau;
-            if (__builtin_amdgcn_ballot_w64(qcount > QCAP) != 0) {
-                for (int tt = 0; tt < tn; ++tt) exact_tile(spts, nc, t0 + tt, tt, h, qx, qy, qz, best, bidx);
-            } else {
+            {
                 int nsurv = 0;
                 for (int e = 0; e < QCAP; ++e)
                     if (e < qcount && mym[e * 64 + lane] <= thr) { myq[nsurv * 64 + lane] = myq[e * 64 + lane]; ++nsurv; }
@@ -278,38 +298,23 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
 }  // namespace
 
 extern "C" size_t dpf_nndistance_mfma_workspace_bytes(int b, int n, int m) {
-    if (b <= 0 || n <= 0 || m <= 0) return 0;
-    const size_t t = (size_t)tiles_of(n) + tiles_of(m);
-    return (size_t)b * t * (64 * 16 * 2 + 32 * 16 + 4) + (size_t)b * 2 * 32 * 16 + 256;
+    (void)b; (void)n; (void)m;
+    return 0;            // the fragments are built inside the kernel since r01; the argument is kept for the ABI
 }
 
 extern "C" int dpf_nndistance_mfma(int b, int n, const float *xyz, int m, const float *xyz2, float *result,
                                    int *result_i, float *result2, int *result2_i, void *workspace,
                                    size_t workspace_bytes, dpf_stream_t stream) {
+    (void)workspace; (void)workspace_bytes;
     if (b < 0 || n <= 0 || m <= 0) return DPF_EINVAL;
     if (b == 0) return 0;
     if (!xyz || !xyz2 || !result || !result_i || !result2 || !result2_i) return DPF_EINVAL;
-    if (b > 65535 || n > 65535 * 32 || m > 65535 * 32 || !workspace ||
-        workspace_bytes < dpf_nndistance_mfma_workspace_bytes(b, n, m) || (n < 32 && m < 32))
+    if (b > 65535 || n > 65535 * 32 || m > 65535 * 32 || (n < 32 && m < 32))
         return dpf_nndistance(b, n, xyz, m, xyz2, result, result_i, result2, result2_i, stream);
     hipStream_t s = (hipStream_t)stream;
-    const size_t nt = tiles_of(n), mt = tiles_of(m);
-    uint4 *fa1 = (uint4 *)workspace;
-    uint4 *fb1 = fa1 + (size_t)b * nt * 64;
-    uint4 *fa2 = fb1 + (size_t)b * nt * 64;
-    uint4 *fb2 = fa2 + (size_t)b * mt * 64;
-    float4 *p1 = (float4 *)(fb2 + (size_t)b * mt * 64);
-    float4 *p2 = p1 + (size_t)b * (nt + 1) * 32;
-    float *tm1 = (float *)(p2 + (size_t)b * (mt + 1) * 32);
-    float *tm2 = tm1 + (size_t)b * nt;
-    PrepArgs pa;
-    pa.s[0] = PrepSet{xyz, fa1, fb1, tm1, p1, n};
-    pa.s[1] = PrepSet{xyz2, fa2, fb2, tm2, p2, m};
-    const int tmax = (int)(nt > mt ? nt : mt);
-    hipLaunchKernelGGL(nnm_prep_kernel, dim3((tmax * 64 + 255) / 256, b, 2), dim3(256), 0, s, pa);
     MArgs ma;
-    ma.d[0] = MDir{p1, p2, fb1, fa2, tm1, tm2, result, result_i, n, m};      // nndistance.cu:126
-    ma.d[1] = MDir{p2, p1, fb2, fa1, tm2, tm1, result2, result2_i, m, n};    // nndistance.cu:127
+    ma.d[0] = MDir{xyz, xyz2, result, result_i, n, m};       // nndistance.cu:126
+    ma.d[1] = MDir{xyz2, xyz, result2, result2_i, m, n};     // nndistance.cu:127
     ma.debug = 0;
     const int nmax = n > m ? n : m;
     const int lds = CT * 1536 + QW * QCAP * 64 * 6;
@@ -321,4 +326,17 @@ extern "C" int dpf_nndistance_mfma(int b, int n, const float *xyz, int m, const 
     }
     hipLaunchKernelGGL(nnm_kernel, dim3((nmax + QW * 32 - 1) / (QW * 32), b, 2), dim3(QW * 64), lds, s, ma);
     return (int)hipGetLastError();
+}
+
+// Same contract and the same bits as dpf_nndistance; picks the matrix-core filtered kernel where it measured faster
+// (r01, tools/nn_impl_sweep.py: 31 vs 52 us at B=32, n=m=2048; 90 vs 191 us at B=8, n=m=8192) -- enough pairs to
+// amortise building the fragments and enough 512-query workgroups to fill the chip -- and the VALU scan otherwise
+// (small clouds and small batches are launch-bound either way; few workgroups leave the matrix cores idle).
+extern "C" int dpf_nndistance_auto(int b, int n, const float *xyz, int m, const float *xyz2, float *result, int *result_i,
+                                   float *result2, int *result2_i, dpf_stream_t stream) {
+    const double pairs = 2.0 * (double)b * (double)n * (double)m;
+    const long wgs = (long)b * ((n + QW * 32 - 1) / (QW * 32) + (m + QW * 32 - 1) / (QW * 32));
+    if (b > 0 && n > 0 && m > 0 && pairs >= 1.0e8 && wgs >= 128)
+        return dpf_nndistance_mfma(b, n, xyz, m, xyz2, result, result_i, result2, result2_i, nullptr, 0, stream);
+    return dpf_nndistance(b, n, xyz, m, xyz2, result, result_i, result2, result2_i, stream);
 }

@@ -12,16 +12,18 @@ import torch
 from ..._lib import lib, check, current_stream
 
 
-# Chamfer forward implementation; all three return identical bits (tests/test_gpu_chamfer.py):
-#   "brute"  O(n*m) exact VALU scan at ~75 % of its issue bound, data-independent cost (default)
-#   "mfma"   matrix-core filter (one bf16 MFMA per 32x32 pairs) + exact verification of the few
-#            candidates that can win; r01: 35 + 10 us vs 50 us brute on cfg-2 -- not yet a clear win
+# Chamfer forward implementation; all return identical bits (tests/test_gpu_chamfer.py):
+#   "auto"   (default) dpf_nndistance_auto: "mfma" for big problems (>= 1e8 pair evaluations, >= 128 workgroups),
+#            "brute" otherwise
+#   "brute"  O(n*m) exact VALU scan at ~80 % of its issue bound, data-independent cost
+#   "mfma"   matrix-core filter (one bf16 MFMA per 32x32 pairs) + exact verification of the few candidates that can
+#            win, fragments built in the kernel; r01: 31 us vs 52 us brute on cfg-2, 90 vs 191 us at B=8, N=8192
 #   "sorted" x-sorted pruned exact scan (pays off only when both clouds cover the same region)
 #   "sym"    every pair evaluated ONCE, row minima per lane + column minima across lanes (csrc/chamfer_sym.hip);
 #            r01: main loop 32 us for both directions (vs 48), but 68 us with its argmin recovery and merge launch
 #   "grid"   quantile 3-D grid in LDS, per-lane cell walk + exact bound (csrc/chamfer_grid.hip): 41 vs 53 us on
 #            uniform cubes, 2-5x SLOWER on surfaces / Gaussian blobs (measured numbers in the file header)
-NN_IMPL = os.environ.get("DPF_CHAMFER_IMPL", "brute")
+NN_IMPL = os.environ.get("DPF_CHAMFER_IMPL", "auto")
 EMD_GRAD_TWO_PASS = bool(int(os.environ.get("DPF_EMD_GRAD_TWO_PASS", "0")))   # 1: separate grad1 / grad2 kernels
 EMD_RMW = bool(int(os.environ.get("DPF_EMD_RMW", "0")))   # 1: the reference's per-level read-modify-write of `match`
 
@@ -63,7 +65,9 @@ def NNDistance(set_d, set_q):
     with torch.cuda.device(dev):
         args = (b, n, set_d.data_ptr(), m, set_q.data_ptr(), dist1.data_ptr(), idx1.data_ptr(), dist2.data_ptr(),
                 idx2.data_ptr())
-        if NN_IMPL == "brute":
+        if NN_IMPL == "auto":
+            check(lib().dpf_nndistance_auto(*args, current_stream()), "nndistance_auto")
+        elif NN_IMPL == "brute":
             check(lib().dpf_nndistance(*args, current_stream()), "nndistance")
         elif NN_IMPL == "sym":
             nbytes = lib().dpf_nndistance_sym_workspace_bytes(b, n, m)

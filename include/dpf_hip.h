@@ -63,13 +63,20 @@ int dpf_nndistance_ws(int b, int n, const float *xyz, int m, const float *xyz2,
 /* Same results as dpf_nndistance, bit for bit, matrix-core filtered: one bf16
  * MFMA per 32x32 pairs bounds every distance to within 2^-14*R2, and only the
  * candidates that can still be the fp32-exact minimiser (or tie with it) are
- * evaluated with the exact formula.  `workspace`: caller-owned scratch of
- * dpf_nndistance_mfma_workspace_bytes(b, n, m) bytes (64 B per point).  NULL /
- * short workspace, or both clouds under 32 points -> the brute-force kernel. */
+ * evaluated with the exact formula.  The fragments are built inside the kernel:
+ * `workspace` is unused (kept for the ABI; _workspace_bytes returns 0).  Both
+ * clouds under 32 points -> the brute-force kernel. */
 size_t dpf_nndistance_mfma_workspace_bytes(int b, int n, int m);
 int dpf_nndistance_mfma(int b, int n, const float *xyz, int m, const float *xyz2,
                         float *result, int *result_i, float *result2, int *result2_i,
                         void *workspace, size_t workspace_bytes, dpf_stream_t stream);
+
+/* dpf_nndistance's contract and bits; the matrix-core filtered kernel where it is the faster
+ * one (>= 1e8 pair evaluations and >= 128 workgroups of 512 queries), the VALU scan otherwise.
+ * This is what the Python mirror calls by default. */
+int dpf_nndistance_auto(int b, int n, const float *xyz, int m, const float *xyz2,
+                        float *result, int *result_i, float *result2, int *result2_i,
+                        dpf_stream_t stream);
 
 /* Same results as dpf_nndistance, bit for bit, from ONE evaluation of every pair:
  * (b - a) and (a - b) square to the same bits, so the row minima (direction 1) and

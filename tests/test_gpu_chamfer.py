@@ -19,7 +19,7 @@ def _gpu():
     return BK
 
 
-IMPLS = ["mfma", "brute", "sorted", "grid", "sym"]
+IMPLS = ["auto", "mfma", "brute", "sorted", "grid", "sym"]
 
 
 def _run(BK, a, b, impl=None):
