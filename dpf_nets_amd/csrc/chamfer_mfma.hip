@@ -15,9 +15,10 @@
 // every exact tie -- has s <= s_min + tau with tau = 2^-12 * R2.  ONE sweep over
 // the candidate tiles: per tile one MFMA and a v_min3 tree over the accumulator
 // fragment (0.5 VALU op per pair); a tile whose minimum is within tau of the
-// RUNNING minimum is queued per lane (the running minimum only decreases, so the
-// queue is a superset of what the final threshold selects: ~ln(#tiles) record
-// lows plus near-ties).  Afterwards the queue is filtered with the final s_min
+// RUNNING minimum is queued per lane; a new minimum that undercuts the old one by
+// more than tau empties the queue first (everything in it is then out of range),
+// so the queue holds genuine near-ties only and is a superset of what the final
+// threshold selects.  Afterwards the queue is filtered with the final s_min
 // and only those few tiles are evaluated with the exact formula and the
 // (d, index) lexicographic rule.  When a lane's queue is full of genuine near-ties
 // (duplicate points, lattice data) its oldest entry is settled exactly on the spot,
@@ -232,21 +233,14 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
         if (wave_live) {
             auto visit = [&](int t, float m) {
                 if (m <= smin + tau) {                                        // record low or near-tie of the running minimum
-                    if (qcount == QCAP) {
-                        // full: drop what the CURRENT threshold already excludes (the final one is no larger)
-                        const float cur = fminf(smin, m) + tau;
-                        int keep = 0;
-                        for (int e = 0; e < QCAP; ++e) {
-                            const float v = mym[e * 64 + lane];
-                            if (v <= cur) { myq[keep * 64 + lane] = myq[e * 64 + lane]; mym[keep * 64 + lane] = v; ++keep; }
-                        }
-                        qcount = keep;
-                    }
+                    // a clear new minimum puts every queued tile (all >= smin) out of range: the queue only ever
+                    // holds tiles within tau of each other, i.e. genuine near-ties
+                    if (m + tau < smin) qcount = 0;
                     if (qcount < QCAP) {
                         myq[qcount * 64 + lane] = (unsigned short)t; mym[qcount * 64 + lane] = m; ++qcount;
                     } else {
-                        // still full of near-ties (duplicate points, lattice data): settle the oldest entry exactly
-                        // now -- evaluation order does not matter for the (d, index) rule -- and reuse its slot
+                        // full of near-ties (duplicate points, lattice data): settle the oldest entry exactly now --
+                        // evaluation order does not matter for the (d, index) rule -- and reuse its slot
                         const int tl = myq[lane];
                         exact_tile(spts, nc, t0 + tl, tl, h, qx, qy, qz, best, bidx);
                         for (int e = 0; e + 1 < QCAP; ++e) { myq[e * 64 + lane] = myq[(e + 1) * 64 + lane]; mym[e * 64 + lane] = mym[(e + 1) * 64 + lane]; }
