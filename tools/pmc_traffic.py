@@ -23,7 +23,7 @@ def main(pmc_dir, tag, out_json):
         if f.endswith(".txt"):
             vals.update(parse(os.path.join(pmc_dir, f)))
     res = json.load(open(out_json)) if os.path.exists(out_json) else {}
-    names = {"flow_kernel": "flow_kernel", "nn_kernel": "nn_kernel", "film_kernel": "film_kernel"}
+    names = {"flow_kernel": "flow_kernel", "nnm_kernel": "nnm_kernel", "nn_kernel": "nn_kernel", "film_kernel": "film_kernel"}
     for (k, c), v in vals.items():
         for short in names:
             if short in k and "pack_" not in k:
