@@ -119,24 +119,36 @@ __device__ __forceinline__ float dist3(float cx, float cy, float cz, float qx, f
     const float dx = cx - qx, dy = cy - qy, dz = cz - qz;
     return (dx * dx + dy * dy) + dz * dz;
 }
-// exact evaluation of the 16 candidates this lane half sees in candidate tile `t`
-// (accumulator rows (r&3) + 8(r>>2) + 4h); ascending k, so ties keep the lowest index
+// exact evaluation of the 16 candidates this lane half sees in candidate tile `t` (accumulator rows
+// (r&3) + 8(r>>2) + 4h).  Minimum first (16 distances + a v_min3 tree); only a tile whose minimum reaches the
+// current best pays for the index: the LOWEST k attaining the minimum (descending scan, last hit wins), then the
+// (d, index) lexicographic rule.  Padding points sit at 3e38, so their distance is +inf.
 template <class P>
 __device__ __forceinline__ void exact_tile(P cp, int nc, int t, int tl, int h, float qx, float qy, float qz,
                                            float &best, int &bidx) {   // tl = tile index inside cp, t = global tile
+    float d[16];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {                       // four points at a time: 16 live registers, not 64
+    for (int g = 0; g < 4; ++g) {                       // four points at a time: few live registers
         float4 v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = cp[(size_t)tl * 32 + 8 * g + 4 * h + e];    // padded: always in range
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = t * 32 + 8 * g + 4 * h + e;
-            const float d = dist3(v[e].x, v[e].y, v[e].z, qx, qy, qz);
-            const bool better = k < nc && (d < best || (d == best && k < bidx));
-            best = better ? d : best;
-            bidx = better ? k : bidx;
+        for (int e = 0; e < 4; ++e) d[4 * g + e] = dist3(v[e].x, v[e].y, v[e].z, qx, qy, qz);
+    }
+    float m = fminf(fminf(d[0], d[1]), d[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) m = fminf(fminf(m, d[r]), d[r + 1]);
+    m = fminf(m, d[15]);
+    if (m <= best) {
+        int kmin = INT_MAX;
+#pragma unroll
+        for (int r = 15; r >= 0; --r) {
+            const int k = t * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+            kmin = (d[r] == m && k < nc) ? k : kmin;
         }
+        const bool better = kmin != INT_MAX && (m < best || kmin < bidx);
+        best = better ? m : best;
+        bidx = better ? kmin : bidx;
     }
 }
 
@@ -196,7 +208,8 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
     unsigned short *myq = qtile + (size_t)wave * QCAP * 64;
     float *mym = qmin + (size_t)wave * QCAP * 64;
     float smin = __builtin_inff();
-    int qcount = 0;
+    int qcount = 0, q0t = 0;
+    float q0m = 0.f;
     float best = __builtin_inff();
     int bidx = INT_MAX;
     const int npass = (nct + CT - 1) / CT;
@@ -215,7 +228,8 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
                 cand_fragment(cx, cy, cz, live, f0, f1);
                 sfrag[t * 64 + i] = f0;
                 sfrag[t * 64 + 32 + i] = f1;
-                spts[t * 32 + i] = make_float4(x, y, z, 0.f);                 // original coordinates: exact evaluation
+                // original coordinates for the exact evaluation; padding far away (its distance is +inf)
+                spts[t * 32 + i] = live ? make_float4(x, y, z, 0.f) : make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
                 if (pass == 0) r2 = fmaxf(r2, (cx * cx + cy * cy) + cz * cz);
             }
         }
@@ -231,20 +245,20 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
             tau = m * 2.44140625e-4f;                                         // 2^-12 * R2
         }
         if (wave_live) {
+            // Queue of a lane: the head (q0t, q0m) lives in registers, near-ties of it in LDS slots 0..qcount-2.  The
+            // common event -- a new minimum that undercuts the old one by more than tau, which puts every queued tile
+            // (all >= smin) out of range -- is three register moves.
             auto visit = [&](int t, float m) {
                 if (m <= smin + tau) {                                        // record low or near-tie of the running minimum
-                    // a clear new minimum puts every queued tile (all >= smin) out of range: the queue only ever
-                    // holds tiles within tau of each other, i.e. genuine near-ties
-                    if (m + tau < smin) qcount = 0;
-                    if (qcount < QCAP) {
-                        myq[qcount * 64 + lane] = (unsigned short)t; mym[qcount * 64 + lane] = m; ++qcount;
+                    if (m + tau < smin || qcount == 0) {                      // (empty: first hit of a later pass)
+                        q0t = t; q0m = m; qcount = 1;
+                    } else if (qcount < QCAP) {
+                        myq[(qcount - 1) * 64 + lane] = (unsigned short)t; mym[(qcount - 1) * 64 + lane] = m; ++qcount;
                     } else {
-                        // full of near-ties (duplicate points, lattice data): settle the oldest entry exactly now --
-                        // evaluation order does not matter for the (d, index) rule -- and reuse its slot
-                        const int tl = myq[lane];
-                        exact_tile(spts, nc, t0 + tl, tl, h, qx, qy, qz, best, bidx);
-                        for (int e = 0; e + 1 < QCAP; ++e) { myq[e * 64 + lane] = myq[(e + 1) * 64 + lane]; mym[e * 64 + lane] = mym[(e + 1) * 64 + lane]; }
-                        myq[(QCAP - 1) * 64 + lane] = (unsigned short)t; mym[(QCAP - 1) * 64 + lane] = m;
+                        // full of near-ties (duplicate points, lattice data): settle the head exactly now -- evaluation
+                        // order does not matter for the (d, index) rule -- and put the newcomer in its place
+                        exact_tile(spts, nc, t0 + q0t, q0t, h, qx, qy, qz, best, bidx);
+                        q0t = t; q0m = m;
                     }
                 }
                 smin = fminf(smin, m);
@@ -262,8 +276,9 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
             const float thr = fminf(smin, __shfl_xor(smin, 32)) + tau;
             {
                 int nsurv = 0;
-                for (int e = 0; e < QCAP; ++e)
-                    if (e < qcount && mym[e * 64 + lane] <= thr) { myq[nsurv * 64 + lane] = myq[e * 64 + lane]; ++nsurv; }
+                for (int e = 0; e + 1 < QCAP; ++e)                            // near-ties first (compacted in place) ...
+                    if (e + 1 < qcount && mym[e * 64 + lane] <= thr) { myq[nsurv * 64 + lane] = myq[e * 64 + lane]; ++nsurv; }
+                if (qcount > 0 && q0m <= thr) { myq[nsurv * 64 + lane] = (unsigned short)q0t; ++nsurv; }   // ... then the head
                 int smax = nsurv;
                 for (int d = 32; d > 0; d >>= 1) smax = max(smax, __shfl_xor(smax, d));
                 smax = __builtin_amdgcn_readfirstlane(smax);
