@@ -373,18 +373,29 @@ __device__ __forceinline__ void branch_tile(const uint8_t *lb, int br, int lane,
         __builtin_amdgcn_sched_barrier(0);
     }
     DPF_T(2)
-    // ---- o = W2' relu(h1 + D): each lane reduces its 32 features
-    oa = 0.f; ob = 0.f;
+    // ---- o = W2' relu(h1 + D): each lane reduces its 32 features.  Written as packed-f32 FMAs on (even, odd)
+    // partial sums over NATURAL register pairs -- two consecutive accumulator registers against the two consecutive
+    // weights of one f32x4 load -- so that no operand pair has to be assembled with v_mov (the SLP vectoriser paired
+    // the scalar chain across the two M tiles and spent ~1.5 v_mov per v_pk_fma_f32 doing so).
+    f32x2 oa2 = {0.f, 0.f}, ob2 = {0.f, 0.f};
     load_w(1, wva[1], wvb[1]);
 #pragma unroll
     for (int tp = 0; tp < 2; ++tp)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float v0 = relu(acc1[tp][4 * q + 0]), v1 = relu(acc1[tp][4 * q + 1]);
-            const float v2 = relu(acc1[tp][4 * q + 2]), v3 = relu(acc1[tp][4 * q + 3]);
-            oa += wva[tp][q].x * v0; oa += wva[tp][q].y * v1; oa += wva[tp][q].z * v2; oa += wva[tp][q].w * v3;
-            if (TWO) { ob += wvb[tp][q].x * v0; ob += wvb[tp][q].y * v1; ob += wvb[tp][q].z * v2; ob += wvb[tp][q].w * v3; }
+            const f32x2 v01 = {relu(acc1[tp][4 * q + 0]), relu(acc1[tp][4 * q + 1])};
+            const f32x2 v23 = {relu(acc1[tp][4 * q + 2]), relu(acc1[tp][4 * q + 3])};
+            const f32x4 wa4 = wva[tp][q];
+            oa2 = __builtin_elementwise_fma(f32x2{wa4.x, wa4.y}, v01, oa2);
+            oa2 = __builtin_elementwise_fma(f32x2{wa4.z, wa4.w}, v23, oa2);
+            if (TWO) {
+                const f32x4 wb4 = wvb[tp][q];
+                ob2 = __builtin_elementwise_fma(f32x2{wb4.x, wb4.y}, v01, ob2);
+                ob2 = __builtin_elementwise_fma(f32x2{wb4.z, wb4.w}, v23, ob2);
+            }
         }
+    oa = oa2.x + oa2.y;
+    ob = ob2.x + ob2.y;
 }
 
 __device__ __forceinline__ float half_sum(float x) {   // x(lane) + x(lane ^ 32)
