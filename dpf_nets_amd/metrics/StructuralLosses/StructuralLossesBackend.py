@@ -17,7 +17,7 @@ from ..._lib import lib, check, current_stream
 #            "brute" otherwise
 #   "brute"  O(n*m) exact VALU scan at ~80 % of its issue bound, data-independent cost
 #   "mfma"   matrix-core filter (one bf16 MFMA per 32x32 pairs) + exact verification of the few candidates that can
-#            win, fragments built in the kernel; r01: 31 us vs 52 us brute on cfg-2, 90 vs 191 us at B=8, N=8192
+#            win, fragments built in the kernel; r01: 25 us vs 52 us brute on cfg-2, 76 vs 190 us at B=8, N=8192
 #   "sorted" x-sorted pruned exact scan (pays off only when both clouds cover the same region)
 #   "sym"    every pair evaluated ONCE, row minima per lane + column minima across lanes (csrc/chamfer_sym.hip);
 #            r01: main loop 32 us for both directions (vs 48), but 68 us with its argmin recovery and merge launch
