@@ -418,9 +418,14 @@ __device__ __forceinline__ f2 level_sum(const LevelPairs &lv, const u64 *r, cons
     else return level_sum<J - 1>(lv, r, rl, d2) + level_term<J>(lv, r, rl, d2);
 }
 
+// COST: also the matching's cost sum_{l,k} match[l][k] * |x1_k - x2_l| (approxmatch.cu:184-224) of this wave's
+// pairs -- the distance is already there -- to costpart[(cloud, workgroup, slice)]; emd_cost_sum_kernel adds a cloud's
+// partials in a fixed order.  Saves matchcost's pass over `match` (4*n*m bytes per cloud).
+template <bool COST>
 __global__ __launch_bounds__(1024) void emd_materialize2_kernel(int n, int m, LevelPairs lv, const float *__restrict__ xyz1,
                                                                 const float *__restrict__ rec, float *__restrict__ match,
-                                                                const float *__restrict__ ws, size_t lstride, size_t rstride) {
+                                                                const float *__restrict__ ws, size_t lstride, size_t rstride,
+                                                                float *__restrict__ costpart) {
     const int bi = blockIdx.y;
     const int lane = threadIdx.x, slice = __builtin_amdgcn_readfirstlane(threadIdx.y), S = blockDim.y;
     const float *__restrict__ P = xyz1 + (size_t)bi * n * 3;
@@ -435,12 +440,32 @@ __global__ __launch_bounds__(1024) void emd_materialize2_kernel(int n, int m, Le
         rl[j] = f2{r[a0], r[a1]};
     }
     const int lb = (int)((long)m * slice / S), le = (int)((long)m * (slice + 1) / S);
+    f2 cost = {0.f, 0.f};
     stream_records<6, 2>((const u64 *)(rec + (size_t)bi * m * 12), lb, le, [&](int l, const u64 *r) {
-        const f2 acc = level_sum<NLEVEL - 1>(lv, r, rl, sqdist2(px, py, pz, r[0], r[1]));
+        const f2 d2 = sqdist2(px, py, pz, r[0], r[1]);
+        const f2 acc = level_sum<NLEVEL - 1>(lv, r, rl, d2);
         float *row = mt + (size_t)l * n;
         if (k0 < n) row[k0] = acc.x;
         if (k1 < n) row[k1] = acc.y;
+        if (COST) cost = fma2(acc, f2{__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)}, cost);
     });
+    if (COST) {
+        float c = (k0 < n ? cost.x : 0.f) + (k1 < n ? cost.y : 0.f);
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        if (lane == 0) costpart[((size_t)bi * gridDim.x + blockIdx.x) * S + slice] = c;
+    }
+}
+
+// out[b] = the cloud's partial costs, added in a fixed order
+__global__ __launch_bounds__(256) void emd_cost_sum_kernel(int nper, const float *__restrict__ costpart, float *__restrict__ out) {
+    __shared__ float red[4];
+    const float *cp = costpart + (size_t)blockIdx.x * nper;
+    float c = 0.f;
+    for (int i = threadIdx.x; i < nper; i += 256) c += cp[i];
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // out[b] = sum_{l,k} match[b,l,k] * |xyz1[k] - xyz2[l]|                           approxmatch.cu:184-224
@@ -640,11 +665,11 @@ extern "C" size_t dpf_approxmatch_workspace_bytes(int b, int n, int m) {
     if (b <= 0 || n <= 0 || m <= 0) return 0;
     // NLEVEL ratio slots | 16 B alignment slack | (x,y,z,w) records of the passes | 12-float records of the materialisation
     return (size_t)b * NLEVEL * ((size_t)n + m) * sizeof(float) + 16 + (size_t)b * ((size_t)n + 2 * (size_t)m) * sizeof(float4) +
-           (size_t)b * m * 12 * sizeof(float);
+           (size_t)b * m * 12 * sizeof(float) + (size_t)b * ((n + PPW - 1) / PPW) * MAXS * sizeof(float);
 }
 
-extern "C" int dpf_approxmatch_ws(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
-                                  void *workspace, size_t workspace_bytes, dpf_stream_t stream) {
+static int approxmatch_impl(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp, float *cost,
+                            void *workspace, size_t workspace_bytes, dpf_stream_t stream) {
     if (b < 0 || n <= 0 || m <= 0) return DPF_EINVAL;
     if (b == 0) return 0;
     if (!xyz1 || !xyz2 || !match || !temp) return DPF_EINVAL;
@@ -696,10 +721,31 @@ extern "C" int dpf_approxmatch_ws(int b, int n, int m, const float *xyz1, const 
         }
         hipLaunchKernelGGL(emd_pack_levels_kernel, dim3((m + 255) / 256, b), dim3(256), 0, s, n, m, xyz2,
                            (const float *)workspace, lstride, rstride, rec);
-        hipLaunchKernelGGL(emd_materialize2_kernel, h1, dim3(64, s1), 0, s, n, m, lp, xyz1, (const float *)rec, match,
-                           (const float *)workspace, lstride, rstride);
+        float *costpart = rec + (size_t)b * m * 12;
+        if (cost) {
+            hipLaunchKernelGGL(emd_materialize2_kernel<true>, h1, dim3(64, s1), 0, s, n, m, lp, xyz1, (const float *)rec, match,
+                               (const float *)workspace, lstride, rstride, costpart);
+            hipLaunchKernelGGL(emd_cost_sum_kernel, dim3(b), dim3(256), 0, s, (int)h1.x * s1, (const float *)costpart, cost);
+        } else {
+            hipLaunchKernelGGL(emd_materialize2_kernel<false>, h1, dim3(64, s1), 0, s, n, m, lp, xyz1, (const float *)rec, match,
+                               (const float *)workspace, lstride, rstride, costpart);
+        }
     }
     return (int)hipGetLastError();
+}
+
+extern "C" int dpf_approxmatch_ws(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
+                                  void *workspace, size_t workspace_bytes, dpf_stream_t stream) {
+    return approxmatch_impl(b, n, m, xyz1, xyz2, match, temp, nullptr, workspace, workspace_bytes, stream);
+}
+
+// approxmatch + matchcost in one call: the materialisation pass also sums match * distance (fixed-order partial
+// sums: deterministic).  The workspace is required (there is no read-modify-write variant of this entry point).
+extern "C" int dpf_approxmatch_cost_ws(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
+                                       float *cost, void *workspace, size_t workspace_bytes, dpf_stream_t stream) {
+    if (!cost || !workspace || (b > 0 && n > 0 && m > 0 && workspace_bytes < dpf_approxmatch_workspace_bytes(b, n, m)))
+        return DPF_EINVAL;
+    return approxmatch_impl(b, n, m, xyz1, xyz2, match, temp, cost, workspace, workspace_bytes, stream);
 }
 
 extern "C" int dpf_approxmatch(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,

@@ -134,6 +134,26 @@ def ApproxMatch(set_d, set_q):
     return [match, temp]
 
 
+def ApproxMatchCost(set_d, set_q):
+    """ApproxMatch followed by MatchCost (match_cost.py:20-22) in one call -> [match (B,m,n), temp, cost (B,)]: the
+    pass that materialises the matching also sums match * distance (dpf_approxmatch_cost_ws)."""
+    if EMD_RMW:
+        match, temp = ApproxMatch(set_d, set_q)
+        return [match, temp, MatchCost(set_d, set_q, match)]
+    _check_input(set_d, "set_d"); _check_input(set_q, "set_q")
+    b, n, m = _dims(set_d, set_q)
+    dev = set_d.device
+    match = torch.empty((b, m, n), dtype=torch.float32, device=dev)
+    temp = torch.empty((b, (n + m) * 2), dtype=torch.float32, device=dev)
+    cost = torch.empty((b,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        nbytes = lib().dpf_approxmatch_workspace_bytes(b, n, m)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        check(lib().dpf_approxmatch_cost_ws(b, n, m, set_d.data_ptr(), set_q.data_ptr(), match.data_ptr(), temp.data_ptr(),
+                                            cost.data_ptr(), ws.data_ptr(), nbytes, current_stream()), "approxmatch_cost_ws")
+    return [match, temp, cost]
+
+
 def MatchCost(set_d, set_q, match):
     """-> cost (B,)                                                         structural_loss.cpp:39-52"""
     _check_input(set_d, "set_d"); _check_input(set_q, "set_q"); _check_input(match, "match")

@@ -3,16 +3,16 @@ Mirror of lib/metrics/pytorch_structural_losses/match_cost.py:6-44 (the matching
 is a constant in backward, :38-42)."""
 import torch
 
-from .StructuralLossesBackend import ApproxMatch, MatchCost, MatchCostGrad
+from .StructuralLossesBackend import ApproxMatch, ApproxMatchCost, MatchCost, MatchCostGrad  # noqa: F401
 
 
 class MatchCostFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, seta, setb):
         ctx.save_for_backward(seta, setb)
-        match, _temp = ApproxMatch(seta, setb)
+        match, _temp, cost = ApproxMatchCost(seta, setb)        # = ApproxMatch, then MatchCost (match_cost.py:20-22)
         ctx.match = match
-        return MatchCost(seta, setb, match)
+        return cost
 
     @staticmethod
     def backward(ctx, grad_output):

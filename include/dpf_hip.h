@@ -118,14 +118,23 @@ int dpf_approxmatch(int b, int n, int m, const float *xyz1, const float *xyz2,
 /* Same results as dpf_approxmatch, bit for bit, with `match` written ONCE: the
  * nine levels' ratio vectors and the packed (x, y, z, weight) candidate records
  * the passes stream through scalar loads are kept in `workspace`
- * (dpf_approxmatch_workspace_bytes = 36*(n+m) + 16*(n+2m) + 48*m (+16) bytes per
- * cloud) and the matching is materialised by a final pass (4*n*m instead of
+ * (dpf_approxmatch_workspace_bytes = 36*(n+m) + 16*(n+2m) + 48*m + n/2 (+16)
+ * bytes per cloud) and the matching is materialised by a final pass (4*n*m instead of
  * 68*n*m bytes of HBM traffic per cloud).  NULL / short workspace -> the
  * read-modify-write path. */
 size_t dpf_approxmatch_workspace_bytes(int b, int n, int m);
 int dpf_approxmatch_ws(int b, int n, int m, const float *xyz1, const float *xyz2,
                        float *match, float *temp, void *workspace, size_t workspace_bytes,
                        dpf_stream_t stream);
+
+/* dpf_approxmatch_ws followed by dpf_matchcost in one call (what MatchCostFunction.forward does,
+ * match_cost.py:20-22): the pass that materialises `match` also accumulates
+ * cost[b] = sum match * |xyz1 - xyz2| (the distance is at hand), saving matchcost's pass over
+ * the (b, m, n) matching.  Fixed-order partial sums (deterministic); agrees with dpf_matchcost
+ * to fp32 summation order.  The workspace (dpf_approxmatch_workspace_bytes) is required. */
+int dpf_approxmatch_cost_ws(int b, int n, int m, const float *xyz1, const float *xyz2,
+                            float *match, float *temp, float *cost, void *workspace,
+                            size_t workspace_bytes, dpf_stream_t stream);
 
 /* replaces matchcost(...)       src/approxmatch.cuh:7, approxmatch.cu:309-316.
  * out: (b,) = sum_{l,k} match[b,l,k] * |xyz1[b,k]-xyz2[b,l]|_2. */

@@ -98,3 +98,23 @@ def test_one_pass_gradients_match_two_pass():
         r1, r2 = S.matchcostgrad(a, b, match.cpu().numpy())
         np.testing.assert_allclose(g1.cpu().numpy(), r1, rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(g2.cpu().numpy(), r2, rtol=1e-4, atol=1e-5)
+
+
+def test_fused_cost_matches_separate_matchcost():
+    """dpf_approxmatch_cost_ws: the same matching bit for bit, the cost within fp32 summation order of dpf_matchcost
+    (and of the oracle fed that matching), deterministic from run to run; match_cost() uses it."""
+    BK = _gpu()
+    from dpf_nets_amd.metrics.StructuralLosses.match_cost import match_cost
+    for (B, n, m) in ((2, 64, 64), (3, 300, 257), (2, 1024, 2048), (1, 100, 37)):
+        a, b = chamfer_inputs(900 + n, B, n, m)
+        ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+        match, temp = BK.ApproxMatch(ta, tb)
+        cost = BK.MatchCost(ta, tb, match)
+        m2, t2, c2 = BK.ApproxMatchCost(ta, tb)
+        m3, t3, c3 = BK.ApproxMatchCost(ta, tb)
+        assert torch.equal(match, m2) and torch.equal(temp[:, :n + m], t2[:, :n + m])
+        assert torch.equal(c2, c3) and torch.equal(m2, m3)
+        np.testing.assert_allclose(c2.cpu().numpy(), cost.cpu().numpy(), rtol=2e-5)
+        np.testing.assert_allclose(c2.cpu().numpy(), S.matchcost(a, b, match.cpu().numpy()), rtol=2e-5)
+        if n == m:                                                    # emd_approx asserts N == M
+            np.testing.assert_allclose(match_cost(ta, tb).cpu().numpy(), c2.cpu().numpy(), rtol=0, atol=0)

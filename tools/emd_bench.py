@@ -28,14 +28,15 @@ def main():
         match, temp = BK.ApproxMatch(a, b)
         t_match = timed(lambda: BK.ApproxMatch(a, b), reps)
         t_cost = timed(lambda: BK.MatchCost(a, b, match), reps)
+        t_fused = timed(lambda: BK.ApproxMatchCost(a, b), reps)
         t_grad = timed(lambda: BK.MatchCostGrad(a, b, match), reps)
         BK.EMD_GRAD_TWO_PASS = True
         t_grad2 = timed(lambda: BK.MatchCostGrad(a, b, match), reps)
         BK.EMD_GRAD_TWO_PASS = False
         nm = float(B) * N * N
-        print("B=%d N=%d  approxmatch %.2f ms (%.0f GB/s of the 76*n*m RMW model, %.2e exp/s)  matchcost %.3f ms (%.0f GB/s)  "
+        print("B=%d N=%d  approxmatch+cost fused %.2f ms |  approxmatch %.2f ms (%.0f GB/s of the 76*n*m RMW model, %.2e exp/s)  matchcost %.3f ms (%.0f GB/s)  "
               "grad one-pass %.3f ms (%.0f GB/s of 4*n*m) | two-pass %.3f ms" %
-              (B, N, t_match, 76 * nm / t_match / 1e6, 36 * nm / t_match * 1e3, t_cost, 4 * nm / t_cost / 1e6, t_grad,
+              (B, N, t_fused, t_match, 76 * nm / t_match / 1e6, 36 * nm / t_match * 1e3, t_cost, 4 * nm / t_cost / 1e6, t_grad,
                4 * nm / t_grad / 1e6, t_grad2), flush=True)
 
 
