@@ -116,7 +116,8 @@ __global__ void k(float *out, int iters, float seed, unsigned long long *ticks) 
                 if (KIND == 28) asm volatile("v_max_i32_e32 %0, 0, %0" : "+v"(u[i]));
                 if (KIND == 29) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]));
             })
-        } else if (KIND >= 30 && KIND <= 45) { // which single-rate VALU opcodes run at the fast (fp32-FMA-class) rate
+        } else if (KIND >= 30 && KIND <= 49) { // which single-rate VALU opcodes run at the fast (fp32-FMA-class) rate
+            unsigned long long cm[2] = {0, 0};
             REP16(for (int i = 0; i < 8; ++i) {
                 if (KIND == 30) asm volatile("v_max_i32_e32 %0, %1, %0" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
                 if (KIND == 31) asm volatile("v_and_b32_e32 %0, %1, %0" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
@@ -134,6 +135,10 @@ __global__ void k(float *out, int iters, float seed, unsigned long long *ticks) 
                 if (KIND == 43) asm volatile("v_fma_f32 %0, %0, %1, -%2" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]));
                 if (KIND == 44) asm volatile("v_add_f32_e64 %0, %0, |%1|" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
                 if (KIND == 45) asm volatile("v_min_f32_e32 %0, %1, %0" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
+                if (KIND == 46) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "s"(0x5555aaaa3333ccccull));
+                if (KIND == 47) asm volatile("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(cm[i & 1]) : "v"(a[i]), "v"(a[(i + 1) & 7]));
+                if (KIND == 48) asm volatile("ds_bpermute_b32 %0, %1, %0\n\ts_waitcnt lgkmcnt(0)" : "+v"(a[i]) : "v"(u[i & 7] & 252));
+                if (KIND == 49) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
             })
         } else if (KIND >= 50 && KIND <= 57) { // dependent-issue distance: chains of 1, 2, 4 registers
             constexpr int D = (KIND & 3) == 0 ? 1 : (KIND & 3) == 1 ? 2 : (KIND & 3) == 2 ? 4 : 8;
@@ -228,6 +233,10 @@ int main(int argc, char **argv) {
         run<43>("v_fma_f32 v,v,-v", 128);
         run<44>("v_add_f32_e64 v,|v|", 128);
         run<45>("v_min_f32 v,v", 128);
+        run<46>("v_cndmask_b32_e64 v,v,s[2]", 128);
+        run<47>("v_cmp_lt_f32_e64 s[2],v,v", 128);
+        run<48>("ds_bpermute_b32 + wait", 128);
+        run<49>("v_mov_b32_dpp quad_perm", 128);
         return 0;
     }
     run<0>("v_fma_f32", 128);
