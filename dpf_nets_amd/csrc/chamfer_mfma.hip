@@ -245,11 +245,14 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
             tau = m * 2.44140625e-4f;                                         // 2^-12 * R2
         }
         if (wave_live) {
+            float hit = smin + tau;
             // Queue of a lane: the head (q0t, q0m) lives in registers, near-ties of it in LDS slots 0..qcount-2.  The
             // common event -- a new minimum that undercuts the old one by more than tau, which puts every queued tile
             // (all >= smin) out of range -- is three register moves.
+            // hit = smin + tau is kept up to date where smin changes -- inside the hit path (a new minimum is a hit) --
+            // so a tile that is not a hit costs one compare
             auto visit = [&](int t, float m) {
-                if (m <= smin + tau) {                                        // record low or near-tie of the running minimum
+                if (m <= hit) {                                               // record low or near-tie of the running minimum
                     if (m + tau < smin || qcount == 0) {                      // (empty: first hit of a later pass)
                         q0t = t; q0m = m; qcount = 1;
                     } else if (qcount < QCAP) {
@@ -260,8 +263,9 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
                         exact_tile(spts, nc, t0 + q0t, q0t, h, qx, qy, qz, best, bidx);
                         q0t = t; q0m = m;
                     }
+                    smin = fminf(smin, m);
+                    hit = smin + tau;
                 }
-                smin = fminf(smin, m);
             };
             int t = 0;
             for (; t + 4 <= tn; t += 4) {                                     // four independent MFMAs in flight
