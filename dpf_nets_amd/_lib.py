@@ -18,6 +18,7 @@ SIGNATURES = {
     "dpf_nndistance": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dpf_nndistance_auto": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dpf_nndistance_strided": (_i, [_i, _i, _vp, ctypes.c_long, _i, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _vp]),
+    "dpf_nndistance_strided_auto": (_i, [_i, _i, _vp, ctypes.c_long, _i, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _vp]),
     "dpf_nndistance_workspace_bytes": (_sz, [_i, _i, _i]),
     "dpf_nndistance_ws": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpf_nndistance_mfma_workspace_bytes": (_sz, [_i, _i, _i]),

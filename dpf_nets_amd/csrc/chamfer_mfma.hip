@@ -101,6 +101,7 @@ struct MDir {
     float *dist;
     int *idx;
     int nq, nc;
+    long qstride, cstride;     // floats between consecutive clouds (0 = one cloud broadcast over the batch)
 };
 struct MArgs { MDir d[2]; int debug; };
 
@@ -175,9 +176,9 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
     const int qt = blockIdx.x * QW + wave;                                   // query tile of this wave
     const int nqt = tiles_of(nq), nct = tiles_of(nc);
     const bool wave_live = qt < nqt;
-    const float *__restrict__ cpts = A.c + (size_t)bi * nc * 3;
+    const float *__restrict__ cpts = A.c + (size_t)bi * A.cstride;
     const int j = qt * 32 + (lane & 31);
-    const float *qsrc = A.q + ((size_t)bi * nq + min(j, nq - 1)) * 3;
+    const float *qsrc = A.q + (size_t)bi * A.qstride + (size_t)min(j, nq - 1) * 3;
     const float qx = qsrc[0], qy = qsrc[1], qz = qsrc[2];
     // The surrogate is evaluated on coordinates translated by mu = the mean of the first 64 candidates (every wave
     // computes the same value: no barrier), so that R2 -- and with it the filter's tolerance tau -- scales with the
@@ -315,19 +316,11 @@ extern "C" size_t dpf_nndistance_mfma_workspace_bytes(int b, int n, int m) {
     return 0;            // the fragments are built inside the kernel since r01; the argument is kept for the ABI
 }
 
-extern "C" int dpf_nndistance_mfma(int b, int n, const float *xyz, int m, const float *xyz2, float *result,
-                                   int *result_i, float *result2, int *result2_i, void *workspace,
-                                   size_t workspace_bytes, dpf_stream_t stream) {
-    (void)workspace; (void)workspace_bytes;
-    if (b < 0 || n <= 0 || m <= 0) return DPF_EINVAL;
-    if (b == 0) return 0;
-    if (!xyz || !xyz2 || !result || !result_i || !result2 || !result2_i) return DPF_EINVAL;
-    if (b > 65535 || n > 65535 * 32 || m > 65535 * 32 || (n < 32 && m < 32))
-        return dpf_nndistance(b, n, xyz, m, xyz2, result, result_i, result2, result2_i, stream);
-    hipStream_t s = (hipStream_t)stream;
+static int launch_nnm(int b, int n, const float *xyz, long xyz_stride, int m, const float *xyz2, long xyz2_stride,
+                      float *result, int *result_i, float *result2, int *result2_i, hipStream_t s) {
     MArgs ma;
-    ma.d[0] = MDir{xyz, xyz2, result, result_i, n, m};       // nndistance.cu:126
-    ma.d[1] = MDir{xyz2, xyz, result2, result2_i, m, n};     // nndistance.cu:127
+    ma.d[0] = MDir{xyz, xyz2, result, result_i, n, m, xyz_stride, xyz2_stride};       // nndistance.cu:126
+    ma.d[1] = MDir{xyz2, xyz, result2, result2_i, m, n, xyz2_stride, xyz_stride};     // nndistance.cu:127
     ma.debug = 0;
     const int nmax = n > m ? n : m;
     const int lds = CT * 1536 + QW * QCAP * 64 * 6;
@@ -341,15 +334,43 @@ extern "C" int dpf_nndistance_mfma(int b, int n, const float *xyz, int m, const 
     return (int)hipGetLastError();
 }
 
-// Same contract and the same bits as dpf_nndistance; picks the matrix-core filtered kernel where it measured faster
-// (r01, tools/nn_impl_sweep.py: 31 vs 52 us at B=32, n=m=2048; 90 vs 191 us at B=8, n=m=8192) -- enough pairs to
-// amortise building the fragments and enough 512-query workgroups to fill the chip -- and the VALU scan otherwise
-// (small clouds and small batches are launch-bound either way; few workgroups leave the matrix cores idle).
-extern "C" int dpf_nndistance_auto(int b, int n, const float *xyz, int m, const float *xyz2, float *result, int *result_i,
-                                   float *result2, int *result2_i, dpf_stream_t stream) {
+// enough pairs to amortise building the fragments and enough 512-query workgroups to fill the chip (r01,
+// tools/nn_impl_sweep.py: 25 vs 52 us at B=32, n=m=2048; 76 vs 190 us at B=8, n=m=8192); small clouds and small
+// batches are launch-bound either way and few workgroups leave the matrix cores idle
+static bool nnm_pays(int b, int n, int m) {
+    if (b <= 0 || n <= 0 || m <= 0 || b > 65535 || n > 65535 * 32 || m > 65535 * 32) return false;
     const double pairs = 2.0 * (double)b * (double)n * (double)m;
     const long wgs = (long)b * ((n + QW * 32 - 1) / (QW * 32) + (m + QW * 32 - 1) / (QW * 32));
-    if (b > 0 && n > 0 && m > 0 && pairs >= 1.0e8 && wgs >= 128)
-        return dpf_nndistance_mfma(b, n, xyz, m, xyz2, result, result_i, result2, result2_i, nullptr, 0, stream);
+    return pairs >= 1.0e8 && wgs >= 128;
+}
+
+extern "C" int dpf_nndistance_mfma(int b, int n, const float *xyz, int m, const float *xyz2, float *result,
+                                   int *result_i, float *result2, int *result2_i, void *workspace,
+                                   size_t workspace_bytes, dpf_stream_t stream) {
+    (void)workspace; (void)workspace_bytes;
+    if (b < 0 || n <= 0 || m <= 0) return DPF_EINVAL;
+    if (b == 0) return 0;
+    if (!xyz || !xyz2 || !result || !result_i || !result2 || !result2_i) return DPF_EINVAL;
+    if (b > 65535 || n > 65535 * 32 || m > 65535 * 32 || (n < 32 && m < 32))
+        return dpf_nndistance(b, n, xyz, m, xyz2, result, result_i, result2, result2_i, stream);
+    return launch_nnm(b, n, xyz, (long)n * 3, m, xyz2, (long)m * 3, result, result_i, result2, result2_i, (hipStream_t)stream);
+}
+
+// Same contract and the same bits as dpf_nndistance; the matrix-core filtered kernel where it measured faster, the
+// VALU scan otherwise.
+extern "C" int dpf_nndistance_auto(int b, int n, const float *xyz, int m, const float *xyz2, float *result, int *result_i,
+                                   float *result2, int *result2_i, dpf_stream_t stream) {
+    if (xyz && xyz2 && result && result_i && result2 && result2_i && nnm_pays(b, n, m))
+        return launch_nnm(b, n, xyz, (long)n * 3, m, xyz2, (long)m * 3, result, result_i, result2, result2_i, (hipStream_t)stream);
     return dpf_nndistance(b, n, xyz, m, xyz2, result, result_i, result2, result2_i, stream);
+}
+
+// dpf_nndistance_strided's contract and bits (explicit per-cloud strides, 0 = broadcast: one row of pairwise_CD per
+// launch) with the same choice of kernel.
+extern "C" int dpf_nndistance_strided_auto(int b, int n, const float *xyz, long xyz_stride, int m, const float *xyz2,
+                                           long xyz2_stride, float *result, int *result_i, float *result2, int *result2_i,
+                                           dpf_stream_t stream) {
+    if (xyz && xyz2 && result && result_i && result2 && result2_i && xyz_stride >= 0 && xyz2_stride >= 0 && nnm_pays(b, n, m))
+        return launch_nnm(b, n, xyz, xyz_stride, m, xyz2, xyz2_stride, result, result_i, result2, result2_i, (hipStream_t)stream);
+    return dpf_nndistance_strided(b, n, xyz, xyz_stride, m, xyz2, xyz2_stride, result, result_i, result2, result2_i, stream);
 }

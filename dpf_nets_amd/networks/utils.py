@@ -38,7 +38,8 @@ def f_score(predicted_clouds, true_clouds, threshold=0.001):
 
 def pairwise_CD(clouds1, clouds2, bs=2048):
     """(N1, N2) matrix of Chamfer distances, cds[i, j] = CD(clouds1[i], clouds2[j])
-    (lib/networks/utils.py:90-117).  Row i is ONE strided Chamfer launch -- cloud i is broadcast
+    (lib/networks/utils.py:90-117).  Row i is ONE strided Chamfer launch (matrix-core filtered for big rows, same
+    bits) -- cloud i is broadcast
     against the batch by a zero stride instead of being expanded and copied N2 times -- plus one
     reduction launch; results are those of the reference's expand-and-call loop."""
     from .._lib import lib, check, current_stream
@@ -59,7 +60,7 @@ def pairwise_CD(clouds1, clouds2, bs=2048):
         for i in range(N1):
             for j_l in range(0, N2, bs):
                 nb = min(N2, j_l + bs) - j_l
-                check(lib().dpf_nndistance_strided(nb, n, clouds1[i].data_ptr(), 0, m, clouds2[j_l].data_ptr(), m * 3,
+                check(lib().dpf_nndistance_strided_auto(nb, n, clouds1[i].data_ptr(), 0, m, clouds2[j_l].data_ptr(), m * 3,
                                                    d1.data_ptr(), i1.data_ptr(), d2.data_ptr(), i2.data_ptr(), st),
                       "nndistance_strided")
                 check(lib().dpf_chamfer_reduce(nb, n, m, d1.data_ptr(), d2.data_ptr(),

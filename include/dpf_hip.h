@@ -77,6 +77,10 @@ int dpf_nndistance_mfma(int b, int n, const float *xyz, int m, const float *xyz2
 int dpf_nndistance_auto(int b, int n, const float *xyz, int m, const float *xyz2,
                         float *result, int *result_i, float *result2, int *result2_i,
                         dpf_stream_t stream);
+int dpf_nndistance_strided_auto(int b, int n, const float *xyz, long xyz_stride, int m,
+                                const float *xyz2, long xyz2_stride, float *result,
+                                int *result_i, float *result2, int *result2_i,
+                                dpf_stream_t stream);   /* dpf_nndistance_strided, same choice */
 
 /* Same results as dpf_nndistance, bit for bit, from ONE evaluation of every pair:
  * (b - a) and (a - b) square to the same bits, so the row minima (direction 1) and

@@ -185,3 +185,29 @@ def test_pairwise_cd_and_fscore_match_the_expand_and_call_form():
     np.testing.assert_allclose(f1, 2 * prec * rec / (prec + rec + 1e-7), rtol=1e-5)
     cd = chamfer_distance(torch.from_numpy(p).cuda(), torch.from_numpy(t).cuda())
     np.testing.assert_allclose(float(cd), float((ld.mean(1) + rd.mean(1)).mean()), rtol=1e-5)
+
+
+def test_pairwise_cd_big_rows_take_the_matrix_core_kernel_and_keep_the_bits():
+    """A row of pairwise_CD at evaluation size (40 clouds of 2048 points against one broadcast cloud) is served by
+    the matrix-core filtered kernel through dpf_nndistance_strided_auto: distances and indices must equal the VALU
+    scan's (dpf_nndistance_strided) bit for bit, and the CD row the expand-and-call form of utils.py:104-107."""
+    BK = _gpu()
+    from dpf_nets_amd._lib import lib, check, current_stream
+    from dpf_nets_amd.networks.utils import pairwise_CD
+    N2, n, m = 40, 2048, 2048
+    a = detrng.uniform_f32(401, (2, n, 3), -0.3, 0.3)
+    b = detrng.normal_f32(402, (N2, m, 3), 0.0, 0.15)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    outs = []
+    for fn in (lib().dpf_nndistance_strided, lib().dpf_nndistance_strided_auto):
+        d1 = torch.empty((N2, n), dtype=torch.float32, device="cuda"); d2 = torch.empty((N2, m), dtype=torch.float32, device="cuda")
+        i1 = torch.empty((N2, n), dtype=torch.int32, device="cuda"); i2 = torch.empty((N2, m), dtype=torch.int32, device="cuda")
+        check(fn(N2, n, ta[1].data_ptr(), 0, m, tb.data_ptr(), m * 3, d1.data_ptr(), i1.data_ptr(), d2.data_ptr(),
+                 i2.data_ptr(), current_stream()), "strided")
+        outs.append((d1, i1, d2, i2))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    cds = pairwise_CD(ta, tb)
+    ref = torch.stack([torch.stack([sum(v.mean(1) for v in BK.NNDistance(ta[i:i + 1].contiguous(), tb[j:j + 1].contiguous())[::2])[0]
+                                    for j in range(0, N2, 13)]) for i in range(2)])
+    assert torch.allclose(cds[:, ::13], ref, rtol=2e-6, atol=0)
