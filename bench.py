@@ -280,7 +280,7 @@ def main():
         else:
             roof = {"kernel": "nn_kernel", "bound": "hbm", "achieved": nn_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": nn_ach / HBM_PEAK_GBS, "traffic": traffic,
-                    "note": "brute-force Chamfer is fp32-VALU bound (AI ~800 FLOP/B); HBM fraction is tiny by construction"}
+                    "note": "exact Chamfer is compute bound (AI ~800 FLOP/B); HBM fraction is tiny by construction"}
         roof["kernels_us"] = kt
         roof["flow_algorithmic_tflops"] = flow_ach
         roof["chamfer_algorithmic_gbs"] = nn_ach
@@ -295,7 +295,9 @@ def main():
                                    "direct/eval-BN, + nn_distance both directions + CD reduction" % (L, L, n_flows),
                        "clouds_per_gpu": B, "points_per_cloud": N, "hidden": 64, "latent": args.latent,
                        "global_clouds": B * n_gpus, "per_layer_lists": bool(args.lists),
-                       "launch": "eager" if args.no_graph else "hipGraph replay", "parallelism": "clouds sharded, no collective"},
+                       "launch": "eager" if args.no_graph else "hipGraph replay", "parallelism": "clouds sharded, no collective",
+                       "chamfer_impl": BK.NN_IMPL + (" (matrix-core filtered exact search at this size)" if BK.NN_IMPL == "auto" and
+                                                     2.0 * B * N * N >= 1e8 and B * 2 * ((N + 511) // 512) >= 128 else "")},
             "roofline": roof,
         }
         if not args.no_cpu_baseline and n_gpus == 1:      # the CPU oracle is timed at N = 1 only
