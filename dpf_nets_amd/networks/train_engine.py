@@ -335,6 +335,7 @@ class FlatStore:
                 gv.copy_(t.grad)
             t.data = pv
             t.grad = gv
+            t._dpf_flat = self              # networks.optimizers.Adam updates a whole store at once
         # BatchNorm running statistics: [FiLM nets (4L) | conditioner stacks (4L)]
         self.bns = [m[1] for m in spec.film_modules()] + spec.flow_bns()
         nb = len(self.bns)

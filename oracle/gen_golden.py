@@ -268,6 +268,43 @@ def gen_encoder():
                    "keys": list(enc.state_dict().keys())}, f, indent=1)
 
 
+OPT_SHAPES = ((1, 64, 3), (64,), (7, 5), ())
+OPT_CASES = {"plain": (False, 0.0), "ams_wd": (True, 1e-6), "ams": (True, 0.0), "wd": (False, 1e-2)}
+
+
+def optimizer_inputs(seed, step):
+    """parameters (step = -1) or the gradients of a step, seeded"""
+    tag = "p" if step < 0 else "g%d" % step
+    return [detrng.normal_f32(detrng.key(seed, "%s:%d" % (tag, i)), shp, 0.0, 1.0 if step < 0 else 0.3) for i, shp in enumerate(OPT_SHAPES)]
+
+
+def gen_optimizer():
+    """lib/networks/optimizers.py: five Adam steps on four tensors under the cosine LRUpdater schedule, for the four
+    (amsgrad, weight_decay) variants; final parameters and moment buffers."""
+    from lib.networks import optimizers
+    out = {}
+    sched_kw = dict(cycle_length=3, min_lr=1e-4, max_lr=2e-3, beta1=0.9, min_beta2=0.99, max_beta2=0.999)
+    for name, (ams, wd) in OPT_CASES.items():
+        params = [torch.nn.Parameter(torch.from_numpy(np.asarray(v))) for v in optimizer_inputs(5, -1)]
+        opt = optimizers.Adam(params, lr=2e-3, weight_decay=wd, betas=(0.9, 0.999), amsgrad=ams)
+        sched = optimizers.LRUpdater(4, **sched_kw)
+        lrs = []
+        for step in range(5):
+            sched(opt, step // 4, step % 4)
+            lrs.append([opt.param_groups[0]["lr"], opt.param_groups[0]["betas"][1]])
+            for p, g in zip(params, optimizer_inputs(5, step)):
+                p.grad = torch.from_numpy(np.asarray(g))
+            opt.step()
+        for i, p in enumerate(params):
+            out["%s_p%d" % (name, i)] = p.detach().numpy()
+            out["%s_m%d" % (name, i)] = opt.state[p]["exp_avg"].numpy()
+            out["%s_v%d" % (name, i)] = opt.state[p]["exp_avg_sq"].numpy()
+            if ams:
+                out["%s_vmax%d" % (name, i)] = opt.state[p]["max_exp_avg_sq"].numpy()
+        out[name + "_sched"] = np.array(lrs, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "optimizer.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -277,6 +314,7 @@ def main():
     gen_decoder(decoders, losses)
     gen_chamfer(evaluation_metrics)
     gen_encoder()
+    gen_optimizer()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -269,3 +269,57 @@ def test_encoder_state_dict_contract(golden_dir):
     enc.eval()
     with pytest.raises(RuntimeError):
         enc(x)
+
+
+def test_mirror_adam_flat_store_path_is_bitwise_the_per_parameter_path():
+    """networks.optimizers.Adam: the parameters of a FlatStore are updated by ONE sequence of ops over the flat buffers;
+    results, per-parameter state entries (views), state_dict round trip and resumption must equal the per-parameter
+    path bit for bit (CPU tensors: no kernels involved)."""
+    import copy
+    import torch
+    from dpf_nets_amd import networks as nets
+    from dpf_nets_amd.networks.train_engine import StackSpec
+    torch.manual_seed(5)
+    ref = nets.LocalCondRNVPDecoder(1, 64, 16)
+    for p in ref.parameters():
+        p.data.normal_()
+    flat = copy.deepcopy(ref)
+    extra_r, extra_f = torch.nn.Parameter(torch.randn(5, 3)), None
+    extra_f = torch.nn.Parameter(extra_r.detach().clone())
+    fs = StackSpec(flat.coupling_layers()).flatten(torch.device("cpu"))
+    kw = dict(lr=1e-2, betas=(0.9, 0.99), weight_decay=1e-3, amsgrad=True)
+    o_r = nets.Adam(list(ref.parameters()) + [extra_r], **kw)
+    o_f = nets.Adam(list(flat.parameters()) + [extra_f], **kw)
+    gen = torch.Generator().manual_seed(1)
+
+    def one_step(opt_r, opt_f):
+        grads = [torch.randn(p.shape, generator=gen) for p in ref.parameters()] + [torch.randn(5, 3, generator=gen)]
+        opt_f.zero_grad(set_to_none=False)
+        for p, g in zip(list(ref.parameters()) + [extra_r], grads):
+            p.grad = g.clone()
+        fs.attach_grads(full=True)
+        for p, g in zip(list(flat.parameters()) + [extra_f], grads):
+            p.grad.copy_(g) if p.grad is not None else setattr(p, "grad", g.clone())
+        opt_r.step(); opt_f.step()
+
+    for _ in range(3):
+        one_step(o_r, o_f)
+    assert fs.attached() and len(o_f._flat) == 1                       # the flat path was taken
+    for (k, a), b in zip(ref.state_dict().items(), flat.state_dict().values()):
+        assert torch.equal(a, b), k
+    assert torch.equal(extra_r, extra_f)
+    w = flat.flows[0].nvp2.T_mu_0[3].weight
+    st = o_f.state[w]
+    lo, hi = o_f._flat[id(fs)]["buf"]["exp_avg"].data_ptr(), o_f._flat[id(fs)]["buf"]["exp_avg"].data_ptr() + 4 * fs.flat_p.numel()
+    assert st["step"] == 3 and lo <= st["exp_avg"].data_ptr() < hi
+    assert torch.equal(st["max_exp_avg_sq"], o_r.state[ref.flows[0].nvp2.T_mu_0[3].weight]["max_exp_avg_sq"])
+    # resume: a fresh optimizer loads the state dict (which copies every tensor) and continues identically
+    sd_r, sd_f = copy.deepcopy(o_r.state_dict()), copy.deepcopy(o_f.state_dict())
+    n_r = nets.Adam(list(ref.parameters()) + [extra_r], **kw); n_r.load_state_dict(sd_r)
+    n_f = nets.Adam(list(flat.parameters()) + [extra_f], **kw); n_f.load_state_dict(sd_f)
+    for _ in range(2):
+        one_step(n_r, n_f)
+    assert len(n_f._flat) == 1
+    for (k, a), b in zip(ref.state_dict().items(), flat.state_dict().values()):
+        assert torch.equal(a, b), k
+    assert n_f.state[w]["step"] == 5

@@ -241,3 +241,38 @@ def test_encoder_oracle_vs_reference_golden(golden_dir):
                     np.testing.assert_allclose(v, ref, rtol=2e-4, atol=2e-5 * max(1.0, float(ref[2])), err_msg=k)
                 for k, v in stats.items():
                     np.testing.assert_allclose(v.numpy(), gold[tag + "_stat_" + k], rtol=RTOL, atol=ATOL, err_msg=k)
+
+
+def test_optimizer_oracle_and_mirror_vs_reference_golden(golden_dir):
+    """oracle/optimizer_oracle.py AND dpf_nets_amd.networks.optimizers (Adam incl. AMSGrad / weight decay, LRUpdater)
+    against five steps of the reference's own optimizer (lib/networks/optimizers.py) under its cosine schedule."""
+    from oracle import optimizer_oracle as OO
+    from oracle.gen_golden import OPT_CASES, optimizer_inputs
+    from dpf_nets_amd.networks import optimizers as MO
+    gold = np.load(os.path.join(golden_dir, "optimizer.npz"))
+    sched_kw = dict(cycle_length=3, min_lr=1e-4, max_lr=2e-3, beta1=0.9, min_beta2=0.99, max_beta2=0.999)
+    for name, (ams, wd) in OPT_CASES.items():
+        ps = [torch.from_numpy(np.asarray(v)) for v in optimizer_inputs(5, -1)]
+        states = [dict() for _ in ps]
+        mps = [torch.nn.Parameter(torch.from_numpy(np.asarray(v))) for v in optimizer_inputs(5, -1)]
+        opt = MO.Adam(mps, lr=2e-3, weight_decay=wd, betas=(0.9, 0.999), amsgrad=ams)
+        sched = MO.LRUpdater(4, **sched_kw)
+        for step in range(5):
+            lr, betas = OO.lr_update(4, 3, 1e-4, 2e-3, 0.9, 0.99, 0.999, step // 4, step % 4)
+            sched(opt, step // 4, step % 4)
+            assert opt.param_groups[0]["lr"] == lr and opt.param_groups[0]["betas"] == betas
+            np.testing.assert_allclose([lr, betas[1]], gold[name + "_sched"][step], rtol=1e-15)
+            gs = [torch.from_numpy(np.asarray(g)) for g in optimizer_inputs(5, step)]
+            ps = [OO.adam_step(p, g, st, lr, betas, 1e-8, wd, ams) for p, g, st in zip(ps, gs, states)]
+            for p, g in zip(mps, gs):
+                p.grad = g
+            opt.step()
+        for i in range(len(ps)):
+            for got, tol in ((ps[i].numpy(), 2e-6), (mps[i].detach().numpy(), 0.0)):    # the mirror runs the same ATen ops
+                np.testing.assert_allclose(got, gold["%s_p%d" % (name, i)], rtol=tol, atol=tol * 1e-2)
+            st = opt.state[mps[i]]
+            assert st["step"] == 5
+            np.testing.assert_array_equal(st["exp_avg"].numpy(), gold["%s_m%d" % (name, i)])
+            np.testing.assert_array_equal(st["exp_avg_sq"].numpy(), gold["%s_v%d" % (name, i)])
+            if ams:
+                np.testing.assert_array_equal(st["max_exp_avg_sq"].numpy(), gold["%s_vmax%d" % (name, i)])
