@@ -267,6 +267,28 @@ __device__ __forceinline__ void chain_mfma(const uint8_t *a1, int br, int lane, 
     }
 }
 
+// The same contraction with the operands swapped (activations = A, weights = B; the two fragment layouts of the
+// 32x32x16 MFMA mirror each other, so the same registers and the same packed fragments serve): the accumulator of
+// M tile tp then holds, in LANE pl, feature 32*tp + pl of the 16 POINTS (r&3) + 8*(r>>2) + 4h of the tile -- sums
+// over the points of a tile become in-lane adds plus one cross-half swap instead of a cross-lane butterfly.
+template <int NS>
+__device__ __forceinline__ void chain_mfma_swapped(const uint8_t *a1, int br, int lane, const u32x4 (&bf)[NS][4], f32x16 (&acc)[2]) {
+    using TT = Terms<NS>;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        u32x4 af[NS][2];
+#pragma unroll
+        for (int part = 0; part < NS; ++part)
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp)
+                af[part][tp] = *(const u32x4 *)(a1 + part * P_A1_PART + (((br * 2 + tp) * 4 + s) * 64 + lane) * 16);
+#pragma unroll
+        for (int term = 0; term < TT::N; ++term)
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp) acc[tp] = mfma(bf[TT::B[term]][s], af[TT::A[term]][tp], acc[tp]);
+    }
+}
+
 // per-lane vector of a per-feature LDS array for the features this lane holds: out[t][r]
 __device__ __forceinline__ void load_features(const float *vec, int h, f32x16 (&out)[2]) {
 #pragma unroll
@@ -351,18 +373,24 @@ __global__ __launch_bounds__(TW * 64) void tstats_h1_kernel(TArgs a, float *__re
         u32x4 bf[NS][4];
         input_mfma(smem + pt_a0(NS), br, lane, b0, acc0);
         split_fragment<true, NS>(acc0, bf);
-        chain_mfma<NS>(smem + PT_A1, br, lane, bf, acc1);
+        chain_mfma_swapped<NS>(smem + PT_A1, br, lane, bf, acc1);         // lane = feature, registers = points
+        const int tile0 = (blockIdx.x * TW + wave) * TILE;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) {
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                acc1[t][r] = valid ? acc1[t][r] : 0.f;                   // padding lanes do not count
+                const float v = tile0 + (r & 3) + 8 * (r >> 2) + 4 * h < N ? acc1[t][r] : 0.f;   // padding points do not count
+                s1 += v;
+                s2 = __builtin_fmaf(v, v, s2);
             }
-        const float s1 = reduce_points(acc1, pl);
-        const float s2 = reduce_points_gen([&](int i) { return acc1[i >> 4][i & 15] * acc1[i >> 4][i & 15]; }, pl);
-        const int f = reduced_feature(pl, h);
-        acc_s[wave][br][0][f] = s1;
-        acc_s[wave][br][1][f] = s2;
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (!h) {
+                acc_s[wave][br][0][32 * t + pl] = s1;
+                acc_s[wave][br][1][32 * t + pl] = s2;
+            }
+        }
     }
     __syncthreads();
     if (threadIdx.x < 256) {
