@@ -256,6 +256,7 @@ def main():
         pts_per_step = args.batch * args.points * n_gpus
         ms_per_step = elapsed / args.steps * 1e3
         kt = kernel_timings(dec, z, g, tgt_pm, L, args.precision)
+        from dpf_nets_amd.metrics.StructuralLosses import StructuralLossesBackend as BK
         dom = max(("flow_kernel", "nn_kernel"), key=lambda k: kt[k])
         B, N = args.batch, args.points
         flow_flops = FLOP_PER_POINT_LAYER * L * B * N

@@ -398,6 +398,110 @@ __device__ __forceinline__ void branch_tile(const uint8_t *lb, int br, int lane,
     ob = ob2.x + ob2.y;
 }
 
+// -DDPF_FLOW_PAIRED_BRANCHES: both conditioner branches (logvar, mu) of one layer for one tile, stage by stage with
+// the branches interleaved: they depend on the same input only, so a wave has twice the independent work in flight
+// (4 input MFMAs back to back, 4 accumulators in the W1 contraction).  Measured r01 at cfg-2: 67.5 us vs 64.8 us for
+// the two branches one after the other (248 vs 72 VGPRs; bit-identical) -- not the default.
+template <int NS, bool TWO>
+__device__ __forceinline__ void branch_pair(const uint8_t *lb, int lane, int h, u32x4 b0, float (&o)[2][2]) {
+    constexpr int A0OFF = p_a0_off(NS), FILMOFF = p_layer_bytes(NS);
+    typedef Terms<NS> TT;
+    const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // ---- h0 = relu(BN0(W0 x))
+    f32x16 acc0[2][2];
+#pragma unroll
+    for (int br = 0; br < 2; ++br)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            acc0[br][t] = mfma(*(const u32x4 *)(lb + A0OFF + ((br * 2 + t) * 64 + lane) * 16), b0, z16);
+    u32x4 bfrag[2][NS][4];
+#pragma unroll
+    for (int br = 0; br < 2; ++br)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float v0 = relu(acc0[br][t][r]), v1 = relu(acc0[br][t][r + 1]);
+                const int s = 2 * t + (r >> 3), d = (r & 7) >> 1;
+                if (NS == 1) {
+                    bfrag[br][0][s][d] = pack_bf16_rne(v0, v1);
+                } else if (NS == 2) {
+                    float l0, l1;
+                    split_hi(v0, l0); split_hi(v1, l1);
+                    bfrag[br][0][s][d] = pack_bf16_trunc(v0, v1);
+                    bfrag[br][1][s][d] = pack_bf16_rne(l0, l1);
+                } else {
+                    float l0, l1, m0, m1;
+                    split_hi(v0, l0); split_hi(v1, l1);
+                    split_hi(l0, m0); split_hi(l1, m1);
+                    bfrag[br][0][s][d] = pack_bf16_trunc(v0, v1);
+                    bfrag[br][1][s][d] = pack_bf16_trunc(l0, l1);
+                    bfrag[br][2][s][d] = pack_bf16_rne(m0, m1);
+                }
+            }
+    // ---- h1 = W1 h0 + D
+    const float *fl = (const float *)(lb + FILMOFF);
+    f32x16 acc1[2][2];
+#pragma unroll
+    for (int br = 0; br < 2; ++br)
+#pragma unroll
+        for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 dv = *(const f32x4 *)(fl + br * FILM_BR_FLOATS + 32 * tp + 8 * q + 4 * h);
+                acc1[br][tp][4 * q + 0] = dv.x; acc1[br][tp][4 * q + 1] = dv.y;
+                acc1[br][tp][4 * q + 2] = dv.z; acc1[br][tp][4 * q + 3] = dv.w;
+            }
+    u32x4 af[2][2][2 * NS];
+    auto load_batch = [&](int ks, u32x4 (&dst)[2][2 * NS]) {
+#pragma unroll
+        for (int br = 0; br < 2; ++br)
+#pragma unroll
+            for (int part = 0; part < NS; ++part)
+#pragma unroll
+                for (int tp = 0; tp < 2; ++tp)
+                    dst[br][part * 2 + tp] = *(const u32x4 *)(lb + part * P_A1_PART + (((br * 2 + tp) * 4 + ks) * 64 + lane) * 16);
+    };
+    load_batch(0, af[0]);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        if (ks + 1 < 4) load_batch(ks + 1, af[(ks + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int term = 0; term < TT::N; ++term)
+#pragma unroll
+            for (int br = 0; br < 2; ++br)
+#pragma unroll
+                for (int tp = 0; tp < 2; ++tp)
+                    acc1[br][tp] = mfma(af[ks & 1][br][TT::A[term] * 2 + tp], bfrag[br][TT::B[term]][ks], acc1[br][tp]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- o = W2' relu(h1 + D): packed FMAs on (even, odd) partial sums over natural register pairs (see branch_tile)
+#pragma unroll
+    for (int br = 0; br < 2; ++br) {
+        const float *wa = fl + br * FILM_BR_FLOATS + 64, *wb2 = wa + 64;
+        f32x2 oa2 = {0.f, 0.f}, ob2 = {0.f, 0.f};
+#pragma unroll
+        for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int f0 = 32 * tp + 8 * q + 4 * h;
+                const f32x2 v01 = {relu(acc1[br][tp][4 * q + 0]), relu(acc1[br][tp][4 * q + 1])};
+                const f32x2 v23 = {relu(acc1[br][tp][4 * q + 2]), relu(acc1[br][tp][4 * q + 3])};
+                const f32x4 wa4 = *(const f32x4 *)(wa + f0);
+                oa2 = __builtin_elementwise_fma(f32x2{wa4.x, wa4.y}, v01, oa2);
+                oa2 = __builtin_elementwise_fma(f32x2{wa4.z, wa4.w}, v23, oa2);
+                if (TWO) {
+                    const f32x4 wb4 = *(const f32x4 *)(wb2 + f0);
+                    ob2 = __builtin_elementwise_fma(f32x2{wb4.x, wb4.y}, v01, ob2);
+                    ob2 = __builtin_elementwise_fma(f32x2{wb4.z, wb4.w}, v23, ob2);
+                }
+            }
+        o[br][0] = oa2.x + oa2.y;
+        o[br][1] = ob2.x + ob2.y;
+    }
+}
+
 __device__ __forceinline__ float half_sum(float x) {   // x(lane) + x(lane ^ 32)
     const auto r = __builtin_amdgcn_permlane32_swap(f2u(x), f2u(x), false, false);
     return u2f(r[0]) + u2f(r[1]);
@@ -452,6 +556,7 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
         int nka, nkb, nwa, nwb;
         layer_meta(ln, nka, nkb, nwa, nwb);
         unsigned long long tt[8];
+        (void)tt;
         DPF_T(0)
         // ---- B operand of the input MFMA: 3-way bf16 split of this half's input channel
         const float xa = sel3(ka, p0, p1, p2);
@@ -460,6 +565,7 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
         const u32x4 b0 = input_fragment(x, h);
 
         float o[2][2];
+#ifndef DPF_FLOW_PAIRED_BRANCHES
         if (wb < 0) {                                       // layer warps one channel
             branch_tile<NS, false>(lb, 0, lane, h, b0, o[0][0], o[0][1], tt);
             branch_tile<NS, false>(lb, 1, lane, h, b0, o[1][0], o[1][1], tt);
@@ -467,6 +573,10 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
             branch_tile<NS, true>(lb, 0, lane, h, b0, o[0][0], o[0][1], tt);
             branch_tile<NS, true>(lb, 1, lane, h, b0, o[1][0], o[1][1], tt);
         }
+#else
+        if (wb < 0) branch_pair<NS, false>(lb, lane, h, b0, o);   // layer warps one channel
+        else branch_pair<NS, true>(lb, lane, h, b0, o);
+#endif
         DPF_T(3)
         const float *b2 = (const float *)(lb + FILMOFF) + FILM_B2_OFF;
 #pragma unroll
