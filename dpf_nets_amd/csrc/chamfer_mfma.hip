@@ -63,7 +63,6 @@ __host__ __device__ inline int tiles_of(int n) { return (n + 31) / 32; }
 //   slots: [x:0-3] [y:4-7] [z:8-11] [norm:12-14] [15: 0]
 //   role A (candidate): coord -> (ch, ch, cl, cl),   norm -> (wh, wm, wl)      w = (x*x + y*y) + z*z
 //   role B (query):     coord -> (qh, ql, qh, ql) of -2q,  norm -> (1, 1, 1)
-__device__ __forceinline__ uint32_t cand_pair_hi(float c) { uint32_t hi, lo; split2(c, hi, lo); return hi | (hi << 16); }
 __device__ __forceinline__ void cand_coord(float c, uint32_t &w0, uint32_t &w1) {      // (ch, ch), (cl, cl)
     uint32_t hi, lo;
     split2(c, hi, lo);
@@ -103,7 +102,7 @@ struct MDir {
     int nq, nc;
     long qstride, cstride;     // floats between consecutive clouds (0 = one cloud broadcast over the batch)
 };
-struct MArgs { MDir d[2]; int debug; };
+struct MArgs { MDir d[2]; };
 
 __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b) {
     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -321,7 +320,6 @@ static int launch_nnm(int b, int n, const float *xyz, long xyz_stride, int m, co
     MArgs ma;
     ma.d[0] = MDir{xyz, xyz2, result, result_i, n, m, xyz_stride, xyz2_stride};       // nndistance.cu:126
     ma.d[1] = MDir{xyz2, xyz, result2, result2_i, m, n, xyz2_stride, xyz_stride};     // nndistance.cu:127
-    ma.debug = 0;
     const int nmax = n > m ? n : m;
     const int lds = CT * 1536 + QW * QCAP * 64 * 6;
     static bool attr_set = false;
