@@ -136,25 +136,30 @@ __global__ __launch_bounds__(256) void tstats_x_kernel(int N, int ka, int kb, co
 
 // BN0 batch statistics (analytic: h0 = W0 x is linear in x) and the two folded input-MFMA fragment
 // sets of the layer.  One workgroup, thread = (branch, feature).
-__global__ __launch_bounds__(128) void tbn0_kernel(int nblk, int nk, double count, const double *__restrict__ part,
+// 512 threads: the moments and the per-feature folds need 128 of them, the 2 x 2048 fragment slots they feed take all
+// (with 128 threads the slot loop alone was 16 serial iterations of ~80 instructions: 9.3 us for the kernel)
+__global__ __launch_bounds__(512) void tbn0_kernel(int nblk, int nk, double count, const double *__restrict__ part,
                                                    const float *__restrict__ tcanon_l, uint8_t *__restrict__ packed_a0,
                                                    float *__restrict__ stats_l) {
     __shared__ double mom[5], wsum[2][5];
     __shared__ float fold[2][64][4];
     __shared__ float foldn[2][64][4];
-    {   // fixed-order tree over the per-workgroup partials
-        double v[5] = {0, 0, 0, 0, 0};
-        for (int b = threadIdx.x; b < nblk; b += 128)
-            for (int i = 0; i < 5; ++i) v[i] += part[(size_t)b * 8 + i];
+    {   // fixed-order tree over the per-workgroup partials (the first two waves, as before)
+        if (threadIdx.x < 128) {
+            double v[5] = {0, 0, 0, 0, 0};
+            for (int b = threadIdx.x; b < nblk; b += 128)
+                for (int i = 0; i < 5; ++i) v[i] += part[(size_t)b * 8 + i];
 #pragma unroll
-        for (int i = 0; i < 5; ++i)
-            for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
-        if ((threadIdx.x & 63) == 0)
-            for (int i = 0; i < 5; ++i) wsum[threadIdx.x >> 6][i] = v[i];
+            for (int i = 0; i < 5; ++i)
+                for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
+            if ((threadIdx.x & 63) == 0)
+                for (int i = 0; i < 5; ++i) wsum[threadIdx.x >> 6][i] = v[i];
+        }
         __syncthreads();
         if (threadIdx.x < 5) mom[threadIdx.x] = (wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) / count;
         __syncthreads();
     }
+    if (threadIdx.x < 128) {
     const int br = threadIdx.x >> 6, f = threadIdx.x & 63;
     const float *cb = tcanon_l + br * T_BR;
     const double wa = cb[T_W0 + f * nk], wb = nk == 2 ? cb[T_W0 + f * 2 + 1] : 0.0;
@@ -176,6 +181,7 @@ __global__ __launch_bounds__(128) void tbn0_kernel(int nblk, int nk, double coun
     const float s0 = gamma * rstd;
     fold[br][f][0] = s0 * (float)wa; fold[br][f][1] = s0 * (float)wb; fold[br][f][2] = beta - (float)mean * s0;
     foldn[br][f][0] = rstd * (float)wa; foldn[br][f][1] = rstd * (float)wb; foldn[br][f][2] = -(float)mean * rstd;
+    }
     __syncthreads();
     uint16_t *a0 = (uint16_t *)packed_a0, *a0n = (uint16_t *)(packed_a0 + 4096);
     for (int idx = threadIdx.x; idx < 2 * 2 * 64 * 8; idx += blockDim.x) {
@@ -997,7 +1003,7 @@ static int prepare_layer(int B, int N, int ka, int kb, const float *tcanon_l, vo
     const int nbx = (N + 255) / 256;
     const double count = (double)B * N;
     hipLaunchKernelGGL(tstats_x_kernel, dim3(nbx, B), dim3(256), 0, s, N, ka, kb, p_in, w.xpart);
-    hipLaunchKernelGGL(tbn0_kernel, dim3(1), dim3(128), 0, s, nbx * B, kb >= 0 ? 2 : 1, count, w.xpart, tcanon_l,
+    hipLaunchKernelGGL(tbn0_kernel, dim3(1), dim3(512), 0, s, nbx * B, kb >= 0 ? 2 : 1, count, w.xpart, tcanon_l,
                        (uint8_t *)packed_l + pt_a0(NS), stats_l);
     TArgs a;
     a.packed_l = (const uint8_t *)packed_l; a.tcanon_l = tcanon_l; a.film_l = film_l; a.filmb_l = film_l + (size_t)B * 512;
