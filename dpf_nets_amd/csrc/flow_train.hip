@@ -607,7 +607,13 @@ __global__ __launch_bounds__(520) void tcloudsum_kernel(int nb, int B, const flo
                                                         float eps, float *__restrict__ pc, float *__restrict__ dfm_l) {
     const int b = blockIdx.x, j = threadIdx.x;
     float s = 0;
-    for (int k = 0; k < nb; ++k) s += part1[((size_t)b * nb + k) * 520 + j];
+    for (int k0 = 0; k0 < nb; k0 += 8) {                                        // eight loads in flight, added in order
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = k0 + i < nb ? part1[((size_t)b * nb + k0 + i) * 520 + j] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[i];
+    }
     pc[(size_t)b * 520 + j] = s;
     if (j < 512) {
         const int br = j >> 8, k = (j >> 6) & 3, f = j & 63;
