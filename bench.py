@@ -298,7 +298,7 @@ def main():
                        "global_clouds": B * n_gpus, "per_layer_lists": bool(args.lists),
                        "launch": "eager" if args.no_graph else "hipGraph replay", "parallelism": "clouds sharded, no collective",
                        "chamfer_impl": BK.NN_IMPL + (" (matrix-core filtered exact search at this size)" if BK.NN_IMPL == "auto" and
-                                                     2.0 * B * N * N >= 1e8 and B * 2 * ((N + 511) // 512) >= 128 else "")},
+                                                     2.0 * B * N * N >= 1e8 and B * 2 * ((N + 255) // 256) >= 64 else "")},
             "roofline": roof,
         }
         if not args.no_cpu_baseline and n_gpus == 1:      # the CPU oracle is timed at N = 1 only

@@ -40,7 +40,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int QW = 16;           // waves per workgroup, 32 queries each
+// waves per workgroup (32 queries each): template parameter QW = 16, or 8 when that is what fills the chip
 constexpr int CT = 64;           // candidate tiles resident in LDS at a time (64 KiB of fragments + 32 KiB of points)
 constexpr int QCAP = 8;          // queued candidate tiles per lane (compacted when full)
 
@@ -159,6 +159,7 @@ typedef __attribute__((address_space(1))) const void glb_void;
 // candidates' MFMA fragments and packed points in LDS (96 KiB; two points per thread) and all 16 waves share them;
 // per tile a wave issues one ds_read_b128, one MFMA and a v_min3 tree.  R2 is taken over ALL candidates and over
 // the queries of THIS workgroup: the surrogate's error bound is per pair.
+template <int QW>
 __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint4 *sfrag = (uint4 *)lds;                                  // [CT][64]
@@ -315,31 +316,41 @@ extern "C" size_t dpf_nndistance_mfma_workspace_bytes(int b, int n, int m) {
     return 0;            // the fragments are built inside the kernel since r01; the argument is kept for the ABI
 }
 
+static long nnm_workgroups(int b, int n, int m, int qw) {
+    return (long)b * ((n + qw * 32 - 1) / (qw * 32) + (m + qw * 32 - 1) / (qw * 32));
+}
+
+template <int QW>
+static int launch_nnm_qw(const MArgs &ma, int b, int nmax, hipStream_t s) {
+    const int lds = CT * 1536 + QW * QCAP * 64 * 6;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)nnm_kernel<QW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(nnm_kernel<QW>, dim3((nmax + QW * 32 - 1) / (QW * 32), b, 2), dim3(QW * 64), lds, s, ma);
+    return (int)hipGetLastError();
+}
+
+// 16 waves (512 queries) per workgroup share one build of the candidates' fragments; when that leaves fewer than 128
+// workgroups (small batches of big clouds, e.g. B = 2, N = 8192 per GPU in cfg-5) 8-wave workgroups fill twice the CUs
 static int launch_nnm(int b, int n, const float *xyz, long xyz_stride, int m, const float *xyz2, long xyz2_stride,
                       float *result, int *result_i, float *result2, int *result2_i, hipStream_t s) {
     MArgs ma;
     ma.d[0] = MDir{xyz, xyz2, result, result_i, n, m, xyz_stride, xyz2_stride};       // nndistance.cu:126
     ma.d[1] = MDir{xyz2, xyz, result2, result2_i, m, n, xyz2_stride, xyz_stride};     // nndistance.cu:127
     const int nmax = n > m ? n : m;
-    const int lds = CT * 1536 + QW * QCAP * 64 * 6;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)nnm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(nnm_kernel, dim3((nmax + QW * 32 - 1) / (QW * 32), b, 2), dim3(QW * 64), lds, s, ma);
-    return (int)hipGetLastError();
+    return nnm_workgroups(b, n, m, 16) >= 128 ? launch_nnm_qw<16>(ma, b, nmax, s) : launch_nnm_qw<8>(ma, b, nmax, s);
 }
 
-// enough pairs to amortise building the fragments and enough 512-query workgroups to fill the chip (r01,
-// tools/nn_impl_sweep.py: 25 vs 52 us at B=32, n=m=2048; 76 vs 190 us at B=8, n=m=8192); small clouds and small
+// enough pairs to amortise building the fragments and enough workgroups to fill the chip (r01, tools/nn_impl_sweep.py:
+// 25 vs 52 us at B=32, n=m=2048; 76 vs 190 us at B=8, n=m=8192; 50 vs 64 us at B=2, n=m=8192); small clouds and small
 // batches are launch-bound either way and few workgroups leave the matrix cores idle
 static bool nnm_pays(int b, int n, int m) {
     if (b <= 0 || n <= 0 || m <= 0 || b > 65535 || n > 65535 * 32 || m > 65535 * 32) return false;
     const double pairs = 2.0 * (double)b * (double)n * (double)m;
-    const long wgs = (long)b * ((n + QW * 32 - 1) / (QW * 32) + (m + QW * 32 - 1) / (QW * 32));
-    return pairs >= 1.0e8 && wgs >= 128;
+    return pairs >= 1.0e8 && nnm_workgroups(b, n, m, 8) >= 64;      // B=1, n=m=8192: 48 vs 57 us
 }
 
 extern "C" int dpf_nndistance_mfma(int b, int n, const float *xyz, int m, const float *xyz2, float *result,

@@ -13,7 +13,7 @@ from ..._lib import lib, check, current_stream
 
 
 # Chamfer forward implementation; all return identical bits (tests/test_gpu_chamfer.py):
-#   "auto"   (default) dpf_nndistance_auto: "mfma" for big problems (>= 1e8 pair evaluations, >= 128 workgroups),
+#   "auto"   (default) dpf_nndistance_auto: "mfma" for big problems (>= 1e8 pair evaluations, >= 64 workgroups of 256 queries),
 #            "brute" otherwise
 #   "brute"  O(n*m) exact VALU scan at ~80 % of its issue bound, data-independent cost
 #   "mfma"   matrix-core filter (one bf16 MFMA per 32x32 pairs) + exact verification of the few candidates that can

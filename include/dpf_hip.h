@@ -72,7 +72,7 @@ int dpf_nndistance_mfma(int b, int n, const float *xyz, int m, const float *xyz2
                         void *workspace, size_t workspace_bytes, dpf_stream_t stream);
 
 /* dpf_nndistance's contract and bits; the matrix-core filtered kernel where it is the faster
- * one (>= 1e8 pair evaluations and >= 128 workgroups of 512 queries), the VALU scan otherwise.
+ * one (>= 1e8 pair evaluations and >= 64 workgroups of 256 queries), the VALU scan otherwise.
  * This is what the Python mirror calls by default. */
 int dpf_nndistance_auto(int b, int n, const float *xyz, int m, const float *xyz2,
                         float *result, int *result_i, float *result2, int *result2_i,
