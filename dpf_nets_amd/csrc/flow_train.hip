@@ -929,6 +929,73 @@ __global__ __launch_bounds__(128) void tfinish2_kernel(int nk, double count, con
 }
 
 // Pass 3: the conditioner path of d(input points), elementwise
+// tfinish2 + tbwd3 in one launch (a tiny dependent kernel costs ~4.5 us here whatever it does): EVERY workgroup
+// recomputes the six input-gradient coefficients from the 512 totals (128 threads of double arithmetic, same
+// operations in the same order as tfinish2, so the same bits), workgroup (0,0) also writes d gamma0 / d beta0 / dW0,
+// and the dW1 totals are converted by whoever comes first (grid-stride).  No cross-workgroup dependency.
+__global__ __launch_bounds__(256) void tbwd3f_kernel(int N, int ka, int kb, int nk, double count, const double *__restrict__ tot,
+                                                     const float *__restrict__ tcanon_l, const float *__restrict__ stats_l,
+                                                     float *__restrict__ dcanon_l, const float *__restrict__ p_in,
+                                                     const float *__restrict__ ubuf, float *__restrict__ dp_in) {
+    __shared__ double acc[2][4][128];
+    __shared__ float coef[8];
+    const int blk = blockIdx.y * gridDim.x + blockIdx.x, nblk = gridDim.x * gridDim.y;
+    for (int i = blk * 256 + threadIdx.x; i < 2 * 4096; i += nblk * 256) {   // dW1: (2, 4096) totals -> dcanon
+        const int b2 = i >> 12, j = i & 4095;
+        dcanon_l[b2 * T_BR + T_W1 + j] = (float)tot[(size_t)b2 * P2_J + 128 + j];
+    }
+    if (threadIdx.x < 128) {
+        const int br = threadIdx.x >> 6, f = threadIdx.x & 63;
+        const double *t = tot + (size_t)br * P2_J;
+        const float *cb = tcanon_l + br * T_BR;
+        const double Sg = t[f], S = t[64 + f], Sa = t[4224 + f], Sb = t[4288 + f];
+        const float *m = stats_l + ST_MOM;
+        const double ea = m[0], eb = m[1], caa = m[2], cbb = m[3], cab = m[4];
+        const double wa = cb[T_W0 + f * nk], wb = nk == 2 ? cb[T_W0 + f * 2 + 1] : 0.0, gamma = cb[T_G0 + f];
+        const double rstd0 = stats_l[br * ST_BR + 64 + f], mean0 = stats_l[br * ST_BR + f];
+        const double A = S / count, Bc = Sg / count;
+        const double hxa = rstd0 * (wa * caa + wb * cab), hxb = rstd0 * (wa * cab + wb * cbb);     // E[h0n x_k]
+        const double sc = rstd0 * gamma;
+        if (blk == 0) {
+            dcanon_l[br * T_BR + T_G0 + f] = (float)Sg;
+            dcanon_l[br * T_BR + T_B0 + f] = (float)S;
+            dcanon_l[br * T_BR + T_W0 + f * nk] = (float)(sc * (Sa - A * ea * count - Bc * hxa * count));
+            if (nk == 2) dcanon_l[br * T_BR + T_W0 + f * 2 + 1] = (float)(sc * (Sb - A * eb * count - Bc * hxb * count));
+            else dcanon_l[br * T_BR + T_W0 + 64 + f] = 0.f;
+        }
+        const double ck[2] = {wa * sc, wb * sc};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            acc[k][0][threadIdx.x] = ck[k] * A;
+            acc[k][1][threadIdx.x] = ck[k] * Bc * rstd0 * wa;
+            acc[k][2][threadIdx.x] = ck[k] * Bc * rstd0 * wb;
+            acc[k][3][threadIdx.x] = ck[k] * Bc * rstd0 * mean0;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const int k = threadIdx.x >> 2, q = threadIdx.x & 3;
+        double s = 0;
+        for (int i = 0; i < 128; ++i) s += acc[k][q][i];
+        acc[k][q][0] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const int k = threadIdx.x;
+        coef[k * 4 + 0] = (float)(acc[k][0][0] - acc[k][3][0]);
+        coef[k * 4 + 1] = (float)acc[k][1][0];
+        coef[k * 4 + 2] = (float)acc[k][2][0];
+    }
+    __syncthreads();
+    const int bi = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const float *pc = p_in + (size_t)bi * 3 * N;
+    float *d = dp_in + (size_t)bi * 3 * N;
+    const float xa = pc[(size_t)ka * N + n], xb = kb >= 0 ? pc[(size_t)kb * N + n] : 0.f;
+    d[(size_t)ka * N + n] += ubuf[((size_t)bi * 2 + 0) * N + n] - coef[0] - coef[1] * xa - coef[2] * xb;
+    if (kb >= 0) d[(size_t)kb * N + n] += ubuf[((size_t)bi * 2 + 1) * N + n] - coef[4] - coef[5] * xa - coef[6] * xb;
+}
+
 __global__ __launch_bounds__(256) void tbwd3_kernel(int N, int ka, int kb, const float *__restrict__ p_in, const float *__restrict__ ubuf,
                                                     const float *__restrict__ coef, float *__restrict__ dp_in) {
     const int bi = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
@@ -1088,8 +1155,8 @@ static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb
     hipLaunchKernelGGL(tfinish1_kernel, dim3(1), dim3(1024), 0, s, B, count, w.pc, a.filmb_l, w.s12, dcanon_l);
     hipLaunchKernelGGL(tbwd2_kernel<NS>, grid, dim3(TW * 64), lds2, s, a, w.s12, w.dout, w.ubuf, w.part2);
     hipLaunchKernelGGL(tcolsum_kernel, dim3((2 * P2_J + 31) / 32), dim3(1024), 0, s, nblk, 2 * P2_J, w.part2, w.tot2);
-    hipLaunchKernelGGL(tfinish2_kernel, dim3(65), dim3(128), 0, s, kb >= 0 ? 2 : 1, count, w.tot2, tcanon_l, stats_l, dcanon_l, w.coef);
-    hipLaunchKernelGGL(tbwd3_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, N, ka, kb, p_in, w.ubuf, w.coef, dp_in);
+    hipLaunchKernelGGL(tbwd3f_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, N, ka, kb, kb >= 0 ? 2 : 1, count, w.tot2, tcanon_l,
+                       stats_l, dcanon_l, p_in, w.ubuf, dp_in);
     return (int)hipGetLastError();
 }
 
