@@ -17,13 +17,18 @@
 //            flow_kernel   (csrc/flow.hip, L = 1) the layer itself
 //  backward  tbwd1         recompute to h2; d(outputs) -> d(o) (4 floats/point, stored), dW2, db2,
 //                          per-cloud d FiLM(a, c)
-//            tfinish1      FiLM gradients, BN1 backward sums
-//            tbwd2         recompute; BN1 backward; dh0 = W1^T dh1 and dW1 = dh1 h0^T on the
-//                          matrix cores; per point u_k = sum_f c_fk dh0a[f] (2 floats, stored);
-//                          per feature sums of dh0a * {1, h0n, x_a, x_b}
-//            tcolsum + tfinish2   d gamma0, d beta0, dW1, dW0 (BN0 backward in closed form: h0n is
-//                          linear in x, so its sums over points follow from the x moments)
-//            tbwd3         d(input) = direct term + u_k - affine(x): elementwise
+//            tcloudsum     per-cloud totals of pass 1, FiLM gradients
+//            tbwd2         (prologue: BN1 backward means, dW2, db2 from those totals -- every workgroup
+//                          recomputes them rather than wait for a one-workgroup kernel); recompute; BN1
+//                          backward; dh0 = W1^T dh1 and dW1 = dh1 h0^T on the matrix cores; per point
+//                          u_k = sum_f c_fk dh0a[f] (2 floats, stored); per feature sums of
+//                          dh0a * {1, h0n, x_a, x_b}
+//            tcolsum       per-workgroup partials -> totals
+//            tbwd3f        d gamma0, d beta0, dW1, dW0 (BN0 backward in closed form: h0n is linear in x,
+//                          so its sums over points follow from the x moments) and
+//                          d(input) = direct term + u_k - affine(x), elementwise, in one launch
+// (every dependent launch costs ~4.5 us on this part however small the kernel, so the tiny finishing steps are
+// recomputed by their consumers instead of being kernels of their own)
 //
 // Activations are RECOMPUTED from the layer input in both backward passes (MFMA work is cheap);
 // nothing of size (B*N, 64) ever goes to HBM -- between the passes travel 4 + 2 floats per point.
@@ -622,34 +627,7 @@ __global__ __launch_bounds__(520) void tcloudsum_kernel(int nb, int B, const flo
     }
 }
 
-// BN1 backward sums and the output SharedDot's parameter gradients from the per-cloud totals:
-//   s12[br][2][64] = (sum dh1n, sum dh1n*h1n) / P,  dh1n = a * dh2a;   dW2, db2 -> dcanon_l
-__global__ __launch_bounds__(1024) void tfinish1_kernel(int B, double count, const float *__restrict__ pc,
-                                                        const float *__restrict__ filmb_l, float *__restrict__ s12,
-                                                        float *__restrict__ dcanon_l) {
-    __shared__ double acc[8][5][128];
-    const int q = threadIdx.x & 127, grp = threadIdx.x >> 7, br = q >> 6, f = q & 63;
-    double S1 = 0, S2 = 0, w2a = 0, w2b = 0, bb = 0;
-    for (int b = grp; b < B; b += 8) {
-        const float *qq = pc + (size_t)b * 520 + br * 256;
-        const double av = filmb_l[(size_t)b * FB_CLOUD + br * FB_BR + f];
-        S1 += av * qq[3 * 64 + f];                                               // dh1n = a * dh2a
-        S2 += av * qq[2 * 64 + f];                                               // dh1n * h1n
-        w2a += qq[0 * 64 + f]; w2b += qq[1 * 64 + f];
-        if (f < 2) bb += pc[(size_t)b * 520 + 512 + br * 2 + f];
-    }
-    acc[grp][0][q] = S1; acc[grp][1][q] = S2; acc[grp][2][q] = w2a; acc[grp][3][q] = w2b; acc[grp][4][q] = bb;
-    __syncthreads();
-    if (grp != 0) return;
-    S1 = S2 = w2a = w2b = bb = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { S1 += acc[k][0][q]; S2 += acc[k][1][q]; w2a += acc[k][2][q]; w2b += acc[k][3][q]; bb += acc[k][4][q]; }
-    s12[(br * 2 + 0) * 64 + f] = (float)(S1 / count);
-    s12[(br * 2 + 1) * 64 + f] = (float)(S2 / count);
-    dcanon_l[br * T_BR + T_W2 + f] = (float)w2a;
-    dcanon_l[br * T_BR + T_W2 + 64 + f] = (float)w2b;
-    if (f < 4) dcanon_l[br * T_BR + T_B2 + f] = (float)bb;
-}
+// (the BN1-backward means and dW2 / db2 -- formerly a one-workgroup tfinish1 kernel -- are computed in tbwd2's prologue)
 
 // Pass 2: BN1 backward, dh0 = W1^T dh1 (matrix cores), dW1 = dh1 h0^T (matrix cores, contraction over the
 // tile's 32 points through an LDS transpose), relu backward.
@@ -664,7 +642,8 @@ __device__ unsigned long long *g_tprof = nullptr;
 #define TP(i)
 #endif
 template <int NS>
-__global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__restrict__ s12, const float *__restrict__ dout,
+__global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__restrict__ pcs, double count, float *__restrict__ dcanon_l,
+                                                        const float *__restrict__ dout,
                                                         float *__restrict__ ubuf, float *__restrict__ part2) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int L_FILM = l_film(NS), L_FILMB = l_filmb(NS), L_RED = l_red(NS);
@@ -708,8 +687,41 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
     float *w2s = s12s + 256;                                               // [2 br][2][64] raw sd2.weight
     if (threadIdx.x >= 256) {
         const int i = threadIdx.x - 256;
-        s12s[i] = s12[i];
         w2s[i] = a.tcanon_l[(i >> 7) * T_BR + T_W2 + (i & 127)];
+    }
+    {   // BN1-backward means s12[br][2][64] = (sum dh1n, sum dh1n*h1n) / P over the per-cloud totals of pass 1 -- what
+        // the one-workgroup tfinish1 kernel did, recomputed by every workgroup (same sums in the same order, under the
+        // weight DMA; a dependent tiny launch costs ~4.5 us); workgroup 0 also writes dW2 / db2.  Scratch: redw.
+        double (*acc)[5][128] = (double (*)[5][128])redw;
+        const int q = threadIdx.x & 127, br_ = q >> 6, f_ = q & 63;
+        const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+        for (int gg = threadIdx.x >> 7; gg < 8; gg += TW / 2) {
+            double S1 = 0, S2 = 0, w2a = 0, w2b = 0, bb = 0;
+            for (int b = gg; b < a.B; b += 8) {
+                const float *qq = pcs + (size_t)b * 520 + br_ * 256;
+                const double av = a.filmb_l[(size_t)b * FB_CLOUD + br_ * FB_BR + f_];
+                S1 += av * qq[3 * 64 + f_];                                    // dh1n = a * dh2a
+                S2 += av * qq[2 * 64 + f_];                                    // dh1n * h1n
+                if (first) {
+                    w2a += qq[0 * 64 + f_]; w2b += qq[1 * 64 + f_];
+                    if (f_ < 2) bb += pcs[(size_t)b * 520 + 512 + br_ * 2 + f_];
+                }
+            }
+            acc[gg][0][q] = S1; acc[gg][1][q] = S2; acc[gg][2][q] = w2a; acc[gg][3][q] = w2b; acc[gg][4][q] = bb;
+        }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            double S1 = 0, S2 = 0, w2a = 0, w2b = 0, bb = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { S1 += acc[k][0][q]; S2 += acc[k][1][q]; w2a += acc[k][2][q]; w2b += acc[k][3][q]; bb += acc[k][4][q]; }
+            s12s[(br_ * 2 + 0) * 64 + f_] = (float)(S1 / count);
+            s12s[(br_ * 2 + 1) * 64 + f_] = (float)(S2 / count);
+            if (first) {
+                dcanon_l[br_ * T_BR + T_W2 + f_] = (float)w2a;
+                dcanon_l[br_ * T_BR + T_W2 + 64 + f_] = (float)w2b;
+                if (f_ < 4) dcanon_l[br_ * T_BR + T_B2 + f_] = (float)bb;
+            }
+        }
     }
     float ua = 0.f, ub = 0.f;
 #ifdef DPF_PROFILE
@@ -872,61 +884,11 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
     }
 }
 
-// Totals of pass 2 -> d gamma0, d beta0, dW1, dW0 and the coefficients of the input gradient.
+// (tbwd3f_kernel below) Totals of pass 2 -> d gamma0, d beta0, dW1, dW0 and the coefficients of the input gradient.
 //   tot[br][P2_J] doubles.  BN0 backward:  dh0pre = rstd0*gamma0*(dh0a - A - h0n*Bc),  A = S/P,  Bc = Sg/P
 //   dW0[f][k] = sum_pt dh0pre * x_k = rstd0*gamma0*(Sk - A*sum x_k - Bc * sum h0n*x_k), and h0n is linear in x:
 //   sum_pt h0n_f x_k / P = rstd0_f (w_fa cov(a,k) + w_fb cov(b,k)) + (mean of h0n = 0) * E[x_k]
 //   dx_k[pt] = u_k[pt] - C_k - (alpha_k x_a + beta_k x_b - delta_k):  coef[k] = {C_k - delta_k, alpha_k, beta_k}
-__global__ __launch_bounds__(128) void tfinish2_kernel(int nk, double count, const double *__restrict__ tot, const float *__restrict__ tcanon_l,
-                                                       const float *__restrict__ stats_l, float *__restrict__ dcanon_l,
-                                                       float *__restrict__ coef) {
-    __shared__ double acc[2][4][128];
-    if (blockIdx.x > 0) {                                                  // dW1: (2, 4096) totals -> dcanon
-        const int i = (blockIdx.x - 1) * 128 + threadIdx.x;                // 64 workgroups x 128
-        const int b2 = i >> 12, j = i & 4095;
-        dcanon_l[b2 * T_BR + T_W1 + j] = (float)tot[(size_t)b2 * P2_J + 128 + j];
-        return;
-    }
-    const int br = threadIdx.x >> 6, f = threadIdx.x & 63;
-    const double *t = tot + (size_t)br * P2_J;
-    const float *cb = tcanon_l + br * T_BR;
-    const double Sg = t[f], S = t[64 + f], Sa = t[4224 + f], Sb = t[4288 + f];
-    dcanon_l[br * T_BR + T_G0 + f] = (float)Sg;
-    dcanon_l[br * T_BR + T_B0 + f] = (float)S;
-    const float *m = stats_l + ST_MOM;
-    const double ea = m[0], eb = m[1], caa = m[2], cbb = m[3], cab = m[4];
-    const double wa = cb[T_W0 + f * nk], wb = nk == 2 ? cb[T_W0 + f * 2 + 1] : 0.0, gamma = cb[T_G0 + f];
-    const double rstd0 = stats_l[br * ST_BR + 64 + f], mean0 = stats_l[br * ST_BR + f];
-    const double A = S / count, Bc = Sg / count;
-    const double hxa = rstd0 * (wa * caa + wb * cab), hxb = rstd0 * (wa * cab + wb * cbb);     // E[h0n x_k]
-    const double sc = rstd0 * gamma;
-    dcanon_l[br * T_BR + T_W0 + f * nk] = (float)(sc * (Sa - A * ea * count - Bc * hxa * count));
-    if (nk == 2) dcanon_l[br * T_BR + T_W0 + f * 2 + 1] = (float)(sc * (Sb - A * eb * count - Bc * hxb * count));
-    else dcanon_l[br * T_BR + T_W0 + 64 + f] = 0.f;
-    // input-gradient coefficients: sum over all 128 (branch, feature) rows
-    const double ck[2] = {wa * sc, wb * sc};
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        acc[k][0][threadIdx.x] = ck[k] * A;
-        acc[k][1][threadIdx.x] = ck[k] * Bc * rstd0 * wa;
-        acc[k][2][threadIdx.x] = ck[k] * Bc * rstd0 * wb;
-        acc[k][3][threadIdx.x] = ck[k] * Bc * rstd0 * mean0;
-    }
-    __syncthreads();
-    if (threadIdx.x < 8) {
-        const int k = threadIdx.x >> 2, q = threadIdx.x & 3;
-        double s = 0;
-        for (int i = 0; i < 128; ++i) s += acc[k][q][i];
-        acc[k][q][0] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < 2) {
-        const int k = threadIdx.x;
-        coef[k * 4 + 0] = (float)(acc[k][0][0] - acc[k][3][0]);
-        coef[k * 4 + 1] = (float)acc[k][1][0];
-        coef[k * 4 + 2] = (float)acc[k][2][0];
-    }
-}
 
 // Pass 3: the conditioner path of d(input points), elementwise
 // tfinish2 + tbwd3 in one launch (a tiny dependent kernel costs ~4.5 us here whatever it does): EVERY workgroup
@@ -996,16 +958,6 @@ __global__ __launch_bounds__(256) void tbwd3f_kernel(int N, int ka, int kb, int 
     if (kb >= 0) d[(size_t)kb * N + n] += ubuf[((size_t)bi * 2 + 1) * N + n] - coef[4] - coef[5] * xa - coef[6] * xb;
 }
 
-__global__ __launch_bounds__(256) void tbwd3_kernel(int N, int ka, int kb, const float *__restrict__ p_in, const float *__restrict__ ubuf,
-                                                    const float *__restrict__ coef, float *__restrict__ dp_in) {
-    const int bi = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    const float *pc = p_in + (size_t)bi * 3 * N;
-    float *d = dp_in + (size_t)bi * 3 * N;
-    const float xa = pc[(size_t)ka * N + n], xb = kb >= 0 ? pc[(size_t)kb * N + n] : 0.f;
-    d[(size_t)ka * N + n] += ubuf[((size_t)bi * 2 + 0) * N + n] - coef[0] - coef[1] * xa - coef[2] * xb;
-    if (kb >= 0) d[(size_t)kb * N + n] += ubuf[((size_t)bi * 2 + 1) * N + n] - coef[4] - coef[5] * xa - coef[6] * xb;
-}
 
 #ifdef DPF_PROFILE
 __global__ void tprof_set_kernel(unsigned long long *p) { g_tprof = p; }
@@ -1152,8 +1104,7 @@ static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb
     }
     hipLaunchKernelGGL(tbwd1_kernel<NS>, grid, dim3(TW * 64), lds1, s, a, g_p, g_p2, g_mu, g_lv, dp_in, w.dout, w.part1);
     hipLaunchKernelGGL(tcloudsum_kernel, dim3(B), dim3(520), 0, s, nb, B, w.part1, a.filmb_l, flow_eps, w.pc, dfm_l);
-    hipLaunchKernelGGL(tfinish1_kernel, dim3(1), dim3(1024), 0, s, B, count, w.pc, a.filmb_l, w.s12, dcanon_l);
-    hipLaunchKernelGGL(tbwd2_kernel<NS>, grid, dim3(TW * 64), lds2, s, a, w.s12, w.dout, w.ubuf, w.part2);
+    hipLaunchKernelGGL(tbwd2_kernel<NS>, grid, dim3(TW * 64), lds2, s, a, w.pc, count, dcanon_l, w.dout, w.ubuf, w.part2);
     hipLaunchKernelGGL(tcolsum_kernel, dim3((2 * P2_J + 31) / 32), dim3(1024), 0, s, nblk, 2 * P2_J, w.part2, w.tot2);
     hipLaunchKernelGGL(tbwd3f_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, N, ka, kb, kb >= 0 ? 2 : 1, count, w.tot2, tcanon_l,
                        stats_l, dcanon_l, p_in, w.ubuf, dp_in);
