@@ -510,7 +510,9 @@ __device__ __forceinline__ float half_sum(float x) {   // x(lane) + x(lane ^ 32)
 // The fused L-layer stack.  FW waves per workgroup, each wave owns one 32-point tile of ONE
 // cloud for all layers (both conditioner branches).  Every workgroup streams the layer weights
 // through its own LDS, so bigger workgroups mean less L2->LDS traffic per point.
-template <int NS, int FW>
+// LPB = layers per LDS buffer: with two layers per buffer (2 x 2 x 38 KiB at bf16x3: one workgroup per CU, which is
+// all cfg-2 offers anyway) the workgroup barrier that hands a buffer over comes every other layer.
+template <int NS, int FW, int LPB = 1>
 __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int LBYTES = p_layer_bytes(NS) + FILM_BYTES;
@@ -530,7 +532,14 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
     const size_t list_stride = (size_t)a.B * 3 * N;
 
     const int lfirst = inverse ? L - 1 : 0;
-    stage_layer<NS, FW>(a, lfirst, bi, smem, wave, lane);
+    auto stage_group = [&](int g) {                      // the LPB layers of steps g*LPB .. into buffer g & 1
+#pragma unroll
+        for (int k = 0; k < LPB; ++k) {
+            const int st = g * LPB + k;
+            if (st < L) stage_layer<NS, FW>(a, inverse ? L - 1 - st : st, bi, smem + ((g & 1) * LPB + k) * LBYTES, wave, lane);
+        }
+    };
+    stage_group(0);
     // Layer descriptors (keep/warp channels): lane l of every wave holds the rows of layers l and 64 + l, a
     // layer's row comes out with v_readlane.  (Loading them inside the loop puts a vector-memory wait at the top of every
     // layer, and vmcnt retires in order: it waited for the whole next-layer DMA issued just before -- r01
@@ -551,8 +560,9 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
     for (int step = 0; step < L; ++step) {
         const int li = inverse ? L - 1 - step : step;
         const int ln = inverse ? (li > 0 ? li - 1 : 0) : (li + 1 < L ? li + 1 : li);
-        const uint8_t *lb = smem + (step & 1) * LBYTES;
-        if (step + 1 < L) stage_layer<NS, FW>(a, ln, bi, smem + ((step + 1) & 1) * LBYTES, wave, lane);
+        const int grp = step / LPB, within = step - grp * LPB;
+        const uint8_t *lb = smem + ((grp & 1) * LPB + within) * LBYTES;
+        if (within == 0 && (grp + 1) * LPB < L) stage_group(grp + 1);
         int nka, nkb, nwa, nwb;
         layer_meta(ln, nka, nkb, nwa, nwb);
         unsigned long long tt[8];
@@ -612,7 +622,7 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
         }
         ka = nka; kb = nkb; wa = nwa; wb = nwb;
         DPF_T(4)
-        __syncthreads();   // next layer's weights have landed; everyone is done with this buffer
+        if (within == LPB - 1) __syncthreads();   // the next buffer's weights have landed; everyone is done with this one
         DPF_T(5)
 #ifdef DPF_PROFILE
         DPF_T(6)
@@ -721,17 +731,23 @@ extern "C" int dpf_flow_forward(int n_layers, int B, int N, int mode, int precis
         if (N <= 64) fw = 2;
         if (N <= 32) fw = 1;
     }
-#define DPF_LAUNCH(NSV, FWV)                                                                                    \
+#define DPF_LAUNCH_LPB(NSV, FWV, LPBV)                                                                          \
     {                                                                                                           \
-        const int lds = 2 * (p_layer_bytes(NSV) + FILM_BYTES);                                                  \
+        const int lds = 2 * LPBV * (p_layer_bytes(NSV) + FILM_BYTES);                                           \
         static bool attr_set = false;                                                                           \
         if (!attr_set) {                                                                                        \
-            e = hipFuncSetAttribute((const void *)flow_kernel<NSV, FWV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            e = hipFuncSetAttribute((const void *)flow_kernel<NSV, FWV, LPBV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
             if (e != hipSuccess) return (int)e;                                                                 \
             attr_set = true;                                                                                    \
         }                                                                                                       \
         const dim3 grid((N + TILE * FWV - 1) / (TILE * FWV), B), block(FWV * 64);                               \
-        hipLaunchKernelGGL((flow_kernel<NSV, FWV>), grid, block, lds, s, a);                                    \
+        hipLaunchKernelGGL((flow_kernel<NSV, FWV, LPBV>), grid, block, lds, s, a);                              \
+    }
+    // two layers per buffer where a CU gets one workgroup anyway and the 2 x 2 layers fit its LDS (bf16, bf16x3)
+#define DPF_LAUNCH(NSV, FWV)                                                                                    \
+    {                                                                                                           \
+        if (FWV == 8 && NSV <= 2 && pair_ok) DPF_LAUNCH_LPB(NSV, 8, 2)                                          \
+        else DPF_LAUNCH_LPB(NSV, FWV, 1)                                                                        \
     }
 #define DPF_LAUNCH_FW(FWV)                 \
     {                                      \
@@ -739,12 +755,15 @@ extern "C" int dpf_flow_forward(int n_layers, int B, int N, int mode, int precis
         if (ns == 2) DPF_LAUNCH(2, FWV)    \
         if (ns == 3) DPF_LAUNCH(3, FWV)    \
     }
+    static const int lpb_env = getenv("DPF_FLOW_LPB") ? atoi(getenv("DPF_FLOW_LPB")) : 0;
+    const bool pair_ok = n_layers >= 2 && lpb_env != 1 && (lpb_env == 2 || (long)B * ((N + 255) / 256) <= 256);
     if (fw >= 8) DPF_LAUNCH_FW(8)
     else if (fw >= 4) DPF_LAUNCH_FW(4)
     else if (fw >= 2) DPF_LAUNCH_FW(2)
     else DPF_LAUNCH_FW(1)
 #undef DPF_LAUNCH_FW
 #undef DPF_LAUNCH
+#undef DPF_LAUNCH_LPB
     return (int)hipGetLastError();
 }
 
