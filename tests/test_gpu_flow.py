@@ -165,6 +165,17 @@ def test_full_size_properties():
     # the direct pass's inputs by sqrt(1+1e-6) per layer, so the round trip is exact only to ~63 * 1e-6
     assert rel(back[0], z) < 5e-4
     assert len(ps) == 63 and ps.stacked.shape == (63, B, 3, N)
+    # bf16x3 at this size takes the variant with TWO layers per LDS buffer (a barrier every other layer; 63 layers: the
+    # last buffer holds one), a 4-cloud sub-batch the one-layer-per-buffer 4-wave variant: same bits, and the oracle
+    dec.precision = "bf16x3"
+    with torch.no_grad():
+        ps3, _, lvs3 = dec(tz, tg, mode="direct")
+        ps3_sub, _, _ = dec(tz[5:9].contiguous(), tg[5:9].contiguous(), mode="direct")
+        inv3, _, _ = dec(ps3[-1], tg, mode="inverse")
+        inv3_sub, _, _ = dec(ps3[-1][5:9].contiguous(), tg[5:9].contiguous(), mode="inverse")
+    assert torch.equal(ps3_sub[-1], ps3[-1][5:9]) and torch.equal(ps3_sub[31], ps3[31][5:9])
+    assert torch.equal(inv3_sub[0], inv3[0][5:9])
+    assert rel(ps3[-1][:2], rps[-1]) <= REL["bf16x3"] and rel(lvs3.total()[:2], sum(rlvs)) <= REL["bf16x3"]
 
 
 def test_module_semantics():
