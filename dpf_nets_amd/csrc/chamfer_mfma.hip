@@ -246,15 +246,16 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
             tau = m * 2.44140625e-4f;                                         // 2^-12 * R2
         }
         if (wave_live) {
-            float hit = smin + tau;
+            // hit = smin + tau and low = smin - tau are kept up to date where smin changes -- inside the hit path (a new
+            // minimum is a hit) -- so a tile that is not a hit costs one compare, and telling a clear new minimum from a
+            // near-tie another one.  low = +inf at the start of a pass: its first hit becomes the head of the empty queue.
+            float hit = smin + tau, low = __builtin_inff();
             // Queue of a lane: the head (q0t, q0m) lives in registers, near-ties of it in LDS slots 0..qcount-2.  The
             // common event -- a new minimum that undercuts the old one by more than tau, which puts every queued tile
             // (all >= smin) out of range -- is three register moves.
-            // hit = smin + tau is kept up to date where smin changes -- inside the hit path (a new minimum is a hit) --
-            // so a tile that is not a hit costs one compare
             auto visit = [&](int t, float m) {
                 if (m <= hit) {                                               // record low or near-tie of the running minimum
-                    if (m + tau < smin || qcount == 0) {                      // (empty: first hit of a later pass)
+                    if (m < low) {
                         q0t = t; q0m = m; qcount = 1;
                     } else if (qcount < QCAP) {
                         myq[(qcount - 1) * 64 + lane] = (unsigned short)t; mym[(qcount - 1) * 64 + lane] = m; ++qcount;
@@ -266,6 +267,7 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
                     }
                     smin = fminf(smin, m);
                     hit = smin + tau;
+                    low = smin - tau;
                 }
             };
             int t = 0;
