@@ -583,23 +583,29 @@ __device__ __forceinline__ float lane_sums64(const float (&t)[64], int lane) {
     return w[0];
 }
 
-__global__ __launch_bounds__(256) void emd_grad_fused_kernel(int n, int m, const float *__restrict__ xyz1,
-                                                             const float *__restrict__ xyz2,
-                                                             const float *__restrict__ match, float *__restrict__ grad1,
-                                                             float *__restrict__ part2) {
-    __shared__ float red[4][64];
+// RS row slices per workgroup (RS * 256 threads): slice s walks the rows [s*mh, (s+1)*mh) -- the launch has only
+// B * n / 64 column-waves (two per SIMD at B=16, n=8192), RS = 2 doubles the waves that hide each other's latency.
+template <int RS>
+__global__ __launch_bounds__(256 * RS) void emd_grad_fused_kernel(int n, int m, const float *__restrict__ xyz1,
+                                                                  const float *__restrict__ xyz2,
+                                                                  const float *__restrict__ match, float *__restrict__ grad1,
+                                                                  float *__restrict__ part2) {
+    __shared__ float red[RS][4][64];
+    __shared__ float g1s[RS > 1 ? RS - 1 : 1][256][3];
     const int bi = blockIdx.y, kb = blockIdx.x, nkb = gridDim.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, rs = threadIdx.x >> 8, tcol = threadIdx.x & 255;
+    const int mh = ((m + RS - 1) / RS + GROWS - 1) / GROWS * GROWS;       // rows per slice, whole groups
+    const int lbeg = rs * mh, lend = min(m, lbeg + mh);
     const float *__restrict__ P = xyz1 + (size_t)bi * n * 3;
     const float *__restrict__ Q = xyz2 + (size_t)bi * m * 3;
     const float *__restrict__ mt = match + (size_t)bi * n * m;
-    const int k = kb * 256 + threadIdx.x;
+    const int k = kb * 256 + tcol;
     const bool live = k < n;
     const int kc = min(k, n - 1);
     const float px = P[kc * 3 + 0], py = P[kc * 3 + 1], pz = P[kc * 3 + 2];
     const int slot = (int)(__builtin_bitreverse32((unsigned)lane) >> 26);          // value index this lane ends up with
     float gx = 0.f, gy = 0.f, gz = 0.f;
-    for (int l0 = 0; l0 < m; l0 += GROWS) {
+    for (int l0 = lbeg; l0 < lbeg + mh; l0 += GROWS) {   // every slice runs the same number of groups (barriers)
         float v[GROWS];
 #pragma unroll
         for (int u = 0; u < GROWS; ++u) {                       // 21 independent coalesced loads in flight
@@ -612,21 +618,28 @@ __global__ __launch_bounds__(256) void emd_grad_fused_kernel(int n, int m, const
         for (int u = 0; u < GROWS; ++u) {
             const int l = min(l0 + u, m - 1);                   // wave-uniform -> scalar loads
             const float dx = px - Q[l * 3 + 0], dy = py - Q[l * 3 + 1], dz = pz - Q[l * 3 + 2];
-            const float w = live && l0 + u < m ? v[u] : 0.f;
+            const float w = live && l0 + u < lend ? v[u] : 0.f;
             const float c = w * rsqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-20f));
             const float ex = dx * c, ey = dy * c, ez = dz * c;
             gx += ex; gy += ey; gz += ez;
             t[u * 3 + 0] = ex; t[u * 3 + 1] = ey; t[u * 3 + 2] = ez;
         }
-        red[wave][slot] = lane_sums64(t, lane);
+        red[rs][wave][slot] = lane_sums64(t, lane);
         __syncthreads();
-        if (threadIdx.x < GROWS * 3) {
-            const int u = threadIdx.x / 3, c = threadIdx.x - u * 3;
-            if (l0 + u < m)
+        if (tcol < GROWS * 3) {
+            const int u = tcol / 3, c = tcol - u * 3;
+            if (l0 + u < lend)
                 part2[(((size_t)bi * nkb + kb) * m + l0 + u) * 3 + c] =
-                    -((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+                    -((red[rs][0][tcol] + red[rs][1][tcol]) + (red[rs][2][tcol] + red[rs][3][tcol]));
         }
         __syncthreads();
+    }
+    if (RS > 1) {                                               // grad1: the slices' partial sums, added in slice order
+        if (rs > 0) { g1s[rs - 1][tcol][0] = gx; g1s[rs - 1][tcol][1] = gy; g1s[rs - 1][tcol][2] = gz; }
+        __syncthreads();
+        if (rs > 0) return;
+#pragma unroll
+        for (int q = 0; q + 1 < RS; ++q) { gx += g1s[q][tcol][0]; gy += g1s[q][tcol][1]; gz += g1s[q][tcol][2]; }
     }
     if (live) {
         float *g = grad1 + ((size_t)bi * n + k) * 3;
@@ -803,7 +816,10 @@ extern "C" int dpf_matchcostgrad_ws(int b, int n, int m, const float *xyz1, cons
     if (!workspace || workspace_bytes < dpf_matchcostgrad_workspace_bytes(b, n, m) || (long)b * nkb < 512)
         return dpf_matchcostgrad(b, n, m, xyz1, xyz2, match, grad1, grad2, stream);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(emd_grad_fused_kernel, dim3(nkb, b), dim3(256), 0, s, n, m, xyz1, xyz2, match, grad1, (float *)workspace);
+    if ((long)b * nkb < 1024 && m >= 4 * GROWS)     // fewer than four column-waves per SIMD: two row slices per workgroup
+        hipLaunchKernelGGL(emd_grad_fused_kernel<2>, dim3(nkb, b), dim3(512), 0, s, n, m, xyz1, xyz2, match, grad1, (float *)workspace);
+    else
+        hipLaunchKernelGGL(emd_grad_fused_kernel<1>, dim3(nkb, b), dim3(256), 0, s, n, m, xyz1, xyz2, match, grad1, (float *)workspace);
     hipLaunchKernelGGL(emd_grad2_sum_kernel, dim3((m * 3 + 255) / 256, b), dim3(256), 0, s, m, nkb, (const float *)workspace, grad2);
     return (int)hipGetLastError();
 }

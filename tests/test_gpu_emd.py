@@ -82,7 +82,7 @@ def test_emd_full_size_invariants_and_autograd():
 def test_one_pass_gradients_match_two_pass():
     """dpf_matchcostgrad_ws (match read once) vs dpf_matchcostgrad (two kernels): same sums in a different order."""
     BK = _gpu()
-    for (B, n, m) in ((2, 64, 64), (3, 300, 257), (128, 1024, 500), (70, 2048, 700), (600, 200, 129)):
+    for (B, n, m) in ((2, 64, 64), (3, 300, 257), (128, 1024, 500), (70, 2048, 700), (600, 200, 129), (1100, 200, 90)):
         a, b = chamfer_inputs(900 + n, B, n, m)
         ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
         match, _ = BK.ApproxMatch(ta, tb)
