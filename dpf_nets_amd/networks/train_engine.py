@@ -188,7 +188,9 @@ def _forward_core(p, g, spec, mode, prec, tcanon, W0, gam, bet, W1, b1, flat=Non
     else:
         _update_running([m[1] for m in mods], list(film_mean.unbind(0)), list(film_uvar.unbind(0)))
         _update_running(spec.flow_bns(), list(flow_mean.unbind(0)), list(flow_uvar.unbind(0)))
-    outs = ps.unbind(0) + mus.unbind(0) + lvs.unbind(0)            # 3L output tensors: autograd hands back one gradient each
+    # 3L output tensors (autograd hands back one gradient each) + the layer-sum of the log-variances, which is what
+    # PointFlowNLL wants of them (losses.py:13): one reduction here instead of L-1 adds and L-1 backward nodes there
+    outs = ps.unbind(0) + mus.unbind(0) + lvs.unbind(0) + (lvs.sum(0),)
     return outs, (p, g, tcanon, packed, film, stats, ps, W0, gam, W1, xhat, rstd, y, sig, sw)
 
 
@@ -226,7 +228,12 @@ def _backward_core(spec, mode, prec, saved, grads, need_dg):
     dcanon = torch.empty_like(tcanon)
     dfm = torch.empty((L, 2, 2, B, F), dtype=torch.float32, device=dev)
     keep = {}
-    t_ps, t_mus, t_lvs = (_grad_table(grads[i * L:(i + 1) * L], tuple(p.shape), keep) for i in range(3))
+    g_lvs = grads[2 * L:3 * L]
+    if len(grads) > 3 * L and grads[3 * L] is not None:        # d/d(layer-sum) reaches every layer's log-variances
+        dtot = grads[3 * L]
+        g_lvs = [dtot if t is None else t + dtot for t in g_lvs]
+    t_ps, t_mus = (_grad_table(grads[i * L:(i + 1) * L], tuple(p.shape), keep) for i in range(2))
+    t_lvs = _grad_table(g_lvs, tuple(p.shape), keep)
     chain, dp_tmp = torch.empty_like(p), torch.empty_like(p)
     check(L_.dpf_flow_train_backward_lists(L, B, N, MODE[mode], prec, spec.meta_host, tcanon.data_ptr(), packed.data_ptr(),
                                            film.data_ptr(), stats.data_ptr(), p.data_ptr(), ps.data_ptr(), t_ps, t_mus, t_lvs,
@@ -447,4 +454,9 @@ def run_training_stack(spec, p, g, mode, precision=None):
         else:
             outs = _FlowStackTrain.apply(p, g, spec, mode, PREC[precision], *spec.all_params())
     L = spec.L
-    return list(outs[:L]), list(outs[L:2 * L]), list(outs[2 * L:])
+    lvs = list(outs[2 * L:3 * L])
+    token = object()                       # losses.total_logvar recognises the whole list and takes the layer-sum
+    for i, v in enumerate(lvs):
+        v._dpf_pos = (token, i)
+    lvs[-1]._dpf_total = (token, L, outs[3 * L])
+    return list(outs[:L]), list(outs[L:2 * L]), lvs

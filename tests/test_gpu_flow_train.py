@@ -345,3 +345,38 @@ def test_mirror_adam_on_flat_and_per_parameter_decoders_agree_bitwise():
             assert len(opt._flat) == 1 and store.attached()
     for (k, a), b in zip(ref.state_dict().items(), flat.state_dict().values()):
         assert torch.equal(a, b), k
+
+
+def test_training_layer_sum_of_logvars_reaches_the_nll():
+    """The training stack also returns sum(logvars) (one reduction); PointFlowNLL (losses.py:11-15) takes it instead
+    of adding the L tensors, and its gradient reaches every layer's log-variances in the backward -- also when a
+    layer's logvar is used on its own next to the sum.  Same loss and gradients as the plain python sum."""
+    nets = _gpu()
+    from dpf_nets_amd.networks.losses import total_logvar
+    torch.manual_seed(5)
+    B, N, G = 5, 600, 128
+    dec = nets.LocalCondRNVPDecoder(2, 64, G).cuda().train()
+    tgt, z, g = FO.synthetic_inputs(47, B, N, G)
+    tp = torch.from_numpy(tgt).cuda()
+    nll = nets.PointFlowNLL()
+    pm, pl = torch.zeros(B, 3, N).cuda(), torch.full((B, 3, N), -3.6).cuda()
+    res = []
+    for tagged in (True, False):
+        dec.zero_grad()
+        tg = torch.from_numpy(g).cuda().requires_grad_(True)
+        ps, mus, lvs = dec(tp, tg, mode="inverse")
+        tag = lvs[-1]._dpf_total
+        assert tag[1] == len(lvs) == 6 and tag[2].requires_grad
+        if tagged:
+            assert total_logvar(lvs) is tag[2] and total_logvar([pl] + lvs) is not tag[2]
+        else:
+            lvs = [v.view_as(v) for v in lvs]                     # fresh tensor objects: no tags, the plain sum
+            assert getattr(lvs[-1], "_dpf_total", None) is None
+        loss = nll(ps + [tp], [pm] + mus, [pl] + lvs) / (3 * N) + lvs[1].exp().mean()
+        loss.backward()
+        res.append((loss.detach(), tg.grad.clone(), [p.grad.clone() for p in dec.parameters()]))
+    (la, ga, pa), (lb, gb, pb) = res
+    assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb))
+    assert rel(ga, gb) <= 1e-4
+    worst = max(rel(a, b) for a, b in zip(pa, pb) if float(b.abs().max()) > 0)
+    assert worst <= 1e-3, worst
