@@ -1,0 +1,229 @@
+// Latent prior flow: the whole GlobalRNVPDecoder stack on (B, G) codes in ONE launch (eval-mode BatchNorm).
+//
+// Replaces GlobalRNVPDecoder.forward (lib/networks/decoders.py:21-38) = 2*n_flows RealNVPFlow steps
+// (lib/networks/flows.py:198-213), each  Linear(K -> nf, no bias) . BatchNorm1d . Swish . Linear(nf -> K)  twice
+// (mu and logvar nets) on the K = G/2 kept coordinates, then an affine update of the other K coordinates.
+// As tensor ops that is ~25 launches per step on (B, 64..256) operands -- 350+ dependent launches per call,
+// 2-3 ms of launch latency around 60 MFLOP.  Here a workgroup owns RB rows of the batch and walks all steps: the
+// rows live in LDS, the weights (0.13-0.5 MB per step) stream from L2, nothing but the result lists touches HBM.
+// fp32 FMAs in k order -- the work is latency- not throughput-bound, matrix cores would buy nothing.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dpf_hip.h"
+
+namespace {
+
+constexpr int THREADS = 256;
+constexpr int MAX_STEPS = 256;
+
+// step code (2 bits): which coordinates a step warps, RealNVPFlowCouple's two patterns (flows.py:224-233)
+//   0: even (keep odd)   1: odd (keep even)   2: first half (keep second)   3: second half (keep first)
+__device__ __forceinline__ int warp_index(int code, int i, int K) { return code == 0 ? 2 * i : code == 1 ? 2 * i + 1 : code == 2 ? i : i + K; }
+__device__ __forceinline__ int keep_index(int code, int i, int K) { return code == 0 ? 2 * i + 1 : code == 1 ? 2 * i : code == 2 ? i + K : i; }
+
+__host__ __device__ inline size_t canon_net_floats(int K, int nf) { return (size_t)2 * nf * K + 4 * (size_t)nf + K; }
+__host__ __device__ inline size_t packed_net_floats(int K, int nf) { return (size_t)2 * nf * K + 2 * (size_t)nf + K; }
+
+// canon (per step, per net: mu then logvar; the reference's state_dict order, flows.py:176-196):
+//   W0 [nf][K] | bn.weight | bn.bias | bn.running_mean | bn.running_var | W1 [K][nf] | b1 [K]
+// packed (per step, per net):  W0t [K][nf] | a [nf] | c [nf] | W1t [nf][K] | b1 [K]      a = gamma / sqrt(var + eps), c = beta - mean a
+__global__ __launch_bounds__(THREADS) void gprior_pack_kernel(int nets, int K, int nf, float bn_eps, const float *__restrict__ canon,
+                                                              float *__restrict__ packed) {
+    const size_t cn = canon_net_floats(K, nf), pn = packed_net_floats(K, nf);
+    const size_t total = (size_t)nets * pn;
+    for (size_t e = (size_t)blockIdx.x * THREADS + threadIdx.x; e < total; e += (size_t)gridDim.x * THREADS) {
+        const size_t net = e / pn;
+        size_t o = e - net * pn;
+        const float *c = canon + net * cn;
+        const float *gam = c + (size_t)nf * K, *bet = gam + nf, *rm = bet + nf, *rv = rm + nf, *w1 = rv + nf, *b1 = w1 + (size_t)K * nf;
+        float v;
+        if (o < (size_t)K * nf) {
+            const int k = (int)(o / nf), j = (int)(o - (size_t)k * nf);
+            v = c[(size_t)j * K + k];
+        } else if ((o -= (size_t)K * nf) < (size_t)nf) {
+            v = gam[o] / sqrtf(rv[o] + bn_eps);
+        } else if ((o -= nf) < (size_t)nf) {
+            const float a = gam[o] / sqrtf(rv[o] + bn_eps);
+            v = bet[o] - rm[o] * a;
+        } else if ((o -= nf) < (size_t)nf * K) {
+            const int j = (int)(o / K), i = (int)(o - (size_t)j * K);
+            v = w1[(size_t)i * nf + j];
+        } else {
+            v = b1[o - (size_t)nf * K];
+        }
+        packed[e] = v;
+    }
+}
+
+struct GArgs {
+    int S, B, G, nf, inverse, parts;
+    float eps;
+    const float *packed, *g;
+    float *gs, *mus, *lvs, *sum_lv, *g_out;
+    uint32_t codes[MAX_STEPS / 16];
+};
+
+template <int RB>
+__global__ __launch_bounds__(THREADS) void gprior_kernel(GArgs a) {
+    extern __shared__ float lds[];
+    const int G = a.G, K = G >> 1, nf = a.nf, P = a.parts;
+    float *gcur = lds;                          // [RB][G]   the rows as they stand
+    float *tot = gcur + RB * G;                 // [RB][G]   running sum of the logvars
+    float *hs = tot + RB * G;                   // [RB][2 nf] hidden activations, mu net then logvar net
+    float *part = hs + RB * 2 * nf;             // [P][RB][2 K] partial second-map sums
+    const int tid = threadIdx.x, row0 = blockIdx.x * RB;
+    for (int e = tid; e < RB * G; e += THREADS) {
+        const int r = e / G, row = row0 + r;
+        gcur[e] = row < a.B ? a.g[(size_t)row * G + (e - r * G)] : 0.f;
+        tot[e] = 0.f;
+    }
+    __syncthreads();
+    const size_t pn = packed_net_floats(K, nf);
+    for (int t = 0; t < a.S; ++t) {
+        const int s = a.inverse ? a.S - 1 - t : t;
+        const int code = (a.codes[s >> 4] >> ((s & 15) * 2)) & 3;
+        const float *pk = a.packed + (size_t)s * 2 * pn;
+        // ---- first map + BatchNorm + Swish: one (net, j) per thread, the RB rows in registers
+        for (int o = tid; o < 2 * nf; o += THREADS) {
+            const int net = o >= nf, j = o - net * nf;
+            const float *w = pk + net * pn + j;
+            float acc[RB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) acc[r] = 0.f;
+            int k = 0;
+            for (; k + 8 <= K; k += 8) {
+                float wv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) wv[u] = w[(size_t)(k + u) * nf];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int ki = keep_index(code, k + u, K);
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) acc[r] = fmaf(wv[u], gcur[r * G + ki], acc[r]);
+                }
+            }
+            for (; k < K; ++k) {
+                const float wv = w[(size_t)k * nf];
+                const int ki = keep_index(code, k, K);
+#pragma unroll
+                for (int r = 0; r < RB; ++r) acc[r] = fmaf(wv, gcur[r * G + ki], acc[r]);
+            }
+            const float sa = pk[net * pn + (size_t)K * nf + j], sc = pk[net * pn + (size_t)K * nf + nf + j];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const float y = fmaf(acc[r], sa, sc);
+                hs[r * 2 * nf + o] = y / (1.f + expf(-y));
+            }
+        }
+        __syncthreads();
+        // ---- second map: (part p of the hidden range, net, i) per thread
+        for (int o = tid; o < P * 2 * K; o += THREADS) {
+            const int p = o / (2 * K), q = o - p * 2 * K, net = q >= K, i = q - net * K;
+            const int j0 = (int)((long)nf * p / P), j1 = (int)((long)nf * (p + 1) / P);
+            const float *w = pk + net * pn + (size_t)K * nf + 2 * nf + i;
+            const float *h = hs + net * nf;
+            float acc[RB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) acc[r] = 0.f;
+            int j = j0;
+            for (; j + 8 <= j1; j += 8) {
+                float wv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) wv[u] = w[(size_t)(j + u) * K];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) acc[r] = fmaf(wv[u], h[r * 2 * nf + j + u], acc[r]);
+            }
+            for (; j < j1; ++j) {
+                const float wv = w[(size_t)j * K];
+#pragma unroll
+                for (int r = 0; r < RB; ++r) acc[r] = fmaf(wv, h[r * 2 * nf + j], acc[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < RB; ++r) part[(p * RB + r) * 2 * K + q] = acc[r];
+        }
+        __syncthreads();
+        // ---- mu, logvar and the affine update of the warped coordinates: one (row, i) per thread
+        const float *b1m = pk + (size_t)2 * K * nf + 2 * nf, *b1l = b1m + pn;
+        for (int o = tid; o < RB * K; o += THREADS) {
+            const int r = o / K, i = o - r * K, row = row0 + r;
+            float om = b1m[i], ol = b1l[i];
+            for (int p = 0; p < P; ++p) {
+                om += part[(p * RB + r) * 2 * K + i];
+                ol += part[(p * RB + r) * 2 * K + K + i];
+            }
+            const float lv = logf(a.eps + expf(ol));
+            const int wi = warp_index(code, i, K), ki = keep_index(code, i, K);
+            const float gold = gcur[r * G + wi];
+            gcur[r * G + wi] = a.inverse ? expf(-0.5f * lv) * (gold - om) : fmaf(expf(0.5f * lv), gold, om);
+            tot[r * G + wi] += lv;
+            if (row < a.B) {
+                const size_t base = ((size_t)s * a.B + row) * G;
+                if (a.mus) { a.mus[base + wi] = om; a.mus[base + ki] = 0.f; }
+                if (a.lvs) { a.lvs[base + wi] = lv; a.lvs[base + ki] = 0.f; }
+            }
+        }
+        __syncthreads();
+        if (a.gs)
+            for (int e = tid; e < RB * G; e += THREADS) {
+                const int r = e / G, row = row0 + r;
+                if (row < a.B) a.gs[((size_t)s * a.B + row) * G + (e - r * G)] = gcur[e];
+            }
+    }
+    for (int e = tid; e < RB * G; e += THREADS) {
+        const int r = e / G, row = row0 + r;
+        if (row >= a.B) continue;
+        if (a.g_out) a.g_out[(size_t)row * G + (e - r * G)] = gcur[e];
+        if (a.sum_lv) a.sum_lv[(size_t)row * G + (e - r * G)] = tot[e];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dpf_gprior_canon_floats(int G, int n_features) { return G > 0 && n_features > 0 ? 2 * canon_net_floats(G / 2, n_features) : 0; }
+
+size_t dpf_gprior_packed_floats(int n_steps, int G, int n_features) {
+    return n_steps > 0 && G > 0 && n_features > 0 ? (size_t)n_steps * 2 * packed_net_floats(G / 2, n_features) : 0;
+}
+
+int dpf_gprior_pack(int n_steps, int G, int n_features, float bn_eps, const float *canon, float *packed, dpf_stream_t stream) {
+    if (n_steps <= 0 || G < 2 || (G & 1) || n_features <= 0 || !canon || !packed) return DPF_EINVAL;
+    const size_t total = dpf_gprior_packed_floats(n_steps, G, n_features);
+    const int blocks = (int)((total + THREADS - 1) / THREADS < 2048 ? (total + THREADS - 1) / THREADS : 2048);
+    hipLaunchKernelGGL(gprior_pack_kernel, dim3(blocks), dim3(THREADS), 0, (hipStream_t)stream, 2 * n_steps, G / 2, n_features, bn_eps, canon,
+                       packed);
+    return (int)hipGetLastError();
+}
+
+int dpf_gprior_forward(int n_steps, int B, int G, int n_features, int mode, const int *codes, const float *packed, const float *g,
+                       float *gs, float *mus, float *lvs, float *sum_lv, float *g_out, float eps, dpf_stream_t stream) {
+    if (n_steps <= 0 || n_steps > MAX_STEPS || B < 0 || G < 2 || (G & 1) || n_features <= 0 || !codes || !packed || (mode != 0 && mode != 1))
+        return DPF_EINVAL;
+    if (B == 0) return 0;
+    if (!g) return DPF_EINVAL;
+    GArgs a = {};
+    a.S = n_steps; a.B = B; a.G = G; a.nf = n_features; a.inverse = mode; a.eps = eps;
+    a.packed = packed; a.g = g; a.gs = gs; a.mus = mus; a.lvs = lvs; a.sum_lv = sum_lv; a.g_out = g_out;
+    for (int s = 0; s < n_steps; ++s) {
+        if (codes[s] < 0 || codes[s] > 3) return DPF_EINVAL;
+        a.codes[s >> 4] |= (uint32_t)codes[s] << ((s & 15) * 2);
+    }
+    // rows per workgroup: 1 up to one workgroup per CU, 2 beyond (the weights are read once per workgroup and step);
+    // the hidden range of the second map is split over the threads the (net, i) items leave idle
+    const int rb = B > 256 ? 2 : 1;
+    a.parts = THREADS / G > 1 ? (THREADS / G < n_features ? THREADS / G : n_features) : 1;
+    const size_t lds = sizeof(float) * ((size_t)rb * (2 * G + 2 * n_features) + (size_t)a.parts * rb * G);
+    if (lds > 64 * 1024) return DPF_ENOSUP;
+    const int grid = (B + rb - 1) / rb;
+    if (rb == 1)
+        hipLaunchKernelGGL(gprior_kernel<1>, dim3(grid), dim3(THREADS), lds, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(gprior_kernel<2>, dim3(grid), dim3(THREADS), lds, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,5 +1,5 @@
 """Host-side mirror of the reference's lib.networks surface for the per-point flow
-decoder and the PointNet cloud encoder: same class names, constructor signatures, parameter/buffer names and
+decoder, the latent prior flow and the PointNet cloud encoder: same class names, constructor signatures, parameter/buffer names and
 return structures (lib/networks/{layers,flows,decoders,losses,utils}.py)."""
 from .layers import SharedDot, Swish  # noqa: F401
 from .flows import CondRealNVPFlow3D, CondRealNVPFlow3DTriple  # noqa: F401
@@ -7,3 +7,4 @@ from .decoders import LocalCondRNVPDecoder  # noqa: F401
 from .losses import PointFlowNLL  # noqa: F401
 from .encoders import PointNetCloudEncoder, PointFeatures  # noqa: F401
 from .optimizers import Adam, LRUpdater  # noqa: F401
+from .prior_flows import RealNVPFlow, RealNVPFlowCouple, GlobalRNVPDecoder  # noqa: F401

@@ -1,0 +1,247 @@
+"""RealNVPFlow / RealNVPFlowCouple / GlobalRNVPDecoder -- the latent prior flow on (B, G) codes -- with the
+reference's constructor signatures, sub-module, parameter and buffer names (lib/networks/flows.py:163-243,
+lib/networks/decoders.py:7-38), so reference checkpoints load unchanged.
+
+forward(g, mode):
+  * eval mode, CUDA tensors, no autograd (generation / evaluation): the whole stack in ONE HIP launch
+    (csrc/gprior.hip through dpf_gprior_forward); the lists come back as views of three (S,B,G) buffers;
+  * training mode or autograd: the tensor-op restatement (`forward_torch`) -- batch-statistics BatchNorm over the B
+    rows and the backward stay tensor ops (B x 64..256 operands).
+The fused kernel knows RealNVPFlowCouple's two index patterns (even/odd, halves) on an even G; a RealNVPFlow with
+other warp_inds runs as tensor ops."""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .layers import Swish
+from .flowlist import FlowList
+from .._lib import lib, check, current_stream, MODE
+
+
+def _needs_autograd(*tensors):
+    return torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
+
+
+def pattern_code(warp_inds, G):
+    """0 even / 1 odd / 2 first half / 3 second half (the kernel's step codes), None for anything else."""
+    if G % 2:
+        return None
+    w = [int(i) for i in warp_inds]
+    K = G // 2
+    for code, ref in enumerate((range(0, G, 2), range(1, G, 2), range(0, K), range(K, G))):
+        if w == list(ref):
+            return code
+    return None
+
+
+class RealNVPFlow(nn.Module):
+    def __init__(self, n_features, g_n_features, weight_std=0.01, warp_inds=[0], eps=1e-6):
+        super().__init__()
+        self.n_features = n_features
+        self.g_n_features = g_n_features
+        self.weight_std = weight_std
+        self.warp_inds = warp_inds
+        self.keep_inds = [i for i in range(g_n_features) if i not in set(int(w) for w in warp_inds)]
+        self.register_buffer("eps", torch.from_numpy(np.array([eps], dtype=np.float32)))
+        for br in ("mu", "logvar"):
+            net = nn.Sequential(OrderedDict([
+                (br + "_mlp0", nn.Linear(len(self.keep_inds), n_features, bias=False)),
+                (br + "_mlp0_bn", nn.BatchNorm1d(n_features)),
+                (br + "_mlp0_swish", Swish()),
+                (br + "_mlp1", nn.Linear(n_features, len(self.warp_inds), bias=True)),
+            ]))
+            with torch.no_grad():
+                net[-1].weight.normal_(std=weight_std)
+                net[-1].bias.zero_()
+            setattr(self, "T_%s_0" % br, net)
+        self._stack = None
+
+    def canon_pieces(self):
+        """The step's tensors in dpf_gprior_pack's canonical order (include/dpf_hip.h)."""
+        out = []
+        for br in ("mu", "logvar"):
+            net = getattr(self, "T_%s_0" % br)
+            out += [net[0].weight, net[1].weight, net[1].bias, net[1].running_mean, net[1].running_var, net[3].weight, net[3].bias]
+        return [t.detach().reshape(-1) for t in out]
+
+    def forward_torch(self, g, mode="direct"):                  # flows.py:198-213
+        gk = g[:, self.keep_inds].contiguous()
+        logvar = torch.zeros_like(g)
+        mu = torch.zeros_like(g)
+        logvar[:, self.warp_inds] = torch.log(self.eps + torch.exp(self.T_logvar_0(gk)))
+        mu[:, self.warp_inds] = self.T_mu_0(gk)
+        if mode == "direct":
+            out = torch.exp(0.5 * logvar) * g + mu
+        elif mode == "inverse":
+            out = torch.exp(-0.5 * logvar) * (g - mu)
+        else:
+            raise ValueError(mode)
+        return out, mu, logvar
+
+    def forward(self, g, mode="direct"):
+        if mode not in ("direct", "inverse"):
+            raise ValueError(mode)
+        if _fusable(self, [self], g):
+            if self._stack is None:
+                self.__dict__["_stack"] = GPriorStack([self])
+            _, _, gs, mus, lvs = self._stack.run(g, mode)
+            return gs[0], mus[0], lvs[0]
+        return self.forward_torch(g, mode)
+
+
+class RealNVPFlowCouple(nn.Module):
+    def __init__(self, n_features, g_n_features, weight_std=0.01, pattern=0):
+        super().__init__()
+        self.n_features = n_features
+        self.g_n_features = g_n_features
+        self.weight_std = weight_std
+        self.pattern = pattern
+        idx = np.arange(g_n_features)
+        if pattern == 0:
+            w1, w2 = idx[::2], idx[1::2]
+        elif pattern == 1:
+            w1, w2 = idx[:g_n_features // 2], idx[g_n_features // 2:]
+        else:
+            return                                               # as the reference: no sub-modules for other patterns
+        self.nvp1 = RealNVPFlow(n_features, g_n_features, weight_std=weight_std, warp_inds=list(w1))
+        self.nvp2 = RealNVPFlow(n_features, g_n_features, weight_std=weight_std, warp_inds=list(w2))
+
+    def layers(self):
+        return [self.nvp1, self.nvp2]
+
+    def forward_torch(self, g, mode="direct"):                  # flows.py:235-243
+        if mode == "direct":
+            g1, mu1, lv1 = self.nvp1.forward_torch(g, mode)
+            g2, mu2, lv2 = self.nvp2.forward_torch(g1, mode)
+        elif mode == "inverse":
+            g2, mu2, lv2 = self.nvp2.forward_torch(g, mode)
+            g1, mu1, lv1 = self.nvp1.forward_torch(g2, mode)
+        else:
+            raise ValueError(mode)
+        return [g1, g2], [mu1, mu2], [lv1, lv2]
+
+    def forward(self, g, mode="direct"):
+        if mode not in ("direct", "inverse"):
+            raise ValueError(mode)
+        if _fusable(self, self.layers(), g):
+            if self.__dict__.get("_stack") is None:
+                self.__dict__["_stack"] = GPriorStack(self.layers())
+            _, _, gs, mus, lvs = self._stack.run(g, mode)
+            return list(gs.unbind(0)), list(mus.unbind(0)), list(lvs.unbind(0))
+        return self.forward_torch(g, mode)
+
+
+class GlobalRNVPDecoder(nn.Module):
+    def __init__(self, n_flows, n_features, g_n_features, weight_std=0.01):
+        super().__init__()
+        self.n_flows = n_flows
+        self.n_features = n_features
+        self.g_n_features = g_n_features
+        self.weight_std = weight_std
+        self.flows = nn.ModuleList([RealNVPFlowCouple(n_features, g_n_features, weight_std=weight_std, pattern=(i % 2))
+                                    for i in range(n_flows)])
+
+    def coupling_layers(self):
+        """The 2*n_flows RealNVPFlow steps in DIRECT order."""
+        out = []
+        for f in self.flows:
+            out += f.layers()
+        return out
+
+    def stack(self):
+        if self.__dict__.get("_stack") is None:
+            self.__dict__["_stack"] = GPriorStack(self.coupling_layers())
+        return self._stack
+
+    def invalidate_packed(self):
+        """Call after changing weights through views the version counters do not see."""
+        if self.__dict__.get("_stack") is not None:
+            self._stack.invalidate()
+
+    def forward_torch(self, g, mode="direct"):                  # decoders.py:21-38
+        gs, mus, lvs = [], [], []
+        for i in range(self.n_flows):
+            if mode == "direct":
+                buf = self.flows[i].forward_torch(g if i == 0 else gs[-1], mode)
+                gs, mus, lvs = gs + buf[0], mus + buf[1], lvs + buf[2]
+            elif mode == "inverse":
+                buf = self.flows[-(i + 1)].forward_torch(g if i == 0 else gs[0], mode)
+                gs, mus, lvs = buf[0] + gs, buf[1] + mus, buf[2] + lvs
+            else:
+                raise ValueError(mode)
+        return gs, mus, lvs
+
+    def forward(self, g, mode="direct"):
+        if mode not in ("direct", "inverse"):
+            raise ValueError(mode)
+        if self.n_flows and _fusable(self, self.coupling_layers(), g):
+            _, sum_lv, gs, mus, lvs = self.stack().run(g, mode)
+            return FlowList(gs), FlowList(mus), FlowList(lvs, sum_lv)
+        return self.forward_torch(g, mode)
+
+
+def _fusable(module, layers, g):
+    """Eval mode on a CUDA tensor without autograd, every step one of the kernel's index patterns."""
+    if module.training or not g.is_cuda or _needs_autograd(g):      # as the point decoder: autograd follows the INPUT
+        return False
+    G = layers[0].g_n_features
+    return all(l.g_n_features == G and l.n_features == layers[0].n_features and pattern_code(l.warp_inds, G) is not None
+               for l in layers)
+
+
+class GPriorStack:
+    """Packed weights of an ordered list of RealNVPFlow steps (built by dpf_gprior_pack once per weight version)
+    and the launch.  torch is used for device buffers and the stream handle only."""
+
+    def __init__(self, layers):
+        self.layers = list(layers)
+        self.G, self.nf = self.layers[0].g_n_features, self.layers[0].n_features
+        self.codes = [pattern_code(l.warp_inds, self.G) for l in self.layers]
+        self._packed = None
+        self._state = None
+        self._sentinels = []
+        for l in (self.layers[0], self.layers[-1]):
+            self._sentinels += [l.T_mu_0[0].weight, l.T_mu_0[1].running_var, l.T_logvar_0[3].weight, l.T_logvar_0[1].running_mean]
+
+    def invalidate(self):
+        self._packed = None
+
+    def _ensure(self, device):
+        state = tuple((t._version, t.data_ptr()) for t in self._sentinels)
+        if state != self._state or self._packed is None or self._packed.device != device:
+            L_ = lib()
+            S = len(self.layers)
+            pieces = []
+            for l in self.layers:
+                pieces += l.canon_pieces()
+            canon = torch.cat(pieces).to(device=device, dtype=torch.float32).contiguous()
+            assert canon.numel() == S * L_.dpf_gprior_canon_floats(self.G, self.nf), (canon.numel(), S, self.G, self.nf)
+            packed = torch.empty(L_.dpf_gprior_packed_floats(S, self.G, self.nf), dtype=torch.float32, device=device)
+            bn = self.layers[0].T_mu_0[1]
+            check(L_.dpf_gprior_pack(S, self.G, self.nf, bn.eps, canon.data_ptr(), packed.data_ptr(), current_stream()), "gprior_pack")
+            self._packed, self._state = packed, state
+            self._eps = float(self.layers[0].eps.item())
+        return self._packed
+
+    def run(self, g, mode, want_lists=True):
+        """g (B,G) fp32 CUDA -> (g_out (B,G), sum_logvar (B,G), gs, mus, lvs (S,B,G) in DIRECT order or None)."""
+        import ctypes
+        if not g.is_cuda:
+            raise RuntimeError("the fused prior flow runs on MI355X only (g must be a CUDA tensor); there is no CPU fallback")
+        if g.dtype != torch.float32 or g.dim() != 2 or g.shape[1] != self.G:
+            raise RuntimeError("expected g (B,%d) float32" % self.G)
+        g = g.contiguous()
+        B, S = g.shape[0], len(self.layers)
+        with torch.cuda.device(g.device):
+            packed = self._ensure(g.device)
+            g_out, sum_lv = torch.empty_like(g), torch.empty_like(g)
+            gs, mus, lvs = (torch.empty((S, B, self.G), dtype=torch.float32, device=g.device) for _ in range(3)) if want_lists \
+                else (None, None, None)
+            codes = (ctypes.c_int * S)(*self.codes)
+            ptr = lambda t: t.data_ptr() if t is not None else None          # noqa: E731
+            check(lib().dpf_gprior_forward(S, B, self.G, self.nf, MODE[mode], codes, packed.data_ptr(), g.data_ptr(), ptr(gs),
+                                           ptr(mus), ptr(lvs), sum_lv.data_ptr(), g_out.data_ptr(), self._eps, current_stream()),
+                  "gprior_forward")
+        return g_out, sum_lv, gs, mus, lvs

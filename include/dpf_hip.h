@@ -328,6 +328,28 @@ int dpf_encoder_pack(int precision, const float *canon, void *packed, dpf_stream
 int dpf_encoder_forward(int B, int N, int precision, const void *packed, const float *x,
                         float *gmax, float *feat, dpf_stream_t stream);
 
+/* ---- latent prior flow: GlobalRNVPDecoder on (B, G) codes, eval-mode BatchNorm ---------------
+ * replaces GlobalRNVPDecoder.forward (lib/networks/decoders.py:21-38): n_steps = 2 * n_flows
+ * RealNVPFlow steps (lib/networks/flows.py:198-213) in ONE launch, both modes.
+ *
+ * codes (HOST array, n_steps ints): which coordinates a step warps -- RealNVPFlowCouple's
+ * patterns (flows.py:224-233): 0 even, 1 odd, 2 first half, 3 second half; G must be even.
+ * canon: per step dpf_gprior_canon_floats(G, n_features) fp32, for T in (mu, logvar), K = G/2:
+ *   mlp0.weight [n_features][K] | bn.weight | bn.bias | bn.running_mean | bn.running_var |
+ *   mlp1.weight [K][n_features] | mlp1.bias [K]                      (flows.py:176-196).
+ * dpf_gprior_pack folds BatchNorm and transposes the weights (once per weight version).
+ * dpf_gprior_forward: g (B,G) -> gs, mus, lvs (n_steps,B,G) in DIRECT order whatever the mode
+ * (mu / logvar zero on a step's kept coordinates, as the reference's lists), sum_lv (B,G) the sum of
+ * the logvars over the steps, g_out (B,G) the end of the chain (gs[n_steps-1] direct, gs[0]
+ * inverse); every output may be NULL.  eps: RealNVPFlow's logvar floor (flows.py:164,201). */
+size_t dpf_gprior_canon_floats(int G, int n_features);
+size_t dpf_gprior_packed_floats(int n_steps, int G, int n_features);
+int dpf_gprior_pack(int n_steps, int G, int n_features, float bn_eps, const float *canon,
+                    float *packed, dpf_stream_t stream);
+int dpf_gprior_forward(int n_steps, int B, int G, int n_features, int mode, const int *codes,
+                       const float *packed, const float *g, float *gs, float *mus, float *lvs,
+                       float *sum_lv, float *g_out, float eps, dpf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

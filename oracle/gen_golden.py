@@ -19,6 +19,7 @@ import torch
 from . import detrng
 from . import flow_oracle as FO
 from . import encoder_oracle as EO
+from . import gprior_oracle as GO
 
 REF = os.environ.get("DPF_REFERENCE", "/root/reference")
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
@@ -305,16 +306,60 @@ def gen_optimizer():
     np.savez_compressed(os.path.join(OUT, "optimizer.npz"), **out)
 
 
+GPRIOR_CASES = {"a": (21, 2, 32, 16, 5), "b": (22, 7, 128, 128, 4), "c": (23, 1, 128, 512, 3), "d": (24, 3, 48, 10, 1)}
+
+
+def gen_gprior(decoders):
+    """GlobalRNVPDecoder (decoders.py:7-38) on (B,G) latents, both modes: the three DIRECT-order lists in eval mode;
+    in train mode also d/dg of a seeded projection of the lists, projections of the parameter gradients and the
+    BatchNorm running statistics.  Cases: a toy, the generation configs' 7 x 128 on G=128, G=512, and a single row."""
+    out = {}
+    for case, (seed, n_flows, nf, G, B) in GPRIOR_CASES.items():
+        st = GO.make_gprior_state(seed, n_flows, nf, G)
+        g = torch.from_numpy(GO.gprior_inputs(seed, B, G))
+        for training in (False, True):
+            if training and B < 2:
+                continue                                      # BatchNorm1d refuses a single row in train mode
+            for mode in ("direct", "inverse"):
+                dec = decoders.GlobalRNVPDecoder(n_flows, nf, G)
+                dec.load_state_dict(FO.to_torch(st), strict=True)
+                dec.train(training)
+                gin = g.clone().requires_grad_(training)
+                gs, mus, lvs = dec(gin, mode=mode)
+                tag = "%s_%s_%s" % (case, "train" if training else "eval", mode)
+                out[tag + "_gs"] = torch.stack(gs).detach().numpy()
+                out[tag + "_mus"] = torch.stack(mus).detach().numpy()
+                out[tag + "_lvs"] = torch.stack(lvs).detach().numpy()
+                if training:
+                    loss = 0.0
+                    for name, lst in (("gs", gs), ("mus", mus), ("lvs", lvs)):
+                        r = torch.from_numpy(detrng.normal_f32(detrng.key(seed, "gprior_r_" + name), (len(lst), B, G)))
+                        loss = loss + (torch.stack(lst) * r).sum()
+                    loss.backward()
+                    out[tag + "_dg"] = gin.grad.numpy()
+                    for k, v in _grad_projection([(k, p.grad) for k, p in dec.named_parameters()], seed).items():
+                        out[tag + "_gproj_" + k] = v
+                    for k, v in dec.state_dict().items():
+                        if "running" in k:
+                            out[tag + "_stat_" + k] = v.numpy()
+        if case == "a":
+            keys = list(dec.state_dict().keys())
+    np.savez_compressed(os.path.join(OUT, "gprior.npz"), **out)
+    with open(os.path.join(OUT, "gprior.json"), "w") as f:
+        json.dump({"cases": {k: list(v) for k, v in GPRIOR_CASES.items()}, "keys_case_a": keys}, f, indent=1)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     flows, decoders, losses, layers, evaluation_metrics = _import_reference()
-    gen_state_keys(flows, decoders, layers)
-    gen_layer(flows)
-    gen_decoder(decoders, losses)
-    gen_chamfer(evaluation_metrics)
-    gen_encoder()
-    gen_optimizer()
+    only = set(sys.argv[1:])                                  # e.g. `python -m oracle.gen_golden gprior`
+    todo = (("keys", lambda: gen_state_keys(flows, decoders, layers)), ("layer", lambda: gen_layer(flows)),
+            ("decoder", lambda: gen_decoder(decoders, losses)), ("chamfer", lambda: gen_chamfer(evaluation_metrics)),
+            ("encoder", gen_encoder), ("optimizer", gen_optimizer), ("gprior", lambda: gen_gprior(decoders)))
+    for name, fn in todo:
+        if not only or name in only:
+            fn()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -276,3 +276,59 @@ def test_optimizer_oracle_and_mirror_vs_reference_golden(golden_dir):
             np.testing.assert_array_equal(st["exp_avg_sq"].numpy(), gold["%s_v%d" % (name, i)])
             if ams:
                 np.testing.assert_array_equal(st["max_exp_avg_sq"].numpy(), gold["%s_vmax%d" % (name, i)])
+
+
+def test_gprior_oracle_and_module_vs_reference_golden(golden_dir):
+    """oracle/gprior_oracle.py AND the tensor-op path of dpf_nets_amd.networks.GlobalRNVPDecoder against the
+    reference's GlobalRNVPDecoder (decoders.py:7-38, flows.py:163-243): the three DIRECT-order lists in both modes,
+    eval and train; in train mode d/dg, every parameter gradient (projections) and the BatchNorm running statistics."""
+    from oracle import gprior_oracle as GO
+    from dpf_nets_amd import networks as nets
+    gold, meta = _load(golden_dir, "gprior")
+    for case, (seed, n_flows, nf, G, B) in meta["cases"].items():
+        g = torch.from_numpy(GO.gprior_inputs(seed, B, G))
+        state = GO.make_gprior_state(seed, n_flows, nf, G)
+        if case == "a":
+            assert meta["keys_case_a"] == list(state.keys())
+        for training in (False, True):
+            if training and B < 2:
+                continue
+            for mode in ("direct", "inverse"):
+                tag = "%s_%s_%s" % (case, "train" if training else "eval", mode)
+                # ---- the oracle
+                st = FO.to_torch(state)
+                params = {k: v.requires_grad_(True) for k, v in st.items()
+                          if v.dtype == torch.float32 and "running" not in k and not k.endswith("eps")}
+                st.update(params)
+                gin = g.clone().requires_grad_(training)
+                stats = {}
+                lists = GO.global_rnvp_decoder(st, n_flows, gin, mode, training, stats)
+                # ---- the module
+                dec = nets.GlobalRNVPDecoder(n_flows, nf, G)
+                dec.load_state_dict(FO.to_torch(state), strict=True)
+                dec.train(training)
+                gmod = g.clone().requires_grad_(training)
+                mlists = dec(gmod, mode=mode)
+                for name, lst, mlst in zip(("gs", "mus", "lvs"), lists, mlists):
+                    assert len(lst) == len(mlst) == 2 * n_flows
+                    np.testing.assert_allclose(torch.stack(lst).detach().numpy(), gold[tag + "_" + name], rtol=RTOL, atol=ATOL)
+                    np.testing.assert_allclose(torch.stack(list(mlst)).detach().numpy(), gold[tag + "_" + name], rtol=RTOL, atol=ATOL)
+                if not training:
+                    continue
+                for which, ls, gi, named in (("oracle", lists, gin, None), ("module", mlists, gmod, dec)):
+                    loss = 0.0
+                    for name, lst in zip(("gs", "mus", "lvs"), ls):
+                        r = torch.from_numpy(detrng.normal_f32(detrng.key(seed, "gprior_r_" + name), (len(lst), B, G)))
+                        loss = loss + (torch.stack(list(lst)) * r).sum()
+                    loss.backward()
+                    np.testing.assert_allclose(gi.grad.numpy(), gold[tag + "_dg"], rtol=2e-4, atol=2e-5, err_msg=which)
+                    grads = [(k, v.grad) for k, v in params.items()] if named is None else \
+                        [(k, p.grad) for k, p in named.named_parameters()]
+                    for k, v in _grad_projection(grads, seed).items():
+                        ref = gold[tag + "_gproj_" + k]
+                        np.testing.assert_allclose(v, ref, rtol=2e-4, atol=2e-5 * max(1.0, float(ref[2])), err_msg=which + k)
+                for k, v in stats.items():
+                    np.testing.assert_allclose(v.numpy(), gold[tag + "_stat_" + k], rtol=RTOL, atol=ATOL, err_msg=k)
+                for k, v in dec.state_dict().items():
+                    if "running" in k:
+                        np.testing.assert_allclose(v.numpy(), gold[tag + "_stat_" + k], rtol=RTOL, atol=ATOL, err_msg=k)
