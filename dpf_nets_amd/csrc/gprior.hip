@@ -14,25 +14,23 @@
 
 namespace {
 
-constexpr int THREADS = 256;
+constexpr int THREADS = 1024;      // the steps are chains of dependent round trips: many short dot products, not few long ones
+constexpr int PACK_THREADS = 256;
 constexpr int MAX_STEPS = 256;
 
 // step code (2 bits): which coordinates a step warps, RealNVPFlowCouple's two patterns (flows.py:224-233)
 //   0: even (keep odd)   1: odd (keep even)   2: first half (keep second)   3: second half (keep first)
-__device__ __forceinline__ int warp_index(int code, int i, int K) { return code == 0 ? 2 * i : code == 1 ? 2 * i + 1 : code == 2 ? i : i + K; }
-__device__ __forceinline__ int keep_index(int code, int i, int K) { return code == 0 ? 2 * i + 1 : code == 1 ? 2 * i : code == 2 ? i + K : i; }
-
 __host__ __device__ inline size_t canon_net_floats(int K, int nf) { return (size_t)2 * nf * K + 4 * (size_t)nf + K; }
 __host__ __device__ inline size_t packed_net_floats(int K, int nf) { return (size_t)2 * nf * K + 2 * (size_t)nf + K; }
 
 // canon (per step, per net: mu then logvar; the reference's state_dict order, flows.py:176-196):
 //   W0 [nf][K] | bn.weight | bn.bias | bn.running_mean | bn.running_var | W1 [K][nf] | b1 [K]
 // packed (per step, per net):  W0t [K][nf] | a [nf] | c [nf] | W1t [nf][K] | b1 [K]      a = gamma / sqrt(var + eps), c = beta - mean a
-__global__ __launch_bounds__(THREADS) void gprior_pack_kernel(int nets, int K, int nf, float bn_eps, const float *__restrict__ canon,
+__global__ __launch_bounds__(PACK_THREADS) void gprior_pack_kernel(int nets, int K, int nf, float bn_eps, const float *__restrict__ canon,
                                                               float *__restrict__ packed) {
     const size_t cn = canon_net_floats(K, nf), pn = packed_net_floats(K, nf);
     const size_t total = (size_t)nets * pn;
-    for (size_t e = (size_t)blockIdx.x * THREADS + threadIdx.x; e < total; e += (size_t)gridDim.x * THREADS) {
+    for (size_t e = (size_t)blockIdx.x * PACK_THREADS + threadIdx.x; e < total; e += (size_t)gridDim.x * PACK_THREADS) {
         const size_t net = e / pn;
         size_t o = e - net * pn;
         const float *c = canon + net * cn;
@@ -57,105 +55,118 @@ __global__ __launch_bounds__(THREADS) void gprior_pack_kernel(int nets, int K, i
 }
 
 struct GArgs {
-    int S, B, G, nf, inverse, parts;
+    int S, B, G, nf, inverse, parts1, parts2;
     float eps;
     const float *packed, *g;
     float *gs, *mus, *lvs, *sum_lv, *g_out;
     uint32_t codes[MAX_STEPS / 16];
 };
 
-template <int RB>
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global store to be
+// acknowledged, and each step stores its slice of the result lists -- nobody in the kernel reads those back.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0), vmcnt / expcnt untouched
+    __builtin_amdgcn_s_barrier();
+}
+
+// One map phase: out[p][r][q .. q+V) = sum over the p-th part of the inner range of  w[inner][q .. q+V) * x[r][inner],
+// q over `width` outputs (V consecutive ones per thread: one 4 V-byte load per V FMAs), x read through a linear
+// index map (xmul * inner + xadd: the kept coordinates of the row, or the hidden activations).
+template <int RB, int V>
+__device__ __forceinline__ void map_phase(const float *__restrict__ w, int width, int inner, int parts, const float *x, int xstride,
+                                          int xmul, int xadd, int netsplit, int xnet, size_t wnet, float *part, int tid) {
+    typedef float vec __attribute__((ext_vector_type(V)));
+    const int nq = width / V;
+    for (int o = tid; o < parts * nq; o += THREADS) {
+        const int p = o / nq, q = (o - p * nq) * V, net = q >= netsplit;
+        const int i0 = inner * p / parts, i1 = inner * (p + 1) / parts;
+        const float *wp = w + net * wnet + (q - net * netsplit);
+        const float *xp = x + net * xnet + xadd;
+        vec acc[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = (vec)(0.f);
+        int k = i0;
+        constexpr int U = V == 1 ? 16 : 4;
+        for (; k + U <= i1; k += U) {
+            vec wv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) wv[u] = *(const vec *)(wp + (size_t)(k + u) * netsplit);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int r = 0; r < RB; ++r) acc[r] += wv[u] * xp[r * xstride + (k + u) * xmul];
+        }
+        for (; k < i1; ++k) {
+            const vec wv = *(const vec *)(wp + (size_t)k * netsplit);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) acc[r] += wv * xp[r * xstride + k * xmul];
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) *(vec *)(part + (size_t)(p * RB + r) * width + q) = acc[r];
+    }
+}
+
+template <int RB, int V>
 __global__ __launch_bounds__(THREADS) void gprior_kernel(GArgs a) {
     extern __shared__ float lds[];
-    const int G = a.G, K = G >> 1, nf = a.nf, P = a.parts;
+    const int G = a.G, K = G >> 1, nf = a.nf, P1 = a.parts1, P = a.parts2;
     float *gcur = lds;                          // [RB][G]   the rows as they stand
     float *tot = gcur + RB * G;                 // [RB][G]   running sum of the logvars
     float *hs = tot + RB * G;                   // [RB][2 nf] hidden activations, mu net then logvar net
-    float *part = hs + RB * 2 * nf;             // [P][RB][2 K] partial second-map sums
+    float *part = hs + RB * 2 * nf;             // [P1][RB][2 nf] partial first-map sums, then [P][RB][2 K] partial second-map sums
     const int tid = threadIdx.x, row0 = blockIdx.x * RB;
     for (int e = tid; e < RB * G; e += THREADS) {
         const int r = e / G, row = row0 + r;
         gcur[e] = row < a.B ? a.g[(size_t)row * G + (e - r * G)] : 0.f;
         tot[e] = 0.f;
     }
-    __syncthreads();
+    lds_barrier();
     const size_t pn = packed_net_floats(K, nf);
     for (int t = 0; t < a.S; ++t) {
         const int s = a.inverse ? a.S - 1 - t : t;
         const int code = (a.codes[s >> 4] >> ((s & 15) * 2)) & 3;
+        // kept coordinate k of the step sits at kmul * k + kadd, warped coordinate i at kmul * i + wadd
+        const int kmul = code < 2 ? 2 : 1, kadd = code == 0 ? 1 : code == 2 ? K : 0, wadd = code == 1 ? 1 : code == 3 ? K : 0;
         const float *pk = a.packed + (size_t)s * 2 * pn;
-        // ---- first map + BatchNorm + Swish: one (net, j) per thread, the RB rows in registers
-        for (int o = tid; o < 2 * nf; o += THREADS) {
-            const int net = o >= nf, j = o - net * nf;
-            const float *w = pk + net * pn + j;
-            float acc[RB];
-#pragma unroll
-            for (int r = 0; r < RB; ++r) acc[r] = 0.f;
-            int k = 0;
-            for (; k + 8 <= K; k += 8) {
-                float wv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) wv[u] = w[(size_t)(k + u) * nf];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int ki = keep_index(code, k + u, K);
-#pragma unroll
-                    for (int r = 0; r < RB; ++r) acc[r] = fmaf(wv[u], gcur[r * G + ki], acc[r]);
-                }
-            }
-            for (; k < K; ++k) {
-                const float wv = w[(size_t)k * nf];
-                const int ki = keep_index(code, k, K);
-#pragma unroll
-                for (int r = 0; r < RB; ++r) acc[r] = fmaf(wv, gcur[r * G + ki], acc[r]);
-            }
-            const float sa = pk[net * pn + (size_t)K * nf + j], sc = pk[net * pn + (size_t)K * nf + nf + j];
-#pragma unroll
-            for (int r = 0; r < RB; ++r) {
-                const float y = fmaf(acc[r], sa, sc);
-                hs[r * 2 * nf + o] = y / (1.f + expf(-y));
-            }
+        // the step's BatchNorm vectors and biases are fetched now, with the first-map weights, not when they are needed:
+        // a step is a chain of dependent round trips to L2 / the infinity cache, and these two would be links of it
+        float bn_a = 0.f, bn_c = 0.f, b_mu = 0.f, b_lv = 0.f;
+        if (tid < RB * 2 * nf) {
+            const int q = tid % (2 * nf), net = q >= nf, j = q - net * nf;
+            bn_a = pk[net * pn + (size_t)K * nf + j];
+            bn_c = pk[net * pn + (size_t)K * nf + nf + j];
         }
-        __syncthreads();
-        // ---- second map: (part p of the hidden range, net, i) per thread
-        for (int o = tid; o < P * 2 * K; o += THREADS) {
-            const int p = o / (2 * K), q = o - p * 2 * K, net = q >= K, i = q - net * K;
-            const int j0 = (int)((long)nf * p / P), j1 = (int)((long)nf * (p + 1) / P);
-            const float *w = pk + net * pn + (size_t)K * nf + 2 * nf + i;
-            const float *h = hs + net * nf;
-            float acc[RB];
-#pragma unroll
-            for (int r = 0; r < RB; ++r) acc[r] = 0.f;
-            int j = j0;
-            for (; j + 8 <= j1; j += 8) {
-                float wv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) wv[u] = w[(size_t)(j + u) * K];
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-#pragma unroll
-                    for (int r = 0; r < RB; ++r) acc[r] = fmaf(wv[u], h[r * 2 * nf + j + u], acc[r]);
-            }
-            for (; j < j1; ++j) {
-                const float wv = w[(size_t)j * K];
-#pragma unroll
-                for (int r = 0; r < RB; ++r) acc[r] = fmaf(wv, h[r * 2 * nf + j], acc[r]);
-            }
-#pragma unroll
-            for (int r = 0; r < RB; ++r) part[(p * RB + r) * 2 * K + q] = acc[r];
+        if (tid < RB * K) {
+            const int i = tid % K;
+            b_mu = pk[(size_t)2 * K * nf + 2 * nf + i];
+            b_lv = pk[pn + (size_t)2 * K * nf + 2 * nf + i];
         }
-        __syncthreads();
+        // ---- first map: (part of the kept range, net, j): W0t [K][nf] against the kept coordinates
+        map_phase<RB, V>(pk, 2 * nf, K, P1, gcur, G, kmul, kadd, nf, 0, pn, part, tid);
+        lds_barrier();
+        // ---- BatchNorm (folded) + Swish
+        for (int o = tid; o < RB * 2 * nf; o += THREADS) {
+            const int r = o / (2 * nf), q = o - r * 2 * nf, net = q >= nf, j = q - net * nf;
+            float acc = 0.f;
+            for (int p = 0; p < P1; ++p) acc += part[(p * RB + r) * 2 * nf + q];
+            const float y = o < THREADS ? fmaf(acc, bn_a, bn_c) : fmaf(acc, pk[net * pn + (size_t)K * nf + j], pk[net * pn + (size_t)K * nf + nf + j]);
+            hs[o] = y / (1.f + expf(-y));
+        }
+        lds_barrier();
+        // ---- second map: (part of the hidden range, net, i): W1t [nf][K] against the activations of its net
+        map_phase<RB, V>(pk + (size_t)K * nf + 2 * nf, 2 * K, nf, P, hs, 2 * nf, 1, 0, K, nf, pn, part, tid);
+        lds_barrier();
         // ---- mu, logvar and the affine update of the warped coordinates: one (row, i) per thread
         const float *b1m = pk + (size_t)2 * K * nf + 2 * nf, *b1l = b1m + pn;
         for (int o = tid; o < RB * K; o += THREADS) {
             const int r = o / K, i = o - r * K, row = row0 + r;
-            float om = b1m[i], ol = b1l[i];
+            float om = o < THREADS ? b_mu : b1m[i], ol = o < THREADS ? b_lv : b1l[i];
             for (int p = 0; p < P; ++p) {
                 om += part[(p * RB + r) * 2 * K + i];
                 ol += part[(p * RB + r) * 2 * K + K + i];
             }
             const float lv = logf(a.eps + expf(ol));
-            const int wi = warp_index(code, i, K), ki = keep_index(code, i, K);
+            const int wi = kmul * i + wadd, ki = kmul * i + kadd;
             const float gold = gcur[r * G + wi];
             gcur[r * G + wi] = a.inverse ? expf(-0.5f * lv) * (gold - om) : fmaf(expf(0.5f * lv), gold, om);
             tot[r * G + wi] += lv;
@@ -165,7 +176,7 @@ __global__ __launch_bounds__(THREADS) void gprior_kernel(GArgs a) {
                 if (a.lvs) { a.lvs[base + wi] = lv; a.lvs[base + ki] = 0.f; }
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (a.gs)
             for (int e = tid; e < RB * G; e += THREADS) {
                 const int r = e / G, row = row0 + r;
@@ -193,8 +204,8 @@ size_t dpf_gprior_packed_floats(int n_steps, int G, int n_features) {
 int dpf_gprior_pack(int n_steps, int G, int n_features, float bn_eps, const float *canon, float *packed, dpf_stream_t stream) {
     if (n_steps <= 0 || G < 2 || (G & 1) || n_features <= 0 || !canon || !packed) return DPF_EINVAL;
     const size_t total = dpf_gprior_packed_floats(n_steps, G, n_features);
-    const int blocks = (int)((total + THREADS - 1) / THREADS < 2048 ? (total + THREADS - 1) / THREADS : 2048);
-    hipLaunchKernelGGL(gprior_pack_kernel, dim3(blocks), dim3(THREADS), 0, (hipStream_t)stream, 2 * n_steps, G / 2, n_features, bn_eps, canon,
+    const int blocks = (int)((total + PACK_THREADS - 1) / PACK_THREADS < 2048 ? (total + PACK_THREADS - 1) / PACK_THREADS : 2048);
+    hipLaunchKernelGGL(gprior_pack_kernel, dim3(blocks), dim3(PACK_THREADS), 0, (hipStream_t)stream, 2 * n_steps, G / 2, n_features, bn_eps, canon,
                        packed);
     return (int)hipGetLastError();
 }
@@ -215,14 +226,19 @@ int dpf_gprior_forward(int n_steps, int B, int G, int n_features, int mode, cons
     // rows per workgroup: 1 up to one workgroup per CU, 2 beyond (the weights are read once per workgroup and step);
     // the hidden range of the second map is split over the threads the (net, i) items leave idle
     const int rb = B > 256 ? 2 : 1;
-    a.parts = THREADS / G > 1 ? (THREADS / G < n_features ? THREADS / G : n_features) : 1;
-    const size_t lds = sizeof(float) * ((size_t)rb * (2 * G + 2 * n_features) + (size_t)a.parts * rb * G);
+    const int K = G / 2;
+    // V consecutive outputs per thread (16-byte weight loads) when the shapes allow it; the inner ranges are split so
+    // that all 1024 threads have an item
+    const int v = (K % 4 == 0 && n_features % 4 == 0) ? 4 : 1;
+    const int q1 = 2 * n_features / v, q2 = G / v;
+    a.parts1 = THREADS / q1 > 1 ? (THREADS / q1 < K ? THREADS / q1 : K) : 1;
+    a.parts2 = THREADS / q2 > 1 ? (THREADS / q2 < n_features ? THREADS / q2 : n_features) : 1;
+    const size_t p1 = (size_t)a.parts1 * 2 * n_features, p2 = (size_t)a.parts2 * G;
+    const size_t lds = sizeof(float) * rb * ((size_t)2 * G + 2 * n_features + (p1 > p2 ? p1 : p2));
     if (lds > 64 * 1024) return DPF_ENOSUP;
     const int grid = (B + rb - 1) / rb;
-    if (rb == 1)
-        hipLaunchKernelGGL(gprior_kernel<1>, dim3(grid), dim3(THREADS), lds, (hipStream_t)stream, a);
-    else
-        hipLaunchKernelGGL(gprior_kernel<2>, dim3(grid), dim3(THREADS), lds, (hipStream_t)stream, a);
+    void (*kern)(GArgs) = rb == 1 ? (v == 4 ? gprior_kernel<1, 4> : gprior_kernel<1, 1>) : (v == 4 ? gprior_kernel<2, 4> : gprior_kernel<2, 1>);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

@@ -176,7 +176,7 @@ class GlobalRNVPDecoder(nn.Module):
     def forward(self, g, mode="direct"):
         if mode not in ("direct", "inverse"):
             raise ValueError(mode)
-        if self.n_flows and _fusable(self, self.coupling_layers(), g):
+        if self.n_flows and _fusable(self, self.__dict__.get("_steps") or self.__dict__.setdefault("_steps", self.coupling_layers()), g):
             _, sum_lv, gs, mus, lvs = self.stack().run(g, mode)
             return FlowList(gs), FlowList(mus), FlowList(lvs, sum_lv)
         return self.forward_torch(g, mode)
@@ -186,9 +186,12 @@ def _fusable(module, layers, g):
     """Eval mode on a CUDA tensor without autograd, every step one of the kernel's index patterns."""
     if module.training or not g.is_cuda or _needs_autograd(g):      # as the point decoder: autograd follows the INPUT
         return False
-    G = layers[0].g_n_features
-    return all(l.g_n_features == G and l.n_features == layers[0].n_features and pattern_code(l.warp_inds, G) is not None
-               for l in layers)
+    ok = module.__dict__.get("_patterns_ok")
+    if ok is None:                                                 # warp_inds are fixed at construction
+        G = layers[0].g_n_features
+        ok = module.__dict__["_patterns_ok"] = all(
+            l.g_n_features == G and l.n_features == layers[0].n_features and pattern_code(l.warp_inds, G) is not None for l in layers)
+    return ok
 
 
 class GPriorStack:
