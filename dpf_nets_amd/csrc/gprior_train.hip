@@ -1,0 +1,270 @@
+// Latent prior flow, TRAINING mode: GlobalRNVPDecoder.forward under model.train() (BatchNorm1d on the statistics of
+// the B rows, lib/networks/flows.py:176-213, decoders.py:21-38) and what autograd derives from it.
+//
+// The operands are (B x 64..256) matrices: as tensor ops a step is ~25 launches forward and ~50 backward, and the
+// 14 steps of a training iteration cost ~12 ms of launch latency -- more than the whole point decoder.  Here a step
+// is 4 launches forward and 7 backward, issued back to back by one C call: small fp32 GEMMs through one strided
+// LDS-tiled kernel (the kept / warped coordinate sets are strides, not gathers; both nets of a step are one batched
+// launch) and four fused element / column kernels (batch statistics + Swish, the affine update, their backwards).
+// fp32 FMAs throughout: these matrices are launch-latency-, not throughput-bound, and the tolerance is fp32's.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dpf_hip.h"
+
+namespace {
+
+constexpr int T = 256;
+
+inline size_t net_floats(int K, int nf) { return (size_t)2 * nf * K + 4 * (size_t)nf + K; }     // canon floats of one net
+
+struct Gemm {          // C[m][n] (+)= sum over `nsum` operand pairs, sum over k:  A[m][k] * Bm[k][n]     (blockIdx.z = batch)
+    int M, N, Kd, nsum, accumulate;
+    const float *A, *Bm;
+    float *C;
+    long a_rs, a_cs, a_bs, a_ss, b_rs, b_cs, b_bs, b_ss, c_rs, c_cs, c_bs;
+};
+
+__global__ __launch_bounds__(T) void sgemm_kernel(Gemm g) {
+    __shared__ float As[16][64 + 4], Bs[16][64 + 4];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64, z = blockIdx.z;
+    float acc[4][4] = {};
+    for (int si = 0; si < g.nsum; ++si) {
+        const float *A0 = g.A + z * g.a_bs + si * g.a_ss, *B0 = g.Bm + z * g.b_bs + si * g.b_ss;
+        for (int k0 = 0; k0 < g.Kd; k0 += 16) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = tid + u * T, x = e & 63, k = e >> 6;
+                const bool kin = k0 + k < g.Kd;
+                As[k][x] = kin && m0 + x < g.M ? A0[(long)(m0 + x) * g.a_rs + (long)(k0 + k) * g.a_cs] : 0.f;
+                Bs[k][x] = kin && n0 + x < g.N ? B0[(long)(k0 + k) * g.b_rs + (long)(n0 + x) * g.b_cs] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float4 a = *(const float4 *)&As[k][ty * 4], b = *(const float4 *)&Bs[k][tx * 4];
+                const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
+            if (m < g.M && n < g.N) {
+                float *c = g.C + z * g.c_bs + (long)m * g.c_rs + (long)n * g.c_cs;
+                *c = g.accumulate ? *c + acc[i][j] : acc[i][j];
+            }
+        }
+}
+
+void gemm(hipStream_t s, int batch, Gemm g) {
+    hipLaunchKernelGGL(sgemm_kernel, dim3((g.N + 63) / 64, (g.M + 63) / 64, batch), dim3(T), 0, s, g);
+}
+
+__device__ __forceinline__ float swish(float y) { return y / (1.f + expf(-y)); }
+
+// Batch statistics over the B rows of every hidden column (two passes, as torch), BatchNorm affine, Swish.
+// h (B, 2 nf) -> stats (2, 2 nf) = mean | biased variance,  hs (B, 2 nf).   cnet = canon of the step (mu net, then logvar net)
+__global__ __launch_bounds__(T) void bn_swish_kernel(int B, int nf, size_t cn, float bn_eps, const float *__restrict__ cnet,
+                                                     const float *__restrict__ h, float *__restrict__ stats, float *__restrict__ hs) {
+    const int c = blockIdx.x * T + threadIdx.x;
+    if (c >= 2 * nf) return;
+    const int net = c >= nf, j = c - net * nf;
+    float sum = 0.f;
+    for (int b = 0; b < B; ++b) sum += h[(size_t)b * 2 * nf + c];
+    const float mean = sum / B;
+    float sq = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float d = h[(size_t)b * 2 * nf + c] - mean;
+        sq = fmaf(d, d, sq);
+    }
+    const float var = sq / B, rstd = 1.f / sqrtf(var + bn_eps);
+    if (stats) {
+        stats[c] = mean;
+        stats[2 * nf + c] = var;
+    }
+    // gamma / beta sit behind the net's first-map weights: W0 [nf][K] | gamma | beta | ...   (offset passed through cnet)
+    const float gam = cnet[net * cn + j], bet = cnet[net * cn + nf + j];
+    for (int b = 0; b < B; ++b) hs[(size_t)b * 2 * nf + c] = swish(fmaf((h[(size_t)b * 2 * nf + c] - mean) * rstd, gam, bet));
+}
+
+// mu, logvar = log(eps + exp(.)) and the affine update of the warped coordinates; the step's slices of the three lists
+__global__ __launch_bounds__(T) void finalize_kernel(int B, int G, int inverse, int kmul, int kadd, int wadd, float eps,
+                                                     const float *__restrict__ o, const float *__restrict__ b1m,
+                                                     const float *__restrict__ b1l, const float *__restrict__ gin,
+                                                     float *__restrict__ gs, float *__restrict__ mus, float *__restrict__ lvs) {
+    const int K = G >> 1, e = blockIdx.x * T + threadIdx.x;
+    if (e >= B * K) return;
+    const int b = e / K, i = e - b * K, wi = kmul * i + wadd, ki = kmul * i + kadd;
+    const float om = o[(size_t)b * 2 * K + i] + b1m[i], ol = o[(size_t)b * 2 * K + K + i] + b1l[i];
+    const float lv = logf(eps + expf(ol));
+    const size_t at = (size_t)b * G;
+    const float gw = gin[at + wi];
+    gs[at + wi] = inverse ? expf(-0.5f * lv) * (gw - om) : fmaf(expf(0.5f * lv), gw, om);
+    gs[at + ki] = gin[at + ki];
+    mus[at + wi] = om; mus[at + ki] = 0.f;
+    lvs[at + wi] = lv; lvs[at + ki] = 0.f;
+}
+
+// Backward of finalize: d_out = dcur + d_gs.  Writes d_o (B, 2K) for the second map, the direct part of the gradient
+// w.r.t. the step's input (dnext), and recomputes hs = Swish(BatchNorm(h)) for the weight gradients.
+__global__ __launch_bounds__(T) void prep_kernel(int B, int G, int nf, size_t cn, int inverse, int kmul, int kadd, int wadd, float eps,
+                                                 float bn_eps, const float *__restrict__ dcur, const float *__restrict__ d_gs,
+                                                 const float *__restrict__ d_mus, const float *__restrict__ d_lvs,
+                                                 const float *__restrict__ gs, const float *__restrict__ mus,
+                                                 const float *__restrict__ lvs, const float *__restrict__ h,
+                                                 const float *__restrict__ stats, const float *__restrict__ cnet,
+                                                 float *__restrict__ d_o, float *__restrict__ dnext, float *__restrict__ hs) {
+    const int K = G >> 1, e = blockIdx.x * T + threadIdx.x;
+    if (e < B * K) {
+        const int b = e / K, i = e - b * K, wi = kmul * i + wadd, ki = kmul * i + kadd;
+        const size_t at = (size_t)b * G;
+        const float dw = (dcur ? dcur[at + wi] : 0.f) + (d_gs ? d_gs[at + wi] : 0.f);
+        const float dk = (dcur ? dcur[at + ki] : 0.f) + (d_gs ? d_gs[at + ki] : 0.f);
+        const float lv = lvs[at + wi], mu = mus[at + wi], out = gs[at + wi];
+        const float sc = expf(inverse ? -0.5f * lv : 0.5f * lv);
+        const float dmu = (d_mus ? d_mus[at + wi] : 0.f) + (inverse ? -dw * sc : dw);
+        const float dlv = (d_lvs ? d_lvs[at + wi] : 0.f) + (inverse ? -0.5f * dw * out : 0.5f * dw * (out - mu));
+        d_o[(size_t)b * 2 * K + i] = dmu;
+        d_o[(size_t)b * 2 * K + K + i] = dlv * (1.f - eps * expf(-lv));          // d/do log(eps + exp(o)) = exp(o) / (eps + exp(o))
+        dnext[at + wi] = dw * sc;
+        dnext[at + ki] = dk;
+    }
+    if (e < B * 2 * nf) {
+        const int c = e % (2 * nf), net = c >= nf, j = c - net * nf;
+        const float mean = stats[c], rstd = 1.f / sqrtf(stats[2 * nf + c] + bn_eps);
+        hs[e] = swish(fmaf((h[e] - mean) * rstd, cnet[net * cn + j], cnet[net * cn + nf + j]));
+    }
+}
+
+// Backward of Swish and of the batch-statistics BatchNorm, per hidden column; d gamma, d beta; and d b1 = column sums of d_o.
+__global__ __launch_bounds__(T) void bn_backward_kernel(int B, int G, int nf, size_t cn, float bn_eps, const float *__restrict__ cnet,
+                                                        const float *__restrict__ h, const float *__restrict__ stats,
+                                                        const float *__restrict__ dhs, const float *__restrict__ d_o,
+                                                        float *__restrict__ dh, float *__restrict__ dcnet) {
+    const int K = G >> 1, c = blockIdx.x * T + threadIdx.x;
+    if (c < 2 * nf) {
+        const int net = c >= nf, j = c - net * nf;
+        const float mean = stats[c], rstd = 1.f / sqrtf(stats[2 * nf + c] + bn_eps);
+        const float gam = cnet[net * cn + j], bet = cnet[net * cn + nf + j];
+        float s1 = 0.f, s2 = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float xh = (h[(size_t)b * 2 * nf + c] - mean) * rstd, y = fmaf(xh, gam, bet), sg = 1.f / (1.f + expf(-y));
+            const float dy = dhs[(size_t)b * 2 * nf + c] * (sg * (1.f + y * (1.f - sg)));
+            s1 += dy;
+            s2 = fmaf(dy, xh, s2);
+        }
+        dcnet[net * cn + j] = s2;                  // d gamma
+        dcnet[net * cn + nf + j] = s1;             // d beta
+        dcnet[net * cn + 2 * nf + j] = 0.f;        // running statistics carry no gradient
+        dcnet[net * cn + 3 * nf + j] = 0.f;
+        const float m1 = s1 / B, m2 = s2 / B;
+        for (int b = 0; b < B; ++b) {
+            const float xh = (h[(size_t)b * 2 * nf + c] - mean) * rstd, y = fmaf(xh, gam, bet), sg = 1.f / (1.f + expf(-y));
+            const float dy = dhs[(size_t)b * 2 * nf + c] * (sg * (1.f + y * (1.f - sg)));
+            dh[(size_t)b * 2 * nf + c] = gam * rstd * (dy - m1 - xh * m2);
+        }
+    }
+    if (c < 2 * K) {
+        const int net = c >= K, i = c - net * K;
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += d_o[(size_t)b * 2 * K + c];
+        dcnet[net * cn + 4 * (size_t)nf + (size_t)K * nf + i] = s;      // d b1: behind the four BatchNorm vectors and W1 (dcnet starts at gamma)
+    }
+}
+
+bool steps_ok(int S, int B, int G, int nf, int mode, const int *codes) {
+    if (S <= 0 || B < 2 || G < 2 || (G & 1) || nf <= 0 || !codes || (mode != 0 && mode != 1)) return false;
+    for (int s = 0; s < S; ++s)
+        if (codes[s] < 0 || codes[s] > 3) return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dpf_gprior_train_workspace_floats(int B, int G, int n_features) {
+    // hs | o / d_o | dhs | dh | two running-gradient buffers
+    return (size_t)B * (3 * 2 * (size_t)n_features + G + 2 * (size_t)G);
+}
+
+int dpf_gprior_train_forward(int S, int B, int G, int nf, int mode, const int *codes, const float *canon, const float *g, float *gs,
+                             float *mus, float *lvs, float *save_h, float *save_stats, float *workspace, float bn_eps, float eps,
+                             dpf_stream_t stream) {
+    if (!steps_ok(S, B, G, nf, mode, codes) || !canon || !g || !gs || !mus || !lvs || !save_h || !save_stats || !workspace) return DPF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int K = G / 2;
+    const size_t cn = net_floats(K, nf), BG = (size_t)B * G;
+    float *hs = workspace, *o = hs + (size_t)B * 2 * nf;
+    for (int t = 0; t < S; ++t) {
+        const int s = mode ? S - 1 - t : t, code = codes[s];
+        const int kmul = code < 2 ? 2 : 1, kadd = code == 0 ? 1 : code == 2 ? K : 0, wadd = code == 1 ? 1 : code == 3 ? K : 0;
+        const float *cs = canon + (size_t)s * 2 * cn;
+        const float *gin = t == 0 ? g : gs + (size_t)(mode ? s + 1 : s - 1) * BG;
+        float *h = save_h + (size_t)s * B * 2 * nf;
+        Gemm f1 = {B, nf, K, 1, 0, gin + kadd, cs, h, G, kmul, 0, 0, 1, K, (long)cn, 0, 2L * nf, 1, nf};
+        gemm(st, 2, f1);
+        hipLaunchKernelGGL(bn_swish_kernel, dim3((2 * nf + T - 1) / T), dim3(T), 0, st, B, nf, cn, bn_eps, cs + (size_t)nf * K, h,
+                           save_stats + (size_t)s * 4 * nf, hs);
+        const float *w1 = cs + (size_t)nf * K + 4 * nf;
+        Gemm f2 = {B, K, nf, 1, 0, hs, w1, o, 2L * nf, 1, nf, 0, 1, nf, (long)cn, 0, 2L * K, 1, K};
+        gemm(st, 2, f2);
+        hipLaunchKernelGGL(finalize_kernel, dim3((B * K + T - 1) / T), dim3(T), 0, st, B, G, mode, kmul, kadd, wadd, eps, o,
+                           w1 + (size_t)K * nf, w1 + (size_t)K * nf + cn, gin, gs + (size_t)s * BG, mus + (size_t)s * BG,
+                           lvs + (size_t)s * BG);
+    }
+    return (int)hipGetLastError();
+}
+
+int dpf_gprior_train_backward(int S, int B, int G, int nf, int mode, const int *codes, const float *canon, const float *g,
+                              const float *gs, const float *mus, const float *lvs, const float *save_h, const float *save_stats,
+                              const float *d_gs, const float *d_mus, const float *d_lvs, float *dg, float *dcanon, float *workspace,
+                              float bn_eps, float eps, dpf_stream_t stream) {
+    if (!steps_ok(S, B, G, nf, mode, codes) || !canon || !g || !gs || !mus || !lvs || !save_h || !save_stats || !dg || !dcanon || !workspace)
+        return DPF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int K = G / 2;
+    const size_t cn = net_floats(K, nf), BG = (size_t)B * G, BH = (size_t)B * 2 * nf;
+    float *hs = workspace, *d_o = hs + BH, *dhs = d_o + BG, *dh = dhs + BH, *run[2] = {dh + BH, dh + BH + BG};
+    const float *dcur = nullptr;
+    for (int t = S - 1; t >= 0; --t) {                       // the forward's steps, last one first
+        const int s = mode ? S - 1 - t : t, code = codes[s];
+        const int kmul = code < 2 ? 2 : 1, kadd = code == 0 ? 1 : code == 2 ? K : 0, wadd = code == 1 ? 1 : code == 3 ? K : 0;
+        const float *cs = canon + (size_t)s * 2 * cn;
+        float *dcs = dcanon + (size_t)s * 2 * cn;
+        const float *gin = t == 0 ? g : gs + (size_t)(mode ? s + 1 : s - 1) * BG;
+        const float *h = save_h + (size_t)s * BH, *stats = save_stats + (size_t)s * 4 * nf;
+        float *dnext = t == 0 ? dg : run[t & 1];
+        const int n_el = B * K > B * 2 * nf ? B * K : B * 2 * nf;
+        hipLaunchKernelGGL(prep_kernel, dim3((n_el + T - 1) / T), dim3(T), 0, st, B, G, nf, cn, mode, kmul, kadd, wadd, eps, bn_eps, dcur,
+                           d_gs ? d_gs + (size_t)s * BG : nullptr, d_mus ? d_mus + (size_t)s * BG : nullptr,
+                           d_lvs ? d_lvs + (size_t)s * BG : nullptr, gs + (size_t)s * BG, mus + (size_t)s * BG, lvs + (size_t)s * BG, h, stats,
+                           cs + (size_t)nf * K, d_o, dnext, hs);
+        const float *w1 = cs + (size_t)nf * K + 4 * nf;
+        float *dw1 = dcs + (size_t)nf * K + 4 * nf;
+        Gemm g1 = {B, nf, K, 1, 0, d_o, w1, dhs, 2L * K, 1, K, 0, nf, 1, (long)cn, 0, 2L * nf, 1, nf};            // d hs = d_o W1
+        gemm(st, 2, g1);
+        Gemm g2 = {K, nf, B, 1, 0, d_o, hs, dw1, 1, 2L * K, K, 0, 2L * nf, 1, nf, 0, nf, 1, (long)cn};            // d W1 = d_o^T hs
+        gemm(st, 2, g2);
+        const int n_col = 2 * nf > 2 * K ? 2 * nf : 2 * K;
+        hipLaunchKernelGGL(bn_backward_kernel, dim3((n_col + T - 1) / T), dim3(T), 0, st, B, G, nf, cn, bn_eps, cs + (size_t)nf * K, h, stats,
+                           dhs, d_o, dh, dcs + (size_t)nf * K);
+        Gemm g3 = {B, K, nf, 2, 1, dh, cs, dnext + kadd, 2L * nf, 1, 0, nf, K, 1, 0, (long)cn, G, kmul, 0};        // d g_keep += sum_net dh W0
+        gemm(st, 1, g3);
+        Gemm g4 = {nf, K, B, 1, 0, dh, gin + kadd, dcs, 1, 2L * nf, nf, 0, G, kmul, 0, 0, K, 1, (long)cn};        // d W0 = dh^T g_keep
+        gemm(st, 2, g4);
+        dcur = dnext;
+    }
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -5,10 +5,13 @@ lib/networks/decoders.py:7-38), so reference checkpoints load unchanged.
 forward(g, mode):
   * eval mode, CUDA tensors, no autograd (generation / evaluation): the whole stack in ONE HIP launch
     (csrc/gprior.hip through dpf_gprior_forward); the lists come back as views of three (S,B,G) buffers;
-  * training mode or autograd: the tensor-op restatement (`forward_torch`) -- batch-statistics BatchNorm over the B
-    rows and the backward stay tensor ops (B x 64..256 operands).
-The fused kernel knows RealNVPFlowCouple's two index patterns (even/odd, halves) on an even G; a RealNVPFlow with
+  * training mode on CUDA tensors (GlobalRNVPDecoder): BatchNorm on the statistics of the B rows and the whole
+    backward through csrc/gprior_train.hip -- one autograd node, 4 launches per step forward and 7 backward instead
+    of ~75 tensor-op launches; DPF_TRAIN_IMPL=torch selects the tensor-op restatement (`forward_torch`), which is
+    also what CPU tensors, eval mode under autograd and single RealNVPFlow / RealNVPFlowCouple modules get.
+The kernels know RealNVPFlowCouple's two index patterns (even/odd, halves) on an even G; a RealNVPFlow with
 other warp_inds runs as tensor ops."""
+import ctypes
 from collections import OrderedDict
 
 import numpy as np
@@ -176,22 +179,125 @@ class GlobalRNVPDecoder(nn.Module):
     def forward(self, g, mode="direct"):
         if mode not in ("direct", "inverse"):
             raise ValueError(mode)
-        if self.n_flows and _fusable(self, self.__dict__.get("_steps") or self.__dict__.setdefault("_steps", self.coupling_layers()), g):
+        steps = self.__dict__.get("_steps") or self.__dict__.setdefault("_steps", self.coupling_layers())
+        if self.n_flows and _fusable(self, steps, g):
             _, sum_lv, gs, mus, lvs = self.stack().run(g, mode)
             return FlowList(gs), FlowList(mus), FlowList(lvs, sum_lv)
+        from .flows import TRAIN_IMPL
+        if self.n_flows and self.training and g.is_cuda and TRAIN_IMPL == "hip" and g.dtype == torch.float32 and \
+                self.__dict__.get("_patterns_ok", _patterns_ok(self, steps)):
+            return run_training_prior(self, steps, g, mode)
         return self.forward_torch(g, mode)
 
 
-def _fusable(module, layers, g):
-    """Eval mode on a CUDA tensor without autograd, every step one of the kernel's index patterns."""
-    if module.training or not g.is_cuda or _needs_autograd(g):      # as the point decoder: autograd follows the INPUT
-        return False
+def _patterns_ok(module, layers):
     ok = module.__dict__.get("_patterns_ok")
     if ok is None:                                                 # warp_inds are fixed at construction
         G = layers[0].g_n_features
         ok = module.__dict__["_patterns_ok"] = all(
             l.g_n_features == G and l.n_features == layers[0].n_features and pattern_code(l.warp_inds, G) is not None for l in layers)
     return ok
+
+
+def _fusable(module, layers, g):
+    """Eval mode on a CUDA tensor without autograd, every step one of the kernel's index patterns."""
+    if module.training or not g.is_cuda or _needs_autograd(g):      # as the point decoder: autograd follows the INPUT
+        return False
+    return _patterns_ok(module, layers)
+
+
+def _step_params(layers):
+    """Every step's tensors in the canonical order; (parameters, their slots in the canon block, the BatchNorm modules)."""
+    params, slots, bns, off = [], [], [], 0
+    for l in layers:
+        for br in ("mu", "logvar"):
+            net = getattr(l, "T_%s_0" % br)
+            for t in (net[0].weight, net[1].weight, net[1].bias):
+                params.append(t); slots.append((off, t.numel())); off += t.numel()
+            off += 2 * net[1].num_features                             # running_mean | running_var: not parameters
+            for t in (net[3].weight, net[3].bias):
+                params.append(t); slots.append((off, t.numel())); off += t.numel()
+            bns.append(net[1])
+    return params, slots, bns, off
+
+
+class _GPriorTrain(torch.autograd.Function):
+    """The whole training-mode stack as one node: inputs g and every parameter, outputs the three (S,B,G) blocks."""
+
+    @staticmethod
+    def forward(ctx, g, mode, codes, dims, bn_eps, eps, slots, total, *params):
+        S, G, nf = dims
+        B = g.shape[0]
+        L_ = lib()
+        g = g.contiguous()
+        dev = g.device
+        canon = torch.zeros(total, dtype=torch.float32, device=dev)
+        torch._foreach_copy_([canon[o:o + n] for o, n in slots], [p.detach().reshape(-1) for p in params])
+        gs, mus, lvs = (torch.empty((S, B, G), dtype=torch.float32, device=dev) for _ in range(3))
+        save_h = torch.empty((S, B, 2 * nf), dtype=torch.float32, device=dev)
+        stats = torch.empty((S, 2, 2 * nf), dtype=torch.float32, device=dev)
+        ws = torch.empty(L_.dpf_gprior_train_workspace_floats(B, G, nf), dtype=torch.float32, device=dev)
+        check(L_.dpf_gprior_train_forward(S, B, G, nf, MODE[mode], codes, canon.data_ptr(), g.data_ptr(), gs.data_ptr(), mus.data_ptr(),
+                                          lvs.data_ptr(), save_h.data_ptr(), stats.data_ptr(), ws.data_ptr(), bn_eps, eps,
+                                          current_stream()), "gprior_train_forward")
+        ctx.save_for_backward(g, canon, gs, mus, lvs, save_h, stats, *params)
+        ctx.cfg = (mode, codes, dims, bn_eps, eps, slots)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(stats)
+        return gs, mus, lvs, stats
+
+    @staticmethod
+    def backward(ctx, d_gs, d_mus, d_lvs, _):
+        g, canon, gs, mus, lvs, save_h, stats = ctx.saved_tensors[:7]
+        params = ctx.saved_tensors[7:]
+        mode, codes, (S, G, nf), bn_eps, eps, slots = ctx.cfg
+        B = g.shape[0]
+        L_ = lib()
+        dev = g.device
+        dg, dcanon = torch.empty_like(g), torch.empty_like(canon)
+        ws = torch.empty(L_.dpf_gprior_train_workspace_floats(B, G, nf), dtype=torch.float32, device=dev)
+        cg = [t.contiguous() if t is not None else None for t in (d_gs, d_mus, d_lvs)]      # alive across the call
+        with torch.cuda.device(dev):
+            check(L_.dpf_gprior_train_backward(S, B, G, nf, MODE[mode], codes, canon.data_ptr(), g.data_ptr(), gs.data_ptr(),
+                                               mus.data_ptr(), lvs.data_ptr(), save_h.data_ptr(), stats.data_ptr(),
+                                               *[t.data_ptr() if t is not None else None for t in cg],
+                                               dg.data_ptr(), dcanon.data_ptr(), ws.data_ptr(), bn_eps, eps, current_stream()),
+                  "gprior_train_backward")
+        grads = [torch.empty_like(p) for p in params]
+        torch._foreach_copy_(grads, [dcanon[o:o + n].view_as(p) for (o, n), p in zip(slots, params)])
+        return (dg if ctx.needs_input_grad[0] else None, None, None, None, None, None, None, None, *grads)
+
+
+def run_training_prior(module, layers, g, mode):
+    """Training-mode forward of GlobalRNVPDecoder on the HIP path: three python lists of (B,G) tensors in DIRECT order
+    (views of three blocks, attached to autograd); updates the BatchNorm running statistics as nn.BatchNorm1d does."""
+    if g.dim() != 2 or g.shape[1] != layers[0].g_n_features:
+        raise RuntimeError("expected g (B,%d)" % layers[0].g_n_features)
+    if g.shape[0] < 2:
+        raise ValueError("Expected more than 1 value per channel when training")      # as nn.BatchNorm1d
+    cache = module.__dict__.get("_train_plan")
+    if cache is None:
+        params, slots, bns, total = _step_params(layers)
+        S, G, nf = len(layers), layers[0].g_n_features, layers[0].n_features
+        codes = (ctypes.c_int * S)(*[pattern_code(l.warp_inds, G) for l in layers])
+        assert total == S * lib().dpf_gprior_canon_floats(G, nf)
+        cache = module.__dict__["_train_plan"] = (params, slots, bns, total, codes, (S, G, nf), float(layers[0].eps.item()))
+    params, slots, bns, total, codes, dims, eps = cache
+    with torch.cuda.device(g.device):
+        gs, mus, lvs, stats = _GPriorTrain.apply(g, mode, codes, dims, bns[0].eps, eps, slots, total, *params)
+        # running statistics (nn.BatchNorm1d: momentum 0.1, unbiased variance), multi-tensor
+        B, nf = g.shape[0], dims[2]
+        with torch.no_grad():
+            m = bns[0].momentum
+            means = list(stats[:, 0].reshape(-1, nf).unbind(0))
+            uvars = list((stats[:, 1] * (B / (B - 1.0))).reshape(-1, nf).unbind(0))
+            rms, rvs = [b.running_mean for b in bns], [b.running_var for b in bns]
+            torch._foreach_mul_(rms, 1.0 - m)
+            torch._foreach_add_(rms, means, alpha=m)
+            torch._foreach_mul_(rvs, 1.0 - m)
+            torch._foreach_add_(rvs, uvars, alpha=m)
+            torch._foreach_add_([b.num_batches_tracked for b in bns], 1)
+    return list(gs.unbind(0)), list(mus.unbind(0)), list(lvs.unbind(0))
 
 
 class GPriorStack:

@@ -183,3 +183,77 @@ def test_repack_on_weight_change_training_mode_and_loud_failure():
     with pytest.raises(RuntimeError, match="MI355X only"):
         dec.stack().run(g.cpu(), "direct")
     assert len(dec(g[:0])[0]) == 4 and dec(g[:0])[0][0].shape == (0, 12)
+
+
+def _grad_projection(named_grads, seed):
+    from oracle.gen_golden import _grad_projection as gp
+    return gp(named_grads, seed)
+
+
+def test_training_mode_vs_reference_golden(golden_dir):
+    """GlobalRNVPDecoder under train() on CUDA tensors runs csrc/gprior_train.hip (forward with the statistics of the B
+    rows + the whole backward, one autograd node): the three lists, d/dg, every parameter gradient (projections) and the
+    BatchNorm running statistics against the vectors captured from the reference's module."""
+    nets = _gpu()
+    from oracle import detrng
+    from dpf_nets_amd.networks import prior_flows as PF
+    gold = np.load(os.path.join(golden_dir, "gprior.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "gprior.json")))
+    for case, (seed, n_flows, nf, G, B) in meta["cases"].items():
+        if B < 2:
+            continue
+        for mode in ("direct", "inverse"):
+            tag = "%s_train_%s_" % (case, mode)
+            dec = nets.GlobalRNVPDecoder(n_flows, nf, G)
+            dec.load_state_dict(FO.to_torch(GO.make_gprior_state(seed, n_flows, nf, G)), strict=True)
+            dec = dec.cuda().train()
+            g = torch.from_numpy(GO.gprior_inputs(seed, B, G)).cuda().requires_grad_(True)
+            calls = []
+            orig = PF._GPriorTrain.apply
+            PF._GPriorTrain.apply = staticmethod(lambda *a: (calls.append(1), orig(*a))[1])
+            try:
+                lists = dec(g, mode=mode)
+            finally:
+                PF._GPriorTrain.apply = orig
+            assert calls, "the HIP training path was not taken"
+            loss = 0.0
+            for name, lst in zip(("gs", "mus", "lvs"), lists):
+                assert rel(torch.stack(lst), gold[tag + name]) <= TOL, (case, mode, name)
+                r = torch.from_numpy(detrng.normal_f32(detrng.key(seed, "gprior_r_" + name), (len(lst), B, G))).cuda()
+                loss = loss + (torch.stack(lst) * r).sum()
+            loss.backward()
+            assert rel(g.grad, gold[tag + "dg"]) <= 1e-3, (case, mode, rel(g.grad, gold[tag + "dg"]))
+            for k, v in _grad_projection([(k, p.grad.cpu()) for k, p in dec.named_parameters()], seed).items():
+                ref = gold[tag + "gproj_" + k]
+                np.testing.assert_allclose(v, ref, rtol=1e-3, atol=1e-4 * max(1.0, float(ref[2])), err_msg=case + mode + k)
+            for k, v in dec.state_dict().items():
+                if "running" in k:
+                    assert rel(v, gold[tag + "stat_" + k]) <= 1e-5, k
+                if "num_batches" in k:
+                    assert int(v) == 1
+
+
+def test_training_mode_vs_tensor_ops_at_size_and_partial_use():
+    """B=64, G=512 and B=50, G=128 against the tensor-op path on the GPU (same weights, same inputs); a loss that uses
+    only some of the outputs (None gradients for the rest); two steps accumulate gradients."""
+    nets = _gpu()
+    import copy
+    for (n_flows, nf, G, B, mode) in ((7, 128, 512, 64, "inverse"), (7, 128, 128, 50, "direct"), (2, 24, 20, 130, "inverse")):
+        torch.manual_seed(G)
+        hipd = nets.GlobalRNVPDecoder(n_flows, nf, G, weight_std=0.05).cuda().train()
+        tord = copy.deepcopy(hipd)
+        g0 = torch.randn(B, G, device="cuda")
+        outs = []
+        for dec, use_torch in ((hipd, False), (tord, True)):
+            for it in range(2):
+                g = g0.clone().requires_grad_(True)
+                gs, mus, lvs = dec.forward_torch(g, mode) if use_torch else dec(g, mode=mode)
+                first = gs[0] if mode == "inverse" else gs[-1]
+                loss = first.square().mean() + sum(lvs).mean() + (mus[1] * 0.5).sum() * 1e-3
+                loss.backward()
+            outs.append((first.detach(), g.grad, [p.grad for p in dec.parameters()], [b for k, b in dec.state_dict().items() if "running" in k]))
+        (fa, ga, pa, sa), (fb, gb, pb, sb) = outs
+        assert rel(fa, fb) <= TOL and rel(ga, gb) <= 1e-3
+        worst = max(rel(a, b) for a, b in zip(pa, pb) if float(b.abs().max()) > 0)
+        assert worst <= 2e-3, worst
+        assert max(rel(a, b) for a, b in zip(sa, sb)) <= 1e-5
