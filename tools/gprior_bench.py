@@ -47,3 +47,19 @@ for n_flows, nf, G, B in ((7, 128, 128, 32), (7, 128, 128, 64), (7, 128, 512, 64
             tops = timeit(lambda: dec.forward_torch(g, mode), 10)
         print("n_flows=%d nf=%d G=%d B=%d %-7s  fused %.0f us per call (kernel %.1f us)   tensor ops %.0f us" %
               (n_flows, nf, G, B, mode, fused, kern, tops))
+
+# ---- training mode: forward + loss + backward, HIP node vs tensor ops
+for n_flows, nf, G, B in ((7, 128, 128, 32), (7, 128, 512, 64)):
+    torch.manual_seed(0)
+    dec = nets.GlobalRNVPDecoder(n_flows, nf, G, weight_std=0.05).cuda().train()
+    g = torch.randn(B, G, device="cuda")
+
+    def step(fn):
+        dec.zero_grad(set_to_none=True)
+        gin = g.clone().requires_grad_(True)
+        gs, mus, lvs = fn(gin)
+        (gs[0].square().mean() + sum(lvs).mean()).backward()
+
+    hip = timeit(lambda: step(lambda x: dec(x, mode="inverse")), 20)
+    tops = timeit(lambda: step(lambda x: dec.forward_torch(x, "inverse")), 10)
+    print("train n_flows=%d nf=%d G=%d B=%d  forward+backward: HIP node %.0f us   tensor ops %.0f us" % (n_flows, nf, G, B, hip, tops))
