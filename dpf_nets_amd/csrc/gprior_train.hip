@@ -25,75 +25,121 @@ struct Gemm {          // C[m][n] (+)= sum over `nsum` operand pairs, sum over k
     long a_rs, a_cs, a_bs, a_ss, b_rs, b_cs, b_bs, b_ss, c_rs, c_cs, c_bs;
 };
 
+// 32 x 32 tile per workgroup, inner chunks of KC.  The matrices are (B x 64..256): a launch has 16-64 tiles on 256 CUs, so a
+// tile's time is the length of one wave's dependent chain, not throughput -- the four waves of a workgroup each take a
+// quarter of every chunk's inner range (4 x 4 outputs per lane, 16 steps of LDS latency per chunk instead of 64) and
+// add their partial tiles through LDS at the end.  Lanes fetch along whichever index is contiguous in memory (the
+// operands are strided views: weights and their transposes, every other column of the rows, ...).
+constexpr int KC = 64;
 __global__ __launch_bounds__(T) void sgemm_kernel(Gemm g) {
-    __shared__ float As[16][64 + 4], Bs[16][64 + 4];
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64, z = blockIdx.z;
+    __shared__ float smem[2 * KC * 36 > 4 * 32 * 33 ? 2 * KC * 36 : 4 * 32 * 33];
+    float (*As)[36] = (float (*)[36])smem, (*Bs)[36] = (float (*)[36])(smem + KC * 36);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, tx = lane & 7, ty = lane >> 3;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32, z = blockIdx.z;
+    const bool akf = labs(g.a_cs) < labs(g.a_rs), bkf = labs(g.b_rs) < labs(g.b_cs);
+    auto ax = [&](int u) { return akf ? (tid >> 6) + 4 * u : tid & 31; };
+    auto ak = [&](int u) { return akf ? tid & 63 : (tid >> 5) + 8 * u; };
+    auto bx = [&](int u) { return bkf ? (tid >> 6) + 4 * u : tid & 31; };
+    auto bk = [&](int u) { return bkf ? tid & 63 : (tid >> 5) + 8 * u; };
     float acc[4][4] = {};
-    for (int si = 0; si < g.nsum; ++si) {
+    float av[8], bv[8];
+    const int chunks = (g.Kd + KC - 1) / KC, total = g.nsum * chunks;
+    auto fetch = [&](int it) {
+        const int si = it / chunks, k0 = (it - si * chunks) * KC;
         const float *A0 = g.A + z * g.a_bs + si * g.a_ss, *B0 = g.Bm + z * g.b_bs + si * g.b_ss;
-        for (int k0 = 0; k0 < g.Kd; k0 += 16) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = tid + u * T, x = e & 63, k = e >> 6;
-                const bool kin = k0 + k < g.Kd;
-                As[k][x] = kin && m0 + x < g.M ? A0[(long)(m0 + x) * g.a_rs + (long)(k0 + k) * g.a_cs] : 0.f;
-                Bs[k][x] = kin && n0 + x < g.N ? B0[(long)(k0 + k) * g.b_rs + (long)(n0 + x) * g.b_cs] : 0.f;
-            }
-            __syncthreads();
+        for (int u = 0; u < 8; ++u) {
+            const int xa = m0 + ax(u), ka = k0 + ak(u), xb = n0 + bx(u), kb = k0 + bk(u);
+            av[u] = xa < g.M && ka < g.Kd ? A0[(long)xa * g.a_rs + (long)ka * g.a_cs] : 0.f;
+            bv[u] = xb < g.N && kb < g.Kd ? B0[(long)kb * g.b_rs + (long)xb * g.b_cs] : 0.f;
+        }
+    };
+    fetch(0);
+    for (int it = 0; it < total; ++it) {
+        __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const float4 a = *(const float4 *)&As[k][ty * 4], b = *(const float4 *)&Bs[k][tx * 4];
-                const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+        for (int u = 0; u < 8; ++u) {
+            As[ak(u)][ax(u)] = av[u];
+            Bs[bk(u)][bx(u)] = bv[u];
+        }
+        __syncthreads();
+        if (it + 1 < total) fetch(it + 1);                 // in flight while this chunk is multiplied
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+        for (int kk = 0; kk < KC / 4; ++kk) {
+            const int k = wave * (KC / 4) + kk;
+            const float4 a = *(const float4 *)&As[k][ty * 4], b = *(const float4 *)&Bs[k][tx * 4];
+            const float a4[4] = {a.x, a.y, a.z, a.w}, b4[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
-            }
-            __syncthreads();
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a4[i], b4[j], acc[i][j]);
         }
     }
+    __syncthreads();
+    float (*red)[32][33] = (float (*)[32][33])smem;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
-            if (m < g.M && n < g.N) {
-                float *c = g.C + z * g.c_bs + (long)m * g.c_rs + (long)n * g.c_cs;
-                *c = g.accumulate ? *c + acc[i][j] : acc[i][j];
-            }
+        for (int j = 0; j < 4; ++j) red[wave][ty * 4 + i][tx * 4 + j] = acc[i][j];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = tid + u * T, mi = e >> 5, ni = e & 31, m = m0 + mi, n = n0 + ni;
+        if (m < g.M && n < g.N) {
+            const float v = (red[0][mi][ni] + red[1][mi][ni]) + (red[2][mi][ni] + red[3][mi][ni]);
+            float *c = g.C + z * g.c_bs + (long)m * g.c_rs + (long)n * g.c_cs;
+            *c = g.accumulate ? *c + v : v;
         }
+    }
 }
 
 void gemm(hipStream_t s, int batch, Gemm g) {
-    hipLaunchKernelGGL(sgemm_kernel, dim3((g.N + 63) / 64, (g.M + 63) / 64, batch), dim3(T), 0, s, g);
+    hipLaunchKernelGGL(sgemm_kernel, dim3((g.N + 31) / 32, (g.M + 31) / 32, batch), dim3(T), 0, s, g);
 }
 
 __device__ __forceinline__ float swish(float y) { return y / (1.f + expf(-y)); }
 
+// Column kernels: a workgroup owns CW columns; its 256 threads are CW columns x RG row groups, a row group walks
+// every RG-th row and the groups' partial sums meet in LDS (a lone thread per column walking all B rows three times was
+// a chain of dependent loads: 24 us per launch).
+constexpr int CW = 32, RG = T / CW;
+
+__device__ __forceinline__ float column_sum(float v, float (*red)[CW], int cl, int rg) {
+    __syncthreads();                     // the previous use of `red`
+    red[rg][cl] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < RG; ++r) s += red[r][cl];
+    return s;
+}
+
 // Batch statistics over the B rows of every hidden column (two passes, as torch), BatchNorm affine, Swish.
-// h (B, 2 nf) -> stats (2, 2 nf) = mean | biased variance,  hs (B, 2 nf).   cnet = canon of the step (mu net, then logvar net)
+// h (B, 2 nf) -> stats (2, 2 nf) = mean | biased variance,  hs (B, 2 nf).   cnet = gamma of the step's mu net
 __global__ __launch_bounds__(T) void bn_swish_kernel(int B, int nf, size_t cn, float bn_eps, const float *__restrict__ cnet,
                                                      const float *__restrict__ h, float *__restrict__ stats, float *__restrict__ hs) {
-    const int c = blockIdx.x * T + threadIdx.x;
-    if (c >= 2 * nf) return;
+    __shared__ float red[RG][CW];
+    const int cl = threadIdx.x % CW, rg = threadIdx.x / CW, c = blockIdx.x * CW + cl;
+    const bool live = c < 2 * nf;
     const int net = c >= nf, j = c - net * nf;
     float sum = 0.f;
-    for (int b = 0; b < B; ++b) sum += h[(size_t)b * 2 * nf + c];
-    const float mean = sum / B;
+    if (live)
+        for (int b = rg; b < B; b += RG) sum += h[(size_t)b * 2 * nf + c];
+    const float mean = column_sum(sum, red, cl, rg) / B;
     float sq = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const float d = h[(size_t)b * 2 * nf + c] - mean;
-        sq = fmaf(d, d, sq);
-    }
-    const float var = sq / B, rstd = 1.f / sqrtf(var + bn_eps);
-    if (stats) {
+    if (live)
+        for (int b = rg; b < B; b += RG) {
+            const float d = h[(size_t)b * 2 * nf + c] - mean;
+            sq = fmaf(d, d, sq);
+        }
+    const float var = column_sum(sq, red, cl, rg) / B, rstd = 1.f / sqrtf(var + bn_eps);
+    if (!live) return;
+    if (rg == 0) {
         stats[c] = mean;
         stats[2 * nf + c] = var;
     }
-    // gamma / beta sit behind the net's first-map weights: W0 [nf][K] | gamma | beta | ...   (offset passed through cnet)
     const float gam = cnet[net * cn + j], bet = cnet[net * cn + nf + j];
-    for (int b = 0; b < B; ++b) hs[(size_t)b * 2 * nf + c] = swish(fmaf((h[(size_t)b * 2 * nf + c] - mean) * rstd, gam, bet));
+    for (int b = rg; b < B; b += RG) hs[(size_t)b * 2 * nf + c] = swish(fmaf((h[(size_t)b * 2 * nf + c] - mean) * rstd, gam, bet));
 }
 
 // mu, logvar = log(eps + exp(.)) and the affine update of the warped coordinates; the step's slices of the three lists
@@ -146,38 +192,53 @@ __global__ __launch_bounds__(T) void prep_kernel(int B, int G, int nf, size_t cn
 }
 
 // Backward of Swish and of the batch-statistics BatchNorm, per hidden column; d gamma, d beta; and d b1 = column sums of d_o.
+// Workgroups [0, ceil(2nf / CW)) take the hidden columns, the rest the 2K columns of d_o.
 __global__ __launch_bounds__(T) void bn_backward_kernel(int B, int G, int nf, size_t cn, float bn_eps, const float *__restrict__ cnet,
                                                         const float *__restrict__ h, const float *__restrict__ stats,
                                                         const float *__restrict__ dhs, const float *__restrict__ d_o,
                                                         float *__restrict__ dh, float *__restrict__ dcnet) {
-    const int K = G >> 1, c = blockIdx.x * T + threadIdx.x;
-    if (c < 2 * nf) {
+    __shared__ float red[RG][CW];
+    const int K = G >> 1, cl = threadIdx.x % CW, rg = threadIdx.x / CW, hidden_blocks = (2 * nf + CW - 1) / CW;
+    if ((int)blockIdx.x < hidden_blocks) {
+        const int c = blockIdx.x * CW + cl;
+        const bool live = c < 2 * nf;
         const int net = c >= nf, j = c - net * nf;
-        const float mean = stats[c], rstd = 1.f / sqrtf(stats[2 * nf + c] + bn_eps);
-        const float gam = cnet[net * cn + j], bet = cnet[net * cn + nf + j];
+        const float mean = live ? stats[c] : 0.f, rstd = live ? 1.f / sqrtf(stats[2 * nf + c] + bn_eps) : 0.f;
+        const float gam = live ? cnet[net * cn + j] : 0.f, bet = live ? cnet[net * cn + nf + j] : 0.f;
         float s1 = 0.f, s2 = 0.f;
-        for (int b = 0; b < B; ++b) {
-            const float xh = (h[(size_t)b * 2 * nf + c] - mean) * rstd, y = fmaf(xh, gam, bet), sg = 1.f / (1.f + expf(-y));
-            const float dy = dhs[(size_t)b * 2 * nf + c] * (sg * (1.f + y * (1.f - sg)));
-            s1 += dy;
-            s2 = fmaf(dy, xh, s2);
+        if (live)
+            for (int b = rg; b < B; b += RG) {
+                const float xh = (h[(size_t)b * 2 * nf + c] - mean) * rstd, y = fmaf(xh, gam, bet), sg = 1.f / (1.f + expf(-y));
+                const float dy = dhs[(size_t)b * 2 * nf + c] * (sg * (1.f + y * (1.f - sg)));
+                s1 += dy;
+                s2 = fmaf(dy, xh, s2);
+            }
+        s1 = column_sum(s1, red, cl, rg);
+        s2 = column_sum(s2, red, cl, rg);
+        if (!live) return;
+        if (rg == 0) {
+            dcnet[net * cn + j] = s2;                  // d gamma
+            dcnet[net * cn + nf + j] = s1;             // d beta
+            dcnet[net * cn + 2 * nf + j] = 0.f;        // running statistics carry no gradient
+            dcnet[net * cn + 3 * nf + j] = 0.f;
         }
-        dcnet[net * cn + j] = s2;                  // d gamma
-        dcnet[net * cn + nf + j] = s1;             // d beta
-        dcnet[net * cn + 2 * nf + j] = 0.f;        // running statistics carry no gradient
-        dcnet[net * cn + 3 * nf + j] = 0.f;
         const float m1 = s1 / B, m2 = s2 / B;
-        for (int b = 0; b < B; ++b) {
+        for (int b = rg; b < B; b += RG) {
             const float xh = (h[(size_t)b * 2 * nf + c] - mean) * rstd, y = fmaf(xh, gam, bet), sg = 1.f / (1.f + expf(-y));
             const float dy = dhs[(size_t)b * 2 * nf + c] * (sg * (1.f + y * (1.f - sg)));
             dh[(size_t)b * 2 * nf + c] = gam * rstd * (dy - m1 - xh * m2);
         }
-    }
-    if (c < 2 * K) {
-        const int net = c >= K, i = c - net * K;
-        float s = 0.f;
-        for (int b = 0; b < B; ++b) s += d_o[(size_t)b * 2 * K + c];
-        dcnet[net * cn + 4 * (size_t)nf + (size_t)K * nf + i] = s;      // d b1: behind the four BatchNorm vectors and W1 (dcnet starts at gamma)
+    } else {
+        const int c = (blockIdx.x - hidden_blocks) * CW + cl;
+        const bool live = c < 2 * K;
+        float sm = 0.f;
+        if (live)
+            for (int b = rg; b < B; b += RG) sm += d_o[(size_t)b * 2 * K + c];
+        sm = column_sum(sm, red, cl, rg);
+        if (live && rg == 0) {
+            const int net = c >= K, i = c - net * K;
+            dcnet[net * cn + 4 * (size_t)nf + (size_t)K * nf + i] = sm;      // d b1: behind the four BatchNorm vectors and W1 (dcnet starts at gamma)
+        }
     }
 }
 
@@ -213,7 +274,7 @@ int dpf_gprior_train_forward(int S, int B, int G, int nf, int mode, const int *c
         float *h = save_h + (size_t)s * B * 2 * nf;
         Gemm f1 = {B, nf, K, 1, 0, gin + kadd, cs, h, G, kmul, 0, 0, 1, K, (long)cn, 0, 2L * nf, 1, nf};
         gemm(st, 2, f1);
-        hipLaunchKernelGGL(bn_swish_kernel, dim3((2 * nf + T - 1) / T), dim3(T), 0, st, B, nf, cn, bn_eps, cs + (size_t)nf * K, h,
+        hipLaunchKernelGGL(bn_swish_kernel, dim3((2 * nf + CW - 1) / CW), dim3(T), 0, st, B, nf, cn, bn_eps, cs + (size_t)nf * K, h,
                            save_stats + (size_t)s * 4 * nf, hs);
         const float *w1 = cs + (size_t)nf * K + 4 * nf;
         Gemm f2 = {B, K, nf, 1, 0, hs, w1, o, 2L * nf, 1, nf, 0, 1, nf, (long)cn, 0, 2L * K, 1, K};
@@ -255,8 +316,7 @@ int dpf_gprior_train_backward(int S, int B, int G, int nf, int mode, const int *
         gemm(st, 2, g1);
         Gemm g2 = {K, nf, B, 1, 0, d_o, hs, dw1, 1, 2L * K, K, 0, 2L * nf, 1, nf, 0, nf, 1, (long)cn};            // d W1 = d_o^T hs
         gemm(st, 2, g2);
-        const int n_col = 2 * nf > 2 * K ? 2 * nf : 2 * K;
-        hipLaunchKernelGGL(bn_backward_kernel, dim3((n_col + T - 1) / T), dim3(T), 0, st, B, G, nf, cn, bn_eps, cs + (size_t)nf * K, h, stats,
+        hipLaunchKernelGGL(bn_backward_kernel, dim3((2 * nf + CW - 1) / CW + (2 * K + CW - 1) / CW), dim3(T), 0, st, B, G, nf, cn, bn_eps, cs + (size_t)nf * K, h, stats,
                            dhs, d_o, dh, dcs + (size_t)nf * K);
         Gemm g3 = {B, K, nf, 2, 1, dh, cs, dnext + kadd, 2L * nf, 1, 0, nf, K, 1, 0, (long)cn, G, kmul, 0};        // d g_keep += sum_net dh W0
         gemm(st, 1, g3);
