@@ -3,7 +3,7 @@
 //
 // The operands are (B x 64..256) matrices: as tensor ops a step is ~25 launches forward and ~50 backward, and the
 // 14 steps of a training iteration cost ~12 ms of launch latency -- more than the whole point decoder.  Here a step
-// is 4 launches forward and 7 backward, issued back to back by one C call: small fp32 GEMMs through one strided
+// is 4 launches forward and 5 backward, issued back to back by one C call: small fp32 GEMMs through one strided
 // LDS-tiled kernel (the kept / warped coordinate sets are strides, not gathers; both nets of a step are one batched
 // launch) and four fused element / column kernels (batch statistics + Swish, the affine update, their backwards).
 // fp32 FMAs throughout: these matrices are launch-latency-, not throughput-bound, and the tolerance is fp32's.
@@ -31,11 +31,19 @@ struct Gemm {          // C[m][n] (+)= sum over `nsum` operand pairs, sum over k
 // add their partial tiles through LDS at the end.  Lanes fetch along whichever index is contiguous in memory (the
 // operands are strided views: weights and their transposes, every other column of the rows, ...).
 constexpr int KC = 64;
-__global__ __launch_bounds__(T) void sgemm_kernel(Gemm g) {
+struct Gemm2 {          // two independent products in one launch: blockIdx.z < batch0 is a batch index of the first, the rest of the second
+    Gemm p[2];
+    int batch0;
+};
+
+__global__ __launch_bounds__(T) void sgemm_kernel(Gemm2 gg) {
+    const int prob = (int)blockIdx.z >= gg.batch0;
+    const Gemm &g = gg.p[prob];
+    if ((int)blockIdx.x * 32 >= g.N || (int)blockIdx.y * 32 >= g.M) return;          // the grid covers the larger of the two
     __shared__ float smem[2 * KC * 36 > 4 * 32 * 33 ? 2 * KC * 36 : 4 * 32 * 33];
     float (*As)[36] = (float (*)[36])smem, (*Bs)[36] = (float (*)[36])(smem + KC * 36);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, tx = lane & 7, ty = lane >> 3;
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32, z = blockIdx.z;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32, z = blockIdx.z - prob * gg.batch0;
     const bool akf = labs(g.a_cs) < labs(g.a_rs), bkf = labs(g.b_rs) < labs(g.b_cs);
     auto ax = [&](int u) { return akf ? (tid >> 6) + 4 * u : tid & 31; };
     auto ak = [&](int u) { return akf ? tid & 63 : (tid >> 5) + 8 * u; };
@@ -94,7 +102,14 @@ __global__ __launch_bounds__(T) void sgemm_kernel(Gemm g) {
 }
 
 void gemm(hipStream_t s, int batch, Gemm g) {
-    hipLaunchKernelGGL(sgemm_kernel, dim3((g.N + 31) / 32, (g.M + 31) / 32, batch), dim3(T), 0, s, g);
+    Gemm2 gg = {{g, g}, batch};
+    hipLaunchKernelGGL(sgemm_kernel, dim3((g.N + 31) / 32, (g.M + 31) / 32, batch), dim3(T), 0, s, gg);
+}
+
+void gemm2(hipStream_t s, int batch_a, Gemm a, int batch_b, Gemm b) {
+    Gemm2 gg = {{a, b}, batch_a};
+    const int nx = ((a.N > b.N ? a.N : b.N) + 31) / 32, ny = ((a.M > b.M ? a.M : b.M) + 31) / 32;
+    hipLaunchKernelGGL(sgemm_kernel, dim3(nx, ny, batch_a + batch_b), dim3(T), 0, s, gg);
 }
 
 __device__ __forceinline__ float swish(float y) { return y / (1.f + expf(-y)); }
@@ -313,15 +328,13 @@ int dpf_gprior_train_backward(int S, int B, int G, int nf, int mode, const int *
         const float *w1 = cs + (size_t)nf * K + 4 * nf;
         float *dw1 = dcs + (size_t)nf * K + 4 * nf;
         Gemm g1 = {B, nf, K, 1, 0, d_o, w1, dhs, 2L * K, 1, K, 0, nf, 1, (long)cn, 0, 2L * nf, 1, nf};            // d hs = d_o W1
-        gemm(st, 2, g1);
         Gemm g2 = {K, nf, B, 1, 0, d_o, hs, dw1, 1, 2L * K, K, 0, 2L * nf, 1, nf, 0, nf, 1, (long)cn};            // d W1 = d_o^T hs
-        gemm(st, 2, g2);
+        gemm2(st, 2, g1, 2, g2);                                                                                      // independent: one launch
         hipLaunchKernelGGL(bn_backward_kernel, dim3((2 * nf + CW - 1) / CW + (2 * K + CW - 1) / CW), dim3(T), 0, st, B, G, nf, cn, bn_eps, cs + (size_t)nf * K, h, stats,
                            dhs, d_o, dh, dcs + (size_t)nf * K);
         Gemm g3 = {B, K, nf, 2, 1, dh, cs, dnext + kadd, 2L * nf, 1, 0, nf, K, 1, 0, (long)cn, G, kmul, 0};        // d g_keep += sum_net dh W0
-        gemm(st, 1, g3);
         Gemm g4 = {nf, K, B, 1, 0, dh, gin + kadd, dcs, 1, 2L * nf, nf, 0, G, kmul, 0, 0, K, 1, (long)cn};        // d W0 = dh^T g_keep
-        gemm(st, 2, g4);
+        gemm2(st, 1, g3, 2, g4);                                                                                   // independent: one launch
         dcur = dnext;
     }
     return (int)hipGetLastError();

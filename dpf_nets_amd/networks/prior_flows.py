@@ -6,7 +6,7 @@ forward(g, mode):
   * eval mode, CUDA tensors, no autograd (generation / evaluation): the whole stack in ONE HIP launch
     (csrc/gprior.hip through dpf_gprior_forward); the lists come back as views of three (S,B,G) buffers;
   * training mode on CUDA tensors (GlobalRNVPDecoder): BatchNorm on the statistics of the B rows and the whole
-    backward through csrc/gprior_train.hip -- one autograd node, 4 launches per step forward and 7 backward instead
+    backward through csrc/gprior_train.hip -- one autograd node, 4 launches per step forward and 5 backward instead
     of ~75 tensor-op launches; DPF_TRAIN_IMPL=torch selects the tensor-op restatement (`forward_torch`), which is
     also what CPU tensors, eval mode under autograd and single RealNVPFlow / RealNVPFlowCouple modules get.
 The kernels know RealNVPFlowCouple's two index patterns (even/odd, halves) on an even G; a RealNVPFlow with

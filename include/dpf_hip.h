@@ -352,7 +352,7 @@ int dpf_gprior_forward(int n_steps, int B, int G, int n_features, int mode, cons
 
 /* ---- latent prior flow, TRAINING mode (BatchNorm1d on the statistics of the B rows) -----------
  * replaces GlobalRNVPDecoder.forward under model.train() (decoders.py:21-38, flows.py:198-213)
- * and the backward autograd derives from it; 4 launches per step forward, 7 backward, all issued
+ * and the backward autograd derives from it; 4 launches per step forward, 5 backward, all issued
  * by the one call.  canon: the UNPACKED canonical block of dpf_gprior_pack (the running statistics
  * in it are not read); codes, mode, eps as dpf_gprior_forward; B >= 2.
  * forward: g (B,G) -> gs, mus, lvs (S,B,G) DIRECT order, all required; save_h (S,B,2*n_features)

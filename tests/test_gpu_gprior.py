@@ -233,6 +233,22 @@ def test_training_mode_vs_reference_golden(golden_dir):
                     assert int(v) == 1
 
 
+def test_training_c_abi_rejects_bad_arguments():
+    _gpu()
+    from dpf_nets_amd._lib import lib
+    L = lib()
+    codes = (ctypes.c_int * 2)(0, 1)
+    t = torch.zeros(4096, device="cuda")
+    p = t.data_ptr()
+    assert L.dpf_gprior_train_workspace_floats(4, 8, 16) == 4 * (3 * 32 + 24)
+    # a single row has no batch statistics; odd G; unknown step code; missing buffers
+    assert L.dpf_gprior_train_forward(2, 1, 8, 16, 0, codes, p, p, p, p, p, p, p, p, 1e-5, 1e-6, None) == -1
+    assert L.dpf_gprior_train_forward(2, 4, 7, 16, 0, codes, p, p, p, p, p, p, p, p, 1e-5, 1e-6, None) == -1
+    assert L.dpf_gprior_train_forward(2, 4, 8, 16, 0, (ctypes.c_int * 2)(0, 4), p, p, p, p, p, p, p, p, 1e-5, 1e-6, None) == -1
+    assert L.dpf_gprior_train_forward(2, 4, 8, 16, 0, codes, p, p, p, p, p, None, p, p, 1e-5, 1e-6, None) == -1
+    assert L.dpf_gprior_train_backward(2, 4, 8, 16, 0, codes, p, p, p, p, p, p, p, None, None, None, None, p, p, 1e-5, 1e-6, None) == -1
+
+
 def test_training_mode_vs_tensor_ops_at_size_and_partial_use():
     """B=64, G=512 and B=50, G=128 against the tensor-op path on the GPU (same weights, same inputs); a loss that uses
     only some of the outputs (None gradients for the rest); two steps accumulate gradients."""
