@@ -39,7 +39,31 @@ def pattern_code(warp_inds, G):
     return None
 
 
-class RealNVPFlow(nn.Module):
+class _PackedWeights:
+    """Mixin: the packed eval-mode weights are rebuilt after anything that may have changed the parameters behind the
+    version counters' back -- optimizers update through `.data` -- i.e. on every train()/eval() switch, load_state_dict,
+    .to()/.cuda()/.float(); in between, the stack's sentinels catch ordinary in-place edits."""
+
+    def invalidate_packed(self):
+        st = self.__dict__.get("_stack")
+        if st is not None:
+            st.invalidate()
+
+    def train(self, mode=True):
+        if mode != self.training:
+            self.invalidate_packed()
+        return super().train(mode)
+
+    def _apply(self, fn, *a, **kw):
+        self.invalidate_packed()
+        return super()._apply(fn, *a, **kw)
+
+    def _load_from_state_dict(self, *a, **kw):
+        self.invalidate_packed()
+        return super()._load_from_state_dict(*a, **kw)
+
+
+class RealNVPFlow(_PackedWeights, nn.Module):
     def __init__(self, n_features, g_n_features, weight_std=0.01, warp_inds=[0], eps=1e-6):
         super().__init__()
         self.n_features = n_features
@@ -94,7 +118,7 @@ class RealNVPFlow(nn.Module):
         return self.forward_torch(g, mode)
 
 
-class RealNVPFlowCouple(nn.Module):
+class RealNVPFlowCouple(_PackedWeights, nn.Module):
     def __init__(self, n_features, g_n_features, weight_std=0.01, pattern=0):
         super().__init__()
         self.n_features = n_features
@@ -136,7 +160,7 @@ class RealNVPFlowCouple(nn.Module):
         return self.forward_torch(g, mode)
 
 
-class GlobalRNVPDecoder(nn.Module):
+class GlobalRNVPDecoder(_PackedWeights, nn.Module):
     def __init__(self, n_flows, n_features, g_n_features, weight_std=0.01):
         super().__init__()
         self.n_flows = n_flows
@@ -157,11 +181,6 @@ class GlobalRNVPDecoder(nn.Module):
         if self.__dict__.get("_stack") is None:
             self.__dict__["_stack"] = GPriorStack(self.coupling_layers())
         return self._stack
-
-    def invalidate_packed(self):
-        """Call after changing weights through views the version counters do not see."""
-        if self.__dict__.get("_stack") is not None:
-            self._stack.invalidate()
 
     def forward_torch(self, g, mode="direct"):                  # decoders.py:21-38
         gs, mus, lvs = [], [], []

@@ -273,3 +273,24 @@ def test_training_mode_vs_tensor_ops_at_size_and_partial_use():
         worst = max(rel(a, b) for a, b in zip(pa, pb) if float(b.abs().max()) > 0)
         assert worst <= 2e-3, worst
         assert max(rel(a, b) for a, b in zip(sa, sb)) <= 1e-5
+
+
+def test_eval_after_optimizer_steps_uses_the_new_weights():
+    """The reference's loop (training.py:54-56 then evaluate): optimizers write through `.data`, which no version counter
+    sees -- the train()/eval() switch is what invalidates the packed weights."""
+    nets = _gpu()
+    dec = _decoder(nets, 11, 2, 16, 12)
+    g = torch.from_numpy(GO.gprior_inputs(11, 6, 12)).cuda()
+    before = dec(g)[0][-1].clone()
+    opt = nets.Adam(dec.parameters(), lr=5e-2, weight_decay=0.0, betas=(0.9, 0.999), amsgrad=True)
+    dec.train()
+    for _ in range(3):
+        opt.zero_grad()
+        gs, mus, lvs = dec(g, mode="inverse")
+        (gs[0].square().mean() + sum(lvs).mean()).backward()
+        opt.step()
+    dec.eval()
+    after = dec(g)[0][-1]
+    with torch.no_grad():
+        ref = dec.forward_torch(g)[0][-1]
+    assert rel(after, ref) <= TOL and not torch.allclose(before, after)
