@@ -63,8 +63,8 @@ SIGNATURES = {
     "dpf_gprior_pack": (_i, [_i, _i, _i, _f, _vp, _vp, _vp]),
     "dpf_gprior_forward": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp]),
     "dpf_gprior_train_workspace_floats": (_sz, [_i, _i, _i]),
-    "dpf_gprior_train_forward": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp]),
-    "dpf_gprior_train_backward": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+    "dpf_gprior_train_forward": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp]),
+    "dpf_gprior_train_backward": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _f, _f, _vp]),
     "dpf_version": (ctypes.c_char_p, []),
 }

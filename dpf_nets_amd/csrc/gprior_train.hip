@@ -16,7 +16,9 @@ namespace {
 
 constexpr int T = 256;
 
-inline size_t net_floats(int K, int nf) { return (size_t)2 * nf * K + 4 * (size_t)nf + K; }     // canon floats of one net
+// floats of one net in the canonical block: W0 | gamma | beta | [running_mean | running_var] | W1 | b1  (nbn = 4 with the
+// running-statistics slots of dpf_gprior_pack's layout, 2 in the parameters-only layout)
+inline size_t net_floats(int K, int nf, int nbn) { return (size_t)2 * nf * K + (size_t)nbn * nf + K; }
 
 struct Gemm {          // C[m][n] (+)= sum over `nsum` operand pairs, sum over k:  A[m][k] * Bm[k][n]     (blockIdx.z = batch)
     int M, N, Kd, nsum, accumulate;
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(T) void prep_kernel(int B, int G, int nf, size_t cn
 
 // Backward of Swish and of the batch-statistics BatchNorm, per hidden column; d gamma, d beta; and d b1 = column sums of d_o.
 // Workgroups [0, ceil(2nf / CW)) take the hidden columns, the rest the 2K columns of d_o.
-__global__ __launch_bounds__(T) void bn_backward_kernel(int B, int G, int nf, size_t cn, float bn_eps, const float *__restrict__ cnet,
+__global__ __launch_bounds__(T) void bn_backward_kernel(int B, int G, int nf, size_t cn, int nbn, float bn_eps, const float *__restrict__ cnet,
                                                         const float *__restrict__ h, const float *__restrict__ stats,
                                                         const float *__restrict__ dhs, const float *__restrict__ d_o,
                                                         float *__restrict__ dh, float *__restrict__ dcnet) {
@@ -234,8 +236,10 @@ __global__ __launch_bounds__(T) void bn_backward_kernel(int B, int G, int nf, si
         if (rg == 0) {
             dcnet[net * cn + j] = s2;                  // d gamma
             dcnet[net * cn + nf + j] = s1;             // d beta
-            dcnet[net * cn + 2 * nf + j] = 0.f;        // running statistics carry no gradient
-            dcnet[net * cn + 3 * nf + j] = 0.f;
+            if (nbn == 4) {
+                dcnet[net * cn + 2 * nf + j] = 0.f;    // running statistics carry no gradient
+                dcnet[net * cn + 3 * nf + j] = 0.f;
+            }
         }
         const float m1 = s1 / B, m2 = s2 / B;
         for (int b = rg; b < B; b += RG) {
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(T) void bn_backward_kernel(int B, int G, int nf, si
         sm = column_sum(sm, red, cl, rg);
         if (live && rg == 0) {
             const int net = c >= K, i = c - net * K;
-            dcnet[net * cn + 4 * (size_t)nf + (size_t)K * nf + i] = sm;      // d b1: behind the four BatchNorm vectors and W1 (dcnet starts at gamma)
+            dcnet[net * cn + (size_t)nbn * nf + (size_t)K * nf + i] = sm;      // d b1: behind the BatchNorm vectors and W1 (dcnet starts at gamma)
         }
     }
 }
@@ -273,13 +277,14 @@ size_t dpf_gprior_train_workspace_floats(int B, int G, int n_features) {
     return (size_t)B * (3 * 2 * (size_t)n_features + G + 2 * (size_t)G);
 }
 
-int dpf_gprior_train_forward(int S, int B, int G, int nf, int mode, const int *codes, const float *canon, const float *g, float *gs,
+int dpf_gprior_train_forward(int S, int B, int G, int nf, int mode, const int *codes, int params_only, const float *canon, const float *g, float *gs,
                              float *mus, float *lvs, float *save_h, float *save_stats, float *workspace, float bn_eps, float eps,
                              dpf_stream_t stream) {
     if (!steps_ok(S, B, G, nf, mode, codes) || !canon || !g || !gs || !mus || !lvs || !save_h || !save_stats || !workspace) return DPF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int K = G / 2;
-    const size_t cn = net_floats(K, nf), BG = (size_t)B * G;
+    const int nbn = params_only ? 2 : 4;
+    const size_t cn = net_floats(K, nf, nbn), BG = (size_t)B * G;
     float *hs = workspace, *o = hs + (size_t)B * 2 * nf;
     for (int t = 0; t < S; ++t) {
         const int s = mode ? S - 1 - t : t, code = codes[s];
@@ -291,7 +296,7 @@ int dpf_gprior_train_forward(int S, int B, int G, int nf, int mode, const int *c
         gemm(st, 2, f1);
         hipLaunchKernelGGL(bn_swish_kernel, dim3((2 * nf + CW - 1) / CW), dim3(T), 0, st, B, nf, cn, bn_eps, cs + (size_t)nf * K, h,
                            save_stats + (size_t)s * 4 * nf, hs);
-        const float *w1 = cs + (size_t)nf * K + 4 * nf;
+        const float *w1 = cs + (size_t)nf * K + (size_t)nbn * nf;
         Gemm f2 = {B, K, nf, 1, 0, hs, w1, o, 2L * nf, 1, nf, 0, 1, nf, (long)cn, 0, 2L * K, 1, K};
         gemm(st, 2, f2);
         hipLaunchKernelGGL(finalize_kernel, dim3((B * K + T - 1) / T), dim3(T), 0, st, B, G, mode, kmul, kadd, wadd, eps, o,
@@ -301,7 +306,7 @@ int dpf_gprior_train_forward(int S, int B, int G, int nf, int mode, const int *c
     return (int)hipGetLastError();
 }
 
-int dpf_gprior_train_backward(int S, int B, int G, int nf, int mode, const int *codes, const float *canon, const float *g,
+int dpf_gprior_train_backward(int S, int B, int G, int nf, int mode, const int *codes, int params_only, const float *canon, const float *g,
                               const float *gs, const float *mus, const float *lvs, const float *save_h, const float *save_stats,
                               const float *d_gs, const float *d_mus, const float *d_lvs, float *dg, float *dcanon, float *workspace,
                               float bn_eps, float eps, dpf_stream_t stream) {
@@ -309,7 +314,8 @@ int dpf_gprior_train_backward(int S, int B, int G, int nf, int mode, const int *
         return DPF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int K = G / 2;
-    const size_t cn = net_floats(K, nf), BG = (size_t)B * G, BH = (size_t)B * 2 * nf;
+    const int nbn = params_only ? 2 : 4;
+    const size_t cn = net_floats(K, nf, nbn), BG = (size_t)B * G, BH = (size_t)B * 2 * nf;
     float *hs = workspace, *d_o = hs + BH, *dhs = d_o + BG, *dh = dhs + BH, *run[2] = {dh + BH, dh + BH + BG};
     const float *dcur = nullptr;
     for (int t = S - 1; t >= 0; --t) {                       // the forward's steps, last one first
@@ -325,12 +331,12 @@ int dpf_gprior_train_backward(int S, int B, int G, int nf, int mode, const int *
                            d_gs ? d_gs + (size_t)s * BG : nullptr, d_mus ? d_mus + (size_t)s * BG : nullptr,
                            d_lvs ? d_lvs + (size_t)s * BG : nullptr, gs + (size_t)s * BG, mus + (size_t)s * BG, lvs + (size_t)s * BG, h, stats,
                            cs + (size_t)nf * K, d_o, dnext, hs);
-        const float *w1 = cs + (size_t)nf * K + 4 * nf;
-        float *dw1 = dcs + (size_t)nf * K + 4 * nf;
+        const float *w1 = cs + (size_t)nf * K + (size_t)nbn * nf;
+        float *dw1 = dcs + (size_t)nf * K + (size_t)nbn * nf;
         Gemm g1 = {B, nf, K, 1, 0, d_o, w1, dhs, 2L * K, 1, K, 0, nf, 1, (long)cn, 0, 2L * nf, 1, nf};            // d hs = d_o W1
         Gemm g2 = {K, nf, B, 1, 0, d_o, hs, dw1, 1, 2L * K, K, 0, 2L * nf, 1, nf, 0, nf, 1, (long)cn};            // d W1 = d_o^T hs
         gemm2(st, 2, g1, 2, g2);                                                                                      // independent: one launch
-        hipLaunchKernelGGL(bn_backward_kernel, dim3((2 * nf + CW - 1) / CW + (2 * K + CW - 1) / CW), dim3(T), 0, st, B, G, nf, cn, bn_eps, cs + (size_t)nf * K, h, stats,
+        hipLaunchKernelGGL(bn_backward_kernel, dim3((2 * nf + CW - 1) / CW + (2 * K + CW - 1) / CW), dim3(T), 0, st, B, G, nf, cn, nbn, bn_eps, cs + (size_t)nf * K, h, stats,
                            dhs, d_o, dh, dcs + (size_t)nf * K);
         Gemm g3 = {B, K, nf, 2, 1, dh, cs, dnext + kadd, 2L * nf, 1, 0, nf, K, 1, 0, (long)cn, G, kmul, 0};        // d g_keep += sum_net dh W0
         Gemm g4 = {nf, K, B, 1, 0, dh, gin + kadd, dcs, 1, 2L * nf, nf, 0, G, kmul, 0, 0, K, 1, (long)cn};        // d W0 = dh^T g_keep

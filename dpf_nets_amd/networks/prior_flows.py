@@ -182,6 +182,20 @@ class GlobalRNVPDecoder(_PackedWeights, nn.Module):
             self.__dict__["_stack"] = GPriorStack(self.coupling_layers())
         return self._stack
 
+    def flatten_parameters(self):
+        """Opt in to the flat parameter store (see PriorFlatStore); returns it.  Call after .cuda()."""
+        _adopt_flatstore_methods()
+        steps = self.coupling_layers()
+        dev = next(self.parameters()).device
+        store = self.__dict__.get("_flat")
+        if store is None or not store.attached():
+            store = self.__dict__["_flat"] = PriorFlatStore(steps, dev)
+        return store
+
+    def flat_store(self):
+        store = self.__dict__.get("_flat")
+        return store if store is not None and store.attached() else None
+
     def forward_torch(self, g, mode="direct"):                  # decoders.py:21-38
         gs, mus, lvs = [], [], []
         for i in range(self.n_flows):
@@ -240,6 +254,104 @@ def _step_params(layers):
     return params, slots, bns, off
 
 
+def _train_forward(g, canon, params_only, mode, codes, dims, bn_eps, eps):
+    S, G, nf = dims
+    B, dev, L_ = g.shape[0], g.device, lib()
+    gs, mus, lvs = (torch.empty((S, B, G), dtype=torch.float32, device=dev) for _ in range(3))
+    save_h = torch.empty((S, B, 2 * nf), dtype=torch.float32, device=dev)
+    stats = torch.empty((S, 2, 2 * nf), dtype=torch.float32, device=dev)
+    ws = torch.empty(L_.dpf_gprior_train_workspace_floats(B, G, nf), dtype=torch.float32, device=dev)
+    check(L_.dpf_gprior_train_forward(S, B, G, nf, MODE[mode], codes, params_only, canon.data_ptr(), g.data_ptr(), gs.data_ptr(),
+                                      mus.data_ptr(), lvs.data_ptr(), save_h.data_ptr(), stats.data_ptr(), ws.data_ptr(), bn_eps, eps,
+                                      current_stream()), "gprior_train_forward")
+    return gs, mus, lvs, save_h, stats
+
+
+def _train_backward(g, canon, params_only, gs, mus, lvs, save_h, stats, dlists, mode, codes, dims, bn_eps, eps):
+    S, G, nf = dims
+    B, dev, L_ = g.shape[0], g.device, lib()
+    dg, dcanon = torch.empty_like(g), torch.empty_like(canon)
+    ws = torch.empty(L_.dpf_gprior_train_workspace_floats(B, G, nf), dtype=torch.float32, device=dev)
+    cg = [t.contiguous() if t is not None else None for t in dlists]                   # alive across the call
+    with torch.cuda.device(dev):
+        check(L_.dpf_gprior_train_backward(S, B, G, nf, MODE[mode], codes, params_only, canon.data_ptr(), g.data_ptr(), gs.data_ptr(),
+                                           mus.data_ptr(), lvs.data_ptr(), save_h.data_ptr(), stats.data_ptr(),
+                                           *[t.data_ptr() if t is not None else None for t in cg],
+                                           dg.data_ptr(), dcanon.data_ptr(), ws.data_ptr(), bn_eps, eps, current_stream()),
+              "gprior_train_backward")
+    return dg, dcanon
+
+
+class PriorFlatStore:
+    """All parameters of a GlobalRNVPDecoder in ONE buffer laid out exactly as the training kernels read them (the
+    parameters-only canonical block of include/dpf_hip.h) and their gradients in its twin -- the counterpart of
+    train_engine.FlatStore for the latent prior flow.  Every nn.Parameter keeps its identity, name and shape; its `.data`
+    becomes a view of `flat_p`, its `.grad` a view of `flat_g`.  The forward then needs no gather, the backward adds its
+    gradient block with one op instead of feeding 10 tensors per step to AccumulateGrad nodes, networks.optimizers.Adam
+    updates the whole store with one op sequence, and the data-parallel exchange is one all-reduce
+    (distributed.allreduce_flat_gradients).  As with FlatStore, per-parameter autograd hooks do not fire."""
+
+    def __init__(self, layers, dev):
+        params, slots, off = [], [], 0
+        for l in layers:
+            for br in ("mu", "logvar"):
+                net = getattr(l, "T_%s_0" % br)
+                for t in (net[0].weight, net[1].weight, net[1].bias, net[3].weight, net[3].bias):
+                    params.append(t); slots.append((off, t.numel())); off += t.numel()
+        self.params, self.total = params, off
+        self.flat_p = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros_like(self.flat_p)
+        with torch.no_grad():
+            torch._foreach_copy_([self.flat_p[o:o + n] for o, n in slots], [t.detach().reshape(-1).to(dev) for t in params])
+        self.pviews = [self.flat_p[o:o + n].view(t.shape) for (o, n), t in zip(slots, params)]
+        self.gviews = [self.flat_g[o:o + n].view(t.shape) for (o, n), t in zip(slots, params)]
+        for t, pv, gv in zip(params, self.pviews, self.gviews):
+            if t.grad is not None:
+                gv.copy_(t.grad)
+            t.data = pv
+            t.grad = gv
+            t._dpf_flat = self
+        self.token = torch.zeros(1, dtype=torch.float32, device=dev, requires_grad=True)
+
+    def attached(self):
+        a, b = self.params[0], self.params[-1]
+        return a.data_ptr() == self.pviews[0].data_ptr() and b.data_ptr() == self.pviews[-1].data_ptr() and a.device == self.flat_p.device
+
+    def accumulate(self, dcanon):
+        self.attach_grads()
+        self.flat_g.add_(dcanon)
+
+
+def _adopt_flatstore_methods():
+    from .train_engine import FlatStore
+    PriorFlatStore.attach_grads = FlatStore.attach_grads          # same bookkeeping over params / gviews / flat_g
+    PriorFlatStore.zero_grad = FlatStore.zero_grad
+
+
+class _GPriorTrainFlat(torch.autograd.Function):
+    """The training-mode stack over a PriorFlatStore: autograd sees g and a token; parameter gradients go straight to flat_g."""
+
+    @staticmethod
+    def forward(ctx, g, token, store, mode, codes, dims, bn_eps, eps):
+        g = g.contiguous()
+        gs, mus, lvs, save_h, stats = _train_forward(g, store.flat_p, 1, mode, codes, dims, bn_eps, eps)
+        ctx.save_for_backward(g, gs, mus, lvs, save_h, stats)
+        ctx.cfg = (store, mode, codes, dims, bn_eps, eps, store.flat_p._version)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(stats)
+        return gs, mus, lvs, stats
+
+    @staticmethod
+    def backward(ctx, d_gs, d_mus, d_lvs, _):
+        g, gs, mus, lvs, save_h, stats = ctx.saved_tensors
+        store, mode, codes, dims, bn_eps, eps, version = ctx.cfg
+        if store.flat_p._version != version:
+            raise RuntimeError("the flattened parameters were modified in place between forward and backward")
+        dg, dcanon = _train_backward(g, store.flat_p, 1, gs, mus, lvs, save_h, stats, (d_gs, d_mus, d_lvs), mode, codes, dims, bn_eps, eps)
+        store.accumulate(dcanon)
+        return (dg if ctx.needs_input_grad[0] else None, None, None, None, None, None, None, None)
+
+
 class _GPriorTrain(torch.autograd.Function):
     """The whole training-mode stack as one node: inputs g and every parameter, outputs the three (S,B,G) blocks."""
 
@@ -252,13 +364,7 @@ class _GPriorTrain(torch.autograd.Function):
         dev = g.device
         canon = torch.zeros(total, dtype=torch.float32, device=dev)
         torch._foreach_copy_([canon[o:o + n] for o, n in slots], [p.detach().reshape(-1) for p in params])
-        gs, mus, lvs = (torch.empty((S, B, G), dtype=torch.float32, device=dev) for _ in range(3))
-        save_h = torch.empty((S, B, 2 * nf), dtype=torch.float32, device=dev)
-        stats = torch.empty((S, 2, 2 * nf), dtype=torch.float32, device=dev)
-        ws = torch.empty(L_.dpf_gprior_train_workspace_floats(B, G, nf), dtype=torch.float32, device=dev)
-        check(L_.dpf_gprior_train_forward(S, B, G, nf, MODE[mode], codes, canon.data_ptr(), g.data_ptr(), gs.data_ptr(), mus.data_ptr(),
-                                          lvs.data_ptr(), save_h.data_ptr(), stats.data_ptr(), ws.data_ptr(), bn_eps, eps,
-                                          current_stream()), "gprior_train_forward")
+        gs, mus, lvs, save_h, stats = _train_forward(g, canon, 0, mode, codes, dims, bn_eps, eps)
         ctx.save_for_backward(g, canon, gs, mus, lvs, save_h, stats, *params)
         ctx.cfg = (mode, codes, dims, bn_eps, eps, slots)
         ctx.set_materialize_grads(False)
@@ -273,15 +379,7 @@ class _GPriorTrain(torch.autograd.Function):
         B = g.shape[0]
         L_ = lib()
         dev = g.device
-        dg, dcanon = torch.empty_like(g), torch.empty_like(canon)
-        ws = torch.empty(L_.dpf_gprior_train_workspace_floats(B, G, nf), dtype=torch.float32, device=dev)
-        cg = [t.contiguous() if t is not None else None for t in (d_gs, d_mus, d_lvs)]      # alive across the call
-        with torch.cuda.device(dev):
-            check(L_.dpf_gprior_train_backward(S, B, G, nf, MODE[mode], codes, canon.data_ptr(), g.data_ptr(), gs.data_ptr(),
-                                               mus.data_ptr(), lvs.data_ptr(), save_h.data_ptr(), stats.data_ptr(),
-                                               *[t.data_ptr() if t is not None else None for t in cg],
-                                               dg.data_ptr(), dcanon.data_ptr(), ws.data_ptr(), bn_eps, eps, current_stream()),
-                  "gprior_train_backward")
+        dg, dcanon = _train_backward(g, canon, 0, gs, mus, lvs, save_h, stats, (d_gs, d_mus, d_lvs), mode, codes, (S, G, nf), bn_eps, eps)
         grads = [torch.empty_like(p) for p in params]
         torch._foreach_copy_(grads, [dcanon[o:o + n].view_as(p) for (o, n), p in zip(slots, params)])
         return (dg if ctx.needs_input_grad[0] else None, None, None, None, None, None, None, None, *grads)
@@ -302,8 +400,14 @@ def run_training_prior(module, layers, g, mode):
         assert total == S * lib().dpf_gprior_canon_floats(G, nf)
         cache = module.__dict__["_train_plan"] = (params, slots, bns, total, codes, (S, G, nf), float(layers[0].eps.item()))
     params, slots, bns, total, codes, dims, eps = cache
+    store = module.__dict__.get("_flat")
+    if store is not None and not store.attached():               # .to()/.cuda()/.float() re-assigned the parameters' data
+        store = module.__dict__["_flat"] = PriorFlatStore(layers, g.device)
     with torch.cuda.device(g.device):
-        gs, mus, lvs, stats = _GPriorTrain.apply(g, mode, codes, dims, bns[0].eps, eps, slots, total, *params)
+        if store is not None:
+            gs, mus, lvs, stats = _GPriorTrainFlat.apply(g, store.token, store, mode, codes, dims, bns[0].eps, eps)
+        else:
+            gs, mus, lvs, stats = _GPriorTrain.apply(g, mode, codes, dims, bns[0].eps, eps, slots, total, *params)
         # running statistics (nn.BatchNorm1d: momentum 0.1, unbiased variance), multi-tensor
         B, nf = g.shape[0], dims[2]
         with torch.no_grad():

@@ -354,7 +354,10 @@ int dpf_gprior_forward(int n_steps, int B, int G, int n_features, int mode, cons
  * replaces GlobalRNVPDecoder.forward under model.train() (decoders.py:21-38, flows.py:198-213)
  * and the backward autograd derives from it; 4 launches per step forward, 5 backward, all issued
  * by the one call.  canon: the UNPACKED canonical block of dpf_gprior_pack (the running statistics
- * in it are not read); codes, mode, eps as dpf_gprior_forward; B >= 2.
+ * in it are not read) when params_only == 0; with params_only != 0 the same without the two
+ * running-statistics vectors of each net (W0 | bn.weight | bn.bias | W1 | b1: what an optimizer
+ * updates, so a caller can keep all parameters in one buffer of exactly this layout and all
+ * gradients in its twin).  codes, mode, eps as dpf_gprior_forward; B >= 2.
  * forward: g (B,G) -> gs, mus, lvs (S,B,G) DIRECT order, all required; save_h (S,B,2*n_features)
  *   the pre-BatchNorm activations and save_stats (S,2,2*n_features) = batch mean | biased variance per
  *   hidden unit (mu net, then logvar net) -- for the backward and for the caller's running-statistics
@@ -364,11 +367,11 @@ int dpf_gprior_forward(int n_steps, int B, int G, int n_features, int mode, cons
  * workspace: dpf_gprior_train_workspace_floats(B, G, n_features) fp32. */
 size_t dpf_gprior_train_workspace_floats(int B, int G, int n_features);
 int dpf_gprior_train_forward(int n_steps, int B, int G, int n_features, int mode, const int *codes,
-                             const float *canon, const float *g, float *gs, float *mus, float *lvs,
+                             int params_only, const float *canon, const float *g, float *gs, float *mus, float *lvs,
                              float *save_h, float *save_stats, float *workspace, float bn_eps,
                              float eps, dpf_stream_t stream);
 int dpf_gprior_train_backward(int n_steps, int B, int G, int n_features, int mode, const int *codes,
-                              const float *canon, const float *g, const float *gs, const float *mus,
+                              int params_only, const float *canon, const float *g, const float *gs, const float *mus,
                               const float *lvs, const float *save_h, const float *save_stats,
                               const float *d_gs, const float *d_mus, const float *d_lvs, float *dg,
                               float *dcanon, float *workspace, float bn_eps, float eps,

@@ -65,6 +65,21 @@ def _worker(rank, world, port, q):
         off = (w.grad.data_ptr() - fs.flat_g.data_ptr()) // 4
         ok = ok and n2 == ramp.numel() and torch.allclose(fs.flat_g, ramp * ((1 + world) / 2.0))
         ok = ok and 0 <= off < ramp.numel() and torch.allclose(w.grad.reshape(-1), ramp[off:off + w.numel()] * ((1 + world) / 2.0))
+        # ... and over the latent prior flow's store (a rank-dependent training step on the tensor-op path, then one all-reduce)
+        from dpf_nets_amd.networks import GlobalRNVPDecoder
+        torch.manual_seed(11)
+        prior = GlobalRNVPDecoder(2, 8, 6).train()
+        ps_ = prior.flatten_parameters()
+        gl = torch.randn(4, 6, generator=torch.Generator().manual_seed(100 + rank))
+        gsl, _, lvl = prior(gl, mode="inverse")
+        (gsl[0].square().mean() + sum(lvl).mean()).backward()
+        mine = ps_.flat_g.clone()
+        both = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine)
+        n3 = D.allreduce_flat_gradients(ps_)
+        w0 = prior.flows[1].nvp2.T_logvar_0[3].weight
+        ok = ok and n3 == ps_.flat_p.numel() and torch.allclose(ps_.flat_g, sum(both) / world, rtol=1e-6, atol=1e-8)
+        ok = ok and w0.grad.data_ptr() >= ps_.flat_g.data_ptr() and bool(mine.abs().sum() > 0) and not torch.equal(both[0], both[-1])
         q.put((rank, bool(ok), (lo, hi), float(loss)))
     finally:
         dist.destroy_process_group()

@@ -242,11 +242,11 @@ def test_training_c_abi_rejects_bad_arguments():
     p = t.data_ptr()
     assert L.dpf_gprior_train_workspace_floats(4, 8, 16) == 4 * (3 * 32 + 24)
     # a single row has no batch statistics; odd G; unknown step code; missing buffers
-    assert L.dpf_gprior_train_forward(2, 1, 8, 16, 0, codes, p, p, p, p, p, p, p, p, 1e-5, 1e-6, None) == -1
-    assert L.dpf_gprior_train_forward(2, 4, 7, 16, 0, codes, p, p, p, p, p, p, p, p, 1e-5, 1e-6, None) == -1
-    assert L.dpf_gprior_train_forward(2, 4, 8, 16, 0, (ctypes.c_int * 2)(0, 4), p, p, p, p, p, p, p, p, 1e-5, 1e-6, None) == -1
-    assert L.dpf_gprior_train_forward(2, 4, 8, 16, 0, codes, p, p, p, p, p, None, p, p, 1e-5, 1e-6, None) == -1
-    assert L.dpf_gprior_train_backward(2, 4, 8, 16, 0, codes, p, p, p, p, p, p, p, None, None, None, None, p, p, 1e-5, 1e-6, None) == -1
+    assert L.dpf_gprior_train_forward(2, 1, 8, 16, 0, codes, 0, p, p, p, p, p, p, p, p, 1e-5, 1e-6, None) == -1
+    assert L.dpf_gprior_train_forward(2, 4, 7, 16, 0, codes, 0, p, p, p, p, p, p, p, p, 1e-5, 1e-6, None) == -1
+    assert L.dpf_gprior_train_forward(2, 4, 8, 16, 0, (ctypes.c_int * 2)(0, 4), 0, p, p, p, p, p, p, p, p, 1e-5, 1e-6, None) == -1
+    assert L.dpf_gprior_train_forward(2, 4, 8, 16, 0, codes, 1, p, p, p, p, p, None, p, p, 1e-5, 1e-6, None) == -1
+    assert L.dpf_gprior_train_backward(2, 4, 8, 16, 0, codes, 0, p, p, p, p, p, p, p, None, None, None, None, p, p, 1e-5, 1e-6, None) == -1
 
 
 def test_training_mode_vs_tensor_ops_at_size_and_partial_use():
@@ -294,3 +294,48 @@ def test_eval_after_optimizer_steps_uses_the_new_weights():
     with torch.no_grad():
         ref = dec.forward_torch(g)[0][-1]
     assert rel(after, ref) <= TOL and not torch.allclose(before, after)
+
+
+def test_flat_parameter_store_matches_per_parameter_path_bitwise():
+    """GlobalRNVPDecoder.flatten_parameters(): the same kernels on the same numbers, so the reference's loop
+    (`optimizer.zero_grad(); loss.backward(); optimizer.step()`, training.py:54-56) must leave BITWISE the same parameters,
+    gradients, optimizer state and running statistics as the path that hands every parameter to autograd."""
+    nets = _gpu()
+    import copy
+    torch.manual_seed(2)
+    n_flows, nf, G, B = 3, 32, 16, 9
+    ref = nets.GlobalRNVPDecoder(n_flows, nf, G, weight_std=0.05).cuda().train()
+    flat = copy.deepcopy(ref)
+    store = flat.flatten_parameters()
+    assert flat.flat_store() is store and store.attached() and store.flat_p.numel() == sum(p.numel() for p in flat.parameters())
+    assert [k for k, _ in ref.named_parameters()] == [k for k, _ in flat.named_parameters()]
+    g = torch.randn(B, G, device="cuda")
+    res = []
+    for dec in (ref, flat):
+        opt = nets.Adam(dec.parameters(), lr=1e-2, weight_decay=1e-6, betas=(0.9, 0.995), amsgrad=True)
+        gin = g.clone().requires_grad_(True)
+        for it in range(4):
+            if it == 2 and dec is flat:
+                store.zero_grad()
+            else:
+                opt.zero_grad()
+            gin.grad = None
+            gs, mus, lvs = dec(gin, mode="inverse")
+            loss = gs[0].square().mean() + sum(lvs).mean() + dec(gin, mode="direct")[0][-1].abs().mean()     # two uses: gradients add up
+            loss.backward()
+            opt.step()
+        res.append((loss.detach().clone(), gin.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for (k, a), b in zip(ref.state_dict().items(), flat.state_dict().values()):
+        assert torch.equal(a, b), k
+    for (k, a), (_, b) in zip(ref.named_parameters(), flat.named_parameters()):
+        assert torch.equal(a.grad, b.grad), k
+    assert store.attached() and flat.flows[0].nvp1.T_mu_0[0].weight.grad.data_ptr() == store.flat_g.data_ptr()
+    # eval after training sees the trained weights through the views; .float()/.cuda() break the aliasing, the next step re-flattens
+    flat.eval(); ref.eval()
+    assert torch.equal(flat(g)[0][-1], ref(g)[0][-1])
+    flat._apply(lambda t: t.clone())
+    assert flat.flat_store() is None
+    flat.train()
+    flat(g, mode="inverse")
+    assert flat.flat_store() is not None and flat.flat_store() is not store

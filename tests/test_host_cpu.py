@@ -323,3 +323,39 @@ def test_mirror_adam_flat_store_path_is_bitwise_the_per_parameter_path():
     for (k, a), b in zip(ref.state_dict().items(), flat.state_dict().values()):
         assert torch.equal(a, b), k
     assert n_f.state[w]["step"] == 5
+
+
+def test_prior_flat_store_aliases_parameters_and_takes_the_flat_adam_path():
+    """GlobalRNVPDecoder.flatten_parameters() on CPU tensors (no kernels involved): names, shapes and values unchanged,
+    .data / .grad are views of the two flat buffers in the parameters-only canonical layout of include/dpf_hip.h, gradients
+    re-attach after optimizer.zero_grad(set_to_none=True), and networks.optimizers.Adam updates the store with one op
+    sequence, bit for bit the per-parameter path."""
+    import copy
+    import torch
+    from dpf_nets_amd import networks as nets
+    torch.manual_seed(3)
+    ref = nets.GlobalRNVPDecoder(2, 8, 6, weight_std=0.1)
+    flat = copy.deepcopy(ref)
+    before = {k: v.clone() for k, v in flat.state_dict().items()}
+    store = flat.flatten_parameters()
+    assert flat.flat_store() is store and store.flat_p.numel() == sum(p.numel() for p in flat.parameters()) == 4 * 2 * (2 * 8 * 3 + 2 * 8 + 3)
+    assert all(torch.equal(v, before[k]) for k, v in flat.state_dict().items())
+    w = flat.flows[0].nvp1.T_mu_0[0].weight                              # first tensor of the layout
+    assert w.data_ptr() == store.flat_p.data_ptr() and w.grad.data_ptr() == store.flat_g.data_ptr() and w._dpf_flat is store
+    b_last = flat.flows[1].nvp2.T_logvar_0[3].bias                       # and the last one
+    assert b_last.data_ptr() == store.flat_p.data_ptr() + 4 * (store.total - 3)
+    kw = dict(lr=1e-2, betas=(0.9, 0.99), weight_decay=1e-3, amsgrad=True)
+    o_r, o_f = nets.Adam(ref.parameters(), **kw), nets.Adam(flat.parameters(), **kw)
+    g = torch.randn(5, 6)
+    for it in range(3):
+        for dec, opt in ((ref, o_r), (flat, o_f)):
+            opt.zero_grad()                                              # set_to_none: the store re-attaches zeroed views
+            gs, mus, lvs = dec(g, mode="inverse")                        # CPU tensors: the tensor-op path, autograd per parameter
+            (gs[0].square().mean() + sum(lvs).mean()).backward()
+            if dec is flat:
+                store.attach_grads(full=True)                            # tensor-op gradients are copied into the views
+            opt.step()
+    assert len(o_f._flat) == 1 and store.attached()
+    for (k, a), b in zip(ref.state_dict().items(), flat.state_dict().values()):
+        assert torch.equal(a, b), k
+    assert o_f.state[w]["step"] == 3 and torch.equal(o_f.state[w]["exp_avg"], o_r.state[ref.flows[0].nvp1.T_mu_0[0].weight]["exp_avg"])

@@ -62,4 +62,14 @@ for n_flows, nf, G, B in ((7, 128, 128, 32), (7, 128, 512, 64)):
 
     hip = timeit(lambda: step(lambda x: dec(x, mode="inverse")), 20)
     tops = timeit(lambda: step(lambda x: dec.forward_torch(x, "inverse")), 10)
-    print("train n_flows=%d nf=%d G=%d B=%d  forward+backward: HIP node %.0f us   tensor ops %.0f us" % (n_flows, nf, G, B, hip, tops))
+    store = dec.flatten_parameters()
+
+    def flat_step():
+        store.zero_grad()
+        gin = g.clone().requires_grad_(True)
+        gs, mus, lvs = dec(gin, mode="inverse")
+        (gs[0].square().mean() + sum(lvs).mean()).backward()
+
+    flat = timeit(flat_step, 20)
+    print("train n_flows=%d nf=%d G=%d B=%d  zero_grad+forward+loss+backward: HIP node %.0f us, with the flat store %.0f us   tensor ops %.0f us"
+          % (n_flows, nf, G, B, hip, flat, tops))
