@@ -46,6 +46,13 @@ def parse():
                     choices=sorted(MFMA_PRODUCTS))
     ap.add_argument("--lists", action="store_true", help="also materialise the 3 x L per-layer lists")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="consecutive steps go round-robin over this many streams (each with its own buffers), so the Chamfer "
+                         "kernels of one step share the chip with the flow kernel of the next; 1 (default) = strictly one after "
+                         "another, the regime the roofline numbers and the committed profiles describe")
+    ap.add_argument("--pipelined", type=int, default=3,
+                    help="with --streams 1: also report (outside the timed region, as `pipelined`) the throughput with this many "
+                         "steps in flight; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=6)
     return ap.parse_args()
@@ -112,8 +119,8 @@ def time_kernel(fn, reps=20, rounds=5):
     return float(np.median(best))
 
 
-def kernel_timings(dec, z, g, tgt_pm, L, precision):
-    """per-kernel average launch durations (us) measured with HIP events"""
+def make_kernels(dec, z, g, tgt_pm, L, precision):
+    """The three launches of a step as closures over their own buffers: (film, flow, nn)."""
     from dpf_nets_amd._lib import lib, PREC, MODE, current_stream
     from dpf_nets_amd.metrics.StructuralLosses import StructuralLossesBackend as BK
     stack = dec.stack()
@@ -154,9 +161,44 @@ def kernel_timings(dec, z, g, tgt_pm, L, precision):
         else:
             fn(B, N, pm.data_ptr(), N, tgt_pm.data_ptr(), d1.data_ptr(), i1.data_ptr(), d2.data_ptr(), i2.data_ptr(),
                ws.data_ptr(), nws, current_stream())
+    return k_film, k_flow, k_nn
+
+
+def kernel_timings(dec, z, g, tgt_pm, L, precision):
+    """per-kernel average launch durations (us) measured with HIP events, each kernel alone on the chip"""
+    k_film, k_flow, k_nn = make_kernels(dec, z, g, tgt_pm, L, precision)
     k_film(); k_flow(); k_nn()
     torch.cuda.synchronize()
     return {"film_kernel": time_kernel(k_film), "flow_kernel": time_kernel(k_flow), "nn_kernel": time_kernel(k_nn)}
+
+
+def kernel_timings_in_flight(dec, z, g, tgt_pm, L, precision, n_streams, steps=120, warm=30):
+    """The same durations in the regime of the timed loop: steps round-robin over `n_streams` streams, HIP events on the
+    launch stream around each kernel -- what the rocprofv3 kernel trace of this command reports as average durations
+    (kernels of neighbouring steps share the chip, so each takes longer than alone while the steps take less)."""
+    streams = [torch.cuda.Stream() for _ in range(n_streams)]
+    sets = []
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            ks = make_kernels(dec, z, g, tgt_pm, L, precision)
+            for k in ks:
+                k()
+        sets.append(ks)
+    torch.cuda.synchronize()
+    marks = []
+    for i in range(steps):
+        k = i % n_streams
+        with torch.cuda.stream(streams[k]):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record(); sets[k][0](); ev[1].record(); sets[k][1](); ev[2].record(); sets[k][2](); ev[3].record()
+        marks.append(ev)
+    torch.cuda.synchronize()
+    marks = marks[warm:]
+    out = {}
+    for j, name in enumerate(("film_kernel", "flow_kernel", "nn_kernel")):
+        out[name] = float(np.mean([m[j].elapsed_time(m[j + 1]) for m in marks])) * 1e3
+    return out
 
 
 def cpu_baseline(args, state, n_flows, tgt, budget_s=15.0):
@@ -218,28 +260,38 @@ def main():
         out = step()
     torch.cuda.synchronize()
 
-    run_once = step
-    graph = None
-    if not args.no_graph:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+    # Every step is one full pass over one batch.  With --streams S > 1 consecutive steps go round-robin over S streams, each
+    # stream with its own captured graph and therefore its own intermediate / output buffers, so up to S steps are in flight
+    # and the Chamfer kernels of one share the chip with the flow kernel of the next; all K steps have finished at the
+    # closing synchronize.
+    S = max(1, args.streams)
+    S_all = max(S, args.pipelined if S == 1 else 0)
+    streams = [torch.cuda.Stream() for _ in range(S_all)]
+    runners = []
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
             out = step()
-        run_once = graph.replay
+        torch.cuda.synchronize()
+        if args.no_graph:
+            runners.append(step)
+        else:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=st):
+                out = step()
+            runners.append(graph.replay)
 
-    for _ in range(args.warmup):
-        run_once()
+    def run_steps(n, S=S):
+        for i in range(n):
+            with torch.cuda.stream(streams[i % S]):
+                runners[i % S]()
+
+    run_steps(args.warmup)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_once()
+    run_steps(args.steps)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -248,6 +300,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    pipelined = None
+    if S_all > S:                        # the same steps with S_all of them in flight, reported beside the headline
+        run_steps(args.warmup, S_all)
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        run_steps(args.steps, S_all)
+        torch.cuda.synchronize()
+        pipelined = (time.perf_counter() - tp) / args.steps
+
     # sanity on the outputs of the timed path (cheap, outside the timed region)
     p_out, d1, i1, d2, i2, cd = out
     assert torch.isfinite(p_out).all() and torch.isfinite(cd).all() and (d1 >= 0).all()
@@ -255,7 +316,8 @@ def main():
     if rank == 0:
         pts_per_step = args.batch * args.points * n_gpus
         ms_per_step = elapsed / args.steps * 1e3
-        kt = kernel_timings(dec, z, g, tgt_pm, L, args.precision)
+        kt_alone = kernel_timings(dec, z, g, tgt_pm, L, args.precision)
+        kt = kernel_timings_in_flight(dec, z, g, tgt_pm, L, args.precision, S) if S > 1 else kt_alone
         from dpf_nets_amd.metrics.StructuralLosses import StructuralLossesBackend as BK
         dom = max(("flow_kernel", "nn_kernel"), key=lambda k: kt[k])
         B, N = args.batch, args.points
@@ -283,6 +345,10 @@ def main():
                     "frac": nn_ach / HBM_PEAK_GBS, "traffic": traffic,
                     "note": "exact Chamfer is compute bound (AI ~800 FLOP/B); HBM fraction is tiny by construction"}
         roof["kernels_us"] = kt
+        roof["kernels_us_alone"] = kt_alone
+        if S > 1:
+            roof["note"] += "; durations are those of the timed regime (%d steps in flight share the chip: each kernel takes " \
+                            "longer than alone, the steps take less), kernels_us_alone = each kernel by itself" % S
         roof["flow_algorithmic_tflops"] = flow_ach
         roof["chamfer_algorithmic_gbs"] = nn_ach
         roof["chamfer_pair_evals_per_s"] = 2.0 * B * N * N / (kt["nn_kernel"] * 1e-6)
@@ -296,11 +362,21 @@ def main():
                                    "direct/eval-BN, + nn_distance both directions + CD reduction" % (L, L, n_flows),
                        "clouds_per_gpu": B, "points_per_cloud": N, "hidden": 64, "latent": args.latent,
                        "global_clouds": B * n_gpus, "per_layer_lists": bool(args.lists),
-                       "launch": "eager" if args.no_graph else "hipGraph replay", "parallelism": "clouds sharded, no collective",
+                       "launch": ("eager" if args.no_graph else "hipGraph replay") +
+                       (", consecutive steps round-robin over %d streams with their own buffers" % S if S > 1 else ""),
+                       "steps_in_flight": S, "parallelism": "clouds sharded, no collective",
                        "chamfer_impl": BK.NN_IMPL + (" (matrix-core filtered exact search at this size)" if BK.NN_IMPL == "auto" and
                                                      2.0 * B * N * N >= 1e8 and B * 2 * ((N + 255) // 256) >= 64 else "")},
             "roofline": roof,
         }
+        if pipelined is not None:
+            line["pipelined"] = {
+                "steps_in_flight": S_all, "value": args.batch * args.points / pipelined,
+                "unit": "points/s per GPU", "ms_per_step": pipelined * 1e3,
+                "kernels_us": kernel_timings_in_flight(dec, z, g, tgt_pm, L, args.precision, S_all),
+                "note": "consecutive steps round-robin over %d streams with their own buffers (bench.py --streams %d makes this "
+                        "the timed regime): the Chamfer kernels of one step share the chip with the flow kernel of the next, "
+                        "each kernel takes longer than alone, the steps take less" % (S_all, S_all)}
         if not args.no_cpu_baseline and n_gpus == 1:      # the CPU oracle is timed at N = 1 only
             line["cpu_baseline"] = cpu_baseline(args, state, n_flows, tgt)
         else:
