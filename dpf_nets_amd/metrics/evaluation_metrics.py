@@ -1,0 +1,58 @@
+"""The structural-loss CALLERS of the reference's lib/metrics/evaluation_metrics.py, over the HIP entry points:
+
+  distChamferCUDA (:22-23), emd_approx (:26-31)     -- re-exported from networks.utils
+  EMD_CD (:48-82)                                   -- per-pair Chamfer of two equally long sets, batched
+  _pairwise_EMD_CD_ (:85-121)                       -- the (N_sample, N_ref) Chamfer and EMD matrices; the only caller of
+                                                       match_cost in the reference
+
+Same signatures, return structures and values as the reference's loops.  What differs is how a row is fed: the reference
+expands sample i to (batch, n, 3) and copies it (`.contiguous()`) for every block of references; here the Chamfer launch
+reads the one cloud through a zero batch stride (dpf_nndistance_strided_auto, same bits) and reduces to the per-pair CD
+in one more launch; the EMD entry point needs a dense batch, so only that operand is materialised.
+`accelerated_cd=False` asks the reference for its pure-PyTorch distChamfer (the O(N^2)-memory bmm form, :35-45); there
+is no CPU or tensor-op fallback in this package, so both values of the flag run the exact HIP Chamfer."""
+import torch
+
+from ..networks.utils import distChamferCUDA, emd_approx, chamfer_per_cloud  # noqa: F401
+from .._lib import lib, check, current_stream
+
+
+def EMD_CD(sample_pcs, ref_pcs, batch_size, accelerated_cd=False, reduced=True):
+    N_sample, N_ref = sample_pcs.shape[0], ref_pcs.shape[0]
+    assert N_sample == N_ref, "REF:%d SMP:%d" % (N_ref, N_sample)
+    cd_lst = []
+    for b_start in range(0, N_sample, batch_size):
+        b_end = min(N_sample, b_start + batch_size)
+        dl, dr = distChamferCUDA(sample_pcs[b_start:b_end].contiguous(), ref_pcs[b_start:b_end].contiguous())
+        cd_lst.append(chamfer_per_cloud(dl, dr))                       # dl.mean(1) + dr.mean(1), one launch
+    cd = torch.cat(cd_lst).mean() if reduced else torch.cat(cd_lst)
+    return {"MMD-CD": cd}
+
+
+def _pairwise_EMD_CD_(sample_pcs, ref_pcs, batch_size, accelerated_cd=True):
+    if not (sample_pcs.is_cuda and ref_pcs.is_cuda):
+        raise RuntimeError("_pairwise_EMD_CD_ needs CUDA tensors (there is no CPU fallback)")
+    sample_pcs, ref_pcs = sample_pcs.contiguous().float(), ref_pcs.contiguous().float()
+    N_sample, n = sample_pcs.shape[0], sample_pcs.shape[1]
+    N_ref, m = ref_pcs.shape[0], ref_pcs.shape[1]
+    dev = sample_pcs.device
+    all_cd = torch.empty((N_sample, N_ref), dtype=torch.float32, device=dev)
+    all_emd = torch.empty((N_sample, N_ref), dtype=torch.float32, device=dev)
+    bs = max(1, min(batch_size, N_ref))
+    d1 = torch.empty((bs, n), dtype=torch.float32, device=dev)
+    d2 = torch.empty((bs, m), dtype=torch.float32, device=dev)
+    i1 = torch.empty((bs, n), dtype=torch.int32, device=dev)
+    i2 = torch.empty((bs, m), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        for i in range(N_sample):
+            for r0 in range(0, N_ref, batch_size):
+                r1 = min(N_ref, r0 + batch_size)
+                nb = r1 - r0
+                st = current_stream()
+                check(lib().dpf_nndistance_strided_auto(nb, n, sample_pcs[i].data_ptr(), 0, m, ref_pcs[r0].data_ptr(), m * 3,
+                                                        d1.data_ptr(), i1.data_ptr(), d2.data_ptr(), i2.data_ptr(), st),
+                      "nndistance_strided")
+                check(lib().dpf_chamfer_reduce(nb, n, m, d1.data_ptr(), d2.data_ptr(), all_cd[i, r0:r1].data_ptr(), st),
+                      "chamfer_reduce")
+                all_emd[i, r0:r1] = emd_approx(sample_pcs[i].unsqueeze(0).expand(nb, -1, -1).contiguous(), ref_pcs[r0:r1])
+    return all_cd, all_emd

@@ -118,3 +118,35 @@ def test_fused_cost_matches_separate_matchcost():
         np.testing.assert_allclose(c2.cpu().numpy(), S.matchcost(a, b, match.cpu().numpy()), rtol=2e-5)
         if n == m:                                                    # emd_approx asserts N == M
             np.testing.assert_allclose(match_cost(ta, tb).cpu().numpy(), c2.cpu().numpy(), rtol=0, atol=0)
+
+
+def test_pairwise_emd_cd_and_emd_cd_callers():
+    """metrics/evaluation_metrics.py (_pairwise_EMD_CD_, EMD_CD: lib/metrics/evaluation_metrics.py:48-121) against the
+    reference-shaped loops over nn_distance / match_cost (expand + contiguous per row block) and the oracle's Chamfer."""
+    BK = _gpu()
+    from dpf_nets_amd.metrics import evaluation_metrics as EM
+    from dpf_nets_amd.metrics.StructuralLosses.nn_distance import nn_distance
+    from dpf_nets_amd.metrics.StructuralLosses.match_cost import match_cost
+    a, b = chamfer_inputs(77, 5, 96, 96)
+    b = np.concatenate([b, a[:2] + 0.01]).astype(np.float32)               # 7 references
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    cd, emd = EM._pairwise_EMD_CD_(ta, tb, batch_size=3)
+    assert cd.shape == emd.shape == (5, 7)
+    for i in range(5):
+        cds, emds = [], []
+        for r0 in range(0, 7, 3):
+            ref = tb[r0:r0 + 3]
+            exp = ta[i].view(1, -1, 3).expand(ref.shape[0], -1, -1).contiguous()
+            dl, dr = nn_distance(exp, ref)
+            cds.append(dl.mean(1) + dr.mean(1))
+            emds.append(match_cost(exp, ref) / 96.0)
+        np.testing.assert_allclose(cd[i].cpu().numpy(), torch.cat(cds).cpu().numpy(), rtol=1e-6, atol=1e-9)
+        assert torch.equal(emd[i], torch.cat(emds))
+    d1, _, d2, _ = S.nndistance(np.repeat(a[3:4], 7, 0), b)
+    np.testing.assert_allclose(cd[3].cpu().numpy(), d1.mean(1) + d2.mean(1), rtol=1e-5)
+    res = EM.EMD_CD(ta, tb[:5], batch_size=2, reduced=False)["MMD-CD"]
+    dl, dr = nn_distance(ta, tb[:5].contiguous())
+    np.testing.assert_allclose(res.cpu().numpy(), (dl.mean(1) + dr.mean(1)).cpu().numpy(), rtol=1e-6)
+    assert abs(float(EM.EMD_CD(ta, tb[:5], batch_size=4)["MMD-CD"]) - float(res.mean())) < 1e-7
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        EM._pairwise_EMD_CD_(ta.cpu(), tb.cpu(), 3)
