@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+_l = ctypes.c_long
 
 # name -> (restype, argtypes); must list every symbol include/dpf_hip.h declares
 SIGNATURES = {
@@ -66,6 +67,8 @@ SIGNATURES = {
     "dpf_gprior_train_forward": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp]),
     "dpf_gprior_train_backward": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _f, _f, _vp]),
+    "dpf_pointflow_nll_workspace_floats": (_sz, []),
+    "dpf_pointflow_nll": (_i, [_i, _i, _i, _vp, _vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _vp, _vp, _vp]),
     "dpf_version": (ctypes.c_char_p, []),
 }
 

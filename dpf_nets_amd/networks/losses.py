@@ -26,8 +26,37 @@ def total_logvar(logvars):
     return sum(logvars)
 
 
+def _flow_total(logvars):
+    """(total of logvars[1:], True) when logvars is `[base] + <the fused stack's list>` and the stack left its layer-sum."""
+    if len(logvars) < 2:
+        return None, False
+    tag = getattr(logvars[-1], "_dpf_total", None)
+    if tag is None:
+        return None, False
+    token, k, total = tag
+    if len(logvars) == k + 1 and all(getattr(logvars[1 + i], "_dpf_pos", None) == (token, i) for i in range(k)):
+        return total, True
+    return None, False
+
+
 class PointFlowNLL(nn.Module):
     def forward(self, samples, mus, logvars):
-        s0 = samples[0]
-        tot = total_logvar(logvars) + (s0 - mus[0]) ** 2 / torch.exp(logvars[0])
+        s0, mu0, lv0 = samples[0], mus[0], logvars[0]
+        # evaluation (CUDA tensors, nothing to differentiate): one pass over s0 and the kernel's sum of log-variances, the
+        # base distribution's stride-0 expansions read through their strides (csrc/nll.hip)
+        if s0.is_cuda and s0.dim() == 3 and s0.dtype == torch.float32 and mu0.shape == s0.shape and lv0.shape == s0.shape and \
+                mu0.dtype == lv0.dtype == torch.float32 and \
+                not (torch.is_grad_enabled() and (s0.requires_grad or mu0.requires_grad or lv0.requires_grad)):
+            total, ok = _flow_total(logvars)
+            if ok and total.is_contiguous() and not (torch.is_grad_enabled() and total.requires_grad):
+                from .._lib import lib, check, current_stream
+                B, C, N = s0.shape
+                s0 = s0.contiguous()
+                out = torch.empty((), dtype=torch.float32, device=s0.device)
+                ws = torch.empty(lib().dpf_pointflow_nll_workspace_floats(), dtype=torch.float32, device=s0.device)
+                with torch.cuda.device(s0.device):
+                    check(lib().dpf_pointflow_nll(B, C, N, s0.data_ptr(), mu0.data_ptr(), *mu0.stride(), lv0.data_ptr(), *lv0.stride(),
+                                                  total.data_ptr(), ws.data_ptr(), out.data_ptr(), current_stream()), "pointflow_nll")
+                return out
+        tot = total_logvar(logvars) + (s0 - mu0) ** 2 / torch.exp(lv0)
         return 0.5 * (tot.sum() / s0.shape[0] + math.log(2.0 * math.pi) * s0.shape[1] * s0.shape[2])

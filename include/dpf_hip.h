@@ -350,6 +350,18 @@ int dpf_gprior_forward(int n_steps, int B, int G, int n_features, int mode, cons
                        const float *packed, const float *g, float *gs, float *mus, float *lvs,
                        float *sum_lv, float *g_out, float eps, dpf_stream_t stream);
 
+/* ---- PointFlowNLL (lib/networks/losses.py:11-15) in one pass ---------------------------------
+ * out[0] = 0.5 * ( sum_{b,c,n} [ sum_lv + lv0 + (s0 - mu0)^2 / exp(lv0) ] / B + log(2 pi) * C * N ).
+ * s0 (B,C,N) contiguous: the cloud at the base of the flow (samples[0]); sum_lv (B,C,N) contiguous or
+ * NULL: the flow's summed log-variances (dpf_flow_forward's sum_logvar); mu0 / lv0: the base
+ * distribution (mus[0], logvars[0]) read through element strides (batch, channel, point) -- the
+ * reference's stride-0 expansions (models.py:108-117) are never materialised.  Deterministic.
+ * workspace: dpf_pointflow_nll_workspace_floats() fp32. */
+size_t dpf_pointflow_nll_workspace_floats(void);
+int dpf_pointflow_nll(int B, int C, int N, const float *s0, const float *mu0, long mu_sb, long mu_sc,
+                      long mu_sn, const float *lv0, long lv_sb, long lv_sc, long lv_sn,
+                      const float *sum_lv, float *workspace, float *out, dpf_stream_t stream);
+
 /* ---- latent prior flow, TRAINING mode (BatchNorm1d on the statistics of the B rows) -----------
  * replaces GlobalRNVPDecoder.forward under model.train() (decoders.py:21-38, flows.py:198-213)
  * and the backward autograd derives from it; 4 launches per step forward, 5 backward, all issued

@@ -209,3 +209,43 @@ def test_module_semantics():
     assert isinstance(ps, list) and len(ps) == 3
     nets.PointFlowNLL()(ps + [pr], [torch.zeros_like(p)] + mus, [torch.zeros_like(p)] + lvs).backward()
     assert pr.grad is not None and torch.isfinite(pr.grad).all()
+
+
+def test_pointflow_nll_fused_reduction():
+    """PointFlowNLL (losses.py:11-15) on the fused stack's lists in evaluation: one pass over the cloud and the kernel's
+    sum of log-variances with the base distribution's stride-0 expansions read in place (csrc/nll.hip), against the
+    reference's arithmetic on the same tensors in float64 and the tensor-op formula in fp32."""
+    nets = _gpu()
+    import math
+    torch.manual_seed(4)
+    B, N, G = 5, 777, 128
+    dec = nets.LocalCondRNVPDecoder(2, 64, G).cuda().eval()
+    p = torch.randn(B, 3, N, device="cuda") * 0.3
+    g = torch.randn(B, G, device="cuda")
+    pm = torch.zeros(1, 3, 1, device="cuda").expand(B, 3, N)                    # models.py:112-117: stride-0 expansions
+    pl = (torch.randn(B, 3, 1, device="cuda") * 0.1 - 3.0).expand(B, 3, N)
+    nll = nets.PointFlowNLL()
+    with torch.no_grad():
+        ps, mus, lvs = dec(p, g, mode="inverse")
+        calls = []
+        from dpf_nets_amd._lib import lib
+        orig = lib().dpf_pointflow_nll
+        lib().dpf_pointflow_nll = lambda *a: (calls.append(1), orig(*a))[1]
+        try:
+            got = nll(ps + [p], [pm] + mus, [pl] + lvs)
+        finally:
+            lib().dpf_pointflow_nll = orig
+        assert calls, "the fused reduction was not taken"
+        s0 = ps[0].double()
+        tot = sum(v.double() for v in lvs) + pl.double() + (s0 - pm.double()) ** 2 / torch.exp(pl.double())
+        want = 0.5 * (tot.sum() / B + math.log(2.0 * math.pi) * 3 * N)
+        plain = 0.5 * ((sum([pl] + [v.clone() for v in lvs]) + (ps[0] - pm) ** 2 / torch.exp(pl)).sum() / B + math.log(2.0 * math.pi) * 3 * N)
+    assert got.shape == () and got.dtype == torch.float32
+    assert abs(float(got) - float(want)) <= 2e-6 * abs(float(want)), (float(got), float(want))
+    assert abs(float(got) - float(plain)) <= 1e-5 * abs(float(want))
+    assert torch.equal(got, nll(ps + [p], [pm] + mus, [pl] + lvs))                # deterministic
+    # a differentiable base distribution goes through the tensor ops and autograd
+    plg = pl.clone().requires_grad_(True)
+    out = nll(ps + [p], [pm] + mus, [plg] + lvs)
+    out.backward()
+    assert plg.grad is not None and abs(float(out.detach()) - float(want)) <= 1e-5 * abs(float(want))
