@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--precision", default=os.environ.get("DPF_PRECISION", "bf16x3"),
                     choices=sorted(MFMA_PRODUCTS))
     ap.add_argument("--lists", action="store_true", help="also materialise the 3 x L per-layer lists")
+    ap.add_argument("--settle", type=int, default=400,
+                    help="untimed steps run BEFORE the --warmup steps so that the chip's clocks have settled under this load "
+                         "whatever --warmup is (see above); 0 = none")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--streams", type=int, default=1,
                     help="consecutive steps go round-robin over this many streams (each with its own buffers), so the Chamfer "
@@ -289,6 +292,7 @@ def main():
             with torch.cuda.stream(streams[i % S]):
                 runners[i % S]()
 
+    run_steps(args.settle)
     run_steps(args.warmup)
     if dist is not None:
         dist.barrier()
@@ -367,7 +371,7 @@ def main():
                        "global_clouds": B * n_gpus, "per_layer_lists": bool(args.lists),
                        "launch": ("eager" if args.no_graph else "hipGraph replay") +
                        (", consecutive steps round-robin over %d streams with their own buffers" % S if S > 1 else ""),
-                       "steps_in_flight": S, "parallelism": "clouds sharded, no collective",
+                       "steps_in_flight": S, "settle_steps": args.settle, "parallelism": "clouds sharded, no collective",
                        "chamfer_impl": BK.NN_IMPL + (" (matrix-core filtered exact search at this size)" if BK.NN_IMPL == "auto" and
                                                      2.0 * B * N * N >= 1e8 and B * 2 * ((N + 255) // 256) >= 64 else "")},
             "roofline": roof,
