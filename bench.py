@@ -88,11 +88,8 @@ def make_step(dec, z, g, tgt_pm, L):
     def step():
         p_out, sum_lv, ps, mus, lvs = stack.run(z, g, "direct", dec.precision, want_lists=dec.materialize_lists,
                                                 n_layers=L, want_pointmajor=True)
-        if BK.NN_IMPL == "sym":        # both directions from one evaluation of every pair; CD from its merge launch
-            d1, i1, d2, i2, cd = BK.NNDistanceCD(stack.last_pointmajor, tgt_pm)
-        else:
-            d1, i1, d2, i2 = BK.NNDistance(stack.last_pointmajor, tgt_pm)
-            cd = chamfer_per_cloud(d1, d2)
+        d1, i1, d2, i2 = BK.NNDistance(stack.last_pointmajor, tgt_pm)
+        cd = chamfer_per_cloud(d1, d2)
         return p_out, d1, i1, d2, i2, cd
     return step
 
@@ -148,14 +145,7 @@ def make_kernels(dec, z, g, tgt_pm, L, precision):
     i1 = torch.empty((B, N), dtype=torch.int32, device=z.device); i2 = torch.empty_like(i1)
 
     impl = BK.NN_IMPL
-    if impl == "sym":
-        sized = lib().dpf_nndistance_sym_workspace_bytes
-        cdb = torch.empty((B,), dtype=torch.float32, device=z.device)
-
-        def fn(b, n, a, m, c, r1, j1, r2, j2, w, nw, st_):
-            return lib().dpf_nndistance_sym(b, n, a, m, c, r1, j1, r2, j2, cdb.data_ptr(), w, nw, st_)
-    else:
-        sized, fn = BK.nn_impl_entry(impl) if impl not in ("brute", "auto") else (None, None)
+    sized, fn = BK.nn_impl_entry(impl) if impl not in ("brute", "auto") else (None, None)
     nws = sized(B, N, N) if sized else 0
     ws = torch.empty((max(nws, 16),), dtype=torch.uint8, device=z.device)
 

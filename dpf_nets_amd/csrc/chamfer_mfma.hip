@@ -31,6 +31,7 @@
 #include <stdlib.h>
 
 #include "dpf_hip.h"
+#include "lds_attr.h"
 
 #pragma clang fp contract(off)
 
@@ -325,12 +326,8 @@ static long nnm_workgroups(int b, int n, int m, int qw) {
 template <int QW>
 static int launch_nnm_qw(const MArgs &ma, int b, int nmax, hipStream_t s) {
     const int lds = CT * 1536 + QW * QCAP * 64 * 6;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)nnm_kernel<QW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static LdsLimit limit;
+    if (hipError_t e = limit.ensure((const void *)nnm_kernel<QW>, lds); e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(nnm_kernel<QW>, dim3((nmax + QW * 32 - 1) / (QW * 32), b, 2), dim3(QW * 64), lds, s, ma);
     return (int)hipGetLastError();
 }

@@ -379,12 +379,8 @@ template <int NS>
 int launch_enc(const EncArgs &a, hipStream_t s) {
     constexpr int EW = e_waves(NS), EWG_POINTS = EW * e_tp(NS) * TILE;
     const int lds = 8192 + 2 * ep_chunk_bytes(NS) + EW * EC4 * 4;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void *)enc_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr = true;
-    }
+    static LdsLimit limit;
+    if (hipError_t e = limit.ensure((const void *)enc_kernel<NS>, lds); e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(enc_kernel<NS>, dim3((a.N + EWG_POINTS - 1) / EWG_POINTS, a.B), dim3(EW * 64), lds, s, a);
     return (int)hipGetLastError();
 }

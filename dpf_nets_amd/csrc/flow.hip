@@ -688,12 +688,9 @@ extern "C" int dpf_flow_film(int n_layers, int B, int G, int precision, const vo
     if (G % 16 != 0 || G > 2048) return DPF_ENOSUP;
     const float *fw = (const float *)((const uint8_t *)packed + (size_t)n_layers * p_layer_bytes(ns));
     const int lds = (FILM_CLOUDS * G + (2 * 4 + 2 + 1) * FILM_CLOUDS * 64) * (int)sizeof(float);
-    static int attr_lds = 0;
-    if (lds > 65536 && lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute((const void *)film_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr_lds = lds;
-    }
+    static LdsLimit film_limit;
+    if (lds > 65536)
+        if (hipError_t e = film_limit.ensure((const void *)film_kernel, lds); e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(film_kernel, dim3(n_layers * 2, (B + FILM_CLOUDS - 1) / FILM_CLOUDS), dim3(512), lds,
                        (hipStream_t)stream, n_layers, B, G, fw, g, film, flow_eps);
     return (int)hipGetLastError();
@@ -734,12 +731,9 @@ extern "C" int dpf_flow_forward(int n_layers, int B, int N, int mode, int precis
 #define DPF_LAUNCH_LPB(NSV, FWV, LPBV)                                                                          \
     {                                                                                                           \
         const int lds = 2 * LPBV * (p_layer_bytes(NSV) + FILM_BYTES);                                           \
-        static bool attr_set = false;                                                                           \
-        if (!attr_set) {                                                                                        \
-            e = hipFuncSetAttribute((const void *)flow_kernel<NSV, FWV, LPBV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-            if (e != hipSuccess) return (int)e;                                                                 \
-            attr_set = true;                                                                                    \
-        }                                                                                                       \
+        static LdsLimit limit;                                                                                  \
+        e = limit.ensure((const void *)flow_kernel<NSV, FWV, LPBV>, lds);                                       \
+        if (e != hipSuccess) return (int)e;                                                                     \
         const dim3 grid((N + TILE * FWV - 1) / (TILE * FWV), B), block(FWV * 64);                               \
         hipLaunchKernelGGL((flow_kernel<NSV, FWV, LPBV>), grid, block, lds, s, a);                              \
     }

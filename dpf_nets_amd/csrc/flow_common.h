@@ -8,6 +8,7 @@
 #include <stdint.h>
 
 #include "dpf_hip.h"
+#include "lds_attr.h"
 
 namespace {
 

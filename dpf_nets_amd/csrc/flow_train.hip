@@ -963,10 +963,6 @@ __global__ __launch_bounds__(256) void tbwd3f_kernel(int N, int ka, int kb, int 
 __global__ void tprof_set_kernel(unsigned long long *p) { g_tprof = p; }
 #endif
 
-hipError_t set_lds(const void *fn, int bytes) {
-    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-}
-
 }  // namespace
 
 static inline int t_ns(int precision) { return precision == DPF_PREC_BF16X3 ? 2 : (precision == DPF_PREC_BF16X6 ? 3 : 0); }
@@ -1034,12 +1030,8 @@ static int prepare_layer(int B, int N, int ka, int kb, const float *tcanon_l, vo
     a.packed_l = (const uint8_t *)packed_l; a.tcanon_l = tcanon_l; a.film_l = film_l; a.filmb_l = film_l + (size_t)B * 512;
     a.stats_l = stats_l; a.p_in = p_in; a.B = B; a.N = N; a.ka = ka; a.kb = kb; a.wa = 0; a.wb = 0; a.mode = 0;
     a.eps = flow_eps;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = set_lds((const void *)tstats_h1_kernel<NS>, pt_a0n(NS));
-        if (e != hipSuccess) return (int)e;
-        attr = true;
-    }
+    static LdsLimit lim_h1;
+    if (hipError_t e = lim_h1.ensure((const void *)tstats_h1_kernel<NS>, pt_a0n(NS)); e != hipSuccess) return (int)e;
     const dim3 grid((N + TBLK - 1) / TBLK, B);
     hipLaunchKernelGGL(tstats_h1_kernel<NS>, grid, dim3(TW * 64), pt_a0n(NS), s, a, w.part1);
     hipLaunchKernelGGL(tcolsum_kernel, dim3(8), dim3(1024), 0, s, (int)(grid.x * grid.y), 256, w.part1, w.sums);
@@ -1095,13 +1087,9 @@ static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb
     const int nblk = grid.x * grid.y, nb = grid.x;
     const double count = (double)B * N;
     const int lds1 = pt_a0n(NS) + 4096 + (TW * 520 + 256) * 4, lds2 = l_red(NS) + 4096 + TW * XY_WAVE * 2;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = set_lds((const void *)tbwd1_kernel<NS>, lds1);
-        if (e == hipSuccess) e = set_lds((const void *)tbwd2_kernel<NS>, lds2);
-        if (e != hipSuccess) return (int)e;
-        attr = true;
-    }
+    static LdsLimit lim_b1, lim_b2;
+    if (hipError_t e = lim_b1.ensure((const void *)tbwd1_kernel<NS>, lds1); e != hipSuccess) return (int)e;
+    if (hipError_t e = lim_b2.ensure((const void *)tbwd2_kernel<NS>, lds2); e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(tbwd1_kernel<NS>, grid, dim3(TW * 64), lds1, s, a, g_p, g_p2, g_mu, g_lv, dp_in, w.dout, w.part1);
     hipLaunchKernelGGL(tcloudsum_kernel, dim3(B), dim3(520), 0, s, nb, B, w.part1, a.filmb_l, flow_eps, w.pc, dfm_l);
     hipLaunchKernelGGL(tbwd2_kernel<NS>, grid, dim3(TW * 64), lds2, s, a, w.pc, count, dcanon_l, w.dout, w.ubuf, w.part2);

@@ -57,17 +57,24 @@ def allreduce_gradients(parameters, average=True):
     (sum), divide by the world size, scatter back.  13 M parameters = 52 MB for the all_scaled
     model -- one bucket, so RCCL sees one large message per step instead of ~900 small ones."""
     rank, w = world()
-    params = [p for p in parameters if p.grad is not None]
+    # every rank walks ALL trainable parameters in the caller's order, so the flat buffer has the same length
+    # and layout everywhere even if a sub-module produced no gradient on some shard (a missing .grad counts as
+    # zeros and receives the other ranks' average)
+    params = [p for p in parameters if p.requires_grad]
     if w == 1 or not params:
         return 0
-    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     if average:
         flat.div_(w)
     off = 0
     for p in params:
-        n = p.grad.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        n = p.numel()
+        piece = flat[off:off + n].view_as(p)
+        if p.grad is None:
+            p.grad = piece.clone()
+        else:
+            p.grad.copy_(piece)
         off += n
     return flat.numel()
 

@@ -18,11 +18,6 @@ from ..._lib import lib, check, current_stream
 #   "brute"  O(n*m) exact VALU scan at ~80 % of its issue bound, data-independent cost
 #   "mfma"   matrix-core filter (one bf16 MFMA per 32x32 pairs) + exact verification of the few candidates that can
 #            win, fragments built in the kernel; r01: 25 us vs 52 us brute on cfg-2, 76 vs 190 us at B=8, N=8192
-#   "sorted" x-sorted pruned exact scan (pays off only when both clouds cover the same region)
-#   "sym"    every pair evaluated ONCE, row minima per lane + column minima across lanes (csrc/chamfer_sym.hip);
-#            r01: main loop 32 us for both directions (vs 48), but 68 us with its argmin recovery and merge launch
-#   "grid"   quantile 3-D grid in LDS, per-lane cell walk + exact bound (csrc/chamfer_grid.hip): 41 vs 53 us on
-#            uniform cubes, 2-5x SLOWER on surfaces / Gaussian blobs (measured numbers in the file header)
 NN_IMPL = os.environ.get("DPF_CHAMFER_IMPL", "auto")
 EMD_GRAD_TWO_PASS = bool(int(os.environ.get("DPF_EMD_GRAD_TWO_PASS", "0")))   # 1: separate grad1 / grad2 kernels
 EMD_RMW = bool(int(os.environ.get("DPF_EMD_RMW", "0")))   # 1: the reference's per-level read-modify-write of `match`
@@ -31,9 +26,7 @@ EMD_RMW = bool(int(os.environ.get("DPF_EMD_RMW", "0")))   # 1: the reference's p
 def nn_impl_entry(impl):
     """(workspace_bytes, launcher) of a workspace-taking Chamfer implementation"""
     L = lib()
-    return {"mfma": (L.dpf_nndistance_mfma_workspace_bytes, L.dpf_nndistance_mfma),
-            "sorted": (L.dpf_nndistance_workspace_bytes, L.dpf_nndistance_ws),
-            "grid": (L.dpf_nndistance_grid_workspace_bytes, L.dpf_nndistance_grid)}[impl]
+    return {"mfma": (L.dpf_nndistance_mfma_workspace_bytes, L.dpf_nndistance_mfma)}[impl]
 
 
 def _check_input(x, name, dtype=torch.float32):
@@ -69,36 +62,12 @@ def NNDistance(set_d, set_q):
             check(lib().dpf_nndistance_auto(*args, current_stream()), "nndistance_auto")
         elif NN_IMPL == "brute":
             check(lib().dpf_nndistance(*args, current_stream()), "nndistance")
-        elif NN_IMPL == "sym":
-            nbytes = lib().dpf_nndistance_sym_workspace_bytes(b, n, m)
-            ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
-            check(lib().dpf_nndistance_sym(*args, None, ws.data_ptr(), nbytes, current_stream()), "nndistance_sym")
         else:   # same bits; scratch is caller-owned like every other buffer
             sized, fn = nn_impl_entry(NN_IMPL)
             nbytes = sized(b, n, m)
             ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
             check(fn(*args, ws.data_ptr(), nbytes, current_stream()), "nndistance_" + NN_IMPL)
     return [dist1, idx1, dist2, idx2]
-
-
-def NNDistanceCD(set_d, set_q):
-    """NNDistance plus cd (B,) = dist1.mean(1) + dist2.mean(1) (evaluating.py:112) from the symmetric kernel's
-    merge launch -> [dist1, idx1, dist2, idx2, cd]"""
-    _check_input(set_d, "set_d"); _check_input(set_q, "set_q")
-    b, n, m = _dims(set_d, set_q)
-    dev = set_d.device
-    dist1 = torch.empty((b, n), dtype=torch.float32, device=dev)
-    idx1 = torch.empty((b, n), dtype=torch.int32, device=dev)
-    dist2 = torch.empty((b, m), dtype=torch.float32, device=dev)
-    idx2 = torch.empty((b, m), dtype=torch.int32, device=dev)
-    cd = torch.empty((b,), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
-        nbytes = lib().dpf_nndistance_sym_workspace_bytes(b, n, m)
-        ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
-        check(lib().dpf_nndistance_sym(b, n, set_d.data_ptr(), m, set_q.data_ptr(), dist1.data_ptr(), idx1.data_ptr(),
-                                       dist2.data_ptr(), idx2.data_ptr(), cd.data_ptr(), ws.data_ptr(), nbytes,
-                                       current_stream()), "nndistance_sym")
-    return [dist1, idx1, dist2, idx2, cd]
 
 
 def NNDistanceGrad(set_d, set_q, idx1, idx2, grad_dist1, grad_dist2):

@@ -49,17 +49,6 @@ int dpf_nndistance_strided(int b, int n, const float *xyz, long xyz_stride, int 
                            const float *xyz2, long xyz2_stride, float *result, int *result_i,
                            float *result2, int *result2_i, dpf_stream_t stream);
 
-/* Same results as dpf_nndistance, bit for bit (distances AND first-minimum
- * indices), but prunes: clouds are sorted by x once and every query wave scans
- * only the sorted candidates that can still win or tie.  `workspace` is
- * caller-owned scratch of dpf_nndistance_workspace_bytes(b, n, m) bytes
- * (16 B per point).  Falls back to the brute-force kernel when n or m is
- * outside [64, 8192] or the workspace is NULL / too small. */
-size_t dpf_nndistance_workspace_bytes(int b, int n, int m);
-int dpf_nndistance_ws(int b, int n, const float *xyz, int m, const float *xyz2,
-                      float *result, int *result_i, float *result2, int *result2_i,
-                      void *workspace, size_t workspace_bytes, dpf_stream_t stream);
-
 /* Same results as dpf_nndistance, bit for bit, matrix-core filtered: one bf16
  * MFMA per 32x32 pairs bounds every distance to within 2^-14*R2, and only the
  * candidates that can still be the fp32-exact minimiser (or tie with it) are
@@ -81,29 +70,6 @@ int dpf_nndistance_strided_auto(int b, int n, const float *xyz, long xyz_stride,
                                 const float *xyz2, long xyz2_stride, float *result,
                                 int *result_i, float *result2, int *result2_i,
                                 dpf_stream_t stream);   /* dpf_nndistance_strided, same choice */
-
-/* Same results as dpf_nndistance, bit for bit, from ONE evaluation of every pair:
- * (b - a) and (a - b) square to the same bits, so the row minima (direction 1) and
- * the column minima (direction 2) come out of the same pass (csrc/chamfer_sym.hip).
- * cd (optional, may be NULL): b floats, mean(dist1[b]) + mean(dist2[b]) as
- * dpf_chamfer_reduce computes it (evaluating.py:112), emitted by the merge launch.
- * NULL / short workspace -> dpf_nndistance (+ dpf_chamfer_reduce). */
-size_t dpf_nndistance_sym_workspace_bytes(int b, int n, int m);
-int dpf_nndistance_sym(int b, int n, const float *xyz, int m, const float *xyz2,
-                       float *result, int *result_i, float *result2, int *result2_i,
-                       float *cd, void *workspace, size_t workspace_bytes, dpf_stream_t stream);
-
-/* Same results as dpf_nndistance, bit for bit, evaluating only the candidates that
- * can still win: both clouds are counting-sorted into a uniform G^3 grid
- * (G ~ cbrt(n/4) <= 16) and each wave scans the cell rows of a growing box
- * around its 64 spatially coherent queries until no unscanned point can be
- * closer or tie (csrc/chamfer_grid.hip).  Data-dependent cost; degenerates to the
- * full scan, never to a wrong answer.  NULL / short workspace or clouds of
- * < 256 points -> dpf_nndistance. */
-size_t dpf_nndistance_grid_workspace_bytes(int b, int n, int m);
-int dpf_nndistance_grid(int b, int n, const float *xyz, int m, const float *xyz2,
-                        float *result, int *result_i, float *result2, int *result2_i,
-                        void *workspace, size_t workspace_bytes, dpf_stream_t stream);
 
 /* replaces nndistancegrad(...)  src/nndistance.cuh:2, nndistance.cu:149-154.
  * grad_xyz1 / grad_xyz2 are fully overwritten (the zero-fill happens on
