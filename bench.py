@@ -1,23 +1,30 @@
 #!/usr/bin/env python3
 """Headline benchmark: points/s through the L-layer per-point flow + Chamfer.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg3|cfg5] [--layers 14|15|63] [--leg eval|train]
 
-One "step" = one pass of the hot path over one synthetic batch resident in HBM:
-  FiLM conditioner (all layers) -> fused L-layer coupling stack, mode 'direct',
-  eval-BN (lib/networks/decoders.py:54-72 as evaluate() runs it, evaluating.py:70)
-  -> nn_distance(out^T, target) both directions (evaluating.py:110-111)
-  -> per-cloud CD reduction (evaluating.py:112).
-Workload: BASELINE.json configs[1]: B=32 clouds x N=2048 points per GPU, L=14
-coupling layers (first 14 layers of LocalCondRNVPDecoder(n_flows=5)), F=64, G=128.
-N GPUs: one process per GPU (torchrun), every rank runs its own B=32 shard, no
-data-path collective ("weak" scaling); value = all ranks' points / max-rank time.
+One "step" (leg eval, the BASELINE metric) = one pass of the hot path over one synthetic batch resident in HBM:
+  FiLM conditioner (all layers) -> fused L-layer coupling stack, mode 'direct', eval-BN
+  (lib/networks/decoders.py:54-72 as evaluate() runs it, evaluating.py:70)
+  -> nn_distance(out^T, target) both directions (evaluating.py:110-111) -> per-cloud CD reduction (evaluating.py:112).
+Workloads (BASELINE.json `configs`):
+  cfg2 (default)  configs[1]: B=32 clouds x N=2048 per GPU, G=128, L=14 (first 14 layers of n_flows=5); weak scaling
+  cfg3            configs[2]: all-classes model, 64 clouds in total sharded over the ranks, G=512; strong scaling
+  cfg5            configs[4]: 16 clouds of N=M=8192 in total, nn_distance + match_cost (approx-EMD); strong scaling
+Leg train (also reported as `extra.train_step` of the default run): inverse stack in training mode (batch-statistics
+BatchNorm) + PointFlowNLL + backward on a flattened decoder -> ONE all-reduce of the flat gradient (RCCL) -> Adam
+(lib/networks/training.py:37-56 with the collective between :55 and :56).
 
-Prints ONE JSON line (rank 0) carrying `roofline` and `cpu_baseline`.
+N GPUs: one process per GPU.  `--gpus N` without a torchrun environment starts the N ranks itself (children are
+created before this process touches the GPU); under `python -m torch.distributed.run` the ranks read
+RANK/LOCAL_RANK/WORLD_SIZE.  value = all ranks' points / max-over-ranks time.  Rank 0 prints ONE JSON line carrying
+`roofline`, `cpu_baseline` and `parity`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,43 +34,148 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA peak
+XGMI_LINK_GBS = 153.0          # per link and direction; 7 links per GPU
 FLOP_PER_POINT_LAYER = 17152   # 2 branches x (2F|K| + 2F^2 + 2|W|F)
 MFMA_PRODUCTS = {"bf16": 1, "bf16x3": 3, "bf16x6": 6}
+CONFIGS = {
+    #        clouds, per-GPU?, points, latent, scaling
+    "cfg2": dict(clouds=32, per_gpu=True, points=2048, latent=128, scaling="weak",
+                 name="configs[1]: airplane autoencoder shapes, B=32 N=2048 per GPU"),
+    "cfg3": dict(clouds=64, per_gpu=False, points=2048, latent=512, scaling="strong",
+                 name="configs[2]: all-classes autoencoder (all_scaled), 64 clouds sharded over the ranks, G=512"),
+    "cfg5": dict(clouds=16, per_gpu=False, points=8192, latent=128, scaling="strong",
+                 name="configs[4]: dense clouds N=M=8192, 16 clouds sharded over the ranks, Chamfer + approx-EMD"),
+}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: the chip needs a few hundred steps (tens of ms) under load to settle its clocks -- with 20 warm-up steps the
     # same step measures 98-99 us, after 300+ it measures 93 us and stays there
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=300)
-    ap.add_argument("--batch", type=int, default=32, help="clouds per GPU")
-    ap.add_argument("--points", type=int, default=2048)
-    ap.add_argument("--layers", type=int, default=14)
-    ap.add_argument("--latent", type=int, default=128)
-    ap.add_argument("--precision", default=os.environ.get("DPF_PRECISION", "bf16x3"),
-                    choices=sorted(MFMA_PRODUCTS))
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--leg", default="eval", choices=["eval", "train"])
+    ap.add_argument("--batch", type=int, default=None, help="clouds per GPU (overrides the config)")
+    ap.add_argument("--points", type=int, default=None)
+    ap.add_argument("--layers", type=int, default=None, help="coupling layers: 14 (BASELINE metric), 15, 63; train leg default 63")
+    ap.add_argument("--latent", type=int, default=None)
+    ap.add_argument("--precision", default=os.environ.get("DPF_PRECISION", "bf16x3"), choices=sorted(MFMA_PRODUCTS))
     ap.add_argument("--lists", action="store_true", help="also materialise the 3 x L per-layer lists")
-    ap.add_argument("--settle", type=int, default=400,
+    ap.add_argument("--settle", type=int, default=None,
                     help="untimed steps run BEFORE the --warmup steps so that the chip's clocks have settled under this load "
-                         "whatever --warmup is (see above); 0 = none")
+                         "whatever --warmup is; default 400 for the eval leg of cfg2/cfg3, 0 otherwise")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--streams", type=int, default=1,
-                    help="consecutive steps go round-robin over this many streams (each with its own buffers), so the Chamfer "
-                         "kernels of one step share the chip with the flow kernel of the next; 1 (default) = strictly one after "
-                         "another, the regime the roofline numbers and the committed profiles describe")
+                    help="consecutive steps go round-robin over this many streams (each with its own buffers); 1 (default) = "
+                         "strictly one after another, the regime the roofline numbers and the committed profiles describe")
     ap.add_argument("--pipelined", type=int, default=3,
                     help="with --streams 1: also report (outside the timed region, as `pipelined`) the throughput with this many "
                          "steps in flight; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-reps", type=int, default=6)
-    return ap.parse_args()
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra legs of the default run (bf16x6, eager, train step)")
+    ap.add_argument("--train-steps", type=int, default=12, help="timed steps of the `extra.train_step` leg")
+    args = ap.parse_args(argv)
+    cfg = CONFIGS[args.config]
+    if args.steps is None:
+        args.steps = {"cfg5": 10}.get(args.config, 1000) if args.leg == "eval" else 20
+    if args.warmup is None:
+        args.warmup = {"cfg5": 3}.get(args.config, 300) if args.leg == "eval" else 5
+    if args.settle is None:
+        args.settle = 400 if (args.leg == "eval" and args.config != "cfg5") else 0
+    if args.points is None:
+        args.points = cfg["points"]
+    if args.latent is None:
+        args.latent = cfg["latent"]
+    if args.layers is None:
+        args.layers = 14 if args.leg == "eval" else 63
+    return args
 
 
-def build_workload(args, device):
+# ----------------------------------------------------------------------------------------------------------------
+# launching the ranks
+# ----------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as children of THIS process, which has not touched the
+    GPU (no HIP call so far: torch.cuda.device_count() does not initialise it), wait, and exit with their code."""
+    if os.environ.get("DPF_BENCH_BACKEND", "nccl") == "nccl":
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, have))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this driver
+    return subprocess.call(cmd, env=env)
+
+
+def init_ranks(args):
+    """-> (rank, local_rank, world, dist or None).  Fails loudly if the launcher's world size is not --gpus."""
+    if "WORLD_SIZE" not in os.environ:
+        return 0, 0, 1, None
+    world = int(os.environ["WORLD_SIZE"])
+    if world != args.gpus:
+        raise SystemExit("bench.py: launched with WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    rank, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1:
+        return rank, local_rank, 1, None
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend = os.environ.get("DPF_BENCH_BACKEND", "nccl")     # "gloo": the launcher/selftest path of the CPU tests
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend)
+    return rank, local_rank, world, dist
+
+
+def timed_region(run_steps, args, dist, device):
+    """W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides; max over ranks."""
+    run_steps(args.warmup)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def clouds_of_rank(args, rank, world):
+    cfg = CONFIGS[args.config]
+    if args.batch is not None:
+        return args.batch, args.batch * world
+    if cfg["per_gpu"]:
+        return cfg["clouds"], cfg["clouds"] * world
+    from dpf_nets_amd.distributed import shard_bounds
+    lo, hi = shard_bounds(cfg["clouds"], rank, world)
+    if hi - lo < 1:
+        raise SystemExit("bench.py: %s has %d clouds, too few for %d ranks" % (args.config, cfg["clouds"], world))
+    return hi - lo, cfg["clouds"]
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# leg eval: flow (direct, eval-BN) + Chamfer
+# ----------------------------------------------------------------------------------------------------------------
+def build_workload(args, device, batch):
     from dpf_nets_amd import synthetic as FO
     from dpf_nets_amd.networks import LocalCondRNVPDecoder
     n_flows = (args.layers + 2) // 3
@@ -73,24 +185,25 @@ def build_workload(args, device):
     dec = dec.to(device).eval()
     dec.precision = args.precision
     dec.materialize_lists = bool(args.lists)
-    tgt, z, g = FO.synthetic_inputs(0, args.batch, args.points, args.latent)
+    tgt, z, g = FO.synthetic_inputs(0, batch, args.points, args.latent)
     z = torch.from_numpy(z).to(device)
     g = torch.from_numpy(g).to(device)
     tgt_pm = torch.from_numpy(np.ascontiguousarray(tgt.transpose(0, 2, 1))).to(device)   # (B,N,3), resident
     return dec, state, n_flows, z, g, tgt, tgt_pm
 
 
-def make_step(dec, z, g, tgt_pm, L):
+def make_step(dec, z, g, tgt_pm, L, precision=None):
     from dpf_nets_amd.metrics.StructuralLosses import StructuralLossesBackend as BK
     from dpf_nets_amd.networks.utils import chamfer_per_cloud
     stack = dec.stack()
+    precision = precision or dec.precision
 
     def step():
-        p_out, sum_lv, ps, mus, lvs = stack.run(z, g, "direct", dec.precision, want_lists=dec.materialize_lists,
+        p_out, sum_lv, ps, mus, lvs = stack.run(z, g, "direct", precision, want_lists=dec.materialize_lists,
                                                 n_layers=L, want_pointmajor=True)
         d1, i1, d2, i2 = BK.NNDistance(stack.last_pointmajor, tgt_pm)
         cd = chamfer_per_cloud(d1, d2)
-        return p_out, d1, i1, d2, i2, cd
+        return p_out, sum_lv, d1, i1, d2, i2, cd
     return step
 
 
@@ -108,7 +221,7 @@ def time_kernel(fn, reps=20, rounds=5):
     with torch.cuda.graph(graph):
         for _ in range(reps):
             fn()
-    for _ in range(25):                  # settle the clocks under this kernel's load (see --warmup), as in the timed loop
+    for _ in range(25):                  # settle the clocks under this kernel's load, as in the timed loop
         graph.replay()
     torch.cuda.synchronize()
     best = []
@@ -169,9 +282,9 @@ def kernel_timings(dec, z, g, tgt_pm, L, precision):
 
 
 def kernel_timings_in_flight(dec, z, g, tgt_pm, L, precision, n_streams, steps=120, warm=30):
-    """The same durations in the regime of the timed loop: steps round-robin over `n_streams` streams, HIP events on the
-    launch stream around each kernel -- what the rocprofv3 kernel trace of this command reports as average durations
-    (kernels of neighbouring steps share the chip, so each takes longer than alone while the steps take less)."""
+    """The same durations in the regime of a pipelined loop: steps round-robin over `n_streams` streams, HIP events on the
+    launch stream around each kernel (kernels of neighbouring steps share the chip, so each takes longer than alone while
+    the steps take less)."""
     streams = [torch.cuda.Stream() for _ in range(n_streams)]
     sets = []
     for st in streams:
@@ -197,69 +310,94 @@ def kernel_timings_in_flight(dec, z, g, tgt_pm, L, precision, n_streams, steps=1
     return out
 
 
-def cpu_baseline(args, state, n_flows, tgt, budget_s=15.0):
-    """The CPU oracle (kind 'port') timed on this host's cores on a BOUNDED sample of the same
-    workload: whole clouds of the B x N batch, as many as fit ~budget_s of CPU work."""
+def read_traffic(key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc pass (collected by tools/pmc_run.sh
+    with the same command, corrected as MI355X_MICROARCH.md prescribes) -- counters cannot be read inside this process."""
+    tj = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tj):
+        return None, None
+    try:
+        tr = json.load(open(tj))
+        ent = tr.get(key) or {}
+        return ent.get("hbm_bytes"), ent.get("source", "profiles/traffic.json")
+    except Exception:
+        return None, None
+
+
+# ---- the CPU oracle: the checker (parity) and the reported baseline.  Nothing else in this file touches oracle/. -------
+def cpu_baseline_and_parity(args, state, n_flows, batch, tgt, gpu_out, time_it, budget_s=15.0):
+    """Runs the CPU oracle (kind 'port': torch-CPU fp32 restatement of flows.py:95-117 + the C restatement of
+    nndistance.cu) on whole clouds of the workload.
+    parity: the GPU outputs of the first two clouds against it -- flow: norm-wise and elementwise error; Chamfer: the GPU
+    Chamfer of the GPU flow output against the C oracle fed the same (GPU) flow output, bit for bit.
+    cpu_baseline (time_it): as many clouds as fit ~budget_s of CPU work, timed."""
     from oracle import flow_oracle as FO
     from oracle import structural as S
     ncores = min(os.cpu_count() or 1, 32)       # torch-CPU on hundreds of threads thrashes on these small ops
     torch.set_num_threads(ncores)
     st = FO.to_torch(state)
-    _, z, g = FO.synthetic_inputs(0, args.batch, args.points, args.latent)
+    _, z, g = FO.synthetic_inputs(0, batch, args.points, args.latent)
     tgt_pm = np.ascontiguousarray(tgt.transpose(0, 2, 1))
     S.lib()
 
-    def run(nb):
+    def flow(nb):
         tz, tg = torch.from_numpy(z[:nb]), torch.from_numpy(g[:nb])
         with torch.no_grad():
-            ps, _, _ = FO.decoder(st, n_flows, tz, tg, "direct", n_layers=args.layers)
-        out = np.ascontiguousarray(ps[-1].numpy().transpose(0, 2, 1))
-        d1, _, d2, _ = S.nndistance(out, tgt_pm[:nb])
+            ps, _, lvs = FO.decoder(st, n_flows, tz, tg, "direct", n_layers=args.layers)
+        return ps[-1].numpy(), sum(lvs).numpy()
+
+    def run(nb):
+        out, _ = flow(nb)
+        d1, _, d2, _ = S.nndistance(np.ascontiguousarray(out.transpose(0, 2, 1)), tgt_pm[:nb])
         return d1.mean(1) + d2.mean(1)
-    run(1)                                       # warm-up
-    t0 = time.perf_counter(); run(2); t2 = time.perf_counter() - t0          # calibration on 2 clouds
-    nb = int(max(2, min(args.batch, budget_s / max(t2 / 2, 1e-6))))
-    reps, done, t0 = 0, 0, time.perf_counter()
-    while True:
-        run(nb)
-        reps += 1; done += nb
-        dt = time.perf_counter() - t0
-        if dt > budget_s or reps >= 50:
-            break
-    return {"value": done * args.points / dt, "unit": "points/s", "cores": ncores, "kind": "port",
-            "sample": "%d x %d clouds of the workload (N=%d, L=%d): torch-CPU fp32 flow oracle on %d threads + "
-                      "single-thread C Chamfer oracle, %.1f s" % (reps, nb, args.points, args.layers, ncores, dt)}
+
+    nchk = min(2, batch)
+    ref_p, ref_lv = flow(nchk)
+    p_out, sum_lv, d1, i1, d2, i2, cd = [t[:nchk].cpu().numpy() for t in gpu_out]
+
+    def errs(got, ref):
+        scale = float(np.abs(ref).max())
+        e = np.abs(got - ref)
+        return float(e.max() / scale), float(e.max()), int((e > 1e-4 * np.abs(ref) + 1e-5 * scale).sum())
+    rel_p, abs_p, bad_p = errs(p_out, ref_p)
+    rel_l, abs_l, bad_l = errs(sum_lv, ref_lv)
+    r1, j1, r2, j2 = S.nndistance(np.ascontiguousarray(p_out.transpose(0, 2, 1)), tgt_pm[:nchk])
+    parity = {"precision": args.precision, "sample": "%d clouds x %d points, L=%d" % (nchk, args.points, args.layers),
+              "max_rel_vs_oracle": max(rel_p, rel_l), "max_abs_elementwise": max(abs_p, abs_l),
+              "elementwise_violations_rtol1e-4_atol1e-5scale": bad_p + bad_l,
+              "points_max_rel": rel_p, "sum_logvar_max_rel": rel_l,
+              "chamfer_bit_exact": bool(np.array_equal(d1.view(np.uint32), r1.view(np.uint32)) and np.array_equal(i1, j1) and
+                                        np.array_equal(d2.view(np.uint32), r2.view(np.uint32)) and np.array_equal(i2, j2))}
+    base = None
+    if time_it:
+        run(1)                                       # warm-up
+        t0 = time.perf_counter(); run(2); t2 = time.perf_counter() - t0          # calibration on 2 clouds
+        nb = int(max(2, min(batch, budget_s / max(t2 / 2, 1e-6))))
+        reps, done, t0 = 0, 0, time.perf_counter()
+        while True:
+            run(nb)
+            reps += 1; done += nb
+            dt = time.perf_counter() - t0
+            if dt > budget_s or reps >= 50:
+                break
+        base = {"value": done * args.points / dt, "unit": "points/s", "cores": ncores, "kind": "port",
+                "sample": "%d x %d clouds of the workload (N=%d, L=%d): torch-CPU fp32 flow oracle on %d threads + "
+                          "single-thread C Chamfer oracle, %.1f s" % (reps, nb, args.points, args.layers, ncores, dt)}
+    return base, parity
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
-    n_gpus = world if world > 1 else 1
-
-    dec, state, n_flows, z, g, tgt, tgt_pm = build_workload(args, device)
+def leg_eval(args, rank, world, dist, device):
+    batch, global_clouds = clouds_of_rank(args, rank, world)
+    dec, state, n_flows, z, g, tgt, tgt_pm = build_workload(args, device, batch)
     L = args.layers
     step = make_step(dec, z, g, tgt_pm, L)
-
     # first calls: pack weights, set LDS attribute -- outside any capture and outside the timed region
     for _ in range(3):
         out = step()
     torch.cuda.synchronize()
 
     # Every step is one full pass over one batch.  With --streams S > 1 consecutive steps go round-robin over S streams, each
-    # stream with its own captured graph and therefore its own intermediate / output buffers, so up to S steps are in flight
-    # and the Chamfer kernels of one share the chip with the flow kernel of the next; all K steps have finished at the
-    # closing synchronize.
+    # stream with its own captured graph and therefore its own intermediate / output buffers.
     S = max(1, args.streams)
     S_all = max(S, args.pipelined if S == 1 else 0)
     streams = [torch.cuda.Stream() for _ in range(S_all)]
@@ -283,19 +421,7 @@ def main():
                 runners[i % S]()
 
     run_steps(args.settle)
-    run_steps(args.warmup)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed_region(run_steps, args, dist, device)
 
     pipelined = None
     if S_all > S:                        # the same steps with S_all of them in flight, reported beside the headline
@@ -306,78 +432,344 @@ def main():
         torch.cuda.synchronize()
         pipelined = (time.perf_counter() - tp) / args.steps
 
-    # sanity on the outputs of the timed path (cheap, outside the timed region)
-    p_out, d1, i1, d2, i2, cd = out
+    p_out, sum_lv, d1, i1, d2, i2, cd = out     # sanity on the outputs of the timed path (outside the timed region)
     assert torch.isfinite(p_out).all() and torch.isfinite(cd).all() and (d1 >= 0).all()
 
-    if rank == 0:
-        pts_per_step = args.batch * args.points * n_gpus
-        ms_per_step = elapsed / args.steps * 1e3
-        kt_alone = kernel_timings(dec, z, g, tgt_pm, L, args.precision)
-        kt = kernel_timings_in_flight(dec, z, g, tgt_pm, L, args.precision, S) if S > 1 else kt_alone
-        from dpf_nets_amd.metrics.StructuralLosses import StructuralLossesBackend as BK
-        dom = max(("flow_kernel", "nn_kernel"), key=lambda k: kt[k])
-        B, N = args.batch, args.points
-        flow_flops = FLOP_PER_POINT_LAYER * L * B * N
-        flow_ach = flow_flops / (kt["flow_kernel"] * 1e-6) / 1e12
-        nn_bytes = B * (N + N) * 20                         # 12 B in + 8 B out per point
-        nn_ach = nn_bytes / (kt["nn_kernel"] * 1e-6) / 1e9
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tj):
-            try:
-                tr = json.load(open(tj))
-                key = "%s/B%d_N%d_L%d_%s" % (dom, B, N, L, args.precision)
-                traffic = (tr.get(key) or {}).get("hbm_bytes")
-            except Exception:
-                traffic = None
-        if dom == "flow_kernel":
-            roof = {"kernel": "flow_kernel<%s>" % args.precision, "bound": "mfma", "achieved": flow_ach,
-                    "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": flow_ach / MFMA_BF16_PEAK_TF,
-                    "traffic": traffic,
-                    "note": "algorithmic FLOPs (17152/pt/layer); the split precision issues %dx the products of "
-                            "the 64x64 contraction on the matrix cores" % MFMA_PRODUCTS[args.precision]}
-        else:
-            roof = {"kernel": "nn_kernel", "bound": "hbm", "achieved": nn_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": nn_ach / HBM_PEAK_GBS, "traffic": traffic,
-                    "note": "exact Chamfer is compute bound (AI ~800 FLOP/B); HBM fraction is tiny by construction"}
-        roof["kernels_us"] = kt
-        roof["kernels_us_alone"] = kt_alone
-        if S > 1:
-            roof["note"] += "; durations are those of the timed regime (%d steps in flight share the chip: each kernel takes " \
-                            "longer than alone, the steps take less), kernels_us_alone = each kernel by itself" % S
-        roof["flow_algorithmic_tflops"] = flow_ach
-        roof["chamfer_algorithmic_gbs"] = nn_ach
-        roof["chamfer_pair_evals_per_s"] = 2.0 * B * N * N / (kt["nn_kernel"] * 1e-6)
-        line = {
-            "metric": "points/sec through %d-layer flow + Chamfer, B=%d N=%d" % (L, B, N),
-            "value": pts_per_step / (elapsed / args.steps), "unit": "points/s", "n_gpus": n_gpus,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.precision + " MFMA operands, fp32 accumulate/points",
+    extra = {}
+    if not args.no_extra and not args.no_graph and S == 1:
+        extra = eval_extras(args, dec, z, g, tgt_pm, L, step, streams[0])
+    if rank != 0:
+        return None, extra
+    B, N = batch, args.points
+    pts_per_step = args.points * global_clouds
+    kt_alone = kernel_timings(dec, z, g, tgt_pm, L, args.precision)
+    kt = kernel_timings_in_flight(dec, z, g, tgt_pm, L, args.precision, S) if S > 1 else kt_alone
+    from dpf_nets_amd.metrics.StructuralLosses import StructuralLossesBackend as BK
+    dom = max(("flow_kernel", "nn_kernel"), key=lambda k: kt[k])
+    flow_flops = FLOP_PER_POINT_LAYER * L * B * N
+    flow_ach = flow_flops / (kt["flow_kernel"] * 1e-6) / 1e12
+    nn_bytes = B * (N + N) * 20                         # 12 B in + 8 B out per point
+    nn_ach = nn_bytes / (kt["nn_kernel"] * 1e-6) / 1e9
+    traffic, tsrc = read_traffic("%s/B%d_N%d_L%d_%s" % (dom, B, N, L, args.precision))
+    if dom == "flow_kernel":
+        roof = {"kernel": "flow_kernel<%s>" % args.precision, "bound": "mfma", "achieved": flow_ach,
+                "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": flow_ach / MFMA_BF16_PEAK_TF,
+                "traffic": traffic,
+                "note": "algorithmic FLOPs (17152/pt/layer) per launch / HIP-event launch duration; the split precision "
+                        "issues %dx the products of the 64x64 contraction on the matrix cores" % MFMA_PRODUCTS[args.precision]}
+    else:
+        roof = {"kernel": "nn_kernel", "bound": "hbm", "achieved": nn_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": nn_ach / HBM_PEAK_GBS, "traffic": traffic,
+                "note": "exact Chamfer is compute bound (AI ~800 FLOP/B); HBM fraction is tiny by construction"}
+    roof["traffic_source"] = tsrc and (tsrc + " (rocprofv3 --pmc pass of this command, not measured in this run)")
+    roof["kernels_us"] = kt
+    roof["kernels_us_alone"] = kt_alone
+    if S > 1:
+        roof["note"] += "; durations are those of the timed regime (%d steps in flight share the chip)" % S
+    roof["flow_algorithmic_tflops"] = flow_ach
+    roof["chamfer_algorithmic_gbs"] = nn_ach
+    roof["chamfer_pair_evals_per_s"] = 2.0 * B * N * N / (kt["nn_kernel"] * 1e-6)
+    cfg = CONFIGS[args.config]
+    line = {
+        "metric": "points/sec through %d-layer flow + Chamfer, B=%d N=%d" % (L, B, N),
+        "value": pts_per_step / (elapsed / args.steps), "unit": "points/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": cfg["scaling"] if args.batch is None else "weak", "vs_baseline": None,
+        "dtype": args.precision + " MFMA operands, fp32 accumulate/points",
+        "data": "synthetic",
+        "config": {"workload": "%s: %d coupling layers (first %d of LocalCondRNVPDecoder(n_flows=%d)), direct/eval-BN, + "
+                               "nn_distance both directions + CD reduction" % (cfg["name"], L, L, n_flows),
+                   "clouds_per_gpu": B, "points_per_cloud": N, "hidden": 64, "latent": args.latent,
+                   "global_clouds": pts_per_step // N, "per_layer_lists": bool(args.lists),
+                   "launch": ("eager" if args.no_graph else "hipGraph replay") +
+                   (", consecutive steps round-robin over %d streams with their own buffers" % S if S > 1 else ""),
+                   "steps_in_flight": S, "settle_steps": args.settle, "parallelism": "clouds sharded, no collective",
+                   "chamfer_impl": BK.NN_IMPL + (" (matrix-core filtered exact search at this size)" if BK.NN_IMPL == "auto" and
+                                                 2.0 * B * N * N >= 1e8 and B * 2 * ((N + 255) // 256) >= 64 else "")},
+        "roofline": roof,
+    }
+    if pipelined is not None:
+        line["pipelined"] = {
+            "steps_in_flight": S_all, "value": batch * args.points / pipelined,
+            "unit": "points/s per GPU", "ms_per_step": pipelined * 1e3,
+            "note": "consecutive steps round-robin over %d streams with their own buffers (bench.py --streams %d makes this "
+                    "the timed regime): the Chamfer kernels of one step share the chip with the flow kernel of the next" %
+                    (S_all, S_all)}
+    base, parity = cpu_baseline_and_parity(args, state, n_flows, batch, tgt, out,
+                                           time_it=not args.no_cpu_baseline and world == 1)   # CPU timing at N = 1 only
+    line["cpu_baseline"] = base
+    line["parity"] = parity
+    return line, extra
+
+
+def eval_extras(args, dec, z, g, tgt_pm, L, step, stream):
+    """Outside the timed region, every rank: (a) the same step launched eagerly (what a caller that cannot capture pays),
+    (b) the fp32-class precision (bf16x6) beside the benched one."""
+    out = {}
+    try:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            step()
+        torch.cuda.synchronize()
+        out["eager_ms_per_step"] = (time.perf_counter() - t0) / 200 * 1e3
+    except Exception as e:       # noqa: BLE001 -- an extra must never cost the headline line
+        out["eager_error"] = repr(e)
+    other = "bf16x6" if args.precision != "bf16x6" else "bf16x3"
+    try:
+        st2 = make_step(dec, z, g, tgt_pm, L, precision=other)
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            o2 = st2()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            o2 = st2()
+        with torch.cuda.stream(stream):
+            for _ in range(100):
+                graph.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(300):
+                graph.replay()
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 300
+        out[other] = {"ms_per_step": dt * 1e3, "value": z.shape[0] * z.shape[2] / dt, "unit": "points/s per GPU",
+                      "max_rel_points_vs_%s" % args.precision:
+                          float((o2[0] - step()[0]).abs().max() / o2[0].abs().max())}
+    except Exception as e:       # noqa: BLE001
+        out[other + "_error"] = repr(e)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# leg cfg5: Chamfer + approx-EMD on dense clouds
+# ----------------------------------------------------------------------------------------------------------------
+def leg_cfg5(args, rank, world, dist, device):
+    from dpf_nets_amd import synthetic as FO
+    from dpf_nets_amd.metrics.StructuralLosses import StructuralLossesBackend as BK
+    from dpf_nets_amd.networks.utils import chamfer_per_cloud
+    batch, global_clouds = clouds_of_rank(args, rank, world)
+    N = args.points
+    tgt, z, _ = FO.synthetic_inputs(0, batch, N, 16)
+    a = torch.from_numpy(np.ascontiguousarray(tgt.transpose(0, 2, 1))).to(device)
+    # second cloud: the target jittered and permuted, so that the matching is non-trivial but of the same extent
+    rng = np.random.default_rng(1)
+    perm = rng.permutation(N)
+    b_np = (tgt.transpose(0, 2, 1)[:, perm] + 0.02 * rng.standard_normal((batch, N, 3))).astype(np.float32)
+    b = torch.from_numpy(np.ascontiguousarray(b_np)).to(device)
+
+    def step():
+        d1, i1, d2, i2 = BK.NNDistance(a, b)
+        cd = chamfer_per_cloud(d1, d2)
+        match, temp, cost = BK.ApproxMatchCost(a, b)
+        return d1, i1, d2, i2, cd, cost
+
+    out = step()
+    torch.cuda.synchronize()
+
+    def run_steps(n):
+        for _ in range(n):
+            step()
+    elapsed = timed_region(run_steps, args, dist, device)
+    if rank != 0:
+        return None, {}
+
+    def ev_time(fn, reps=5):
+        fn(); torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            fn()
+        e.record(); e.synchronize()
+        return s.elapsed_time(e) / reps * 1e3
+    t_nn = ev_time(lambda: BK.NNDistance(a, b))
+    t_emd = ev_time(lambda: BK.ApproxMatchCost(a, b))
+    emd_bytes = 80.0 * batch * N * N            # SURVEY 8(d): zero-init 4 + 9 levels x 8 (RMW) + matchcost read 4, per pair
+    ach = emd_bytes / (t_emd * 1e-6) / 1e9
+    traffic, tsrc = read_traffic("approxmatch_cost/B%d_N%d" % (batch, N))
+    roof = {"kernel": "approxmatch + matchcost (dpf_approxmatch_cost_ws: 27 level passes + 1 materialise/cost pass)",
+            "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": tsrc,
+            "note": "algorithmic bytes = the reference's 80*n*m B per cloud (RMW of `match` per level); this implementation keeps "
+                    "the level state in a workspace and writes `match` once, so its real HBM traffic is far below that and the "
+                    "op is exp/VALU-bound: `achieved` above the HBM peak is possible and means just that",
+            "kernels_us": {"nn_distance": t_nn, "approxmatch_cost": t_emd},
+            "chamfer_pair_evals_per_s": 2.0 * batch * N * N / (t_nn * 1e-6),
+            "emd_exp_per_s": 36.0 * batch * N * N / (t_emd * 1e-6)}
+    line = {"metric": "points/sec through Chamfer + approx-EMD, B=%d N=M=%d" % (batch, N),
+            "value": global_clouds * N / (elapsed / args.steps), "unit": "points/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if args.batch is None else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": CONFIGS["cfg5"]["name"] + ": nn_distance both directions + CD reduction + match_cost "
+                                   "(approxmatch + matchcost)", "clouds_per_gpu": batch, "points_per_cloud": N,
+                       "global_clouds": global_clouds, "launch": "eager", "parallelism": "clouds sharded, no collective"},
+            "roofline": roof}
+    base = parity = None
+    if world == 1:
+        from oracle import structural as S     # the checker / CPU baseline leg
+        an, bn = a[:1].cpu().numpy(), b[:1].cpu().numpy()
+        t0 = time.perf_counter()
+        r1, j1, r2, j2 = S.nndistance(an, bn)
+        timed = not args.no_cpu_baseline
+        if timed:
+            m_ref, _ = S.approxmatch(an, bn)
+            c_ref = S.matchcost(an, bn, m_ref)
+        dt = time.perf_counter() - t0
+        d1, i1, d2, i2, cd, cost = [t[:1].cpu().numpy() for t in out]
+        parity = {"sample": "1 cloud of the workload (n=m=%d)" % N,
+                  "chamfer_bit_exact": bool(np.array_equal(d1.view(np.uint32), r1.view(np.uint32)) and np.array_equal(i1, j1) and
+                                            np.array_equal(d2.view(np.uint32), r2.view(np.uint32)) and np.array_equal(i2, j2))}
+        if timed:
+            parity["emd_cost_rel_err_vs_oracle"] = float(abs(cost[0] - c_ref[0]) / abs(c_ref[0]))
+            parity["note"] = "approx-EMD oracle is parity-unpinned (the reference has no CPU path; oracle/structural_oracle.c header)"
+            base = {"value": N / dt, "unit": "points/s", "cores": 1, "kind": "port",
+                    "sample": "1 of the %d clouds (n=m=%d): single-thread C oracle nndistance + approxmatch + matchcost, %.1f s"
+                              % (batch, N, dt)}
+    line["cpu_baseline"] = base
+    line["parity"] = parity
+    return line, {}
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# leg train: inverse stack (training-mode BN) + NLL + backward + ONE all-reduce + Adam
+# ----------------------------------------------------------------------------------------------------------------
+def train_step_leg(args, rank, world, dist, device, batch, layers, steps, warmup):
+    from dpf_nets_amd import networks as nets, synthetic as SY
+    from dpf_nets_amd import distributed as D
+    if layers % 3:
+        raise SystemExit("train leg: --layers must be a multiple of 3 (whole CondRealNVPFlow3DTriple's)")
+    n_flows, G, N = layers // 3, args.latent, args.points
+    torch.manual_seed(0)                      # same initial weights on every rank (replicas)
+    dec = nets.LocalCondRNVPDecoder(n_flows, 64, G).to(device).train()
+    store = dec.flatten_parameters()
+    opt = nets.Adam(dec.parameters(), lr=2.56e-4, weight_decay=1e-6, betas=(0.9, 0.999), amsgrad=True)
+    tgt, _, g = SY.synthetic_inputs(3 + rank, batch, N, G)          # every rank its own shard of clouds
+    tp, tg = torch.from_numpy(tgt).to(device), torch.from_numpy(g).to(device)
+    pm, pl = torch.zeros(batch, 3, N, device=device), torch.full((batch, 3, N), -3.6, device=device)
+    nll = nets.PointFlowNLL()
+    ev = []
+
+    def step(record=False):
+        opt.zero_grad(set_to_none=True)
+        ps, mus, lvs = dec(tp, tg, mode="inverse")
+        loss = nll(ps + [tp], [pm] + mus, [pl] + lvs)                # models.py:169-171, losses.py:48
+        loss.backward()                                              # training.py:55
+        if record:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        n = D.allreduce_flat_gradients(store)                        # the ONE collective of the step
+        if record:
+            e1.record()
+            ev.append((e0, e1))
+        opt.step()                                                   # training.py:56
+        return loss, n
+
+    for _ in range(warmup):
+        loss, nred = step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, nred = step(record=True)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ar_us = float(np.median([a.elapsed_time(b) for a, b in ev])) * 1e3
+    nbytes = store.flat_g.numel() * 4
+    info = {"ms_per_step": elapsed / steps * 1e3, "value": batch * world * N / (elapsed / steps), "unit": "points/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "layers": layers, "clouds_per_gpu": batch, "points_per_cloud": N,
+            "latent": G, "loss": float(loss), "precision": os.environ.get("DPF_TRAIN_PRECISION", "bf16x6"),
+            "what": "zero_grad + inverse stack (batch-stat BN) + PointFlowNLL + backward + all-reduce(flat_g) + Adam (AMSGrad mirror)",
+            "flat_gradient_bytes": nbytes, "collectives_per_step": 1 if world > 1 else 0,
+            "algorithmic_tflops": 3.0 * FLOP_PER_POINT_LAYER * layers * batch * N / (elapsed / steps) / 1e12}
+    if world > 1:
+        bus = 2.0 * (world - 1) / world * nbytes / (ar_us * 1e-6) / 1e9
+        info["allreduce"] = {"us": ar_us, "elements": int(nred), "bus_GBps": bus, "backend": dist.get_backend(),
+                             "xgmi_budget_GBps": 7 * XGMI_LINK_GBS, "frac_of_xgmi_budget": bus / (7 * XGMI_LINK_GBS),
+                             "note": "HIP events on the compute stream around dist.all_reduce(flat_g) (includes the wait for the "
+                                     "collective's stream); bus = 2(n-1)/n * bytes / time"}
+    return info
+
+
+def leg_train(args, rank, world, dist, device):
+    batch, global_clouds = clouds_of_rank(args, rank, world)
+    info = train_step_leg(args, rank, world, dist, device, batch, args.layers, args.steps, args.warmup)
+    if rank != 0:
+        return None, {}
+    cfg = CONFIGS[args.config]
+    tf = info["algorithmic_tflops"]
+    line = {"metric": "points/sec through a training step of the %d-layer flow decoder, B=%d N=%d" % (args.layers, batch, args.points),
+            "value": info["value"], "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": info["ms_per_step"], "higher_is_better": True, "scaling": cfg["scaling"] if args.batch is None else "weak",
+            "vs_baseline": None, "dtype": info["precision"] + " MFMA operands, fp32 accumulate/points/gradients",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: %d coupling layers (first %d of LocalCondRNVPDecoder(n_flows=%d)), "
-                                   "direct/eval-BN, + nn_distance both directions + CD reduction" % (L, L, n_flows),
-                       "clouds_per_gpu": B, "points_per_cloud": N, "hidden": 64, "latent": args.latent,
-                       "global_clouds": B * n_gpus, "per_layer_lists": bool(args.lists),
-                       "launch": ("eager" if args.no_graph else "hipGraph replay") +
-                       (", consecutive steps round-robin over %d streams with their own buffers" % S if S > 1 else ""),
-                       "steps_in_flight": S, "settle_steps": args.settle, "parallelism": "clouds sharded, no collective",
-                       "chamfer_impl": BK.NN_IMPL + (" (matrix-core filtered exact search at this size)" if BK.NN_IMPL == "auto" and
-                                                     2.0 * B * N * N >= 1e8 and B * 2 * ((N + 255) // 256) >= 64 else "")},
-            "roofline": roof,
-        }
-        if pipelined is not None:
-            line["pipelined"] = {
-                "steps_in_flight": S_all, "value": args.batch * args.points / pipelined,
-                "unit": "points/s per GPU", "ms_per_step": pipelined * 1e3,
-                "kernels_us": kernel_timings_in_flight(dec, z, g, tgt_pm, L, args.precision, S_all),
-                "note": "consecutive steps round-robin over %d streams with their own buffers (bench.py --streams %d makes this "
-                        "the timed regime): the Chamfer kernels of one step share the chip with the flow kernel of the next, "
-                        "each kernel takes longer than alone, the steps take less" % (S_all, S_all)}
-        if not args.no_cpu_baseline and n_gpus == 1:      # the CPU oracle is timed at N = 1 only
-            line["cpu_baseline"] = cpu_baseline(args, state, n_flows, tgt)
-        else:
-            line["cpu_baseline"] = None
+            "config": {"workload": cfg["name"] + ": " + info["what"], "clouds_per_gpu": batch, "points_per_cloud": args.points,
+                       "global_clouds": batch * world, "layers": args.layers, "latent": args.latent, "launch": "eager",
+                       "parallelism": "data parallel replicas, one all-reduce of the flat gradient per step"},
+            "roofline": {"kernel": "training step (tbwd2/tbwd1/tstats_h1/flow kernels, csrc/flow_train.hip)", "bound": "mfma",
+                         "achieved": tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TF,
+                         "traffic": None, "note": "whole step incl. host: 3 x forward FLOPs (forward + two backward contractions) "
+                                                  "/ step time"},
+            "train_step": info, "cpu_baseline": None, "parity": None}
+    return line, {}
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def selftest_ranks(args, rank, world, dist):
+    """DPF_BENCH_SELFTEST=1: what the CPU test of the launcher runs instead of the GPU legs -- proves that `--gpus N`
+    started N ranks which see each other (gloo), and that the max-over-ranks reduction and the flat all-reduce work."""
+    t = torch.tensor([float(rank + 1)])
+    flat = torch.arange(8, dtype=torch.float32) * (rank + 1)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(flat)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "max_rank_plus_1": float(t.item()),
+                          "flat_sum_ok": bool(torch.equal(flat, torch.arange(8, dtype=torch.float32) * (world * (world + 1) / 2)))}))
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+    rank, local_rank, world, dist = init_ranks(args)
+    if os.environ.get("DPF_BENCH_SELFTEST") == "1":
+        selftest_ranks(args, rank, world, dist)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    if args.leg == "train":
+        line, extra = leg_train(args, rank, world, dist, device)
+    elif args.config == "cfg5":
+        line, extra = leg_cfg5(args, rank, world, dist, device)
+    else:
+        line, extra = leg_eval(args, rank, world, dist, device)
+        if not args.no_extra:
+            # the training step with its single gradient all-reduce, on the default run too: at N > 1 this is where RCCL carries
+            # the 40 / 52 MB flat gradient over xGMI (every rank takes part; reported by rank 0)
+            try:
+                batch, _ = clouds_of_rank(args, rank, world)
+                extra["train_step"] = train_step_leg(args, rank, world, dist, device, batch, 63, args.train_steps, 3)
+            except Exception as e:       # noqa: BLE001 -- never lose the headline line to an extra
+                extra["train_step_error"] = repr(e)
+    if rank == 0:
+        if extra:
+            line["extra"] = extra
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

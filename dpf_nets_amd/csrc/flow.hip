@@ -398,108 +398,151 @@ __device__ __forceinline__ void branch_tile(const uint8_t *lb, int br, int lane,
     ob = ob2.x + ob2.y;
 }
 
-// -DDPF_FLOW_PAIRED_BRANCHES: both conditioner branches (logvar, mu) of one layer for one tile, stage by stage with
-// the branches interleaved: they depend on the same input only, so a wave has twice the independent work in flight
-// (4 input MFMAs back to back, 4 accumulators in the W1 contraction).  Measured r01 at cfg-2: 67.5 us vs 64.8 us for
-// the two branches one after the other (248 vs 72 VGPRs; bit-identical) -- not the default.
+// ---------------------------------------------------------------------------------------------------------
+// Both conditioner branches of one layer for one 32-point tile as ONE software pipeline (NS <= 2).
+//
+// Measured on gfx950 (tools/ubench/mfma_fill.hip, profiles/r02_mfma_fill.txt): a v_mfma_f32_32x32x16_bf16 occupies the
+// SIMD's matrix pipe for 32 cycles, and up to SIX plain VALU instructions issued behind it are free (32.3 cycles per
+// MFMA with 6 fillers, whether the fillers come from the same wave or from the other wave of the SIMD); every further
+// one costs ~4.3 cycles, and a packed-f32 instruction (v_pk_fma/add/mul_f32) costs +16 cycles -- so this file is
+// compiled with -fno-slp-vectorize and the contraction below is scalar.  The two branches (logvar, mu) depend on the
+// layer input only, so their stages interleave: the VALU work of one k-step (relu + bf16 hi/lo split of 8 accumulator
+// registers: 32 instructions) and the LDS fragment reads of the next k-step ride in the issue gaps of the 6 MFMAs of
+// the current k-step.  Every `group` below is one scheduling region (fenced by sched_barrier) holding <= 6 MFMAs and
+// the VALU / DS work to hide behind them; sched_group_barrier pins the MFMA : VALU : DS-read order inside it.
+//
+//   G0      4 input MFMAs (A t0, A t1, B t0, B t1)          | split A k0
+//   G1..G3  chain A k0..k2 (6 MFMAs each at bf16x3)          | split A k1..k3, A fragments of the next k-step, D of B
+//   G4      chain A k3                                       | split B k0
+//   G5..G7  chain B k0..k2                                   | split B k1..k3, B fragments, output weights of A
+//   G8      chain B k3                                       | output contraction of A
+//   tail    output contraction of B
 template <int NS, bool TWO>
-__device__ __forceinline__ void branch_pair(const uint8_t *lb, int lane, int h, u32x4 b0, float (&o)[2][2]) {
+__device__ __forceinline__ void layer_pipe(const uint8_t *lb, int lane, int h, u32x4 b0, float (&o)[2][2]) {
+    static_assert(NS <= 2, "the pipelined body keeps both branches' fragments in registers: bf16 / bf16x3 only");
     constexpr int A0OFF = p_a0_off(NS), FILMOFF = p_layer_bytes(NS);
     typedef Terms<NS> TT;
+    const float *film = (const float *)(lb + FILMOFF);
     const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // ---- h0 = relu(BN0(W0 x))
-    f32x16 acc0[2][2];
-#pragma unroll
-    for (int br = 0; br < 2; ++br)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-            acc0[br][t] = mfma(*(const u32x4 *)(lb + A0OFF + ((br * 2 + t) * 64 + lane) * 16), b0, z16);
+    f32x16 acc0[2][2], acc1[2][2];
     u32x4 bfrag[2][NS][4];
+    u32x4 af[2][2 * NS];
+
+    auto ld_frag = [&](int br, int ks, u32x4 (&dst)[2 * NS]) {     // the NS parts of both M tiles of k-step ks
 #pragma unroll
-    for (int br = 0; br < 2; ++br)
+        for (int part = 0; part < NS; ++part)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const float v0 = relu(acc0[br][t][r]), v1 = relu(acc0[br][t][r + 1]);
-                const int s = 2 * t + (r >> 3), d = (r & 7) >> 1;
-                if (NS == 1) {
-                    bfrag[br][0][s][d] = pack_bf16_rne(v0, v1);
-                } else if (NS == 2) {
-                    float l0, l1;
-                    split_hi(v0, l0); split_hi(v1, l1);
-                    bfrag[br][0][s][d] = pack_bf16_trunc(v0, v1);
-                    bfrag[br][1][s][d] = pack_bf16_rne(l0, l1);
-                } else {
-                    float l0, l1, m0, m1;
-                    split_hi(v0, l0); split_hi(v1, l1);
-                    split_hi(l0, m0); split_hi(l1, m1);
-                    bfrag[br][0][s][d] = pack_bf16_trunc(v0, v1);
-                    bfrag[br][1][s][d] = pack_bf16_trunc(l0, l1);
-                    bfrag[br][2][s][d] = pack_bf16_rne(m0, m1);
-                }
-            }
-    // ---- h1 = W1 h0 + D
-    const float *fl = (const float *)(lb + FILMOFF);
-    f32x16 acc1[2][2];
-#pragma unroll
-    for (int br = 0; br < 2; ++br)
-#pragma unroll
-        for (int tp = 0; tp < 2; ++tp)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 dv = *(const f32x4 *)(fl + br * FILM_BR_FLOATS + 32 * tp + 8 * q + 4 * h);
-                acc1[br][tp][4 * q + 0] = dv.x; acc1[br][tp][4 * q + 1] = dv.y;
-                acc1[br][tp][4 * q + 2] = dv.z; acc1[br][tp][4 * q + 3] = dv.w;
-            }
-    u32x4 af[2][2][2 * NS];
-    auto load_batch = [&](int ks, u32x4 (&dst)[2][2 * NS]) {
-#pragma unroll
-        for (int br = 0; br < 2; ++br)
-#pragma unroll
-            for (int part = 0; part < NS; ++part)
-#pragma unroll
-                for (int tp = 0; tp < 2; ++tp)
-                    dst[br][part * 2 + tp] = *(const u32x4 *)(lb + part * P_A1_PART + (((br * 2 + tp) * 4 + ks) * 64 + lane) * 16);
+            for (int tp = 0; tp < 2; ++tp)
+                dst[part * 2 + tp] = *(const u32x4 *)(lb + part * P_A1_PART + (((br * 2 + tp) * 4 + ks) * 64 + lane) * 16);
     };
-    load_batch(0, af[0]);
+    auto init_acc1 = [&](int br, int tp) {                          // accumulator starts at the folded FiLM shift D
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        if (ks + 1 < 4) load_batch(ks + 1, af[(ks + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 dv = *(const f32x4 *)(film + br * FILM_BR_FLOATS + 32 * tp + 8 * q + 4 * h);
+            acc1[br][tp][4 * q + 0] = dv.x; acc1[br][tp][4 * q + 1] = dv.y;
+            acc1[br][tp][4 * q + 2] = dv.z; acc1[br][tp][4 * q + 3] = dv.w;
+        }
+    };
+    // relu + bf16 split of the 8 accumulator registers that form the B fragment(s) of k-step ks: 32 VALU at bf16x3
+    auto split_ks = [&](int br, int ks) {
+        const int t = ks >> 1;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int r = 8 * (ks & 1) + 2 * d;
+            const float v0 = relu(acc0[br][t][r]), v1 = relu(acc0[br][t][r + 1]);
+            if (NS == 1) {
+                bfrag[br][0][ks][d] = pack_bf16_rne(v0, v1);
+            } else {
+                float l0, l1;
+                split_hi(v0, l0); split_hi(v1, l1);
+                bfrag[br][0][ks][d] = pack_bf16_trunc(v0, v1);
+                bfrag[br][NS - 1][ks][d] = pack_bf16_rne(l0, l1);
+            }
+        }
+    };
+    auto chain_ks = [&](int br, int ks, const u32x4 (&a)[2 * NS]) {
 #pragma unroll
         for (int term = 0; term < TT::N; ++term)
 #pragma unroll
-            for (int br = 0; br < 2; ++br)
+            for (int tp = 0; tp < 2; ++tp)
+                acc1[br][tp] = mfma(a[TT::A[term] * 2 + tp], bfrag[br][TT::B[term]][ks], acc1[br][tp]);
+    };
+    // o = W2' relu(h1 + D) over this lane's 32 features: scalar FMAs on two partial sums per output (no packed f32)
+    float pa[2][2], pb[2][2];                                      // [br][even/odd]
+    auto contract = [&](int br, int tp) {
+        const float *wa = film + br * FILM_BR_FLOATS + 64, *wb2 = wa + 64;
 #pragma unroll
-                for (int tp = 0; tp < 2; ++tp)
-                    acc1[br][tp] = mfma(af[ks & 1][br][TT::A[term] * 2 + tp], bfrag[br][TT::B[term]][ks], acc1[br][tp]);
+        for (int q = 0; q < 4; ++q) {
+            const int f0 = 32 * tp + 8 * q + 4 * h;
+            const f32x4 wa4 = *(const f32x4 *)(wa + f0);
+            const float r0 = relu(acc1[br][tp][4 * q + 0]), r1 = relu(acc1[br][tp][4 * q + 1]);
+            const float r2 = relu(acc1[br][tp][4 * q + 2]), r3 = relu(acc1[br][tp][4 * q + 3]);
+            pa[br][0] = __builtin_fmaf(wa4.x, r0, pa[br][0]); pa[br][1] = __builtin_fmaf(wa4.y, r1, pa[br][1]);
+            pa[br][0] = __builtin_fmaf(wa4.z, r2, pa[br][0]); pa[br][1] = __builtin_fmaf(wa4.w, r3, pa[br][1]);
+            if (TWO) {
+                const f32x4 wb4 = *(const f32x4 *)(wb2 + f0);
+                pb[br][0] = __builtin_fmaf(wb4.x, r0, pb[br][0]); pb[br][1] = __builtin_fmaf(wb4.y, r1, pb[br][1]);
+                pb[br][0] = __builtin_fmaf(wb4.z, r2, pb[br][0]); pb[br][1] = __builtin_fmaf(wb4.w, r3, pb[br][1]);
+            }
+        }
+    };
+#pragma unroll
+    for (int br = 0; br < 2; ++br) { pa[br][0] = pa[br][1] = 0.f; pb[br][0] = pb[br][1] = 0.f; }
+
+    // `n` MFMAs, each followed by `v` VALU and (first `ds` of them) one DS read
+#define DPF_PIPE_PATTERN(n, v, ds)                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {                        \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      \
+        __builtin_amdgcn_sched_group_barrier(0x002, (v), 0);                    \
+        if (i_ < (ds)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       \
+    }
+    constexpr int NM = 2 * TT::N;      // MFMAs per k-step
+    constexpr int VS = NS == 1 ? 16 : 32;   // VALU of one split_ks
+    constexpr int VG = (VS + NM - 1) / NM;  // per MFMA gap
+
+    // ---- G0: input MFMAs (h0 pre-activation, fp32-accurate), A's first split
+    {
+        const u32x4 a00 = *(const u32x4 *)(lb + A0OFF + ((0 * 2 + 0) * 64 + lane) * 16);
+        const u32x4 a01 = *(const u32x4 *)(lb + A0OFF + ((0 * 2 + 1) * 64 + lane) * 16);
+        const u32x4 a10 = *(const u32x4 *)(lb + A0OFF + ((1 * 2 + 0) * 64 + lane) * 16);
+        const u32x4 a11 = *(const u32x4 *)(lb + A0OFF + ((1 * 2 + 1) * 64 + lane) * 16);
+        init_acc1(0, 0); init_acc1(0, 1);
+        ld_frag(0, 0, af[0]);
+        acc0[0][0] = mfma(a00, b0, z16);
+        acc0[0][1] = mfma(a01, b0, z16);
+        acc0[1][0] = mfma(a10, b0, z16);
+        acc0[1][1] = mfma(a11, b0, z16);
+        split_ks(0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- G1..G4: chain A
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        if (ks + 1 < 4) ld_frag(0, ks + 1, af[(ks + 1) & 1]); else ld_frag(1, 0, af[(ks + 1) & 1]);
+        if (ks == 1) init_acc1(1, 0);
+        if (ks == 2) init_acc1(1, 1);
+        chain_ks(0, ks, af[ks & 1]);
+        if (ks + 1 < 4) split_ks(0, ks + 1); else split_ks(1, 0);
+        DPF_PIPE_PATTERN(NM, VG, 2 * NS + 4)
         __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- o = W2' relu(h1 + D): packed FMAs on (even, odd) partial sums over natural register pairs (see branch_tile)
+    // ---- G5..G8: chain B; A's output contraction rides in the later groups
 #pragma unroll
-    for (int br = 0; br < 2; ++br) {
-        const float *wa = fl + br * FILM_BR_FLOATS + 64, *wb2 = wa + 64;
-        f32x2 oa2 = {0.f, 0.f}, ob2 = {0.f, 0.f};
-#pragma unroll
-        for (int tp = 0; tp < 2; ++tp)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int f0 = 32 * tp + 8 * q + 4 * h;
-                const f32x2 v01 = {relu(acc1[br][tp][4 * q + 0]), relu(acc1[br][tp][4 * q + 1])};
-                const f32x2 v23 = {relu(acc1[br][tp][4 * q + 2]), relu(acc1[br][tp][4 * q + 3])};
-                const f32x4 wa4 = *(const f32x4 *)(wa + f0);
-                oa2 = __builtin_elementwise_fma(f32x2{wa4.x, wa4.y}, v01, oa2);
-                oa2 = __builtin_elementwise_fma(f32x2{wa4.z, wa4.w}, v23, oa2);
-                if (TWO) {
-                    const f32x4 wb4 = *(const f32x4 *)(wb2 + f0);
-                    ob2 = __builtin_elementwise_fma(f32x2{wb4.x, wb4.y}, v01, ob2);
-                    ob2 = __builtin_elementwise_fma(f32x2{wb4.z, wb4.w}, v23, ob2);
-                }
-            }
-        o[br][0] = oa2.x + oa2.y;
-        o[br][1] = ob2.x + ob2.y;
+    for (int ks = 0; ks < 4; ++ks) {
+        if (ks + 1 < 4) ld_frag(1, ks + 1, af[(ks + 1) & 1]);
+        chain_ks(1, ks, af[ks & 1]);
+        if (ks + 1 < 4) split_ks(1, ks + 1);
+        if (ks == 2) contract(0, 0);
+        if (ks == 3) contract(0, 1);
+        DPF_PIPE_PATTERN(NM, 12, 8)
+        __builtin_amdgcn_sched_barrier(0);
     }
+    // ---- tail: B's output contraction
+    contract(1, 0);
+    contract(1, 1);
+#undef DPF_PIPE_PATTERN
+#pragma unroll
+    for (int br = 0; br < 2; ++br) { o[br][0] = pa[br][0] + pa[br][1]; o[br][1] = pb[br][0] + pb[br][1]; }
 }
 
 __device__ __forceinline__ float half_sum(float x) {   // x(lane) + x(lane ^ 32)
@@ -512,7 +555,7 @@ __device__ __forceinline__ float half_sum(float x) {   // x(lane) + x(lane ^ 32)
 // through its own LDS, so bigger workgroups mean less L2->LDS traffic per point.
 // LPB = layers per LDS buffer: with two layers per buffer (2 x 2 x 38 KiB at bf16x3: one workgroup per CU, which is
 // all cfg-2 offers anyway) the workgroup barrier that hands a buffer over comes every other layer.
-template <int NS, int FW, int LPB = 1>
+template <int NS, int FW, int LPB = 1, bool PIPE = false>
 __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int LBYTES = p_layer_bytes(NS) + FILM_BYTES;
@@ -575,18 +618,16 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
         const u32x4 b0 = input_fragment(x, h);
 
         float o[2][2];
-#ifndef DPF_FLOW_PAIRED_BRANCHES
-        if (wb < 0) {                                       // layer warps one channel
+        if constexpr (PIPE) {
+            if (wb < 0) layer_pipe<NS, false>(lb, lane, h, b0, o);   // layer warps one channel
+            else layer_pipe<NS, true>(lb, lane, h, b0, o);
+        } else if (wb < 0) {                                // layer warps one channel
             branch_tile<NS, false>(lb, 0, lane, h, b0, o[0][0], o[0][1], tt);
             branch_tile<NS, false>(lb, 1, lane, h, b0, o[1][0], o[1][1], tt);
         } else {
             branch_tile<NS, true>(lb, 0, lane, h, b0, o[0][0], o[0][1], tt);
             branch_tile<NS, true>(lb, 1, lane, h, b0, o[1][0], o[1][1], tt);
         }
-#else
-        if (wb < 0) branch_pair<NS, false>(lb, lane, h, b0, o);   // layer warps one channel
-        else branch_pair<NS, true>(lb, lane, h, b0, o);
-#endif
         DPF_T(3)
         const float *b2 = (const float *)(lb + FILMOFF) + FILM_B2_OFF;
 #pragma unroll
@@ -728,14 +769,19 @@ extern "C" int dpf_flow_forward(int n_layers, int B, int N, int mode, int precis
         if (N <= 64) fw = 2;
         if (N <= 32) fw = 1;
     }
-#define DPF_LAUNCH_LPB(NSV, FWV, LPBV)                                                                          \
+#define DPF_LAUNCH_LPB_P(NSV, FWV, LPBV, PIPEV)                                                                 \
     {                                                                                                           \
         const int lds = 2 * LPBV * (p_layer_bytes(NSV) + FILM_BYTES);                                           \
         static LdsLimit limit;                                                                                  \
-        e = limit.ensure((const void *)flow_kernel<NSV, FWV, LPBV>, lds);                                       \
+        e = limit.ensure((const void *)flow_kernel<NSV, FWV, LPBV, PIPEV>, lds);                                \
         if (e != hipSuccess) return (int)e;                                                                     \
         const dim3 grid((N + TILE * FWV - 1) / (TILE * FWV), B), block(FWV * 64);                               \
-        hipLaunchKernelGGL((flow_kernel<NSV, FWV, LPBV>), grid, block, lds, s, a);                              \
+        hipLaunchKernelGGL((flow_kernel<NSV, FWV, LPBV, PIPEV>), grid, block, lds, s, a);                       \
+    }
+#define DPF_LAUNCH_LPB(NSV, FWV, LPBV)                                                                          \
+    {                                                                                                           \
+        if (NSV <= 2 && FWV == 8 && pipe) DPF_LAUNCH_LPB_P((NSV <= 2 ? NSV : 2), FWV, LPBV, true)               \
+        else DPF_LAUNCH_LPB_P(NSV, FWV, LPBV, false)                                                            \
     }
     // two layers per buffer where a CU gets one workgroup anyway and the 2 x 2 layers fit its LDS (bf16, bf16x3)
 #define DPF_LAUNCH(NSV, FWV)                                                                                    \
@@ -749,6 +795,7 @@ extern "C" int dpf_flow_forward(int n_layers, int B, int N, int mode, int precis
         if (ns == 2) DPF_LAUNCH(2, FWV)    \
         if (ns == 3) DPF_LAUNCH(3, FWV)    \
     }
+    static const bool pipe = !(getenv("DPF_FLOW_PIPE") && atoi(getenv("DPF_FLOW_PIPE")) == 0);
     static const int lpb_env = getenv("DPF_FLOW_LPB") ? atoi(getenv("DPF_FLOW_LPB")) : 0;
     const bool pair_ok = n_layers >= 2 && lpb_env != 1 && (lpb_env == 2 || (long)B * ((N + 255) / 256) <= 256);
     if (fw >= 8) DPF_LAUNCH_FW(8)
@@ -758,6 +805,7 @@ extern "C" int dpf_flow_forward(int n_layers, int B, int N, int mode, int precis
 #undef DPF_LAUNCH_FW
 #undef DPF_LAUNCH
 #undef DPF_LAUNCH_LPB
+#undef DPF_LAUNCH_LPB_P
     return (int)hipGetLastError();
 }
 
