@@ -66,7 +66,7 @@ SIGNATURES = {
     "dpf_version": (ctypes.c_char_p, []),
 }
 
-PREC = {"bf16": 1, "bf16x3": 2, "bf16x6": 3}
+PREC = {"bf16": 1, "bf16x3": 2, "bf16x6": 3, "f16x3": 4}
 MODE = {"direct": 0, "inverse": 1}
 
 

@@ -58,7 +58,7 @@ __host__ __device__ constexpr int c_layer_floats(int G) { return 2 * c_branch_fl
 // ===========================================================================
 // pack
 // ===========================================================================
-template <int NS>
+template <int NS, bool F16 = false>
 __global__ __launch_bounds__(256) void pack_kernel(int G, const float *__restrict__ canon, uint8_t *__restrict__ packed) {
     const int l = blockIdx.x;
     const float *cl = canon + (size_t)l * c_layer_floats(G);
@@ -73,7 +73,12 @@ __global__ __launch_bounds__(256) void pack_kernel(int G, const float *__restric
         const int r = 8 * (s & 1) + j;
         const int fi = 32 * (s >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h;
         const float w = cl[br * c_branch_floats(G) + C_W1 + (32 * tp + i) * 64 + fi];
-        if (NS == 1) {
+        if (F16) {                     // fp16 hi (RNE) + fp16 of the exact remainder: 22 significant bits
+            const _Float16 wh = (_Float16)w;
+            const _Float16 wl = (_Float16)(w - (float)wh);
+            o16[idx] = __builtin_bit_cast(uint16_t, wh);
+            o16[P_A1_PART / 2 + idx] = __builtin_bit_cast(uint16_t, wl);
+        } else if (NS == 1) {
             o16[idx] = (uint16_t)bf16_rne(w);
         } else if (NS == 2) {
             float r1;
@@ -264,7 +269,7 @@ struct FlowArgs {
     const float *film;
     const float *p_in;
     float *p_out, *p_out_pm, *sum_lv, *ps, *mus, *lvs;
-    int L, B, N, mode;
+    int L, B, N, mode, prio;
     float eps;
 #ifdef DPF_PROFILE
     unsigned long long *prof;
@@ -273,15 +278,34 @@ struct FlowArgs {
 
 // Stream one layer (packed weights + this cloud's FiLM vectors) into an LDS
 // buffer: 1 KiB per wave-instruction, straight to LDS (no VGPR staging).
+// Issuing a piece blocks the issuing wave for ~60-180 cycles (MI355X_MICROARCH.md, "LDS-DMA piece issue cost").  In an
+// 8-wave workgroup the SIMD's arbiter favours the older wave of each pair, so waves 0-3 run ahead and idle at the
+// workgroup barrier (r02 phase profile: ~4300 cycles per two layers) while waves 4-7 are the critical path: the leaders
+// issue ALL pieces (LW = FW / 2 issuing waves) and the laggards none.
+template <int K, int PER>
+__device__ __forceinline__ void issue_pieces(const uint8_t *src, uint8_t *dst) {
+    if constexpr (K < PER) {
+        __builtin_amdgcn_global_load_lds((glb_void *)(src + (K / 4) * 4096), (lds_void *)(dst + (K / 4) * 4096), 16, (K % 4) * 1024, 0);
+        issue_pieces<K + 1, PER>(src, dst);
+    }
+}
 template <int NS, int FW>
 __device__ __forceinline__ void stage_layer(const FlowArgs &a, int li, int bi, uint8_t *lds, int wave, int lane) {
-    constexpr int NP = p_layer_bytes(NS) / 1024, NC = NP + FILM_BYTES / 1024;
-    const uint8_t *wsrc = a.packed + (size_t)li * p_layer_bytes(NS);
-    const uint8_t *fsrc = (const uint8_t *)a.film + ((size_t)li * a.B + bi) * FILM_BYTES;
-    for (int c = wave; c < NC; c += FW) {
-        const uint8_t *src = (c < NP ? wsrc + c * 1024 : fsrc + (c - NP) * 1024) + lane * 16;
-        __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(lds + c * 1024), 16, 0, 0);
-    }
+    constexpr int NP = p_layer_bytes(NS) / 1024, NF = FILM_BYTES / 1024;
+    constexpr int LW = FW >= 8 ? FW / 2 : FW, PER = NP / LW;
+    static_assert(NP % LW == 0, "every issuing wave takes the same contiguous run of weight pieces");
+    if (wave >= LW) return;
+    // a wave's pieces are contiguous in memory and in LDS, so one (address, M0) pair serves four pieces through the
+    // instruction's immediate offset (it advances both sides): ~1.5 instructions per piece instead of ~18
+    const uint8_t *src = a.packed + (size_t)li * p_layer_bytes(NS) + wave * (PER * 1024) + lane * 16;
+    uint8_t *dst = lds + wave * (PER * 1024);
+    issue_pieces<0, PER>(src, dst);
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+        if (wave == f % LW) {
+            const uint8_t *fsrc = (const uint8_t *)a.film + ((size_t)li * a.B + bi) * FILM_BYTES + f * 1024 + lane * 16;
+            __builtin_amdgcn_global_load_lds((glb_void *)fsrc, (lds_void *)(lds + (NP + f) * 1024), 16, 0, 0);
+        }
 }
 
 #ifdef DPF_PROFILE
@@ -417,8 +441,10 @@ __device__ __forceinline__ void branch_tile(const uint8_t *lb, int br, int lane,
 //   G5..G7  chain B k0..k2                                   | split B k1..k3, B fragments, output weights of A
 //   G8      chain B k3                                       | output contraction of A
 //   tail    output contraction of B
-template <int NS, bool TWO>
-__device__ __forceinline__ void layer_pipe(const uint8_t *lb, int lane, int h, u32x4 b0, float (&o)[2][2]) {
+template <int NS, bool TWO, bool F16>
+__device__ __forceinline__ void layer_pipe(const uint8_t *lb, int lane, int h, u32x4 b0, float negone, bool midbar, bool prio,
+                                           float (&o)[2][2], unsigned long long *tt) {
+    static_assert(!F16 || NS == 2, "fp16 operands: hi/lo split only");
     static_assert(NS <= 2, "the pipelined body keeps both branches' fragments in registers: bf16 / bf16x3 only");
     constexpr int A0OFF = p_a0_off(NS), FILMOFF = p_layer_bytes(NS);
     typedef Terms<NS> TT;
@@ -450,7 +476,16 @@ __device__ __forceinline__ void layer_pipe(const uint8_t *lb, int lane, int h, u
         for (int d = 0; d < 4; ++d) {
             const int r = 8 * (ks & 1) + 2 * d;
             const float v0 = relu(acc0[br][t][r]), v1 = relu(acc0[br][t][r + 1]);
-            if (NS == 1) {
+            if (F16) {
+                // hi = the pair truncated to fp16 (one v_cvt_pkrtz_f16_f32); lo = fp16(v - hi) formed and packed by
+                // v_fma_mixlo_f16 / v_fma_mixhi_f16, which read hi's halves as fp16 operands: 5 VALU per pair instead of 8.
+                // `negone` is -1.0 in an SGPR the compiler cannot see through (a literal -1 turns the fma into a
+                // subtraction of an extended half, which does not select the mix instructions).
+                const fp16x2 hi = __builtin_amdgcn_cvt_pkrtz(v0, v1);
+                const f16x2 lo = {(_Float16)__builtin_fmaf((float)hi[0], negone, v0), (_Float16)__builtin_fmaf((float)hi[1], negone, v1)};
+                bfrag[br][0][ks][d] = __builtin_bit_cast(uint32_t, hi);
+                bfrag[br][1][ks][d] = __builtin_bit_cast(uint32_t, lo);
+            } else if (NS == 1) {
                 bfrag[br][0][ks][d] = pack_bf16_rne(v0, v1);
             } else {
                 float l0, l1;
@@ -465,22 +500,34 @@ __device__ __forceinline__ void layer_pipe(const uint8_t *lb, int lane, int h, u
         for (int term = 0; term < TT::N; ++term)
 #pragma unroll
             for (int tp = 0; tp < 2; ++tp)
-                acc1[br][tp] = mfma(a[TT::A[term] * 2 + tp], bfrag[br][TT::B[term]][ks], acc1[br][tp]);
+                acc1[br][tp] = F16 ? mfma_f16(a[TT::A[term] * 2 + tp], bfrag[br][TT::B[term]][ks], acc1[br][tp])
+                                   : mfma(a[TT::A[term] * 2 + tp], bfrag[br][TT::B[term]][ks], acc1[br][tp]);
     };
-    // o = W2' relu(h1 + D) over this lane's 32 features: scalar FMAs on two partial sums per output (no packed f32)
+    // o = W2' relu(h1 + D) over this lane's 32 features: scalar FMAs on two partial sums per output (no packed f32).
+    // The weights of one M tile are fetched one group ahead of the FMAs that use them.
     float pa[2][2], pb[2][2];                                      // [br][even/odd]
-    auto contract = [&](int br, int tp) {
+    f32x4 cwa[2][4], cwb[2][4];                                    // [slot][q]: slot = (br + tp) & 1 alternates
+    auto ld_cw = [&](int br, int tp) {
         const float *wa = film + br * FILM_BR_FLOATS + 64, *wb2 = wa + 64;
+        const int sl = (br * 2 + tp) & 1;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int f0 = 32 * tp + 8 * q + 4 * h;
-            const f32x4 wa4 = *(const f32x4 *)(wa + f0);
+            cwa[sl][q] = *(const f32x4 *)(wa + f0);
+            if (TWO) cwb[sl][q] = *(const f32x4 *)(wb2 + f0);
+        }
+    };
+    auto contract = [&](int br, int tp) {
+        const int sl = (br * 2 + tp) & 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 wa4 = cwa[sl][q];
             const float r0 = relu(acc1[br][tp][4 * q + 0]), r1 = relu(acc1[br][tp][4 * q + 1]);
             const float r2 = relu(acc1[br][tp][4 * q + 2]), r3 = relu(acc1[br][tp][4 * q + 3]);
             pa[br][0] = __builtin_fmaf(wa4.x, r0, pa[br][0]); pa[br][1] = __builtin_fmaf(wa4.y, r1, pa[br][1]);
             pa[br][0] = __builtin_fmaf(wa4.z, r2, pa[br][0]); pa[br][1] = __builtin_fmaf(wa4.w, r3, pa[br][1]);
             if (TWO) {
-                const f32x4 wb4 = *(const f32x4 *)(wb2 + f0);
+                const f32x4 wb4 = cwb[sl][q];
                 pb[br][0] = __builtin_fmaf(wb4.x, r0, pb[br][0]); pb[br][1] = __builtin_fmaf(wb4.y, r1, pb[br][1]);
                 pb[br][0] = __builtin_fmaf(wb4.z, r2, pb[br][0]); pb[br][1] = __builtin_fmaf(wb4.w, r3, pb[br][1]);
             }
@@ -489,16 +536,33 @@ __device__ __forceinline__ void layer_pipe(const uint8_t *lb, int lane, int h, u
 #pragma unroll
     for (int br = 0; br < 2; ++br) { pa[br][0] = pa[br][1] = 0.f; pb[br][0] = pb[br][1] = 0.f; }
 
-    // `n` MFMAs, each followed by `v` VALU and (first `ds` of them) one DS read
-#define DPF_PIPE_PATTERN(n, v, ds)                                              \
-    _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {                        \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      \
-        __builtin_amdgcn_sched_group_barrier(0x002, (v), 0);                    \
-        if (i_ < (ds)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       \
+    // sched_barrier fences the machine scheduler only: pure arithmetic (VALU, MFMA) still drifts across it when the
+    // selection DAG is linearised.  An empty volatile asm that "rewrites" a value is ordered with the fences (both have
+    // side effects), so pinning a group's VALU INPUTS at its top and its OUTPUTS at its bottom keeps the work inside.
+    auto pin = [](auto &x) { asm volatile("" : "+v"(x)); };
+    auto pin_acc0 = [&](int br, int ks) {                          // the 8 registers split_ks(br, ks) reads
+        const int t = ks >> 1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { float v = acc0[br][t][8 * (ks & 1) + i]; pin(v); acc0[br][t][8 * (ks & 1) + i] = v; }
+    };
+    auto pin_bfrag = [&](int br, int ks) {
+#pragma unroll
+        for (int part = 0; part < NS; ++part) pin(bfrag[br][part][ks]);
+    };
+    auto pin_acc1 = [&](int br, int tp) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { float v = acc1[br][tp][i]; pin(v); acc1[br][tp][i] = v; }
+    };
+    auto pin_sums = [&](int br) { pin(pa[br][0]); pin(pa[br][1]); if (TWO) { pin(pb[br][0]); pin(pb[br][1]); } };
+    // `n` MFMAs, each followed by (the first `ds` of them) `dsper` LDS reads and by `v` VALU: the reads a later group waits
+    // for are issued at the top of this one
+#define DPF_PIPE_PATTERN(n, v, ds, dsper)                                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {                            \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          \
+        if (i_ < (ds)) __builtin_amdgcn_sched_group_barrier(0x100, (dsper), 0);     \
+        __builtin_amdgcn_sched_group_barrier(0x002, (v), 0);                        \
     }
     constexpr int NM = 2 * TT::N;      // MFMAs per k-step
-    constexpr int VS = NS == 1 ? 16 : 32;   // VALU of one split_ks
-    constexpr int VG = (VS + NM - 1) / NM;  // per MFMA gap
 
     // ---- G0: input MFMAs (h0 pre-activation, fp32-accurate), A's first split
     {
@@ -506,38 +570,73 @@ __device__ __forceinline__ void layer_pipe(const uint8_t *lb, int lane, int h, u
         const u32x4 a01 = *(const u32x4 *)(lb + A0OFF + ((0 * 2 + 1) * 64 + lane) * 16);
         const u32x4 a10 = *(const u32x4 *)(lb + A0OFF + ((1 * 2 + 0) * 64 + lane) * 16);
         const u32x4 a11 = *(const u32x4 *)(lb + A0OFF + ((1 * 2 + 1) * 64 + lane) * 16);
-        init_acc1(0, 0); init_acc1(0, 1);
         ld_frag(0, 0, af[0]);
         acc0[0][0] = mfma(a00, b0, z16);
         acc0[0][1] = mfma(a01, b0, z16);
         acc0[1][0] = mfma(a10, b0, z16);
         acc0[1][1] = mfma(a11, b0, z16);
         split_ks(0, 0);
+        pin_bfrag(0, 0);
+        init_acc1(0, 0); init_acc1(0, 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);       // input fragments, A's first k-step
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);       // D of A: what G1's first MFMAs wait for
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
+    DPF_T(1)
+    // MFMA chains run at low priority, the VALU-only stretch of a layer (B's contraction, coupling transform, the next
+    // input fragment and G0) at high priority: the stretch is a latency-bound dependent chain that uses a fraction of the
+    // VALU slots, the chains' fillers take what is left
+    if (prio) __builtin_amdgcn_s_setprio(0);
     // ---- G1..G4: chain A
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        if (ks + 1 < 4) ld_frag(0, ks + 1, af[(ks + 1) & 1]); else ld_frag(1, 0, af[(ks + 1) & 1]);
+        const int sbr = ks + 1 < 4 ? 0 : 1, sks = (ks + 1) & 3;      // the split that rides in this group
+        pin_acc0(sbr, sks);
+        ld_frag(sbr, sks, af[(ks + 1) & 1]);
         if (ks == 1) init_acc1(1, 0);
         if (ks == 2) init_acc1(1, 1);
         chain_ks(0, ks, af[ks & 1]);
-        if (ks + 1 < 4) split_ks(0, ks + 1); else split_ks(1, 0);
-        DPF_PIPE_PATTERN(NM, VG, 2 * NS + 4)
+        split_ks(sbr, sks);
+        pin_bfrag(sbr, sks);
+        DPF_PIPE_PATTERN(NM, 6, 4, 2)
         __builtin_amdgcn_sched_barrier(0);
+#ifdef DPF_PROFILE
+        if (ks == 0) DPF_T(8) else if (ks == 1) DPF_T(9) else if (ks == 2) DPF_T(10)
+#endif
     }
+    DPF_T(2)
+    // skewed ring (flow_kernel<.., SKEW>): the lagging half of the workgroup meets the leading half's end-of-layer barrier
+    // HERE, half a layer behind, so that one wave's MFMA chains run beside its SIMD partner's VALU-only phases
+    if (midbar) __syncthreads();
     // ---- G5..G8: chain B; A's output contraction rides in the later groups
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        if (ks + 1 < 4) ld_frag(1, ks + 1, af[(ks + 1) & 1]);
+        if (ks + 1 < 4) { pin_acc0(1, ks + 1); ld_frag(1, ks + 1, af[(ks + 1) & 1]); }
+        if (ks == 1) ld_cw(0, 0);
+        if (ks == 2) { pin_acc1(0, 0); ld_cw(0, 1); }
+        if (ks == 3) { pin_acc1(0, 1); ld_cw(1, 0); }
         chain_ks(1, ks, af[ks & 1]);
-        if (ks + 1 < 4) split_ks(1, ks + 1);
-        if (ks == 2) contract(0, 0);
-        if (ks == 3) contract(0, 1);
-        DPF_PIPE_PATTERN(NM, 12, 8)
+        if (ks + 1 < 4) { split_ks(1, ks + 1); pin_bfrag(1, ks + 1); }
+        if (ks == 2) { contract(0, 0); pin_sums(0); }
+        if (ks == 3) { contract(0, 1); pin_sums(0); }
+        if (ks < 2) { DPF_PIPE_PATTERN(NM, 6, 4, 3) }
+        else if (ks == 2) { if (TWO) { DPF_PIPE_PATTERN(NM, 14, 4, 3) } else { DPF_PIPE_PATTERN(NM, 11, 4, 3) } }
+        else { if (TWO) { DPF_PIPE_PATTERN(NM, 8, 4, 3) } else { DPF_PIPE_PATTERN(NM, 6, 4, 3) } }
         __builtin_amdgcn_sched_barrier(0);
+#ifdef DPF_PROFILE
+        if (ks == 0) DPF_T(11) else if (ks == 1) DPF_T(12) else if (ks == 2) DPF_T(13)
+#endif
     }
+    DPF_T(3)
+    if (prio) __builtin_amdgcn_s_setprio(2);
     // ---- tail: B's output contraction
+    ld_cw(1, 1);
     contract(1, 0);
     contract(1, 1);
 #undef DPF_PIPE_PATTERN
@@ -555,8 +654,19 @@ __device__ __forceinline__ float half_sum(float x) {   // x(lane) + x(lane ^ 32)
 // through its own LDS, so bigger workgroups mean less L2->LDS traffic per point.
 // LPB = layers per LDS buffer: with two layers per buffer (2 x 2 x 38 KiB at bf16x3: one workgroup per CU, which is
 // all cfg-2 offers anyway) the workgroup barrier that hands a buffer over comes every other layer.
-template <int NS, int FW, int LPB = 1, bool PIPE = false>
+// SKEW (8-wave workgroups, pipelined body): three one-layer LDS buffers in a ring and a phase-locked half-layer skew
+// between the two waves of every SIMD.  Waves 0-3 ("leaders") hit the workgroup barrier at the END of layer n and then
+// issue the DMA of layer n + 2 into the buffer layer n - 1 used; waves 4-7 ("laggards") hit the same barrier in the MIDDLE
+// of their layer n (between the two MFMA chains, layer_pipe's midbar).  Barrier n therefore completes when the leaders
+// have finished layer n and the laggards half of it: every wave makes the same number of barrier calls, the skew is
+// sustained by construction, and while one wave of a SIMD is in its MFMA chains (matrix pipe busy, <= 6 VALU per gap)
+// its partner is in the VALU-only part of a layer (contraction tail, coupling transform, next input fragment, input
+// MFMAs + first split).  Buffer safety: after barrier n nobody reads layer n - 1 any more (laggards are past the middle
+// of layer n), and the DMA of layer n + 1, issued after barrier n - 1, was waited for (vmcnt 0) by its issuers before
+// they arrived at barrier n.
+template <int NS, int FW, int LPB = 1, bool PIPE = false, bool F16 = false, bool SKEW = false>
 __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
+    static_assert(!SKEW || (FW == 8 && LPB == 1 && PIPE), "the skewed ring is built for 8-wave pipelined workgroups");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int LBYTES = p_layer_bytes(NS) + FILM_BYTES;
     constexpr int FILMOFF = p_layer_bytes(NS);
@@ -574,6 +684,8 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
     const bool inverse = a.mode == DPF_MODE_INVERSE;
     const size_t list_stride = (size_t)a.B * 3 * N;
 
+    float negone = -1.0f;                      // opaque to the compiler: see layer_pipe's fp16 split
+    asm volatile("" : "+s"(negone));
     const int lfirst = inverse ? L - 1 : 0;
     auto stage_group = [&](int g) {                      // the LPB layers of steps g*LPB .. into buffer g & 1
 #pragma unroll
@@ -582,7 +694,11 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
             if (st < L) stage_layer<NS, FW>(a, inverse ? L - 1 - st : st, bi, smem + ((g & 1) * LPB + k) * LBYTES, wave, lane);
         }
     };
-    stage_group(0);
+    const bool lag = SKEW && wave >= FW / 2;
+    auto stage_step = [&](int st) {                      // SKEW: the layer of step st into ring slot st % 3
+        if (st < L) stage_layer<NS, FW>(a, inverse ? L - 1 - st : st, bi, smem + (st % 3) * LBYTES, wave, lane);
+    };
+    if constexpr (SKEW) { stage_step(0); stage_step(1); } else stage_group(0);
     // Layer descriptors (keep/warp channels): lane l of every wave holds the rows of layers l and 64 + l, a
     // layer's row comes out with v_readlane.  (Loading them inside the loop puts a vector-memory wait at the top of every
     // layer, and vmcnt retires in order: it waited for the whole next-layer DMA issued just before -- r01
@@ -604,11 +720,12 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
         const int li = inverse ? L - 1 - step : step;
         const int ln = inverse ? (li > 0 ? li - 1 : 0) : (li + 1 < L ? li + 1 : li);
         const int grp = step / LPB, within = step - grp * LPB;
-        const uint8_t *lb = smem + ((grp & 1) * LPB + within) * LBYTES;
-        if (within == 0 && (grp + 1) * LPB < L) stage_group(grp + 1);
+        const uint8_t *lb = smem + (SKEW ? step % 3 : (grp & 1) * LPB + within) * LBYTES;
+        if constexpr (!SKEW)
+            if (within == 0 && (grp + 1) * LPB < L) stage_group(grp + 1);
         int nka, nkb, nwa, nwb;
         layer_meta(ln, nka, nkb, nwa, nwb);
-        unsigned long long tt[8];
+        unsigned long long tt[16];
         (void)tt;
         DPF_T(0)
         // ---- B operand of the input MFMA: 3-way bf16 split of this half's input channel
@@ -619,8 +736,8 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
 
         float o[2][2];
         if constexpr (PIPE) {
-            if (wb < 0) layer_pipe<NS, false>(lb, lane, h, b0, o);   // layer warps one channel
-            else layer_pipe<NS, true>(lb, lane, h, b0, o);
+            if (wb < 0) layer_pipe<NS, false, F16>(lb, lane, h, b0, negone, lag, a.prio != 0, o, tt);   // layer warps one channel
+            else layer_pipe<NS, true, F16>(lb, lane, h, b0, negone, lag, a.prio != 0, o, tt);
         } else if (wb < 0) {                                // layer warps one channel
             branch_tile<NS, false>(lb, 0, lane, h, b0, o[0][0], o[0][1], tt);
             branch_tile<NS, false>(lb, 1, lane, h, b0, o[1][0], o[1][1], tt);
@@ -628,7 +745,7 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
             branch_tile<NS, true>(lb, 0, lane, h, b0, o[0][0], o[0][1], tt);
             branch_tile<NS, true>(lb, 1, lane, h, b0, o[1][0], o[1][1], tt);
         }
-        DPF_T(3)
+        DPF_T(4)
         const float *b2 = (const float *)(lb + FILMOFF) + FILM_B2_OFF;
 #pragma unroll
         for (int br = 0; br < 2; ++br)
@@ -662,14 +779,24 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
             if (!h) *dst[4] = val[4];
         }
         ka = nka; kb = nkb; wa = nwa; wb = nwb;
-        DPF_T(4)
-        if (within == LPB - 1) __syncthreads();   // the next buffer's weights have landed; everyone is done with this one
         DPF_T(5)
 #ifdef DPF_PROFILE
+        if (within == LPB - 1 && !lag) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own DMA pieces landed (split from the barrier wait)
+#endif
         DPF_T(6)
+        if constexpr (SKEW) {
+            if (!lag) {               // leaders: barrier n; layer n - 1's slot is free now -> layer n + 2
+                __syncthreads();
+                stage_step(step + 2);
+            }
+        } else {
+            if (within == LPB - 1) __syncthreads();   // the next buffer's weights have landed; everyone is done with this one
+        }
+#ifdef DPF_PROFILE
+        DPF_T(7)
         if (a.prof != nullptr && lane == 0 && blockIdx.x < 2 && blockIdx.y == 0) {
-            unsigned long long *o2 = a.prof + (((size_t)(blockIdx.x * FW + wave)) * L + step) * 8;
-            for (int i = 0; i < 7; ++i) o2[i] = tt[i];
+            unsigned long long *o2 = a.prof + (((size_t)(blockIdx.x * FW + wave)) * L + step) * 16;
+            for (int i = 0; i < 16; ++i) o2[i] = tt[i];
         }
 #endif
     }
@@ -689,8 +816,39 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
 #ifdef DPF_PROFILE
 unsigned long long *g_prof = nullptr;
 #endif
-int ns_of(int precision) {
-    return precision == DPF_PREC_BF16 ? 1 : precision == DPF_PREC_BF16X3 ? 2 : precision == DPF_PREC_BF16X6 ? 3 : 0;
+int ns_of(int precision) {   // number of operand parts; DPF_PREC_F16X3 shares the hi/lo layout of bf16x3
+    return precision == DPF_PREC_BF16 ? 1 : (precision == DPF_PREC_BF16X3 || precision == DPF_PREC_F16X3) ? 2
+           : precision == DPF_PREC_BF16X6 ? 3 : 0;
+}
+
+template <int NS, int FW, int LPB, bool PIPE, bool F16, bool SKEW = false>
+int launch_flow(const FlowArgs &a, hipStream_t s) {
+    const int lds = (SKEW ? 3 : 2 * LPB) * (p_layer_bytes(NS) + FILM_BYTES);
+    static LdsLimit limit;
+    if (hipError_t e = limit.ensure((const void *)flow_kernel<NS, FW, LPB, PIPE, F16, SKEW>, lds); e != hipSuccess) return (int)e;
+    const dim3 grid((a.N + TILE * FW - 1) / (TILE * FW), a.B), block(FW * 64);
+    hipLaunchKernelGGL((flow_kernel<NS, FW, LPB, PIPE, F16, SKEW>), grid, block, lds, s, a);
+    return (int)hipGetLastError();
+}
+// bf16 / bf16x3 / f16x3 run the pipelined layer body (layer_pipe); bf16x6 keeps one branch at a time (branch_tile:
+// three operand parts per branch do not fit two branches' fragments into the 256 VGPRs of two waves per SIMD)
+template <int FW, int LPB>
+int launch_flow_prec(int precision, const FlowArgs &a, hipStream_t s) {
+    if constexpr (FW == 8 && LPB == 0) {          // 8-wave workgroups of the two-part precisions: the skewed ring
+        switch (precision) {
+            case DPF_PREC_BF16: return launch_flow<1, 8, 1, true, false, true>(a, s);
+            case DPF_PREC_BF16X3: return launch_flow<2, 8, 1, true, false, true>(a, s);
+            case DPF_PREC_F16X3: return launch_flow<2, 8, 1, true, true, true>(a, s);
+            default: return launch_flow<3, 8, 1, false, false>(a, s);
+        }
+    }
+    constexpr int LP = LPB ? LPB : 1;
+    switch (precision) {
+        case DPF_PREC_BF16: return launch_flow<1, FW, LP, true, false>(a, s);
+        case DPF_PREC_BF16X3: return launch_flow<2, FW, LP, true, false>(a, s);
+        case DPF_PREC_F16X3: return launch_flow<2, FW, LP, true, true>(a, s);
+        default: return launch_flow<3, FW, 1, false, false>(a, s);
+    }
 }
 
 }  // namespace
@@ -713,7 +871,10 @@ extern "C" int dpf_flow_pack(int n_layers, int G, int precision, const float *ca
     if (!canon || !packed) return DPF_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (ns == 1) hipLaunchKernelGGL(pack_kernel<1>, dim3(n_layers), dim3(256), 0, s, G, canon, (uint8_t *)packed);
-    if (ns == 2) hipLaunchKernelGGL(pack_kernel<2>, dim3(n_layers), dim3(256), 0, s, G, canon, (uint8_t *)packed);
+    if (ns == 2 && precision != DPF_PREC_F16X3)
+        hipLaunchKernelGGL(pack_kernel<2>, dim3(n_layers), dim3(256), 0, s, G, canon, (uint8_t *)packed);
+    if (precision == DPF_PREC_F16X3)
+        hipLaunchKernelGGL((pack_kernel<2, true>), dim3(n_layers), dim3(256), 0, s, G, canon, (uint8_t *)packed);
     if (ns == 3) hipLaunchKernelGGL(pack_kernel<3>, dim3(n_layers), dim3(256), 0, s, G, canon, (uint8_t *)packed);
     float *fw = (float *)((uint8_t *)packed + (size_t)n_layers * p_layer_bytes(ns));
     hipLaunchKernelGGL(pack_film_kernel, dim3(n_layers * 4), dim3(256), 0, s, n_layers, G, canon, fw);
@@ -751,11 +912,12 @@ extern "C" int dpf_flow_forward(int n_layers, int B, int N, int mode, int precis
     a.packed = (const uint8_t *)packed; a.meta = meta; a.film = film; a.p_in = p_in;
     a.p_out = p_out; a.p_out_pm = p_out_pointmajor; a.sum_lv = sum_logvar; a.ps = ps; a.mus = mus; a.lvs = logvars;
     a.L = n_layers; a.B = B; a.N = N; a.mode = mode; a.eps = flow_eps;
+    static const int prio_env = getenv("DPF_FLOW_PRIO") ? atoi(getenv("DPF_FLOW_PRIO")) : 1;
+    a.prio = prio_env;
 #ifdef DPF_PROFILE
     a.prof = g_prof;
 #endif
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipSuccess;
     // 8-wave workgroups (256 points of one cloud) unless that leaves CUs without a workgroup
     static const int force_fw = getenv("DPF_FLOW_WAVES") ? atoi(getenv("DPF_FLOW_WAVES")) : 0;
     // waves (32-point tiles) per workgroup: as many as possible (each workgroup streams the layer
@@ -769,44 +931,15 @@ extern "C" int dpf_flow_forward(int n_layers, int B, int N, int mode, int precis
         if (N <= 64) fw = 2;
         if (N <= 32) fw = 1;
     }
-#define DPF_LAUNCH_LPB_P(NSV, FWV, LPBV, PIPEV)                                                                 \
-    {                                                                                                           \
-        const int lds = 2 * LPBV * (p_layer_bytes(NSV) + FILM_BYTES);                                           \
-        static LdsLimit limit;                                                                                  \
-        e = limit.ensure((const void *)flow_kernel<NSV, FWV, LPBV, PIPEV>, lds);                                \
-        if (e != hipSuccess) return (int)e;                                                                     \
-        const dim3 grid((N + TILE * FWV - 1) / (TILE * FWV), B), block(FWV * 64);                               \
-        hipLaunchKernelGGL((flow_kernel<NSV, FWV, LPBV, PIPEV>), grid, block, lds, s, a);                       \
-    }
-#define DPF_LAUNCH_LPB(NSV, FWV, LPBV)                                                                          \
-    {                                                                                                           \
-        if (NSV <= 2 && FWV == 8 && pipe) DPF_LAUNCH_LPB_P((NSV <= 2 ? NSV : 2), FWV, LPBV, true)               \
-        else DPF_LAUNCH_LPB_P(NSV, FWV, LPBV, false)                                                            \
-    }
-    // two layers per buffer where a CU gets one workgroup anyway and the 2 x 2 layers fit its LDS (bf16, bf16x3)
-#define DPF_LAUNCH(NSV, FWV)                                                                                    \
-    {                                                                                                           \
-        if (FWV == 8 && NSV <= 2 && pair_ok) DPF_LAUNCH_LPB(NSV, 8, 2)                                          \
-        else DPF_LAUNCH_LPB(NSV, FWV, 1)                                                                        \
-    }
-#define DPF_LAUNCH_FW(FWV)                 \
-    {                                      \
-        if (ns == 1) DPF_LAUNCH(1, FWV)    \
-        if (ns == 2) DPF_LAUNCH(2, FWV)    \
-        if (ns == 3) DPF_LAUNCH(3, FWV)    \
-    }
-    static const bool pipe = !(getenv("DPF_FLOW_PIPE") && atoi(getenv("DPF_FLOW_PIPE")) == 0);
+    // two layers per LDS buffer where a CU gets one workgroup anyway and the 2 x 2 layers fit its LDS (two-part precisions)
     static const int lpb_env = getenv("DPF_FLOW_LPB") ? atoi(getenv("DPF_FLOW_LPB")) : 0;
-    const bool pair_ok = n_layers >= 2 && lpb_env != 1 && (lpb_env == 2 || (long)B * ((N + 255) / 256) <= 256);
-    if (fw >= 8) DPF_LAUNCH_FW(8)
-    else if (fw >= 4) DPF_LAUNCH_FW(4)
-    else if (fw >= 2) DPF_LAUNCH_FW(2)
-    else DPF_LAUNCH_FW(1)
-#undef DPF_LAUNCH_FW
-#undef DPF_LAUNCH
-#undef DPF_LAUNCH_LPB
-#undef DPF_LAUNCH_LPB_P
-    return (int)hipGetLastError();
+    const bool pair_ok = ns <= 2 && n_layers >= 2 && lpb_env != 1 && (lpb_env == 2 || (long)B * ((N + 255) / 256) <= 256);
+    static const int skew_env = getenv("DPF_FLOW_SKEW") ? atoi(getenv("DPF_FLOW_SKEW")) : 1;
+    if (fw >= 8 && skew_env && ns <= 2) return launch_flow_prec<8, 0>(precision, a, s);
+    if (fw >= 8) return pair_ok ? launch_flow_prec<8, 2>(precision, a, s) : launch_flow_prec<8, 1>(precision, a, s);
+    if (fw >= 4) return launch_flow_prec<4, 1>(precision, a, s);
+    if (fw >= 2) return launch_flow_prec<2, 1>(precision, a, s);
+    return launch_flow_prec<1, 1>(precision, a, s);
 }
 
 #ifdef DPF_PROFILE

@@ -23,7 +23,7 @@ class LocalCondRNVPDecoder(nn.Module):
             CondRealNVPFlow3DTriple(f_n_features, g_n_features, weight_std=weight_std, pattern=i % 2)
             for i in range(n_flows)])
         object.__setattr__(self, "_stack", None)
-        self.precision = None          # None -> engine.DEFAULT_PRECISION ("bf16x3")
+        self.precision = None          # None -> engine.DEFAULT_PRECISION ("f16x3")
         self.materialize_lists = True  # False: skip the 3 x L per-layer tensors (lists then hold the final layer only)
         self.register_load_state_dict_post_hook(lambda m, keys: m.invalidate_packed())
 

@@ -13,7 +13,10 @@ import torch
 
 from .._lib import lib, check, current_stream, PREC, MODE
 
-DEFAULT_PRECISION = os.environ.get("DPF_PRECISION", "bf16x3")
+# "f16x3" (default): W1 and the hidden activations as fp16 hi + lo parts, three MFMA products -- ~5e-7 of the reference
+# (fp32-class), and the cheapest split on the VALU; "bf16x3": the same with bf16 parts (~7e-6; no fp16 range limit);
+# "bf16x6": three bf16 parts, six products (fp32-class, no range limit); "bf16": one product (~6e-4, speed reference only)
+DEFAULT_PRECISION = os.environ.get("DPF_PRECISION", "f16x3")
 F = 64
 
 

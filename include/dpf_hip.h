@@ -164,6 +164,9 @@ int dpf_chamfer_reduce(int b, int n, int m, const float *dist1, const float *dis
 #define DPF_PREC_BF16   1  /* one bf16 MFMA product                      ~3e-3 rel */
 #define DPF_PREC_BF16X3 2  /* hi/lo split, 3 bf16 MFMA products          ~1e-5 rel */
 #define DPF_PREC_BF16X6 3  /* hi/mid/lo split, 6 bf16 MFMA products      fp32-class */
+#define DPF_PREC_F16X3  4  /* hi/lo split in fp16 (11 + 11 bits), 3 MFMA products ~1e-6 rel; the activations'
+                            * split costs 5 instead of 8 VALU per pair (v_cvt_pkrtz_f16_f32 + v_fma_mixlo/hi_f16).
+                            * Hidden activations and W1 must stay below 65504 in magnitude (fp16 range). */
 
 #define DPF_MODE_DIRECT  0 /* p_out = sqrt(eps+exp(logvar))*p + mu     flows.py:113 */
 #define DPF_MODE_INVERSE 1 /* p_out = (p-mu)/sqrt(eps+exp(logvar))     flows.py:115 */

@@ -17,7 +17,7 @@ def test_steps_in_flight_produce_the_single_step_results():
         pytest.skip("needs a GPU")
     sys.path.insert(0, ROOT)
     import bench
-    args = types.SimpleNamespace(batch=6, points=700, layers=6, latent=128, precision="bf16x3", lists=False)
+    args = types.SimpleNamespace(batch=6, points=700, layers=6, latent=128, precision="f16x3", lists=False)
     dev = torch.device("cuda", 0)
     dec, state, n_flows, z, g, tgt, tgt_pm = bench.build_workload(args, dev, args.batch)
     step = bench.make_step(dec, z, g, tgt_pm, args.layers)

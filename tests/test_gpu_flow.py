@@ -1,11 +1,14 @@
 """Parity of the fused HIP flow stack (through the C ABI) against the golden vectors captured
 from the reference's PyTorch modules and against the CPU oracle.
 
-Tolerance (north star: <= 1e-4 rel fp32): relative error is measured against the tensor's scale,
-    rel(got, ref) = max|got - ref| / max|ref|,
-and must be <= 1e-4 for the default precision (bf16x3 split MFMA).  The bf16x6 path additionally
-meets an elementwise fp32-class bound.  Plain bf16 (one MFMA product) does NOT meet 1e-4 and is
-checked only against its own, looser, measured bound."""
+Tolerance (north star: <= 1e-4 rel fp32).  Two measures, both asserted for every split precision:
+    norm-wise    rel(got, ref) = max|got - ref| / max|ref|            <= REL[prec]
+    elementwise  |got - ref| <= 1e-4 * |ref| + ATOL_SCALE[prec] * max|ref|   (np.testing.assert_allclose with
+                 the absolute term tied to the tensor's scale: entries near zero cannot be held to a relative bound)
+f16x3 (default: fp16 hi/lo operands, 22 significant bits) and bf16x6 are fp32-class; bf16x3 (16 bits) meets 1e-4
+norm-wise; elementwise it is held only to atol = 1e-4 * scale (its 16-bit parts leave ~3e-5 of the tensor's scale on
+the small early-layer logvar tensors) -- which is why it is no longer the default.  Plain bf16 (one MFMA product) does NOT meet 1e-4 and
+is checked only against its own, looser, measured bound."""
 import json
 import math
 import os
@@ -19,7 +22,14 @@ from oracle.gen_golden import layer_inputs
 
 pytestmark = pytest.mark.gpu
 
-REL = {"bf16x6": 2e-6, "bf16x3": 1e-4, "bf16": 5e-3}
+REL = {"bf16x6": 2e-6, "f16x3": 4e-6, "bf16x3": 1e-4, "bf16": 5e-3}
+ATOL_SCALE = {"bf16x6": 1e-6, "f16x3": 2e-6, "bf16x3": 1e-4}
+
+
+def assert_elementwise(got, ref, prec, what):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else got
+    ref = ref.detach().cpu().numpy() if torch.is_tensor(ref) else np.asarray(ref)
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=ATOL_SCALE[prec] * float(np.abs(ref).max()), err_msg=str(what))
 
 
 def _gpu():
@@ -40,7 +50,7 @@ def _load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name + ".npz")), json.load(open(os.path.join(golden_dir, name + ".json")))
 
 
-@pytest.mark.parametrize("prec", ["bf16x3", "bf16x6", "bf16"])
+@pytest.mark.parametrize("prec", ["f16x3", "bf16x3", "bf16x6", "bf16"])
 def test_single_layer_vs_reference_golden(golden_dir, prec):
     nets = _gpu()
     gold, meta = _load(golden_dir, "flow_layer")
@@ -59,6 +69,8 @@ def test_single_layer_vs_reference_golden(golden_dir, prec):
         for name, got in (("p_out", po), ("mu", mu), ("logvar", lv)):
             r = rel(got, gold[t + "/" + name])
             assert r <= REL[prec], (t, name, prec, r)
+            if prec in ATOL_SCALE:
+                assert_elementwise(got, gold[t + "/" + name], prec, (t, name))
         # channels that are not warped carry exactly mu = 0, logvar = 0 (flows.py:96-97)
         keep = [c for c in range(3) if c not in case["warp"]]
         assert (mu[:, keep] == 0).all() and (lv[:, keep] == 0).all()
@@ -66,7 +78,7 @@ def test_single_layer_vs_reference_golden(golden_dir, prec):
             np.testing.assert_allclose(po.cpu().numpy(), gold[t + "/p_out"], rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("prec", ["bf16x3", "bf16x6"])
+@pytest.mark.parametrize("prec", ["f16x3", "bf16x3", "bf16x6"])
 def test_decoder_vs_reference_golden(golden_dir, prec):
     nets = _gpu()
     gold, meta = _load(golden_dir, "flow_decoder")
@@ -88,6 +100,7 @@ def test_decoder_vs_reference_golden(golden_dir, prec):
             for name, lst in (("ps", ps), ("mus", mus), ("logvars", lvs)):
                 r = rel(lst[k], gold["%s/%s%d" % (c, name, k)])
                 assert r <= REL[prec], (c, name, k, prec, r)
+                assert_elementwise(lst[k], gold["%s/%s%d" % (c, name, k)], prec, (c, name, k))
         assert rel(lvs.total(), gold[c + "/sum_logvars"]) <= REL[prec]
         assert rel(sum(lvs), gold[c + "/sum_logvars"]) <= REL[prec]            # python sum over the list views
         # the loss exactly as models.py:152-171 + losses.py:11-15 assemble it
@@ -96,6 +109,7 @@ def test_decoder_vs_reference_golden(golden_dir, prec):
         smp = ps + [src] if mode == "inverse" else [src] + ps
         nll = nets.PointFlowNLL()(smp, [prior_mu] + mus, [prior_lv] + lvs)
         np.testing.assert_allclose(float(nll), float(gold[c + "/nll"]), rtol=1e-4 if prec == "bf16x3" else 2e-5)
+        assert_elementwise(lvs.total(), gold[c + "/sum_logvars"], prec, (c, "sum_logvars"))
         # `+=` of models.py:119-122 extends a python list with the FlowList
         acc = [prior_lv]
         acc += lvs
@@ -115,8 +129,9 @@ def test_l14_truncated_stack_vs_reference_golden(golden_dir):
         with torch.no_grad():
             ps, mus, lvs = dec(torch.from_numpy(z).cuda(), torch.from_numpy(g).cuda(), mode="direct", n_layers=14)
         assert len(ps) == (14 if lists else 1)
-        assert rel(ps[-1], gold["nf5_L14_direct/final"]) <= REL["bf16x3"]
-        assert rel(lvs.total(), gold["nf5_L14_direct/sum_logvars"]) <= REL["bf16x3"]
+        assert rel(ps[-1], gold["nf5_L14_direct/final"]) <= REL["f16x3"]           # default precision
+        assert rel(lvs.total(), gold["nf5_L14_direct/sum_logvars"]) <= REL["f16x3"]
+        assert_elementwise(ps[-1], gold["nf5_L14_direct/final"], "f16x3", "L14 final")
 
 
 @pytest.mark.parametrize("shape", [(1, 1, 128), (3, 31, 128), (2, 33, 128), (2, 129, 512), (5, 257, 128), (2, 2500, 512)])
@@ -135,8 +150,8 @@ def test_ragged_sizes_vs_oracle(shape):
             ps, mus, lvs = dec(torch.from_numpy(src).cuda(), torch.from_numpy(g).cuda(), mode=mode)
             rps, rmus, rlvs = FO.decoder(FO.to_torch(state), nf, torch.from_numpy(src), torch.from_numpy(g), mode)
         for k in range(3 * nf):
-            assert rel(ps[k], rps[k]) <= REL["bf16x3"] and rel(mus[k], rmus[k]) <= REL["bf16x3"]
-            assert rel(lvs[k], rlvs[k]) <= REL["bf16x3"], (shape, mode, k)
+            assert rel(ps[k], rps[k]) <= REL["f16x3"] and rel(mus[k], rmus[k]) <= REL["f16x3"]
+            assert rel(lvs[k], rlvs[k]) <= REL["f16x3"], (shape, mode, k)
         assert torch.isfinite(ps.stacked).all()
 
 
@@ -167,15 +182,18 @@ def test_full_size_properties():
     assert len(ps) == 63 and ps.stacked.shape == (63, B, 3, N)
     # bf16x3 at this size takes the variant with TWO layers per LDS buffer (a barrier every other layer; 63 layers: the
     # last buffer holds one), a 4-cloud sub-batch the one-layer-per-buffer 4-wave variant: same bits, and the oracle
-    dec.precision = "bf16x3"
-    with torch.no_grad():
-        ps3, _, lvs3 = dec(tz, tg, mode="direct")
-        ps3_sub, _, _ = dec(tz[5:9].contiguous(), tg[5:9].contiguous(), mode="direct")
-        inv3, _, _ = dec(ps3[-1], tg, mode="inverse")
-        inv3_sub, _, _ = dec(ps3[-1][5:9].contiguous(), tg[5:9].contiguous(), mode="inverse")
-    assert torch.equal(ps3_sub[-1], ps3[-1][5:9]) and torch.equal(ps3_sub[31], ps3[31][5:9])
-    assert torch.equal(inv3_sub[0], inv3[0][5:9])
-    assert rel(ps3[-1][:2], rps[-1]) <= REL["bf16x3"] and rel(lvs3.total()[:2], sum(rlvs)) <= REL["bf16x3"]
+    for prec in ("bf16x3", "f16x3"):
+        dec.precision = prec
+        with torch.no_grad():
+            ps3, _, lvs3 = dec(tz, tg, mode="direct")
+            ps3_sub, _, _ = dec(tz[5:9].contiguous(), tg[5:9].contiguous(), mode="direct")
+            inv3, _, _ = dec(ps3[-1], tg, mode="inverse")
+            inv3_sub, _, _ = dec(ps3[-1][5:9].contiguous(), tg[5:9].contiguous(), mode="inverse")
+        assert torch.equal(ps3_sub[-1], ps3[-1][5:9]) and torch.equal(ps3_sub[31], ps3[31][5:9])
+        assert torch.equal(inv3_sub[0], inv3[0][5:9])
+        assert rel(ps3[-1][:2], rps[-1]) <= REL[prec] and rel(lvs3.total()[:2], sum(rlvs)) <= REL[prec]
+        assert_elementwise(ps3[-1][:2], rps[-1], prec, "full size, 63 layers: points")
+        assert_elementwise(lvs3.total()[:2], sum(rlvs), prec, "full size, 63 layers: sum of logvars")
 
 
 def test_module_semantics():

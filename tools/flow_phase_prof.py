@@ -23,11 +23,12 @@ def main():
     handle = _lib.lib()
     handle.dpf_debug_set_prof.argtypes = [ctypes.c_void_p]
     FW = 8
-    for prec in ("bf16x3",):
+    for prec in (os.environ.get("DPF_PRECISION", "bf16x3"),):
         args.precision = prec
         L = args.layers
-        dec, state, n_flows, z, g, tgt, tgt_pm = bench.build_workload(args, dev)
-        prof = torch.zeros((2 * FW, L, 8), dtype=torch.int64, device=dev)
+        dec, state, n_flows, z, g, tgt, tgt_pm = bench.build_workload(args, dev, args.batch or 32)
+        FW = int(os.environ.get('DPF_FLOW_WAVES', '8'))
+        prof = torch.zeros((2 * FW, L, 16), dtype=torch.int64, device=dev)
         step = bench.make_step(dec, z, g, tgt_pm, L)
         for _ in range(3):
             step()
@@ -36,16 +37,25 @@ def main():
         torch.cuda.synchronize()
         handle.dpf_debug_set_prof(None)
         t = prof.cpu().numpy().astype(np.int64)
-        d = np.diff(t[:, :, :7], axis=2)            # phases 0..5
-        # stamps 1 and 2 are taken inside branch_tile, which runs twice per layer: the second call (branch mu) overwrites them
-        names = ["branch 0 (all) + branch 1 input/split", "branch 1 chain", "branch 1 epilogue", "transform + list stores",
-                 "end-of-layer DMA wait + barrier", "-"]
+        d = np.diff(t[:, :, :8], axis=2)            # phases 0..6
+        names = ["input fragment + G0 (input MFMAs, split A k0)", "G1-G4 chain A (24 MFMA)", "G5-G8 chain B (24 MFMA)",
+                 "tail: contraction B", "half sums + transform + list stores", "wait for own DMA pieces (vmcnt 0)", "workgroup barrier"]
         print("== %s: cycles per layer (median over waves/layers) | per-wave layer period" % prec)
         for i, nme in enumerate(names):
             print("   %-38s median %7.0f  p90 %7.0f" % (nme, np.median(d[:, 1:, i]), np.percentile(d[:, 1:, i], 90)))
         period = np.diff(t[:, :, 0], axis=1)
         print("   layer period   median %7.0f  (total/layer incl. staging issue + B0 build)" % np.median(period))
         print("   wave0 first 3 layers raw deltas:", d[0, :3].tolist())
+        # per-group stamps of the pipelined body: [1]=G0 end, 8,9,10 = end of G1,G2,G3, [2] = G4 end, 11,12,13 = end of G5,G6,G7, [3] = G8 end
+        order = [1, 8, 9, 10, 2, 11, 12, 13, 3]
+        gd = np.diff(t[:, :, order], axis=2)
+        print("   cycles per group G1..G8 (median over waves/layers):", np.median(gd[:, 1:, :], axis=(0, 1)).tolist())
+        print("   wave0 layer 2 groups:", gd[0, 2].tolist())
+        odd = d[:, 1::2, :]                          # layers that end a buffer group (LPB = 2)
+        print("   per wave (WG0 w0-7, WG1 w0-7), layers ending a group: own-DMA wait | barrier wait | start skew vs wave 0")
+        for w in range(t.shape[0]):
+            print("     wave %2d: %6.0f | %6.0f | %6.0f" % (w, np.median(odd[w, :, 5]), np.median(odd[w, :, 6]),
+                                                   np.median(t[w, 1:, 0] - t[8 * (w // 8), 1:, 0])))
 
 
 if __name__ == "__main__":

@@ -11,7 +11,7 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE
            "GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_LDS_UNALIGNED_STALL SQ_INSTS_SMEM" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --pmc $set -d $OUT/pass$i -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --pipelined 0 --no-graph --steps 20 --warmup 5 "$@" > $OUT/pass$i.log 2>&1
+  rocprofv3 --pmc $set -d $OUT/pass$i -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extra --pipelined 0 --no-graph --settle 0 --steps 20 --warmup 5 "$@" > $OUT/pass$i.log 2>&1
   for db in $(find $OUT/pass$i -name "*.db"); do python3 $GRAFT_REPO_ROOT/tools/rocprof_summary.py $db > $OUT/pass$i.txt 2>&1; done
   rm -rf $OUT/pass$i
 done

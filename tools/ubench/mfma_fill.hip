@@ -1,7 +1,7 @@
-// Micro-benchmark (gfx950): how many plain VALU instructions hide in the 32-cycle issue gap of a
+// Micro-benchmark (gfx950): how many plain VALU instructions (and LDS reads) hide in the 32-cycle issue gap of a
 // v_mfma_f32_32x32x16_bf16 stream, per filler type, at 1 and 2 waves per SIMD -- the question VERDICT r01 asked
-// ("<= 5 plain, independent VALU per MFMA gap; v_pk_fma_f32 vs 2 x v_fma_f32").  Every loop body is ONE inline-asm
-// block, so the instruction order is exactly the one written here (hipcc does not schedule inside asm).
+// ("<= 5 plain, independent VALU per MFMA gap; v_pk_fma_f32 vs 2 x v_fma_f32").  Every instruction is a volatile
+// inline-asm statement, so the instruction order is exactly the one written here.
 //   build: hipcc --offload-arch=gfx950 -O3 mfma_fill.hip -o mfma_fill ; run: ./mfma_fill
 // Output: per (kind, fillers-per-gap K, waves/SIMD): shader cycles per MFMA (s_memtime, slowest wave of CU 0) and
 // wall ns per MFMA per SIMD.
@@ -15,7 +15,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // filler kinds
 enum { F_FMA = 0, F_SPLIT = 1, F_PKFMA = 2, F_MAX = 3, F_CVT = 4, F_PERM = 5, F_EXP = 6, F_FMAC = 7, F_SUB = 8, F_AND = 9, F_MAXI = 10,
-       F_MUL = 11, F_DSR = 12 };
+       F_MUL = 11, F_DSR = 12, F_DSV = 13, F_DSV2 = 14 };
 
 #define MFMA0 "v_mfma_f32_32x32x16_bf16 %[c0], %[a], %[b], %[c0]\n"
 #define MFMA1 "v_mfma_f32_32x32x16_bf16 %[c1], %[a], %[b], %[c1]\n"
@@ -30,8 +30,34 @@ enum { F_FMA = 0, F_SPLIT = 1, F_PKFMA = 2, F_MAX = 3, F_CVT = 4, F_PERM = 5, F_
 #define FILL_EXP(i) "v_exp_f32 %[x" #i "], %[x" #i "]\n"
 #define FILL_PK(i, j) "v_pk_fma_f32 %[p" #i "], %[p" #i "], %[kk], %[kk]\n"
 
+__device__ u32x4 g_sink[4];
 template <int KIND, int K>
 __device__ __forceinline__ void gap(float (&x)[8], double (&p)[4], float k, double kk, uint32_t sel) {
+    if (KIND == F_DSR || KIND == F_DSV || KIND == F_DSV2) {
+        // ds_read_b128 fillers (conflict-free: lane * 16 B), results never consumed inside the loop; the rest of the gap is
+        // the split-mix VALU
+        extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+        const uint32_t addr = (uint32_t)(uintptr_t)lds_raw + (threadIdx.x & 63) * 16 + ((threadIdx.x >> 6) & 7) * 1024;
+        constexpr int ND = KIND == F_DSR ? K : (KIND == F_DSV ? 1 : 2);
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            u32x4 d;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"((i & 7) * 8192));
+            asm volatile("" ::"v"(d));
+        }
+#pragma unroll
+        for (int i = 0; i < (KIND == F_DSR ? 0 : K - ND); ++i) {
+            float &r = x[i & 7];
+            switch (i % 5) {
+                case 0: asm volatile("v_max_i32 %0, 0, %0" : "+v"(r)); break;
+                case 1: asm volatile("v_and_b32 %0, 0xffff0000, %0" : "+v"(r)); break;
+                case 2: asm volatile("v_sub_f32 %0, %0, %1" : "+v"(r) : "v"(k)); break;
+                case 3: asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(r) : "v"(k), "v"(sel)); break;
+                default: asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(r) : "v"(k)); break;
+            }
+        }
+        return;
+    }
     // K filler instructions (for F_PKFMA: K/2 packed instructions = the work of K scalar ones)
     if (KIND == F_PKFMA) {
 #pragma unroll
@@ -145,7 +171,7 @@ void run(const char *name, int wps) {
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 2; ++rep) {   // first run warms up
         hipEventRecord(e0);
-        hipLaunchKernelGGL((kern<KIND, K, NACC, MODE>), dim3(blocks), dim3(threads), 0, 0, d_out, iters, 1.0f, d_ticks);
+        hipLaunchKernelGGL((kern<KIND, K, NACC, MODE>), dim3(blocks), dim3(threads), 65536, 0, d_out, iters, 1.0f, d_ticks);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
     }
@@ -179,6 +205,14 @@ void run(const char *name, int wps) {
 int main(int argc, char **argv) {
     hipMalloc(&d_out, 256 * 1024 * sizeof(float));
     hipMalloc(&d_ticks, 64 * sizeof(unsigned long long));
+    if (argc > 1 && argv[1][0] == 'd') {   // LDS reads as gap fillers
+        for (int wps = 1; wps <= 2; ++wps) {
+            SWEEP(F_DSR, "dsr", 2, 0, wps)      // K ds_read_b128 per MFMA gap, nothing else
+            SWEEP(F_DSV, "ds1+v", 2, 0, wps)    // 1 ds_read_b128 + (K-1) VALU per gap
+            SWEEP(F_DSV2, "ds2+v", 2, 0, wps)   // 2 ds_read_b128 + (K-2) VALU per gap
+        }
+        return 0;
+    }
     if (argc > 1) {   // pure-VALU issue rates (mode 3: cyc column = cycles per 16 instructions per SIMD-"slot")
         PURE(F_FMA, "fma") PURE(F_FMAC, "fmac") PURE(F_SUB, "sub") PURE(F_MUL, "mul") PURE(F_AND, "and") PURE(F_MAXI, "maxi")
         PURE(F_MAX, "maxf") PURE(F_PERM, "perm") PURE(F_CVT, "cvtpk") PURE(F_PKFMA, "pkfma") PURE(F_EXP, "exp") PURE(F_SPLIT, "split")
