@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Drop-in proof against the reference's own CALLERS (build container only: imports /root/reference).
+
+1. Imports the reference's lib/networks/models.py twice: as it is, and with the classes INTEGRATION.md section 2 tells a
+   maintainer to swap (SharedDot/Swish, CondRealNVPFlow3D(Triple), RealNVPFlow(Couple), LocalCondRNVPDecoder,
+   GlobalRNVPDecoder, PointNetCloudEncoder, PointFlowNLL) taken from dpf_nets_amd.networks.  Both models load the same state
+   dict (strict), run `Local_Cond_RNVP_MC_Global_RNVP_VAE.forward` in TRAINING mode on CPU (the mirror's tensor-op path)
+   under the same torch generator seed, and every entry of the output dict, the loss terms
+   (Local_Cond_RNVP_MC_Global_RNVP_VAE_Loss, losses.py:37-51) and every parameter gradient are compared.
+2. Runs the reference model in EVALUATING mode (models.py:173-216) with reparameterize's noise replaced by a fixed eps and
+   writes tests/golden/model_eval.npz -- what tests/test_gpu_model.py reproduces through the HIP path with the mirror
+   classes only, and tests/test_oracle_golden.py through the CPU oracles.
+Usage: python oracle/check_dropin.py [--write]
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("DPF_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+
+from oracle import flow_oracle as FO          # noqa: E402
+from oracle import model_oracle as MO         # noqa: E402
+
+
+def _load(pkg, name, path):
+    spec = importlib.util.spec_from_file_location(pkg + "." + name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[pkg + "." + name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_reference(pkg, swap):
+    """The reference's lib/networks/{models,losses}.py as package `pkg`; with `swap` the building blocks come from the mirror."""
+    net = os.path.join(REF, "lib", "networks")
+    for p in (pkg.split(".")[0], pkg):
+        m = types.ModuleType(p)
+        m.__path__ = []
+        sys.modules[p] = m
+    layers = _load(pkg, "layers", os.path.join(net, "layers.py"))
+    flows = _load(pkg, "flows", os.path.join(net, "flows.py"))
+    decoders = _load(pkg, "decoders", os.path.join(net, "decoders.py"))
+    encoders = _load(pkg, "encoders", os.path.join(net, "encoders.py"))
+    _load(pkg, "resnet", os.path.join(net, "resnet.py"))
+    losses = _load(pkg, "losses", os.path.join(net, "losses.py"))
+    if swap:                                     # INTEGRATION.md section 2, line for line
+        from dpf_nets_amd import networks as M
+        from dpf_nets_amd.networks import layers as ML, flows as MF, prior_flows as MP, decoders as MD, encoders as ME, losses as MLo
+        layers.SharedDot, layers.Swish = ML.SharedDot, ML.Swish
+        flows.CondRealNVPFlow3D, flows.CondRealNVPFlow3DTriple = MF.CondRealNVPFlow3D, MF.CondRealNVPFlow3DTriple
+        flows.RealNVPFlow, flows.RealNVPFlowCouple = MP.RealNVPFlow, MP.RealNVPFlowCouple
+        decoders.LocalCondRNVPDecoder, decoders.GlobalRNVPDecoder = MD.LocalCondRNVPDecoder, MP.GlobalRNVPDecoder
+        encoders.PointNetCloudEncoder = ME.PointNetCloudEncoder
+        losses.PointFlowNLL = MLo.PointFlowNLL
+        assert M.LocalCondRNVPDecoder is MD.LocalCondRNVPDecoder
+    models = _load(pkg, "models", os.path.join(net, "models.py"))     # binds the (possibly swapped) names at import
+    return models, losses
+
+
+def build(models, losses, cfg, state):
+    model = models.Local_Cond_RNVP_MC_Global_RNVP_VAE(**cfg)
+    model.load_state_dict(FO.to_torch(state), strict=True)
+    return model, losses.Local_Cond_RNVP_MC_Global_RNVP_VAE_Loss(**cfg)
+
+
+def flat(v):
+    if torch.is_tensor(v):
+        return [v]
+    return [t for x in v for t in flat(x)]
+
+
+def main():
+    write = "--write" in sys.argv
+    cfg = dict(MO.CONFIG)
+    state = MO.make_model_state(11, cfg)
+    B, N = 4, 96
+    x, eps = MO.model_inputs(11, B, N)
+    tx = torch.from_numpy(x)
+    torch.set_num_threads(4)
+
+    ref_models, ref_losses = load_reference("libref.networks", swap=False)
+    mir_models, mir_losses = load_reference("libmir.networks", swap=True)
+
+    # ---- 1. training mode: reference model vs the same model on the mirror's classes ------------------------
+    worst = 0.0
+    results = []
+    for tag, (models, losses) in (("reference", (ref_models, ref_losses)), ("mirror", (mir_models, mir_losses))):
+        cfg_t = dict(cfg, util_mode="training")
+        model, loss_fn = build(models, losses, cfg_t, state)
+        model.train()
+        torch.manual_seed(5)
+        out = model(tx, tx)
+        loss, pnll, gnll, gent = loss_fn(tx, tx, out)
+        loss.backward()
+        grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        bufs = {k: b.clone() for k, b in model.named_buffers()}
+        results.append((out, (loss, pnll, gnll, gent), grads, bufs, type(model.pc_decoder).__module__))
+    (o1, l1, g1, b1, m1), (o2, l2, g2, b2, m2) = results
+    assert m1.startswith("libref") and m2.startswith("dpf_nets_amd"), (m1, m2)       # the swap really took place
+    assert set(o1) == set(o2), set(o1) ^ set(o2)
+    for k in sorted(o1):
+        a, b = flat(o1[k]), flat(o2[k])
+        assert len(a) == len(b), (k, len(a), len(b))
+        for i, (u, v) in enumerate(zip(a, b)):
+            assert u.shape == v.shape, (k, i, u.shape, v.shape)
+            err = float((u.detach() - v.detach()).abs().max() / (u.detach().abs().max() + 1e-30))
+            worst = max(worst, err)
+            assert err < 2e-5, ("output", k, i, err)
+    for u, v, name in zip(l1, l2, ("loss", "pnll", "gnll", "gent")):
+        assert abs(float(u) - float(v)) <= 2e-5 * max(1.0, abs(float(u))), (name, float(u), float(v))
+    assert set(g1) == set(g2)
+    for k in g1:
+        err = float((g1[k] - g2[k]).abs().max() / (g1[k].abs().max() + 1e-30))
+        assert err < 2e-3, ("grad", k, err)
+    for k in b1:                                   # BatchNorm running statistics after the step
+        assert torch.allclose(b1[k].float(), b2[k].float(), rtol=1e-4, atol=1e-6), ("buffer", k)
+    print("training mode: %d output entries, 4 loss terms, %d gradients, %d buffers agree (worst output rel err %.2e)"
+          % (len(o1), len(g1), len(b1), worst))
+
+    # ---- 2. evaluating mode golden from the REFERENCE model (fixed eps instead of torch.randn_like) ----------
+    model, _ = build(ref_models, ref_losses, cfg, state)
+    model.eval()
+    teps = torch.from_numpy(eps)
+    model.reparameterize = lambda mu, logvar: teps * torch.exp(0.5 * logvar) + mu        # models.py:76-79 with a fixed eps
+    with torch.no_grad():
+        out = model(tx, tx)
+    gold = {"x": x, "eps": eps, "seed": np.array(11), "B": np.array(B), "N": np.array(N)}
+    for k in ("g_posterior_mus", "g_posterior_logvars"):
+        gold[k] = out[k].detach().numpy()
+    for k in ("g_prior_samples", "g_prior_logvars", "p_prior_samples", "p_prior_mus", "p_prior_logvars"):
+        gold[k + "_len"] = np.array(len(out[k]))
+        for i in (0, 1, len(out[k]) // 2, len(out[k]) - 1):
+            gold["%s/%d" % (k, i)] = np.ascontiguousarray(out[k][i].detach().numpy())
+    gold["sum_p_logvars"] = sum(out["p_prior_logvars"]).detach().numpy()
+    pnll = ref_losses.PointFlowNLL()(out["p_prior_samples"], out["p_prior_mus"], out["p_prior_logvars"])
+    gold["pnll_as_losses_py"] = np.array(float(pnll))
+    # reconstruction Chamfer as evaluating.py:110-113 reduces it, with the reference's pure-PyTorch distChamfer
+    sys.modules.setdefault("lib", types.ModuleType("lib"))
+    for name in ("lib.metrics", "lib.metrics.StructuralLosses", "lib.metrics.StructuralLosses.match_cost",
+                 "lib.metrics.StructuralLosses.nn_distance"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["lib.metrics.StructuralLosses.match_cost"].match_cost = None
+    sys.modules["lib.metrics.StructuralLosses.nn_distance"].nn_distance = None
+    em = _load("lib.metrics", "evaluation_metrics", os.path.join(REF, "lib", "metrics", "evaluation_metrics.py"))
+    r = out["p_prior_samples"][-1].transpose(1, 2).contiguous()
+    t = tx.transpose(1, 2).contiguous()
+    dl, dr = em.distChamfer(r, t)
+    gold["cd_per_cloud"] = (dl.mean(1) + dr.mean(1)).numpy()
+    path = os.path.join(ROOT, "tests", "golden", "model_eval.npz")
+    if write:
+        np.savez_compressed(path, **gold)
+        print("wrote %s (%d arrays, %.0f KB)" % (path, len(gold), os.path.getsize(path) / 1024))
+    else:
+        old = np.load(path)
+        for k in gold:
+            np.testing.assert_allclose(old[k], gold[k], rtol=1e-6, atol=1e-7, err_msg=k)
+        print("evaluating mode: %s is up to date (%d arrays)" % (path, len(gold)))
+
+
+if __name__ == "__main__":
+    main()

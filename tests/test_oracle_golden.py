@@ -332,3 +332,30 @@ def test_gprior_oracle_and_module_vs_reference_golden(golden_dir):
                 for k, v in dec.state_dict().items():
                     if "running" in k:
                         np.testing.assert_allclose(v.numpy(), gold[tag + "_stat_" + k], rtol=RTOL, atol=ATOL, err_msg=k)
+
+
+def test_model_oracle_evaluating_forward_vs_reference_golden(golden_dir):
+    """oracle/model_oracle.evaluating_forward (models.py:173-216 restated) over the CPU oracles reproduces what the
+    reference's own Local_Cond_RNVP_MC_Global_RNVP_VAE produced (oracle/check_dropin.py -> tests/golden/model_eval.npz)."""
+    from oracle import model_oracle as MO, encoder_oracle as EO, gprior_oracle as GO
+    gold = np.load(os.path.join(golden_dir, "model_eval.npz"))
+    cfg = MO.CONFIG
+    st = FO.to_torch(MO.make_model_state(int(gold["seed"]), cfg))
+    x, eps = MO.model_inputs(int(gold["seed"]), int(gold["B"]), int(gold["N"]))
+    assert np.array_equal(x, gold["x"]) and np.array_equal(eps, gold["eps"])
+    blocks = {
+        "pc_encoder": lambda t: EO.encoder_features(FO.sub_state(st, "pc_encoder."), t),
+        "g_prior": lambda g, mode: GO.global_rnvp_decoder(FO.sub_state(st, "g_prior."), cfg["g_prior_n_flows"], g, mode),
+        "pc_decoder": lambda p, g, mode: FO.decoder(FO.sub_state(st, "pc_decoder."), cfg["p_decoder_n_flows"], p, g, mode),
+    }
+    with torch.no_grad():
+        out = MO.evaluating_forward(blocks, st, torch.from_numpy(x), torch.from_numpy(eps))
+    for k in ("g_posterior_mus", "g_posterior_logvars"):
+        np.testing.assert_allclose(out[k].numpy(), gold[k], rtol=2e-5, atol=1e-6)
+    for k in ("g_prior_samples", "g_prior_logvars", "p_prior_samples", "p_prior_mus", "p_prior_logvars"):
+        assert len(out[k]) == int(gold[k + "_len"]), k
+        for i in (0, 1, len(out[k]) // 2, len(out[k]) - 1):
+            ref = gold["%s/%d" % (k, i)]
+            np.testing.assert_allclose(out[k][i].numpy(), ref, rtol=1e-4, atol=2e-6 * max(1.0, float(np.abs(ref).max())), err_msg="%s/%d" % (k, i))
+    np.testing.assert_allclose(float(FO.point_flow_nll(out["p_prior_samples"], out["p_prior_mus"], out["p_prior_logvars"])),
+                               float(gold["pnll_as_losses_py"]), rtol=1e-5)
