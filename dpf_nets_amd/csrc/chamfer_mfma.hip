@@ -103,7 +103,10 @@ struct MDir {
     int nq, nc;
     long qstride, cstride;     // floats between consecutive clouds (0 = one cloud broadcast over the batch)
 };
-struct MArgs { MDir d[2]; };
+// pairwise mode (pn2 > 0): blockIdx.y = j, blockIdx.z = 2 i + direction select the pair (clouds1[i], clouds2[j]); instead of
+// per-point distances and indices a workgroup writes the SUM of its queries' distances (fixed order) to
+// part[((i * pn2 + j) * 2 + direction) * gridDim.x + blockIdx.x] -- the (N1, N2, n) intermediates never exist
+struct MArgs { MDir d[2]; int pn2; float *part; };
 
 __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b) {
     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -168,18 +171,29 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
     unsigned short *qtile = (unsigned short *)(lds + CT * 1536);   // [QW][QCAP][64]
     float *qmin = (float *)(lds + CT * 1536 + QW * QCAP * 64 * 2); // [QW][QCAP][64]
     __shared__ float s_r2[QW];
-    const MDir A = args.d[blockIdx.z];
-    const int bi = blockIdx.y;
+    const bool pairwise = args.pn2 > 0;
+    const int dir = pairwise ? (int)(blockIdx.z & 1) : (int)blockIdx.z;
+    const MDir A = args.d[dir];
+    // pairwise: direction 0 takes its queries from cloud i of the first set and its candidates from cloud j of the second
+    // (strides of the "other" index are 0 in MDir), direction 1 the other way round
+    const int pi = pairwise ? (int)(blockIdx.z >> 1) : 0, pj = (int)blockIdx.y;
+    const int bi = pairwise ? 0 : (int)blockIdx.y;
     const int nq = A.nq, nc = A.nc;
-    if ((int)blockIdx.x * QW * 32 >= nq) return;
+    const size_t part_at = pairwise ? (((size_t)pi * args.pn2 + pj) * 2 + dir) * gridDim.x + blockIdx.x : 0;
+    if ((int)blockIdx.x * QW * 32 >= nq) {
+        if (pairwise && threadIdx.x == 0) args.part[part_at] = 0.f;
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qt = blockIdx.x * QW + wave;                                   // query tile of this wave
     const int nqt = tiles_of(nq), nct = tiles_of(nc);
     const bool wave_live = qt < nqt;
-    const float *__restrict__ cpts = A.c + (size_t)bi * A.cstride;
+    const size_t qcloud = pairwise ? (size_t)(dir == 0 ? pi : pj) * A.qstride : (size_t)bi * A.qstride;
+    const size_t ccloud = pairwise ? (size_t)(dir == 0 ? pj : pi) * A.cstride : (size_t)bi * A.cstride;
+    const float *__restrict__ cpts = A.c + ccloud;
     const int j = qt * 32 + (lane & 31);
-    const float *qsrc = A.q + (size_t)bi * A.qstride + (size_t)min(j, nq - 1) * 3;
+    const float *qsrc = A.q + qcloud + (size_t)min(j, nq - 1) * 3;
     const float qx = qsrc[0], qy = qsrc[1], qz = qsrc[2];
     // The surrogate is evaluated on coordinates translated by mu = the mean of the first 64 candidates (every wave
     // computes the same value: no barrier), so that R2 -- and with it the filter's tolerance tau -- scales with the
@@ -301,15 +315,43 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
             qcount = 0;                                                       // the queue is per pass; smin carries over
         }
     }
-    if (!wave_live) return;
+    if (!wave_live && !pairwise) return;
     // merge the two lane halves of each query
     const float od = __shfl_xor(best, 32);
     const int oi = __shfl_xor(bidx, 32);
     if (od < best || (od == best && oi < bidx)) { best = od; bidx = oi; }
-    if (h == 0 && j < nq) {
-        A.dist[(size_t)bi * nq + j] = best;
-        A.idx[(size_t)bi * nq + j] = bidx;
+    if (!pairwise) {
+        if (h == 0 && j < nq) {
+            A.dist[(size_t)bi * nq + j] = best;
+            A.idx[(size_t)bi * nq + j] = bidx;
+        }
+        return;
     }
+    // pairwise: sum of this workgroup's distances in a fixed order -- butterfly over the 32 queries of a wave, waves in
+    // ascending order -- so that the result does not depend on scheduling
+    float sum = (wave_live && h == 0 && j < nq) ? best : 0.f;
+    for (int d = 16; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+    __syncthreads();                                   // s_r2 is free again (every wave has read tau's inputs long ago)
+    if (lane == 0) s_r2[wave] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        float t = s_r2[0];
+#pragma unroll
+        for (int w = 1; w < QW; ++w) t += s_r2[w];
+        args.part[part_at] = t;
+    }
+}
+
+// cds[i, j] = mean(dist1) + mean(dist2) from the workgroups' partial sums, tiles in ascending order
+// (lib/networks/utils.py:108-115: `(dl.mean(1) + dr.mean(1))`)
+__global__ __launch_bounds__(256) void pairwise_finish_kernel(long npairs, int nwg, int n, int m, const float *__restrict__ part,
+                                                              float *__restrict__ cds) {
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= npairs) return;
+    const float *p = part + (size_t)v * 2 * nwg;
+    float s1 = 0.f, s2 = 0.f;
+    for (int x = 0; x < nwg; ++x) { s1 += p[x]; s2 += p[nwg + x]; }
+    cds[v] = s1 / (float)n + s2 / (float)m;
 }
 
 }  // namespace
@@ -337,6 +379,7 @@ static int launch_nnm_qw(const MArgs &ma, int b, int nmax, hipStream_t s) {
 static int launch_nnm(int b, int n, const float *xyz, long xyz_stride, int m, const float *xyz2, long xyz2_stride,
                       float *result, int *result_i, float *result2, int *result2_i, hipStream_t s) {
     MArgs ma;
+    ma.pn2 = 0; ma.part = nullptr;
     ma.d[0] = MDir{xyz, xyz2, result, result_i, n, m, xyz_stride, xyz2_stride};       // nndistance.cu:126
     ma.d[1] = MDir{xyz2, xyz, result2, result2_i, m, n, xyz2_stride, xyz_stride};     // nndistance.cu:127
     const int nmax = n > m ? n : m;
@@ -381,4 +424,46 @@ extern "C" int dpf_nndistance_strided_auto(int b, int n, const float *xyz, long 
     if (xyz && xyz2 && result && result_i && result2 && result2_i && xyz_stride >= 0 && xyz2_stride >= 0 && nnm_pays(b, n, m))
         return launch_nnm(b, n, xyz, xyz_stride, m, xyz2, xyz2_stride, result, result_i, result2, result2_i, (hipStream_t)stream);
     return dpf_nndistance_strided(b, n, xyz, xyz_stride, m, xyz2, xyz2_stride, result, result_i, result2, result2_i, stream);
+}
+
+// The whole (N1, N2) Chamfer-distance matrix of lib/networks/utils.py:90-117 (pairwise_CD) in ONE launch (+ one tiny finish):
+// cds[i, j] = mean_k min_l |a_ik - b_jl|^2 + mean_l min_k |a_ik - b_jl|^2 for clouds1 (N1, n, 3) and clouds2 (N2, m, 3).
+// The reference expands cloud i against a batch of clouds2, copies it, and calls nn_distance once per i (utils.py:104-107);
+// here grid = (query tiles, j, 2 i + direction), every workgroup reads its two clouds in place, the per-point distances
+// are summed in the kernel and never written.  workspace: dpf_pairwise_cd_workspace_bytes(N1, N2, n, m) bytes.
+// Rows [i0, i1) only: what one rank of a row-sharded evaluation computes (cds still has N2 columns).
+// 512-query workgroups; 256-query ones for clouds of <= 256 points (half of a 16-wave workgroup would idle)
+static int pairwise_qw(int nmax) { return nmax <= 256 ? 8 : 16; }
+extern "C" size_t dpf_pairwise_cd_workspace_bytes(int n1, int n2, int n, int m) {
+    const int nmax = n > m ? n : m, per = pairwise_qw(nmax) * 32;
+    return (size_t)n1 * n2 * 2 * ((nmax + per - 1) / per) * sizeof(float);
+}
+extern "C" int dpf_pairwise_cd(int n1, int n2, int n, int m, const float *clouds1, const float *clouds2, float *cds,
+                               void *workspace, size_t workspace_bytes, dpf_stream_t stream) {
+    if (n1 < 0 || n2 < 0 || n <= 0 || m <= 0) return DPF_EINVAL;
+    if (n1 == 0 || n2 == 0) return 0;
+    if (!clouds1 || !clouds2 || !cds || !workspace) return DPF_EINVAL;
+    if (workspace_bytes < dpf_pairwise_cd_workspace_bytes(n1, n2, n, m)) return DPF_EINVAL;
+    if (n2 > 65535 || n1 > 32767 || n < 32 || m < 32 || n > 65535 * 32 || m > 65535 * 32) return DPF_ENOSUP;
+    MArgs ma;
+    ma.d[0] = MDir{clouds1, clouds2, nullptr, nullptr, n, m, (long)n * 3, (long)m * 3};
+    ma.d[1] = MDir{clouds2, clouds1, nullptr, nullptr, m, n, (long)m * 3, (long)n * 3};
+    ma.pn2 = n2; ma.part = (float *)workspace;
+    const int nmax = n > m ? n : m, qw = pairwise_qw(nmax), nwg = (nmax + qw * 32 - 1) / (qw * 32);
+    hipStream_t s = (hipStream_t)stream;
+    if (qw == 16) {
+        const int lds = CT * 1536 + 16 * QCAP * 64 * 6;
+        static LdsLimit limit;
+        if (hipError_t e = limit.ensure((const void *)nnm_kernel<16>, lds); e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(nnm_kernel<16>, dim3(nwg, n2, 2 * n1), dim3(16 * 64), lds, s, ma);
+    } else {
+        const int lds = CT * 1536 + 8 * QCAP * 64 * 6;
+        static LdsLimit limit;
+        if (hipError_t e = limit.ensure((const void *)nnm_kernel<8>, lds); e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(nnm_kernel<8>, dim3(nwg, n2, 2 * n1), dim3(8 * 64), lds, s, ma);
+    }
+    const long npairs = (long)n1 * n2;
+    hipLaunchKernelGGL(pairwise_finish_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, s, npairs, nwg, n, m,
+                       (const float *)workspace, cds);
+    return (int)hipGetLastError();
 }

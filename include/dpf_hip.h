@@ -131,6 +131,17 @@ int dpf_matchcostgrad_ws(int b, int n, int m, const float *xyz1, const float *xy
 int dpf_chamfer_reduce(int b, int n, int m, const float *dist1, const float *dist2,
                        float *cd, dpf_stream_t stream);
 
+/* pairwise_CD, lib/networks/utils.py:90-117 (called three times per generative evaluation, evaluating.py:245-247):
+ * cds[i, j] = mean(dist1) + mean(dist2) of nn_distance(clouds1[i], clouds2[j]) for ALL pairs in one launch (+ a
+ * finish over the workgroups' fixed-order partial sums).  clouds1 (n1, n, 3), clouds2 (n2, m, 3), cds (n1, n2),
+ * all point-major fp32; the reference's per-i `expand + contiguous + nn_distance` loop (utils.py:104-107) and its
+ * (N2, n) intermediates disappear.  Distances are those of dpf_nndistance (bit-exact minima); the means are summed
+ * per 512-query workgroup, then in ascending tile order.  n, m >= 32; n1 <= 32767, n2 <= 65535.
+ * A row-sharded evaluation passes its own rows of clouds1 and gathers the (rows, n2) blocks. */
+size_t dpf_pairwise_cd_workspace_bytes(int n1, int n2, int n, int m);
+int dpf_pairwise_cd(int n1, int n2, int n, int m, const float *clouds1, const float *clouds2, float *cds,
+                    void *workspace, size_t workspace_bytes, dpf_stream_t stream);
+
 /* ------------------------------------------------------------------------ *
  * Per-point conditional affine-coupling flow (eval-mode BatchNorm), i.e.
  * LocalCondRNVPDecoder.forward (lib/networks/decoders.py:54-72) over

@@ -211,3 +211,28 @@ def test_pairwise_cd_big_rows_take_the_matrix_core_kernel_and_keep_the_bits():
     ref = torch.stack([torch.stack([sum(v.mean(1) for v in BK.NNDistance(ta[i:i + 1].contiguous(), tb[j:j + 1].contiguous())[::2])[0]
                                     for j in range(0, N2, 13)]) for i in range(2)])
     assert torch.allclose(cds[:, ::13], ref, rtol=2e-6, atol=0)
+
+
+def test_pairwise_cd_one_launch_matrix():
+    """dpf_pairwise_cd: the whole (N1, N2) matrix from one launch -- against per-pair nn_distance + mean (the oracle for the
+    distances is pinned above; here the in-kernel means), ragged sizes (tails in both clouds, n != m, one tile and
+    several), deterministic, rows of a row-sharded call identical to the full call."""
+    BK = _gpu()
+    from dpf_nets_amd.networks.utils import pairwise_CD
+    for (N1, N2, n, m) in ((3, 5, 33, 600), (4, 3, 1100, 520), (2, 70, 2048, 2048)):
+        a = detrng.normal_f32(500 + n, (N1, n, 3), 0.0, 0.2)
+        b = detrng.uniform_f32(600 + m, (N2, m, 3), -0.4, 0.4)
+        ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+        cds = pairwise_CD(ta, tb)
+        assert cds.shape == (N1, N2) and torch.equal(cds, pairwise_CD(ta, tb))
+        ref = torch.empty_like(cds)
+        for i in range(N1):
+            d1, _, d2, _ = BK.NNDistance(ta[i:i + 1].expand(N2, n, 3).contiguous(), tb)       # utils.py:104-107
+            ref[i] = d1.double().mean(1).float() + d2.double().mean(1).float()
+        assert torch.allclose(cds, ref, rtol=3e-6, atol=0), float((cds - ref).abs().max())
+        assert torch.equal(pairwise_CD(ta, tb, bs=1), cds)                 # chunked rows: same bits
+        assert torch.equal(pairwise_CD(ta, tb, shard_rows=True), cds)      # world size 1: the whole matrix
+    # the C ABI rejects what it cannot serve
+    from dpf_nets_amd._lib import lib
+    assert lib().dpf_pairwise_cd(1, 1, 8, 64, ta.data_ptr(), tb.data_ptr(), cds.data_ptr(), cds.data_ptr(), 1 << 20, None) == -2
+    assert lib().dpf_pairwise_cd(1, 1, 64, 64, ta.data_ptr(), tb.data_ptr(), cds.data_ptr(), cds.data_ptr(), 4, None) == -1
