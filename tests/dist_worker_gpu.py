@@ -1,0 +1,79 @@
+"""Rank program of tests/test_gpu_multi.py (started with `python -m torch.distributed.run`): data-parallel training step of
+the flow decoder over RCCL.  Every rank runs inverse stack (batch-stat BN) + PointFlowNLL + backward on ITS shard of
+clouds through the HIP training kernels, then the ONE collective of the step, allreduce_flat_gradients (SURVEY 8e;
+lib/networks/training.py:55-56).  Checked on every rank: the reduced flat gradient is the mean of the ranks' local
+gradients; on rank 0 additionally: each rank's local gradient equals what a single process computes for that shard
+(parity is per replica: BatchNorm statistics are local)."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from dpf_nets_amd import distributed as D                      # noqa: E402
+from dpf_nets_amd import networks as nets, synthetic as SY     # noqa: E402
+
+
+def local_step(dec, store, p, g):
+    store.zero_grad()
+    ps, mus, lvs = dec(p, g, mode="inverse")
+    pm, pl = torch.zeros_like(p), torch.full_like(p, -3.6)
+    loss = nets.PointFlowNLL()(ps + [p], [pm] + mus, [pl] + lvs)
+    loss.backward()
+    return float(loss)
+
+
+def main():
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist.init_process_group("nccl", device_id=dev)
+    try:
+        B, N, G, nf = 4 * world, 256, 128, 2
+        state = SY.make_decoder_state(9, nf, 64, G)
+        tgt, _, g = SY.synthetic_inputs(9, B, N, G)
+        allp, allg = torch.from_numpy(tgt).to(dev), torch.from_numpy(g).to(dev)
+
+        def fresh():
+            dec = nets.LocalCondRNVPDecoder(nf, 64, G)
+            dec.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in state.items()}, strict=True)
+            dec = dec.to(dev).train()
+            return dec, dec.flatten_parameters()
+        dec, store = fresh()
+        p, gg = D.shard(allp, allg)                              # this rank's clouds
+        assert p.shape[0] == B // world
+        local_step(dec, store, p, gg)
+        mine = store.flat_g.clone()
+        n = D.allreduce_flat_gradients(store)                   # the ONE collective
+        assert n == (store.flat_g.numel() if world > 1 else 0)
+        locs = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(locs, mine)
+        want = sum(locs) / world
+        assert torch.allclose(store.flat_g, want, rtol=1e-6, atol=1e-9), float((store.flat_g - want).abs().max())
+        if world > 1:
+            assert not torch.equal(locs[0], locs[1])             # the shards really differ
+        if rank == 0:                                            # per-shard parity against a single process
+            for r in range(world):
+                lo, hi = D.shard_bounds(B, r, world)
+                d2, s2 = fresh()
+                local_step(d2, s2, allp[lo:hi].contiguous(), allg[lo:hi].contiguous())
+                assert torch.allclose(s2.flat_g, locs[r], rtol=1e-5, atol=1e-8), (r, float((s2.flat_g - locs[r]).abs().max()))
+        # eval path shards with no collective at all; per-cloud results come back in batch order
+        dec.eval()
+        with torch.no_grad():
+            ps, _, _ = dec(p, gg, mode="direct")
+        per_cloud = ps[-1].square().mean((1, 2))
+        gathered = D.gather_clouds(per_cloud)
+        assert gathered.shape[0] == B
+        dist.barrier()
+        if rank == 0:
+            print("DIST_OK world=%d flat=%d" % (world, store.flat_g.numel()))
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -150,3 +150,39 @@ def test_pairwise_emd_cd_and_emd_cd_callers():
     assert abs(float(EM.EMD_CD(ta, tb[:5], batch_size=4)["MMD-CD"]) - float(res.mean())) < 1e-7
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         EM._pairwise_EMD_CD_(ta.cpu(), tb.cpu(), 3)
+
+
+def test_emd_at_the_specified_size_vs_oracle_and_properties():
+    """BASELINE.json configs[4]: N = M = 8192.  One cloud against the C oracle (approxmatch.cu:3-224 restated; ~20 s of one
+    host core) -- cost, row/column mass and the elementwise fraction as above -- then B = 2 through the properties the
+    domain offers (mass conservation, nonnegativity, symmetry of the cost under swapping the clouds within the auction's
+    tolerance, match_cost() == MatchCost(ApproxMatch()), deferred == read-modify-write bits)."""
+    BK = _gpu()
+    n = 8192
+    a, b = chamfer_inputs(4242, 2, n, n)
+    b = (a[:, ::-1] + 0.03 * b).astype(np.float32).copy()              # a jittered, re-ordered copy: a non-trivial matching
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    match, temp, cost = BK.ApproxMatchCost(ta, tb)
+    torch.cuda.synchronize()
+    rmatch, _ = S.approxmatch(a[:1], b[:1])
+    rcost = S.matchcost(a[:1], b[:1], rmatch)
+    np.testing.assert_allclose(cost[:1].cpu().numpy(), rcost, rtol=1e-4)
+    gm = match[:1].cpu().numpy()
+    np.testing.assert_allclose(gm.sum(1), rmatch.sum(1), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(gm.sum(2), rmatch.sum(2), rtol=1e-3, atol=1e-4)
+    bad = np.abs(gm - rmatch) > 5e-3 * np.abs(rmatch) + 1e-4
+    assert bad.mean() < 1e-3, bad.mean()
+    del gm, rmatch, bad
+    # properties at B = 2
+    assert (match >= 0).all()
+    assert (match.sum(1) <= 1 + 1e-3).all() and (match.sum(2) <= 1 + 1e-3).all() and match.sum() > 0.95 * 2 * n
+    assert torch.allclose(BK.MatchCost(ta, tb, match), cost, rtol=1e-5)
+    BK.EMD_RMW = True
+    try:
+        m_rmw, _ = BK.ApproxMatch(ta, tb)
+    finally:
+        BK.EMD_RMW = False
+    assert torch.equal(m_rmw, match)
+    del m_rmw
+    _, _, cost_swapped = BK.ApproxMatchCost(tb, ta)
+    assert torch.allclose(cost_swapped, cost, rtol=5e-2)               # the auction is not symmetric, its optimum nearly is
