@@ -201,8 +201,11 @@ def make_step(dec, z, g, tgt_pm, L, precision=None):
     def step():
         p_out, sum_lv, ps, mus, lvs = stack.run(z, g, "direct", precision, want_lists=dec.materialize_lists,
                                                 n_layers=L, want_pointmajor=True)
-        d1, i1, d2, i2 = BK.NNDistance(stack.last_pointmajor, tgt_pm)
-        cd = chamfer_per_cloud(d1, d2)
+        if BK.NN_IMPL == "auto":          # distances, indices and the per-cloud CD from the search kernel's workgroups
+            d1, i1, d2, i2, cd = BK.NNDistanceCD(stack.last_pointmajor, tgt_pm)
+        else:
+            d1, i1, d2, i2 = BK.NNDistance(stack.last_pointmajor, tgt_pm)
+            cd = chamfer_per_cloud(d1, d2)
         return p_out, sum_lv, d1, i1, d2, i2, cd
     return step
 

@@ -106,6 +106,9 @@ struct MDir {
 // pairwise mode (pn2 > 0): blockIdx.y = j, blockIdx.z = 2 i + direction select the pair (clouds1[i], clouds2[j]); instead of
 // per-point distances and indices a workgroup writes the SUM of its queries' distances (fixed order) to
 // part[((i * pn2 + j) * 2 + direction) * gridDim.x + blockIdx.x] -- the (N1, N2, n) intermediates never exist
+// batch mode with part != nullptr (dpf_nndistance_cd): distances and indices are written AND the workgroup's sum goes to
+// part[(bi * 2 + direction) * gridDim.x + blockIdx.x] -- the per-cloud CD reduction then reads a handful of partial sums
+// instead of the (B, n) distances
 struct MArgs { MDir d[2]; int pn2; float *part; };
 
 __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b) {
@@ -179,9 +182,11 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
     const int pi = pairwise ? (int)(blockIdx.z >> 1) : 0, pj = (int)blockIdx.y;
     const int bi = pairwise ? 0 : (int)blockIdx.y;
     const int nq = A.nq, nc = A.nc;
-    const size_t part_at = pairwise ? (((size_t)pi * args.pn2 + pj) * 2 + dir) * gridDim.x + blockIdx.x : 0;
+    const bool sums = args.part != nullptr;                   // pairwise mode always; batch mode on request
+    const size_t part_at = pairwise ? (((size_t)pi * args.pn2 + pj) * 2 + dir) * gridDim.x + blockIdx.x
+                                    : ((size_t)bi * 2 + dir) * gridDim.x + blockIdx.x;
     if ((int)blockIdx.x * QW * 32 >= nq) {
-        if (pairwise && threadIdx.x == 0) args.part[part_at] = 0.f;
+        if (sums && threadIdx.x == 0) args.part[part_at] = 0.f;
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
@@ -315,19 +320,19 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
             qcount = 0;                                                       // the queue is per pass; smin carries over
         }
     }
-    if (!wave_live && !pairwise) return;
+    if (!wave_live && !sums) return;
     // merge the two lane halves of each query
     const float od = __shfl_xor(best, 32);
     const int oi = __shfl_xor(bidx, 32);
     if (od < best || (od == best && oi < bidx)) { best = od; bidx = oi; }
     if (!pairwise) {
-        if (h == 0 && j < nq) {
+        if (wave_live && h == 0 && j < nq) {
             A.dist[(size_t)bi * nq + j] = best;
             A.idx[(size_t)bi * nq + j] = bidx;
         }
-        return;
+        if (!sums) return;
     }
-    // pairwise: sum of this workgroup's distances in a fixed order -- butterfly over the 32 queries of a wave, waves in
+    // sum of this workgroup's distances in a fixed order -- butterfly over the 32 queries of a wave, waves in
     // ascending order -- so that the result does not depend on scheduling
     float sum = (wave_live && h == 0 && j < nq) ? best : 0.f;
     for (int d = 16; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
@@ -367,6 +372,7 @@ static long nnm_workgroups(int b, int n, int m, int qw) {
 
 template <int QW>
 static int launch_nnm_qw(const MArgs &ma, int b, int nmax, hipStream_t s) {
+    // (the grid's x extent is the stride of the partial sums when ma.part is set)
     const int lds = CT * 1536 + QW * QCAP * 64 * 6;
     static LdsLimit limit;
     if (hipError_t e = limit.ensure((const void *)nnm_kernel<QW>, lds); e != hipSuccess) return (int)e;
@@ -377,13 +383,14 @@ static int launch_nnm_qw(const MArgs &ma, int b, int nmax, hipStream_t s) {
 // 16 waves (512 queries) per workgroup share one build of the candidates' fragments; when that leaves fewer than 128
 // workgroups (small batches of big clouds, e.g. B = 2, N = 8192 per GPU in cfg-5) 8-wave workgroups fill twice the CUs
 static int launch_nnm(int b, int n, const float *xyz, long xyz_stride, int m, const float *xyz2, long xyz2_stride,
-                      float *result, int *result_i, float *result2, int *result2_i, hipStream_t s) {
+                      float *result, int *result_i, float *result2, int *result2_i, hipStream_t s, float *part = nullptr,
+                      bool force16 = false) {
     MArgs ma;
-    ma.pn2 = 0; ma.part = nullptr;
+    ma.pn2 = 0; ma.part = part;
     ma.d[0] = MDir{xyz, xyz2, result, result_i, n, m, xyz_stride, xyz2_stride};       // nndistance.cu:126
     ma.d[1] = MDir{xyz2, xyz, result2, result2_i, m, n, xyz2_stride, xyz_stride};     // nndistance.cu:127
     const int nmax = n > m ? n : m;
-    return nnm_workgroups(b, n, m, 16) >= 128 ? launch_nnm_qw<16>(ma, b, nmax, s) : launch_nnm_qw<8>(ma, b, nmax, s);
+    return (force16 || nnm_workgroups(b, n, m, 16) >= 128) ? launch_nnm_qw<16>(ma, b, nmax, s) : launch_nnm_qw<8>(ma, b, nmax, s);
 }
 
 // enough pairs to amortise building the fragments and enough workgroups to fill the chip (r01, tools/nn_impl_sweep.py:
@@ -466,4 +473,35 @@ extern "C" int dpf_pairwise_cd(int n1, int n2, int n, int m, const float *clouds
     hipLaunchKernelGGL(pairwise_finish_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, s, npairs, nwg, n, m,
                        (const float *)workspace, cds);
     return (int)hipGetLastError();
+}
+
+// nn_distance + the per-cloud reduction of its callers in one go (lib/networks/evaluating.py:110-113:
+// `dl, dr = distChamferCUDA(...); cd = (dl.mean(1) + dr.mean(1))`): the outputs of dpf_nndistance (same bits) and
+// cd[b] = mean(result[b]) + mean(result2[b]).  Where the matrix-core kernel serves the problem its workgroups also emit
+// fixed-order sums of their distances and a tiny finish kernel adds them (workspace: dpf_nndistance_cd_workspace_bytes);
+// otherwise dpf_nndistance + dpf_chamfer_reduce.  The two reductions associate differently (last-bit differences in cd).
+extern "C" size_t dpf_nndistance_cd_workspace_bytes(int b, int n, int m) {
+    const int nmax = n > m ? n : m;
+    return (size_t)(b > 0 ? b : 0) * 2 * ((nmax + 511) / 512) * sizeof(float) + 16;
+}
+extern "C" int dpf_nndistance_cd(int b, int n, const float *xyz, int m, const float *xyz2, float *result, int *result_i,
+                                 float *result2, int *result2_i, float *cd, void *workspace, size_t workspace_bytes,
+                                 dpf_stream_t stream) {
+    if (b < 0 || n <= 0 || m <= 0) return DPF_EINVAL;
+    if (b == 0) return 0;
+    if (!xyz || !xyz2 || !result || !result_i || !result2 || !result2_i || !cd) return DPF_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (workspace && workspace_bytes >= dpf_nndistance_cd_workspace_bytes(b, n, m) && nnm_pays(b, n, m) &&
+        nnm_workgroups(b, n, m, 16) >= 128) {
+        const int nmax = n > m ? n : m, nwg = (nmax + 511) / 512;
+        int rc = launch_nnm(b, n, xyz, (long)n * 3, m, xyz2, (long)m * 3, result, result_i, result2, result2_i, s,
+                            (float *)workspace, true);
+        if (rc) return rc;
+        hipLaunchKernelGGL(pairwise_finish_kernel, dim3((b + 255) / 256), dim3(256), 0, s, (long)b, nwg, n, m,
+                           (const float *)workspace, cd);
+        return (int)hipGetLastError();
+    }
+    int rc = dpf_nndistance_auto(b, n, xyz, m, xyz2, result, result_i, result2, result2_i, stream);
+    if (rc) return rc;
+    return dpf_chamfer_reduce(b, n, m, result, result2, cd, stream);
 }

@@ -70,6 +70,26 @@ def NNDistance(set_d, set_q):
     return [dist1, idx1, dist2, idx2]
 
 
+def NNDistanceCD(set_d, set_q):
+    """NNDistance plus cd (B,) = dist1.mean(1) + dist2.mean(1) (evaluating.py:112) -> [dist1, idx1, dist2, idx2, cd]; the
+    reduction rides on the search kernel's workgroups (dpf_nndistance_cd) instead of a pass over the distances."""
+    _check_input(set_d, "set_d"); _check_input(set_q, "set_q")
+    b, n, m = _dims(set_d, set_q)
+    dev = set_d.device
+    dist1 = torch.empty((b, n), dtype=torch.float32, device=dev)
+    idx1 = torch.empty((b, n), dtype=torch.int32, device=dev)
+    dist2 = torch.empty((b, m), dtype=torch.float32, device=dev)
+    idx2 = torch.empty((b, m), dtype=torch.int32, device=dev)
+    cd = torch.empty((b,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        nbytes = lib().dpf_nndistance_cd_workspace_bytes(b, n, m)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        check(lib().dpf_nndistance_cd(b, n, set_d.data_ptr(), m, set_q.data_ptr(), dist1.data_ptr(), idx1.data_ptr(),
+                                      dist2.data_ptr(), idx2.data_ptr(), cd.data_ptr(), ws.data_ptr(), nbytes,
+                                      current_stream()), "nndistance_cd")
+    return [dist1, idx1, dist2, idx2, cd]
+
+
 def NNDistanceGrad(set_d, set_q, idx1, idx2, grad_dist1, grad_dist2):
     """-> [grad1 (B,n,3), grad2 (B,m,3)]                                    structural_loss.cpp:101-124"""
     _check_input(set_d, "set_d"); _check_input(set_q, "set_q")

@@ -131,6 +131,15 @@ int dpf_matchcostgrad_ws(int b, int n, int m, const float *xyz1, const float *xy
 int dpf_chamfer_reduce(int b, int n, int m, const float *dist1, const float *dist2,
                        float *cd, dpf_stream_t stream);
 
+/* nn_distance and its callers' reduction in one call (lib/networks/evaluating.py:110-113): the four outputs of
+ * dpf_nndistance (same bits) plus cd[b] = mean(result[b]) + mean(result2[b]).  With the matrix-core kernel the
+ * workgroups emit fixed-order sums of their distances and a finish kernel adds them in tile order (workspace of
+ * dpf_nndistance_cd_workspace_bytes bytes, caller-owned); otherwise dpf_nndistance_auto + dpf_chamfer_reduce. */
+size_t dpf_nndistance_cd_workspace_bytes(int b, int n, int m);
+int dpf_nndistance_cd(int b, int n, const float *xyz, int m, const float *xyz2,
+                      float *result, int *result_i, float *result2, int *result2_i, float *cd,
+                      void *workspace, size_t workspace_bytes, dpf_stream_t stream);
+
 /* pairwise_CD, lib/networks/utils.py:90-117 (called three times per generative evaluation, evaluating.py:245-247):
  * cds[i, j] = mean(dist1) + mean(dist2) of nn_distance(clouds1[i], clouds2[j]) for ALL pairs in one launch (+ a
  * finish over the workgroups' fixed-order partial sums).  clouds1 (n1, n, 3), clouds2 (n2, m, 3), cds (n1, n2),

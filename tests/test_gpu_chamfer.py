@@ -236,3 +236,18 @@ def test_pairwise_cd_one_launch_matrix():
     from dpf_nets_amd._lib import lib
     assert lib().dpf_pairwise_cd(1, 1, 8, 64, ta.data_ptr(), tb.data_ptr(), cds.data_ptr(), cds.data_ptr(), 1 << 20, None) == -2
     assert lib().dpf_pairwise_cd(1, 1, 64, 64, ta.data_ptr(), tb.data_ptr(), cds.data_ptr(), cds.data_ptr(), 4, None) == -1
+
+
+def test_nndistance_cd_fused_reduction():
+    """dpf_nndistance_cd: the same four outputs as NNDistance, bit for bit, and cd = dist1.mean(1) + dist2.mean(1) -- on the
+    matrix-core path (workgroup sums + finish) and on the fallback (small problem: scan + chamfer_reduce)."""
+    BK = _gpu()
+    for (B, n, m) in ((32, 2048, 2048), (3, 257, 300), (8, 2500, 2048)):
+        a, b = chamfer_inputs(900 + n, B, n, m)
+        ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+        d1, i1, d2, i2, cd = BK.NNDistanceCD(ta, tb)
+        for x, y in zip((d1, i1, d2, i2), BK.NNDistance(ta, tb)):
+            assert torch.equal(x, y)
+        ref = d1.double().mean(1) + d2.double().mean(1)
+        assert torch.allclose(cd.double(), ref, rtol=2e-6, atol=0)
+        assert torch.equal(cd, BK.NNDistanceCD(ta, tb)[4])              # deterministic
