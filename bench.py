@@ -69,6 +69,9 @@ def parse(argv=None):
                     help="untimed steps run BEFORE the --warmup steps so that the chip's clocks have settled under this load "
                          "whatever --warmup is; default 400 for the eval leg of cfg2/cfg3, 0 otherwise")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--graph-steps", type=int, default=10,
+                    help="steps captured per hipGraph (a replay has a fixed cost of ~10 us whatever it holds); n steps run as "
+                         "n // G replays of the G-step graph + n %% G replays of a one-step graph, so exactly n steps execute")
     ap.add_argument("--streams", type=int, default=1,
                     help="consecutive steps go round-robin over this many streams (each with its own buffers); 1 (default) = "
                          "strictly one after another, the regime the roofline numbers and the committed profiles describe")
@@ -404,7 +407,8 @@ def leg_eval(args, rank, world, dist, device):
     S = max(1, args.streams)
     S_all = max(S, args.pipelined if S == 1 else 0)
     streams = [torch.cuda.Stream() for _ in range(S_all)]
-    runners = []
+    G = max(1, args.graph_steps) if (S == 1 and not args.no_graph) else 1     # multi-step graphs only in the one-stream regime
+    runners, multi = [], None
     for st in streams:
         st.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(st):
@@ -417,8 +421,20 @@ def leg_eval(args, rank, world, dist, device):
             with torch.cuda.graph(graph, stream=st):
                 out = step()
             runners.append(graph.replay)
+            if G > 1 and multi is None:
+                multi = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(multi, stream=st):
+                    for _ in range(G):
+                        out = step()
 
     def run_steps(n, S=S):
+        if multi is not None and S == 1:
+            with torch.cuda.stream(streams[0]):
+                for _ in range(n // G):
+                    multi.replay()
+                for _ in range(n % G):
+                    runners[0]()
+            return
         for i in range(n):
             with torch.cuda.stream(streams[i % S]):
                 runners[i % S]()
@@ -484,7 +500,7 @@ def leg_eval(args, rank, world, dist, device):
                                "nn_distance both directions + CD reduction" % (cfg["name"], L, L, n_flows),
                    "clouds_per_gpu": B, "points_per_cloud": N, "hidden": 64, "latent": args.latent,
                    "global_clouds": pts_per_step // N, "per_layer_lists": bool(args.lists),
-                   "launch": ("eager" if args.no_graph else "hipGraph replay") +
+                   "launch": ("eager" if args.no_graph else "hipGraph replay, %d step(s) per graph" % G) +
                    (", consecutive steps round-robin over %d streams with their own buffers" % S if S > 1 else ""),
                    "steps_in_flight": S, "settle_steps": args.settle, "parallelism": "clouds sharded, no collective",
                    "chamfer_impl": BK.NN_IMPL + (" (matrix-core filtered exact search at this size)" if BK.NN_IMPL == "auto" and

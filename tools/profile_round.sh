@@ -1,0 +1,27 @@
+#!/bin/bash
+# One call that collects everything profiles/ needs for a round (run on the GPU box through gpurun):
+#   tools/profile_round.sh r02        -> gpurun_out/r02_prof/{kernel_trace_stats.txt, pmc/pass*.txt, traffic.json, bench_*.json}
+# Kernel trace and counters come from SEPARATE rocprofv3 runs (never combined with trace domains); the profiled program is
+# python3 bench.py itself, directly after `--`.
+set -u
+TAG=$1
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extra --pipelined 0 > $OUT/kt.log 2>&1
+for db in $(find $OUT/kt -name "*.db"); do
+  { echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-extra --pipelined 0   ($TAG; hipGraph replay, default precision)"; python3 $GRAFT_REPO_ROOT/tools/rocprof_summary.py $db; } > $OUT/kernel_trace_stats.txt 2>&1
+done
+rm -rf $OUT/kt
+cd $GRAFT_REPO_ROOT
+bash tools/pmc_run.sh ${TAG}_prof/pmc > /dev/null 2>&1
+cp profiles/traffic.json $OUT/traffic.json 2>/dev/null
+python3 tools/pmc_traffic.py $OUT/pmc B32_N2048_L14_f16x3 $OUT/traffic.json > /dev/null 2>&1
+python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+python3 bench.py --layers 63 --no-extra --no-cpu-baseline > $OUT/bench_L63.json 2>> $OUT/bench_default.err
+python3 bench.py --layers 15 --no-extra --no-cpu-baseline > $OUT/bench_L15.json 2>> $OUT/bench_default.err
+python3 bench.py --config cfg3 --no-extra > $OUT/bench_cfg3.json 2>> $OUT/bench_default.err
+python3 bench.py --config cfg5 > $OUT/bench_cfg5.json 2>> $OUT/bench_default.err
+python3 bench.py --leg train > $OUT/bench_train.json 2>> $OUT/bench_default.err
+python3 bench.py --no-graph --no-extra --no-cpu-baseline > $OUT/bench_eager.json 2>> $OUT/bench_default.err
+ls -la $OUT
