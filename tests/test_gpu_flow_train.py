@@ -380,3 +380,61 @@ def test_training_layer_sum_of_logvars_reaches_the_nll():
     assert rel(ga, gb) <= 1e-4
     worst = max(rel(a, b) for a, b in zip(pa, pb) if float(b.abs().max()) > 0)
     assert worst <= 1e-3, worst
+
+
+def test_training_stack_error_budget_vs_float64(golden_dir):
+    """instead of a flat tolerance, hold the HIP training path to the error the fp32 tensor-op path ITSELF has
+    against float64 on the same inputs.  Both are measured against forward_torch in float64 on the reference's own
+    6-layer golden case (flow_decoder.json, bn == 'train') and on a full-size batch; the numbers are printed (pytest -s) and
+    written to gpurun_out/train_error_budget.json.
+      outputs (ps[0], sum of logvars, loss): HIP (bf16x6 forward) <= 2 x the fp32 path's error (floor 1e-6: both are at the
+        rounding level of fp32 there);
+      gradients (d/dp, d/dg, every parameter): HIP <= 6 x the fp32 path's error.  Measured r02 on the golden case: d/dp
+        6.0e-5 vs 1.8e-5, d/dg 2.1e-5 vs 5.5e-6, worst parameter gradient 9.9e-5 vs 2.0e-5 -- the factor 3-5 is the hi/lo
+        bf16 split of the gradient contractions (dh0 = W1^T dh1, dW1 = dh1 h0^T: 16 significant bits per operand; DESIGN
+        4.6), not the forward (bf16x6, at fp32's own level); fp16 parts as in the eval kernel would close it."""
+    nets = _gpu()
+    import json as _json
+    gold, meta = _load(golden_dir, "flow_decoder")
+    case = [c for c in meta["cases"] if c.get("bn") == "train"][0]
+    report = {}
+    for tag, (n_flows, B, N, G, seed) in (("golden_6_layers", tuple(case[k] for k in ("n_flows", "B", "N", "G", "seed"))),
+                                          ("full_size_6_layers", (2, 32, 2048, 128, 77))):
+        sd = FO.to_torch(FO.make_decoder_state(seed, n_flows, 64, G))
+        tgt, z, g = FO.synthetic_inputs(seed, B, N, G)
+        res = {}
+        for impl in ("hip", "torch", "torch64"):
+            dec = nets.LocalCondRNVPDecoder(n_flows, 64, G, weight_std=0.01)
+            dec.load_state_dict(sd, strict=True)
+            dec = dec.cuda().train()
+            tp, tg = torch.from_numpy(tgt.copy()).cuda(), torch.from_numpy(g.copy()).cuda()
+            if impl == "torch64":
+                dec, tp, tg = dec.double(), tp.double(), tg.double()
+            tp.requires_grad_(True); tg.requires_grad_(True)
+            ps, mus, lvs = dec(tp, tg, mode="inverse") if impl == "hip" else dec.forward_torch(tp, tg, mode="inverse")
+            pm, pl = torch.zeros(B, 3, N).cuda().to(tp.dtype), torch.full((B, 3, N), -3.6).cuda().to(tp.dtype)
+            loss = nets.PointFlowNLL()(ps + [tp], [pm] + mus, [pl] + lvs)
+            loss.backward()
+            res[impl] = dict(ps0=ps[0].detach(), slv=sum(lvs).detach(), loss=float(loss), gp=tp.grad, gg=tg.grad,
+                             grads={k: v.grad for k, v in dec.named_parameters()})
+        t = res["torch64"]
+        rows = {}
+        for key in ("ps0", "slv", "gp", "gg"):
+            rows[key] = (rel(res["hip"][key], t[key]), rel(res["torch"][key], t[key]))
+        rows["loss"] = (abs(res["hip"]["loss"] - t["loss"]) / abs(t["loss"]), abs(res["torch"]["loss"] - t["loss"]) / abs(t["loss"]))
+        worst_h = worst_t = 0.0
+        for k in t["grads"]:
+            worst_h = max(worst_h, rel(res["hip"]["grads"][k], t["grads"][k]))
+            worst_t = max(worst_t, rel(res["torch"]["grads"][k], t["grads"][k]))
+        rows["param_grads_worst"] = (worst_h, worst_t)
+        report[tag] = {k: {"hip_vs_f64": a, "fp32_tensor_ops_vs_f64": b} for k, (a, b) in rows.items()}
+        print(tag, {k: ("%.2e" % a, "%.2e" % b) for k, (a, b) in rows.items()})
+        for key in ("ps0", "slv", "loss"):
+            a, b = rows[key]
+            assert a <= max(2 * b, 1e-6), (tag, key, a, b)
+        for key in ("gp", "gg", "param_grads_worst"):
+            a, b = rows[key]
+            assert a <= 6 * b, (tag, key, a, b)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    _json.dump(report, open(os.path.join(out, "train_error_budget.json"), "w"), indent=1)
