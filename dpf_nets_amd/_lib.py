@@ -41,6 +41,8 @@ SIGNATURES = {
     "dpf_flow_pack": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "dpf_flow_film": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _f, _vp]),
     "dpf_flow_forward": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp]),
+    "dpf_flow_forward_base": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _vp, _vp, _vp, _vp, _vp,
+                                   _vp, _f, _vp]),
     "dpf_flow_train_canon_floats": (_sz, []),
     "dpf_flow_train_packed_bytes": (_sz, [_i, _i]),
     "dpf_flow_train_stats_floats": (_sz, []),
@@ -67,6 +69,7 @@ SIGNATURES = {
                                        _f, _f, _vp]),
     "dpf_pointflow_nll_workspace_floats": (_sz, []),
     "dpf_pointflow_nll": (_i, [_i, _i, _i, _vp, _vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _vp, _vp, _vp]),
+    "dpf_pointflow_nll_backward": (_i, [_i, _i, _i, _vp, _vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dpf_version": (ctypes.c_char_p, []),
 }
 

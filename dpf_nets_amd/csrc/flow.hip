@@ -271,6 +271,12 @@ struct FlowArgs {
     float *p_out, *p_out_pm, *sum_lv, *ps, *mus, *lvs;
     int L, B, N, mode, prio;
     float eps;
+    // optional prologue (direct mode, models.py:76-79 + :212): p_in is the NOISE and the stack starts from
+    // z = p_in * exp(0.5 * lv0) + mu0, the base distribution read through its (batch, channel, point) strides -- the
+    // reference's stride-0 expansions (models.py:153-158, 203-209) are never materialised; z_out (optional) receives z
+    const float *base_mu, *base_lv;
+    long mu_sb, mu_sc, mu_sn, lv_sb, lv_sc, lv_sn;
+    float *z_out;
 #ifdef DPF_PROFILE
     unsigned long long *prof;
 #endif
@@ -680,6 +686,18 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
     const int nc = valid ? n : N - 1;
     const size_t cloud = (size_t)bi * 3 * N;
     float p0 = a.p_in[cloud + nc], p1 = a.p_in[cloud + N + nc], p2 = a.p_in[cloud + 2 * (size_t)N + nc];
+    if (a.base_mu != nullptr) {            // reparameterize: eps.mul(exp(0.5 * logvar)).add_(mu), every op rounded as torch's
+        float *pp[3] = {&p0, &p1, &p2};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float lv = a.base_lv[bi * a.lv_sb + c * a.lv_sc + nc * a.lv_sn];
+            const float mu = a.base_mu[bi * a.mu_sb + c * a.mu_sc + nc * a.mu_sn];
+            *pp[c] = __fadd_rn(__fmul_rn(*pp[c], expf(__fmul_rn(0.5f, lv))), mu);
+        }
+        if (a.z_out != nullptr && valid && !(lane >> 5)) {
+            a.z_out[cloud + n] = p0; a.z_out[cloud + N + n] = p1; a.z_out[cloud + 2 * (size_t)N + n] = p2;
+        }
+    }
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;   // running sum of logvar per channel
     const bool inverse = a.mode == DPF_MODE_INVERSE;
     const size_t list_stride = (size_t)a.B * 3 * N;
@@ -898,10 +916,11 @@ extern "C" int dpf_flow_film(int n_layers, int B, int G, int precision, const vo
     return (int)hipGetLastError();
 }
 
-extern "C" int dpf_flow_forward(int n_layers, int B, int N, int mode, int precision, const void *packed,
-                                const int *meta, const float *film, const float *p_in, float *p_out,
-                                float *p_out_pointmajor, float *sum_logvar, float *ps, float *mus, float *logvars,
-                                float flow_eps, dpf_stream_t stream) {
+static int flow_forward_impl(int n_layers, int B, int N, int mode, int precision, const void *packed,
+                             const int *meta, const float *film, const float *p_in, float *p_out,
+                             float *p_out_pointmajor, float *sum_logvar, float *ps, float *mus, float *logvars,
+                             float flow_eps, dpf_stream_t stream, const float *base_mu, const long *mu_strides,
+                             const float *base_lv, const long *lv_strides, float *z_out) {
     const int ns = ns_of(precision);
     if (!ns || n_layers <= 0 || B < 0 || N <= 0 || (mode != DPF_MODE_DIRECT && mode != DPF_MODE_INVERSE)) return DPF_EINVAL;
     if (B == 0) return 0;
@@ -912,6 +931,12 @@ extern "C" int dpf_flow_forward(int n_layers, int B, int N, int mode, int precis
     a.packed = (const uint8_t *)packed; a.meta = meta; a.film = film; a.p_in = p_in;
     a.p_out = p_out; a.p_out_pm = p_out_pointmajor; a.sum_lv = sum_logvar; a.ps = ps; a.mus = mus; a.lvs = logvars;
     a.L = n_layers; a.B = B; a.N = N; a.mode = mode; a.eps = flow_eps;
+    a.base_mu = base_mu; a.base_lv = base_lv; a.z_out = z_out;
+    a.mu_sb = a.mu_sc = a.mu_sn = a.lv_sb = a.lv_sc = a.lv_sn = 0;
+    if (base_mu != nullptr) {
+        a.mu_sb = mu_strides[0]; a.mu_sc = mu_strides[1]; a.mu_sn = mu_strides[2];
+        a.lv_sb = lv_strides[0]; a.lv_sc = lv_strides[1]; a.lv_sn = lv_strides[2];
+    }
     static const int prio_env = getenv("DPF_FLOW_PRIO") ? atoi(getenv("DPF_FLOW_PRIO")) : 1;
     a.prio = prio_env;
 #ifdef DPF_PROFILE
@@ -940,6 +965,28 @@ extern "C" int dpf_flow_forward(int n_layers, int B, int N, int mode, int precis
     if (fw >= 4) return launch_flow_prec<4, 1>(precision, a, s);
     if (fw >= 2) return launch_flow_prec<2, 1>(precision, a, s);
     return launch_flow_prec<1, 1>(precision, a, s);
+}
+
+extern "C" int dpf_flow_forward(int n_layers, int B, int N, int mode, int precision, const void *packed,
+                                const int *meta, const float *film, const float *p_in, float *p_out,
+                                float *p_out_pointmajor, float *sum_logvar, float *ps, float *mus, float *logvars,
+                                float flow_eps, dpf_stream_t stream) {
+    return flow_forward_impl(n_layers, B, N, mode, precision, packed, meta, film, p_in, p_out, p_out_pointmajor, sum_logvar, ps,
+                             mus, logvars, flow_eps, stream, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+// dpf_flow_forward in DIRECT mode with the reparameterisation of the base sample fused into its prologue
+// (models.py:76-79, :212): noise (B,3,N) in, z = noise * exp(0.5 * lv0) + mu0 formed in registers (and stored to z_out,
+// which the models return as p_prior_samples[0]); mu0 / lv0 through (batch, channel, point) element strides.
+extern "C" int dpf_flow_forward_base(int n_layers, int B, int N, int precision, const void *packed, const int *meta,
+                                     const float *film, const float *noise, const float *mu0, long mu_sb, long mu_sc,
+                                     long mu_sn, const float *lv0, long lv_sb, long lv_sc, long lv_sn, float *z_out,
+                                     float *p_out, float *p_out_pointmajor, float *sum_logvar, float *ps, float *mus,
+                                     float *logvars, float flow_eps, dpf_stream_t stream) {
+    if (!mu0 || !lv0) return DPF_EINVAL;
+    const long ms[3] = {mu_sb, mu_sc, mu_sn}, ls[3] = {lv_sb, lv_sc, lv_sn};
+    return flow_forward_impl(n_layers, B, N, DPF_MODE_DIRECT, precision, packed, meta, film, noise, p_out, p_out_pointmajor,
+                             sum_logvar, ps, mus, logvars, flow_eps, stream, mu0, ms, lv0, ls, z_out);
 }
 
 #ifdef DPF_PROFILE

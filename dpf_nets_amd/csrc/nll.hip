@@ -37,7 +37,39 @@ __global__ void nll_finish_kernel(int nwg, int B, float constant, const float *_
     out[0] = 0.5f * (s / B + constant);
 }
 
+// d(out)/d(s0), d(out)/d(sum_lv) and, on request, d/d(mu0), d/d(lv0) as FULL (B,C,N) tensors (autograd's expand-backward
+// reduces them over the broadcast dimensions when the base distribution is a learned per-cloud vector):
+//   out = 0.5 * (S / B + const),  S = sum [ sum_lv + lv0 + (s0 - mu0)^2 / e^{lv0} ]
+//   d s0 = g (s0 - mu0) / e^{lv0} / B,  d sum_lv = g / (2B),  d mu0 = -d s0,  d lv0 = g (1 - (s0 - mu0)^2 / e^{lv0}) / (2B)
+__global__ __launch_bounds__(T) void nll_backward_kernel(int B, int C, int N, const float *__restrict__ s0, const float *__restrict__ mu0,
+                                                         long mu_sb, long mu_sc, long mu_sn, const float *__restrict__ lv0, long lv_sb,
+                                                         long lv_sc, long lv_sn, const float *__restrict__ gout, float *__restrict__ ds0,
+                                                         float *__restrict__ dsum, float *__restrict__ dmu, float *__restrict__ dlv) {
+    const long total = (long)B * C * N;
+    const float g = gout[0] / (float)B;
+    for (long e = (long)blockIdx.x * T + threadIdx.x; e < total; e += (long)gridDim.x * T) {
+        const int n = (int)(e % N), c = (int)((e / N) % C), b = (int)(e / ((long)N * C));
+        const float lv = lv0[b * lv_sb + c * lv_sc + n * lv_sn], d = s0[e] - mu0[b * mu_sb + c * mu_sc + n * mu_sn];
+        const float iv = 1.0f / expf(lv), gd = g * d * iv;
+        if (ds0) ds0[e] = gd;
+        if (dsum) dsum[e] = 0.5f * g;
+        if (dmu) dmu[e] = -gd;
+        if (dlv) dlv[e] = 0.5f * g * (1.0f - d * d * iv);
+    }
+}
+
 }  // namespace
+
+extern "C" int dpf_pointflow_nll_backward(int B, int C, int N, const float *s0, const float *mu0, long mu_sb, long mu_sc, long mu_sn,
+                                          const float *lv0, long lv_sb, long lv_sc, long lv_sn, const float *grad_out, float *d_s0,
+                                          float *d_sum_lv, float *d_mu0, float *d_lv0, dpf_stream_t stream) {
+    if (B <= 0 || C <= 0 || N <= 0 || !s0 || !mu0 || !lv0 || !grad_out) return DPF_EINVAL;
+    const long total = (long)B * C * N;
+    const int nwg = (int)((total + 4 * T - 1) / (4 * T) < 1024 ? (total + 4 * T - 1) / (4 * T) : 1024);
+    hipLaunchKernelGGL(nll_backward_kernel, dim3(nwg), dim3(T), 0, (hipStream_t)stream, B, C, N, s0, mu0, mu_sb, mu_sc, mu_sn, lv0, lv_sb,
+                       lv_sc, lv_sn, grad_out, d_s0, d_sum_lv, d_mu0, d_lv0);
+    return (int)hipGetLastError();
+}
 
 extern "C" size_t dpf_pointflow_nll_workspace_floats(void) { return MAXWG; }
 

@@ -78,6 +78,29 @@ class LocalCondRNVPDecoder(nn.Module):
                 ps, mus, lvs = buf[0] + ps, buf[1] + mus, buf[2] + lvs
         return ps, mus, lvs
 
+    def sample_and_decode(self, mu0, logvar0, g, noise=None):
+        """`reparameterize` + `forward(z, g, mode='direct')` of lib/networks/models.py:211-213 (and :118-119, :250-253) as
+        ONE call (extension): returns (z, ps, mus, logvars) with z = noise * exp(0.5 * logvar0) + mu0 =
+        what the models store as p_prior_samples[0].  mu0 / logvar0 are the models' (B,3,S) stride-0 expansions, read in
+        place; `noise` defaults to torch.randn_like(logvar0) -- drawn by torch, so the generator stream is the caller's.
+        In eval mode on CUDA the sample is formed in the fused kernel's prologue (no exp / mul / add launches, no
+        materialised z round trip); otherwise this is exactly the two reference calls."""
+        import torch
+        if noise is None:
+            noise = torch.randn_like(logvar0)                                      # models.py:78
+        fused = (not self.training and noise.is_cuda and not _needs_autograd(noise, mu0, logvar0, g)
+                 and noise.dtype == torch.float32 and mu0.dtype == torch.float32 and logvar0.dtype == torch.float32)
+        if not fused:
+            z = noise.mul(torch.exp(0.5 * logvar0)).add_(mu0)                      # models.py:77-79
+            return (z,) + tuple(self.forward(z, g, mode="direct"))
+        stack = self.stack()
+        p_out, sum_lv, ps, mus, lvs = stack.run(noise, g, "direct", self.precision, want_lists=self.materialize_lists,
+                                                base=(mu0, logvar0))
+        z = stack.last_base_sample
+        if ps is None:
+            return z, FlowList(p_out.unsqueeze(0)), None, FlowList(sum_lv.unsqueeze(0), sum_lv)
+        return z, FlowList(ps), FlowList(mus), FlowList(lvs, sum_lv)
+
     def forward(self, p, g, mode="direct", n_layers=None):
         """n_layers (extension, default all): run only the first n_layers DIRECT-order layers
         (the BASELINE metric's 14-layer stack = first 14 layers of n_flows=5)."""

@@ -109,10 +109,13 @@ class FlowStack:
         return self._canon, self._meta, self._packed[key], G
 
     # -- run ---------------------------------------------------------------------
-    def run(self, p, g, mode, precision=None, want_lists=True, n_layers=None, want_pointmajor=False):
+    def run(self, p, g, mode, precision=None, want_lists=True, n_layers=None, want_pointmajor=False, base=None):
         """p (B,3,N), g (B,G) fp32 CUDA.  Returns (p_out, sum_logvar, ps, mus, logvars); the
         last three are (L,B,3,N) buffers in DIRECT order or None.  With want_pointmajor the
-        (B,N,3) copy of p_out is left in self.last_pointmajor."""
+        (B,N,3) copy of p_out is left in self.last_pointmajor.
+        base = (mu0, lv0) (direct mode only): p is the NOISE and the stack starts from
+        z = p * exp(0.5 * lv0) + mu0 (models.py:76-79), formed in the kernel's prologue from the (possibly stride-0
+        expanded) (B,3,N) views mu0 / lv0; z is left in self.last_base_sample."""
         precision = precision or DEFAULT_PRECISION
         if precision not in PREC:
             raise ValueError("precision must be one of %s" % sorted(PREC))
@@ -148,10 +151,25 @@ class FlowStack:
             stream = current_stream()
             check(lib().dpf_flow_film(L, B, G, PREC[precision], packed.data_ptr(), g.data_ptr(), film.data_ptr(), eps,
                                       stream), "flow_film")
-            check(lib().dpf_flow_forward(L, B, N, MODE[mode], PREC[precision], packed.data_ptr(), meta.data_ptr(),
-                                         film.data_ptr(), p.data_ptr(), p_out.data_ptr(),
-                                         pm.data_ptr() if pm is not None else None, sum_lv.data_ptr(),
-                                         lp[0], lp[1], lp[2], eps, stream), "flow_forward")
+            self.last_base_sample = None
+            if base is not None:
+                if mode != "direct":
+                    raise ValueError("a base distribution is sampled in direct mode only")
+                mu0, lv0 = base
+                for t in (mu0, lv0):
+                    if not t.is_cuda or t.dtype != torch.float32 or tuple(t.shape) != (B, 3, N):
+                        raise RuntimeError("base mu / logvar must be float32 CUDA tensors (views) of shape (B,3,N)")
+                z = torch.empty_like(p)
+                self.last_base_sample = z
+                check(lib().dpf_flow_forward_base(L, B, N, PREC[precision], packed.data_ptr(), meta.data_ptr(), film.data_ptr(),
+                                                  p.data_ptr(), mu0.data_ptr(), *mu0.stride(), lv0.data_ptr(), *lv0.stride(),
+                                                  z.data_ptr(), p_out.data_ptr(), pm.data_ptr() if pm is not None else None,
+                                                  sum_lv.data_ptr(), lp[0], lp[1], lp[2], eps, stream), "flow_forward_base")
+            else:
+                check(lib().dpf_flow_forward(L, B, N, MODE[mode], PREC[precision], packed.data_ptr(), meta.data_ptr(),
+                                             film.data_ptr(), p.data_ptr(), p_out.data_ptr(),
+                                             pm.data_ptr() if pm is not None else None, sum_lv.data_ptr(),
+                                             lp[0], lp[1], lp[2], eps, stream), "flow_forward")
         if want_lists:
             return p_out, sum_lv, lists[0], lists[1], lists[2]
         return p_out, sum_lv, None, None, None

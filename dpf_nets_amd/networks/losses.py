@@ -39,9 +39,54 @@ def _flow_total(logvars):
     return None, False
 
 
+class _PointFlowNLLNode(torch.autograd.Function):
+    """losses.py:11-15 as ONE autograd node over HIP kernels (training step): forward =
+    dpf_pointflow_nll (one pass over s0 and the stack's layer-sum of log-variances, base distribution through its strides),
+    backward = dpf_pointflow_nll_backward (one launch: d s0, the constant d sum_lv, and d mu0 / d lv0 only if the base
+    distribution is learned)."""
+
+    @staticmethod
+    def forward(ctx, s0, mu0, lv0, total):
+        from .._lib import lib, check, current_stream
+        B, C, N = s0.shape
+        s0c = s0.contiguous()
+        out = torch.empty((), dtype=torch.float32, device=s0.device)
+        ws = torch.empty(lib().dpf_pointflow_nll_workspace_floats(), dtype=torch.float32, device=s0.device)
+        with torch.cuda.device(s0.device):
+            check(lib().dpf_pointflow_nll(B, C, N, s0c.data_ptr(), mu0.data_ptr(), *mu0.stride(), lv0.data_ptr(), *lv0.stride(),
+                                          total.data_ptr(), ws.data_ptr(), out.data_ptr(), current_stream()), "pointflow_nll")
+        ctx.save_for_backward(s0c, mu0, lv0)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from .._lib import lib, check, current_stream
+        s0, mu0, lv0 = ctx.saved_tensors
+        B, C, N = s0.shape
+        need = ctx.needs_input_grad
+        d_s0 = torch.empty_like(s0) if need[0] else None
+        d_mu = torch.empty_like(s0) if need[1] else None
+        d_lv = torch.empty_like(s0) if need[2] else None
+        d_tot = torch.empty_like(s0) if need[3] else None
+        g = grad_out.contiguous().to(torch.float32)
+        with torch.cuda.device(s0.device):
+            check(lib().dpf_pointflow_nll_backward(B, C, N, s0.data_ptr(), mu0.data_ptr(), *mu0.stride(), lv0.data_ptr(), *lv0.stride(),
+                                                   g.data_ptr(), d_s0.data_ptr() if need[0] else None,
+                                                   d_tot.data_ptr() if need[3] else None, d_mu.data_ptr() if need[1] else None,
+                                                   d_lv.data_ptr() if need[2] else None, current_stream()), "pointflow_nll_backward")
+        return d_s0, d_mu, d_lv, d_tot
+
+
 class PointFlowNLL(nn.Module):
     def forward(self, samples, mus, logvars):
         s0, mu0, lv0 = samples[0], mus[0], logvars[0]
+        # training step on CUDA tensors: the stack's layer-sum of log-variances is at hand -> one fused node
+        if s0.is_cuda and s0.dim() == 3 and s0.dtype == torch.float32 and mu0.shape == s0.shape and lv0.shape == s0.shape and \
+                mu0.dtype == lv0.dtype == torch.float32 and torch.is_grad_enabled() and \
+                (s0.requires_grad or mu0.requires_grad or lv0.requires_grad):
+            total, ok = _flow_total(logvars)
+            if ok and total.dtype == torch.float32 and total.shape == s0.shape:
+                return _PointFlowNLLNode.apply(s0, mu0, lv0, total.contiguous())
         # evaluation (CUDA tensors, nothing to differentiate): one pass over s0 and the kernel's sum of log-variances, the
         # base distribution's stride-0 expansions read through their strides (csrc/nll.hip)
         if s0.is_cuda and s0.dim() == 3 and s0.dtype == torch.float32 and mu0.shape == s0.shape and lv0.shape == s0.shape and \

@@ -222,6 +222,15 @@ int dpf_flow_forward(int n_layers, int B, int N, int mode, int precision,
                      float *p_out, float *p_out_pointmajor, float *sum_logvar,
                      float *ps, float *mus, float *logvars,
                      float flow_eps, dpf_stream_t stream);
+/* dpf_flow_forward in direct mode with `reparameterize` (lib/networks/models.py:76-79, called at :212 / :118) fused into
+ * the prologue: `noise` (B,3,N) is what torch.randn_like drew (the generator stream stays the caller's), the stack starts
+ * from z = noise * exp(0.5 * lv0) + mu0 with mu0 / lv0 read through (batch, channel, point) element strides (the models'
+ * stride-0 expansions, models.py:153-158 / 203-209); z_out (B,3,N, may be NULL) receives z = p_prior_samples[0]. */
+int dpf_flow_forward_base(int n_layers, int B, int N, int precision, const void *packed, const int *meta,
+                          const float *film, const float *noise, const float *mu0, long mu_sb, long mu_sc, long mu_sn,
+                          const float *lv0, long lv_sb, long lv_sc, long lv_sn, float *z_out, float *p_out,
+                          float *p_out_pointmajor, float *sum_logvar, float *ps, float *mus, float *logvars,
+                          float flow_eps, dpf_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Training mode (model.train()) of one coupling layer: batch-statistics
@@ -350,6 +359,14 @@ size_t dpf_pointflow_nll_workspace_floats(void);
 int dpf_pointflow_nll(int B, int C, int N, const float *s0, const float *mu0, long mu_sb, long mu_sc,
                       long mu_sn, const float *lv0, long lv_sb, long lv_sc, long lv_sn,
                       const float *sum_lv, float *workspace, float *out, dpf_stream_t stream);
+/* Backward of dpf_pointflow_nll for a scalar upstream gradient grad_out[0] (device): d_s0 and d_sum_lv (B,C,N)
+ * contiguous, and -- when non-NULL -- d_mu0 / d_lv0 as full (B,C,N) tensors (the caller's expand-backward reduces
+ * them); any output pointer may be NULL.  One launch; with it the flow NLL of a training step (losses.py:48) is a single
+ * autograd node over HIP kernels. */
+int dpf_pointflow_nll_backward(int B, int C, int N, const float *s0, const float *mu0, long mu_sb, long mu_sc,
+                               long mu_sn, const float *lv0, long lv_sb, long lv_sc, long lv_sn,
+                               const float *grad_out, float *d_s0, float *d_sum_lv, float *d_mu0, float *d_lv0,
+                               dpf_stream_t stream);
 
 /* ---- latent prior flow, TRAINING mode (BatchNorm1d on the statistics of the B rows) -----------
  * replaces GlobalRNVPDecoder.forward under model.train() (decoders.py:21-38, flows.py:198-213)
