@@ -41,6 +41,13 @@
 
 #include "flow_common.h"
 
+// -DDPF_ABLATE=<bitmask>: timing experiments of tools/ab_run.py (results are garbage): 1 no relu/split VALU, 2 no output
+// contraction, 4 one chain MFMA per k-step, 8 no fragment reads, 16 no weight DMA, 32 no workgroup barriers, 64 no
+// transcendental coupling transform, 128 no conditioner at all, 256 no input MFMAs (G0), 512 no accumulator init from LDS
+#ifndef DPF_ABLATE
+#define DPF_ABLATE 0
+#endif
+
 namespace {
 
 // ---- canonical fp32 layout (see dpf_hip.h) --------------------------------
@@ -269,7 +276,7 @@ struct FlowArgs {
     const float *film;
     const float *p_in;
     float *p_out, *p_out_pm, *sum_lv, *ps, *mus, *lvs;
-    int L, B, N, mode, prio;
+    int L, B, N, mode;
     float eps;
     // optional prologue (direct mode, models.py:76-79 + :212): p_in is the NOISE and the stack starts from
     // z = p_in * exp(0.5 * lv0) + mu0, the base distribution read through its (batch, channel, point) strides -- the
@@ -300,7 +307,7 @@ __device__ __forceinline__ void stage_layer(const FlowArgs &a, int li, int bi, u
     constexpr int NP = p_layer_bytes(NS) / 1024, NF = FILM_BYTES / 1024;
     constexpr int LW = FW >= 8 ? FW / 2 : FW, PER = NP / LW;
     static_assert(NP % LW == 0, "every issuing wave takes the same contiguous run of weight pieces");
-    if (wave >= LW) return;
+    if ((unsigned)wave >= (unsigned)LW) return;          // `wave` = index among the issuing waves (negative: not an issuer)
     // a wave's pieces are contiguous in memory and in LDS, so one (address, M0) pair serves four pieces through the
     // instruction's immediate offset (it advances both sides): ~1.5 instructions per piece instead of ~18
     const uint8_t *src = a.packed + (size_t)li * p_layer_bytes(NS) + wave * (PER * 1024) + lane * 16;
@@ -448,7 +455,7 @@ __device__ __forceinline__ void branch_tile(const uint8_t *lb, int br, int lane,
 //   G8      chain B k3                                       | output contraction of A
 //   tail    output contraction of B
 template <int NS, bool TWO, bool F16>
-__device__ __forceinline__ void layer_pipe(const uint8_t *lb, int lane, int h, u32x4 b0, float negone, bool midbar, bool prio,
+__device__ __forceinline__ void layer_pipe(const uint8_t *lb, int lane, int h, u32x4 b0, float negone, int midbar,
                                            float (&o)[2][2], unsigned long long *tt) {
     static_assert(!F16 || NS == 2, "fp16 operands: hi/lo split only");
     static_assert(NS <= 2, "the pipelined body keeps both branches' fragments in registers: bf16 / bf16x3 only");
@@ -461,6 +468,11 @@ __device__ __forceinline__ void layer_pipe(const uint8_t *lb, int lane, int h, u
     u32x4 af[2][2 * NS];
 
     auto ld_frag = [&](int br, int ks, u32x4 (&dst)[2 * NS]) {     // the NS parts of both M tiles of k-step ks
+        if ((DPF_ABLATE & 8) && !(br == 0 && ks == 0)) {   // timing experiment: no fragment reads after the first
+#pragma unroll
+            for (int i = 0; i < 2 * NS; ++i) dst[i] = af[0][i] + (uint32_t)ks;
+            return;
+        }
 #pragma unroll
         for (int part = 0; part < NS; ++part)
 #pragma unroll
@@ -468,6 +480,7 @@ __device__ __forceinline__ void layer_pipe(const uint8_t *lb, int lane, int h, u
                 dst[part * 2 + tp] = *(const u32x4 *)(lb + part * P_A1_PART + (((br * 2 + tp) * 4 + ks) * 64 + lane) * 16);
     };
     auto init_acc1 = [&](int br, int tp) {                          // accumulator starts at the folded FiLM shift D
+        if (DPF_ABLATE & 512) { acc1[br][tp] = z16; return; }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 dv = *(const f32x4 *)(film + br * FILM_BR_FLOATS + 32 * tp + 8 * q + 4 * h);
@@ -481,6 +494,11 @@ __device__ __forceinline__ void layer_pipe(const uint8_t *lb, int lane, int h, u
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const int r = 8 * (ks & 1) + 2 * d;
+            if (DPF_ABLATE & 1) {          // timing experiment: no relu / split VALU
+                bfrag[br][0][ks][d] = f2u(acc0[br][t][r]);
+                if (NS > 1) bfrag[br][NS - 1][ks][d] = f2u(acc0[br][t][r + 1]);
+                continue;
+            }
             const float v0 = relu(acc0[br][t][r]), v1 = relu(acc0[br][t][r + 1]);
             if (F16) {
                 // hi = the pair truncated to fp16 (one v_cvt_pkrtz_f16_f32); lo = fp16(v - hi) formed and packed by
@@ -502,6 +520,11 @@ __device__ __forceinline__ void layer_pipe(const uint8_t *lb, int lane, int h, u
         }
     };
     auto chain_ks = [&](int br, int ks, const u32x4 (&a)[2 * NS]) {
+        if (DPF_ABLATE & 4) {              // timing experiment: one MFMA per k-step instead of 6
+            acc1[br][0] = mfma(a[0], bfrag[br][0][ks], acc1[br][0]);
+            acc1[br][1][0] += u2f(a[1].x ^ bfrag[br][NS - 1][ks].x);
+            return;
+        }
 #pragma unroll
         for (int term = 0; term < TT::N; ++term)
 #pragma unroll
@@ -525,6 +548,10 @@ __device__ __forceinline__ void layer_pipe(const uint8_t *lb, int lane, int h, u
     };
     auto contract = [&](int br, int tp) {
         const int sl = (br * 2 + tp) & 1;
+        if (DPF_ABLATE & 2) {              // timing experiment: no output contraction VALU
+            pa[br][0] += acc1[br][tp][0] + cwa[sl][0].x; pb[br][0] += acc1[br][tp][1];
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 wa4 = cwa[sl][q];
@@ -539,8 +566,13 @@ __device__ __forceinline__ void layer_pipe(const uint8_t *lb, int lane, int h, u
             }
         }
     };
-#pragma unroll
-    for (int br = 0; br < 2; ++br) { pa[br][0] = pa[br][1] = 0.f; pb[br][0] = pb[br][1] = 0.f; }
+    {   // the output SharedDot's bias starts the sums: half of it in each lane half (exact halving; the halves are added later)
+        const float *b2 = film + FILM_B2_OFF;
+        for (int br = 0; br < 2; ++br) {
+            pa[br][0] = 0.5f * b2[br * 2]; pa[br][1] = 0.f;
+            pb[br][0] = TWO ? 0.5f * b2[br * 2 + 1] : 0.f; pb[br][1] = 0.f;
+        }
+    }
 
     // sched_barrier fences the machine scheduler only: pure arithmetic (VALU, MFMA) still drifts across it when the
     // selection DAG is linearised.  An empty volatile asm that "rewrites" a value is ordered with the fences (both have
@@ -577,10 +609,15 @@ __device__ __forceinline__ void layer_pipe(const uint8_t *lb, int lane, int h, u
         const u32x4 a10 = *(const u32x4 *)(lb + A0OFF + ((1 * 2 + 0) * 64 + lane) * 16);
         const u32x4 a11 = *(const u32x4 *)(lb + A0OFF + ((1 * 2 + 1) * 64 + lane) * 16);
         ld_frag(0, 0, af[0]);
+        if (DPF_ABLATE & 256) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc0[0][0][i] = u2f(b0.x + i); acc0[0][1][i] = u2f(b0.y + i); acc0[1][0][i] = u2f(b0.z + i); acc0[1][1][i] = u2f(b0.w ^ i); }
+        } else {
         acc0[0][0] = mfma(a00, b0, z16);
         acc0[0][1] = mfma(a01, b0, z16);
         acc0[1][0] = mfma(a10, b0, z16);
         acc0[1][1] = mfma(a11, b0, z16);
+        }
         split_ks(0, 0);
         pin_bfrag(0, 0);
         init_acc1(0, 0); init_acc1(0, 1);
@@ -595,10 +632,6 @@ __device__ __forceinline__ void layer_pipe(const uint8_t *lb, int lane, int h, u
     }
     __builtin_amdgcn_sched_barrier(0);
     DPF_T(1)
-    // MFMA chains run at low priority, the VALU-only stretch of a layer (B's contraction, coupling transform, the next
-    // input fragment and G0) at high priority: the stretch is a latency-bound dependent chain that uses a fraction of the
-    // VALU slots, the chains' fillers take what is left
-    if (prio) __builtin_amdgcn_s_setprio(0);
     // ---- G1..G4: chain A
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -612,14 +645,16 @@ __device__ __forceinline__ void layer_pipe(const uint8_t *lb, int lane, int h, u
         pin_bfrag(sbr, sks);
         DPF_PIPE_PATTERN(NM, 6, 4, 2)
         __builtin_amdgcn_sched_barrier(0);
+        if (ks < 3 && midbar == ks + 1) __syncthreads();
 #ifdef DPF_PROFILE
         if (ks == 0) DPF_T(8) else if (ks == 1) DPF_T(9) else if (ks == 2) DPF_T(10)
 #endif
     }
     DPF_T(2)
     // skewed ring (flow_kernel<.., SKEW>): the lagging half of the workgroup meets the leading half's end-of-layer barrier
-    // HERE, half a layer behind, so that one wave's MFMA chains run beside its SIMD partner's VALU-only phases
-    if (midbar) __syncthreads();
+    // at the group boundary `midbar` (r02 sweep over all eight boundaries: 46.2 us at 5, 46.5-48.4 elsewhere), about half a
+    // layer behind, so that one wave's MFMA chains run beside its SIMD partner's VALU-only stretch
+    if (!(DPF_ABLATE & 32) && midbar == 4) __syncthreads();
     // ---- G5..G8: chain B; A's output contraction rides in the later groups
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -635,12 +670,12 @@ __device__ __forceinline__ void layer_pipe(const uint8_t *lb, int lane, int h, u
         else if (ks == 2) { if (TWO) { DPF_PIPE_PATTERN(NM, 14, 4, 3) } else { DPF_PIPE_PATTERN(NM, 11, 4, 3) } }
         else { if (TWO) { DPF_PIPE_PATTERN(NM, 8, 4, 3) } else { DPF_PIPE_PATTERN(NM, 6, 4, 3) } }
         __builtin_amdgcn_sched_barrier(0);
+        if (midbar == ks + 5) __syncthreads();
 #ifdef DPF_PROFILE
         if (ks == 0) DPF_T(11) else if (ks == 1) DPF_T(12) else if (ks == 2) DPF_T(13)
 #endif
     }
     DPF_T(3)
-    if (prio) __builtin_amdgcn_s_setprio(2);
     // ---- tail: B's output contraction
     ld_cw(1, 1);
     contract(1, 0);
@@ -714,6 +749,7 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
     };
     const bool lag = SKEW && wave >= FW / 2;
     auto stage_step = [&](int st) {                      // SKEW: the layer of step st into ring slot st % 3
+        if ((DPF_ABLATE & 16) && st >= 3) return;        // timing experiment: no weight DMA after the first three layers
         if (st < L) stage_layer<NS, FW>(a, inverse ? L - 1 - st : st, bi, smem + (st % 3) * LBYTES, wave, lane);
     };
     if constexpr (SKEW) { stage_step(0); stage_step(1); } else stage_group(0);
@@ -753,9 +789,13 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
         const u32x4 b0 = input_fragment(x, h);
 
         float o[2][2];
+        if (DPF_ABLATE & 128) {            // timing experiment: no conditioner at all (loop, staging, barriers, transform only)
+            o[0][0] = p0 * 0.1f; o[0][1] = p1 * 0.1f; o[1][0] = p2 * 0.1f; o[1][1] = p0 * 0.05f;
+            (void)b0;
+        } else
         if constexpr (PIPE) {
-            if (wb < 0) layer_pipe<NS, false, F16>(lb, lane, h, b0, negone, lag, a.prio != 0, o, tt);   // layer warps one channel
-            else layer_pipe<NS, true, F16>(lb, lane, h, b0, negone, lag, a.prio != 0, o, tt);
+            if (wb < 0) layer_pipe<NS, false, F16>(lb, lane, h, b0, negone, lag ? 5 : 0, o, tt);   // layer warps one channel
+            else layer_pipe<NS, true, F16>(lb, lane, h, b0, negone, lag ? 5 : 0, o, tt);
         } else if (wb < 0) {                                // layer warps one channel
             branch_tile<NS, false>(lb, 0, lane, h, b0, o[0][0], o[0][1], tt);
             branch_tile<NS, false>(lb, 1, lane, h, b0, o[1][0], o[1][1], tt);
@@ -768,18 +808,20 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
 #pragma unroll
         for (int br = 0; br < 2; ++br)
 #pragma unroll
-            for (int e = 0; e < 2; ++e) o[br][e] = half_sum(o[br][e]) + b2[br * 2 + e];
+            for (int e = 0; e < 2; ++e) o[br][e] = PIPE ? half_sum(o[br][e]) : half_sum(o[br][e]) + b2[br * 2 + e];   // layer_pipe starts its sums at b2 / 2
         // ---- coupling transform (flows.py:96-115); branch 0 = logvar, 1 = mu
-        const float lva = o[0][0] * __builtin_amdgcn_rcpf(1.0f + fabsf(o[0][0]));   // softsign, :99
-        const float lvb = o[0][1] * __builtin_amdgcn_rcpf(1.0f + fabsf(o[0][1]));
+        const float lva = (DPF_ABLATE & 64) ? o[0][0] : o[0][0] * __builtin_amdgcn_rcpf(1.0f + fabsf(o[0][0]));   // softsign, :99
+        const float lvb = (DPF_ABLATE & 64) ? o[0][1] : o[0][1] * __builtin_amdgcn_rcpf(1.0f + fabsf(o[0][1]));
         float lv[3], mu[3], pn[3];
         const float pin[3] = {p0, p1, p2};
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             lv[c] = c == wa ? lva : (c == wb ? lvb : 0.f);
             mu[c] = c == wa ? o[1][0] : (c == wb ? o[1][1] : 0.f);
-            const float var = a.eps + __expf(lv[c]);
+            const float var = a.eps + ((DPF_ABLATE & 64) ? lv[c] : __expf(lv[c]));
             // keep channels are scaled by sqrt(1 + eps) too, as in the reference (:113/:115)
+            if (DPF_ABLATE & 64) pn[c] = var * pin[c] + mu[c];
+            else
             pn[c] = inverse ? (pin[c] - mu[c]) * __builtin_amdgcn_rsqf(var) : __builtin_amdgcn_sqrtf(var) * pin[c] + mu[c];
         }
         p0 = pn[0]; p1 = pn[1]; p2 = pn[2];
@@ -804,7 +846,7 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
         DPF_T(6)
         if constexpr (SKEW) {
             if (!lag) {               // leaders: barrier n; layer n - 1's slot is free now -> layer n + 2
-                __syncthreads();
+                if (!(DPF_ABLATE & 32)) __syncthreads();
                 stage_step(step + 2);
             }
         } else {
@@ -937,11 +979,6 @@ static int flow_forward_impl(int n_layers, int B, int N, int mode, int precision
         a.mu_sb = mu_strides[0]; a.mu_sc = mu_strides[1]; a.mu_sn = mu_strides[2];
         a.lv_sb = lv_strides[0]; a.lv_sc = lv_strides[1]; a.lv_sn = lv_strides[2];
     }
-    static const int prio_env = getenv("DPF_FLOW_PRIO") ? atoi(getenv("DPF_FLOW_PRIO")) : 1;
-    a.prio = prio_env;
-#ifdef DPF_PROFILE
-    a.prof = g_prof;
-#endif
     hipStream_t s = (hipStream_t)stream;
     // 8-wave workgroups (256 points of one cloud) unless that leaves CUs without a workgroup
     static const int force_fw = getenv("DPF_FLOW_WAVES") ? atoi(getenv("DPF_FLOW_WAVES")) : 0;

@@ -15,7 +15,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // filler kinds
 enum { F_FMA = 0, F_SPLIT = 1, F_PKFMA = 2, F_MAX = 3, F_CVT = 4, F_PERM = 5, F_EXP = 6, F_FMAC = 7, F_SUB = 8, F_AND = 9, F_MAXI = 10,
-       F_MUL = 11, F_DSR = 12, F_DSV = 13, F_DSV2 = 14 };
+       F_MUL = 11, F_DSR = 12, F_DSV = 13, F_DSV2 = 14, F_PKMAXH = 15, F_MIXLO = 16, F_PKRTZ = 17 };
 
 #define MFMA0 "v_mfma_f32_32x32x16_bf16 %[c0], %[a], %[b], %[c0]\n"
 #define MFMA1 "v_mfma_f32_32x32x16_bf16 %[c1], %[a], %[b], %[c1]\n"
@@ -81,6 +81,9 @@ __device__ __forceinline__ void gap(float (&x)[8], double (&p)[4], float k, doub
         if (KIND == F_AND) asm volatile("v_and_b32_e32 %0, 0xffff0000, %0" : "+v"(r));
         if (KIND == F_MAXI) asm volatile("v_max_i32_e32 %0, 0, %0" : "+v"(r));
         if (KIND == F_MUL) asm volatile("v_mul_f32_e32 %0, %1, %0" : "+v"(r) : "v"(k));
+        if (KIND == F_PKMAXH) asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(r) : "v"(k));
+        if (KIND == F_MIXLO) asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %1 op_sel_hi:[1,0,0] clamp" : "+v"(r) : "v"(k));
+        if (KIND == F_PKRTZ) asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1" : "+v"(r) : "v"(k));
         if (KIND == F_CVT) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(r) : "v"(k));
         if (KIND == F_PERM) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(r) : "v"(k), "v"(sel));
         if (KIND == F_EXP) asm volatile("v_exp_f32 %0, %0" : "+v"(r));
@@ -205,6 +208,12 @@ void run(const char *name, int wps) {
 int main(int argc, char **argv) {
     hipMalloc(&d_out, 256 * 1024 * sizeof(float));
     hipMalloc(&d_ticks, 64 * sizeof(unsigned long long));
+    if (argc > 1 && argv[1][0] == 'h') {   // the fp16 split's instructions as gap fillers
+        SWEEP(F_PKMAXH, "pkmaxh", 2, 0, 2)
+        SWEEP(F_MIXLO, "mixlo", 2, 0, 2)
+        SWEEP(F_PKRTZ, "pkrtz", 2, 0, 2)
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 'd') {   // LDS reads as gap fillers
         for (int wps = 1; wps <= 2; ++wps) {
             SWEEP(F_DSR, "dsr", 2, 0, wps)      // K ds_read_b128 per MFMA gap, nothing else
