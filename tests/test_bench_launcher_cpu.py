@@ -46,6 +46,8 @@ def test_config_defaults():
     assert (a.config, a.layers, a.points, a.latent, a.steps, a.warmup) == ("cfg2", 14, 2048, 128, 1000, 300)
     a = bench.parse(["--config", "cfg3", "--layers", "63"])
     assert (a.latent, a.layers) == (512, 63)
+    a = bench.parse(["--config", "cfg4"])
+    assert (a.latent, a.points, a.layers) == (512, 2048, 14)
     a = bench.parse(["--config", "cfg5"])
     assert (a.points, a.steps) == (8192, 10)
     a = bench.parse(["--leg", "train"])
