@@ -705,7 +705,7 @@ __device__ __forceinline__ float half_sum(float x) {   // x(lane) + x(lane ^ 32)
 // MFMAs + first split).  Buffer safety: after barrier n nobody reads layer n - 1 any more (laggards are past the middle
 // of layer n), and the DMA of layer n + 1, issued after barrier n - 1, was waited for (vmcnt 0) by its issuers before
 // they arrived at barrier n.
-template <int NS, int FW, int LPB = 1, bool PIPE = false, bool F16 = false, bool SKEW = false>
+template <int NS, int FW, int LPB = 1, bool PIPE = false, bool F16 = false, bool SKEW = false, bool INV = false>
 __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
     static_assert(!SKEW || (FW == 8 && LPB == 1 && PIPE), "the skewed ring is built for 8-wave pipelined workgroups");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
         }
     }
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;   // running sum of logvar per channel
-    const bool inverse = a.mode == DPF_MODE_INVERSE;
+    constexpr bool inverse = INV;              // the direction is compiled in: the coupling update has no uniform branches
     const size_t list_stride = (size_t)a.B * 3 * N;
 
     float negone = -1.0f;                      // opaque to the compiler: see layer_pipe's fp16 split
@@ -757,14 +757,16 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
     // layer's row comes out with v_readlane.  (Loading them inside the loop puts a vector-memory wait at the top of every
     // layer, and vmcnt retires in order: it waited for the whole next-layer DMA issued just before -- r01
     // profile: ~3000 of the 9700 cycles per layer.)
-    const int4 meta_lo = ((const int4 *)a.meta)[min(lane, L - 1)], meta_hi = ((const int4 *)a.meta)[min(64 + lane, L - 1)];
+    // ... packed into one word per layer: 2 bits per field (value + 1), so a layer's descriptor is ONE v_readlane and
+    // four scalar bit-field extracts -- no branches (the four-readlane form compiled to a branch ladder per field)
+    auto pack_meta = [&](int row) {
+        const int4 m = ((const int4 *)a.meta)[min(row, L - 1)];
+        return (m.x + 1) | ((m.y + 1) << 2) | ((m.z + 1) << 4) | ((m.w + 1) << 6);
+    };
+    const int code_lo = pack_meta(lane), code_hi = pack_meta(64 + lane);
     auto layer_meta = [&](int l, int &k0, int &k1, int &w0, int &w1) {      // L <= 128 (checked by the launcher)
-        const int s = l & 63;
-        const bool hi = l >= 64;
-        k0 = hi ? __builtin_amdgcn_readlane(meta_hi.x, s) : __builtin_amdgcn_readlane(meta_lo.x, s);
-        k1 = hi ? __builtin_amdgcn_readlane(meta_hi.y, s) : __builtin_amdgcn_readlane(meta_lo.y, s);
-        w0 = hi ? __builtin_amdgcn_readlane(meta_hi.z, s) : __builtin_amdgcn_readlane(meta_lo.z, s);
-        w1 = hi ? __builtin_amdgcn_readlane(meta_hi.w, s) : __builtin_amdgcn_readlane(meta_lo.w, s);
+        const int c = __builtin_amdgcn_readlane(l >= 64 ? code_hi : code_lo, l & 63);
+        k0 = (c & 3) - 1; k1 = ((c >> 2) & 3) - 1; w0 = ((c >> 4) & 3) - 1; w1 = ((c >> 6) & 3) - 1;
     };
     int ka, kb, wa, wb;
     layer_meta(lfirst, ka, kb, wa, wb);
@@ -881,14 +883,19 @@ int ns_of(int precision) {   // number of operand parts; DPF_PREC_F16X3 shares t
            : precision == DPF_PREC_BF16X6 ? 3 : 0;
 }
 
-template <int NS, int FW, int LPB, bool PIPE, bool F16, bool SKEW = false>
-int launch_flow(const FlowArgs &a, hipStream_t s) {
+template <int NS, int FW, int LPB, bool PIPE, bool F16, bool SKEW, bool INV>
+int launch_flow_dir(const FlowArgs &a, hipStream_t s) {
     const int lds = (SKEW ? 3 : 2 * LPB) * (p_layer_bytes(NS) + FILM_BYTES);
     static LdsLimit limit;
-    if (hipError_t e = limit.ensure((const void *)flow_kernel<NS, FW, LPB, PIPE, F16, SKEW>, lds); e != hipSuccess) return (int)e;
+    if (hipError_t e = limit.ensure((const void *)flow_kernel<NS, FW, LPB, PIPE, F16, SKEW, INV>, lds); e != hipSuccess) return (int)e;
     const dim3 grid((a.N + TILE * FW - 1) / (TILE * FW), a.B), block(FW * 64);
-    hipLaunchKernelGGL((flow_kernel<NS, FW, LPB, PIPE, F16, SKEW>), grid, block, lds, s, a);
+    hipLaunchKernelGGL((flow_kernel<NS, FW, LPB, PIPE, F16, SKEW, INV>), grid, block, lds, s, a);
     return (int)hipGetLastError();
+}
+template <int NS, int FW, int LPB, bool PIPE, bool F16, bool SKEW = false>
+int launch_flow(const FlowArgs &a, hipStream_t s) {
+    return a.mode == DPF_MODE_INVERSE ? launch_flow_dir<NS, FW, LPB, PIPE, F16, SKEW, true>(a, s)
+                                      : launch_flow_dir<NS, FW, LPB, PIPE, F16, SKEW, false>(a, s);
 }
 // bf16 / bf16x3 / f16x3 run the pipelined layer body (layer_pipe); bf16x6 keeps one branch at a time (branch_tile:
 // three operand parts per branch do not fit two branches' fragments into the 256 VGPRs of two waves per SIMD)
