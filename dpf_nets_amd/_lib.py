@@ -54,6 +54,7 @@ SIGNATURES = {
                                      _vp, _f, _vp, _vp]),
     "dpf_flow_train_backward_lists": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                            _vp, _f, _vp, _vp]),
+    "dpf_fscore_reduce": (_i, [_i, _i, _i, _vp, _vp, _f, _vp, _vp]),
     "dpf_chamfer_reduce": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "dpf_encoder_canon_floats": (_sz, []),
     "dpf_encoder_packed_bytes": (_sz, [_i]),

@@ -287,7 +287,37 @@ __global__ __launch_bounds__(RT) void chamfer_reduce_kernel(int n, int m, const 
         cd[bi] = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)n + ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)m;
 }
 
+// f_score of lib/networks/utils.py:38-42 from the two distance rows of one nn_distance call:
+//   precision = 100 * mean(dist2 < t), recall = 100 * mean(dist1 < t), F = 2 P R / (P + R + 1e-7)
+// one workgroup per cloud, integer counts (exact, order-independent), the float arithmetic in the reference's order
+__global__ __launch_bounds__(RT) void fscore_kernel(int n, int m, const float *__restrict__ d1, const float *__restrict__ d2,
+                                                    float threshold, float *__restrict__ out) {
+    __shared__ int red[2][RT / 64];
+    const int bi = blockIdx.x, tid = threadIdx.x;
+    const float *a = d1 + (size_t)bi * n, *b = d2 + (size_t)bi * m;
+    int c1 = 0, c2 = 0;
+    for (int j = tid; j < n; j += RT) c1 += a[j] < threshold ? 1 : 0;
+    for (int j = tid; j < m; j += RT) c2 += b[j] < threshold ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) { c1 += __shfl_xor(c1, o); c2 += __shfl_xor(c2, o); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = c1; red[1][tid >> 6] = c2; }
+    __syncthreads();
+    if (tid == 0) {
+        const int r = red[0][0] + red[0][1] + red[0][2] + red[0][3], p = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        const float recall = 100.0f * ((float)r / (float)n), precision = 100.0f * ((float)p / (float)m);
+        out[bi] = 2.0f * precision * recall / (precision + recall + 1e-7f);
+    }
+}
+
 }  // namespace
+
+extern "C" int dpf_fscore_reduce(int b, int n, int m, const float *dist1, const float *dist2, float threshold, float *out,
+                                 dpf_stream_t stream) {
+    if (b < 0 || n <= 0 || m <= 0) return DPF_EINVAL;
+    if (b == 0) return 0;
+    if (!dist1 || !dist2 || !out) return DPF_EINVAL;
+    hipLaunchKernelGGL(fscore_kernel, dim3(b), dim3(RT), 0, (hipStream_t)stream, n, m, dist1, dist2, threshold, out);
+    return (int)hipGetLastError();
+}
 
 extern "C" int dpf_chamfer_reduce(int b, int n, int m, const float *dist1, const float *dist2, float *cd,
                                   dpf_stream_t stream) {

@@ -30,7 +30,16 @@ def chamfer_per_cloud(dl, dr):
 
 
 def f_score(predicted_clouds, true_clouds, threshold=0.001):
+    """lib/networks/utils.py:38-42.  Without autograd the thresholds, means and the F1 formula are one launch over the two
+    distance rows (dpf_fscore_reduce: integer counts, the float arithmetic in the reference's order)."""
     ld, rd = distChamferCUDA(predicted_clouds, true_clouds)
+    if ld.is_cuda and not (torch.is_grad_enabled() and (ld.requires_grad or rd.requires_grad)):
+        from .._lib import lib, check, current_stream
+        out = torch.empty((ld.shape[0],), dtype=torch.float32, device=ld.device)
+        with torch.cuda.device(ld.device):
+            check(lib().dpf_fscore_reduce(ld.shape[0], ld.shape[1], rd.shape[1], ld.contiguous().data_ptr(), rd.contiguous().data_ptr(),
+                                          float(threshold), out.data_ptr(), current_stream()), "fscore_reduce")
+        return out
     precision = 100.0 * (rd < threshold).float().mean(1)
     recall = 100.0 * (ld < threshold).float().mean(1)
     return 2.0 * precision * recall / (precision + recall + 1e-7)

@@ -131,6 +131,12 @@ int dpf_matchcostgrad_ws(int b, int n, int m, const float *xyz1, const float *xy
 int dpf_chamfer_reduce(int b, int n, int m, const float *dist1, const float *dist2,
                        float *cd, dpf_stream_t stream);
 
+/* f_score's reductions, lib/networks/utils.py:38-42, from the two distance rows of one nn_distance call:
+ * out[b] = 2 P R / (P + R + 1e-7), P = 100 * mean(dist2[b] < threshold), R = 100 * mean(dist1[b] < threshold).
+ * One launch instead of ~10 elementwise / reduction launches; counts are integers (exact). */
+int dpf_fscore_reduce(int b, int n, int m, const float *dist1, const float *dist2, float threshold,
+                      float *out, dpf_stream_t stream);
+
 /* nn_distance and its callers' reduction in one call (lib/networks/evaluating.py:110-113): the four outputs of
  * dpf_nndistance (same bits) plus cd[b] = mean(result[b]) + mean(result2[b]).  With the matrix-core kernel the
  * workgroups emit fixed-order sums of their distances and a finish kernel adds them in tile order (workspace of
