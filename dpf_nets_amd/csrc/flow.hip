@@ -43,7 +43,8 @@
 
 // -DDPF_ABLATE=<bitmask>: timing experiments of tools/ab_run.py (results are garbage): 1 no relu/split VALU, 2 no output
 // contraction, 4 one chain MFMA per k-step, 8 no fragment reads, 16 no weight DMA, 32 no workgroup barriers, 64 no
-// transcendental coupling transform, 128 no conditioner at all, 256 no input MFMAs (G0), 512 no accumulator init from LDS
+// transcendental coupling transform, 128 no conditioner at all, 256 no input MFMAs (G0), 512 no accumulator init from LDS,
+// 1024 half the A-fragment reads (the second M tile reuses the first's)
 #ifndef DPF_ABLATE
 #define DPF_ABLATE 0
 #endif
@@ -383,8 +384,10 @@ __device__ __forceinline__ void branch_tile(const uint8_t *lb, int br, int lane,
 #pragma unroll
         for (int part = 0; part < NS; ++part)
 #pragma unroll
-            for (int tp = 0; tp < 2; ++tp)
+            for (int tp = 0; tp < 2; ++tp) {
+                if ((DPF_ABLATE & 1024) && tp == 1) { dst[part * 2 + 1] = dst[part * 2]; continue; }   // timing: half the fragment reads
                 dst[part * 2 + tp] = *(const u32x4 *)(lb + part * P_A1_PART + (((br * 2 + tp) * 4 + ks) * 64 + lane) * 16);
+            }
     };
     load_batch(0, af[0]);
     const float *wa = fl + 64, *wb2 = fl + 128;
@@ -546,14 +549,14 @@ __device__ __forceinline__ void layer_pipe(const uint8_t *lb, int lane, int h, u
             if (TWO) cwb[sl][q] = *(const f32x4 *)(wb2 + f0);
         }
     };
-    auto contract = [&](int br, int tp) {
+    auto contract = [&](int br, int tp, int q0 = 0, int q1 = 4) {   // features 8 q0 .. 8 q1 of M tile tp
         const int sl = (br * 2 + tp) & 1;
         if (DPF_ABLATE & 2) {              // timing experiment: no output contraction VALU
-            pa[br][0] += acc1[br][tp][0] + cwa[sl][0].x; pb[br][0] += acc1[br][tp][1];
+            if (q0 == 0) { pa[br][0] += acc1[br][tp][0] + cwa[sl][0].x; pb[br][0] += acc1[br][tp][1]; }
             return;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = q0; q < q1; ++q) {
             const f32x4 wa4 = cwa[sl][q];
             const float r0 = relu(acc1[br][tp][4 * q + 0]), r1 = relu(acc1[br][tp][4 * q + 1]);
             const float r2 = relu(acc1[br][tp][4 * q + 2]), r3 = relu(acc1[br][tp][4 * q + 3]);
@@ -640,6 +643,7 @@ __device__ __forceinline__ void layer_pipe(const uint8_t *lb, int lane, int h, u
         ld_frag(sbr, sks, af[(ks + 1) & 1]);
         if (ks == 1) init_acc1(1, 0);
         if (ks == 2) init_acc1(1, 1);
+        if (ks == 3) ld_cw(0, 0);                                     // A's output weights, one group ahead of their use
         chain_ks(0, ks, af[ks & 1]);
         split_ks(sbr, sks);
         pin_bfrag(sbr, sks);
@@ -659,16 +663,18 @@ __device__ __forceinline__ void layer_pipe(const uint8_t *lb, int lane, int h, u
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         if (ks + 1 < 4) { pin_acc0(1, ks + 1); ld_frag(1, ks + 1, af[(ks + 1) & 1]); }
-        if (ks == 1) ld_cw(0, 0);
-        if (ks == 2) { pin_acc1(0, 0); ld_cw(0, 1); }
-        if (ks == 3) { pin_acc1(0, 1); ld_cw(1, 0); }
+        // A's output contraction in four quarters, one per group of chain B (a split of B + a quarter = 36..44 VALU behind
+        // 6 MFMAs at f16x3: at the free-filler budget; bf16x3's 32-VALU split runs ~2 over per gap)
+        if (ks == 0) pin_acc1(0, 0);
+        if (ks == 1) ld_cw(0, 1);
+        if (ks == 2) pin_acc1(0, 1);
+        if (ks == 3) ld_cw(1, 0);
         chain_ks(1, ks, af[ks & 1]);
         if (ks + 1 < 4) { split_ks(1, ks + 1); pin_bfrag(1, ks + 1); }
-        if (ks == 2) { contract(0, 0); pin_sums(0); }
-        if (ks == 3) { contract(0, 1); pin_sums(0); }
-        if (ks < 2) { DPF_PIPE_PATTERN(NM, 6, 4, 3) }
-        else if (ks == 2) { if (TWO) { DPF_PIPE_PATTERN(NM, 14, 4, 3) } else { DPF_PIPE_PATTERN(NM, 11, 4, 3) } }
-        else { if (TWO) { DPF_PIPE_PATTERN(NM, 8, 4, 3) } else { DPF_PIPE_PATTERN(NM, 6, 4, 3) } }
+        contract(0, ks >> 1, 2 * (ks & 1), 2 * (ks & 1) + 2);
+        pin_sums(0);
+        if (ks < 3) { if (TWO) { DPF_PIPE_PATTERN(NM, (F16 ? 8 : 10), 4, 3) } else { DPF_PIPE_PATTERN(NM, (F16 ? 6 : 8), 4, 3) } }
+        else { if (TWO) { DPF_PIPE_PATTERN(NM, 4, 4, 3) } else { DPF_PIPE_PATTERN(NM, 3, 4, 3) } }
         __builtin_amdgcn_sched_barrier(0);
         if (midbar == ks + 5) __syncthreads();
 #ifdef DPF_PROFILE
