@@ -20,6 +20,15 @@ def _env():
     return env
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def _world():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
@@ -29,7 +38,7 @@ def _world():
 def test_data_parallel_step_one_allreduce_over_rccl():
     world = _world()
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-                        "--master-addr", "127.0.0.1", "--master-port", "29731", os.path.join(ROOT, "tests", "dist_worker_gpu.py")],
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker_gpu.py")],
                        env=_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     assert "DIST_OK world=%d" % world in r.stdout
