@@ -23,7 +23,7 @@ SIGNATURES = {
     "dpf_nndistance_mfma_workspace_bytes": (_sz, [_i, _i, _i]),
     "dpf_nndistance_mfma": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpf_nndistance_cd_workspace_bytes": (_sz, [_i, _i, _i]),
-    "dpf_nndistance_cd": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dpf_nndistance_cd": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     "dpf_pairwise_cd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "dpf_pairwise_cd": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpf_nndistancegrad": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

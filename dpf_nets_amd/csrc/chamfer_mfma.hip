@@ -109,7 +109,12 @@ struct MDir {
 // batch mode with part != nullptr (dpf_nndistance_cd): distances and indices are written AND the workgroup's sum goes to
 // part[(bi * 2 + direction) * gridDim.x + blockIdx.x] -- the per-cloud CD reduction then reads a handful of partial sums
 // instead of the (B, n) distances
-struct MArgs { MDir d[2]; int pn2; float *part; };
+// ticket != nullptr: no finish launch -- every workgroup publishes its sum with an agent-scope store, waits for it, and
+// takes a ticket of its pair / cloud (agent-scope atomic add); the LAST arriver reads the 2 * gridDim.x sums back with
+// agent-scope loads, adds them in tile order, writes cd and resets the ticket (tickets are zero on entry and on exit).
+// Payload and ticket go through device-coherent accesses on both sides (MI355X_MICROARCH.md, "valid forms"): per-XCD L2s
+// are not coherent with each other and a plain load could be served a stale line of the previous launch's sums.
+struct MArgs { MDir d[2]; int pn2; float *part; unsigned *ticket; float *cd; };
 
 __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b) {
     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -185,8 +190,27 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
     const bool sums = args.part != nullptr;                   // pairwise mode always; batch mode on request
     const size_t part_at = pairwise ? (((size_t)pi * args.pn2 + pj) * 2 + dir) * gridDim.x + blockIdx.x
                                     : ((size_t)bi * 2 + dir) * gridDim.x + blockIdx.x;
+    // cloud / pair index of the partial sums, and their publication + finish by the last arriver
+    const size_t unit = pairwise ? (size_t)pi * args.pn2 + pj : (size_t)bi;
+    auto publish = [&](float t) {                                 // called by thread 0 of every workgroup of the launch
+        if (args.ticket == nullptr) { args.part[part_at] = t; return; }
+        __hip_atomic_store(&args.part[part_at], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the sum has left this CU before the ticket is taken
+        const unsigned nwg2 = 2u * gridDim.x;
+        const unsigned old = __hip_atomic_fetch_add(&args.ticket[unit], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == nwg2 - 1) {
+            const float *p = args.part + unit * nwg2;
+            float s1 = 0.f, s2 = 0.f;
+            for (unsigned x = 0; x < gridDim.x; ++x) {
+                s1 += __hip_atomic_load(&p[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s2 += __hip_atomic_load(&p[gridDim.x + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            args.cd[unit] = s1 / (float)args.d[0].nq + s2 / (float)args.d[1].nq;
+            __hip_atomic_store(&args.ticket[unit], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
     if ((int)blockIdx.x * QW * 32 >= nq) {
-        if (sums && threadIdx.x == 0) args.part[part_at] = 0.f;
+        if (sums && threadIdx.x == 0) publish(0.f);
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
@@ -343,20 +367,8 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
         float t = s_r2[0];
 #pragma unroll
         for (int w = 1; w < QW; ++w) t += s_r2[w];
-        args.part[part_at] = t;
+        publish(t);
     }
-}
-
-// cds[i, j] = mean(dist1) + mean(dist2) from the workgroups' partial sums, tiles in ascending order
-// (lib/networks/utils.py:108-115: `(dl.mean(1) + dr.mean(1))`)
-__global__ __launch_bounds__(256) void pairwise_finish_kernel(long npairs, int nwg, int n, int m, const float *__restrict__ part,
-                                                              float *__restrict__ cds) {
-    const long v = (long)blockIdx.x * 256 + threadIdx.x;
-    if (v >= npairs) return;
-    const float *p = part + (size_t)v * 2 * nwg;
-    float s1 = 0.f, s2 = 0.f;
-    for (int x = 0; x < nwg; ++x) { s1 += p[x]; s2 += p[nwg + x]; }
-    cds[v] = s1 / (float)n + s2 / (float)m;
 }
 
 }  // namespace
@@ -384,9 +396,9 @@ static int launch_nnm_qw(const MArgs &ma, int b, int nmax, hipStream_t s) {
 // workgroups (small batches of big clouds, e.g. B = 2, N = 8192 per GPU in cfg-5) 8-wave workgroups fill twice the CUs
 static int launch_nnm(int b, int n, const float *xyz, long xyz_stride, int m, const float *xyz2, long xyz2_stride,
                       float *result, int *result_i, float *result2, int *result2_i, hipStream_t s, float *part = nullptr,
-                      bool force16 = false) {
+                      bool force16 = false, unsigned *ticket = nullptr, float *cd = nullptr) {
     MArgs ma;
-    ma.pn2 = 0; ma.part = part;
+    ma.pn2 = 0; ma.part = part; ma.ticket = ticket; ma.cd = cd;
     ma.d[0] = MDir{xyz, xyz2, result, result_i, n, m, xyz_stride, xyz2_stride};       // nndistance.cu:126
     ma.d[1] = MDir{xyz2, xyz, result2, result2_i, m, n, xyz2_stride, xyz_stride};     // nndistance.cu:127
     const int nmax = n > m ? n : m;
@@ -443,7 +455,7 @@ extern "C" int dpf_nndistance_strided_auto(int b, int n, const float *xyz, long 
 static int pairwise_qw(int nmax) { return nmax <= 256 ? 8 : 16; }
 extern "C" size_t dpf_pairwise_cd_workspace_bytes(int n1, int n2, int n, int m) {
     const int nmax = n > m ? n : m, per = pairwise_qw(nmax) * 32;
-    return (size_t)n1 * n2 * 2 * ((nmax + per - 1) / per) * sizeof(float);
+    return (size_t)n1 * n2 * (2 * ((nmax + per - 1) / per) + 1) * sizeof(float);      // sums + one ticket per pair
 }
 extern "C" int dpf_pairwise_cd(int n1, int n2, int n, int m, const float *clouds1, const float *clouds2, float *cds,
                                void *workspace, size_t workspace_bytes, dpf_stream_t stream) {
@@ -455,9 +467,12 @@ extern "C" int dpf_pairwise_cd(int n1, int n2, int n, int m, const float *clouds
     MArgs ma;
     ma.d[0] = MDir{clouds1, clouds2, nullptr, nullptr, n, m, (long)n * 3, (long)m * 3};
     ma.d[1] = MDir{clouds2, clouds1, nullptr, nullptr, m, n, (long)m * 3, (long)n * 3};
-    ma.pn2 = n2; ma.part = (float *)workspace;
     const int nmax = n > m ? n : m, qw = pairwise_qw(nmax), nwg = (nmax + qw * 32 - 1) / (qw * 32);
+    const long npairs = (long)n1 * n2;
     hipStream_t s = (hipStream_t)stream;
+    ma.pn2 = n2; ma.ticket = (unsigned *)workspace; ma.part = (float *)workspace + npairs; ma.cd = cds;
+    // the tickets (first n1 * n2 words) start at zero; the last arriver of every pair resets its own
+    if (hipError_t e = hipMemsetAsync(workspace, 0, (size_t)npairs * sizeof(unsigned), s); e != hipSuccess) return (int)e;
     if (qw == 16) {
         const int lds = CT * 1536 + 16 * QCAP * 64 * 6;
         static LdsLimit limit;
@@ -469,9 +484,6 @@ extern "C" int dpf_pairwise_cd(int n1, int n2, int n, int m, const float *clouds
         if (hipError_t e = limit.ensure((const void *)nnm_kernel<8>, lds); e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(nnm_kernel<8>, dim3(nwg, n2, 2 * n1), dim3(8 * 64), lds, s, ma);
     }
-    const long npairs = (long)n1 * n2;
-    hipLaunchKernelGGL(pairwise_finish_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, s, npairs, nwg, n, m,
-                       (const float *)workspace, cds);
     return (int)hipGetLastError();
 }
 
@@ -482,24 +494,23 @@ extern "C" int dpf_pairwise_cd(int n1, int n2, int n, int m, const float *clouds
 // otherwise dpf_nndistance + dpf_chamfer_reduce.  The two reductions associate differently (last-bit differences in cd).
 extern "C" size_t dpf_nndistance_cd_workspace_bytes(int b, int n, int m) {
     const int nmax = n > m ? n : m;
-    return (size_t)(b > 0 ? b : 0) * 2 * ((nmax + 511) / 512) * sizeof(float) + 16;
+    return (size_t)(b > 0 ? b : 0) * (2 * ((nmax + 511) / 512) + 1) * sizeof(float) + 16;    // sums + one ticket per cloud
 }
 extern "C" int dpf_nndistance_cd(int b, int n, const float *xyz, int m, const float *xyz2, float *result, int *result_i,
                                  float *result2, int *result2_i, float *cd, void *workspace, size_t workspace_bytes,
-                                 dpf_stream_t stream) {
+                                 int tickets_are_zero, dpf_stream_t stream) {
     if (b < 0 || n <= 0 || m <= 0) return DPF_EINVAL;
     if (b == 0) return 0;
     if (!xyz || !xyz2 || !result || !result_i || !result2 || !result2_i || !cd) return DPF_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (workspace && workspace_bytes >= dpf_nndistance_cd_workspace_bytes(b, n, m) && nnm_pays(b, n, m) &&
         nnm_workgroups(b, n, m, 16) >= 128) {
-        const int nmax = n > m ? n : m, nwg = (nmax + 511) / 512;
-        int rc = launch_nnm(b, n, xyz, (long)n * 3, m, xyz2, (long)m * 3, result, result_i, result2, result2_i, s,
-                            (float *)workspace, true);
-        if (rc) return rc;
-        hipLaunchKernelGGL(pairwise_finish_kernel, dim3((b + 255) / 256), dim3(256), 0, s, (long)b, nwg, n, m,
-                           (const float *)workspace, cd);
-        return (int)hipGetLastError();
+        // tickets (first b words): zero on entry -- `tickets_are_zero` = 0 makes this call clear them first -- and zero again
+        // on exit, so a caller that keeps the workspace pays the memset once
+        if (!tickets_are_zero)
+            if (hipError_t e = hipMemsetAsync(workspace, 0, (size_t)b * sizeof(unsigned), s); e != hipSuccess) return (int)e;
+        return launch_nnm(b, n, xyz, (long)n * 3, m, xyz2, (long)m * 3, result, result_i, result2, result2_i, s,
+                          (float *)workspace + b, true, (unsigned *)workspace, cd);
     }
     int rc = dpf_nndistance_auto(b, n, xyz, m, xyz2, result, result_i, result2, result2_i, stream);
     if (rc) return rc;

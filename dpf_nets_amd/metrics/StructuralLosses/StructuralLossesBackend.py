@@ -70,6 +70,9 @@ def NNDistance(set_d, set_q):
     return [dist1, idx1, dist2, idx2]
 
 
+_CD_WORKSPACES = {}
+
+
 def NNDistanceCD(set_d, set_q):
     """NNDistance plus cd (B,) = dist1.mean(1) + dist2.mean(1) (evaluating.py:112) -> [dist1, idx1, dist2, idx2, cd]; the
     reduction rides on the search kernel's workgroups (dpf_nndistance_cd) instead of a pass over the distances."""
@@ -83,9 +86,14 @@ def NNDistanceCD(set_d, set_q):
     cd = torch.empty((b,), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         nbytes = lib().dpf_nndistance_cd_workspace_bytes(b, n, m)
-        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        # the workspace holds one ticket per cloud that must be zero on entry and is left zero: kept per (device, stream,
+        # size) and cleared once, so a call is ONE launch (calls on one stream are ordered, so they can share it)
+        key = (dev, current_stream(), nbytes)
+        ws = _CD_WORKSPACES.get(key)
+        if ws is None:
+            ws = _CD_WORKSPACES[key] = torch.zeros((nbytes,), dtype=torch.uint8, device=dev)
         check(lib().dpf_nndistance_cd(b, n, set_d.data_ptr(), m, set_q.data_ptr(), dist1.data_ptr(), idx1.data_ptr(),
-                                      dist2.data_ptr(), idx2.data_ptr(), cd.data_ptr(), ws.data_ptr(), nbytes,
+                                      dist2.data_ptr(), idx2.data_ptr(), cd.data_ptr(), ws.data_ptr(), nbytes, 1,
                                       current_stream()), "nndistance_cd")
     return [dist1, idx1, dist2, idx2, cd]
 

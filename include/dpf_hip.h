@@ -139,16 +139,19 @@ int dpf_fscore_reduce(int b, int n, int m, const float *dist1, const float *dist
 
 /* nn_distance and its callers' reduction in one call (lib/networks/evaluating.py:110-113): the four outputs of
  * dpf_nndistance (same bits) plus cd[b] = mean(result[b]) + mean(result2[b]).  With the matrix-core kernel the
- * workgroups emit fixed-order sums of their distances and a finish kernel adds them in tile order (workspace of
- * dpf_nndistance_cd_workspace_bytes bytes, caller-owned); otherwise dpf_nndistance_auto + dpf_chamfer_reduce. */
+ * workgroups publish fixed-order sums of their distances and the LAST workgroup of every cloud (a ticket per cloud,
+ * device-coherent stores / loads on both sides) adds them in tile order: no second launch.  workspace:
+ * dpf_nndistance_cd_workspace_bytes bytes, caller-owned; its first b words are the tickets -- they must be zero on
+ * entry and are zero again on exit: pass tickets_are_zero = 1 for a workspace that was cleared once and is kept,
+ * 0 to have this call clear them.  Small problems: dpf_nndistance_auto + dpf_chamfer_reduce. */
 size_t dpf_nndistance_cd_workspace_bytes(int b, int n, int m);
 int dpf_nndistance_cd(int b, int n, const float *xyz, int m, const float *xyz2,
                       float *result, int *result_i, float *result2, int *result2_i, float *cd,
-                      void *workspace, size_t workspace_bytes, dpf_stream_t stream);
+                      void *workspace, size_t workspace_bytes, int tickets_are_zero, dpf_stream_t stream);
 
 /* pairwise_CD, lib/networks/utils.py:90-117 (called three times per generative evaluation, evaluating.py:245-247):
- * cds[i, j] = mean(dist1) + mean(dist2) of nn_distance(clouds1[i], clouds2[j]) for ALL pairs in one launch (+ a
- * finish over the workgroups' fixed-order partial sums).  clouds1 (n1, n, 3), clouds2 (n2, m, 3), cds (n1, n2),
+ * cds[i, j] = mean(dist1) + mean(dist2) of nn_distance(clouds1[i], clouds2[j]) for ALL pairs in ONE launch (the last
+ * workgroup of every pair adds the workgroups' fixed-order partial sums; + a memset of the pairs' tickets).  clouds1 (n1, n, 3), clouds2 (n2, m, 3), cds (n1, n2),
  * all point-major fp32; the reference's per-i `expand + contiguous + nn_distance` loop (utils.py:104-107) and its
  * (N2, n) intermediates disappear.  Distances are those of dpf_nndistance (bit-exact minima); the means are summed
  * per 512-query workgroup, then in ascending tile order.  n, m >= 32; n1 <= 32767, n2 <= 65535.

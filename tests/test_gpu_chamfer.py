@@ -251,3 +251,30 @@ def test_nndistance_cd_fused_reduction():
         ref = d1.double().mean(1) + d2.double().mean(1)
         assert torch.allclose(cd.double(), ref, rtol=2e-6, atol=0)
         assert torch.equal(cd, BK.NNDistanceCD(ta, tb)[4])              # deterministic
+
+
+def test_nndistance_cd_ticket_finish_under_load():
+    """The in-kernel finish of dpf_nndistance_cd reads other workgroups' sums (other CUs, other XCDs, lines that held the
+    PREVIOUS call's sums): 150 calls on changing data, the same workspace, a second stream keeping the chip unevenly busy --
+    every cd must equal the mean of the distances the same call wrote, and the tickets must be back at zero."""
+    BK = _gpu()
+    B, n = 32, 2048
+    g = torch.Generator(device="cuda").manual_seed(7)
+    base = torch.randn(B, n, 3, device="cuda", generator=g) * 0.2
+    other = torch.randn(B, n, 3, device="cuda", generator=g) * 0.2
+    side = torch.cuda.Stream()
+    junk = torch.randn(4096, 4096, device="cuda")
+    bad = 0
+    for it in range(150):
+        a = (base * (1.0 + 0.01 * it)).contiguous()
+        b = (other + 0.003 * it).contiguous()
+        if it % 3 == 0:
+            with torch.cuda.stream(side):
+                junk2 = junk @ junk                      # uneven load on part of the chip while the call runs
+        d1, i1, d2, i2, cd = BK.NNDistanceCD(a, b)
+        ref = d1.double().mean(1) + d2.double().mean(1)
+        bad += int((~torch.isclose(cd.double(), ref, rtol=3e-6, atol=0)).sum())
+    torch.cuda.synchronize()
+    assert bad == 0, bad
+    for ws in BK._CD_WORKSPACES.values():
+        assert int(ws[:4 * B].view(torch.int32).abs().sum()) == 0        # tickets left at zero
