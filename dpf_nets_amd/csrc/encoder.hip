@@ -23,18 +23,9 @@
 // The 672 KiB (bf16x3) of layer 1-3 fragments stream through LDS in 11 chunks of 64 KiB (double-buffered,
 // global_load_lds, one workgroup barrier per chunk).
 #include "flow_common.h"
+#include "encoder_layout.h"
 
 namespace {
-
-constexpr int EC0 = 3, EC1 = 64, EC2 = 128, EC3 = 256, EC4 = 512;
-// canonical fp32 block (dpf_hip.h): per layer W[cout][cin], gamma, beta, running_mean, running_var
-__host__ __device__ constexpr int e_layer_off(int l) {
-    return l == 0 ? 0 : l == 1 ? EC1 * EC0 + 4 * EC1 : l == 2 ? EC1 * EC0 + 4 * EC1 + EC2 * EC1 + 4 * EC2
-                                                              : EC1 * EC0 + 4 * EC1 + EC2 * EC1 + 4 * EC2 + EC3 * EC2 + 4 * EC3;
-}
-__host__ __device__ constexpr int e_cin(int l) { return l == 0 ? EC0 : l == 1 ? EC1 : l == 2 ? EC2 : EC3; }
-__host__ __device__ constexpr int e_cout(int l) { return l == 0 ? EC1 : l == 1 ? EC2 : l == 2 ? EC3 : EC4; }
-constexpr int E_CANON = e_layer_off(3) + EC4 * EC3 + 4 * EC4;      // 176 064 floats
 
 // packed: [A0 4 KiB: [t2][ks2][lane64][8] | bias 4 KiB: b1acc[4][2][16] b2acc[8][2][16] b3[512] pad | chunks]
 // The fragments of layers 1-3 form one stream of 336 slots (a slot = the NS parts of one 1 KiB fragment):

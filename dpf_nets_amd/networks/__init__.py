@@ -5,6 +5,6 @@ from .layers import SharedDot, Swish  # noqa: F401
 from .flows import CondRealNVPFlow3D, CondRealNVPFlow3DTriple  # noqa: F401
 from .decoders import LocalCondRNVPDecoder  # noqa: F401
 from .losses import PointFlowNLL  # noqa: F401
-from .encoders import PointNetCloudEncoder, PointFeatures  # noqa: F401
+from .encoders import PointNetCloudEncoder, PointFeatures, TrainPointFeatures  # noqa: F401
 from .optimizers import Adam, LRUpdater  # noqa: F401
 from .prior_flows import RealNVPFlow, RealNVPFlowCouple, GlobalRNVPDecoder  # noqa: F401

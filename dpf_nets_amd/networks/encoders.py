@@ -7,9 +7,15 @@ forward(input (B,3,N)) -> per-point features (B,512,N):
     (models.py:85,131,175) and use nothing else, so forward returns a `PointFeatures`: that max is answered from
     the kernel's own (B,512) result and the (B,512,N) tensor (134 MB at B=32, N=2048) is only produced -- by the
     same kernel with its feature output switched on -- if something else is asked of it;
-  * training mode / autograd / other widths: the tensor-op path (`self.features(input)`), on PyTorch-ROCm;
+  * training mode on CUDA tensors, same architecture, input not differentiable: forward returns a
+    `TrainPointFeatures`; its max over the points runs csrc/encoder_train.hip (batch-statistics BatchNorm, running
+    statistics updated in place, argmax kept) and is an autograd node whose backward is the HIP backward pass to
+    the twelve parameter gradients.  Any other use of the features materialises them with tensor ops;
+  * a differentiable input, other widths, BatchNorm without running statistics or with momentum=None: the
+    tensor-op path (`self.features(input)`), on PyTorch-ROCm;
   * eval mode on CPU tensors raises (no CPU fallback).
 """
+import ctypes
 from collections import OrderedDict
 
 import torch
@@ -127,6 +133,94 @@ for _n in ("add", "radd", "sub", "rsub", "mul", "rmul", "truediv", "rtruediv", "
 PointFeatures.__hash__ = object.__hash__
 
 
+class _TrainPool(torch.autograd.Function):
+    """pooled = max over the points of the training-mode encoder (encoders.py:27-28 + models.py:131) on
+    dpf_encoder_train_forward / dpf_encoder_train_backward.  params: W, gamma, beta of the four layers."""
+
+    @staticmethod
+    def forward(ctx, enc, x, *params):
+        B, _, N = x.shape
+        dev = x.device
+        L_ = lib()
+        canon = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in enc._layer_tensors()]).contiguous()
+        ws = torch.empty(L_.dpf_encoder_train_workspace_bytes(B, N), dtype=torch.uint8, device=dev)
+        pooled = torch.empty((B, enc.n_features[-1]), dtype=torch.float32, device=dev)
+        bns = [getattr(enc.features, n + "_bn") for n in _LAYERS]
+        ptrs = (ctypes.c_void_p * 8)(*[t.data_ptr() for bn in bns for t in (bn.running_mean, bn.running_var)])
+        with torch.cuda.device(dev):
+            check(L_.dpf_encoder_train_forward(B, N, PREC[enc.train_precision], canon.data_ptr(), x.data_ptr(), ws.data_ptr(), pooled.data_ptr(), None,
+                                               ptrs, float(bns[0].momentum), current_stream()), "encoder_train_forward")
+        for bn in bns:                                                    # written behind torch's back
+            torch.autograd.graph.increment_version(bn.running_mean)
+            torch.autograd.graph.increment_version(bn.running_var)
+        torch._foreach_add_([bn.num_batches_tracked for bn in bns], 1)
+        ctx.enc_state = (canon, x, ws, B, N)
+        ctx.save_for_backward(pooled)
+        ctx.shapes = [p.shape for p in params]
+        return pooled
+
+    @staticmethod
+    def backward(ctx, g):
+        canon, x, ws, B, N = ctx.enc_state
+        pooled, = ctx.saved_tensors
+        dcanon = torch.empty_like(canon)
+        with torch.cuda.device(x.device):
+            check(lib().dpf_encoder_train_backward(B, N, canon.data_ptr(), x.data_ptr(), ws.data_ptr(), pooled.data_ptr(),
+                                                   g.contiguous().to(torch.float32).data_ptr(), dcanon.data_ptr(), current_stream()),
+                  "encoder_train_backward")
+        ctx.enc_state = None
+        grads, off = [], 0
+        cin = _HIP_ARCH[0]
+        for i, cout in enumerate((_HIP_ARCH[1],) + tuple(_HIP_ARCH[2])):
+            for n in (cout * cin, cout, cout):                            # W, gamma, beta; then the running-statistics slots
+                grads.append(dcanon[off:off + n].view(ctx.shapes[len(grads)]))
+                off += n
+            off += 2 * cout
+            cin = cout
+        return (None, None) + tuple(grads)
+
+
+_LAYERS = ("init_sd", "sd0", "sd1", "sd2")
+
+
+class TrainPointFeatures(PointFeatures):
+    """Lazy (B,512,N) features of one TRAINING-mode encoder call: the max over the points is the HIP autograd node
+    (batch statistics are taken, running statistics updated, exactly once -- by whichever use comes first)."""
+
+    def __init__(self, encoder, x):
+        super().__init__(encoder, x)
+        self.requires_grad = torch.is_grad_enabled() and any(p.requires_grad for p in encoder.parameters())
+
+    def max_over_points(self):
+        if self._max is None:
+            enc = self._enc
+            if self._full is not None:                                   # the features were asked for first
+                self._max = torch.max(self._full, dim=2)[0]
+            else:
+                params = [t for name in _LAYERS for t in (getattr(enc.features, name).weight, getattr(enc.features, name + "_bn").weight,
+                                                          getattr(enc.features, name + "_bn").bias)]
+                self._max = _TrainPool.apply(enc, self._x, *params)
+        return self._max
+
+    def tensor(self):
+        if self._full is None:
+            enc = self._enc
+            if self._max is None:
+                self._full = enc.forward_torch(self._x)
+            else:                                                         # statistics already taken by the HIP pass
+                bns = [getattr(enc.features, n + "_bn") for n in _LAYERS]
+                keep = [(bn.momentum, bn.num_batches_tracked.clone()) for bn in bns]
+                try:
+                    for bn in bns:
+                        bn.momentum = 0.0
+                    self._full = enc.forward_torch(self._x)
+                finally:
+                    for bn, (m, nb) in zip(bns, keep):
+                        bn.momentum = m
+                        bn.num_batches_tracked.copy_(nb)
+        return self._full
+
+
 class PointNetCloudEncoder(nn.Module):
     def __init__(self, init_n_channels, init_n_features, n_features):
         super().__init__()
@@ -142,6 +236,8 @@ class PointNetCloudEncoder(nn.Module):
             self.features.add_module("sd{}_bn".format(i), nn.BatchNorm1d(n_features[i]))
             self.features.add_module("sd{}_relu".format(i), nn.ReLU(inplace=True))
         self.precision = "bf16x3"            # "bf16x3" (default, ~1e-5), "bf16x6" (fp32-class), "bf16"
+        self.hip_training = True             # training mode on csrc/encoder_train.hip (False: tensor ops)
+        self.train_precision = "bf16x6"      # forward contractions of the training path ("bf16x6" fp32-class, "bf16x3")
         object.__setattr__(self, "_pack_cache", {})
 
     def hip_supported(self):
@@ -177,10 +273,23 @@ class PointNetCloudEncoder(nn.Module):
     def forward_torch(self, input):
         return self.features(input)                                       # encoders.py:27-28
 
+    def hip_training_supported(self, input):
+        bns = [getattr(self.features, n + "_bn") for n in _LAYERS]
+        return self.hip_training and input.is_cuda and input.dtype == torch.float32 and input.dim() == 3 and input.shape[1] == 3 \
+            and input.shape[0] * input.shape[2] >= 2 and input.shape[0] <= 65535 \
+            and all(bn.track_running_stats and bn.momentum is not None and bn.running_mean is not None
+                    and bn.running_mean.dtype == torch.float32 and bn.weight is not None and bn.weight.dtype == torch.float32
+                    for bn in bns) \
+            and len({bn.momentum for bn in bns}) == 1 and all(getattr(self.features, n).weight.dtype == torch.float32 for n in _LAYERS)
+
     def forward(self, input):
-        # training mode (batch statistics + autograd), a differentiable input, or other widths: tensor ops
-        if self.training or not self.hip_supported() or (torch.is_grad_enabled() and input.requires_grad):
+        # a differentiable input or other widths: tensor ops
+        if not self.hip_supported() or (torch.is_grad_enabled() and input.requires_grad):
             return self.forward_torch(input)
+        if self.training:
+            if not self.hip_training_supported(input):
+                return self.forward_torch(input)
+            return TrainPointFeatures(self, input.contiguous())
         if not input.is_cuda:
             raise RuntimeError("PointNetCloudEncoder: the eval-mode path runs on MI355X only (input must be a CUDA tensor); "
                                "there is no CPU fallback")

@@ -335,6 +335,28 @@ int dpf_encoder_pack(int precision, const float *canon, void *packed, dpf_stream
 int dpf_encoder_forward(int B, int N, int precision, const void *packed, const float *x,
                         float *gmax, float *feat, dpf_stream_t stream);
 
+/* ---- PointNet cloud encoder, TRAINING mode (batch-statistics BatchNorm) + max over the points, and backward ----
+ * replaces, under model.train(), PointNetCloudEncoder.forward (lib/networks/encoders.py:27-28) followed by
+ * torch.max(features, dim=2)[0] (lib/networks/models.py:131), and the gradients autograd derives for the
+ * encoder's parameters (lib/networks/training.py:55).  precision: DPF_PREC_BF16X6 or DPF_PREC_BF16X3 for the
+ * forward contractions (they decide the ReLU masks and the argmax); gradient contractions are bf16x3; fp32
+ * accumulation; every reduction in a fixed order (deterministic).
+ *
+ * canon: the block of dpf_encoder_forward (running_mean / running_var slots are not read).
+ * ws: dpf_encoder_train_workspace_bytes(B, N) bytes; the forward pass leaves the pre-BatchNorm activations,
+ *   the batch statistics and the argmax there, the backward pass of the SAME step reads them.
+ * forward: x (B,3,N) -> pooled (B,512).  batch_stats (optional, 2 * 960 floats): per layer mean[C] | biased
+ *   var[C], layers in order.  running (optional): HOST array of 8 DEVICE pointers running_mean_0,
+ *   running_var_0, ... updated in place as torch.nn.BatchNorm1d does with `momentum` (unbiased variance).
+ *   B * N must be >= 2.
+ * backward: g_pooled (B,512) = d loss / d pooled, pooled = the forward's output -> dcanon (canon layout: dW,
+ *   d gamma, d beta per layer; the running-statistics slots are left untouched).  d(input) is not produced. */
+size_t dpf_encoder_train_workspace_bytes(int B, int N);
+int dpf_encoder_train_forward(int B, int N, int precision, const float *canon, const float *x, void *ws, float *pooled,
+                              float *batch_stats, float *const *running, float momentum, dpf_stream_t stream);
+int dpf_encoder_train_backward(int B, int N, const float *canon, const float *x, void *ws, const float *pooled,
+                               const float *g_pooled, float *dcanon, dpf_stream_t stream);
+
 /* ---- latent prior flow: GlobalRNVPDecoder on (B, G) codes, eval-mode BatchNorm ---------------
  * replaces GlobalRNVPDecoder.forward (lib/networks/decoders.py:21-38): n_steps = 2 * n_flows
  * RealNVPFlow steps (lib/networks/flows.py:198-213) in ONE launch, both modes.

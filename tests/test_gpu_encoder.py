@@ -84,7 +84,7 @@ def test_encoder_vs_oracle_shapes(B, N):
 
 
 def test_encoder_module_semantics():
-    """Weight-version tracking (an in-place update must be seen), train() goes to the tensor-op path, torch.max forms
+    """Weight-version tracking (an in-place update must be seen), train() goes to the training-mode kernels (tests/test_gpu_encoder_train.py), torch.max forms
     used on the features, a non-default architecture stays on tensor ops."""
     nets = _gpu()
     enc = _encoder(nets, 5)
@@ -105,7 +105,7 @@ def test_encoder_module_semantics():
         assert rel(a2, b2) <= TOL["bf16x3"] and rel(a2, a) > 1e-2
     enc.train()
     out = enc(x)
-    assert torch.is_tensor(out) and out.requires_grad
+    assert isinstance(out, nets.TrainPointFeatures) and torch.max(out, dim=2)[0].requires_grad
     enc.eval()
     xg = x.clone().requires_grad_(True)
     assert torch.is_tensor(enc(xg))                                                 # differentiable input: tensor ops
