@@ -36,6 +36,12 @@
 #include "flow_common.h"
 #include "encoder_layout.h"
 
+// Timing experiments only (results are garbage): -DET_ABLATE=<mask> removes parts of et_pgemm_kernel --
+// 1 operand-row loads, 2 epilogue loads / stores, 4 MFMAs, 8 weight staging, 16 the prologue arithmetic.
+#ifndef ET_ABLATE
+#define ET_ABLATE 0
+#endif
+
 namespace {
 
 constexpr int TCSUM = EC1 + EC2 + EC3 + EC4;                               // 960 features over the four layers
@@ -75,34 +81,46 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&part)[NS]) {
 
 // ---- weights as B-operand fragments ---------------------------------------------------------------------------------
 // out: [chunk][kstep KS][nt NT][part NS][lane 64][8 bf16]; element = Bm[k][n], k = 16 ks + 8 (lane >> 5) + j,
-// n = 32 (chunk NT + nt) + (lane & 31), Bm[k][n] = W[k * sk + n * sn]
+// n = 32 (chunk NT + nt) + (lane & 31), Bm[k][n] = W[k * sk + n * sn].  One launch packs all six matrices (blockIdx.y).
+struct WPackJob { const float *W; uint8_t *out; int sk, sn, KS, NT, nchunk, NS; };
+struct WPackArgs { WPackJob job[6]; };
 template <int NS>
-__global__ __launch_bounds__(256) void et_wpack_kernel(const float *__restrict__ W, int sk, int sn, int KS, int NT, int nchunk,
-                                                        uint8_t *__restrict__ out) {
-    const int total = nchunk * KS * NT * 64;
+__device__ __forceinline__ void wpack_job(const WPackJob &q) {
+    const int total = q.nchunk * q.KS * q.NT * 64;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int lane = idx & 63, frag = idx >> 6;
-        const int nt = frag % NT, ks = (frag / NT) % KS, chunk = frag / (NT * KS);
-        const int n = 32 * (chunk * NT + nt) + (lane & 31), k0 = 16 * ks + 8 * (lane >> 5);
+        const int nt = frag % q.NT, ks = (frag / q.NT) % q.KS, chunk = frag / (q.NT * q.KS);
+        const int n = 32 * (chunk * q.NT + nt) + (lane & 31), k0 = 16 * ks + 8 * (lane >> 5);
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = W[(size_t)(k0 + j) * sk + (size_t)n * sn];
+        for (int j = 0; j < 8; ++j) v[j] = q.W[(size_t)(k0 + j) * q.sk + (size_t)n * q.sn];
         u32x4 part[NS];
         split8<NS>(v, part);
-        uint8_t *o = out + ((size_t)frag * NS) * 1024 + lane * 16;
+        uint8_t *o = q.out + ((size_t)frag * NS) * 1024 + lane * 16;
 #pragma unroll
-        for (int q = 0; q < NS; ++q) *(u32x4 *)(o + q * 1024) = part[q];
+        for (int t = 0; t < NS; ++t) *(u32x4 *)(o + t * 1024) = part[t];
     }
+}
+__global__ __launch_bounds__(256) void et_wpack_kernel(WPackArgs a) {
+    const WPackJob &q = a.job[blockIdx.y];
+    if (q.NS == 3) wpack_job<3>(q); else wpack_job<2>(q);
 }
 
 // ---- layer 0: y0 = W0 x --------------------------------------------------------------------------------------------
+// Statistics travel as (sum, M2 about the group's own mean, count): tile -> workgroup here, workgroup -> batch in
+// et_bn_finish (Chan's pairwise combination), so a variance far below the squared mean keeps its digits.
+__device__ __forceinline__ int tile_count(const Geo &g, int ptile) {     // valid points of a 32-point tile
+    if (ptile >= g.ptiles) return 0;
+    const int left = g.N - (ptile % g.tpc) * TILE;
+    return left >= TILE ? TILE : (left > 0 ? left : 0);
+}
 __global__ __launch_bounds__(256) void et_l0_kernel(Geo g, const float *__restrict__ W0, const float *__restrict__ x,
-                                                     float *__restrict__ y0, float *__restrict__ part) {
+                                                     float *__restrict__ y0, float *__restrict__ part, float *__restrict__ cnt) {
     __shared__ float w[EC1 * EC0];
-    __shared__ float red[4][2][EC1];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float tile[32][257];
+    __shared__ float ts[PW][2][EC1];
+    const int tid = threadIdx.x;
     if (tid < EC1 * EC0) w[tid] = W0[tid];
-    __syncthreads();
     const int ptile = blockIdx.x * PW + (tid >> 5), pl = tid & 31;
     const bool tile_ok = ptile < g.ptiles;
     const int b = tile_ok ? ptile / g.tpc : 0, p = tile_ok ? (ptile % g.tpc) * TILE + pl : 0;
@@ -113,35 +131,96 @@ __global__ __launch_bounds__(256) void et_l0_kernel(Geo g, const float *__restri
         x0 = xc[0]; x1 = xc[g.N]; x2 = xc[2 * (size_t)g.N];
     }
     float *yo = y0 + (size_t)b * EC1 * g.Np + p;
-    for (int f = 0; f < EC1; ++f) {
-        const float v = live ? fmaf(w[3 * f + 2], x2, fmaf(w[3 * f + 1], x1, w[3 * f] * x0)) : 0.f;
-        if (tile_ok) yo[(size_t)f * g.Np] = v;
-        const float s1 = wave_sum(v), s2 = wave_sum(v * v);
-        if (lane == 0) { red[wave][0][f] = s1; red[wave][1][f] = s2; }
-    }
+    const int rf = tid & 31, rt = tid >> 5, rn = tile_count(g, blockIdx.x * PW + rt);      // reduction role: feature, tile
     __syncthreads();
-    if (tid < 2 * EC1) {
-        const int which = tid >> 6, f = tid & 63;
-        part[((size_t)blockIdx.x * 2 + which) * EC1 + f] = (red[0][which][f] + red[1][which][f]) + (red[2][which][f] + red[3][which][f]);
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) {
+            const int f = 32 * half + i;
+            const float v = live ? fmaf(w[3 * f + 2], x2, fmaf(w[3 * f + 1], x1, w[3 * f] * x0)) : 0.f;
+            if (tile_ok) yo[(size_t)f * g.Np] = v;
+            tile[i][tid] = v;
+        }
+        __syncthreads();
+        float s = 0.f, m2 = 0.f;
+#pragma unroll 8
+        for (int q = 0; q < 32; ++q) s += tile[rf][32 * rt + q];
+        const float m = rn > 0 ? s / (float)rn : 0.f;
+        for (int q = 0; q < rn; ++q) { const float d = tile[rf][32 * rt + q] - m; m2 = fmaf(d, d, m2); }
+        ts[rt][0][32 * half + rf] = s;
+        ts[rt][1][32 * half + rf] = m2;
+        __syncthreads();
+    }
+    if (tid < EC1) {
+        float n = 0.f, s = 0.f;
+        for (int t = 0; t < PW; ++t) { n += (float)tile_count(g, blockIdx.x * PW + t); s += ts[t][0][tid]; }
+        const float mean = n > 0.f ? s / n : 0.f;
+        float m2 = 0.f;
+        for (int t = 0; t < PW; ++t) {
+            const float nt = (float)tile_count(g, blockIdx.x * PW + t);
+            if (nt > 0.f) { const float d = ts[t][0][tid] / nt - mean; m2 += ts[t][1][tid] + nt * d * d; }
+        }
+        part[((size_t)blockIdx.x * 2) * EC1 + tid] = s;
+        part[((size_t)blockIdx.x * 2 + 1) * EC1 + tid] = m2;
+        if (tid == 0) cnt[blockIdx.x] = n;
     }
 }
 
 // ---- BatchNorm statistics: partials -> folded parameters -----------------------------------------------------------
-// bnp: [4][C] = scale (gamma / std), shift (beta - mean * scale), mean, 1 / std
-__global__ __launch_bounds__(64) void et_bn_finish_kernel(int nwg, int C, double count, const float *__restrict__ part,
-                                                           const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                           float *__restrict__ bnp, float *__restrict__ run_mean,
-                                                           float *__restrict__ run_var, float momentum, float *__restrict__ bstat) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int w = 0; w < nwg; ++w) {
-        s1 += (double)part[((size_t)w * 2) * C + c];
-        s2 += (double)part[((size_t)w * 2 + 1) * C + c];
+// part: [nwg][2][C] = per-workgroup (sum, M2 about the workgroup mean); cnt[nwg] = its number of points.
+// bnp: [4][C] = scale (gamma / std), shift (beta - mean * scale), mean, 1 / std.  One workgroup per 64 features, 16
+// slices of the partials per feature, combined in a fixed order.
+constexpr int FS = 64, FF = 16;            // slices of the partials per feature, features per workgroup
+__global__ __launch_bounds__(FF * FS) void et_bn_finish_kernel(int nwg, int C, double count, const float *__restrict__ part,
+                                                                const float *__restrict__ cnt, const float *__restrict__ gamma,
+                                                                const float *__restrict__ beta, float *__restrict__ bnp,
+                                                                float *__restrict__ run_mean, float *__restrict__ run_var, float momentum,
+                                                                float *__restrict__ bstat) {
+    __shared__ double rn[FS][FF], rs[FS][FF], rm[FS][FF];
+    const int f = threadIdx.x % FF, sl = threadIdx.x / FF, c = blockIdx.x * FF + f;
+    double N = 0.0, S = 0.0, M2 = 0.0;                       // this thread's groups, M2 about their own mean S / N
+    for (int w0 = sl; w0 < nwg; w0 += 4 * FS) {              // (one trip up to 256 workgroups) all loads in flight at once
+        float vn[4], v1[4], v2[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int w = w0 + q * FS;
+            const bool ok = w < nwg;
+            vn[q] = ok ? cnt[w] : 0.f;
+            v1[q] = ok ? part[((size_t)w * 2) * C + c] : 0.f;
+            v2[q] = ok ? part[((size_t)w * 2 + 1) * C + c] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double n = (double)vn[q];
+            if (n > 0.0) {                                   // Chan's pairwise update
+                const double d = (double)v1[q] / n - (N > 0.0 ? S / N : 0.0);
+                M2 += (double)v2[q] + d * d * N * n / (N + n);
+                N += n;
+                S += (double)v1[q];
+            }
+        }
     }
-    const double mean = s1 / count;
-    double var = s2 / count - mean * mean;
-    var = var > 0.0 ? var : 0.0;
+    rn[sl][f] = N; rs[sl][f] = S; rm[sl][f] = M2;
+    __syncthreads();
+    for (int step = FS / 2; step >= 1; step >>= 1) {         // pairwise (Chan) tree over the slices, fixed order
+        if (sl < step) {
+            const double na = rn[sl][f], nb = rn[sl + step][f];
+            if (nb > 0.0) {
+                if (na > 0.0) {
+                    const double d = rs[sl + step][f] / nb - rs[sl][f] / na;
+                    rm[sl][f] += rm[sl + step][f] + d * d * na * nb / (na + nb);
+                } else {
+                    rm[sl][f] = rm[sl + step][f];
+                }
+                rn[sl][f] = na + nb;
+                rs[sl][f] += rs[sl + step][f];
+            }
+        }
+        __syncthreads();
+    }
+    if (sl != 0) return;
+    const double mean = rs[0][f] / count, t = rm[0][f];
+    const double var = t / count;
     const float rstd = (float)(1.0 / sqrt(var + (double)BN_EPS));
     const float sc = gamma[c] * rstd;
     bnp[c] = sc;
@@ -157,16 +236,29 @@ __global__ __launch_bounds__(64) void et_bn_finish_kernel(int nwg, int C, double
 }
 
 // backward: partials of (sum dz, sum dz * yhat) -> d beta, d gamma, coef [3][C]:  d y = c0 dz + c1 + c2 y
-__global__ __launch_bounds__(64) void et_bn_bwd_finish_kernel(int nwg, int C, double count, const float *__restrict__ part,
-                                                               const float *__restrict__ bnp, float *__restrict__ coef,
-                                                               float *__restrict__ dgamma, float *__restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(FF * FS) void et_bn_bwd_finish_kernel(int nwg, int C, double count, const float *__restrict__ part,
+                                                                    const float *__restrict__ bnp, float *__restrict__ coef,
+                                                                    float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    __shared__ double red[2][FS][FF];
+    const int f = threadIdx.x % FF, sl = threadIdx.x / FF, c = blockIdx.x * FF + f;
     double t1 = 0.0, t2 = 0.0;
-    for (int w = 0; w < nwg; ++w) {
-        t1 += (double)part[((size_t)w * 2) * C + c];
-        t2 += (double)part[((size_t)w * 2 + 1) * C + c];
+    for (int w0 = sl; w0 < nwg; w0 += 4 * FS) {
+        float v1[4], v2[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int w = w0 + q * FS;
+            v1[q] = w < nwg ? part[((size_t)w * 2) * C + c] : 0.f;
+            v2[q] = w < nwg ? part[((size_t)w * 2 + 1) * C + c] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { t1 += (double)v1[q]; t2 += (double)v2[q]; }
     }
+    red[0][sl][f] = t1;
+    red[1][sl][f] = t2;
+    __syncthreads();
+    if (sl != 0) return;
+    t1 = 0.0; t2 = 0.0;
+    for (int q = 0; q < FS; ++q) { t1 += red[0][q][f]; t2 += red[1][q][f]; }
     dbeta[c] = (float)t1;
     dgamma[c] = (float)t2;
     const float sc = bnp[c], mean = bnp[2 * C + c], rstd = bnp[3 * C + c];
@@ -178,6 +270,13 @@ __global__ __launch_bounds__(64) void et_bn_bwd_finish_kernel(int nwg, int C, do
 }
 
 // ---- per-point GEMM: out[point][n] = sum_k op(in)[point][k] Bm[k][n] -------------------------------------------------
+// A workgroup = 8 waves = 8 tiles of 32 points; it produces NT * 32 output features (chunk blockIdx -> `chunk`) of them.
+// Four waves per SIMD (<= 128 VGPRs, two workgroups per CU): these kernels move 3-4 bytes per bf16x3 flop-triple and are
+// HBM-bound, so what matters is bytes in flight -- each wave keeps the operand rows of the next two k-steps in
+// registers (plain loads, counted in order by vmcnt, never drained by a barrier), and the weight fragments of the next
+// chunk travel global -> registers -> LDS one chunk ahead (one workgroup barrier per chunk of two k-steps).
+// Workgroup ids are remapped so that the `nch` chunks of the same eight tiles run on the same XCD (ids equal mod 8)
+// back to back: their operand rows are read from HBM once and from that XCD's L2 afterwards.
 enum { FWD = 0, BWD = 1, BWD_SPARSE = 2 };
 struct PArgs {
     Geo g;
@@ -186,83 +285,101 @@ struct PArgs {
     const float *pin;       // FWD: bnp of layer l-1 [4][K]; BWD: coef of layer l [3][K]
     const int *arg;         // BWD_SPARSE: (B, K) argmax point
     const float *gz;        // BWD_SPARSE: (B, K) masked pooled gradient
-    const uint8_t *wpk;     // [nchunk][KS][NT][NS][64][16 B]
+    const uint8_t *wpk;     // [nch][KS][NT][NS][64][16 B]
     float *out;             // (B, Ntot, Np): FWD y_l; BWD dz_{l-1}
     const float *yprev;     // BWD: (B, Ntot, Np) y_{l-1}
     const float *bnprev;    // BWD: bnp of layer l-1 [4][Ntot]
     float *part;            // [nwg][2][Ntot]
-    int Ntot;
+    uint8_t *apk;           // BWD: a_{l-1} = relu(BN(y_{l-1})) as K = points fragments (operand of dW_l), see et_packp_kernel
+    int Ntot, nch;
 };
 
 template <int KS, int NT, int MODE, int NS>
-__global__ __launch_bounds__(PW * 64) void et_pgemm_kernel(PArgs a) {
+__global__ __launch_bounds__(PW * 64, 4) void et_pgemm_kernel(PArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     typedef Terms<NS> TT;
-    constexpr int K = KS * 16, KC = 16 / NT, NCH = KS / KC, BUF = KC * NT * NS * 1024;   // 16 KiB of fragments per part and buffer
-    constexpr int NG = NT < 4 ? NT : 4;                      // output tiles whose MFMAs are interleaved
-    static_assert(KS % KC == 0 && BUF == NS * 16384, "chunking");
+    constexpr int K = KS * 16, KC = 2, NCH = KS / KC, BUF = KC * NT * NS * 1024, NW = BUF / (PW * 1024);
+    constexpr int NG = NT < 2 ? NT : 2;                      // output tiles whose MFMAs are interleaved
+    static_assert(KS % KC == 0 && BUF % (PW * 1024) == 0 && NW >= 1, "chunking");
     constexpr int NPAR = MODE == FWD ? 2 : 3;
     uint8_t *l_w = smem;                                     // [2][BUF]
     float *l_par = (float *)(smem + 2 * BUF);                // [NPAR][K]
     float *l_red = l_par + NPAR * K;                         // [PW][2][NT * 32]
+    int *l_arg = (int *)(l_red + PW * 2 * NT * 32);          // BWD_SPARSE: [PW][K] argmax point of the wave's cloud
+    float *l_gz = (float *)(l_arg + PW * K);                 //             [PW][K] its masked pooled gradient
 
     const Geo &g = a.g;
     const int lane = threadIdx.x & 63, h = lane >> 5, pl = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int chunk = blockIdx.y;
-    int ptile = blockIdx.x * PW + wave;
+    const int id = blockIdx.x;
+    const int tg = (id / (8 * a.nch)) * 8 + (id & 7), chunk = (id >> 3) % a.nch;
+    if (tg >= g.nwg) return;
+    int ptile = tg * PW + wave;
     const bool tile_ok = ptile < g.ptiles;
     if (!tile_ok) ptile = g.ptiles - 1;
     const int b = ptile / g.tpc, p0 = (ptile % g.tpc) * TILE;
     const bool live = tile_ok && p0 + pl < g.N;              // this lane's point exists
 
-    const uint8_t *wsrc = a.wpk + (size_t)chunk * KS * NT * NS * 1024;
-    auto stage = [&](int c) {                                // chunk c of the weight stream -> buffer c & 1
-        const uint8_t *src = wsrc + (size_t)c * BUF;
-        uint8_t *dst = l_w + (c & 1) * BUF;
+    const uint8_t *wsrc = a.wpk + (size_t)chunk * KS * NT * NS * 1024 + (size_t)wave * NW * 1024 + lane * 16;
+    u32x4 wreg[NW];
+    auto wload = [&](int c) {                                // this wave's share of chunk c of the weight stream
 #pragma unroll
-        for (int i = 0; i < BUF / 1024 / PW; ++i) {
-            const int k = wave + i * PW;
-            __builtin_amdgcn_global_load_lds((glb_void *)(src + k * 1024 + lane * 16), (lds_void *)(dst + k * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < NW; ++i) wreg[i] = *(const u32x4 *)(wsrc + (size_t)c * BUF + i * 1024);
     };
-    stage(0);
-    if (NCH > 1) stage(1);
+    auto wstore = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) *(u32x4 *)(l_w + (c & 1) * BUF + (wave * NW + i) * 1024 + lane * 16) = wreg[i];
+    };
+    wload(0);
     for (int i = threadIdx.x; i < NPAR * K; i += PW * 64) l_par[i] = a.pin[i];
+    if (MODE == BWD_SPARSE) {
+#pragma unroll
+        for (int i = 0; i < K / 256; ++i) {
+            *(int4 *)(l_arg + wave * K + i * 256 + lane * 4) = *(const int4 *)(a.arg + (size_t)b * K + i * 256 + lane * 4);
+            *(f32x4 *)(l_gz + wave * K + i * 256 + lane * 4) = *(const f32x4 *)(a.gz + (size_t)b * K + i * 256 + lane * 4);
+        }
+    }
+    wstore(0);
+    if (NCH > 1) wload(1);
 
     // operand rows of this lane: features 16 s + 8 h + j of point p0 + pl
     const size_t in_base = (size_t)b * K * g.Np + p0 + pl;
-    float ry[8], rz[8];
-    auto fetch = [&](int s) {
+    float ry[2][8], rz[2][8];
+    auto fetch = [&](int s, float (&y)[8], float (&z)[8]) {
         const size_t o = in_base + (size_t)(16 * s + 8 * h) * g.Np;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            ry[j] = a.yin[o + (size_t)j * g.Np];
-            if (MODE == BWD) rz[j] = a.dzin[o + (size_t)j * g.Np];
-        }
-        if (MODE == BWD_SPARSE) {
-            const int f0 = 16 * s + 8 * h;
-            const int4 a0 = *(const int4 *)(a.arg + (size_t)b * K + f0), a1 = *(const int4 *)(a.arg + (size_t)b * K + f0 + 4);
-            const f32x4 g0 = *(const f32x4 *)(a.gz + (size_t)b * K + f0), g1 = *(const f32x4 *)(a.gz + (size_t)b * K + f0 + 4);
-            const int p = p0 + pl;
-            rz[0] = a0.x == p ? g0.x : 0.f; rz[1] = a0.y == p ? g0.y : 0.f; rz[2] = a0.z == p ? g0.z : 0.f; rz[3] = a0.w == p ? g0.w : 0.f;
-            rz[4] = a1.x == p ? g1.x : 0.f; rz[5] = a1.y == p ? g1.y : 0.f; rz[6] = a1.z == p ? g1.z : 0.f; rz[7] = a1.w == p ? g1.w : 0.f;
+            if (ET_ABLATE & 1) { y[j] = 1.f + (float)o; z[j] = 2.f; continue; }
+            y[j] = a.yin[o + (size_t)j * g.Np];
+            if (MODE == BWD) z[j] = a.dzin[o + (size_t)j * g.Np];
         }
     };
-    auto operand = [&](int s, u32x4 (&frag)[NS]) {           // prologue: raw rows -> the NS bf16 parts of the A fragment
+    auto operand = [&](int s, const float (&y)[8], const float (&z)[8], u32x4 (&frag)[NS]) {   // prologue -> A fragment parts
         const int f0 = 16 * s + 8 * h;
         float v[8];
+        if (ET_ABLATE & 16) {
+#pragma unroll
+            for (int q = 0; q < NS; ++q) frag[q] = u32x4{f2u(y[0]), f2u(y[1]), f2u(y[2]) + q, f2u(y[3]) ^ f2u(y[4]) ^ f2u(y[5]) ^ f2u(y[6]) ^ f2u(y[7]) ^ f2u(z[0])};
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const f32x4 c0 = *(const f32x4 *)(l_par + f0 + 4 * q), c1 = *(const f32x4 *)(l_par + K + f0 + 4 * q);
-            f32x4 c2 = c1;
+            f32x4 c2 = c1, zz = c1;
             if (MODE != FWD) c2 = *(const f32x4 *)(l_par + 2 * K + f0 + 4 * q);
+            if (MODE == BWD) zz = f32x4{z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]};
+            if (MODE == BWD_SPARSE) {
+                const int4 ap = *(const int4 *)(l_arg + wave * K + f0 + 4 * q);
+                const f32x4 gv = *(const f32x4 *)(l_gz + wave * K + f0 + 4 * q);
+                const int p = p0 + pl;
+                zz = f32x4{ap.x == p ? gv.x : 0.f, ap.y == p ? gv.y : 0.f, ap.z == p ? gv.z : 0.f, ap.w == p ? gv.w : 0.f};
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int j = 4 * q + e;
                 float r;
-                if (MODE == FWD) r = fmaxf(fmaf(ry[j], c0[e], c1[e]), 0.f);
-                else r = fmaf(c0[e], rz[j], fmaf(c2[e], ry[j], c1[e]));
+                if (MODE == FWD) r = fmaxf(fmaf(y[j], c0[e], c1[e]), 0.f);
+                else r = fmaf(c0[e], zz[e], fmaf(c2[e], y[j], c1[e]));
                 v[j] = live ? r : 0.f;
             }
         }
@@ -272,16 +389,21 @@ __global__ __launch_bounds__(PW * 64) void et_pgemm_kernel(PArgs a) {
     f32x16 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    fetch(0);
+    fetch(0, ry[0], rz[0]);
+    fetch(1, ry[1], rz[1]);
     for (int c = 0; c < NCH; ++c) {
-        __syncthreads();                                     // chunk c has landed (and l_par on the first pass)
+        __syncthreads();                                     // chunk c is in buffer c & 1; nobody reads the other buffer any more
+        if (c + 1 < NCH && !(ET_ABLATE & 8)) {
+            wstore(c + 1);
+            if (c + 2 < NCH) wload(c + 2);
+        }
         const uint8_t *wb = l_w + (c & 1) * BUF;
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
             const int s = c * KC + kc;
             u32x4 af[NS];
-            operand(s, af);
-            if (s + 1 < KS) fetch(s + 1);
+            operand(s, ry[kc], rz[kc], af);
+            if (s + 2 < KS) fetch(s + 2, ry[kc], rz[kc]);
 #pragma unroll
             for (int ng = 0; ng < NT; ng += NG) {
                 u32x4 wf[NG][NS];
@@ -293,42 +415,78 @@ __global__ __launch_bounds__(PW * 64) void et_pgemm_kernel(PArgs a) {
 #pragma unroll
                 for (int term = 0; term < TT::N; ++term)
 #pragma unroll
-                    for (int i = 0; i < NG; ++i) acc[ng + i] = mfma(af[TT::A[term]], wf[i][TT::B[term]], acc[ng + i]);
+                    for (int i = 0; i < NG; ++i) {
+                        if (ET_ABLATE & 4) { acc[ng + i][term] += u2f(af[TT::A[term]][0] ^ wf[i][TT::B[term]][1]); continue; }
+                        acc[ng + i] = mfma(af[TT::A[term]], wf[i][TT::B[term]], acc[ng + i]);
+                    }
             }
         }
-        if (c + 2 < NCH) {
-            __syncthreads();                                 // everybody is done with buffer c & 1
-            stage(c + 2);
-        }
+    }
+    if (ET_ABLATE & 2) {
+        float t = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += acc[nt][r];
+        if (t == 12345.f) a.part[0] = t;
+        return;
     }
 
     // epilogue: accumulator register r = point p0 + (r & 3) + 8 (r >> 2) + 4 h, lane column = feature n0 + 32 nt + pl
     const int n0 = chunk * NT * 32;
+    const int nw = tile_ok ? tile_count(g, ptile) : 0;       // valid points of this wave's tile
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int f = n0 + 32 * nt + pl;
         const size_t o = ((size_t)b * a.Ntot + f) * g.Np + p0 + 4 * h;
         float s1 = 0.f, s2 = 0.f;
-        float sc = 0.f, sh = 0.f, mean = 0.f, rstd = 0.f;
-        if (MODE != FWD) { sc = a.bnprev[f]; sh = a.bnprev[a.Ntot + f]; mean = a.bnprev[2 * a.Ntot + f]; rstd = a.bnprev[3 * a.Ntot + f]; }
+        if (MODE == FWD) {          // (sum, M2 about the tile's own mean); padded points hold exact zeros
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 v = {acc[nt][4 * q], acc[nt][4 * q + 1], acc[nt][4 * q + 2], acc[nt][4 * q + 3]};
-            if (MODE == FWD) {
+            for (int r = 0; r < 16; ++r) s1 += acc[nt][r];
+            s1 = half_add(s1);
+            const float m = nw > 0 ? s1 / (float)nw : 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { s1 += v[e]; s2 = fmaf(v[e], v[e], s2); }
-            } else {
-                const f32x4 y = *(const f32x4 *)(a.yprev + o + 8 * q);
+            for (int r = 0; r < 16; ++r) {
+                const float d = acc[nt][r] - m;
+                const bool valid = nw == TILE || (r & 3) + 8 * (r >> 2) + 4 * h < nw;
+                s2 = valid ? fmaf(d, d, s2) : s2;
+            }
+            s2 = half_add(s2);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (tile_ok) *(f32x4 *)(a.out + o + 8 * q) = f32x4{acc[nt][4 * q], acc[nt][4 * q + 1], acc[nt][4 * q + 2], acc[nt][4 * q + 3]};
+        } else {
+            const float sc = a.bnprev[f], sh = a.bnprev[a.Ntot + f], mean = a.bnprev[2 * a.Ntot + f], rstd = a.bnprev[3 * a.Ntot + f];
+            f32x4 y[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) y[q] = *(const f32x4 *)(a.yprev + o + 8 * q);      // all four in flight before the first store
+            const long ks0 = ((long)b * g.Np + p0) / 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v = {acc[nt][4 * q], acc[nt][4 * q + 1], acc[nt][4 * q + 2], acc[nt][4 * q + 3]};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] = fmaf(y[e], sc, sh) > 0.f ? v[e] : 0.f;
+                    const float z = fmaf(y[q][e], sc, sh);
+                    v[e] = z > 0.f ? v[e] : 0.f;
                     s1 += v[e];
-                    s2 = fmaf(v[e], (y[e] - mean) * rstd, s2);
+                    s2 = fmaf(v[e], (y[q][e] - mean) * rstd, s2);
+                    y[q][e] = (nw == TILE || 4 * h + 8 * q + e < nw) ? fmaxf(z, 0.f) : 0.f;      // a_{l-1}; padded points give 0
+                }
+                if (tile_ok) *(f32x4 *)(a.out + o + 8 * q) = v;
+            }
+            if (tile_ok) {          // k-step j2 of the tile: this lane (row pl, k group h) holds points 16 j2 + 8 (i >> 2) + 4 h + (i & 3)
+#pragma unroll
+                for (int j2 = 0; j2 < 2; ++j2) {
+                    const float v8[8] = {y[2 * j2][0], y[2 * j2][1], y[2 * j2][2], y[2 * j2][3], y[2 * j2 + 1][0], y[2 * j2 + 1][1], y[2 * j2 + 1][2], y[2 * j2 + 1][3]};
+                    u32x4 hl[2];
+                    split8<2>(v8, hl);
+                    uint8_t *dst = a.apk + ((((size_t)(n0 / 32 + nt)) * (g.P / 16) + ks0 + j2) * 2) * 1024 + lane * 16;
+                    *(u32x4 *)dst = hl[0];
+                    *(u32x4 *)(dst + 1024) = hl[1];
                 }
             }
-            if (tile_ok) *(f32x4 *)(a.out + o + 8 * q) = v;
+            s1 = half_add(s1); s2 = half_add(s2);
         }
-        s1 = half_add(s1); s2 = half_add(s2);
         if (!tile_ok) { s1 = 0.f; s2 = 0.f; }
         if (!h) {
             l_red[(wave * 2 + 0) * (NT * 32) + 32 * nt + pl] = s1;
@@ -336,12 +494,25 @@ __global__ __launch_bounds__(PW * 64) void et_pgemm_kernel(PArgs a) {
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * NT * 32; i += PW * 64) {
-        const int which = i / (NT * 32), f = i % (NT * 32);
-        float s = 0.f;
+    if (threadIdx.x < NT * 32) {
+        const int f = threadIdx.x;
+        float s = 0.f, t = 0.f;
+        if (MODE == FWD) {
+            float n = 0.f;
 #pragma unroll
-        for (int w = 0; w < PW; ++w) s += l_red[(w * 2 + which) * (NT * 32) + f];
-        a.part[((size_t)blockIdx.x * 2 + which) * a.Ntot + n0 + f] = s;
+            for (int w = 0; w < PW; ++w) { n += (float)tile_count(g, tg * PW + w); s += l_red[(w * 2) * (NT * 32) + f]; }
+            const float mean = n > 0.f ? s / n : 0.f;
+#pragma unroll
+            for (int w = 0; w < PW; ++w) {
+                const float nt_ = (float)tile_count(g, tg * PW + w);
+                if (nt_ > 0.f) { const float d = l_red[(w * 2) * (NT * 32) + f] / nt_ - mean; t += l_red[(w * 2 + 1) * (NT * 32) + f] + nt_ * d * d; }
+            }
+        } else {
+#pragma unroll
+            for (int w = 0; w < PW; ++w) { s += l_red[(w * 2) * (NT * 32) + f]; t += l_red[(w * 2 + 1) * (NT * 32) + f]; }
+        }
+        a.part[((size_t)tg * 2) * a.Ntot + n0 + f] = s;
+        a.part[((size_t)tg * 2 + 1) * a.Ntot + n0 + f] = t;
     }
 }
 
@@ -377,84 +548,51 @@ __global__ __launch_bounds__(256) void et_pool_kernel(Geo g, const float *__rest
 }
 
 // the pooled gradient as the sparse dz3: gz[b, f] = g[b, f] [pooled > 0] at point arg[b, f]; its BatchNorm sums
-__global__ __launch_bounds__(64) void et_pool_bwd_kernel(int B, const float *__restrict__ gp, const float *__restrict__ pooled,
-                                                          const float *__restrict__ yarg, const float *__restrict__ bnp,
-                                                          float *__restrict__ gz, float *__restrict__ part) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= EC4) return;
+__global__ __launch_bounds__(256) void et_pool_bwd_kernel(int B, const float *__restrict__ gp, const float *__restrict__ pooled,
+                                                           const float *__restrict__ yarg, const float *__restrict__ bnp,
+                                                           float *__restrict__ gz, float *__restrict__ part) {
+    __shared__ float red[2][4][64];
+    const int fl = threadIdx.x & 63, sl = threadIdx.x >> 6, f = blockIdx.x * 64 + fl;
     const float mean = bnp[2 * EC4 + f], rstd = bnp[3 * EC4 + f];
     float s1 = 0.f, s2 = 0.f;
-    for (int b = 0; b < B; ++b) {
+    for (int b = sl; b < B; b += 4) {
         const float v = pooled[b * EC4 + f] > 0.f ? gp[b * EC4 + f] : 0.f;
         gz[b * EC4 + f] = v;
         s1 += v;
         s2 = fmaf(v, (yarg[b * EC4 + f] - mean) * rstd, s2);
     }
-    part[f] = s1;
-    part[EC4 + f] = s2;
-}
-
-// ---- operands of the weight gradient: rows = features, K = points ----------------------------------------------------
-// out: [ftile C/32][kstep P/16][part 2][lane 64][8 bf16]; lane (row, kg) holds points 16 s + 8 kg + j of feature 32 ft + row.
-// MODE FWD: a = relu(BN(y)); BWD: d y = c0 dz + c1 + c2 y; BWD_SPARSE: dz = gz at the argmax point.  Padded points give 0.
-template <int MODE>
-__global__ __launch_bounds__(256) void et_packp_kernel(Geo g, int C, const float *__restrict__ y, const float *__restrict__ dz,
-                                                        const float *__restrict__ par, const int *__restrict__ arg,
-                                                        const float *__restrict__ gz, uint8_t *__restrict__ out) {
-    const int lane = threadIdx.x & 63, row = lane & 31, kg = lane >> 5;
-    const long PS = g.P / 16, items = (long)(C / 32) * (PS / 2);
-    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= items) return;
-    const int ft = (int)(item / (PS / 2));
-    const long s2 = item % (PS / 2);
-    const int f = 32 * ft + row;
-    const float c0 = par[f], c1 = par[C + f], c2 = MODE == FWD ? 0.f : par[2 * C + f];
-#pragma unroll
-    for (int sp = 0; sp < 2; ++sp) {
-        const long s = 2 * s2 + sp, q = 16 * s + 8 * kg;
-        const int b = (int)(q / g.Np), p = (int)(q % g.Np);
-        const size_t o = ((size_t)b * C + f) * g.Np + p;
-        const f32x4 y0 = *(const f32x4 *)(y + o), y1 = *(const f32x4 *)(y + o + 4);
-        const float yy[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
-        float v[8];
-        if (MODE == FWD) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaxf(fmaf(yy[j], c0, c1), 0.f);
-        } else if (MODE == BWD) {
-            const f32x4 d0 = *(const f32x4 *)(dz + o), d1 = *(const f32x4 *)(dz + o + 4);
-            const float dd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaf(c0, dd[j], fmaf(c2, yy[j], c1));
-        } else {
-            const int ap = arg[(size_t)b * C + f];
-            const float gv = gz[(size_t)b * C + f];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaf(c0, ap == p + j ? gv : 0.f, fmaf(c2, yy[j], c1));
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) if (p + j >= g.N) v[j] = 0.f;
-        u32x4 hl[2];
-        split8<2>(v, hl);
-        uint8_t *dst = out + (((size_t)ft * PS + s) * 2) * 1024 + lane * 16;
-        *(u32x4 *)dst = hl[0];
-        *(u32x4 *)(dst + 1024) = hl[1];
+    red[0][sl][fl] = s1;
+    red[1][sl][fl] = s2;
+    __syncthreads();
+    if (sl == 0) {
+        part[f] = (red[0][0][fl] + red[0][1][fl]) + (red[0][2][fl] + red[0][3][fl]);
+        part[EC4 + f] = (red[1][0][fl] + red[1][1][fl]) + (red[1][2][fl] + red[1][3][fl]);
     }
 }
 
-// ---- weight gradient: part[kchunk][m][n] = sum over the chunk's points of A[m][p] Bm[n][p] ---------------------------------
+// ---- weight gradient: part[kchunk][m][n] = sum over the chunk's points of d y[m][p] a[n][p] -----------------------------
+// The a operand arrives as K = points fragments (written by the per-point GEMM's epilogue).  The d y operand is formed
+// HERE from the fp32 rows: d y = c0 dz + c1 + c2 y (MODE BWD), dz = gz at the argmax point (BWD_SPARSE), on the way from
+// the global loads to LDS -- each element is transformed once per workgroup, ~100 VALU instructions per wave next to 48 MFMAs.
 struct WArgs {
-    const uint8_t *A, *Bm;      // packed K = points operands: [tile][PS][2][64][16 B]
-    float *part;                // [nchunk][M][Ncols]
+    Geo g;
+    const float *y, *dz, *coef;     // (B, M, Np) rows of layer l; coef [3][M]
+    const int *arg;                 // BWD_SPARSE: (B, M)
+    const float *gz;
+    const uint8_t *Bm;              // packed K = points operand a_{l-1}: [tile][PS][2][64][16 B]
+    float *part;                    // [nchunk][M][Ncols]
     long PS;
     int ks_chunk, M, Ncols;
 };
 
-template <int WM, int WN, int GM, int GN>
+template <int WM, int WN, int GM, int GN, int MODE>
 __global__ __launch_bounds__(GM * GN * 64) void et_wgrad_kernel(WArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int NWV = GM * GN, BM = GM * WM, BN = GN * WN, KC = 2;
-    constexpr int STAGE = KC * (BM + BN) * 2048, NI = STAGE / 1024;
-    static_assert(NI % NWV == 0, "staging");
+    constexpr int STAGE = KC * (BM + BN) * 2048;
+    constexpr int NA = KC * BM / NWV, NB = KC * BN * 2 / NWV;      // per wave and stage: d y fragment pairs to form, a fragments to copy
+    static_assert(KC * BM % NWV == 0 && KC * BN * 2 % NWV == 0, "staging");
+    const Geo &g = a.g;
     const int lane = threadIdx.x & 63, h = lane >> 5, pl = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / GN, wn = wave % GN;
@@ -463,17 +601,66 @@ __global__ __launch_bounds__(GM * GN * 64) void et_wgrad_kernel(WArgs a) {
     const int nst = (int)((s_end_l - s_begin + KC - 1) / KC);
     const int rb = blockIdx.y, cb = blockIdx.z;
 
-    auto stage = [&](int st) {      // k-steps s_begin + st KC .. of all block tiles -> buffer st & 1: [kc][tile BM + BN][part]
-        uint8_t *dst = smem + (st & 1) * STAGE;
+    // a stage = KC k-steps of all the block's tiles in LDS: [kc][tile BM + BN][part]; it travels global -> registers ->
+    // (transform) -> LDS one stage ahead of its use (plain loads: the vmcnt waits are exact and no barrier drains them)
+    f32x4 ry[NA][2], rd[NA][2];
+    int rarg[NA];
+    float rgz[NA];
+    int rp[NA];                                               // first point (within its cloud) of the lane's 8, or -1
+    float cf[NA][3];
+    u32x4 rb_[NB];
 #pragma unroll
-        for (int i = 0; i < NI / NWV; ++i) {
-            const int k = wave + i * NWV;
-            const int part = k & 1, tile = (k >> 1) % (BM + BN), kc = (k >> 1) / (BM + BN);
+    for (int i = 0; i < NA; ++i) {
+        const int tile = (wave + i * NWV) % BM, f = (rb * BM + tile) * 32 + pl;
+        cf[i][0] = a.coef[f]; cf[i][1] = a.coef[a.M + f]; cf[i][2] = a.coef[2 * a.M + f];
+    }
+    auto sload = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int k = wave + i * NWV, tile = k % BM, kc = k / BM;
             long s = s_begin + (long)st * KC + kc;
             if (s >= a.PS) s = a.PS - 1;                      // tail: a repeated k-step, not used
-            const uint8_t *src = tile < BM ? a.A + ((((size_t)(rb * BM + tile)) * a.PS + s) * 2 + part) * 1024
-                                           : a.Bm + ((((size_t)(cb * BN + tile - BM)) * a.PS + s) * 2 + part) * 1024;
-            __builtin_amdgcn_global_load_lds((glb_void *)(src + lane * 16), (lds_void *)(dst + k * 1024), 16, 0, 0);
+            const long q = 16 * s + 4 * h;
+            const int b = (int)(q / g.Np), p = (int)(q % g.Np), f = (rb * BM + tile) * 32 + pl;
+            const size_t o = ((size_t)b * a.M + f) * g.Np + p;
+            ry[i][0] = *(const f32x4 *)(a.y + o); ry[i][1] = *(const f32x4 *)(a.y + o + 8);
+            if (MODE == BWD) { rd[i][0] = *(const f32x4 *)(a.dz + o); rd[i][1] = *(const f32x4 *)(a.dz + o + 8); }
+            if (MODE == BWD_SPARSE) { rarg[i] = a.arg[(size_t)b * a.M + f]; rgz[i] = a.gz[(size_t)b * a.M + f]; }
+            rp[i] = p;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int k = wave + i * NWV, part = k & 1, tile = (k >> 1) % BN, kc = (k >> 1) / BN;
+            long s = s_begin + (long)st * KC + kc;
+            if (s >= a.PS) s = a.PS - 1;
+            rb_[i] = *(const u32x4 *)(a.Bm + ((((size_t)(cb * BN + tile)) * a.PS + s) * 2 + part) * 1024 + lane * 16);
+        }
+    };
+    auto sstore = [&](int st) {
+        uint8_t *dst = smem + (st & 1) * STAGE;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int k = wave + i * NWV, tile = k % BM, kc = k / BM;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float yv = ry[i][j >> 2][j & 3];
+                const int pj = rp[i] + (j & 3) + 8 * (j >> 2);
+                float dzv;
+                if (MODE == BWD) dzv = rd[i][j >> 2][j & 3];
+                else dzv = rarg[i] == pj ? rgz[i] : 0.f;
+                const float r = fmaf(cf[i][0], dzv, fmaf(cf[i][2], yv, cf[i][1]));
+                v[j] = pj < g.N ? r : 0.f;
+            }
+            u32x4 hl[2];
+            split8<2>(v, hl);
+            *(u32x4 *)(dst + ((kc * (BM + BN) + tile) * 2 + 0) * 1024 + lane * 16) = hl[0];
+            *(u32x4 *)(dst + ((kc * (BM + BN) + tile) * 2 + 1) * 1024 + lane * 16) = hl[1];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int k = wave + i * NWV, part = k & 1, tile = (k >> 1) % BN, kc = (k >> 1) / BN;
+            *(u32x4 *)(dst + ((kc * (BM + BN) + BM + tile) * 2 + part) * 1024 + lane * 16) = rb_[i];
         }
     };
     f32x16 acc[WM][WN];
@@ -481,10 +668,15 @@ __global__ __launch_bounds__(GM * GN * 64) void et_wgrad_kernel(WArgs a) {
     for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j) acc[i][j] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    stage(0);
-    if (nst > 1) stage(1);
+    sload(0);
+    sstore(0);
+    if (nst > 1) sload(1);
     for (int st = 0; st < nst; ++st) {
         __syncthreads();
+        if (st + 1 < nst) {
+            sstore(st + 1);
+            if (st + 2 < nst) sload(st + 2);
+        }
         const uint8_t *sb = smem + (st & 1) * STAGE;
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
@@ -515,10 +707,6 @@ __global__ __launch_bounds__(GM * GN * 64) void et_wgrad_kernel(WArgs a) {
                     for (int j = 0; j < WN; ++j) acc[i][j] = mfma(ah[i], bh[j], acc[i][j]);
             }
         }
-        if (st + 2 < nst) {
-            __syncthreads();
-            stage(st + 2);
-        }
     }
     float *po = a.part + (size_t)blockIdx.x * a.M * a.Ncols;
 #pragma unroll
@@ -534,16 +722,22 @@ __global__ __launch_bounds__(GM * GN * 64) void et_wgrad_kernel(WArgs a) {
         }
 }
 
-// out[e] = sum over the chunks of part[chunk][e], fixed order
+// out[e] = sum over the chunks of part[chunk][e]: four slices of the chunks per element, combined in a fixed order
 __global__ __launch_bounds__(256) void et_wreduce_kernel(int nchunk, int E4, const f32x4 *__restrict__ part, f32x4 *__restrict__ out) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E4) return;
-    f32x4 s = part[e];
-    for (int c = 1; c < nchunk; ++c) {
+    __shared__ f32x4 red[4][64];
+    const int el = threadIdx.x & 63, sl = threadIdx.x >> 6, e = blockIdx.x * 64 + el;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int c = sl; c < nchunk; c += 4) {
         const f32x4 v = part[(size_t)c * E4 + e];
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    out[e] = s;
+    red[sl][el] = s;
+    __syncthreads();
+    if (sl == 0) {
+        const f32x4 a0 = red[0][el], a1 = red[1][el], a2 = red[2][el], a3 = red[3][el];
+        out[e] = f32x4{(a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w)};
+    }
 }
 
 // dW0[f][k] = sum_p d y0[f][p] x[k][p], d y0 = c0 dz0 + c1 + c2 y0: one workgroup per (feature, cloud) -> part[b][f][3 (+1 pad)]
@@ -568,11 +762,14 @@ __global__ __launch_bounds__(256) void et_wgrad0_kernel(Geo g, const float *__re
     if (threadIdx.x < 3)
         part[((size_t)b * EC1 + f) * 3 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-__global__ __launch_bounds__(192) void et_w0reduce_kernel(int B, const float *__restrict__ part, float *__restrict__ out) {
-    const int e = threadIdx.x;
+__global__ __launch_bounds__(768) void et_w0reduce_kernel(int B, const float *__restrict__ part, float *__restrict__ out) {
+    __shared__ float red[4][192];
+    const int e = threadIdx.x % 192, sl = threadIdx.x / 192;
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += part[(size_t)b * EC1 * 3 + e];
-    out[e] = s;
+    for (int b = sl; b < B; b += 4) s += part[(size_t)b * EC1 * 3 + e];
+    red[sl][e] = s;
+    __syncthreads();
+    if (sl == 0) out[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
@@ -586,8 +783,8 @@ constexpr int KS_CHUNK = 32;                 // point k-steps (512 points) per w
 
 struct TWork {
     float *y[4], *dz[3];
-    uint8_t *aP[3], *dyP, *wf[3], *wb[3];
-    float *part, *bnp, *coef, *yarg, *gz, *wpart, *w0part;
+    uint8_t *aP[3], *wf[3], *wb[3];
+    float *part, *cnt, *bnp, *coef, *yarg, *gz, *wpart, *w0part;
     int *arg;
 };
 size_t t_carve(void *ws, const Geo &g, TWork *w) {
@@ -598,12 +795,12 @@ size_t t_carve(void *ws, const Geo &g, TWork *w) {
     for (int l = 0; l < 4; ++l) { p = take((size_t)C[l] * g.P * 4); if (w) w->y[l] = (float *)p; }
     for (int l = 0; l < 3; ++l) { p = take((size_t)C[l] * g.P * 4); if (w) w->dz[l] = (float *)p; }
     for (int l = 0; l < 3; ++l) { p = take((size_t)C[l] * g.P * 4); if (w) w->aP[l] = (uint8_t *)p; }
-    p = take((size_t)EC4 * g.P * 4); if (w) w->dyP = (uint8_t *)p;
     for (int l = 1; l < 4; ++l) {
         p = take((size_t)C[l] * C[l - 1] * 6); if (w) w->wf[l - 1] = (uint8_t *)p;
         p = take((size_t)C[l] * C[l - 1] * 4); if (w) w->wb[l - 1] = (uint8_t *)p;
     }
     p = take((size_t)g.nwg * 2 * EC4 * 4); if (w) w->part = (float *)p;
+    p = take((size_t)g.nwg * 4); if (w) w->cnt = (float *)p;
     p = take((size_t)4 * TCSUM * 4); if (w) w->bnp = (float *)p;
     p = take((size_t)3 * TCSUM * 4); if (w) w->coef = (float *)p;
     p = take((size_t)g.B * EC4 * 4); if (w) w->yarg = (float *)p;
@@ -619,29 +816,29 @@ inline const float *cW(const float *canon, int l) { return canon + e_layer_off(l
 inline const float *cG(const float *canon, int l) { return canon + e_layer_off(l) + e_cout(l) * e_cin(l); }
 
 template <int KS, int NT, int MODE, int NS>
-int launch_pgemm(const PArgs &a, int nchunk, hipStream_t s) {
+int launch_pgemm(PArgs a, hipStream_t s) {
     constexpr int K = KS * 16, NPAR = MODE == FWD ? 2 : 3;
-    const int lds = 2 * NS * 16384 + NPAR * K * 4 + PW * 2 * NT * 32 * 4;
+    a.nch = a.Ntot / (NT * 32);
+    const int lds = 2 * 2 * NT * NS * 1024 + NPAR * K * 4 + PW * 2 * NT * 32 * 4 + (MODE == BWD_SPARSE ? PW * K * 8 : 0);
     static LdsLimit limit;
     if (hipError_t e = limit.ensure((const void *)et_pgemm_kernel<KS, NT, MODE, NS>, lds); e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((et_pgemm_kernel<KS, NT, MODE, NS>), dim3(a.g.nwg, nchunk), dim3(PW * 64), lds, s, a);
+    hipLaunchKernelGGL((et_pgemm_kernel<KS, NT, MODE, NS>), dim3((a.g.nwg + 7) / 8 * 8 * a.nch), dim3(PW * 64), lds, s, a);
     return (int)hipGetLastError();
 }
 template <int NS>
-int forward_layers(const Geo &g, const TWork &w, const float *canon, hipStream_t s, const int (&C)[4]) {
-    for (int l = 1; l < 4; ++l) {
-        const int cin = C[l - 1], cout = C[l];
-        const int ntf = cout >= 256 ? 8 : 4;
-        hipLaunchKernelGGL(et_wpack_kernel<NS>, dim3(64), dim3(256), 0, s, cW(canon, l), 1, cin, cin / 16, ntf, cout / 32 / ntf, w.wf[l - 1]);
-    }
-    return (int)hipGetLastError();
+int forward_gemms(const Geo &g, const TWork &w, hipStream_t s, const int (&C)[4], int l) {
+    PArgs a{};
+    a.g = g; a.yin = w.y[l - 1]; a.pin = w.bnp + 4 * t_coff(l - 1); a.wpk = w.wf[l - 1]; a.out = w.y[l]; a.part = w.part; a.Ntot = C[l];
+    if (l == 1) return launch_pgemm<4, 4, FWD, NS>(a, s);
+    if (l == 2) return launch_pgemm<8, 4, FWD, NS>(a, s);
+    return launch_pgemm<16, 4, FWD, NS>(a, s);
 }
-template <int WM, int WN, int GM, int GN>
+template <int WM, int WN, int GM, int GN, int MODE>
 int launch_wgrad(const WArgs &a, int nchunk, int rblocks, int cblocks, hipStream_t s) {
     const int lds = 2 * 2 * (GM * WM + GN * WN) * 2048;
     static LdsLimit limit;
-    if (hipError_t e = limit.ensure((const void *)et_wgrad_kernel<WM, WN, GM, GN>, lds); e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((et_wgrad_kernel<WM, WN, GM, GN>), dim3(nchunk, rblocks, cblocks), dim3(GM * GN * 64), lds, s, a);
+    if (hipError_t e = limit.ensure((const void *)et_wgrad_kernel<WM, WN, GM, GN, MODE>, lds); e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((et_wgrad_kernel<WM, WN, GM, GN, MODE>), dim3(nchunk, rblocks, cblocks), dim3(GM * GN * 64), lds, s, a);
     return (int)hipGetLastError();
 }
 
@@ -669,27 +866,25 @@ extern "C" int dpf_encoder_train_forward(int B, int N, int precision, const floa
     const double count = (double)B * N;
     const int C[4] = {EC1, EC2, EC3, EC4};
     // weights -> fragments: forward Bm[k = cin][n = cout] = W[n][k]; backward Bm[k = cout][n = cin] = W[k][n]
-    ET_CHECK(x6 ? forward_layers<3>(g, w, canon, s, C) : forward_layers<2>(g, w, canon, s, C));
+    WPackArgs wp;
     for (int l = 1; l < 4; ++l) {
         const int cin = C[l - 1], cout = C[l];
-        const int ntb = l == 3 ? 8 : l == 2 ? 4 : 2;
-        hipLaunchKernelGGL(et_wpack_kernel<2>, dim3(64), dim3(256), 0, s, cW(canon, l), cin, 1, cout / 16, ntb, cin / 32 / ntb, w.wb[l - 1]);
+        const int ntb = cin >= 128 ? 4 : 2;
+        wp.job[l - 1] = WPackJob{cW(canon, l), w.wf[l - 1], 1, cin, cin / 16, 4, cout / 128, x6 ? 3 : 2};
+        wp.job[l + 2] = WPackJob{cW(canon, l), w.wb[l - 1], cin, 1, cout / 16, ntb, cin / 32 / ntb, 2};
     }
-    hipLaunchKernelGGL(et_l0_kernel, dim3(g.nwg), dim3(256), 0, s, g, cW(canon, 0), x, w.y[0], w.part);
+    hipLaunchKernelGGL(et_wpack_kernel, dim3(32, 6), dim3(256), 0, s, wp);
+    hipLaunchKernelGGL(et_l0_kernel, dim3(g.nwg), dim3(256), 0, s, g, cW(canon, 0), x, w.y[0], w.part, w.cnt);
     ET_LAST();
     auto finish = [&](int l) {
         const float *gam = cG(canon, l);
-        hipLaunchKernelGGL(et_bn_finish_kernel, dim3((C[l] + 63) / 64), dim3(64), 0, s, g.nwg, C[l], count, w.part, gam, gam + C[l],
+        hipLaunchKernelGGL(et_bn_finish_kernel, dim3(C[l] / FF), dim3(FF * FS), 0, s, g.nwg, C[l], count, w.part, w.cnt, gam, gam + C[l],
                            w.bnp + 4 * t_coff(l), running ? running[2 * l] : nullptr, running ? running[2 * l + 1] : nullptr, momentum,
                            batch_stats ? batch_stats + 2 * t_coff(l) : nullptr);
     };
     finish(0);
     for (int l = 1; l < 4; ++l) {
-        PArgs a{};
-        a.g = g; a.yin = w.y[l - 1]; a.pin = w.bnp + 4 * t_coff(l - 1); a.wpk = w.wf[l - 1]; a.out = w.y[l]; a.part = w.part; a.Ntot = C[l];
-        if (l == 1) ET_CHECK(x6 ? (launch_pgemm<4, 4, FWD, 3>(a, 1, s)) : (launch_pgemm<4, 4, FWD, 2>(a, 1, s)));
-        if (l == 2) ET_CHECK(x6 ? (launch_pgemm<8, 8, FWD, 3>(a, 1, s)) : (launch_pgemm<8, 8, FWD, 2>(a, 1, s)));
-        if (l == 3) ET_CHECK(x6 ? (launch_pgemm<16, 8, FWD, 3>(a, 2, s)) : (launch_pgemm<16, 8, FWD, 2>(a, 2, s)));
+        ET_CHECK(x6 ? forward_gemms<3>(g, w, s, C, l) : forward_gemms<2>(g, w, s, C, l));
         finish(l);
     }
     hipLaunchKernelGGL(et_pool_kernel, dim3((B * EC4 + 3) / 4), dim3(256), 0, s, g, w.y[3], w.bnp + 4 * t_coff(3), pooled, w.arg, w.yarg);
@@ -710,42 +905,31 @@ extern "C" int dpf_encoder_train_backward(int B, int N, const float *canon, cons
     const int nchunk = (int)((PS + KS_CHUNK - 1) / KS_CHUNK);
     auto dG = [&](int l) { return dcanon + e_layer_off(l) + e_cout(l) * e_cin(l); };
 
-    hipLaunchKernelGGL(et_pool_bwd_kernel, dim3(EC4 / 64), dim3(64), 0, s, B, g_pooled, pooled, w.yarg, w.bnp + 4 * t_coff(3), w.gz, w.part);
+    hipLaunchKernelGGL(et_pool_bwd_kernel, dim3(EC4 / 64), dim3(256), 0, s, B, g_pooled, pooled, w.yarg, w.bnp + 4 * t_coff(3), w.gz, w.part);
     ET_LAST();
     for (int l = 3; l >= 1; --l) {
         const int cin = C[l - 1], cout = C[l];
         float *coef = w.coef + 3 * t_coff(l);
-        hipLaunchKernelGGL(et_bn_bwd_finish_kernel, dim3(cout / 64), dim3(64), 0, s, l == 3 ? 1 : g.nwg, cout, count, w.part,
+        hipLaunchKernelGGL(et_bn_bwd_finish_kernel, dim3(cout / FF), dim3(FF * FS), 0, s, l == 3 ? 1 : g.nwg, cout, count, w.part,
                            w.bnp + 4 * t_coff(l), coef, dG(l), dG(l) + cout);
-        // operands of dW_l
-        const long items_dy = (long)(cout / 32) * (PS / 2), items_a = (long)(cin / 32) * (PS / 2);
-        if (l == 3)
-            hipLaunchKernelGGL(et_packp_kernel<BWD_SPARSE>, dim3((unsigned)((items_dy + 3) / 4)), dim3(256), 0, s, g, cout, w.y[3], nullptr, coef,
-                               w.arg, w.gz, w.dyP);
-        else
-            hipLaunchKernelGGL(et_packp_kernel<BWD>, dim3((unsigned)((items_dy + 3) / 4)), dim3(256), 0, s, g, cout, w.y[l], w.dz[l], coef,
-                               nullptr, nullptr, w.dyP);
-        hipLaunchKernelGGL(et_packp_kernel<FWD>, dim3((unsigned)((items_a + 3) / 4)), dim3(256), 0, s, g, cin, w.y[l - 1], nullptr,
-                           w.bnp + 4 * t_coff(l - 1), nullptr, nullptr, w.aP[l - 1]);
-        ET_LAST();
-        WArgs wa{w.dyP, w.aP[l - 1], w.wpart, PS, KS_CHUNK, cout, cin};
-        if (l == 3) ET_CHECK((launch_wgrad<4, 2, 2, 4>(wa, nchunk, 2, 1, s)));
-        if (l == 2) ET_CHECK((launch_wgrad<2, 2, 4, 2>(wa, nchunk, 1, 1, s)));
-        if (l == 1) ET_CHECK((launch_wgrad<1, 1, 4, 2>(wa, nchunk, 1, 1, s)));
-        const int E4 = cout * cin / 4;
-        hipLaunchKernelGGL(et_wreduce_kernel, dim3((E4 + 255) / 256), dim3(256), 0, s, nchunk, E4, (const f32x4 *)w.wpart,
-                           (f32x4 *)(dcanon + e_layer_off(l)));
-        // dz_{l-1} and its BatchNorm sums
+        // dz_{l-1}, its BatchNorm sums, and a_{l-1} as the other operand of dW_l
         PArgs a{};
         a.g = g; a.yin = w.y[l]; a.dzin = l == 3 ? nullptr : w.dz[l]; a.pin = coef; a.arg = w.arg; a.gz = w.gz; a.wpk = w.wb[l - 1];
-        a.out = w.dz[l - 1]; a.yprev = w.y[l - 1]; a.bnprev = w.bnp + 4 * t_coff(l - 1); a.part = w.part; a.Ntot = cin;
-        if (l == 3) ET_CHECK((launch_pgemm<32, 8, BWD_SPARSE, 2>(a, 1, s)));
-        if (l == 2) ET_CHECK((launch_pgemm<16, 4, BWD, 2>(a, 1, s)));
-        if (l == 1) ET_CHECK((launch_pgemm<8, 2, BWD, 2>(a, 1, s)));
+        a.out = w.dz[l - 1]; a.yprev = w.y[l - 1]; a.bnprev = w.bnp + 4 * t_coff(l - 1); a.part = w.part; a.Ntot = cin; a.apk = w.aP[l - 1];
+        if (l == 3) ET_CHECK((launch_pgemm<32, 4, BWD_SPARSE, 2>(a, s)));
+        if (l == 2) ET_CHECK((launch_pgemm<16, 4, BWD, 2>(a, s)));
+        if (l == 1) ET_CHECK((launch_pgemm<8, 2, BWD, 2>(a, s)));
+        WArgs wa{g, w.y[l], l == 3 ? nullptr : w.dz[l], coef, w.arg, w.gz, w.aP[l - 1], w.wpart, PS, KS_CHUNK, cout, cin};
+        if (l == 3) ET_CHECK((launch_wgrad<4, 2, 2, 4, BWD_SPARSE>(wa, nchunk, 2, 1, s)));
+        if (l == 2) ET_CHECK((launch_wgrad<2, 2, 2, 2, BWD>(wa, nchunk, 2, 1, s)));
+        if (l == 1) ET_CHECK((launch_wgrad<1, 1, 2, 2, BWD>(wa, nchunk, 2, 1, s)));
+        const int E4 = cout * cin / 4;
+        hipLaunchKernelGGL(et_wreduce_kernel, dim3(E4 / 64), dim3(256), 0, s, nchunk, E4, (const f32x4 *)w.wpart,
+                           (f32x4 *)(dcanon + e_layer_off(l)));
     }
     float *coef0 = w.coef;
-    hipLaunchKernelGGL(et_bn_bwd_finish_kernel, dim3(1), dim3(64), 0, s, g.nwg, EC1, count, w.part, w.bnp, coef0, dG(0), dG(0) + EC1);
+    hipLaunchKernelGGL(et_bn_bwd_finish_kernel, dim3(EC1 / FF), dim3(FF * FS), 0, s, g.nwg, EC1, count, w.part, w.bnp, coef0, dG(0), dG(0) + EC1);
     hipLaunchKernelGGL(et_wgrad0_kernel, dim3(EC1, B), dim3(256), 0, s, g, w.y[0], w.dz[0], coef0, x, w.w0part);
-    hipLaunchKernelGGL(et_w0reduce_kernel, dim3(1), dim3(192), 0, s, B, w.w0part, dcanon);
+    hipLaunchKernelGGL(et_w0reduce_kernel, dim3(1), dim3(768), 0, s, B, w.w0part, dcanon);
     return (int)hipGetLastError();
 }

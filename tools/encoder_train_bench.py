@@ -22,6 +22,7 @@ def timeit(fn, iters):
 
 def main():
     B, N, iters = (int(v) for v in (sys.argv[1:4] + ["32", "2048", "30"][len(sys.argv) - 1:]))
+    hiponly = "hiponly" in sys.argv
     torch.manual_seed(0)
     enc = networks.PointNetCloudEncoder(3, 64, [128, 256, 512]).cuda().train()
     x = (torch.rand(B, 3, N, device="cuda") - 0.5) * 0.5
@@ -40,10 +41,10 @@ def main():
             torch.max(enc(x), dim=2)[0]
 
     res = {}
-    for name, hip in (("torch", False), ("hip", True)):
+    for name, hip in (("hip", True),) if hiponly else (("torch", False), ("hip", True)):
         res[name + "_fwd_ms"] = timeit(lambda: fwd(hip), iters)
         res[name + "_fwd_bwd_ms"] = timeit(lambda: step(hip), iters)
-    for prec in ("bf16x3",):
+    for prec in () if hiponly else ("bf16x3",):
         enc.train_precision = prec
         res["hip_%s_fwd_ms" % prec] = timeit(lambda: fwd(True), iters)
         res["hip_%s_fwd_bwd_ms" % prec] = timeit(lambda: step(True), iters)
