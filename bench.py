@@ -86,6 +86,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra legs of the default run (bf16x6, eager, train step)")
     ap.add_argument("--train-steps", type=int, default=12, help="timed steps of the `extra.train_step` leg")
+    ap.add_argument("--encoder", default="none", choices=["none", "hip", "tensor"],
+                    help="train leg: put the training-mode PointNet encoder (+ a linear code head) in front of the decoder, as "
+                         "models.py:130-140 does; hip = csrc/encoder_train.hip, tensor = the tensor-op path")
     args = ap.parse_args(argv)
     cfg = CONFIGS[args.config]
     if args.steps is None:
@@ -676,7 +679,16 @@ def train_step_leg(args, rank, world, dist, device, batch, layers, steps, warmup
     torch.manual_seed(0)                      # same initial weights on every rank (replicas)
     dec = nets.LocalCondRNVPDecoder(n_flows, 64, G).to(device).train()
     store = dec.flatten_parameters()
-    opt = nets.Adam(dec.parameters(), lr=2.56e-4, weight_decay=1e-6, betas=(0.9, 0.999), amsgrad=True)
+    params = list(dec.parameters())
+    enc = head = None
+    if getattr(args, "encoder", "none") != "none":
+        # models.py:130-140: cloud code = head(max over the points of pc_encoder(p_input)); the reference's head is a
+        # FeatureEncoder (tensor ops there and here) -- its mean layer stands in for it
+        enc = nets.PointNetCloudEncoder(3, 64, [128, 256, 512]).to(device).train()
+        enc.hip_training = args.encoder == "hip"
+        head = torch.nn.Linear(512, G).to(device)
+        params += list(enc.parameters()) + list(head.parameters())
+    opt = nets.Adam(params, lr=2.56e-4, weight_decay=1e-6, betas=(0.9, 0.999), amsgrad=True)
     tgt, _, g = SY.synthetic_inputs(3 + rank, batch, N, G)          # every rank its own shard of clouds
     tp, tg = torch.from_numpy(tgt).to(device), torch.from_numpy(g).to(device)
     pm, pl = torch.zeros(batch, 3, N, device=device), torch.full((batch, 3, N), -3.6, device=device)
@@ -685,13 +697,16 @@ def train_step_leg(args, rank, world, dist, device, batch, layers, steps, warmup
 
     def step(record=False):
         opt.zero_grad(set_to_none=True)
-        ps, mus, lvs = dec(tp, tg, mode="inverse")
+        code = tg if enc is None else head(torch.max(enc(tp), dim=2)[0])
+        ps, mus, lvs = dec(tp, code, mode="inverse")
         loss = nll(ps + [tp], [pm] + mus, [pl] + lvs)                # models.py:169-171, losses.py:48
         loss.backward()                                              # training.py:55
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        n = D.allreduce_flat_gradients(store)                        # the ONE collective of the step
+        n = D.allreduce_flat_gradients(store)                        # the ONE collective of the step (decoder)
+        if enc is not None and dist is not None:
+            D.allreduce_gradients(list(enc.parameters()) + list(head.parameters()))
         if record:
             e1.record()
             ev.append((e0, e1))
@@ -718,7 +733,9 @@ def train_step_leg(args, rank, world, dist, device, batch, layers, steps, warmup
     info = {"ms_per_step": elapsed / steps * 1e3, "value": batch * world * N / (elapsed / steps), "unit": "points/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "layers": layers, "clouds_per_gpu": batch, "points_per_cloud": N,
             "latent": G, "loss": float(loss), "precision": os.environ.get("DPF_TRAIN_PRECISION", "bf16x6"),
-            "what": "zero_grad + inverse stack (batch-stat BN) + PointFlowNLL + backward + all-reduce(flat_g) + Adam (AMSGrad mirror)",
+            "what": ("" if enc is None else "PointNet encoder (training mode, %s) + code head + " % args.encoder) +
+                    "zero_grad + inverse stack (batch-stat BN) + PointFlowNLL + backward + all-reduce(flat_g) + Adam (AMSGrad mirror)",
+            "encoder": getattr(args, "encoder", "none"),
             "flat_gradient_bytes": nbytes, "collectives_per_step": 1 if world > 1 else 0,
             "algorithmic_tflops": 3.0 * FLOP_PER_POINT_LAYER * layers * batch * N / (elapsed / steps) / 1e12}
     if world > 1:

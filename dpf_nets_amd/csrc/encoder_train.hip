@@ -10,21 +10,24 @@
 // In training mode every BatchNorm normalises with statistics over all B*N points, so each layer ends in a grid-wide
 // reduction and -- unlike the eval-mode kernel (encoder.hip) -- the stack cannot be one launch.  Each reduction is a
 // kernel boundary; between boundaries the pre-BatchNorm outputs y_l (fp32, (B, C_l, Np), Np = N rounded up to 32)
-// live in HBM: at cfg-2 that is 252 MB, a few percent of the part, read and written at 4-5 TB/s.
+// live in HBM: at cfg-2 that is 252 MB, a few percent of the part.  Every kernel here moves 3-4 bytes per bf16x3
+// product triple and is HBM-bound; the design removes passes over the activations rather than flops:
 //
-//  forward   et_wpack     W_l as bf16 hi/lo MFMA B-operand fragments, both orientations (forward and W^T)
-//            et_l0        y0 = W0 x (fp32 FMA), per-workgroup sum / sum of squares
-//            et_bn_finish per-workgroup partials -> mean, 1/std, folded scale/shift; running statistics
-//            et_pgemm<FWD> y_l = W_l relu(BN(y_{l-1})): the BatchNorm + ReLU + bf16 hi/lo split is the PROLOGUE on the
-//                         operand registers (the activations a_l are never stored); epilogue stores y_l and emits the
-//                         per-workgroup sum / sum of squares                                       (l = 1, 2, 3)
+//  forward   et_wpack     W_l as bf16 split MFMA B-operand fragments, both orientations (forward and W^T), one launch
+//            et_l0        y0 = W0 x (fp32 FMA) and its statistics
+//            et_bn_finish per-workgroup (sum, M2, count) -> mean, 1/std, folded scale/shift; running statistics
+//            et_pgemm<FWD> y_l = W_l relu(BN(y_{l-1})): the BatchNorm + ReLU + bf16 split is the PROLOGUE on the operand
+//                         registers (the activations a_l are never stored); the epilogue stores y_l and emits the
+//                         per-workgroup statistics                                                  (l = 1, 2, 3)
 //            et_pool      pooled[b, f] = relu(max_p BN(y3)), the argmax and y3 there
 //  backward  et_pool_bwd  the pooled gradient is a sparse d z3 (one point per (b, f)); its BatchNorm sums
 //            et_bn_bwd_finish  d gamma, d beta and the coefficients of  d y_l = c0 dz_l + c1 + c2 y_l
-//            et_packp     d y_l and a_{l-1} as bf16 hi/lo fragments with K = points (operands of the weight gradient)
-//            et_pgemm<BWD> G = W_l^T d y_l (prologue forms d y_l from dz_l and y_l); epilogue masks with the ReLU of
-//                         layer l-1, stores dz_{l-1} and emits its BatchNorm sums
-//            et_wgrad     dW_l = d y_l a_{l-1}^T, split over the points; et_wreduce adds the splits in a fixed order
+//            et_pgemm<BWD> G = W_l^T d y_l (prologue forms d y_l from dz_l and y_l, for l = 3 from y_3 and the argmax);
+//                         the epilogue masks with the ReLU of layer l-1, stores dz_{l-1}, emits its BatchNorm sums, and
+//                         writes a_{l-1} = relu(BN(y_{l-1})) as bf16 hi/lo fragments with K = points -- the layout a lane
+//                         of this epilogue already holds -- for the weight gradient
+//            et_wgrad     dW_l = d y_l a_{l-1}^T, split over the points: d y_l is formed from the fp32 rows on the way
+//                         from the global loads to LDS; et_wreduce adds the splits in a fixed order
 //            et_wgrad0    dW_0 = d y_0 x^T (fp32)
 //
 // The forward contractions -- which decide every ReLU mask and the argmax -- run at the precision the caller asks for:
@@ -290,7 +293,7 @@ struct PArgs {
     const float *yprev;     // BWD: (B, Ntot, Np) y_{l-1}
     const float *bnprev;    // BWD: bnp of layer l-1 [4][Ntot]
     float *part;            // [nwg][2][Ntot]
-    uint8_t *apk;           // BWD: a_{l-1} = relu(BN(y_{l-1})) as K = points fragments (operand of dW_l), see et_packp_kernel
+    uint8_t *apk;           // BWD: a_{l-1} = relu(BN(y_{l-1})) as K = points fragments (operand of dW_l), layout at WArgs
     int Ntot, nch;
 };
 
@@ -574,6 +577,9 @@ __global__ __launch_bounds__(256) void et_pool_bwd_kernel(int B, const float *__
 // The a operand arrives as K = points fragments (written by the per-point GEMM's epilogue).  The d y operand is formed
 // HERE from the fp32 rows: d y = c0 dz + c1 + c2 y (MODE BWD), dz = gz at the argmax point (BWD_SPARSE), on the way from
 // the global loads to LDS -- each element is transformed once per workgroup, ~100 VALU instructions per wave next to 48 MFMAs.
+// K = points fragment stream: [feature tile C/32][k-step P/16][part hi, lo][lane 64][8 bf16]; lane (row, kg) holds, for
+// feature 32 ft + row, the points 16 s + 8 (i >> 2) + 4 kg + (i & 3), i = 0..7 (any order of a k-step's 16 points works
+// as long as both operands use it; this is the order a lane of the per-point GEMM's epilogue holds).  Padded points are 0.
 struct WArgs {
     Geo g;
     const float *y, *dz, *coef;     // (B, M, Np) rows of layer l; coef [3][M]

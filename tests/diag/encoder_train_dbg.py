@@ -1,6 +1,8 @@
+"""Per-parameter gradient error of the training-mode encoder (csrc/encoder_train.hip) and of the fp32 tensor-op path against
+float64 tensor ops: python tests/diag/encoder_train_dbg.py B N"""
 import copy, sys
 import torch
-sys.path.insert(0, __file__.rsplit("/", 2)[0])
+sys.path.insert(0, __file__.rsplit("/", 3)[0])
 from dpf_nets_amd import networks as nets
 from oracle import encoder_oracle as EO, flow_oracle as FO, detrng
 

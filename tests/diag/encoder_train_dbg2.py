@@ -1,7 +1,7 @@
 """Intermediates of the training-mode encoder kernels (y_l, dz_l in the workspace) against float64 autograd."""
 import copy, ctypes, sys
 import torch
-sys.path.insert(0, __file__.rsplit("/", 2)[0])
+sys.path.insert(0, __file__.rsplit("/", 3)[0])
 from dpf_nets_amd import networks as nets
 from dpf_nets_amd._lib import lib, check, current_stream
 from oracle import encoder_oracle as EO, flow_oracle as FO, detrng
