@@ -502,17 +502,28 @@ __device__ __forceinline__ void layer_pipe(const uint8_t *lb, int lane, int h, u
                 if (NS > 1) bfrag[br][NS - 1][ks][d] = f2u(acc0[br][t][r + 1]);
                 continue;
             }
-            const float v0 = relu(acc0[br][t][r]), v1 = relu(acc0[br][t][r + 1]);
             if (F16) {
                 // hi = the pair truncated to fp16 (one v_cvt_pkrtz_f16_f32); lo = fp16(v - hi) formed and packed by
-                // v_fma_mixlo_f16 / v_fma_mixhi_f16, which read hi's halves as fp16 operands: 5 VALU per pair instead of 8.
-                // `negone` is -1.0 in an SGPR the compiler cannot see through (a literal -1 turns the fma into a
-                // subtraction of an extended half, which does not select the mix instructions).
-                const fp16x2 hi = __builtin_amdgcn_cvt_pkrtz(v0, v1);
-                const f16x2 lo = {(_Float16)__builtin_fmaf((float)hi[0], negone, v0), (_Float16)__builtin_fmaf((float)hi[1], negone, v1)};
+                // v_fma_mixlo_f16 / v_fma_mixhi_f16, which read hi's halves as fp16 operands.  `negone` is -1.0 in an SGPR
+                // the compiler cannot see through (a literal -1 turns the fma into a subtraction of an extended half,
+                // which does not select the mix instructions).
+                // The ReLU is folded in: the RAW pair is truncated (toward zero), so for x < 0 the remainder x - hi is
+                // <= 0 and the mix instructions' clamp modifier ([0, 1]) makes it 0, for x >= 0 it is in [0, ulp(hi)) --
+                // below 1 for |x| < 1024 -- and untouched; one v_pk_max_f16 then zeroes the negative hi halves:
+                // 4 VALU per pair instead of 5 + 2 v_max.
+                const float x0 = acc0[br][t][r], x1 = acc0[br][t][r + 1];
+                const fp16x2 hr = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+                const f16x2 lo_raw = {(_Float16)__builtin_fmaf((float)hr[0], negone, x0), (_Float16)__builtin_fmaf((float)hr[1], negone, x1)};
+                const f16x2 one2 = {(_Float16)1.f, (_Float16)1.f}, zz2 = {(_Float16)0.f, (_Float16)0.f};
+                const uint32_t lo = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_elementwise_max(lo_raw, zz2), one2));
+                const f16x2 zero2 = {(_Float16)0.f, (_Float16)0.f};
+                const f16x2 hi = __builtin_elementwise_max(__builtin_bit_cast(f16x2, hr), zero2);
                 bfrag[br][0][ks][d] = __builtin_bit_cast(uint32_t, hi);
-                bfrag[br][1][ks][d] = __builtin_bit_cast(uint32_t, lo);
-            } else if (NS == 1) {
+                bfrag[br][1][ks][d] = lo;
+                continue;
+            }
+            const float v0 = relu(acc0[br][t][r]), v1 = relu(acc0[br][t][r + 1]);
+            if (NS == 1) {
                 bfrag[br][0][ks][d] = pack_bf16_rne(v0, v1);
             } else {
                 float l0, l1;
@@ -745,6 +756,10 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
 
     float negone = -1.0f;                      // opaque to the compiler: see layer_pipe's fp16 split
     asm volatile("" : "+s"(negone));
+    float zero_lv = 0.0f;                      // a kept channel's logvar, opaque so that its factor is computed, not folded
+    asm volatile("" : "+s"(zero_lv));
+    const float v_keep = a.eps + __expf(zero_lv);
+    const float k_keep = inverse ? __builtin_amdgcn_rsqf(v_keep) : __builtin_amdgcn_sqrtf(v_keep);
     const int lfirst = inverse ? L - 1 : 0;
     auto stage_group = [&](int g) {                      // the LPB layers of steps g*LPB .. into buffer g & 1
 #pragma unroll
@@ -817,20 +832,30 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
         for (int br = 0; br < 2; ++br)
 #pragma unroll
             for (int e = 0; e < 2; ++e) o[br][e] = PIPE ? half_sum(o[br][e]) : half_sum(o[br][e]) + b2[br * 2 + e];   // layer_pipe starts its sums at b2 / 2
-        // ---- coupling transform (flows.py:96-115); branch 0 = logvar, 1 = mu
-        const float lva = (DPF_ABLATE & 64) ? o[0][0] : o[0][0] * __builtin_amdgcn_rcpf(1.0f + fabsf(o[0][0]));   // softsign, :99
-        const float lvb = (DPF_ABLATE & 64) ? o[0][1] : o[0][1] * __builtin_amdgcn_rcpf(1.0f + fabsf(o[0][1]));
+        // ---- coupling transform (flows.py:96-115); branch 0 = logvar, 1 = mu.  Only the warped channels (one or two,
+        // wave-uniform) go through softsign / exp / sqrt; a kept channel has logvar 0, so its factor is the constant
+        // sqrt(eps + exp(0)) (direct) or its reciprocal square root (inverse), formed once with the same instructions.
+        float lva, lvb = 0.f, fa, fb = k_keep;
+        if (DPF_ABLATE & 64) { lva = o[0][0]; lvb = o[0][1]; fa = a.eps + lva; fb = a.eps + lvb; }
+        else {
+            lva = o[0][0] * __builtin_amdgcn_rcpf(1.0f + fabsf(o[0][0]));   // softsign, :99
+            const float va = a.eps + __expf(lva);
+            fa = inverse ? __builtin_amdgcn_rsqf(va) : __builtin_amdgcn_sqrtf(va);
+            if (wb >= 0) {
+                lvb = o[0][1] * __builtin_amdgcn_rcpf(1.0f + fabsf(o[0][1]));
+                const float vb = a.eps + __expf(lvb);
+                fb = inverse ? __builtin_amdgcn_rsqf(vb) : __builtin_amdgcn_sqrtf(vb);
+            }
+        }
         float lv[3], mu[3], pn[3];
         const float pin[3] = {p0, p1, p2};
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             lv[c] = c == wa ? lva : (c == wb ? lvb : 0.f);
             mu[c] = c == wa ? o[1][0] : (c == wb ? o[1][1] : 0.f);
-            const float var = a.eps + ((DPF_ABLATE & 64) ? lv[c] : __expf(lv[c]));
+            const float f = c == wa ? fa : (c == wb ? fb : k_keep);
             // keep channels are scaled by sqrt(1 + eps) too, as in the reference (:113/:115)
-            if (DPF_ABLATE & 64) pn[c] = var * pin[c] + mu[c];
-            else
-            pn[c] = inverse ? (pin[c] - mu[c]) * __builtin_amdgcn_rsqf(var) : __builtin_amdgcn_sqrtf(var) * pin[c] + mu[c];
+            pn[c] = inverse ? (pin[c] - mu[c]) * f : f * pin[c] + mu[c];
         }
         p0 = pn[0]; p1 = pn[1]; p2 = pn[2];
         s0 += lv[0]; s1 += lv[1]; s2 += lv[2];
