@@ -1013,6 +1013,9 @@ static int flow_forward_impl(int n_layers, int B, int N, int mode, int precision
     a.L = n_layers; a.B = B; a.N = N; a.mode = mode; a.eps = flow_eps;
     a.base_mu = base_mu; a.base_lv = base_lv; a.z_out = z_out;
     a.mu_sb = a.mu_sc = a.mu_sn = a.lv_sb = a.lv_sc = a.lv_sn = 0;
+#ifdef DPF_PROFILE
+    a.prof = g_prof;
+#endif
     if (base_mu != nullptr) {
         a.mu_sb = mu_strides[0]; a.mu_sc = mu_strides[1]; a.mu_sn = mu_strides[2];
         a.lv_sb = lv_strides[0]; a.lv_sc = lv_strides[1]; a.lv_sn = lv_strides[2];

@@ -51,6 +51,13 @@ def main():
         gd = np.diff(t[:, :, order], axis=2)
         print("   cycles per group G1..G8 (median over waves/layers):", np.median(gd[:, 1:, :], axis=(0, 1)).tolist())
         print("   wave0 layer 2 groups:", gd[0, 2].tolist())
+        # leaders (waves 0-3) and laggards (4-7) separately, with the gap from the end of a layer to the start of the next
+        gap = t[:, 1:, 0] - t[:, :-1, 7]
+        for nm, ws in (("leaders ", [0, 1, 2, 3]), ("laggards", [4, 5, 6, 7])):
+            if max(ws) >= t.shape[0]:
+                continue
+            print("   %s: phases %s | gap to next layer %5.0f | period %5.0f" % (
+                nm, [int(np.median(d[ws, 2:-1, i])) for i in range(7)], np.median(gap[ws, 1:]), np.median(period[ws, 1:])))
         odd = d[:, 1::2, :]                          # layers that end a buffer group (LPB = 2)
         print("   per wave (WG0 w0-7, WG1 w0-7), layers ending a group: own-DMA wait | barrier wait | start skew vs wave 0")
         for w in range(t.shape[0]):
