@@ -62,7 +62,7 @@ SIGNATURES = {
     "dpf_encoder_forward": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dpf_encoder_train_workspace_bytes": (_sz, [_i, _i]),
     "dpf_encoder_train_forward": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp]),
-    "dpf_encoder_train_backward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dpf_encoder_train_backward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dpf_gprior_canon_floats": (_sz, [_i, _i]),
     "dpf_gprior_packed_floats": (_sz, [_i, _i, _i]),
     "dpf_gprior_pack": (_i, [_i, _i, _i, _f, _vp, _vp, _vp]),

@@ -35,7 +35,7 @@
 // the forward error of zero takes the other subgradient than the reference's, and at 1e-5 that happens to ~1e-5 of
 // all ReLUs) or bf16x3.  The gradient contractions use hi/lo splits (hi*hi + hi*lo + lo*hi), fp32 accumulation.
 // Every sum is taken in a fixed order (no floating-point atomics): the result is deterministic.
-// d(input) is not produced (the clouds are data); the host side keeps the tensor-op path for a differentiable input.
+// d(input) is produced on request (et_dx; the clouds are normally data and it is skipped).
 #include "flow_common.h"
 #include "encoder_layout.h"
 
@@ -778,6 +778,26 @@ __global__ __launch_bounds__(768) void et_w0reduce_kernel(int B, const float *__
     if (sl == 0) out[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
 }
 
+// d x[b][k][p] = sum_f W0[f][k] d y0[f][p] (only when the caller asks for the input gradient)
+__global__ __launch_bounds__(256) void et_dx_kernel(Geo g, const float *__restrict__ y0, const float *__restrict__ dz0,
+                                                     const float *__restrict__ coef, const float *__restrict__ W0, float *__restrict__ dx) {
+    __shared__ float w[EC1 * EC0], c[3 * EC1];
+    if (threadIdx.x < EC1 * EC0) w[threadIdx.x] = W0[threadIdx.x];
+    if (threadIdx.x < 3 * EC1) c[threadIdx.x] = coef[threadIdx.x];
+    __syncthreads();
+    const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= g.N) return;
+    const float *yr = y0 + (size_t)b * EC1 * g.Np + p, *dr = dz0 + (size_t)b * EC1 * g.Np + p;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll 8
+    for (int f = 0; f < EC1; ++f) {
+        const float dy = fmaf(c[f], dr[(size_t)f * g.Np], fmaf(c[2 * EC1 + f], yr[(size_t)f * g.Np], c[EC1 + f]));
+        a0 = fmaf(w[3 * f], dy, a0); a1 = fmaf(w[3 * f + 1], dy, a1); a2 = fmaf(w[3 * f + 2], dy, a2);
+    }
+    float *o = dx + (size_t)b * 3 * g.N + p;
+    o[0] = a0; o[g.N] = a1; o[2 * (size_t)g.N] = a2;
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------
 Geo make_geo(int B, int N) {
     Geo g;
@@ -898,7 +918,7 @@ extern "C" int dpf_encoder_train_forward(int B, int N, int precision, const floa
 }
 
 extern "C" int dpf_encoder_train_backward(int B, int N, const float *canon, const float *x, void *ws, const float *pooled,
-                                          const float *g_pooled, float *dcanon, dpf_stream_t stream) {
+                                          const float *g_pooled, float *dcanon, float *dx, dpf_stream_t stream) {
     if (B <= 0 || N <= 0) return DPF_EINVAL;
     if (!canon || !x || !ws || !pooled || !g_pooled || !dcanon) return DPF_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -937,5 +957,7 @@ extern "C" int dpf_encoder_train_backward(int B, int N, const float *canon, cons
     hipLaunchKernelGGL(et_bn_bwd_finish_kernel, dim3(EC1 / FF), dim3(FF * FS), 0, s, g.nwg, EC1, count, w.part, w.bnp, coef0, dG(0), dG(0) + EC1);
     hipLaunchKernelGGL(et_wgrad0_kernel, dim3(EC1, B), dim3(256), 0, s, g, w.y[0], w.dz[0], coef0, x, w.w0part);
     hipLaunchKernelGGL(et_w0reduce_kernel, dim3(1), dim3(768), 0, s, B, w.w0part, dcanon);
+    if (dx != nullptr)
+        hipLaunchKernelGGL(et_dx_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, g, w.y[0], w.dz[0], coef0, cW(canon, 0), dx);
     return (int)hipGetLastError();
 }

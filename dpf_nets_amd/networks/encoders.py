@@ -7,11 +7,12 @@ forward(input (B,3,N)) -> per-point features (B,512,N):
     (models.py:85,131,175) and use nothing else, so forward returns a `PointFeatures`: that max is answered from
     the kernel's own (B,512) result and the (B,512,N) tensor (134 MB at B=32, N=2048) is only produced -- by the
     same kernel with its feature output switched on -- if something else is asked of it;
-  * training mode on CUDA tensors, same architecture, input not differentiable: forward returns a
+  * training mode on CUDA tensors, same architecture: forward returns a
     `TrainPointFeatures`; its max over the points runs csrc/encoder_train.hip (batch-statistics BatchNorm, running
     statistics updated in place, argmax kept) and is an autograd node whose backward is the HIP backward pass to
-    the twelve parameter gradients.  Any other use of the features materialises them with tensor ops;
-  * a differentiable input, other widths, BatchNorm without running statistics or with momentum=None: the
+    the twelve parameter gradients (and to the input when it requires grad).  Any other use of the features
+    materialises them with tensor ops;
+  * eval mode with a differentiable input, other widths, BatchNorm without running statistics or with momentum=None: the
     tensor-op path (`self.features(input)`), on PyTorch-ROCm;
   * eval mode on CPU tensors raises (no CPU fallback).
 """
@@ -164,9 +165,11 @@ class _TrainPool(torch.autograd.Function):
         canon, x, ws, B, N = ctx.enc_state
         pooled, = ctx.saved_tensors
         dcanon = torch.empty_like(canon)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[1] else None
         with torch.cuda.device(x.device):
             check(lib().dpf_encoder_train_backward(B, N, canon.data_ptr(), x.data_ptr(), ws.data_ptr(), pooled.data_ptr(),
-                                                   g.contiguous().to(torch.float32).data_ptr(), dcanon.data_ptr(), current_stream()),
+                                                   g.contiguous().to(torch.float32).data_ptr(), dcanon.data_ptr(),
+                                                   dx.data_ptr() if dx is not None else None, current_stream()),
                   "encoder_train_backward")
         ctx.enc_state = None
         grads, off = [], 0
@@ -177,7 +180,7 @@ class _TrainPool(torch.autograd.Function):
                 off += n
             off += 2 * cout
             cin = cout
-        return (None, None) + tuple(grads)
+        return (None, dx) + tuple(grads)
 
 
 _LAYERS = ("init_sd", "sd0", "sd1", "sd2")
@@ -283,8 +286,8 @@ class PointNetCloudEncoder(nn.Module):
             and len({bn.momentum for bn in bns}) == 1 and all(getattr(self.features, n).weight.dtype == torch.float32 for n in _LAYERS)
 
     def forward(self, input):
-        # a differentiable input or other widths: tensor ops
-        if not self.hip_supported() or (torch.is_grad_enabled() and input.requires_grad):
+        # other widths, or a differentiable input in eval mode: tensor ops
+        if not self.hip_supported() or (torch.is_grad_enabled() and input.requires_grad and not self.training):
             return self.forward_torch(input)
         if self.training:
             if not self.hip_training_supported(input):

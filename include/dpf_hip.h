@@ -350,12 +350,12 @@ int dpf_encoder_forward(int B, int N, int precision, const void *packed, const f
  *   running_var_0, ... updated in place as torch.nn.BatchNorm1d does with `momentum` (unbiased variance).
  *   B * N must be >= 2.
  * backward: g_pooled (B,512) = d loss / d pooled, pooled = the forward's output -> dcanon (canon layout: dW,
- *   d gamma, d beta per layer; the running-statistics slots are left untouched).  d(input) is not produced. */
+ *   d gamma, d beta per layer; the running-statistics slots are left untouched); dx (optional, (B,3,N)) = d loss / d x. */
 size_t dpf_encoder_train_workspace_bytes(int B, int N);
 int dpf_encoder_train_forward(int B, int N, int precision, const float *canon, const float *x, void *ws, float *pooled,
                               float *batch_stats, float *const *running, float momentum, dpf_stream_t stream);
 int dpf_encoder_train_backward(int B, int N, const float *canon, const float *x, void *ws, const float *pooled,
-                               const float *g_pooled, float *dcanon, dpf_stream_t stream);
+                               const float *g_pooled, float *dcanon, float *dx, dpf_stream_t stream);
 
 /* ---- latent prior flow: GlobalRNVPDecoder on (B, G) codes, eval-mode BatchNorm ---------------
  * replaces GlobalRNVPDecoder.forward (lib/networks/decoders.py:21-38): n_steps = 2 * n_flows

@@ -51,6 +51,7 @@ def _encoder(nets, seed):
 def _step(enc, x, r):
     for p in enc.parameters():
         p.grad = None
+    x.grad = None
     feats = enc(x)
     pooled = torch.max(feats, dim=2)[0]
     (pooled * r).sum().backward()
@@ -63,12 +64,13 @@ def test_encoder_train_vs_reference_golden(golden_dir):
     meta = json.load(open(os.path.join(golden_dir, "encoder.json")))
     for case, (seed, B, N) in meta["cases"].items():
         enc = _encoder(nets, seed)
-        x = torch.from_numpy(EO.encoder_inputs(seed, B, N)).cuda()
+        x = torch.from_numpy(EO.encoder_inputs(seed, B, N)).cuda().requires_grad_(True)     # the golden run took d/dx too
         r = torch.from_numpy(detrng.normal_f32(detrng.key(seed, "enc_r"), (B, 512))).cuda()
         feats, pooled = _step(enc, x, r)
         assert isinstance(feats, nets.TrainPointFeatures) and feats._full is None      # no (B,512,N) tensor was formed
         tag = case + "_train"
         assert rel(pooled, gold[tag + "_max"]) <= TOL_OUT, (case, rel(pooled, gold[tag + "_max"]))
+        assert rel(x.grad, gold[tag + "_dx"]) <= TOL_GRAD, (case, rel(x.grad, gold[tag + "_dx"]))
         for k, v in _grad_projection([(k, p.grad.cpu()) for k, p in enc.named_parameters()], seed).items():
             ref = gold[tag + "_gproj_" + k]
             for i in range(3):
@@ -80,19 +82,21 @@ def test_encoder_train_vs_reference_golden(golden_dir):
                 assert int(v) == 1
 
 
-@pytest.mark.parametrize("B,N", [(1, 2), (2, 31), (3, 33), (2, 255), (1, 257), (5, 700), (4, 2048)])
+@pytest.mark.parametrize("B,N", [(2, 5), (2, 31), (3, 33), (2, 255), (1, 257), (5, 700), (4, 2048)])
 def test_encoder_train_vs_float64_tensor_ops(B, N):
     nets = _gpu()
     enc = _encoder(nets, 300 + N)
     ref = copy.deepcopy(enc).double()
     ref.hip_training = False
-    x = torch.from_numpy(EO.encoder_inputs(400 + N, B, N)).cuda()
+    x = torch.from_numpy(EO.encoder_inputs(400 + N, B, N)).cuda().requires_grad_(True)
     r = torch.from_numpy(detrng.normal_f32(detrng.key(N, "r"), (B, 512))).cuda()
     feats, pooled = _step(enc, x, r)
     assert isinstance(feats, nets.TrainPointFeatures)
-    rfeats, rpooled = _step(ref, x.double(), r.double())
+    x64 = x.detach().double().requires_grad_(True)
+    rfeats, rpooled = _step(ref, x64, r.double())
     assert torch.is_tensor(rfeats)
     assert rel(pooled, rpooled) <= TOL_OUT, rel(pooled, rpooled)
+    assert rel(x.grad, x64.grad) <= TOL_GRAD, rel(x.grad, x64.grad)
     for (k, p), (_, q) in zip(enc.named_parameters(), ref.named_parameters()):
         assert p.grad is not None and p.grad.shape == p.shape
         assert rel(p.grad, q.grad) <= TOL_GRAD, (k, rel(p.grad, q.grad))
@@ -143,8 +147,8 @@ def test_encoder_train_deterministic_and_semantics():
         e1 = torch.max(enc(x), dim=2)[0]
         e2 = torch.max(enc.forward_torch(x), dim=2)[0]
     assert rel(e1, e2) <= TOL_OUT
+    assert torch.is_tensor(enc(x.clone().requires_grad_(True)))      # eval mode, differentiable input: tensor ops
     enc.train()
-    assert torch.is_tensor(enc(x.clone().requires_grad_(True)))
     enc.hip_training = False
     assert torch.is_tensor(enc(x))
 
