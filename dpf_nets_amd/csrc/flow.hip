@@ -502,24 +502,11 @@ __device__ __forceinline__ void layer_pipe(const uint8_t *lb, int lane, int h, u
                 if (NS > 1) bfrag[br][NS - 1][ks][d] = f2u(acc0[br][t][r + 1]);
                 continue;
             }
-            if (F16) {
-                // hi = the pair truncated to fp16 (one v_cvt_pkrtz_f16_f32); lo = fp16(v - hi) formed and packed by
-                // v_fma_mixlo_f16 / v_fma_mixhi_f16, which read hi's halves as fp16 operands.  `negone` is -1.0 in an SGPR
-                // the compiler cannot see through (a literal -1 turns the fma into a subtraction of an extended half,
-                // which does not select the mix instructions).
-                // The ReLU is folded in: the RAW pair is truncated (toward zero), so for x < 0 the remainder x - hi is
-                // <= 0 and the mix instructions' clamp modifier ([0, 1]) makes it 0, for x >= 0 it is in [0, ulp(hi)) --
-                // below 1 for |x| < 1024 -- and untouched; one v_pk_max_f16 then zeroes the negative hi halves:
-                // 4 VALU per pair instead of 5 + 2 v_max.
-                const float x0 = acc0[br][t][r], x1 = acc0[br][t][r + 1];
-                const fp16x2 hr = __builtin_amdgcn_cvt_pkrtz(x0, x1);
-                const f16x2 lo_raw = {(_Float16)__builtin_fmaf((float)hr[0], negone, x0), (_Float16)__builtin_fmaf((float)hr[1], negone, x1)};
-                const f16x2 one2 = {(_Float16)1.f, (_Float16)1.f}, zz2 = {(_Float16)0.f, (_Float16)0.f};
-                const uint32_t lo = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_elementwise_max(lo_raw, zz2), one2));
-                const f16x2 zero2 = {(_Float16)0.f, (_Float16)0.f};
-                const f16x2 hi = __builtin_elementwise_max(__builtin_bit_cast(f16x2, hr), zero2);
-                bfrag[br][0][ks][d] = __builtin_bit_cast(uint32_t, hi);
-                bfrag[br][1][ks][d] = lo;
+            if (F16) {                     // fp16 hi/lo with the ReLU folded in: flow_common.h
+                uint32_t hi_, lo_;
+                split_relu_f16(acc0[br][t][r], acc0[br][t][r + 1], negone, hi_, lo_);
+                bfrag[br][0][ks][d] = hi_;
+                bfrag[br][1][ks][d] = lo_;
                 continue;
             }
             const float v0 = relu(acc0[br][t][r]), v1 = relu(acc0[br][t][r + 1]);

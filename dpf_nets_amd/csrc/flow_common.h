@@ -66,6 +66,21 @@ typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
+// fp16 hi/lo split of a pair with the ReLU folded in (operands of the f16x3 contraction; csrc/flow.hip layer_pipe and
+// the training kernels' recomputation use this one function, so their fragments are bit-identical):
+//   hi = relu(x) truncated to fp16 -- the RAW pair is truncated toward zero (one v_cvt_pkrtz_f16_f32) and one
+//        v_pk_max_f16 zeroes the negative halves;
+//   lo = fp16(x - hi): for x < 0 the remainder is <= 0 and the clamp modifier ([0, 1]) of v_fma_mixlo/hi_f16 makes it 0,
+//        for x >= 0 it lies in [0, ulp(hi)) -- below 1 for |x| < 1024 -- and passes.
+// `negone` must be -1.0 in an SGPR the compiler cannot see through (a literal -1 turns the fma into a subtraction of an
+// extended half, which does not select the mix instructions).  4 VALU per pair.
+__device__ __forceinline__ void split_relu_f16(float x0, float x1, float negone, uint32_t &hi, uint32_t &lo) {
+    const fp16x2 hr = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+    const f16x2 lo_raw = {(_Float16)__builtin_fmaf((float)hr[0], negone, x0), (_Float16)__builtin_fmaf((float)hr[1], negone, x1)};
+    const f16x2 one2 = {(_Float16)1.f, (_Float16)1.f}, zero2 = {(_Float16)0.f, (_Float16)0.f};
+    lo = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_elementwise_max(lo_raw, zero2), one2));
+    hi = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(f16x2, hr), zero2));
+}
 __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
