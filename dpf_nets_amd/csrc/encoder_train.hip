@@ -805,7 +805,13 @@ Geo make_geo(int B, int N) {
     g.nwg = (g.ptiles + PW - 1) / PW; g.P = (long)B * g.Np;
     return g;
 }
-constexpr int KS_CHUNK = 32;                 // point k-steps (512 points) per weight-gradient workgroup
+// point k-steps per weight-gradient workgroup: 32 (512 points) up to 131 072 points, then as many as keep the number of
+// split-K partial blocks (nchunk x 512 KB for dW_3) at 256
+inline int ks_chunk_of(long PS) {
+    long k = (PS + 255) / 256;
+    k = (k + 1) & ~1L;
+    return (int)(k < 32 ? 32 : k);
+}
 
 struct TWork {
     float *y[4], *dz[3];
@@ -832,7 +838,7 @@ size_t t_carve(void *ws, const Geo &g, TWork *w) {
     p = take((size_t)g.B * EC4 * 4); if (w) w->yarg = (float *)p;
     p = take((size_t)g.B * EC4 * 4); if (w) w->gz = (float *)p;
     p = take((size_t)g.B * EC4 * 4); if (w) w->arg = (int *)p;
-    const long nchunk = (g.P / 16 + KS_CHUNK - 1) / KS_CHUNK;
+    const long nchunk = (g.P / 16 + ks_chunk_of(g.P / 16) - 1) / ks_chunk_of(g.P / 16);
     p = take((size_t)nchunk * EC4 * EC3 * 4); if (w) w->wpart = (float *)p;
     p = take((size_t)g.B * EC1 * 3 * 4); if (w) w->w0part = (float *)p;
     return off;
@@ -928,6 +934,7 @@ extern "C" int dpf_encoder_train_backward(int B, int N, const float *canon, cons
     const double count = (double)B * N;
     const int C[4] = {EC1, EC2, EC3, EC4};
     const long PS = g.P / 16;
+    const int KS_CHUNK = ks_chunk_of(PS);
     const int nchunk = (int)((PS + KS_CHUNK - 1) / KS_CHUNK);
     auto dG = [&](int l) { return dcanon + e_layer_off(l) + e_cout(l) * e_cin(l); };
 

@@ -82,7 +82,7 @@ def test_encoder_train_vs_reference_golden(golden_dir):
                 assert int(v) == 1
 
 
-@pytest.mark.parametrize("B,N", [(2, 5), (2, 31), (3, 33), (2, 255), (1, 257), (5, 700), (4, 2048)])
+@pytest.mark.parametrize("B,N", [(2, 5), (2, 31), (3, 33), (2, 255), (1, 257), (5, 700), (4, 2048), (8, 20011)])
 def test_encoder_train_vs_float64_tensor_ops(B, N):
     nets = _gpu()
     enc = _encoder(nets, 300 + N)
