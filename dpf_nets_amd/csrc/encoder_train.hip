@@ -19,7 +19,8 @@
 //            et_pgemm<FWD> y_l = W_l relu(BN(y_{l-1})): the BatchNorm + ReLU + bf16 split is the PROLOGUE on the operand
 //                         registers (the activations a_l are never stored); the epilogue stores y_l and emits the
 //                         per-workgroup statistics                                                  (l = 1, 2, 3)
-//            et_pool      pooled[b, f] = relu(max_p BN(y3)), the argmax and y3 there
+//            et_pool      pooled[b, f] = relu(max_p BN(y3)), the argmax and y3 there -- from the per-tile extremes the layer-3
+//                         epilogue leaves (no pass over y3)
 //  backward  et_pool_bwd  the pooled gradient is a sparse d z3 (one point per (b, f)); its BatchNorm sums
 //            et_bn_bwd_finish  d gamma, d beta and the coefficients of  d y_l = c0 dz_l + c1 + c2 y_l
 //            et_pgemm<BWD> G = W_l^T d y_l (prologue forms d y_l from dz_l and y_l, for l = 3 from y_3 and the argmax);
@@ -294,10 +295,11 @@ struct PArgs {
     const float *bnprev;    // BWD: bnp of layer l-1 [4][Ntot]
     float *part;            // [nwg][2][Ntot]
     uint8_t *apk;           // BWD: a_{l-1} = relu(BN(y_{l-1})) as K = points fragments (operand of dW_l), layout at WArgs
+    float *tmax, *tmin;     // FWD, last layer: [ptile][Ntot] largest / smallest y of every tile's valid points (for et_pool)
     int Ntot, nch;
 };
 
-template <int KS, int NT, int MODE, int NS>
+template <int KS, int NT, int MODE, int NS, bool POOL = false>
 __global__ __launch_bounds__(PW * 64, 4) void et_pgemm_kernel(PArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     typedef Terms<NS> TT;
@@ -458,6 +460,21 @@ __global__ __launch_bounds__(PW * 64, 4) void et_pgemm_kernel(PArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (tile_ok) *(f32x4 *)(a.out + o + 8 * q) = f32x4{acc[nt][4 * q], acc[nt][4 * q + 1], acc[nt][4 * q + 2], acc[nt][4 * q + 3]};
+            if (POOL) {             // extremes of the tile's valid points: et_pool picks the winning tile per (cloud, feature) from them
+                float mx = -__builtin_inff(), mn = __builtin_inff();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool valid = nw == TILE || (r & 3) + 8 * (r >> 2) + 4 * h < nw;
+                    mx = valid ? fmaxf(mx, acc[nt][r]) : mx;
+                    mn = valid ? fminf(mn, acc[nt][r]) : mn;
+                }
+                const auto rx = __builtin_amdgcn_permlane32_swap(f2u(mx), f2u(mx), false, false);
+                const auto rn = __builtin_amdgcn_permlane32_swap(f2u(mn), f2u(mn), false, false);
+                if (tile_ok && !h) {
+                    a.tmax[(size_t)ptile * a.Ntot + f] = fmaxf(u2f(rx[0]), u2f(rx[1]));
+                    a.tmin[(size_t)ptile * a.Ntot + f] = fminf(u2f(rn[0]), u2f(rn[1]));
+                }
+            }
         } else {
             const float sc = a.bnprev[f], sh = a.bnprev[a.Ntot + f], mean = a.bnprev[2 * a.Ntot + f], rstd = a.bnprev[3 * a.Ntot + f];
             f32x4 y[4];
@@ -520,34 +537,42 @@ __global__ __launch_bounds__(PW * 64, 4) void et_pgemm_kernel(PArgs a) {
 }
 
 // ---- max over the points -------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void et_pool_kernel(Geo g, const float *__restrict__ y3, const float *__restrict__ bnp,
-                                                       float *__restrict__ pooled, int *__restrict__ arg, float *__restrict__ yarg) {
-    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+// pooled[b, f] = relu(max_p BN(y3)[b, f, p]).  BN is monotone in y (increasing for scale >= 0, decreasing otherwise), so
+// the winner is the point with the largest (smallest) y: the layer-3 GEMM's epilogue left every tile's extremes, a thread
+// per (cloud, feature) finds the first winning tile and then the first winning point inside it -- 64 + 32 values read
+// instead of the cloud's whole row of y3.
+__global__ __launch_bounds__(64) void et_pool_kernel(Geo g, const float *__restrict__ y3, const float *__restrict__ tmax,
+                                                      const float *__restrict__ tmin, const float *__restrict__ bnp,
+                                                      float *__restrict__ pooled, int *__restrict__ arg, float *__restrict__ yarg) {
+    const int row = blockIdx.x * 64 + threadIdx.x;
     if (row >= g.B * EC4) return;
-    const int f = row % EC4;
+    const int b = row / EC4, f = row % EC4;
     const float sc = bnp[f], sh = bnp[EC4 + f];
-    const float *yr = y3 + (size_t)row * g.Np;
-    float best = -__builtin_inff(), by = 0.f;
-    int bi = 0x7fffffff;
-    for (int p = lane * 4; p < g.N; p += 256) {
-        const f32x4 y = *(const f32x4 *)(yr + p);
+    const bool up = sc >= 0.f;
+    const float *ext = (up ? tmax : tmin) + (size_t)b * g.tpc * EC4 + f;
+    float best = up ? -__builtin_inff() : __builtin_inff();
+    int bt = 0;
+    for (int t0 = 0; t0 < g.tpc; t0 += 16) {                 // sixteen independent loads in flight, then the compares in tile order
+        float v[16];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float z = fmaf(y[e], sc, sh);
-            if (p + e < g.N && z > best) { best = z; by = y[e]; bi = p + e; }
-        }
-    }
+        for (int q = 0; q < 16; ++q) v[q] = t0 + q < g.tpc ? ext[(size_t)(t0 + q) * EC4] : best;
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        const float ob = __shfl_xor(best, o, 64), oy = __shfl_xor(by, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (ob > best || (ob == best && oi < bi)) { best = ob; by = oy; bi = oi; }
+        for (int q = 0; q < 16; ++q)
+            if (up ? v[q] > best : v[q] < best) { best = v[q]; bt = t0 + q; }
     }
-    if (lane == 0) {
-        pooled[row] = fmaxf(best, 0.f);
-        arg[row] = bi;
-        yarg[row] = by;
-    }
+    const float *yr = y3 + (size_t)row * g.Np + bt * TILE;
+    f32x4 r[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) r[q] = *(const f32x4 *)(yr + 4 * q);
+    int bi = -1;
+#pragma unroll
+    for (int q = 7; q >= 0; --q)
+#pragma unroll
+        for (int e = 3; e >= 0; --e)
+            if (r[q][e] == best && bt * TILE + 4 * q + e < g.N) bi = bt * TILE + 4 * q + e;      // descending: the first one wins
+    pooled[row] = fmaxf(fmaf(best, sc, sh), 0.f);
+    arg[row] = bi;
+    yarg[row] = best;
 }
 
 // the pooled gradient as the sparse dz3: gz[b, f] = g[b, f] [pooled > 0] at point arg[b, f]; its BatchNorm sums
@@ -816,7 +841,7 @@ inline int ks_chunk_of(long PS) {
 struct TWork {
     float *y[4], *dz[3];
     uint8_t *aP[3], *wf[3], *wb[3];
-    float *part, *cnt, *bnp, *coef, *yarg, *gz, *wpart, *w0part;
+    float *part, *cnt, *bnp, *coef, *yarg, *gz, *wpart, *w0part, *tmax, *tmin;
     int *arg;
 };
 size_t t_carve(void *ws, const Geo &g, TWork *w) {
@@ -841,29 +866,32 @@ size_t t_carve(void *ws, const Geo &g, TWork *w) {
     const long nchunk = (g.P / 16 + ks_chunk_of(g.P / 16) - 1) / ks_chunk_of(g.P / 16);
     p = take((size_t)nchunk * EC4 * EC3 * 4); if (w) w->wpart = (float *)p;
     p = take((size_t)g.B * EC1 * 3 * 4); if (w) w->w0part = (float *)p;
+    p = take((size_t)g.ptiles * EC4 * 4); if (w) w->tmax = (float *)p;
+    p = take((size_t)g.ptiles * EC4 * 4); if (w) w->tmin = (float *)p;
     return off;
 }
 
 inline const float *cW(const float *canon, int l) { return canon + e_layer_off(l); }
 inline const float *cG(const float *canon, int l) { return canon + e_layer_off(l) + e_cout(l) * e_cin(l); }
 
-template <int KS, int NT, int MODE, int NS>
+template <int KS, int NT, int MODE, int NS, bool POOL = false>
 int launch_pgemm(PArgs a, hipStream_t s) {
     constexpr int K = KS * 16, NPAR = MODE == FWD ? 2 : 3;
     a.nch = a.Ntot / (NT * 32);
     const int lds = 2 * 2 * NT * NS * 1024 + NPAR * K * 4 + PW * 2 * NT * 32 * 4 + (MODE == BWD_SPARSE ? PW * K * 8 : 0);
     static LdsLimit limit;
-    if (hipError_t e = limit.ensure((const void *)et_pgemm_kernel<KS, NT, MODE, NS>, lds); e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((et_pgemm_kernel<KS, NT, MODE, NS>), dim3((a.g.nwg + 7) / 8 * 8 * a.nch), dim3(PW * 64), lds, s, a);
+    if (hipError_t e = limit.ensure((const void *)et_pgemm_kernel<KS, NT, MODE, NS, POOL>, lds); e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((et_pgemm_kernel<KS, NT, MODE, NS, POOL>), dim3((a.g.nwg + 7) / 8 * 8 * a.nch), dim3(PW * 64), lds, s, a);
     return (int)hipGetLastError();
 }
 template <int NS>
 int forward_gemms(const Geo &g, const TWork &w, hipStream_t s, const int (&C)[4], int l) {
     PArgs a{};
     a.g = g; a.yin = w.y[l - 1]; a.pin = w.bnp + 4 * t_coff(l - 1); a.wpk = w.wf[l - 1]; a.out = w.y[l]; a.part = w.part; a.Ntot = C[l];
+    a.tmax = w.tmax; a.tmin = w.tmin;
     if (l == 1) return launch_pgemm<4, 4, FWD, NS>(a, s);
     if (l == 2) return launch_pgemm<8, 4, FWD, NS>(a, s);
-    return launch_pgemm<16, 4, FWD, NS>(a, s);
+    return launch_pgemm<16, 4, FWD, NS, true>(a, s);
 }
 template <int WM, int WN, int GM, int GN, int MODE>
 int launch_wgrad(const WArgs &a, int nchunk, int rblocks, int cblocks, hipStream_t s) {
@@ -919,7 +947,8 @@ extern "C" int dpf_encoder_train_forward(int B, int N, int precision, const floa
         ET_CHECK(x6 ? forward_gemms<3>(g, w, s, C, l) : forward_gemms<2>(g, w, s, C, l));
         finish(l);
     }
-    hipLaunchKernelGGL(et_pool_kernel, dim3((B * EC4 + 3) / 4), dim3(256), 0, s, g, w.y[3], w.bnp + 4 * t_coff(3), pooled, w.arg, w.yarg);
+    hipLaunchKernelGGL(et_pool_kernel, dim3((B * EC4 + 63) / 64), dim3(64), 0, s, g, w.y[3], w.tmax, w.tmin, w.bnp + 4 * t_coff(3), pooled,
+                       w.arg, w.yarg);
     return (int)hipGetLastError();
 }
 
