@@ -741,9 +741,16 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
             chain_mfma<NS>(smem + L_PACK + PT_A1, br, lane, bf, pre);      // pre = h1 + D
         }
         TP(2)
-        const float *fb = filmb + br * FB_BR + h4;                         // lane bases; feature offsets are immediates
-        const float *w2 = w2s + br * 128 + h4;
-        const float *s12h = s12s + br * 128 + h4;
+        // The per-feature tables are read through a lane offset that is tied to the end of the contraction above (an
+        // empty asm that consumes its last accumulator register): without the tie the 224 LDS reads of the loop below
+        // float to the top of the block, live across the whole forward chain, and the register allocator spills 46 VGPRs
+        // to scratch -- whose reloads, each followed by a vmcnt(0), were a third of this kernel's time (r02 phase profile:
+        // 15 000 of the 52 000 cycles of a branch).
+        int h4t = h4;
+        asm volatile("" : "+v"(h4t) : "v"(pre[1][15]));
+        const float *fb = filmb + br * FB_BR + h4t;                        // lane bases; feature offsets are immediates
+        const float *w2 = w2s + br * 128 + h4t;
+        const float *s12h = s12s + br * 128 + h4t;
         const float doa = dov[br][0], dob = dov[br][1];
         // dh1 = rstd1 * (dh1n - mean(dh1n) - h1n * mean(dh1n*h1n)),  dh1n = a*dh2a,  h1n = pre*rstd1 - c/a
         f32x16 dh1[2];
@@ -776,22 +783,34 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
         __builtin_amdgcn_sched_barrier(0);
         TP(4)
         {
-            const float *c0 = cf + br * 128 + h4;
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int F0 = acc_feature(t, r, 0);
-                    ua += c0[F0] * dh0a[t][r]; ub += c0[64 + F0] * dh0a[t][r];
-                }
             const int f = reduced_feature(pl, h);
             const float r1 = reduce_points(dh0a, pl);
             const float r2 = reduce_points_gen([&](int i) { return dh0a[i >> 4][i & 15] * xa; }, pl);
             const float r3 = reduce_points_gen([&](int i) { return dh0a[i >> 4][i & 15] * xb; }, pl);
-            f32x16 h0n[2];
-            input_mfma(smem + L_PACK + pt_a0n(NS), br, lane, b0, h0n);     // normalised h0
-            const float r0 = reduce_points_gen([&](int i) { return dh0a[i >> 4][i & 15] * h0n[i >> 4][i & 15]; }, pl);
+            float r0;
+            {
+                f32x16 h0n[2];
+                input_mfma(smem + L_PACK + pt_a0n(NS), br, lane, b0, h0n); // normalised h0
+                r0 = reduce_points_gen([&](int i) { return dh0a[i >> 4][i & 15] * h0n[i >> 4][i & 15]; }, pl);
+            }
             rsum[0] = r0; rsum[1] = r1; rsum[2] = r2; rsum[3] = r3; rfeat = f;
+            // u_k: after the reductions, its 64 table reads tied to their last result -- hoisted into the butterflies (where
+            // four accumulator fragments are live) they were loaded and spilled to scratch at once
+            // (and in four chunks, each tied to the previous chunk's sum: 16 table values in flight, not 64)
+            int h4u = h4;
+            asm volatile("" : "+v"(h4u) : "v"(r0));
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int rh = 0; rh < 2; ++rh) {
+                    const float *c0 = cf + br * 128 + h4u;
+#pragma unroll
+                    for (int r = 8 * rh; r < 8 * rh + 8; ++r) {
+                        const int F0 = acc_feature(t, r, 0);
+                        ua += c0[F0] * dh0a[t][r]; ub += c0[64 + F0] * dh0a[t][r];
+                    }
+                    asm volatile("" : "+v"(h4u) : "v"(ua), "v"(ub));
+                }
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- dW1[fo][fi] += sum_points dh1[fo][pt] * h0[fi][pt]: both fragments are transposed through LDS so
