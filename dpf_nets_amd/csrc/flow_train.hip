@@ -231,6 +231,33 @@ __device__ __forceinline__ void input_mfma(const uint8_t *a0, int br, int lane, 
         acc[t] = mfma(*(const u32x4 *)(a0 + ((br * 2 + t) * 64 + lane) * 16), b0, zero16());
 }
 
+// the same with the operands swapped: acc[t] holds, in LANE pl, feature 32 t + pl of the 16 POINTS (r & 3) + 8 (r >> 2) + 4 h
+__device__ __forceinline__ void input_mfma_swapped(const uint8_t *a0, int br, int lane, u32x4 b0, f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+        acc[t] = mfma(b0, *(const u32x4 *)(a0 + ((br * 2 + t) * 64 + lane) * 16), zero16());
+}
+
+// Swapped accumulators (lane = feature, registers = points) as bf16 hi/lo operand fragments whose K dimension is the
+// tile's 32 points: k-step j takes registers 8 j .. 8 j + 7 of the lane, i.e. k-slot i of lane-half kg holds point
+// (i & 3) + 8 (2 j + (i >> 2)) + 4 kg -- some fixed order of the k-step's 16 points, the same for every operand built here.
+template <bool RELU>
+__device__ __forceinline__ void kfrags_from_swapped(const f32x16 (&v)[2], u32x4 (&hi)[2][2], u32x4 (&lo)[2][2]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const float v0 = RELU ? relu(v[t][8 * j2 + 2 * d]) : v[t][8 * j2 + 2 * d];
+                const float v1 = RELU ? relu(v[t][8 * j2 + 2 * d + 1]) : v[t][8 * j2 + 2 * d + 1];
+                float l0, l1;
+                split_hi(v0, l0); split_hi(v1, l1);
+                hi[t][j2][d] = pack_bf16_trunc(v0, v1);
+                lo[t][j2][d] = pack_bf16_rne(l0, l1);
+            }
+}
+
 // bf16 split (NS parts) of an accumulator fragment pair into the B fragments of the next contraction
 // (register r of M tile t = element j = r&7 of k-step 2t + (r>>3)); RELU = clamp at zero first.
 // Same arithmetic as branch_tile in csrc/flow.hip: the recomputed activations are bit-identical to
@@ -648,8 +675,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int L_FILM = l_film(NS), L_FILMB = l_filmb(NS), L_RED = l_red(NS);
     float *cf = (float *)(smem + L_RED) + 256;                             // c_fk [2 br][2][64]   (first 1 KB of the region: spare)
-    uint16_t *tr = (uint16_t *)(smem + L_RED + 4096);                      // per wave: X[64][32], Y[64][32] bf16, swizzled
-    float *redw = (float *)(smem + L_RED + 4096);                          // per-wave slots of the workgroup reduction, ALIAS tr once the MFMAs are done
+    float *redw = (float *)(smem + L_RED + 4096);                          // per-wave slots (8 KB) of the workgroup reduction; their head is the wave's per-point scratch before that
     const int bi = blockIdx.y, lane = threadIdx.x & 63, h = lane >> 5, pl = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int h4 = 4 * h;                   // opaque to the optimiser: feature offsets stay "lane base + immediate"
@@ -674,15 +700,6 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
     const float *film = (const float *)(smem + L_FILM);
     const float *filmb = (const float *)(smem + L_FILMB);
     const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-    uint16_t *X = tr + wave * XY_WAVE, *Y = X + 64 * 32;
-    // tile element (row f, point q) lives at f*32 + ((q>>3) ^ ((f>>2)&3))*8 + (q&7): the 16-byte chunks of a
-    // row are XOR-swizzled so that the 16 rows a ds_read_b128 group touches hit 16 distinct bank quads.
-    // Writes: row f = F0 + 4h with F0 a compile-time constant per register, (f>>2)&3 = (2q + h)&3 with
-    // q = bit 2 of the register index  ->  two lane-dependent bases; reads likewise (two k-steps).
-    const int wbase0 = 128 * h + (pl & 7) + ((((pl >> 3) ^ h) & 3) << 3);
-    const int wbase[2] = {wbase0, wbase0 ^ 16};
-    const int rbase0 = pl * 32 + (((h ^ (pl >> 2)) & 3) << 3);
-    const int rbase[2] = {rbase0, rbase0 ^ 16};
     float *s12s = cf + 256;                                                // [2 br][2][64] BN1 backward means
     float *w2s = s12s + 256;                                               // [2 br][2][64] raw sd2.weight
     if (threadIdx.x >= 256) {
@@ -728,77 +745,91 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
     unsigned long long tt[12];
     tt[11] = __builtin_amdgcn_s_memtime();
 #endif
+    // identity fragments: B operand of the MFMA that turns K = points fragments back into an accumulator with lane = point
+    // (k-slot i of lane-half kg in k-step j holds point (i & 3) + 8 (2 j + (i >> 2)) + 4 kg, see kfrags_from_swapped)
+    u32x4 eye[2];
+#pragma unroll
+    for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int p0 = ((2 * d) & 3) + 8 * (2 * j2 + ((2 * d) >> 2)) + 4 * h, p1 = p0 + 1;
+            eye[j2][d] = (pl == p0 ? 0x3F80u : 0u) | (pl == p1 ? 0x3F800000u : 0u);
+        }
+    float *pts = redw + wave * 2048;                                     // per-wave scratch (free until the reduction): [4][32] per-point values
+    const int tile0 = (blockIdx.x * TW + wave) * TILE;
     for (int br = 0; br < 2; ++br) {
         TP(0)
         __syncthreads();                                                   // staging landed / previous branch flushed
         TP(1)
+        // per-point values every lane needs in the swapped orientation (registers = points): d(o) of this branch, x_a, x_b
+        if (!h) { pts[pl] = dov[br][0]; pts[32 + pl] = dov[br][1]; pts[64 + pl] = xa; pts[96 + pl] = xb; }
+        // ---- forward: h0 (lane = point) -> fragments; pre = h1 + D in the SWAPPED orientation (lane = feature 32 t + pl,
+        // register r = point (r & 3) + 8 (r >> 2) + 4 h): per-feature constants become per-lane, sums over the points in-lane
         f32x16 h0a[2], pre[2];
         {
             u32x4 bf[NS][4];
             input_mfma(smem + L_PACK + pt_a0(NS), br, lane, b0, h0a);      // gamma*h0n + beta
             split_fragment<true, NS>(h0a, bf);
-            load_features(film + br * FILM_BR_FLOATS, h, pre);
-            chain_mfma<NS>(smem + L_PACK + PT_A1, br, lane, bf, pre);      // pre = h1 + D
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float dsh = film[br * FILM_BR_FLOATS + 32 * t + pl];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pre[t][r] = dsh;
+            }
+            chain_mfma_swapped<NS>(smem + L_PACK + PT_A1, br, lane, bf, pre);   // same products in the same order as the forward kernel
         }
         TP(2)
-        // The per-feature tables are read through a lane offset that is tied to the end of the contraction above (an
-        // empty asm that consumes its last accumulator register): without the tie the 224 LDS reads of the loop below
-        // float to the top of the block, live across the whole forward chain, and the register allocator spills 46 VGPRs
-        // to scratch -- whose reloads, each followed by a vmcnt(0), were a third of this kernel's time (r02 phase profile:
-        // 15 000 of the 52 000 cycles of a branch).
-        int h4t = h4;
-        asm volatile("" : "+v"(h4t) : "v"(pre[1][15]));
-        const float *fb = filmb + br * FB_BR + h4t;                        // lane bases; feature offsets are immediates
-        const float *w2 = w2s + br * 128 + h4t;
-        const float *s12h = s12s + br * 128 + h4t;
-        const float doa = dov[br][0], dob = dov[br][1];
-        // dh1 = rstd1 * (dh1n - mean(dh1n) - h1n * mean(dh1n*h1n)),  dh1n = a*dh2a,  h1n = pre*rstd1 - c/a
-        f32x16 dh1[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int F0 = acc_feature(t, r, 0);
-                const float av = fb[0 * 64 + F0], rstd1 = fb[2 * 64 + F0];
-                const float g2 = dh2a_of(pre[t][r], w2[F0], w2[64 + F0], doa, dob);
-                const float h1n = pre[t][r] * rstd1 - fb[3 * 64 + F0];
-                const float v = rstd1 * (av * g2 - s12h[F0] - h1n * s12h[64 + F0]);
-                dh1[t][r] = valid ? v : 0.f;
-            }
-        TP(3)
-        // ---- dh0 = W1^T dh1, relu backward
-        f32x16 dh0a[2] = {zero16(), zero16()};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- dh1 = rstd1 * (dh1n - mean(dh1n) - h1n * mean(dh1n*h1n)),  dh1n = a*dh2a,  h1n = pre*rstd1 - c/a   (in place)
+        u32x4 xh[2][2], xl[2][2];                                          // dh1 as K = points fragments [feature tile][k-step]
         {
-            u32x4 bg[2][4];
-            split_fragment<false, 2>(dh1, bg);
-            chain_mfma<2>(smem + L_PACK + pt_a1t(NS), br, lane, bg, dh0a);
+            f32x4 doa4[4], dob4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { doa4[q] = *(const f32x4 *)(pts + 8 * q + h4); dob4[q] = *(const f32x4 *)(pts + 32 + 8 * q + h4); }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int fo = 32 * t + pl;
+                const float av = filmb[br * FB_BR + 0 * 64 + fo], rstd1 = filmb[br * FB_BR + 2 * 64 + fo], ca = filmb[br * FB_BR + 3 * 64 + fo];
+                const float w2a = w2s[br * 128 + fo], w2b = w2s[br * 128 + 64 + fo];
+                const float m1 = s12s[br * 128 + fo], m2 = s12s[br * 128 + 64 + fo];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float g2 = dh2a_of(pre[t][r], w2a, w2b, doa4[r >> 2][r & 3], dob4[r >> 2][r & 3]);
+                    const float h1n = pre[t][r] * rstd1 - ca;
+                    const float v = rstd1 * (av * g2 - m1 - h1n * m2);
+                    pre[t][r] = tile0 + (r & 3) + 8 * (r >> 2) + 4 * h < N ? v : 0.f;
+                }
+            }
+            kfrags_from_swapped<false>(pre, xh, xl);
         }
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dh0a[t][r] = h0a[t][r] > 0.f ? dh0a[t][r] : 0.f;
-        // ---- per-point u_k and the per-feature sums of dh0a * {h0n, 1, x_a, x_b}
-        float rsum[4];
-        int rfeat;
-        __builtin_amdgcn_sched_barrier(0);
-        TP(4)
+        TP(3)
+        // ---- dh1 back to lane = point (an MFMA against the identity: hi + lo is exact), split, dh0 = W1^T dh1 in BOTH
+        // orientations: lane = point for the per-point u_k, lane = feature for the per-feature sums
+        u32x4 bg[2][4];
         {
-            const int f = reduced_feature(pl, h);
-            const float r1 = reduce_points(dh0a, pl);
-            const float r2 = reduce_points_gen([&](int i) { return dh0a[i >> 4][i & 15] * xa; }, pl);
-            const float r3 = reduce_points_gen([&](int i) { return dh0a[i >> 4][i & 15] * xb; }, pl);
-            float r0;
-            {
-                f32x16 h0n[2];
-                input_mfma(smem + L_PACK + pt_a0n(NS), br, lane, b0, h0n); // normalised h0
-                r0 = reduce_points_gen([&](int i) { return dh0a[i >> 4][i & 15] * h0n[i >> 4][i & 15]; }, pl);
+            f32x16 dn[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                dn[t] = zero16();
+#pragma unroll
+                for (int j2 = 0; j2 < 2; ++j2) {
+                    dn[t] = mfma(xh[t][j2], eye[j2], dn[t]);
+                    dn[t] = mfma(xl[t][j2], eye[j2], dn[t]);
+                }
             }
-            rsum[0] = r0; rsum[1] = r1; rsum[2] = r2; rsum[3] = r3; rfeat = f;
-            // u_k: after the reductions, its 64 table reads tied to their last result -- hoisted into the butterflies (where
-            // four accumulator fragments are live) they were loaded and spilled to scratch at once
-            // (and in four chunks, each tied to the previous chunk's sum: 16 table values in flight, not 64)
+            split_fragment<false, 2>(dn, bg);
+        }
+        {
+            f32x16 dh0a[2] = {zero16(), zero16()};
+            chain_mfma<2>(smem + L_PACK + pt_a1t(NS), br, lane, bg, dh0a);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dh0a[t][r] = h0a[t][r] > 0.f ? dh0a[t][r] : 0.f;
+            // u_k (table reads tied to the chain's last result and chunked: see the r02 note on scratch spills)
             int h4u = h4;
-            asm volatile("" : "+v"(h4u) : "v"(r0));
+            asm volatile("" : "+v"(h4u) : "v"(dh0a[1][15]));
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -812,47 +843,48 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
                     asm volatile("" : "+v"(h4u) : "v"(ua), "v"(ub));
                 }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- dW1[fo][fi] += sum_points dh1[fo][pt] * h0[fi][pt]: both fragments are transposed through LDS so
-        // that the tile's 32 points become the K dimension (2 k-steps of 16).  hi/lo split like every other
-        // contraction: three rounds (hi.hi, hi.lo, lo.hi) over the same two LDS tiles.
-        TP(5)
-        f32x16 dw[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};     // [fo tile][fi tile]
-        auto put = [&](uint16_t *dst, const f32x16 (&v)[2], bool clamp, bool lo) {
+        TP(4)
+        float rsum[2][4];                                                  // [feature tile][k]: sums over the tile's points, lanes h = 0
+        f32x16 h0s[2];                                                     // h0 pre-activation, lane = feature
+        {
+            input_mfma_swapped(smem + L_PACK + pt_a0(NS), br, lane, b0, h0s);
+            f32x16 dh0s[2] = {zero16(), zero16()};
+            chain_mfma_swapped<2>(smem + L_PACK + pt_a1t(NS), br, lane, bg, dh0s);
+            f32x16 h0n[2];
+            input_mfma_swapped(smem + L_PACK + pt_a0n(NS), br, lane, b0, h0n);   // normalised h0
+            f32x4 xa4[4], xb4[4];
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int q = 0; q < 4; ++q) { xa4[q] = *(const f32x4 *)(pts + 64 + 8 * q + h4); xb4[q] = *(const f32x4 *)(pts + 96 + 8 * q + h4); }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float x = v[t][r];
-                    asm volatile("" : "+v"(x));      // no CSE with the forward split: keep h0a live, not 3 copies of it
-                    x = clamp ? relu(x) : x;
-                    float rest;
-                    const uint32_t hi = split_hi(x, rest);
-                    (dst + wbase[(r >> 2) & 1])[acc_feature(t, r, 0) * 32] = lo ? (uint16_t)bf16_rne(rest) : (uint16_t)(hi >> 16);
+                    const float d = h0s[t][r] > 0.f ? dh0s[t][r] : 0.f;
+                    s0 += d * h0n[t][r]; s1 += d; s2 += d * xa4[r >> 2][r & 3]; s3 += d * xb4[r >> 2][r & 3];
                 }
-        };
-        auto outer = [&]() {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+                rsum[t][0] = s0 + __shfl_xor(s0, 32); rsum[t][1] = s1 + __shfl_xor(s1, 32);
+                rsum[t][2] = s2 + __shfl_xor(s2, 32); rsum[t][3] = s3 + __shfl_xor(s3, 32);
+            }
+        }
+        TP(5)
+        // ---- dW1[fo][fi] += sum_points dh1[fo][pt] * h0[fi][pt]: both operands are K = points fragments straight from
+        // the swapped accumulators; hi/lo split like every other contraction: hi.hi, hi.lo, lo.hi
+        f32x16 dw[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};     // [fo tile][fi tile]
+        {
+            u32x4 yh[2][2], yl[2][2];
+            kfrags_from_swapped<true>(h0s, yh, yl);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                u32x4 fa[2], fbb[2];
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    fa[mt] = *(const u32x4 *)((X + rbase[ks]) + mt * 1024);     // row fo = 32mt + pl, 8 consecutive points
-                    fbb[mt] = *(const u32x4 *)((Y + rbase[ks]) + mt * 1024);    // col fi, same points
-                }
+            for (int j2 = 0; j2 < 2; ++j2)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) dw[mt][nt] = mfma(fa[mt], fbb[nt], dw[mt][nt]);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        };
-        put(X, dh1, false, false); put(Y, h0a, true, false); outer();       // hi . hi
-        put(Y, h0a, true, true); outer();                                   // hi . lo
-        put(X, dh1, false, true); put(Y, h0a, true, false); outer();        // lo . hi
+                    for (int nt = 0; nt < 2; ++nt) {
+                        dw[mt][nt] = mfma(xl[mt][j2], yh[nt][j2], dw[mt][nt]);
+                        dw[mt][nt] = mfma(xh[mt][j2], yl[nt][j2], dw[mt][nt]);
+                        dw[mt][nt] = mfma(xh[mt][j2], yh[nt][j2], dw[mt][nt]);
+                    }
+        }
         TP(6)
         // ---- workgroup reduction through per-wave LDS slots (plain stores: LDS float atomics are ~1000 cycles
         // per wave instruction), two rounds of 32 accumulator registers, then the four per-feature sums
@@ -879,8 +911,12 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
         }
         TP(7)
         __syncthreads();
+        if (!h) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) redw[wave * 256 + k * 64 + rfeat] = rsum[k];
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) redw[wave * 256 + k * 64 + 32 * t + pl] = rsum[t][k];
+        }
         TP(8)
         __syncthreads();
         TP(9)
