@@ -529,17 +529,16 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
     __syncthreads();
     const float *film = (const float *)(smem + L_FILM);
     const float *filmb = (const float *)(smem + L_FILMB);
-    // ---- forward recompute of both branches: o[br][w], and the h2 pre-activations
-    f32x16 pre[2][2];                                                      // acc1 = h1 + D  (h2a = FA * acc1)
+    // ---- forward recompute of both branches (lane = point): the two outputs o[br][w] per point
     float o[2][2];
 #pragma unroll
     for (int br = 0; br < 2; ++br) {
-        f32x16 acc0[2];
+        f32x16 acc0[2], pre[2];                                            // pre = h1 + D  (h2a = FA * pre)
         u32x4 bf[NS][4];
         input_mfma(smem + L_PACK + pt_a0(NS), br, lane, b0, acc0);
         split_fragment<true, NS>(acc0, bf);
-        load_features(film + br * FILM_BR_FLOATS, h, pre[br]);             // accumulator starts at D
-        chain_mfma<NS>(smem + L_PACK + PT_A1, br, lane, bf, pre[br]);
+        load_features(film + br * FILM_BR_FLOATS, h, pre);                 // accumulator starts at D
+        chain_mfma<NS>(smem + L_PACK + PT_A1, br, lane, bf, pre);
         float oa = 0.f, ob = 0.f;
         const float *wab = film + br * FILM_BR_FLOATS + 64 + h4;           // lane base; feature offsets are immediates
 #pragma unroll
@@ -547,7 +546,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int F0 = acc_feature(t, r, 0);
-                const float v = relu(pre[br][t][r]);
+                const float v = relu(pre[t][r]);
                 oa += wab[F0] * v; ob += wab[64 + F0] * v;
             }
         oa += __shfl_xor(oa, 32); ob += __shfl_xor(ob, 32);
@@ -586,42 +585,65 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
         d[0] = h ? dmu_w[0] : dlv_w[0];
         d[N] = h ? dmu_w[1] : dlv_w[1];
     }
-    // ---- output SharedDot backward, FiLM backward, per-feature sums
+    // ---- output SharedDot backward, FiLM backward, per-feature sums: the pre-activations once more, in the SWAPPED
+    // orientation (lane = feature 32 t + pl, register r = point (r & 3) + 8 (r >> 2) + 4 h; same products in the same order, so
+    // the same bits) -- the per-feature constants are per-lane and the sums over the tile's points are in-lane adds plus one
+    // cross-half add, where the lane = point layout needed four 31-shuffle butterflies per branch
+    float *pts = w2s + 256 + wave * 64;                                    // per-wave scratch: d(o) of the tile's 32 points [2][32]
 #pragma unroll
     for (int br = 0; br < 2; ++br) {
         const float doa = br == 0 ? dlv_w[0] : dmu_w[0], dob = br == 0 ? dlv_w[1] : dmu_w[1];
-        const float *w2 = w2s + br * 128 + h4;                             // lane bases; feature offsets are immediates
-        const float *fb = filmb + br * FB_BR + h4;
-        f32x16 dh2a[2];
+        if (!h) { pts[pl] = doa; pts[32 + pl] = dob; }
+        f32x16 pre[2];
+        {
+            f32x16 acc0[2];
+            u32x4 bf[NS][4];
+            input_mfma(smem + L_PACK + pt_a0(NS), br, lane, b0, acc0);
+            split_fragment<true, NS>(acc0, bf);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t) {
+                const float dsh = film[br * FILM_BR_FLOATS + 32 * t + pl];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pre[t][r] = dsh;
+            }
+            chain_mfma_swapped<NS>(smem + L_PACK + PT_A1, br, lane, bf, pre);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        f32x4 doa4[4], dob4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { doa4[q] = *(const f32x4 *)(pts + 8 * q + h4); dob4[q] = *(const f32x4 *)(pts + 32 + 8 * q + h4); }
+        float *rw = red + wave * 520;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int fo = 32 * t + pl;
+            const float fa = filmb[br * FB_BR + 0 * 64 + fo] * filmb[br * FB_BR + 2 * 64 + fo];      // h2 = FA * relu(pa)
+            const float rstd1 = filmb[br * FB_BR + 2 * 64 + fo], ca = filmb[br * FB_BR + 3 * 64 + fo];
+            const float w2a = w2s[br * 128 + fo], w2b = w2s[br * 128 + 64 + fo];
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int F0 = acc_feature(t, r, 0);
-                dh2a[t][r] = dh2a_of(pre[br][t][r], w2[F0], w2[64 + F0], doa, dob);   // [pa > 0] sum_w W2[w]*do_w
+                const float da = doa4[r >> 2][r & 3], db = dob4[r >> 2][r & 3];
+                const float g = dh2a_of(pre[t][r], w2a, w2b, da, db);                         // [pa > 0] sum_w W2[w]*do_w
+                const float h2 = relu(pre[t][r]) * fa;
+                s0 += da * h2;                                                                 // dW2[w] = sum do_w * h2
+                s1 += db * h2;
+                s2 += g * (pre[t][r] * rstd1 - ca);                                            // da = sum dh2a * h1n
+                s3 += g;
             }
-        const int f = reduced_feature(pl, h);
-        // dW2[w] = sum do_w * h2,  h2 = FA * relu(pa)
-        auto h2 = [&](int i) {
-            const int F0 = acc_feature(i >> 4, i & 15, 0);
-            return relu(pre[br][i >> 4][i & 15]) * (fb[0 * 64 + F0] * fb[2 * 64 + F0]);
-        };
-        const float r0 = reduce_points_gen([&](int i) { return doa * h2(i); }, pl);
-        const float r1 = reduce_points_gen([&](int i) { return dob * h2(i); }, pl);
-        // da = sum dh2a * h1n,  h1n = pa*rstd1 - c/a
-        const float r2 = reduce_points_gen([&](int i) {
-            const int F0 = acc_feature(i >> 4, i & 15, 0);
-            return dh2a[i >> 4][i & 15] * (pre[br][i >> 4][i & 15] * fb[2 * 64 + F0] - fb[3 * 64 + F0]);
-        }, pl);
-        const float r3 = reduce_points(dh2a, pl);
-        float *rw = red + wave * 520;
-        rw[(br * 4 + 0) * 64 + f] = r0;
-        rw[(br * 4 + 1) * 64 + f] = r1;
-        rw[(br * 4 + 2) * 64 + f] = r2;
-        rw[(br * 4 + 3) * 64 + f] = r3;
+            s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32); s3 += __shfl_xor(s3, 32);
+            if (!h) {
+                rw[(br * 4 + 0) * 64 + fo] = s0;
+                rw[(br * 4 + 1) * 64 + fo] = s1;
+                rw[(br * 4 + 2) * 64 + fo] = s2;
+                rw[(br * 4 + 3) * 64 + fo] = s3;
+            }
+        }
         float sa = h == 0 ? doa : 0.f, sb = h == 0 ? dob : 0.f;                   // db2: each point once
         for (int q = 32; q > 0; q >>= 1) { sa += __shfl_xor(sa, q); sb += __shfl_xor(sb, q); }
         if (lane == 0) { rw[512 + br * 2 + 0] = sa; rw[512 + br * 2 + 1] = sb; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                                   // the scratch is rewritten for the next branch
     }
     __syncthreads();
     const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
@@ -1141,7 +1163,7 @@ static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb
     const dim3 grid((N + TBLK - 1) / TBLK, B);
     const int nblk = grid.x * grid.y, nb = grid.x;
     const double count = (double)B * N;
-    const int lds1 = pt_a0n(NS) + 4096 + (TW * 520 + 256) * 4, lds2 = l_red(NS) + 4096 + TW * XY_WAVE * 2;
+    const int lds1 = pt_a0n(NS) + 4096 + (TW * 520 + 256 + TW * 64) * 4, lds2 = l_red(NS) + 4096 + TW * XY_WAVE * 2;
     static LdsLimit lim_b1, lim_b2;
     if (hipError_t e = lim_b1.ensure((const void *)tbwd1_kernel<NS>, lds1); e != hipSuccess) return (int)e;
     if (hipError_t e = lim_b2.ensure((const void *)tbwd2_kernel<NS>, lds2); e != hipSuccess) return (int)e;
