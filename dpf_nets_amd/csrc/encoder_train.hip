@@ -39,6 +39,7 @@
 // d(input) is produced on request (et_dx; the clouds are normally data and it is skipped).
 #include "flow_common.h"
 #include "encoder_layout.h"
+#include "graph_cache.h"
 
 // Timing experiments only (results are garbage): -DET_ABLATE=<mask> removes parts of et_pgemm_kernel --
 // 1 operand-row loads, 2 epilogue loads / stores, 4 MFMAs, 8 weight staging, 16 the prologue arithmetic.
@@ -912,8 +913,46 @@ extern "C" size_t dpf_encoder_train_workspace_bytes(int B, int N) {
     return t_carve(nullptr, make_geo(B, N), nullptr);
 }
 
+static int encoder_train_forward_direct(int B, int N, int precision, const float *canon, const float *x, void *ws, float *pooled,
+                                        float *batch_stats, float *const *running, float momentum, dpf_stream_t stream);
+static int encoder_train_backward_direct(int B, int N, const float *canon, const float *x, void *ws, const float *pooled,
+                                         const float *g_pooled, float *dcanon, float *dx, dpf_stream_t stream);
+
+// The ~13 (forward) / ~17 (backward) launches of a call as one graph launch once the same call has been seen twice
+// (graph_cache.h): in a training loop the allocator hands back the same workspace, so the steady state is all replays.
 extern "C" int dpf_encoder_train_forward(int B, int N, int precision, const float *canon, const float *x, void *ws, float *pooled,
                                          float *batch_stats, float *const *running, float momentum, dpf_stream_t stream) {
+    auto direct = [&](hipStream_t st) {
+        return encoder_train_forward_direct(B, N, precision, canon, x, ws, pooled, batch_stats, running, momentum, (dpf_stream_t)st);
+    };
+    static GraphCache cache;
+    GraphKey k;
+    k.val(B); k.val(N); k.val(precision); k.val(canon); k.val(x); k.val(ws); k.val(pooled); k.val(batch_stats); k.val(momentum);
+    const int has_running = running != nullptr;
+    k.val(has_running);
+    if (has_running) k.add(running, sizeof(float *) * 8);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    k.val(dev);
+    return cache.run(k.h, (hipStream_t)stream, direct);
+}
+
+extern "C" int dpf_encoder_train_backward(int B, int N, const float *canon, const float *x, void *ws, const float *pooled,
+                                          const float *g_pooled, float *dcanon, float *dx, dpf_stream_t stream) {
+    auto direct = [&](hipStream_t st) {
+        return encoder_train_backward_direct(B, N, canon, x, ws, pooled, g_pooled, dcanon, dx, (dpf_stream_t)st);
+    };
+    static GraphCache cache;
+    GraphKey k;
+    k.val(B); k.val(N); k.val(canon); k.val(x); k.val(ws); k.val(pooled); k.val(g_pooled); k.val(dcanon); k.val(dx);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    k.val(dev);
+    return cache.run(k.h, (hipStream_t)stream, direct);
+}
+
+static int encoder_train_forward_direct(int B, int N, int precision, const float *canon, const float *x, void *ws, float *pooled,
+                                        float *batch_stats, float *const *running, float momentum, dpf_stream_t stream) {
     if (B <= 0 || N <= 0) return DPF_EINVAL;
     if (!canon || !x || !ws || !pooled) return DPF_EINVAL;
     if ((long)B * N < 2) return DPF_EINVAL;                   // BatchNorm1d refuses a single value per channel in training
@@ -952,8 +991,8 @@ extern "C" int dpf_encoder_train_forward(int B, int N, int precision, const floa
     return (int)hipGetLastError();
 }
 
-extern "C" int dpf_encoder_train_backward(int B, int N, const float *canon, const float *x, void *ws, const float *pooled,
-                                          const float *g_pooled, float *dcanon, float *dx, dpf_stream_t stream) {
+static int encoder_train_backward_direct(int B, int N, const float *canon, const float *x, void *ws, const float *pooled,
+                                         const float *g_pooled, float *dcanon, float *dx, dpf_stream_t stream) {
     if (B <= 0 || N <= 0) return DPF_EINVAL;
     if (!canon || !x || !ws || !pooled || !g_pooled || !dcanon) return DPF_EINVAL;
     hipStream_t s = (hipStream_t)stream;

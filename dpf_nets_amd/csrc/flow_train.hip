@@ -44,6 +44,7 @@
 #include <stdlib.h>
 
 #include "flow_common.h"
+#include "graph_cache.h"
 
 namespace {
 
@@ -1119,10 +1120,10 @@ static int prepare_layer(int B, int N, int ka, int kb, const float *tcanon_l, vo
 
 // Training-mode forward of an L-layer stack: per layer (in the order the mode prescribes) the batch statistics
 // and folds, then the layer itself through dpf_flow_forward(n_layers = 1).
-extern "C" int dpf_flow_train_forward(int n_layers, int B, int N, int mode, int precision, const int *meta_host,
-                                      const int *meta_dev, const float *tcanon, void *packed, const float *fm,
-                                      const float *p_in, float *ps, float *mus, float *logvars, float *stats, float *film,
-                                      float flow_eps, void *workspace, dpf_stream_t stream) {
+static int flow_train_forward_direct(int n_layers, int B, int N, int mode, int precision, const int *meta_host,
+                                     const int *meta_dev, const float *tcanon, void *packed, const float *fm,
+                                     const float *p_in, float *ps, float *mus, float *logvars, float *stats, float *film,
+                                     float flow_eps, void *workspace, dpf_stream_t stream) {
     if (n_layers <= 0 || B <= 0 || N <= 0 || !meta_host || !meta_dev || !tcanon || !packed || !fm || !p_in || !ps || !mus ||
         !logvars || !stats || !film || !workspace)
         return DPF_EINVAL;
@@ -1147,6 +1148,27 @@ extern "C" int dpf_flow_train_forward(int n_layers, int B, int N, int mode, int 
         cur = ps + l * lst;
     }
     return 0;
+}
+
+// The stack's ~6 n_layers launches as one graph launch once the same call has been seen twice (graph_cache.h)
+extern "C" int dpf_flow_train_forward(int n_layers, int B, int N, int mode, int precision, const int *meta_host,
+                                      const int *meta_dev, const float *tcanon, void *packed, const float *fm,
+                                      const float *p_in, float *ps, float *mus, float *logvars, float *stats, float *film,
+                                      float flow_eps, void *workspace, dpf_stream_t stream) {
+    auto direct = [&](hipStream_t st) {
+        return flow_train_forward_direct(n_layers, B, N, mode, precision, meta_host, meta_dev, tcanon, packed, fm, p_in, ps, mus,
+                                         logvars, stats, film, flow_eps, workspace, (dpf_stream_t)st);
+    };
+    if (n_layers <= 0 || !meta_host) return direct((hipStream_t)stream);
+    static GraphCache cache;
+    GraphKey k;
+    k.val(n_layers); k.val(B); k.val(N); k.val(mode); k.val(precision); k.add(meta_host, sizeof(int) * 4 * n_layers);
+    k.val(meta_dev); k.val(tcanon); k.val(packed); k.val(fm); k.val(p_in); k.val(ps); k.val(mus); k.val(logvars); k.val(stats);
+    k.val(film); k.val(flow_eps); k.val(workspace);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    k.val(dev);
+    return cache.run(k.h, (hipStream_t)stream, direct);
 }
 
 template <int NS>
@@ -1220,9 +1242,21 @@ extern "C" int dpf_flow_train_backward(int n_layers, int B, int N, int mode, int
     if (!g_ps) return DPF_EINVAL;
     const size_t lst = (size_t)(B > 0 ? B : 0) * 3 * (N > 0 ? N : 0);
     const float *base[3] = {g_ps, g_mus, g_lvs};
-    return backward_stack(n_layers, B, N, mode, precision, meta_host, tcanon, packed, film, stats, p_in, ps,
-                          [&](int which, int l) { return base[which] ? base[which] + l * lst : nullptr; }, dp_in, dp_tmp, dcanon,
-                          dfm, flow_eps, workspace, stream);
+    auto direct = [&](hipStream_t st) {
+        return backward_stack(n_layers, B, N, mode, precision, meta_host, tcanon, packed, film, stats, p_in, ps,
+                              [&](int which, int l) { return base[which] ? base[which] + l * lst : nullptr; }, dp_in, dp_tmp,
+                              dcanon, dfm, flow_eps, workspace, (dpf_stream_t)st);
+    };
+    if (n_layers <= 0 || !meta_host) return direct((hipStream_t)stream);
+    static GraphCache cache;
+    GraphKey k;
+    k.val(n_layers); k.val(B); k.val(N); k.val(mode); k.val(precision); k.add(meta_host, sizeof(int) * 4 * n_layers);
+    k.val(tcanon); k.val(packed); k.val(film); k.val(stats); k.val(p_in); k.val(ps); k.val(g_ps); k.val(g_mus); k.val(g_lvs);
+    k.val(dp_in); k.val(dp_tmp); k.val(dcanon); k.val(dfm); k.val(flow_eps); k.val(workspace);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    k.val(dev);
+    return cache.run(k.h, (hipStream_t)stream, direct);
 }
 
 // The same with one (B,3,N) gradient pointer per layer and list: autograd hands the node a gradient per output
@@ -1235,9 +1269,26 @@ extern "C" int dpf_flow_train_backward_lists(int n_layers, int B, int N, int mod
                                              float *dp_tmp, float *dcanon, float *dfm, float flow_eps, void *workspace,
                                              dpf_stream_t stream) {
     const float *const *tab[3] = {g_ps, g_mus, g_lvs};
-    return backward_stack(n_layers, B, N, mode, precision, meta_host, tcanon, packed, film, stats, p_in, ps,
-                          [&](int which, int l) { return tab[which] ? tab[which][l] : nullptr; }, dp_in, dp_tmp, dcanon, dfm,
-                          flow_eps, workspace, stream);
+    auto direct = [&](hipStream_t st) {
+        return backward_stack(n_layers, B, N, mode, precision, meta_host, tcanon, packed, film, stats, p_in, ps,
+                              [&](int which, int l) { return tab[which] ? tab[which][l] : nullptr; }, dp_in, dp_tmp, dcanon,
+                              dfm, flow_eps, workspace, (dpf_stream_t)st);
+    };
+    if (n_layers <= 0 || !meta_host) return direct((hipStream_t)stream);
+    static GraphCache cache;
+    GraphKey k;
+    k.val(n_layers); k.val(B); k.val(N); k.val(mode); k.val(precision); k.add(meta_host, sizeof(int) * 4 * n_layers);
+    k.val(tcanon); k.val(packed); k.val(film); k.val(stats); k.val(p_in); k.val(ps);
+    for (int w = 0; w < 3; ++w) {
+        const int present = tab[w] != nullptr;
+        k.val(present);
+        if (present) k.add(tab[w], sizeof(const float *) * n_layers);      // the per-layer gradient pointers themselves
+    }
+    k.val(dp_in); k.val(dp_tmp); k.val(dcanon); k.val(dfm); k.val(flow_eps); k.val(workspace);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    k.val(dev);
+    return cache.run(k.h, (hipStream_t)stream, direct);
 }
 
 #ifdef DPF_PROFILE
