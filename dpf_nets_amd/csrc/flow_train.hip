@@ -144,9 +144,12 @@ __global__ __launch_bounds__(256) void tstats_x_kernel(int N, int ka, int kb, co
 // sets of the layer.  One workgroup, thread = (branch, feature).
 // 512 threads: the moments and the per-feature folds need 128 of them, the 2 x 2048 fragment slots they feed take all
 // (with 128 threads the slot loop alone was 16 serial iterations of ~80 instructions: 9.3 us for the kernel)
-__global__ __launch_bounds__(512) void tbn0_kernel(int nblk, int nk, double count, const double *__restrict__ part,
-                                                   const float *__restrict__ tcanon_l, uint8_t *__restrict__ packed_a0,
-                                                   float *__restrict__ stats_l) {
+// (r02: a device function run by every workgroup of tstats_h1 -- the consumer -- straight into its LDS: 2 048 partial
+// values and 8 KiB of fragments are cheaper to redo 256 times than a dependent one-workgroup launch is to wait for;
+// workgroup 0 also publishes the fragments and the statistics for the kernels that follow.  512 threads.)
+__device__ __forceinline__ void bn0_fold(int nblk, int nk, double count, const double *__restrict__ part,
+                                         const float *__restrict__ tcanon_l, uint8_t *lds_a0, uint8_t *__restrict__ packed_a0,
+                                         float *__restrict__ stats_l) {
     __shared__ double mom[5], wsum[2][5];
     __shared__ float fold[2][64][4];
     __shared__ float foldn[2][64][4];
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(512) void tbn0_kernel(int nblk, int nk, double coun
     const double wa = cb[T_W0 + f * nk], wb = nk == 2 ? cb[T_W0 + f * 2 + 1] : 0.0;
     const double ea = mom[0], eb = mom[1];
     const double caa = mom[2] - ea * ea, cbb = mom[3] - eb * eb, cab = mom[4] - ea * eb;
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && stats_l != nullptr) {
         float *m = stats_l + ST_MOM;
         m[0] = (float)ea; m[1] = (float)eb; m[2] = (float)caa; m[3] = (float)cbb; m[4] = (float)cab;
     }
@@ -180,21 +183,26 @@ __global__ __launch_bounds__(512) void tbn0_kernel(int nblk, int nk, double coun
     if (var < 0) var = 0;
     const float rstd = (float)(1.0 / sqrt(var + (double)BN_EPS));
     const float gamma = cb[T_G0 + f], beta = cb[T_B0 + f];
+    if (stats_l != nullptr) {
     float *st = stats_l + br * ST_BR;
     st[0 * 64 + f] = (float)mean;
     st[1 * 64 + f] = rstd;
     st[4 * 64 + f] = (float)(var * (count / (count > 1 ? count - 1 : 1)));      // unbiased: running_var update
+    }
     const float s0 = gamma * rstd;
     fold[br][f][0] = s0 * (float)wa; fold[br][f][1] = s0 * (float)wb; fold[br][f][2] = beta - (float)mean * s0;
     foldn[br][f][0] = rstd * (float)wa; foldn[br][f][1] = rstd * (float)wb; foldn[br][f][2] = -(float)mean * rstd;
     }
     __syncthreads();
-    uint16_t *a0 = (uint16_t *)packed_a0, *a0n = (uint16_t *)(packed_a0 + 4096);
+    uint16_t *a0 = (uint16_t *)lds_a0, *a0n = (uint16_t *)(lds_a0 + 4096);
+    uint16_t *g0 = (uint16_t *)packed_a0, *g0n = (uint16_t *)(packed_a0 + 4096);
     for (int idx = threadIdx.x; idx < 2 * 2 * 64 * 8; idx += blockDim.x) {
         const int j = idx & 7, lane = (idx >> 3) & 63, t = (idx >> 9) & 1, b2 = idx >> 10;
         const int ff = 32 * t + (lane & 31), h = lane >> 5;
-        a0[idx] = (uint16_t)input_weight_slot(fold[b2][ff][h], fold[b2][ff][2], h, j);
-        a0n[idx] = (uint16_t)input_weight_slot(foldn[b2][ff][h], foldn[b2][ff][2], h, j);
+        const uint16_t v = (uint16_t)input_weight_slot(fold[b2][ff][h], fold[b2][ff][2], h, j);
+        const uint16_t vn = (uint16_t)input_weight_slot(foldn[b2][ff][h], foldn[b2][ff][2], h, j);
+        a0[idx] = v; a0n[idx] = vn;
+        if (packed_a0 != nullptr) { g0[idx] = v; g0n[idx] = vn; }
     }
 }
 
@@ -393,12 +401,18 @@ struct TArgs {
 // h1 = W1 relu(BN0(W0 x)) for every point; per-workgroup partial sums and sums of squares
 //   part[blk][br][2][64]
 template <int NS>
-__global__ __launch_bounds__(TW * 64) void tstats_h1_kernel(TArgs a, float *__restrict__ part) {
+__global__ __launch_bounds__(TW * 64) void tstats_h1_kernel(TArgs a, float *__restrict__ part, int nblk_x, double count,
+                                                            const double *__restrict__ xpart, uint8_t *__restrict__ packed_a0) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ float acc_s[TW][2][2][64];                                 // per-wave slots (LDS float atomics are slow)
     const int bi = blockIdx.y, lane = threadIdx.x & 63, h = lane >> 5, pl = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    stage_bytes(a.packed_l, smem, pt_a0n(NS), wave, lane);                // A1 + A0
+    stage_bytes(a.packed_l, smem, NS * P_A1_PART, wave, lane);            // A1; the A0 fragments are folded right here
+    {
+        const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+        bn0_fold(nblk_x, a.kb >= 0 ? 2 : 1, count, xpart, a.tcanon_l, smem + pt_a0(NS), first ? packed_a0 : nullptr,
+                 first ? const_cast<float *>(a.stats_l) : nullptr);
+    }
     const int N = a.N, n = (blockIdx.x * TW + wave) * TILE + pl;
     const bool valid = n < N;
     const float *pc = a.p_in + (size_t)bi * 3 * N;
@@ -1102,8 +1116,6 @@ static int prepare_layer(int B, int N, int ka, int kb, const float *tcanon_l, vo
     const int nbx = (N + 255) / 256;
     const double count = (double)B * N;
     hipLaunchKernelGGL(tstats_x_kernel, dim3(nbx, B), dim3(256), 0, s, N, ka, kb, p_in, w.xpart);
-    hipLaunchKernelGGL(tbn0_kernel, dim3(1), dim3(512), 0, s, nbx * B, kb >= 0 ? 2 : 1, count, w.xpart, tcanon_l,
-                       (uint8_t *)packed_l + pt_a0(NS), stats_l);
     TArgs a;
     a.packed_l = (const uint8_t *)packed_l; a.tcanon_l = tcanon_l; a.film_l = film_l; a.filmb_l = film_l + (size_t)B * 512;
     a.stats_l = stats_l; a.p_in = p_in; a.B = B; a.N = N; a.ka = ka; a.kb = kb; a.wa = 0; a.wb = 0; a.mode = 0;
@@ -1111,7 +1123,8 @@ static int prepare_layer(int B, int N, int ka, int kb, const float *tcanon_l, vo
     static LdsLimit lim_h1;
     if (hipError_t e = lim_h1.ensure((const void *)tstats_h1_kernel<NS>, pt_a0n(NS)); e != hipSuccess) return (int)e;
     const dim3 grid((N + TBLK - 1) / TBLK, B);
-    hipLaunchKernelGGL(tstats_h1_kernel<NS>, grid, dim3(TW * 64), pt_a0n(NS), s, a, w.part1);
+    hipLaunchKernelGGL(tstats_h1_kernel<NS>, grid, dim3(TW * 64), pt_a0n(NS), s, a, w.part1, nbx * B, count, w.xpart,
+                       (uint8_t *)packed_l + pt_a0(NS));
     hipLaunchKernelGGL(tcolsum_kernel, dim3(8), dim3(1024), 0, s, (int)(grid.x * grid.y), 256, w.part1, w.sums);
     hipLaunchKernelGGL(tfilm_fold_kernel, dim3(B), dim3(128), 0, s, count, w.sums, tcanon_l, fm_l, B, flow_eps, stats_l, film_l,
                        film_l + (size_t)B * 512);
