@@ -227,6 +227,38 @@ def test_training_path_uses_hip_and_repeats(monkeypatch):
         assert torch.equal(a, b)       # per-wave slots, per-workgroup partials, fixed-order column sums: no atomics
 
 
+def test_training_graph_replay_is_bitwise_the_eager_call():
+    """csrc/graph_cache.h: a stack call seen twice is recorded and replayed as one hipGraph.  Five identical steps on
+    persistent inputs (the allocator hands the same blocks back, so the later ones are replays) must give bit-identical
+    outputs and gradients, equal to a run with the replay switched off (DPF_TRAIN_GRAPH=0 in a child process)."""
+    import subprocess
+    import sys
+    nets = _gpu()
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "from dpf_nets_amd import networks as nets\n"
+        "from oracle import flow_oracle as FO\n"
+        "torch.manual_seed(0)\n"
+        "dec = nets.LocalCondRNVPDecoder(2, 64, 128).cuda().train(); dec.flatten_parameters()\n"
+        "tgt, z, g = FO.synthetic_inputs(7, 4, 700, 128)\n"
+        "tp, tg = torch.from_numpy(tgt).cuda(), torch.from_numpy(g).cuda()\n"
+        "sig = []\n"
+        "for it in range(5):\n"
+        "    dec.zero_grad(set_to_none=True)\n"
+        "    ps, mus, lvs = dec(tp, tg, mode='inverse')\n"
+        "    (ps[0].square().mean() + sum(lvs).mean()).backward()\n"
+        "    sig.append((float(ps[0].double().sum()), float(dec.flows[0].nvp1.T_mu_0[3].weight.grad.double().sum()),\n"
+        "                float(dec.flows[1].nvp3.T_logvar_0[0].weight.grad.double().abs().sum())))\n"
+        "print(repr(sig))\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    outs = {}
+    for flag in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DPF_TRAIN_GRAPH=flag), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[flag] = eval(r.stdout.strip().splitlines()[-1])
+    assert len(set(outs["1"])) == 1, outs["1"]            # every step the same bits: eager, recorded, replayed
+    assert outs["1"] == outs["0"]
+
+
 def test_training_loop_with_optimizer_and_eval_switch():
     """A few optimizer steps the way training.py:37-56 drives the decoder (inverse flow + NLL, backward, Adam),
     plus a Chamfer term through nn_distance's backward; then eval() must see the UPDATED weights (the packed
