@@ -1304,6 +1304,9 @@ extern "C" int dpf_flow_train_backward_lists(int n_layers, int B, int N, int mod
     return cache.run(k.h, (hipStream_t)stream, direct);
 }
 
+// number of training-mode calls served by a graph replay so far in this process (csrc/graph_cache.h); diagnostics / tests
+extern "C" long dpf_train_graph_replays(void) { return dpf_graph_replay_counter().load(); }
+
 #ifdef DPF_PROFILE
 extern "C" void dpf_debug_set_tprof(void *p) {
     hipLaunchKernelGGL(tprof_set_kernel, dim3(1), dim3(1), 0, 0, (unsigned long long *)p);

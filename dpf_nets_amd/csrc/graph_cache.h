@@ -14,7 +14,10 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <mutex>
+
+inline std::atomic<long> &dpf_graph_replay_counter() { static std::atomic<long> n{0}; return n; }   // graph launches, process-wide
 
 struct GraphKey {
     uint64_t h = 1469598103934665603ull;           // FNV-1a over everything that shapes the launch sequence
@@ -84,6 +87,7 @@ public:
             (void)hipGraphDestroy(g);
             hit->state = 2;
         }
+        dpf_graph_replay_counter().fetch_add(1, std::memory_order_relaxed);
         return (int)hipGraphLaunch(hit->exec, s);
     }
 };

@@ -357,6 +357,12 @@ int dpf_encoder_train_forward(int B, int N, int precision, const float *canon, c
 int dpf_encoder_train_backward(int B, int N, const float *canon, const float *x, void *ws, const float *pooled,
                                const float *g_pooled, float *dcanon, float *dx, dpf_stream_t stream);
 
+/* The training-mode entry points (dpf_flow_train_forward / _backward[_lists], dpf_encoder_train_forward / _backward) issue
+ * hundreds of small dependent launches per call; a call whose scalars AND pointers have been seen twice is recorded once
+ * (stream capture) and from then on replayed as one hipGraph -- a training loop presents the same addresses every step.
+ * DPF_TRAIN_GRAPH=0 in the environment switches that off.  dpf_train_graph_replays(): calls served by a replay so far. */
+long dpf_train_graph_replays(void);
+
 /* ---- latent prior flow: GlobalRNVPDecoder on (B, G) codes, eval-mode BatchNorm ---------------
  * replaces GlobalRNVPDecoder.forward (lib/networks/decoders.py:21-38): n_steps = 2 * n_flows
  * RealNVPFlow steps (lib/networks/flows.py:198-213) in ONE launch, both modes.

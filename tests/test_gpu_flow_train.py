@@ -228,8 +228,8 @@ def test_training_path_uses_hip_and_repeats(monkeypatch):
 
 
 def test_training_graph_replay_is_bitwise_the_eager_call():
-    """csrc/graph_cache.h: a stack call seen twice is recorded and replayed as one hipGraph.  Five identical steps on
-    persistent inputs (the allocator hands the same blocks back, so the later ones are replays) must give bit-identical
+    """csrc/graph_cache.h: a stack call seen twice is recorded and replayed as one hipGraph.  Ten identical steps on
+    persistent inputs (the allocator settles into handing the same blocks back, so the later ones are replays) must give bit-identical
     outputs and gradients, equal to a run with the replay switched off (DPF_TRAIN_GRAPH=0 in a child process)."""
     import subprocess
     import sys
@@ -243,20 +243,23 @@ def test_training_graph_replay_is_bitwise_the_eager_call():
         "tgt, z, g = FO.synthetic_inputs(7, 4, 700, 128)\n"
         "tp, tg = torch.from_numpy(tgt).cuda(), torch.from_numpy(g).cuda()\n"
         "sig = []\n"
-        "for it in range(5):\n"
+        "for it in range(10):\n"
         "    dec.zero_grad(set_to_none=True)\n"
         "    ps, mus, lvs = dec(tp, tg, mode='inverse')\n"
         "    (ps[0].square().mean() + sum(lvs).mean()).backward()\n"
         "    sig.append((float(ps[0].double().sum()), float(dec.flows[0].nvp1.T_mu_0[3].weight.grad.double().sum()),\n"
         "                float(dec.flows[1].nvp3.T_logvar_0[0].weight.grad.double().abs().sum())))\n"
-        "print(repr(sig))\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        "from dpf_nets_amd._lib import lib\n"
+        "print(repr((sig, int(lib().dpf_train_graph_replays()))))\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     outs = {}
     for flag in ("1", "0"):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DPF_TRAIN_GRAPH=flag), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[flag] = eval(r.stdout.strip().splitlines()[-1])
-    assert len(set(outs["1"])) == 1, outs["1"]            # every step the same bits: eager, recorded, replayed
-    assert outs["1"] == outs["0"]
+    (sig1, replays1), (sig0, replays0) = outs["1"], outs["0"]
+    assert len(set(sig1)) == 1, sig1                      # every step the same bits: eager, recorded, replayed
+    assert sig1 == sig0
+    assert replays0 == 0 and replays1 >= 4, (replays0, replays1)      # the later steps ran as graphs (forward and backward)
 
 
 def test_training_loop_with_optimizer_and_eval_switch():
