@@ -670,6 +670,11 @@ def leg_cfg5(args, rank, world, dist, device):
 # ----------------------------------------------------------------------------------------------------------------
 # leg train: inverse stack (training-mode BN) + NLL + backward + ONE all-reduce + Adam
 # ----------------------------------------------------------------------------------------------------------------
+def _lib_handle():
+    from dpf_nets_amd._lib import lib
+    return lib()
+
+
 def train_step_leg(args, rank, world, dist, device, batch, layers, steps, warmup):
     from dpf_nets_amd import networks as nets, synthetic as SY
     from dpf_nets_amd import distributed as D
@@ -737,6 +742,7 @@ def train_step_leg(args, rank, world, dist, device, batch, layers, steps, warmup
                     "zero_grad + inverse stack (batch-stat BN) + PointFlowNLL + backward + all-reduce(flat_g) + Adam (AMSGrad mirror)",
             "encoder": getattr(args, "encoder", "none"),
             "flat_gradient_bytes": nbytes, "collectives_per_step": 1 if world > 1 else 0,
+            "graph_replays": int(_lib_handle().dpf_train_graph_replays()),
             "algorithmic_tflops": 3.0 * FLOP_PER_POINT_LAYER * layers * batch * N / (elapsed / steps) / 1e12}
     if world > 1:
         bus = 2.0 * (world - 1) / world * nbytes / (ar_us * 1e-6) / 1e9
@@ -760,7 +766,9 @@ def leg_train(args, rank, world, dist, device):
             "vs_baseline": None, "dtype": info["precision"] + " MFMA operands, fp32 accumulate/points/gradients",
             "data": "synthetic",
             "config": {"workload": cfg["name"] + ": " + info["what"], "clouds_per_gpu": batch, "points_per_cloud": args.points,
-                       "global_clouds": batch * world, "layers": args.layers, "latent": args.latent, "launch": "eager",
+                       "global_clouds": batch * world, "layers": args.layers, "latent": args.latent,
+                       "launch": "eager Python step; the stack's ~700 kernel launches replay as hipGraphs (csrc/graph_cache.h, "
+                                 "DPF_TRAIN_GRAPH=0 to switch off): %d graph launches so far" % info.get("graph_replays", 0),
                        "parallelism": "data parallel replicas, one all-reduce of the flat gradient per step"},
             "roofline": {"kernel": "training step (tbwd2/tbwd1/tstats_h1/flow kernels, csrc/flow_train.hip)", "bound": "mfma",
                          "achieved": tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TF,
