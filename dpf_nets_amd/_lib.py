@@ -50,9 +50,9 @@ SIGNATURES = {
     "dpf_flow_train_workspace_bytes": (_sz, [_i, _i]),
     "dpf_flow_train_pack": (_i, [_i, _i, _vp, _vp, _vp]),
     "dpf_flow_train_forward": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
-    "dpf_flow_train_backward": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+    "dpf_flow_train_backward": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _vp, _f, _vp, _vp]),
-    "dpf_flow_train_backward_lists": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+    "dpf_flow_train_backward_lists": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                            _vp, _f, _vp, _vp]),
     "dpf_fscore_reduce": (_i, [_i, _i, _i, _vp, _vp, _f, _vp, _vp]),
     "dpf_chamfer_reduce": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),

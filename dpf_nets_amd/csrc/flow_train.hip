@@ -512,6 +512,7 @@ __device__ __forceinline__ float dh2a_of(float pre, float w2a, float w2b, float 
 template <int NS>
 __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__restrict__ g_p, const float *__restrict__ g_p2,
                                                         const float *__restrict__ g_mu, const float *__restrict__ g_lv,
+                                                        const float *__restrict__ mu_l, const float *__restrict__ lv_l,
                                                         float *__restrict__ dp_in, float *__restrict__ dout,
                                                         float *__restrict__ part1) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -530,11 +531,13 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
     const bool valid = n < N;
     const int nc = valid ? n : N - 1;
     const size_t cloud = (size_t)bi * 3 * N;
-    float p[3], gp[3], gm[3], gl[3];
+    float p[3], gp[3], gm[3], gl[3], mus[3], lvs[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const size_t o = cloud + (size_t)c * N + nc;
         p[c] = a.p_in[o];
+        mus[c] = mu_l[o];                                                   // the forward pass's own outputs of this layer
+        lvs[c] = lv_l[o];
         gp[c] = valid ? (g_p ? g_p[o] : 0.f) + (g_p2 ? g_p2[o] : 0.f) : 0.f;
         gm[c] = valid && g_mu ? g_mu[o] : 0.f;
         gl[c] = valid && g_lv ? g_lv[o] : 0.f;
@@ -544,39 +547,16 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
     __syncthreads();
     const float *film = (const float *)(smem + L_FILM);
     const float *filmb = (const float *)(smem + L_FILMB);
-    // ---- forward recompute of both branches (lane = point): the two outputs o[br][w] per point
-    float o[2][2];
-#pragma unroll
-    for (int br = 0; br < 2; ++br) {
-        f32x16 acc0[2], pre[2];                                            // pre = h1 + D  (h2a = FA * pre)
-        u32x4 bf[NS][4];
-        input_mfma(smem + L_PACK + pt_a0(NS), br, lane, b0, acc0);
-        split_fragment<true, NS>(acc0, bf);
-        load_features(film + br * FILM_BR_FLOATS, h, pre);                 // accumulator starts at D
-        chain_mfma<NS>(smem + L_PACK + PT_A1, br, lane, bf, pre);
-        float oa = 0.f, ob = 0.f;
-        const float *wab = film + br * FILM_BR_FLOATS + 64 + h4;           // lane base; feature offsets are immediates
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int F0 = acc_feature(t, r, 0);
-                const float v = relu(pre[t][r]);
-                oa += wab[F0] * v; ob += wab[64 + F0] * v;
-            }
-        oa += __shfl_xor(oa, 32); ob += __shfl_xor(ob, 32);
-        o[br][0] = oa + film[FILM_B2_OFF + br * 2 + 0];
-        o[br][1] = ob + film[FILM_B2_OFF + br * 2 + 1];
-    }
     // ---- coupling transform and its derivative (flows.py:96-115)
     const bool inverse = a.mode == DPF_MODE_INVERSE;
     float dmu_w[2] = {0.f, 0.f}, dlv_w[2] = {0.f, 0.f};
 #pragma unroll
+    // mu and logvar = softsign(o_logvar) of the warped channels are the forward kernel's stored outputs (r02: no third
+    // recomputation of the conditioner here); d softsign / d o = 1 / (1 + |o|)^2 = (1 - |logvar|)^2
     for (int c = 0; c < 3; ++c) {
         const bool isa = c == a.wa, isb = c == a.wb;
-        const float olv = isa ? o[0][0] : (isb ? o[0][1] : 0.f);
-        const float lv = olv / (1.0f + fabsf(olv));
-        const float mu = isa ? o[1][0] : (isb ? o[1][1] : 0.f);
+        const float lv = (isa || isb) ? lvs[c] : 0.f;
+        const float mu = (isa || isb) ? mus[c] : 0.f;
         const float e = expf(lv), var = a.eps + e;
         float dmu, dlv, dpc;
         if (inverse) {
@@ -591,7 +571,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
             dlv = gl[c] + gp[c] * p[c] * (0.5f * e / s);
         }
         if (valid && h == 0) dp_in[cloud + (size_t)c * N + n] = dpc;       // direct term; pass 3 adds the conditioner path
-        const float dsoft = 1.0f / ((1.0f + fabsf(olv)) * (1.0f + fabsf(olv)));
+        const float dsoft = (1.0f - fabsf(lv)) * (1.0f - fabsf(lv));
         if (isa) { dmu_w[0] = dmu; dlv_w[0] = dlv * dsoft; }
         if (isb) { dmu_w[1] = dmu; dlv_w[1] = dlv * dsoft; }
     }
@@ -1186,9 +1166,9 @@ extern "C" int dpf_flow_train_forward(int n_layers, int B, int N, int mode, int 
 
 template <int NS>
 static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb, const float *tcanon_l, const void *packed_l,
-                          const float *film_l, const float *stats_l, const float *p_in, const float *g_p, const float *g_p2,
-                          const float *g_mu, const float *g_lv, float *dp_in, float *dcanon_l, float *dfm_l, float flow_eps,
-                          void *workspace, hipStream_t s) {
+                          const float *film_l, const float *stats_l, const float *p_in, const float *mu_l, const float *lv_l,
+                          const float *g_p, const float *g_p2, const float *g_mu, const float *g_lv, float *dp_in, float *dcanon_l,
+                          float *dfm_l, float flow_eps, void *workspace, hipStream_t s) {
     TWork w;
     carve(workspace, B, N, &w);
     TArgs a;
@@ -1202,7 +1182,7 @@ static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb
     static LdsLimit lim_b1, lim_b2;
     if (hipError_t e = lim_b1.ensure((const void *)tbwd1_kernel<NS>, lds1); e != hipSuccess) return (int)e;
     if (hipError_t e = lim_b2.ensure((const void *)tbwd2_kernel<NS>, lds2); e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(tbwd1_kernel<NS>, grid, dim3(TW * 64), lds1, s, a, g_p, g_p2, g_mu, g_lv, dp_in, w.dout, w.part1);
+    hipLaunchKernelGGL(tbwd1_kernel<NS>, grid, dim3(TW * 64), lds1, s, a, g_p, g_p2, g_mu, g_lv, mu_l, lv_l, dp_in, w.dout, w.part1);
     hipLaunchKernelGGL(tcloudsum_kernel, dim3(B), dim3(520), 0, s, nb, B, w.part1, a.filmb_l, flow_eps, w.pc, dfm_l);
     hipLaunchKernelGGL(tbwd2_kernel<NS>, grid, dim3(TW * 64), lds2, s, a, w.pc, count, dcanon_l, w.dout, w.ubuf, w.part2);
     hipLaunchKernelGGL(tcolsum_kernel, dim3((2 * P2_J + 31) / 32), dim3(1024), 0, s, nblk, 2 * P2_J, w.part2, w.tot2);
@@ -1217,9 +1197,9 @@ static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb
 template <class GP>
 static int backward_stack(int n_layers, int B, int N, int mode, int precision, const int *meta_host, const float *tcanon,
                           const void *packed, const float *film, const float *stats, const float *p_in, const float *ps,
-                          GP &&grad_of, float *dp_in, float *dp_tmp, float *dcanon, float *dfm, float flow_eps,
-                          void *workspace, dpf_stream_t stream) {
-    if (n_layers <= 0 || B <= 0 || N <= 0 || !meta_host || !tcanon || !packed || !film || !stats || !p_in || !ps ||
+                          const float *mus, const float *logvars, GP &&grad_of, float *dp_in, float *dp_tmp, float *dcanon,
+                          float *dfm, float flow_eps, void *workspace, dpf_stream_t stream) {
+    if (n_layers <= 0 || B <= 0 || N <= 0 || !meta_host || !tcanon || !packed || !film || !stats || !p_in || !ps || !mus || !logvars ||
         !dp_in || !dp_tmp || !dcanon || !dfm || !workspace)
         return DPF_EINVAL;
     if (mode != DPF_MODE_DIRECT && mode != DPF_MODE_INVERSE) return DPF_EINVAL;
@@ -1236,7 +1216,7 @@ static int backward_stack(int n_layers, int B, int N, int mode, int precision, c
 #define DPF_BWD(NSV)                                                                                                      \
     backward_layer<NSV>(B, N, mode, m[0], m[1], m[2], m[3], tcanon + (size_t)l * T_LAYER,                               \
                         (const uint8_t *)packed + (size_t)l * pt_bytes(NSV), film + l * fls, stats + (size_t)l * ST_LAYER, pin, \
-                        grad_of(0, l), chain, grad_of(1, l), grad_of(2, l), out,                                         \
+                        mus + l * lst, logvars + l * lst, grad_of(0, l), chain, grad_of(1, l), grad_of(2, l), out,       \
                         dcanon + (size_t)l * T_LAYER, dfm + l * fms, flow_eps, workspace, (hipStream_t)stream)
         const int rc = ns == 2 ? DPF_BWD(2) : DPF_BWD(3);
 #undef DPF_BWD
@@ -1249,14 +1229,14 @@ static int backward_stack(int n_layers, int B, int N, int mode, int precision, c
 // g_ps / g_mus / g_lvs: (L,B,3,N) gradients w.r.t. the three output lists (g_mus / g_lvs may be NULL)
 extern "C" int dpf_flow_train_backward(int n_layers, int B, int N, int mode, int precision, const int *meta_host,
                                        const float *tcanon, const void *packed, const float *film, const float *stats,
-                                       const float *p_in, const float *ps, const float *g_ps, const float *g_mus,
-                                       const float *g_lvs, float *dp_in, float *dp_tmp, float *dcanon, float *dfm,
-                                       float flow_eps, void *workspace, dpf_stream_t stream) {
+                                       const float *p_in, const float *ps, const float *mus, const float *logvars,
+                                       const float *g_ps, const float *g_mus, const float *g_lvs, float *dp_in, float *dp_tmp,
+                                       float *dcanon, float *dfm, float flow_eps, void *workspace, dpf_stream_t stream) {
     if (!g_ps) return DPF_EINVAL;
     const size_t lst = (size_t)(B > 0 ? B : 0) * 3 * (N > 0 ? N : 0);
     const float *base[3] = {g_ps, g_mus, g_lvs};
     auto direct = [&](hipStream_t st) {
-        return backward_stack(n_layers, B, N, mode, precision, meta_host, tcanon, packed, film, stats, p_in, ps,
+        return backward_stack(n_layers, B, N, mode, precision, meta_host, tcanon, packed, film, stats, p_in, ps, mus, logvars,
                               [&](int which, int l) { return base[which] ? base[which] + l * lst : nullptr; }, dp_in, dp_tmp,
                               dcanon, dfm, flow_eps, workspace, (dpf_stream_t)st);
     };
@@ -1264,7 +1244,8 @@ extern "C" int dpf_flow_train_backward(int n_layers, int B, int N, int mode, int
     static GraphCache cache;
     GraphKey k;
     k.val(n_layers); k.val(B); k.val(N); k.val(mode); k.val(precision); k.add(meta_host, sizeof(int) * 4 * n_layers);
-    k.val(tcanon); k.val(packed); k.val(film); k.val(stats); k.val(p_in); k.val(ps); k.val(g_ps); k.val(g_mus); k.val(g_lvs);
+    k.val(tcanon); k.val(packed); k.val(film); k.val(stats); k.val(p_in); k.val(ps); k.val(mus); k.val(logvars); k.val(g_ps);
+    k.val(g_mus); k.val(g_lvs);
     k.val(dp_in); k.val(dp_tmp); k.val(dcanon); k.val(dfm); k.val(flow_eps); k.val(workspace);
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -1277,13 +1258,13 @@ extern "C" int dpf_flow_train_backward(int n_layers, int B, int N, int mode, int
 // blocks and the layers whose outputs are unused read nothing.  Any table, and any entry, may be NULL (zero).
 extern "C" int dpf_flow_train_backward_lists(int n_layers, int B, int N, int mode, int precision, const int *meta_host,
                                              const float *tcanon, const void *packed, const float *film, const float *stats,
-                                             const float *p_in, const float *ps, const float *const *g_ps,
-                                             const float *const *g_mus, const float *const *g_lvs, float *dp_in,
-                                             float *dp_tmp, float *dcanon, float *dfm, float flow_eps, void *workspace,
-                                             dpf_stream_t stream) {
+                                             const float *p_in, const float *ps, const float *mus, const float *logvars,
+                                             const float *const *g_ps, const float *const *g_mus, const float *const *g_lvs,
+                                             float *dp_in, float *dp_tmp, float *dcanon, float *dfm, float flow_eps,
+                                             void *workspace, dpf_stream_t stream) {
     const float *const *tab[3] = {g_ps, g_mus, g_lvs};
     auto direct = [&](hipStream_t st) {
-        return backward_stack(n_layers, B, N, mode, precision, meta_host, tcanon, packed, film, stats, p_in, ps,
+        return backward_stack(n_layers, B, N, mode, precision, meta_host, tcanon, packed, film, stats, p_in, ps, mus, logvars,
                               [&](int which, int l) { return tab[which] ? tab[which][l] : nullptr; }, dp_in, dp_tmp, dcanon,
                               dfm, flow_eps, workspace, (dpf_stream_t)st);
     };
@@ -1291,7 +1272,7 @@ extern "C" int dpf_flow_train_backward_lists(int n_layers, int B, int N, int mod
     static GraphCache cache;
     GraphKey k;
     k.val(n_layers); k.val(B); k.val(N); k.val(mode); k.val(precision); k.add(meta_host, sizeof(int) * 4 * n_layers);
-    k.val(tcanon); k.val(packed); k.val(film); k.val(stats); k.val(p_in); k.val(ps);
+    k.val(tcanon); k.val(packed); k.val(film); k.val(stats); k.val(p_in); k.val(ps); k.val(mus); k.val(logvars);
     for (int w = 0; w < 3; ++w) {
         const int present = tab[w] != nullptr;
         k.val(present);

@@ -191,7 +191,7 @@ def _forward_core(p, g, spec, mode, prec, tcanon, W0, gam, bet, W1, b1, flat=Non
     # 3L output tensors (autograd hands back one gradient each) + the layer-sum of the log-variances, which is what
     # PointFlowNLL wants of them (losses.py:13): one reduction here instead of L-1 adds and L-1 backward nodes there
     outs = ps.unbind(0) + mus.unbind(0) + lvs.unbind(0) + (lvs.sum(0),)
-    return outs, (p, g, tcanon, packed, film, stats, ps, W0, gam, W1, xhat, rstd, y, sig, sw)
+    return outs, (p, g, tcanon, packed, film, stats, ps, W0, gam, W1, xhat, rstd, y, sig, sw, mus, lvs)
 
 
 def _grad_table(grads, shape, keep):
@@ -218,7 +218,7 @@ def _grad_table(grads, shape, keep):
 def _backward_core(spec, mode, prec, saved, grads, need_dg):
     """grads: the 3L gradients of (ps, mus, lvs), None where an output is unused.
     -> (dL/dp, dL/dg, d canon block, dW0, dgamma, dbeta, dW1, db1), the last five batched over the K FiLM nets."""
-    p, g, tcanon, packed, film, stats, ps, W0, gam, W1, xhat, rstd, y, sig, sw = saved
+    p, g, tcanon, packed, film, stats, ps, W0, gam, W1, xhat, rstd, y, sig, sw, mus, lvs = saved
     L, G = spec.L, spec.G
     B, _, N = p.shape
     dev = p.device
@@ -236,7 +236,8 @@ def _backward_core(spec, mode, prec, saved, grads, need_dg):
     t_lvs = _grad_table(g_lvs, tuple(p.shape), keep)
     chain, dp_tmp = torch.empty_like(p), torch.empty_like(p)
     check(L_.dpf_flow_train_backward_lists(L, B, N, MODE[mode], prec, spec.meta_host, tcanon.data_ptr(), packed.data_ptr(),
-                                           film.data_ptr(), stats.data_ptr(), p.data_ptr(), ps.data_ptr(), t_ps, t_mus, t_lvs,
+                                           film.data_ptr(), stats.data_ptr(), p.data_ptr(), ps.data_ptr(), mus.data_ptr(),
+                                           lvs.data_ptr(), t_ps, t_mus, t_lvs,
                                            chain.data_ptr(), dp_tmp.data_ptr(), dcanon.data_ptr(), dfm.data_ptr(), spec.eps,
                                            ws.data_ptr(), stream),
           "flow_train_backward_lists")
@@ -285,7 +286,7 @@ class _FlowStackTrain(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        saved, params = ctx.saved_tensors[:15], ctx.saved_tensors[15:]
+        saved, params = ctx.saved_tensors[:17], ctx.saved_tensors[17:]
         spec = ctx.spec
         chain, dg, dcanon, dW0, dgam, dbet, dW1, db1 = _backward_core(spec, ctx.mode, ctx.prec, saved, grads,
                                                                       ctx.needs_input_grad[1])

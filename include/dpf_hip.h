@@ -292,13 +292,15 @@ int dpf_flow_train_forward(int n_layers, int B, int N, int mode, int precision,
                            float *logvars, float *stats, float *film, float flow_eps,
                            void *workspace, dpf_stream_t stream);
 
-/* Backward of the stack.  g_ps / g_mus / g_lvs: (L,B,3,N) gradients w.r.t. the three output lists
- * (g_mus, g_lvs may be NULL = zero).  Overwrites dp_in (B,3,N), dcanon (L, canon_floats) and dfm
- * (L,[branch][w|b][B][64]); dp_tmp: (B,3,N) scratch. */
+/* Backward of the stack.  ps / mus / logvars: the forward call's three (L,B,3,N) outputs, unmodified (the
+ * per-point mu and logvar of a layer are read back rather than recomputed).  g_ps / g_mus / g_lvs: (L,B,3,N)
+ * gradients w.r.t. the three output lists (g_mus, g_lvs may be NULL = zero).  Overwrites dp_in (B,3,N),
+ * dcanon (L, canon_floats) and dfm (L,[branch][w|b][B][64]); dp_tmp: (B,3,N) scratch. */
 int dpf_flow_train_backward(int n_layers, int B, int N, int mode, int precision,
                             const int *meta_host, const float *tcanon, const void *packed,
                             const float *film, const float *stats, const float *p_in,
-                            const float *ps, const float *g_ps, const float *g_mus,
+                            const float *ps, const float *mus, const float *logvars,
+                            const float *g_ps, const float *g_mus,
                             const float *g_lvs, float *dp_in, float *dp_tmp, float *dcanon,
                             float *dfm, float flow_eps, void *workspace, dpf_stream_t stream);
 
@@ -309,7 +311,8 @@ int dpf_flow_train_backward(int n_layers, int B, int N, int mode, int precision,
 int dpf_flow_train_backward_lists(int n_layers, int B, int N, int mode, int precision,
                                   const int *meta_host, const float *tcanon, const void *packed,
                                   const float *film, const float *stats, const float *p_in,
-                                  const float *ps, const float *const *g_ps,
+                                  const float *ps, const float *mus, const float *logvars,
+                                  const float *const *g_ps,
                                   const float *const *g_mus, const float *const *g_lvs,
                                   float *dp_in, float *dp_tmp, float *dcanon, float *dfm,
                                   float flow_eps, void *workspace, dpf_stream_t stream);
