@@ -285,6 +285,10 @@ struct FlowArgs {
     const float *base_mu, *base_lv;
     long mu_sb, mu_sc, mu_sn, lv_sb, lv_sc, lv_sn;
     float *z_out;
+    // optional epilogue (training forward, csrc/flow_train.hip): moments of the output's channels xs_ka / xs_kb -- the
+    // NEXT layer's kept coordinates -- per workgroup, in tstats_x_kernel's layout: xs_part[workgroup][8] doubles
+    double *xs_part;
+    int xs_ka, xs_kb;
 #ifdef DPF_PROFILE
     unsigned long long *prof;
 #endif
@@ -891,6 +895,30 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
             a.sum_lv[cloud + n] = s0; a.sum_lv[cloud + N + n] = s1; a.sum_lv[cloud + 2 * (size_t)N + n] = s2;
         }
     }
+    if (a.xs_part != nullptr) {   // sum xa, xb, xa^2, xb^2, xa*xb over this workgroup's points, fixed order, as doubles
+        __syncthreads();                               // everybody is done with the weight buffers
+        double *lanes = (double *)smem, *red = lanes + FW * 5 * 32;       // [wave][moment][point], [wave][moment]
+        if (!h) {
+            double xa = 0, xb = 0;
+            if (valid) { xa = sel3(a.xs_ka, p0, p1, p2); xb = a.xs_kb >= 0 ? sel3(a.xs_kb, p0, p1, p2) : 0.f; }
+            double *q = lanes + wave * 5 * 32 + pl;
+            q[0] = xa; q[32] = xb; q[64] = xa * xa; q[96] = xb * xb; q[128] = xa * xb;
+        }
+        __syncthreads();
+        if (threadIdx.x < FW * 5) {                    // thread = (wave, moment): 32 points, four accumulators
+            const double *q = lanes + threadIdx.x * 32;
+            double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+            for (int i = 0; i < 32; i += 4) { t0 += q[i]; t1 += q[i + 1]; t2 += q[i + 2]; t3 += q[i + 3]; }
+            red[threadIdx.x] = (t0 + t1) + (t2 + t3);
+        }
+        __syncthreads();
+        if (threadIdx.x < 5) {
+            double t = 0;
+            for (int w = 0; w < FW; ++w) t += red[w * 5 + threadIdx.x];
+            a.xs_part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + threadIdx.x] = t;
+        }
+    }
 }
 
 #ifdef DPF_PROFILE
@@ -987,7 +1015,8 @@ static int flow_forward_impl(int n_layers, int B, int N, int mode, int precision
                              const int *meta, const float *film, const float *p_in, float *p_out,
                              float *p_out_pointmajor, float *sum_logvar, float *ps, float *mus, float *logvars,
                              float flow_eps, dpf_stream_t stream, const float *base_mu, const long *mu_strides,
-                             const float *base_lv, const long *lv_strides, float *z_out) {
+                             const float *base_lv, const long *lv_strides, float *z_out, double *xs_part = nullptr,
+                             int xs_ka = 0, int xs_kb = -1, int *xs_rows = nullptr) {
     const int ns = ns_of(precision);
     if (!ns || n_layers <= 0 || B < 0 || N <= 0 || (mode != DPF_MODE_DIRECT && mode != DPF_MODE_INVERSE)) return DPF_EINVAL;
     if (B == 0) return 0;
@@ -999,6 +1028,7 @@ static int flow_forward_impl(int n_layers, int B, int N, int mode, int precision
     a.p_out = p_out; a.p_out_pm = p_out_pointmajor; a.sum_lv = sum_logvar; a.ps = ps; a.mus = mus; a.lvs = logvars;
     a.L = n_layers; a.B = B; a.N = N; a.mode = mode; a.eps = flow_eps;
     a.base_mu = base_mu; a.base_lv = base_lv; a.z_out = z_out;
+    a.xs_part = xs_part; a.xs_ka = xs_ka; a.xs_kb = xs_kb;
     a.mu_sb = a.mu_sc = a.mu_sn = a.lv_sb = a.lv_sc = a.lv_sn = 0;
 #ifdef DPF_PROFILE
     a.prof = g_prof;
@@ -1021,6 +1051,7 @@ static int flow_forward_impl(int n_layers, int B, int N, int mode, int precision
         if (N <= 64) fw = 2;
         if (N <= 32) fw = 1;
     }
+    if (xs_rows != nullptr) *xs_rows = (N + TILE * (fw >= 8 ? 8 : fw >= 4 ? 4 : fw >= 2 ? 2 : 1) - 1) / (TILE * (fw >= 8 ? 8 : fw >= 4 ? 4 : fw >= 2 ? 2 : 1));
     // two layers per LDS buffer where a CU gets one workgroup anyway and the 2 x 2 layers fit its LDS (two-part precisions)
     static const int lpb_env = getenv("DPF_FLOW_LPB") ? atoi(getenv("DPF_FLOW_LPB")) : 0;
     const bool pair_ok = ns <= 2 && n_layers >= 2 && lpb_env != 1 && (lpb_env == 2 || (long)B * ((N + 255) / 256) <= 256);
@@ -1038,6 +1069,15 @@ extern "C" int dpf_flow_forward(int n_layers, int B, int N, int mode, int precis
                                 float flow_eps, dpf_stream_t stream) {
     return flow_forward_impl(n_layers, B, N, mode, precision, packed, meta, film, p_in, p_out, p_out_pointmajor, sum_logvar, ps,
                              mus, logvars, flow_eps, stream, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+// csrc-internal (flow_train.hip): one training-mode layer through dpf_flow_forward that also leaves the moments of the
+// output's channels ka / kb per workgroup in xs_part (tstats_x_kernel's layout, *xs_rows partial rows per cloud)
+int flow_forward_xstats(int B, int N, int mode, int precision, const void *packed, const int *meta, const float *film,
+                        const float *p_in, float *ps, float *mus, float *logvars, float flow_eps, dpf_stream_t stream,
+                        double *xs_part, int xs_ka, int xs_kb, int *xs_rows) {
+    return flow_forward_impl(1, B, N, mode, precision, packed, meta, film, p_in, ps, nullptr, nullptr, ps, mus, logvars, flow_eps,
+                             stream, nullptr, nullptr, nullptr, nullptr, nullptr, xs_part, xs_ka, xs_kb, xs_rows);
 }
 
 // dpf_flow_forward in DIRECT mode with the reparameterisation of the base sample fused into its prologue

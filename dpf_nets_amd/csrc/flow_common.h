@@ -134,4 +134,9 @@ __device__ __forceinline__ uint32_t input_weight_slot(float w, float T, int h, i
 __device__ __forceinline__ constexpr int acc_feature(int t, int r, int h) { return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 }  // namespace
+
+// csrc-internal: defined in flow.hip, used by flow_train.hip (see there)
+int flow_forward_xstats(int B, int N, int mode, int precision, const void *packed, const int *meta, const float *film,
+                        const float *p_in, float *ps, float *mus, float *logvars, float flow_eps, dpf_stream_t stream,
+                        double *xs_part, int xs_ka, int xs_kb, int *xs_rows);
 #endif  // DPF_FLOW_COMMON_H

@@ -1053,7 +1053,7 @@ struct TWork {
     float *part1, *pc, *s12, *part2, *dout, *ubuf, *coef;
 };
 static size_t carve(void *ws, int B, int N, TWork *w) {
-    const size_t nblk = (size_t)t_nblk(B, N), nbx = (size_t)B * ((N + 255) / 256);
+    const size_t nblk = (size_t)t_nblk(B, N), nbx = (size_t)B * ((N + TILE - 1) / TILE);   // the flow kernel's smallest workgroup is one tile
     uint8_t *p = (uint8_t *)ws;
     auto take = [&](size_t bytes) { uint8_t *q = p; p += (bytes + 255) / 256 * 256; return q; };
     uint8_t *xpart = take(nbx * 8 * sizeof(double));
@@ -1090,12 +1090,15 @@ extern "C" int dpf_flow_train_pack(int n_layers, int precision, const float *tca
 
 template <int NS>
 static int prepare_layer(int B, int N, int ka, int kb, const float *tcanon_l, void *packed_l, const float *fm_l,
-                         const float *p_in, float *stats_l, float *film_l, float flow_eps, void *workspace, hipStream_t s) {
+                         const float *p_in, float *stats_l, float *film_l, float flow_eps, void *workspace, hipStream_t s,
+                         int xrows) {
     TWork w;
     carve(workspace, B, N, &w);
-    const int nbx = (N + 255) / 256;
+    // moments of the layer's input: left behind by the previous layer's flow kernel (xrows partial rows per cloud), or
+    // computed here for the first layer of the call
+    const int nbx = xrows > 0 ? xrows : (N + 255) / 256;
     const double count = (double)B * N;
-    hipLaunchKernelGGL(tstats_x_kernel, dim3(nbx, B), dim3(256), 0, s, N, ka, kb, p_in, w.xpart);
+    if (xrows <= 0) hipLaunchKernelGGL(tstats_x_kernel, dim3(nbx, B), dim3(256), 0, s, N, ka, kb, p_in, w.xpart);
     TArgs a;
     a.packed_l = (const uint8_t *)packed_l; a.tcanon_l = tcanon_l; a.film_l = film_l; a.filmb_l = film_l + (size_t)B * 512;
     a.stats_l = stats_l; a.p_in = p_in; a.B = B; a.N = N; a.ka = ka; a.kb = kb; a.wa = 0; a.wb = 0; a.mode = 0;
@@ -1125,18 +1128,30 @@ static int flow_train_forward_direct(int n_layers, int B, int N, int mode, int p
     if (!ns || B > 65535) return DPF_ENOSUP;
     const size_t lst = (size_t)B * 3 * N, fls = dpf_flow_train_film_floats(B), fms = (size_t)4 * B * DPF_FLOW_F;
     const float *cur = p_in;
+    TWork w;
+    carve(workspace, B, N, &w);
+    int xrows = 0;                                   // partial rows per cloud the previous layer's kernel left in w.xpart
     for (int step = 0; step < n_layers; ++step) {
         const int l = mode == DPF_MODE_DIRECT ? step : n_layers - 1 - step;
         const int *m = meta_host + 4 * l;
         uint8_t *pk = (uint8_t *)packed + (size_t)l * pt_bytes(ns);
         float *film_l = film + l * fls;
         int rc = ns == 2 ? prepare_layer<2>(B, N, m[0], m[1], tcanon + (size_t)l * T_LAYER, pk, fm + l * fms, cur,
-                                            stats + (size_t)l * ST_LAYER, film_l, flow_eps, workspace, (hipStream_t)stream)
+                                            stats + (size_t)l * ST_LAYER, film_l, flow_eps, workspace, (hipStream_t)stream, xrows)
                          : prepare_layer<3>(B, N, m[0], m[1], tcanon + (size_t)l * T_LAYER, pk, fm + l * fms, cur,
-                                            stats + (size_t)l * ST_LAYER, film_l, flow_eps, workspace, (hipStream_t)stream);
+                                            stats + (size_t)l * ST_LAYER, film_l, flow_eps, workspace, (hipStream_t)stream, xrows);
         if (rc) return rc;
-        rc = dpf_flow_forward(1, B, N, mode, precision, pk, meta_dev + 4 * l, film_l, cur, ps + l * lst, nullptr, nullptr,
-                              ps + l * lst, mus + l * lst, logvars + l * lst, flow_eps, stream);
+        // the layer itself; its epilogue leaves the moments of the NEXT layer's kept coordinates (w.xpart was consumed by
+        // this layer's tstats_h1 above)
+        xrows = 0;
+        if (step + 1 < n_layers) {
+            const int *mnext = meta_host + 4 * (mode == DPF_MODE_DIRECT ? l + 1 : l - 1);
+            rc = flow_forward_xstats(B, N, mode, precision, pk, meta_dev + 4 * l, film_l, cur, ps + l * lst, mus + l * lst,
+                                     logvars + l * lst, flow_eps, stream, w.xpart, mnext[0], mnext[1], &xrows);
+        } else {
+            rc = dpf_flow_forward(1, B, N, mode, precision, pk, meta_dev + 4 * l, film_l, cur, ps + l * lst, nullptr, nullptr,
+                                  ps + l * lst, mus + l * lst, logvars + l * lst, flow_eps, stream);
+        }
         if (rc) return rc;
         cur = ps + l * lst;
     }
