@@ -454,39 +454,62 @@ __global__ __launch_bounds__(TW * 64) void tstats_h1_kernel(TArgs a, float *__re
     }
 }
 
-// BN1 batch statistics from the column sums, then this step's FiLM fold for one cloud:
+// BN1 batch statistics from tstats_h1's per-workgroup partials, then this step's FiLM fold:
 //   eval block  (csrc/flow.hip film layout): D = FC/FA, W2' = W2*FA, b2
 //   bwd block   a = eps + e^cw, c = cb, rstd1, c/a
-// sums: [br][2][64] doubles;  fm_l: [br][sub(w,b)][B][64]
-__global__ __launch_bounds__(128) void tfilm_fold_kernel(double count, const double *__restrict__ sums,
-                                                         const float *__restrict__ tcanon_l, const float *__restrict__ fm_l,
-                                                         int B, float eps, float *__restrict__ stats_l,
-                                                         float *__restrict__ film_l, float *__restrict__ filmb_l) {
-    const int b = blockIdx.x, br = threadIdx.x >> 6, f = threadIdx.x & 63;
-    const double mean = sums[(br * 2 + 0) * 64 + f] / count;
-    double var = sums[(br * 2 + 1) * 64 + f] / count - mean * mean;
-    if (var < 0) var = 0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)BN_EPS));
-    if (b == 0) {
-        float *st = stats_l + br * ST_BR;
-        st[2 * 64 + f] = (float)mean;
-        st[3 * 64 + f] = rstd;
-        st[5 * 64 + f] = (float)(var * (count / (count > 1 ? count - 1 : 1)));
+// part: (nrows, [br][2][64]) floats;  fm_l: [br][sub(w,b)][B][64]
+// One launch instead of a column-sum launch + a fold launch (a dependent tiny launch costs ~4.5 us): workgroup k owns 16
+// features of one branch -- its 32 columns (sum, sum of squares) are summed exactly as tcolsum_kernel does (32 row groups,
+// then the groups in order, doubles), then its threads fold (cloud, feature) items for all B clouds.
+__global__ __launch_bounds__(1024) void tfold_kernel(double count, int nrows, const float *__restrict__ part,
+                                                     const float *__restrict__ tcanon_l, const float *__restrict__ fm_l,
+                                                     int B, float eps, float *__restrict__ stats_l,
+                                                     float *__restrict__ film_l, float *__restrict__ filmb_l) {
+    __shared__ double acc[32][33];
+    __shared__ double tot[32];
+    const int br = blockIdx.x >> 2, f0 = (blockIdx.x & 3) * 16;
+    {
+        const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+        const int col = (br * 2 + (c >> 4)) * 64 + f0 + (c & 15);
+        double s = 0;
+        for (int r = rg; r < nrows; r += 32) s += part[(size_t)r * 256 + col];
+        acc[rg][c] = s;
+        __syncthreads();
+        if (rg == 0) {
+            double t = 0;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) t += acc[r][c];
+            tot[c] = t;
+        }
+        __syncthreads();
     }
-    const float cw = fm_l[((size_t)(br * 2 + 0) * B + b) * 64 + f], cb = fm_l[((size_t)(br * 2 + 1) * B + b) * 64 + f];
-    const float av = eps + expf(cw);
-    const float FA = av * rstd, FC = -av * (float)mean * rstd + cb;
     const float *cbp = tcanon_l + br * T_BR;
-    float *o = film_l + (size_t)b * (FILM_BYTES / 4) + br * FILM_BR_FLOATS;
-    o[f] = FC / FA;
-    o[64 + f] = cbp[T_W2 + f] * FA;
-    o[128 + f] = cbp[T_W2 + 64 + f] * FA;
-    if (f < 2) film_l[(size_t)b * (FILM_BYTES / 4) + FILM_B2_OFF + br * 2 + f] = cbp[T_B2 + f];
-    float *ob = filmb_l + (size_t)b * FB_CLOUD + br * FB_BR;
-    ob[0 * 64 + f] = av;
-    ob[1 * 64 + f] = cb;
-    ob[2 * 64 + f] = rstd;
-    ob[3 * 64 + f] = cb / av;
+    for (int item = threadIdx.x; item < B * 16; item += 1024) {
+        const int b = item >> 4, fl = item & 15, f = f0 + fl;
+        const double mean = tot[fl] / count;
+        double var = tot[16 + fl] / count - mean * mean;
+        if (var < 0) var = 0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)BN_EPS));
+        if (b == 0) {
+            float *st = stats_l + br * ST_BR;
+            st[2 * 64 + f] = (float)mean;
+            st[3 * 64 + f] = rstd;
+            st[5 * 64 + f] = (float)(var * (count / (count > 1 ? count - 1 : 1)));
+        }
+        const float cw = fm_l[((size_t)(br * 2 + 0) * B + b) * 64 + f], cb = fm_l[((size_t)(br * 2 + 1) * B + b) * 64 + f];
+        const float av = eps + expf(cw);
+        const float FA = av * rstd, FC = -av * (float)mean * rstd + cb;
+        float *o = film_l + (size_t)b * (FILM_BYTES / 4) + br * FILM_BR_FLOATS;
+        o[f] = FC / FA;
+        o[64 + f] = cbp[T_W2 + f] * FA;
+        o[128 + f] = cbp[T_W2 + 64 + f] * FA;
+        if (f < 2) film_l[(size_t)b * (FILM_BYTES / 4) + FILM_B2_OFF + br * 2 + f] = cbp[T_B2 + f];
+        float *ob = filmb_l + (size_t)b * FB_CLOUD + br * FB_BR;
+        ob[0 * 64 + f] = av;
+        ob[1 * 64 + f] = cb;
+        ob[2 * 64 + f] = rstd;
+        ob[3 * 64 + f] = cb / av;
+    }
 }
 
 // ===================================================================================================
@@ -1108,9 +1131,8 @@ static int prepare_layer(int B, int N, int ka, int kb, const float *tcanon_l, vo
     const dim3 grid((N + TBLK - 1) / TBLK, B);
     hipLaunchKernelGGL(tstats_h1_kernel<NS>, grid, dim3(TW * 64), pt_a0n(NS), s, a, w.part1, nbx * B, count, w.xpart,
                        (uint8_t *)packed_l + pt_a0(NS));
-    hipLaunchKernelGGL(tcolsum_kernel, dim3(8), dim3(1024), 0, s, (int)(grid.x * grid.y), 256, w.part1, w.sums);
-    hipLaunchKernelGGL(tfilm_fold_kernel, dim3(B), dim3(128), 0, s, count, w.sums, tcanon_l, fm_l, B, flow_eps, stats_l, film_l,
-                       film_l + (size_t)B * 512);
+    hipLaunchKernelGGL(tfold_kernel, dim3(8), dim3(1024), 0, s, count, (int)(grid.x * grid.y), w.part1, tcanon_l, fm_l, B, flow_eps,
+                       stats_l, film_l, film_l + (size_t)B * 512);
     return (int)hipGetLastError();
 }
 
