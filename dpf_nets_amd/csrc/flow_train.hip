@@ -250,6 +250,17 @@ __device__ __forceinline__ void input_mfma_swapped(const uint8_t *a0, int br, in
 // Swapped accumulators (lane = feature, registers = points) as bf16 hi/lo operand fragments whose K dimension is the
 // tile's 32 points: k-step j takes registers 8 j .. 8 j + 7 of the lane, i.e. k-slot i of lane-half kg holds point
 // (i & 3) + 8 (2 j + (i >> 2)) + 4 kg -- some fixed order of the k-step's 16 points, the same for every operand built here.
+// Symmetric hi/lo split of a pair: hi = bf16 round-to-nearest-even, lo = bf16(x - hi), signed.  The truncating split of the
+// forward path (split_hi: the remainder has the sign of x) leaves a lo.lo term of the sign of the product out of every
+// hi.hi + hi.lo + lo.hi contraction -- a bias of ~2^-18 per term that does not average out over a sum of 16 384 terms
+// (r02: the cancelling bias gradients of the deeper layers).  With a zero-mean remainder on the activation side the omitted
+// term is zero-mean.  Same six instructions per pair.  Backward-only operands: the forward recomputation keeps the forward
+// kernel's split, bit for bit.
+__device__ __forceinline__ void split_pair_sym(float v0, float v1, uint32_t &hi, uint32_t &lo) {
+    hi = pack_bf16_rne(v0, v1);
+    lo = pack_bf16_rne(v0 - u2f(hi << 16), v1 - u2f(hi & 0xFFFF0000u));
+}
+
 template <bool RELU>
 __device__ __forceinline__ void kfrags_from_swapped(const f32x16 (&v)[2], u32x4 (&hi)[2][2], u32x4 (&lo)[2][2]) {
 #pragma unroll
@@ -260,10 +271,10 @@ __device__ __forceinline__ void kfrags_from_swapped(const f32x16 (&v)[2], u32x4 
             for (int d = 0; d < 4; ++d) {
                 const float v0 = RELU ? relu(v[t][8 * j2 + 2 * d]) : v[t][8 * j2 + 2 * d];
                 const float v1 = RELU ? relu(v[t][8 * j2 + 2 * d + 1]) : v[t][8 * j2 + 2 * d + 1];
-                float l0, l1;
-                split_hi(v0, l0); split_hi(v1, l1);
-                hi[t][j2][d] = pack_bf16_trunc(v0, v1);
-                lo[t][j2][d] = pack_bf16_rne(l0, l1);
+                uint32_t hp, lp;
+                split_pair_sym(v0, v1, hp, lp);
+                hi[t][j2][d] = hp;
+                lo[t][j2][d] = lp;
             }
 }
 
@@ -271,7 +282,7 @@ __device__ __forceinline__ void kfrags_from_swapped(const f32x16 (&v)[2], u32x4 
 // (register r of M tile t = element j = r&7 of k-step 2t + (r>>3)); RELU = clamp at zero first.
 // Same arithmetic as branch_tile in csrc/flow.hip: the recomputed activations are bit-identical to
 // the forward kernel's.
-template <bool RELU, int NS>
+template <bool RELU, int NS, bool SYM = false>
 __device__ __forceinline__ void split_fragment(const f32x16 (&v)[2], u32x4 (&bf)[NS][4]) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -279,6 +290,14 @@ __device__ __forceinline__ void split_fragment(const f32x16 (&v)[2], u32x4 (&bf)
         for (int r = 0; r < 16; r += 2) {
             const float v0 = RELU ? relu(v[t][r]) : v[t][r], v1 = RELU ? relu(v[t][r + 1]) : v[t][r + 1];
             const int s = 2 * t + (r >> 3), d = (r & 7) >> 1;
+            if constexpr (SYM) {               // backward-only operand (NS == 2): symmetric split
+                static_assert(!SYM || NS == 2, "symmetric split: hi/lo only");
+                uint32_t hp, lp;
+                split_pair_sym(v0, v1, hp, lp);
+                bf[0][s][d] = hp;
+                bf[NS - 1][s][d] = lp;
+                continue;
+            }
             float l0, l1;
             split_hi(v0, l0); split_hi(v1, l1);
             bf[0][s][d] = pack_bf16_trunc(v0, v1);
@@ -528,6 +547,81 @@ __device__ __forceinline__ float dh2a_of(float pre, float w2a, float w2b, float 
     return pre > 0.f ? w2a * doa + w2b * dob : 0.f;
 }
 
+constexpr int P2_J = 4352;       // floats of a workgroup's pass-2 partial row per branch (layout: tbwd2_kernel)
+// Totals of pass 2 of a layer -> the coefficients of the conditioner path of its input gradient,
+//   dx_k[pt] = u_k[pt] - coef[4k] - coef[4k+1] x_a - coef[4k+2] x_b   (see tbwd3f_kernel),
+// left in LDS (`coef`, 8 floats; `acc` is 8 KiB of scratch); EVERY workgroup of the caller runs this (128 threads of double
+// arithmetic, same operations in the same order, so the same bits), workgroup 0 also writes d gamma0 / d beta0 / dW0 and
+// the dW1 totals are converted by whoever comes first (grid-stride).  Ends with a workgroup barrier.
+__device__ __forceinline__ void bwd3_coefs(int blk, int nblk, int nk, double count, const double *__restrict__ tot,
+                                           const float *__restrict__ tcanon_l, const float *__restrict__ stats_l,
+                                           float *__restrict__ dcanon_l, double (*acc)[4][128], float *coef) {
+    const int nth = blockDim.x;
+    for (int i = blk * nth + threadIdx.x; i < 2 * 4096; i += nblk * nth) {   // dW1: (2, 4096) totals -> dcanon
+        const int b2 = i >> 12, j = i & 4095;
+        dcanon_l[b2 * T_BR + T_W1 + j] = (float)tot[(size_t)b2 * P2_J + 128 + j];
+    }
+    if (threadIdx.x < 128) {
+        const int br = threadIdx.x >> 6, f = threadIdx.x & 63;
+        const double *t = tot + (size_t)br * P2_J;
+        const float *cb = tcanon_l + br * T_BR;
+        const double Sg = t[f], S = t[64 + f], Sa = t[4224 + f], Sb = t[4288 + f];
+        const float *m = stats_l + ST_MOM;
+        const double ea = m[0], eb = m[1], caa = m[2], cbb = m[3], cab = m[4];
+        const double wa = cb[T_W0 + f * nk], wb = nk == 2 ? cb[T_W0 + f * 2 + 1] : 0.0, gamma = cb[T_G0 + f];
+        const double rstd0 = stats_l[br * ST_BR + 64 + f], mean0 = stats_l[br * ST_BR + f];
+        const double A = S / count, Bc = Sg / count;
+        const double hxa = rstd0 * (wa * caa + wb * cab), hxb = rstd0 * (wa * cab + wb * cbb);     // E[h0n x_k]
+        const double sc = rstd0 * gamma;
+        if (blk == 0) {
+            dcanon_l[br * T_BR + T_G0 + f] = (float)Sg;
+            dcanon_l[br * T_BR + T_B0 + f] = (float)S;
+            dcanon_l[br * T_BR + T_W0 + f * nk] = (float)(sc * (Sa - A * ea * count - Bc * hxa * count));
+            if (nk == 2) dcanon_l[br * T_BR + T_W0 + f * 2 + 1] = (float)(sc * (Sb - A * eb * count - Bc * hxb * count));
+            else dcanon_l[br * T_BR + T_W0 + 64 + f] = 0.f;
+        }
+        const double ck[2] = {wa * sc, wb * sc};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            acc[k][0][threadIdx.x] = ck[k] * A;
+            acc[k][1][threadIdx.x] = ck[k] * Bc * rstd0 * wa;
+            acc[k][2][threadIdx.x] = ck[k] * Bc * rstd0 * wb;
+            acc[k][3][threadIdx.x] = ck[k] * Bc * rstd0 * mean0;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const int k = threadIdx.x >> 2, q = threadIdx.x & 3;
+        double s = 0;
+        for (int i = 0; i < 128; ++i) s += acc[k][q][i];
+        acc[k][q][0] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const int k = threadIdx.x;
+        coef[k * 4 + 0] = (float)(acc[k][0][0] - acc[k][3][0]);
+        coef[k * 4 + 1] = (float)acc[k][1][0];
+        coef[k * 4 + 2] = (float)acc[k][2][0];
+    }
+    __syncthreads();
+}
+
+// u_k - C_k - alpha_k x_a - beta_k x_b, every operation rounded on its own (no contraction: pass 3 as its own launch
+// and pass 3 inside the next layer's pass 1 must agree bit for bit)
+__device__ __forceinline__ float cond_path(float u, float c0, float c1, float c2, float xa, float xb) {
+    return __fsub_rn(__fsub_rn(__fsub_rn(u, c0), __fmul_rn(c1, xa)), __fmul_rn(c2, xb));
+}
+
+// the layer whose input gradient's conditioner path the NEXT backward layer's pass 1 finishes (instead of a tbwd3f launch)
+struct PrevLayer {
+    const double *tot;           // its pass-2 totals
+    const float *tcanon_l, *stats_l, *ubuf;
+    const float *x;              // its input points = the output of the layer at hand
+    float *dcanon_l;
+    double count;
+    int ka, kb, has;
+};
+
 // Pass 1: recompute the layer to h2, differentiate the coupling transform and the output SharedDot.
 //   stores  dout (B,4,N) = d(o_logvar a,b), d(o_mu a,b)         dp_in <- direct term  g * d(p_out)/d(p)
 //   partial sums per workgroup: part1[blk][br][k][64], k = 0 dW2a, 1 dW2b, 2 da, 3 dc;  part1[blk][512 + br*2 + w] = db2
@@ -537,7 +631,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
                                                         const float *__restrict__ g_mu, const float *__restrict__ g_lv,
                                                         const float *__restrict__ mu_l, const float *__restrict__ lv_l,
                                                         float *__restrict__ dp_in, float *__restrict__ dout,
-                                                        float *__restrict__ part1) {
+                                                        float *__restrict__ part1, PrevLayer pv) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int L_FILM = pt_a0n(NS), L_FILMB = L_FILM + 2048, L_RED = L_FILMB + 2048;
     float *red = (float *)(smem + L_RED);                                  // per wave [2 br][4][64] + [2][2] (+4 pad)
@@ -550,6 +644,10 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
     stage_bytes((const uint8_t *)(a.filmb_l + (size_t)bi * FB_CLOUD), smem + L_FILMB, 2048, wave, lane);
     float *w2s = red + TW * 520;                                                // [2 br][2][64] raw sd2.weight
     if (threadIdx.x < 256) w2s[threadIdx.x] = a.tcanon_l[(threadIdx.x >> 7) * T_BR + T_W2 + (threadIdx.x & 127)];
+    float *pcoef = w2s + 256 + TW * 64;                                         // 8 floats behind the per-wave scratch
+    if (pv.has)   // the previous backward layer's pass 3, under the weight DMA (scratch: the reduction slots, free until the end)
+        bwd3_coefs(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, pv.kb >= 0 ? 2 : 1, pv.count, pv.tot, pv.tcanon_l,
+                   pv.stats_l, pv.dcanon_l, (double (*)[4][128])red, pcoef);
     const int N = a.N, n = (blockIdx.x * TW + wave) * TILE + pl;
     const bool valid = n < N;
     const int nc = valid ? n : N - 1;
@@ -561,9 +659,24 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
         p[c] = a.p_in[o];
         mus[c] = mu_l[o];                                                   // the forward pass's own outputs of this layer
         lvs[c] = lv_l[o];
-        gp[c] = valid ? (g_p ? g_p[o] : 0.f) + (g_p2 ? g_p2[o] : 0.f) : 0.f;
+        gp[c] = g_p2 ? g_p2[o] : 0.f;                                       // what the layer above passes down (direct term so far)
         gm[c] = valid && g_mu ? g_mu[o] : 0.f;
         gl[c] = valid && g_lv ? g_lv[o] : 0.f;
+    }
+    if (pv.has) {   // + the conditioner path of the layer above: dx_k = u_k - C_k - alpha_k x_a - beta_k x_b on ITS kept channels
+        const float *xc = pv.x + cloud;
+        const float xa2 = xc[(size_t)pv.ka * N + nc], xb2 = pv.kb >= 0 ? xc[(size_t)pv.kb * N + nc] : 0.f;
+        // every operation rounded on its own, in tbwd3f_kernel's order (the two launch forms give the same bits)
+        const float ta = cond_path(pv.ubuf[((size_t)bi * 2 + 0) * N + nc], pcoef[0], pcoef[1], pcoef[2], xa2, xb2);
+        const float tb = pv.kb >= 0 ? cond_path(pv.ubuf[((size_t)bi * 2 + 1) * N + nc], pcoef[4], pcoef[5], pcoef[6], xa2, xb2) : 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            if (c == pv.ka || c == pv.kb) gp[c] = __fadd_rn(gp[c], c == pv.ka ? ta : tb);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const size_t o = cloud + (size_t)c * N + nc;
+        gp[c] = valid ? __fadd_rn(g_p ? g_p[o] : 0.f, gp[c]) : 0.f;
     }
     const float xa = sel3(a.ka, p[0], p[1], p[2]), xb = a.kb >= 0 ? sel3(a.kb, p[0], p[1], p[2]) : 0.f;
     const u32x4 b0 = input_fragment(h ? xb : xa, h);
@@ -701,7 +814,6 @@ __global__ __launch_bounds__(520) void tcloudsum_kernel(int nb, int B, const flo
 //   part2[blk][br][P2_J]: [0..63] sum dh0a*h0n (d gamma0), [64..127] sum dh0a (d beta0), [128..4223] dW1
 //                         (row = out feature), [4224..4287] sum dh0a*x_a, [4288..4351] sum dh0a*x_b
 //   ubuf (B,2,N): u_k = sum over both branches and all features of W0[f][k]*rstd0*gamma0 * dh0a[f]
-constexpr int P2_J = 4352;
 #ifdef DPF_PROFILE
 __device__ unsigned long long *g_tprof = nullptr;
 #define TP(i) { __builtin_amdgcn_sched_barrier(0); if (br == 0) tt[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
@@ -858,7 +970,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
                     dn[t] = mfma(xl[t][j2], eye[j2], dn[t]);
                 }
             }
-            split_fragment<false, 2>(dn, bg);
+            split_fragment<false, 2, true>(dn, bg);
         }
         {
             f32x16 dh0a[2] = {zero16(), zero16()};
@@ -996,61 +1108,15 @@ __global__ __launch_bounds__(256) void tbwd3f_kernel(int N, int ka, int kb, int 
                                                      const float *__restrict__ ubuf, float *__restrict__ dp_in) {
     __shared__ double acc[2][4][128];
     __shared__ float coef[8];
-    const int blk = blockIdx.y * gridDim.x + blockIdx.x, nblk = gridDim.x * gridDim.y;
-    for (int i = blk * 256 + threadIdx.x; i < 2 * 4096; i += nblk * 256) {   // dW1: (2, 4096) totals -> dcanon
-        const int b2 = i >> 12, j = i & 4095;
-        dcanon_l[b2 * T_BR + T_W1 + j] = (float)tot[(size_t)b2 * P2_J + 128 + j];
-    }
-    if (threadIdx.x < 128) {
-        const int br = threadIdx.x >> 6, f = threadIdx.x & 63;
-        const double *t = tot + (size_t)br * P2_J;
-        const float *cb = tcanon_l + br * T_BR;
-        const double Sg = t[f], S = t[64 + f], Sa = t[4224 + f], Sb = t[4288 + f];
-        const float *m = stats_l + ST_MOM;
-        const double ea = m[0], eb = m[1], caa = m[2], cbb = m[3], cab = m[4];
-        const double wa = cb[T_W0 + f * nk], wb = nk == 2 ? cb[T_W0 + f * 2 + 1] : 0.0, gamma = cb[T_G0 + f];
-        const double rstd0 = stats_l[br * ST_BR + 64 + f], mean0 = stats_l[br * ST_BR + f];
-        const double A = S / count, Bc = Sg / count;
-        const double hxa = rstd0 * (wa * caa + wb * cab), hxb = rstd0 * (wa * cab + wb * cbb);     // E[h0n x_k]
-        const double sc = rstd0 * gamma;
-        if (blk == 0) {
-            dcanon_l[br * T_BR + T_G0 + f] = (float)Sg;
-            dcanon_l[br * T_BR + T_B0 + f] = (float)S;
-            dcanon_l[br * T_BR + T_W0 + f * nk] = (float)(sc * (Sa - A * ea * count - Bc * hxa * count));
-            if (nk == 2) dcanon_l[br * T_BR + T_W0 + f * 2 + 1] = (float)(sc * (Sb - A * eb * count - Bc * hxb * count));
-            else dcanon_l[br * T_BR + T_W0 + 64 + f] = 0.f;
-        }
-        const double ck[2] = {wa * sc, wb * sc};
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            acc[k][0][threadIdx.x] = ck[k] * A;
-            acc[k][1][threadIdx.x] = ck[k] * Bc * rstd0 * wa;
-            acc[k][2][threadIdx.x] = ck[k] * Bc * rstd0 * wb;
-            acc[k][3][threadIdx.x] = ck[k] * Bc * rstd0 * mean0;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 8) {
-        const int k = threadIdx.x >> 2, q = threadIdx.x & 3;
-        double s = 0;
-        for (int i = 0; i < 128; ++i) s += acc[k][q][i];
-        acc[k][q][0] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < 2) {
-        const int k = threadIdx.x;
-        coef[k * 4 + 0] = (float)(acc[k][0][0] - acc[k][3][0]);
-        coef[k * 4 + 1] = (float)acc[k][1][0];
-        coef[k * 4 + 2] = (float)acc[k][2][0];
-    }
-    __syncthreads();
+    bwd3_coefs(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, nk, count, tot, tcanon_l, stats_l, dcanon_l, acc, coef);
     const int bi = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     const float *pc = p_in + (size_t)bi * 3 * N;
     float *d = dp_in + (size_t)bi * 3 * N;
     const float xa = pc[(size_t)ka * N + n], xb = kb >= 0 ? pc[(size_t)kb * N + n] : 0.f;
-    d[(size_t)ka * N + n] += ubuf[((size_t)bi * 2 + 0) * N + n] - coef[0] - coef[1] * xa - coef[2] * xb;
-    if (kb >= 0) d[(size_t)kb * N + n] += ubuf[((size_t)bi * 2 + 1) * N + n] - coef[4] - coef[5] * xa - coef[6] * xb;
+    d[(size_t)ka * N + n] = __fadd_rn(d[(size_t)ka * N + n], cond_path(ubuf[((size_t)bi * 2 + 0) * N + n], coef[0], coef[1], coef[2], xa, xb));
+    if (kb >= 0)
+        d[(size_t)kb * N + n] = __fadd_rn(d[(size_t)kb * N + n], cond_path(ubuf[((size_t)bi * 2 + 1) * N + n], coef[4], coef[5], coef[6], xa, xb));
 }
 
 
@@ -1205,7 +1271,7 @@ template <int NS>
 static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb, const float *tcanon_l, const void *packed_l,
                           const float *film_l, const float *stats_l, const float *p_in, const float *mu_l, const float *lv_l,
                           const float *g_p, const float *g_p2, const float *g_mu, const float *g_lv, float *dp_in, float *dcanon_l,
-                          float *dfm_l, float flow_eps, void *workspace, hipStream_t s) {
+                          float *dfm_l, float flow_eps, void *workspace, hipStream_t s, PrevLayer *pv, bool last) {
     TWork w;
     carve(workspace, B, N, &w);
     TArgs a;
@@ -1215,16 +1281,21 @@ static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb
     const dim3 grid((N + TBLK - 1) / TBLK, B);
     const int nblk = grid.x * grid.y, nb = grid.x;
     const double count = (double)B * N;
-    const int lds1 = pt_a0n(NS) + 4096 + (TW * 520 + 256 + TW * 64) * 4, lds2 = l_red(NS) + 4096 + TW * XY_WAVE * 2;
+    const int lds1 = pt_a0n(NS) + 4096 + (TW * 520 + 256 + TW * 64 + 8) * 4, lds2 = l_red(NS) + 4096 + TW * XY_WAVE * 2;
     static LdsLimit lim_b1, lim_b2;
     if (hipError_t e = lim_b1.ensure((const void *)tbwd1_kernel<NS>, lds1); e != hipSuccess) return (int)e;
     if (hipError_t e = lim_b2.ensure((const void *)tbwd2_kernel<NS>, lds2); e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(tbwd1_kernel<NS>, grid, dim3(TW * 64), lds1, s, a, g_p, g_p2, g_mu, g_lv, mu_l, lv_l, dp_in, w.dout, w.part1);
+    hipLaunchKernelGGL(tbwd1_kernel<NS>, grid, dim3(TW * 64), lds1, s, a, g_p, g_p2, g_mu, g_lv, mu_l, lv_l, dp_in, w.dout, w.part1, *pv);
     hipLaunchKernelGGL(tcloudsum_kernel, dim3(B), dim3(520), 0, s, nb, B, w.part1, a.filmb_l, flow_eps, w.pc, dfm_l);
     hipLaunchKernelGGL(tbwd2_kernel<NS>, grid, dim3(TW * 64), lds2, s, a, w.pc, count, dcanon_l, w.dout, w.ubuf, w.part2);
     hipLaunchKernelGGL(tcolsum_kernel, dim3((2 * P2_J + 31) / 32), dim3(1024), 0, s, nblk, 2 * P2_J, w.part2, w.tot2);
-    hipLaunchKernelGGL(tbwd3f_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, N, ka, kb, kb >= 0 ? 2 : 1, count, w.tot2, tcanon_l,
-                       stats_l, dcanon_l, p_in, w.ubuf, dp_in);
+    // pass 3 (the conditioner path of d(input points), d gamma0 / d beta0 / dW0 / dW1 from the totals): folded into the NEXT
+    // backward layer's pass 1, which needs that gradient anyway; only the last layer of the call launches it
+    if (last)
+        hipLaunchKernelGGL(tbwd3f_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, N, ka, kb, kb >= 0 ? 2 : 1, count, w.tot2,
+                           tcanon_l, stats_l, dcanon_l, p_in, w.ubuf, dp_in);
+    pv->tot = w.tot2; pv->tcanon_l = tcanon_l; pv->stats_l = stats_l; pv->ubuf = w.ubuf; pv->x = p_in; pv->dcanon_l = dcanon_l;
+    pv->count = count; pv->ka = ka; pv->kb = kb; pv->has = 1;
     return (int)hipGetLastError();
 }
 
@@ -1244,6 +1315,7 @@ static int backward_stack(int n_layers, int B, int N, int mode, int precision, c
     if (!ns || B > 65535) return DPF_ENOSUP;
     const size_t lst = (size_t)B * 3 * N, fls = dpf_flow_train_film_floats(B), fms = (size_t)4 * B * DPF_FLOW_F;
     const float *chain = nullptr;
+    PrevLayer pv = {};
     for (int step = n_layers - 1; step >= 0; --step) {
         const int l = mode == DPF_MODE_DIRECT ? step : n_layers - 1 - step;
         const int lprev = mode == DPF_MODE_DIRECT ? step - 1 : n_layers - step;       // layer whose output fed layer l
@@ -1254,7 +1326,7 @@ static int backward_stack(int n_layers, int B, int N, int mode, int precision, c
     backward_layer<NSV>(B, N, mode, m[0], m[1], m[2], m[3], tcanon + (size_t)l * T_LAYER,                               \
                         (const uint8_t *)packed + (size_t)l * pt_bytes(NSV), film + l * fls, stats + (size_t)l * ST_LAYER, pin, \
                         mus + l * lst, logvars + l * lst, grad_of(0, l), chain, grad_of(1, l), grad_of(2, l), out,       \
-                        dcanon + (size_t)l * T_LAYER, dfm + l * fms, flow_eps, workspace, (hipStream_t)stream)
+                        dcanon + (size_t)l * T_LAYER, dfm + l * fms, flow_eps, workspace, (hipStream_t)stream, &pv, step == 0)
         const int rc = ns == 2 ? DPF_BWD(2) : DPF_BWD(3);
 #undef DPF_BWD
         if (rc) return rc;
