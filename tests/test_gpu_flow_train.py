@@ -10,8 +10,10 @@ Tolerance: ONE layer: outputs rel <= 1e-4 of the tensor's scale (north star; mea
 gradients rel <= 1e-3 of the gradient tensor's scale (measured ~2e-5; they pass through two BatchNorm
 backward reductions over all B*N points).  A STACK of training-mode layers amplifies any perturbation
 of a layer's output by ~1.3x per layer -- fp32 itself goes from 5e-7 after one layer to 2.3e-6 after
-six against float64 (tests/diag/train_dbg2.py) -- so the 6-layer stacks are held to 5e-4 on outputs and
-2e-3 on gradients."""
+six against float64 (tests/diag/train_dbg2.py).  At the default training precision (bf16x6) the 6-layer
+stacks are nevertheless held to the one-layer bars, 1e-4 on outputs and 1e-3 on gradients (measured against
+float64: outputs 2e-6..8e-6, gradients 2e-5..4e-4, profiles/r02_train_error_budget.json); the opt-in bf16x3 gets
+5e-4 / 2e-3."""
 import json
 import os
 
@@ -26,8 +28,7 @@ pytestmark = pytest.mark.gpu
 
 OUT_REL = 1e-4
 GRAD_REL = 1e-3
-STACK_OUT_REL = 5e-4     # six layers
-STACK_GRAD_REL = 2e-3
+STACK_TOL = {"bf16x6": (1e-4, 1e-3), "bf16x3": (5e-4, 2e-3)}     # six layers: (outputs, gradients)
 
 
 def _gpu():
@@ -114,6 +115,7 @@ def test_decoder_training_step_vs_reference_golden(golden_dir, prec):
     """training.py:37-55: inverse flow + PointFlowNLL + backward, n_flows = 2 (6 coupling layers)."""
     nets = _gpu()
     kf, loose = (2e-4, 1.0) if prec == "bf16x6" else (3e-2, 10.0)   # 384 points: one flipped ReLU moves every sum
+    STACK_OUT_REL, STACK_GRAD_REL = STACK_TOL[prec]
     gold, meta = _load(golden_dir, "flow_decoder")
     case = [c for c in meta["cases"] if c.get("bn") == "train"][0]
     c, n_flows, B, N, G, seed = (case[k] for k in ("tag", "n_flows", "B", "N", "G", "seed"))
@@ -161,6 +163,7 @@ def test_training_hip_vs_tensor_op_path(B, N, mode, prec):
     dh0 = W1^T dh1 contraction, which runs as a hi/lo split (~1e-5 per term) at either precision."""
     nets = _gpu()
     kf, loose = (2e-4, 1.0) if prec == "bf16x6" else (1e-2, 10.0)
+    STACK_OUT_REL, STACK_GRAD_REL = STACK_TOL[prec]
     n_flows, G, seed = 2, 128, 31
     sd = FO.to_torch(FO.make_decoder_state(seed, n_flows, 64, G))
     tgt, z, g = FO.synthetic_inputs(seed, B, N, G)
@@ -425,7 +428,7 @@ def test_training_stack_error_budget_vs_float64(golden_dir):
       outputs (ps[0], sum of logvars, loss): HIP (bf16x6 forward) <= 2 x the fp32 path's error (floor 1e-6: both are at the
         rounding level of fp32 there);
       gradients (d/dp, d/dg, every parameter): HIP <= 6 x the fp32 path's error.  Measured r02 on the golden case: d/dp
-        6.0e-5 vs 1.8e-5, d/dg 2.1e-5 vs 5.5e-6, worst parameter gradient 9.9e-5 vs 2.0e-5 -- the factor 3-5 is the hi/lo
+        8.2e-5 vs 1.8e-5, d/dg 1.7e-5 vs 5.5e-6, worst parameter gradient 1.0e-4 vs 2.0e-5 -- the factor 3-5 is the hi/lo
         bf16 split of the gradient contractions (dh0 = W1^T dh1, dW1 = dh1 h0^T: 16 significant bits per operand; DESIGN
         4.6), not the forward (bf16x6, at fp32's own level); fp16 parts as in the eval kernel would close it."""
     nets = _gpu()
