@@ -92,9 +92,9 @@ def parse(argv=None):
     args = ap.parse_args(argv)
     cfg = CONFIGS[args.config]
     if args.steps is None:
-        args.steps = {"cfg5": 10}.get(args.config, 1000) if args.leg == "eval" else 20
+        args.steps = {"cfg5": 10}.get(args.config, 1000) if args.leg == "eval" else 40
     if args.warmup is None:
-        args.warmup = {"cfg5": 3}.get(args.config, 300) if args.leg == "eval" else 5
+        args.warmup = {"cfg5": 3}.get(args.config, 300) if args.leg == "eval" else 12   # train: the allocator settles and the stack's calls become graph replays within ~10 steps
     if args.settle is None:
         args.settle = 400 if (args.leg == "eval" and args.config != "cfg5") else 0
     if args.points is None:
@@ -820,7 +820,7 @@ def main(argv=None):
             # the 40 / 52 MB flat gradient over xGMI (every rank takes part; reported by rank 0)
             try:
                 batch, _ = clouds_of_rank(args, rank, world)
-                extra["train_step"] = train_step_leg(args, rank, world, dist, device, batch, 63, args.train_steps, 3)
+                extra["train_step"] = train_step_leg(args, rank, world, dist, device, batch, 63, args.train_steps, 10)
             except Exception as e:       # noqa: BLE001 -- never lose the headline line to an extra
                 extra["train_step_error"] = repr(e)
     if rank == 0:
