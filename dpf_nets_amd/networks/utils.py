@@ -104,3 +104,82 @@ def emd_approx(sample, ref):
     B, N, N_ref = sample.size(0), sample.size(1), ref.size(1)
     assert N == N_ref, "Not sure what would EMD do in this case"
     return match_cost(sample, ref) / float(N)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# The consumers of pairwise_CD in the reference's generative evaluation (evaluating.py:245-262): coverage, minimum matching
+# distance and the 1-NN two-sample accuracy over the (N1, N2) Chamfer matrices, the voxel-occupancy Jensen-Shannon divergence
+# over the clouds themselves, and the running-average helper of both loops.  Same names, arguments and values as
+# lib/networks/utils.py:8-22, 45-87, 120-146; tensor / numpy plumbing, no kernels.
+# ----------------------------------------------------------------------------------------------------------------
+class AverageMeter:
+    """lib/networks/utils.py:8-22: last value, running sum / count / mean."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+def COV(dists, axis=1):
+    """Coverage (utils.py:120-121): the share of the clouds along `axis` that are the nearest neighbour of some cloud of the
+    other set."""
+    nearest = torch.argmin(dists, dim=axis)
+    return float(torch.unique(nearest).numel()) / float(dists.shape[axis])
+
+
+def MMD(dists, axis=1):
+    """Minimum matching distance (utils.py:124-125): every cloud along `axis` to its nearest cloud of the other set, averaged."""
+    return float(torch.amin(dists, dim=(axis + 1) % 2).float().mean())
+
+
+def KNN(Mxx, Mxy, Myy, k, sqrt=False):
+    """Leave-one-out k-NN two-sample accuracy (utils.py:128-146): the two sets are labelled -1 / +1, every cloud is classified
+    by the sign of the label sum of its k nearest other clouds (ties go to +1); returns the share classified correctly."""
+    n0, n1 = Mxx.shape[0], Myy.shape[0]
+    label = torch.cat((-torch.ones(n0), torch.ones(n1))).to(Mxx)
+    M = torch.cat((torch.cat((Mxx, Mxy), 1), torch.cat((Mxy.t(), Myy), 1)), 0)
+    if sqrt:
+        M = M.abs().sqrt()
+    M = M + torch.diag(torch.full((n0 + n1,), float("inf")).to(Mxx))       # a cloud is not its own neighbour
+    idx = torch.topk(M, k, dim=0, largest=False).indices                   # (k, n0 + n1): neighbours of every column
+    votes = label[idx].sum(0)
+    pred = torch.where(votes >= 0, torch.ones_like(votes), -torch.ones_like(votes))
+    return float((pred == label).float().mean())
+
+
+def get_voxel_occ_dist(all_clouds, clouds_flag='gen', res=28, bound=0.5, bs=128, warning=True):
+    """Occupancy distribution of the points of all clouds over the res^3 voxels of [-0.5, 0.5)^3 (utils.py:45-80).
+    all_clouds: (K, n, 3) numpy array.  A point outside the cube (or NaN) is not counted.  The bin edges are the reference's
+    doubles -0.5 + i / res and the intervals half-open on the right, so every point lands in the voxel the reference
+    picks; the counting is one bincount instead of batched comparison tables (`bs` is accepted and ignored)."""
+    import numpy as np
+    all_clouds = np.asarray(all_clouds)
+    if np.any(np.fabs(all_clouds) > bound) and warning:
+        print('{} clouds out of cube bounds: [-{}; {}]'.format(clouds_flag, bound, bound))
+    n_nans = np.isnan(all_clouds).sum()
+    if n_nans > 0:
+        print('{} NaN values in point cloud tensors.'.format(n_nans))
+    edges = -0.5 + np.arange(res + 1) * (1. / res)
+    pts = all_clouds.reshape(-1, 3)
+    cell = np.searchsorted(edges, pts, side='right') - 1                    # edges[c] <= x < edges[c + 1]; NaN sorts past the end
+    inside = np.all((cell >= 0) & (cell < res), axis=1)
+    cell = cell[inside]
+    flat = (cell[:, 0] * res + cell[:, 1]) * res + cell[:, 2]
+    counts = np.bincount(flat, minlength=res ** 3).astype(np.uint64).reshape(res, res, res)
+    return np.float64(counts) / counts.sum()
+
+
+def JSD(clouds1, clouds2, clouds1_flag='gen', clouds2_flag='ref', warning=True):
+    """Jensen-Shannon divergence (base 2) between the voxel occupancy distributions of two sets of clouds (utils.py:83-87)."""
+    from scipy.stats import entropy
+    d1 = get_voxel_occ_dist(clouds1, clouds_flag=clouds1_flag, warning=warning).flatten()
+    d2 = get_voxel_occ_dist(clouds2, clouds_flag=clouds2_flag, warning=warning).flatten()
+    return entropy((d1 + d2) / 2.0, base=2) - 0.5 * (entropy(d1, base=2) + entropy(d2, base=2))

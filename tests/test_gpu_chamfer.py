@@ -278,3 +278,34 @@ def test_nndistance_cd_ticket_finish_under_load():
     assert bad == 0, bad
     for ws in BK._CD_WORKSPACES.values():
         assert int(ws[:4 * B].view(torch.int32).abs().sum()) == 0        # tickets left at zero
+
+
+def test_generative_evaluation_fragment_on_the_mirror():
+    """evaluating.py:245-257 with the mirror's utils: three pairwise_CD matrices on the GPU -> COV, MMD, 1-NN accuracy; JSD of
+    the clouds.  The matrices against the oracle's per-pair Chamfer (expand-and-call form), the metrics computed from the
+    device matrices against the same functions on the oracle's matrices (exact: they are order statistics of the entries
+    unless two entries tie within the matrices' 2e-6 agreement, which these continuous inputs do not)."""
+    _gpu()
+    from dpf_nets_amd.networks import utils as U
+    Ng, Nr, n = 11, 8, 160
+    gen = detrng.normal_f32(701, (Ng, n, 3), 0.0, 0.12)
+    ref = (detrng.normal_f32(702, (Nr, n, 3), 0.0, 0.15) + np.float32(0.03)).astype(np.float32)
+    tg, tr = torch.from_numpy(gen).cuda(), torch.from_numpy(ref).cuda()
+    gg, tt, gt = U.pairwise_CD(tg, tg), U.pairwise_CD(tr, tr), U.pairwise_CD(tg, tr)
+
+    def oracle_matrix(a, b):
+        out = np.zeros((a.shape[0], b.shape[0]), np.float32)
+        for i in range(a.shape[0]):
+            d1, _, d2, _ = S.nndistance(np.ascontiguousarray(np.broadcast_to(a[i], (b.shape[0],) + a.shape[1:])), b)
+            out[i] = d1.mean(1) + d2.mean(1)
+        return out
+    ogg, ott, ogt = oracle_matrix(gen, gen), oracle_matrix(ref, ref), oracle_matrix(gen, ref)
+    for got, want in ((gg, ogg), (tt, ott), (gt, ogt)):
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=3e-6, atol=1e-9)
+    o = [torch.from_numpy(x) for x in (ogg, ogt, ott)]
+    assert U.COV(gt) == U.COV(o[1]) and U.COV(gt, axis=0) == U.COV(o[1], axis=0)
+    assert abs(U.MMD(gt) - U.MMD(o[1])) <= 3e-6 * U.MMD(o[1])
+    for k in (1, 3):
+        assert U.KNN(gg, gt, tt, k) == U.KNN(o[0], o[1], o[2], k)
+    jsd = U.JSD(tg.cpu().numpy(), tr.cpu().numpy(), warning=False)
+    assert 0.0 < jsd < 1.0
