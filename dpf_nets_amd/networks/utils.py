@@ -183,3 +183,14 @@ def JSD(clouds1, clouds2, clouds1_flag='gen', clouds2_flag='ref', warning=True):
     d1 = get_voxel_occ_dist(clouds1, clouds_flag=clouds1_flag, warning=warning).flatten()
     d2 = get_voxel_occ_dist(clouds2, clouds_flag=clouds2_flag, warning=warning).flatten()
     return entropy((d1 + d2) / 2.0, base=2) - 0.5 * (entropy(d1, base=2) + entropy(d2, base=2))
+
+
+def save_model(state, model_name):
+    """utils.py:25-27 (training.py's checkpoint writer): pickle protocol 4, one line on stdout."""
+    torch.save(state, model_name, pickle_protocol=4)
+    print('Model saved to ' + model_name)
+
+
+def cnt_params(params):
+    """utils.py:30-31: number of trainable scalars."""
+    return sum(p.numel() for p in params if p.requires_grad)

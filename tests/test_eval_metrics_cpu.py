@@ -54,3 +54,11 @@ def test_mirror_exports_what_evaluating_py_imports(U):
     """evaluating.py:9-10: from lib.networks.utils import AverageMeter, distChamferCUDA, f_score, pairwise_CD, JSD, COV, MMD, KNN"""
     for name in ("AverageMeter", "distChamferCUDA", "f_score", "pairwise_CD", "JSD", "COV", "MMD", "KNN"):
         assert callable(getattr(U, name)), name
+    # training.py:7 and train_ae.py:16 take save_model / cnt_params from the same module
+    lin = torch.nn.Linear(3, 2)
+    lin.bias.requires_grad_(False)
+    assert U.cnt_params(lin.parameters()) == 6
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        U.save_model({"w": lin.weight.detach()}, os.path.join(d, "m.pkl"))
+        assert torch.equal(torch.load(os.path.join(d, "m.pkl"))["w"], lin.weight.detach())
