@@ -61,4 +61,4 @@ def test_mirror_exports_what_evaluating_py_imports(U):
     import tempfile
     with tempfile.TemporaryDirectory() as d:
         U.save_model({"w": lin.weight.detach()}, os.path.join(d, "m.pkl"))
-        assert torch.equal(torch.load(os.path.join(d, "m.pkl"))["w"], lin.weight.detach())
+        assert torch.equal(torch.load(os.path.join(d, "m.pkl"), weights_only=False)["w"], lin.weight.detach())
