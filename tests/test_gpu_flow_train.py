@@ -476,3 +476,58 @@ def test_training_stack_error_budget_vs_float64(golden_dir):
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
     _json.dump(report, open(os.path.join(out, "train_error_budget.json"), "w"), indent=1)
+
+
+@pytest.mark.parametrize("mode", ["direct", "inverse"])
+def test_c_abi_backward_block_form_equals_the_pointer_list_form(mode):
+    """include/dpf_hip.h: dpf_flow_train_backward takes the three gradients as (L,B,3,N) blocks, dpf_flow_train_backward_lists
+    as one pointer per layer and list (what the autograd node uses).  Same kernels, same order: every output bit for bit --
+    with all three lists given, and with g_mus / g_lvs absent (NULL = zero)."""
+    nets = _gpu()
+    import ctypes
+    from dpf_nets_amd._lib import lib, check, current_stream
+    from dpf_nets_amd.networks import train_engine as TE
+    B, N, G, n_flows = 3, 700, 64, 2
+    dec = nets.LocalCondRNVPDecoder(n_flows, 64, G, weight_std=0.02).cuda().train()
+    spec = TE.StackSpec(dec.coupling_layers())
+    L, prec = spec.L, TE.PREC["bf16x6"]
+    tgt, z, g = FO.synthetic_inputs(5, B, N, G)
+    p = torch.from_numpy((tgt if mode == "inverse" else z).copy()).cuda()
+    tg = torch.from_numpy(g.copy()).cuda()
+    cp, fp = spec.canon_params(), spec.film_params()
+    zeros = spec.zeros_on(p.device)
+    K = 4 * L
+    with torch.no_grad():
+        tcanon = torch.cat([cp[i].reshape(-1) if kind == "p" else zeros[:i] for kind, i in spec.cat_plan]).view(L, -1)
+        W0 = torch.cat([t.reshape(-1) for t in fp[0::5]]).view(K, 64, G)
+        gam, bet = torch.cat(fp[1::5]).view(K, 1, 64), torch.cat(fp[2::5]).view(K, 1, 64)
+        W1, b1 = torch.cat([t.reshape(-1) for t in fp[3::5]]).view(K, 64, 64), torch.cat(fp[4::5]).view(K, 1, 64)
+        outs, saved = TE._forward_core(p, tg, spec, mode, prec, tcanon, W0, gam, bet, W1, b1)
+    p_, g_, tcanon, packed, film, stats, ps, *_rest = saved
+    mus, lvs = saved[-2], saved[-1]
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    g_ps, g_mus, g_lvs = (torch.randn(ps.shape, device="cuda", generator=gen) * s for s in (1.0, 0.3, 0.1))
+    L_ = lib()
+
+    def run(lists, with_ml):
+        ws = torch.empty(L_.dpf_flow_train_workspace_bytes(B, N), dtype=torch.uint8, device="cuda")
+        dp, tmp = torch.empty_like(p), torch.empty_like(p)
+        dcanon, dfm = torch.zeros_like(tcanon), torch.zeros((L, 2, 2, B, 64), device="cuda")
+        common = (L, B, N, TE.MODE[mode], prec, spec.meta_host, tcanon.data_ptr(), packed.data_ptr(), film.data_ptr(),
+                  stats.data_ptr(), p.data_ptr(), ps.data_ptr(), mus.data_ptr(), lvs.data_ptr())
+        tail = (dp.data_ptr(), tmp.data_ptr(), dcanon.data_ptr(), dfm.data_ptr(), spec.eps, ws.data_ptr(), current_stream())
+        if lists:
+            tab = lambda t: (ctypes.c_void_p * L)(*[t[i].data_ptr() for i in range(L)])
+            check(L_.dpf_flow_train_backward_lists(*common, tab(g_ps), tab(g_mus) if with_ml else None,
+                                                   tab(g_lvs) if with_ml else None, *tail), "lists")
+        else:
+            check(L_.dpf_flow_train_backward(*common, g_ps.data_ptr(), g_mus.data_ptr() if with_ml else None,
+                                             g_lvs.data_ptr() if with_ml else None, *tail), "blocks")
+        torch.cuda.synchronize()
+        return dp, dcanon, dfm
+
+    for with_ml in (True, False):
+        a, b = run(True, with_ml), run(False, with_ml)
+        for x, y, name in zip(a, b, ("dp_in", "dcanon", "dfm")):
+            assert torch.isfinite(x).all() and float(x.abs().max()) > 0, name
+            assert torch.equal(x, y), (name, with_ml)
