@@ -508,6 +508,7 @@ def test_c_abi_backward_block_form_equals_the_pointer_list_form(mode):
     gen = torch.Generator(device="cuda").manual_seed(11)
     g_ps, g_mus, g_lvs = (torch.randn(ps.shape, device="cuda", generator=gen) * s for s in (1.0, 0.3, 0.1))
     L_ = lib()
+    assert L_.dpf_flow_train_canon_floats() == tcanon.shape[1] == 2 * 4484          # the size query of the (L, canon) block
 
     def run(lists, with_ml):
         ws = torch.empty(L_.dpf_flow_train_workspace_bytes(B, N), dtype=torch.uint8, device="cuda")
