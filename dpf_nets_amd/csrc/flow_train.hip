@@ -17,7 +17,7 @@
 //            flow_kernel   (csrc/flow.hip, L = 1) the layer itself
 //  backward  tbwd1         recompute to h2; d(outputs) -> d(o) (4 floats/point, stored), dW2, db2,
 //                          per-cloud d FiLM(a, c)
-//            tcloudsum     per-cloud totals of pass 1, FiLM gradients
+//            (per-cloud totals of pass 1 and the FiLM gradients: the last workgroup of each cloud in tbwd1)
 //            tbwd2         (prologue: BN1 backward means, dW2, db2 from those totals -- every workgroup
 //                          recomputes them rather than wait for a one-workgroup kernel); recompute; BN1
 //                          backward; dh0 = W1^T dh1 and dW1 = dh1 h0^T on the matrix cores; per point
@@ -631,7 +631,8 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
                                                         const float *__restrict__ g_mu, const float *__restrict__ g_lv,
                                                         const float *__restrict__ mu_l, const float *__restrict__ lv_l,
                                                         float *__restrict__ dp_in, float *__restrict__ dout,
-                                                        float *__restrict__ part1, PrevLayer pv) {
+                                                        float *__restrict__ part1, PrevLayer pv, unsigned *__restrict__ tickets,
+                                                        float *__restrict__ pc, float *__restrict__ dfm_l) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int L_FILM = pt_a0n(NS), L_FILMB = L_FILM + 2048, L_RED = L_FILMB + 2048;
     float *red = (float *)(smem + L_RED);                                  // per wave [2 br][4][64] + [2][2] (+4 pad)
@@ -782,29 +783,39 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < TW; ++w) t += red[w * 520 + i];
-        part1[blk * 520 + i] = t;
+        // written through (agent scope): the last workgroup of this cloud reads it below, possibly from another XCD
+        __hip_atomic_store(&part1[blk * 520 + i], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-}
-
-// Per-cloud totals of pass 1: pc[b][520]; and the FiLM gradients of the cloud
-//   dfm_l[br][sub][b][64] = (da * e^cw, dc)
-__global__ __launch_bounds__(520) void tcloudsum_kernel(int nb, int B, const float *__restrict__ part1, const float *__restrict__ filmb_l,
-                                                        float eps, float *__restrict__ pc, float *__restrict__ dfm_l) {
-    const int b = blockIdx.x, j = threadIdx.x;
-    float s = 0;
-    for (int k0 = 0; k0 < nb; k0 += 8) {                                        // eight loads in flight, added in order
-        float v[8];
+    // ---- per-cloud totals of pass 1 and the FiLM gradients of the cloud (formerly the tcloudsum launch), by whichever of the
+    // cloud's workgroups arrives last: partial rows published with write-through stores, a ticket per cloud, rows read back
+    // with agent-scope loads (per-XCD L2s are not coherent) and added in workgroup order -- the same sums in the same order
+    // wherever the workgroups ran.  The ticket returns to zero for the next layer.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // this workgroup's row has left the CU
+    __syncthreads();
+    unsigned *tk = (unsigned *)(w2s + 256 + TW * 64 + 8);                  // one word behind the pass-3 coefficients
+    if (threadIdx.x == 0)
+        *tk = __hip_atomic_fetch_add(&tickets[bi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int nb = gridDim.x;
+    if (*tk != (unsigned)(nb - 1)) return;
+    for (int j = threadIdx.x; j < 520; j += TW * 64) {
+        float s = 0.f;
+        for (int k0 = 0; k0 < nb; k0 += 8) {                               // eight loads in flight, added in order
+            float v[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = k0 + i < nb ? part1[((size_t)b * nb + k0 + i) * 520 + j] : 0.f;
+            for (int i = 0; i < 8; ++i)
+                v[i] = k0 + i < nb ? __hip_atomic_load(&part1[((size_t)bi * nb + k0 + i) * 520 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s += v[i];
+            for (int i = 0; i < 8; ++i) s += v[i];
+        }
+        pc[(size_t)bi * 520 + j] = s;
+        if (j < 512) {
+            const int br = j >> 8, k = (j >> 6) & 3, f = j & 63;
+            if (k == 2) dfm_l[((size_t)(br * 2 + 0) * a.B + bi) * 64 + f] = s * (filmb[br * FB_BR + f] - a.eps);
+            if (k == 3) dfm_l[((size_t)(br * 2 + 1) * a.B + bi) * 64 + f] = s;
+        }
     }
-    pc[(size_t)b * 520 + j] = s;
-    if (j < 512) {
-        const int br = j >> 8, k = (j >> 6) & 3, f = j & 63;
-        if (k == 2) dfm_l[((size_t)(br * 2 + 0) * B + b) * 64 + f] = s * (filmb_l[(size_t)b * FB_CLOUD + br * FB_BR + f] - eps);
-        if (k == 3) dfm_l[((size_t)(br * 2 + 1) * B + b) * 64 + f] = s;
-    }
+    if (threadIdx.x == 0) __hip_atomic_store(&tickets[bi], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // (the BN1-backward means and dW2 / db2 -- formerly a one-workgroup tfinish1 kernel -- are computed in tbwd2's prologue)
@@ -1140,6 +1151,7 @@ static inline int t_nblk(int B, int N) { return B * ((N + TBLK - 1) / TBLK); }
 struct TWork {
     double *xpart, *sums, *tot2;
     float *part1, *pc, *s12, *part2, *dout, *ubuf, *coef;
+    unsigned *tickets;           // per cloud: arrivals of pass-1 workgroups (zero between layers)
 };
 static size_t carve(void *ws, int B, int N, TWork *w) {
     const size_t nblk = (size_t)t_nblk(B, N), nbx = (size_t)B * ((N + TILE - 1) / TILE);   // the flow kernel's smallest workgroup is one tile
@@ -1150,6 +1162,7 @@ static size_t carve(void *ws, int B, int N, TWork *w) {
     uint8_t *tot2 = take(2 * P2_J * sizeof(double));
     uint8_t *part1 = take(nblk * 520 * 4);
     uint8_t *pc = take((size_t)B * 520 * 4);
+    uint8_t *tickets = take((size_t)B * 4);
     uint8_t *s12 = take(256 * 4);
     uint8_t *part2 = take(nblk * 2 * P2_J * 4);
     uint8_t *dout = take((size_t)B * 4 * N * 4);
@@ -1157,6 +1170,7 @@ static size_t carve(void *ws, int B, int N, TWork *w) {
     uint8_t *coef = take(8 * 4);
     if (w) {
         w->xpart = (double *)xpart; w->sums = (double *)sums; w->tot2 = (double *)tot2; w->part1 = (float *)part1;
+        w->tickets = (unsigned *)tickets;
         w->pc = (float *)pc; w->s12 = (float *)s12; w->part2 = (float *)part2; w->dout = (float *)dout;
         w->ubuf = (float *)ubuf; w->coef = (float *)coef;
     }
@@ -1279,14 +1293,14 @@ static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb
     a.stats_l = stats_l; a.p_in = p_in; a.B = B; a.N = N; a.ka = ka; a.kb = kb; a.wa = wa; a.wb = wb; a.mode = mode;
     a.eps = flow_eps;
     const dim3 grid((N + TBLK - 1) / TBLK, B);
-    const int nblk = grid.x * grid.y, nb = grid.x;
+    const int nblk = grid.x * grid.y;
     const double count = (double)B * N;
-    const int lds1 = pt_a0n(NS) + 4096 + (TW * 520 + 256 + TW * 64 + 8) * 4, lds2 = l_red(NS) + 4096 + TW * XY_WAVE * 2;
+    const int lds1 = pt_a0n(NS) + 4096 + (TW * 520 + 256 + TW * 64 + 8 + 4) * 4, lds2 = l_red(NS) + 4096 + TW * XY_WAVE * 2;
     static LdsLimit lim_b1, lim_b2;
     if (hipError_t e = lim_b1.ensure((const void *)tbwd1_kernel<NS>, lds1); e != hipSuccess) return (int)e;
     if (hipError_t e = lim_b2.ensure((const void *)tbwd2_kernel<NS>, lds2); e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(tbwd1_kernel<NS>, grid, dim3(TW * 64), lds1, s, a, g_p, g_p2, g_mu, g_lv, mu_l, lv_l, dp_in, w.dout, w.part1, *pv);
-    hipLaunchKernelGGL(tcloudsum_kernel, dim3(B), dim3(520), 0, s, nb, B, w.part1, a.filmb_l, flow_eps, w.pc, dfm_l);
+    hipLaunchKernelGGL(tbwd1_kernel<NS>, grid, dim3(TW * 64), lds1, s, a, g_p, g_p2, g_mu, g_lv, mu_l, lv_l, dp_in, w.dout, w.part1, *pv,
+                       w.tickets, w.pc, dfm_l);
     hipLaunchKernelGGL(tbwd2_kernel<NS>, grid, dim3(TW * 64), lds2, s, a, w.pc, count, dcanon_l, w.dout, w.ubuf, w.part2);
     hipLaunchKernelGGL(tcolsum_kernel, dim3((2 * P2_J + 31) / 32), dim3(1024), 0, s, nblk, 2 * P2_J, w.part2, w.tot2);
     // pass 3 (the conditioner path of d(input points), d gamma0 / d beta0 / dW0 / dW1 from the totals): folded into the NEXT
@@ -1316,6 +1330,11 @@ static int backward_stack(int n_layers, int B, int N, int mode, int precision, c
     const size_t lst = (size_t)B * 3 * N, fls = dpf_flow_train_film_floats(B), fms = (size_t)4 * B * DPF_FLOW_F;
     const float *chain = nullptr;
     PrevLayer pv = {};
+    {   // pass 1's per-cloud arrival tickets start at zero (every layer leaves them there)
+        TWork w;
+        carve(workspace, B, N, &w);
+        if (hipError_t e = hipMemsetAsync(w.tickets, 0, (size_t)B * 4, (hipStream_t)stream); e != hipSuccess) return (int)e;
+    }
     for (int step = n_layers - 1; step >= 0; --step) {
         const int l = mode == DPF_MODE_DIRECT ? step : n_layers - 1 - step;
         const int lprev = mode == DPF_MODE_DIRECT ? step - 1 : n_layers - step;       // layer whose output fed layer l
