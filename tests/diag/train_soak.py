@@ -1,0 +1,39 @@
+"""Soak of the training step's in-kernel hand-offs (tickets in tbwd1, graph replays): the loss sequence of N optimizer steps
+from two independent processes must agree bit for bit.  usage: train_soak.py [steps]"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+CHILD = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from dpf_nets_amd import networks as nets, synthetic as SY
+steps = int(sys.argv[1])
+torch.manual_seed(0)
+dec = nets.LocalCondRNVPDecoder(7, 64, 128).cuda().train()
+store = dec.flatten_parameters()
+opt = nets.Adam(list(dec.parameters()), lr=2.56e-4, weight_decay=1e-6, betas=(0.9, 0.999), amsgrad=True)
+tgt, _, g = SY.synthetic_inputs(3, 32, 2048, 128)
+tp, tg = torch.from_numpy(tgt).cuda(), torch.from_numpy(g).cuda()
+pm, pl = torch.zeros(32, 3, 2048).cuda(), torch.full((32, 3, 2048), -3.6).cuda()
+nll = nets.PointFlowNLL()
+out = []
+for s in range(steps):
+    opt.zero_grad(set_to_none=True)
+    ps, mus, lvs = dec(tp + 0.001 * (s %% 7), tg, mode="inverse")
+    loss = nll(ps + [tp], [pm] + mus, [pl] + lvs)
+    loss.backward()
+    opt.step()
+    out.append(loss.detach())
+print(" ".join(np.float32(x.item()).tobytes().hex() for x in out))
+""" % ROOT
+steps = sys.argv[1] if len(sys.argv) > 1 else "300"
+runs = []
+for i in range(2):
+    r = subprocess.run([sys.executable, "-c", CHILD, steps], capture_output=True, text=True)
+    if r.returncode:
+        print(r.stderr[-800:]); sys.exit(1)
+    runs.append(r.stdout.strip().split()[-int(steps):])
+same = sum(a == b for a, b in zip(*runs))
+print("steps %s: %d identical losses, first difference at %s" % (steps, same, next((i for i, (a, b) in enumerate(zip(*runs)) if a != b), None)))
