@@ -7,28 +7,29 @@
 // statistics over all B*N points (flows.py:27,30,62,65), which puts two grid-wide reductions in
 // the forward pass and two in the backward pass.  Each reduction is a kernel boundary:
 //
-//  forward   tstats_x      moments of the (<=2) kept coordinates       -> BN0 batch stats are an
-//            tbn0          analytic function of them (h0 = W0 x is linear): folded input-MFMA
-//                          fragments with the BATCH statistics
-//            tstats_h1     h1 = W1 relu(BN0(W0 x)) on the matrix cores, sum / sum of squares
-//            tcolsum       per-workgroup partials -> totals (fixed order, no global atomics)
-//            tfilm_fold    BN1 batch stats + this step's FiLM vectors  -> the per-cloud block the
-//                          eval kernel consumes
-//            flow_kernel   (csrc/flow.hip, L = 1) the layer itself
-//  backward  tbwd1         recompute to h2; d(outputs) -> d(o) (4 floats/point, stored), dW2, db2,
-//                          per-cloud d FiLM(a, c)
-//            (per-cloud totals of pass 1 and the FiLM gradients: the last workgroup of each cloud in tbwd1)
+//  forward   (tstats_x     moments of the (<=2) kept coordinates: first layer of a call only -- afterwards the
+//                          previous layer's flow kernel leaves them behind in its epilogue)
+//            tstats_h1     prologue (every workgroup): BN0 batch stats as an analytic function of those moments
+//                          (h0 = W0 x is linear) -> folded input-MFMA fragments with the BATCH statistics;
+//                          h1 = W1 relu(BN0(W0 x)) on the matrix cores, sum / sum of squares per workgroup
+//            tfold         those partials -> totals (fixed order, no global atomics) -> BN1 batch stats + this
+//                          step's FiLM vectors -> the per-cloud block the eval kernel consumes
+//            flow_kernel   (csrc/flow.hip, L = 1) the layer itself (+ the next layer's input moments)
+//  backward  tbwd1         prologue: pass 3 of the layer ABOVE (d gamma0, d beta0, dW1, dW0 from its totals -- BN0
+//                          backward in closed form: h0n is linear in x, so its sums over points follow from the x
+//                          moments -- and the conditioner path of its input gradient, u_k - affine(x), added to the
+//                          gradient this layer receives); recompute to h2; d(outputs) -> d(o) (4 floats/point,
+//                          stored), dW2, db2, per-cloud d FiLM(a, c): per-workgroup partials, finished per cloud by
+//                          the cloud's last workgroup (ticket)
 //            tbwd2         (prologue: BN1 backward means, dW2, db2 from those totals -- every workgroup
 //                          recomputes them rather than wait for a one-workgroup kernel); recompute; BN1
 //                          backward; dh0 = W1^T dh1 and dW1 = dh1 h0^T on the matrix cores; per point
 //                          u_k = sum_f c_fk dh0a[f] (2 floats, stored); per feature sums of
 //                          dh0a * {1, h0n, x_a, x_b}
 //            tcolsum       per-workgroup partials -> totals
-//            tbwd3f        d gamma0, d beta0, dW1, dW0 (BN0 backward in closed form: h0n is linear in x,
-//                          so its sums over points follow from the x moments) and
-//                          d(input) = direct term + u_k - affine(x), elementwise, in one launch
+//            (tbwd3f       pass 3 as its own launch: last layer of a call only)
 // (every dependent launch costs ~4.5 us on this part however small the kernel, so the tiny finishing steps are
-// recomputed by their consumers instead of being kernels of their own)
+// recomputed by their consumers instead of being kernels of their own: 6 launches per layer, 12 in r01)
 //
 // Activations are RECOMPUTED from the layer input in both backward passes (MFMA work is cheap);
 // nothing of size (B*N, 64) ever goes to HBM -- between the passes travel 4 + 2 floats per point.
