@@ -85,7 +85,7 @@ def parse(argv=None):
                          "steps in flight; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra legs of the default run (bf16x6, eager, train step)")
-    ap.add_argument("--train-steps", type=int, default=12, help="timed steps of the `extra.train_step` leg")
+    ap.add_argument("--train-steps", type=int, default=20, help="timed steps of the `extra.train_step` leg")
     ap.add_argument("--encoder", default="none", choices=["none", "hip", "tensor"],
                     help="train leg: put the training-mode PointNet encoder (+ a linear code head) in front of the decoder, as "
                          "models.py:130-140 does; hip = csrc/encoder_train.hip, tensor = the tensor-op path")
@@ -820,7 +820,7 @@ def main(argv=None):
             # the 40 / 52 MB flat gradient over xGMI (every rank takes part; reported by rank 0)
             try:
                 batch, _ = clouds_of_rank(args, rank, world)
-                extra["train_step"] = train_step_leg(args, rank, world, dist, device, batch, 63, args.train_steps, 10)
+                extra["train_step"] = train_step_leg(args, rank, world, dist, device, batch, 63, args.train_steps, 16)
             except Exception as e:       # noqa: BLE001 -- never lose the headline line to an extra
                 extra["train_step_error"] = repr(e)
     if rank == 0:
