@@ -25,7 +25,7 @@ class Adam(Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad)
         super().__init__(params, defaults)
         self._flat = {}          # id(store) -> flat state buffers
-        self._fast = {}          # id(param group) -> (its FlatStore or None, len, first, last)
+        self._fast = {}          # id(param group) -> (its whole FlatStores, its other parameters, len, first, last)
 
     # ---- the update of optimizers.py:52-74 on lists of tensors (lists of one flat tensor for a FlatStore)
     @staticmethod
@@ -92,17 +92,24 @@ class Adam(Optimizer):
         self._flat[id(store)] = fs
         return fs
 
-    def _whole_store(self, group):
-        """The FlatStore whose parameters are exactly this group's, or None (cached per group; three sentinels re-checked)."""
+    def _split_group(self, group):
+        """(FlatStores whose parameters all belong to this group, the group's other parameters) -- cached per group, keyed
+        by the list's length and end points."""
         params = group["params"]
         c = self._fast.get(id(group))
-        if c is None or c[1] != len(params) or (len(params) and (c[2] is not params[0] or c[3] is not params[-1])):
-            store = getattr(params[0], "_dpf_flat", None) if len(params) else None
-            ok = store is not None and len(params) == len(store.params) and \
-                set(map(id, params)) == set(map(id, store.params))
-            c = self._fast[id(group)] = (store if ok else None, len(params), params[0] if len(params) else None,
+        if c is None or c[2] != len(params) or (len(params) and (c[3] is not params[0] or c[4] is not params[-1])):
+            ids = set(map(id, params))
+            stores, covered = [], set()
+            for p in params:
+                st = getattr(p, "_dpf_flat", None)
+                if st is not None and id(st) not in covered and all(id(q) in ids for q in st.params):
+                    covered.add(id(st))
+                    stores.append(st)
+            in_store = set(id(q) for st in stores for q in st.params)
+            rest = [p for p in params if id(p) not in in_store]
+            c = self._fast[id(group)] = (stores, rest, len(params), params[0] if len(params) else None,
                                          params[-1] if len(params) else None)
-        return c[0]
+        return c[0], c[1]
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -113,23 +120,31 @@ class Adam(Optimizer):
         for group in self.param_groups:
             lr, (beta1, beta2), eps = group["lr"], group["betas"], group["eps"]
             wd, amsgrad = group["weight_decay"], group["amsgrad"]
-            # ---- the common case of a training loop over a flattened decoder: the whole group is one FlatStore with every
-            # gradient attached -- a handful of checks and one sequence of ops on the flat buffers, no per-parameter pass but
-            # the step counters (the general path below walks the 2016 parameters of n_flows = 21 about ten times)
-            store = self._whole_store(group)
-            if store is not None and store.attached():
-                ps, gv, mid = store.params, store.gviews, len(store.params) // 2
-                if ps[0].grad is gv[0] and ps[mid].grad is gv[mid] and ps[-1].grad is gv[-1]:
-                    fs = self._flat_state(store, amsgrad)
-                    pst = fs["pstates"]
-                    if pst[0]["step"] == pst[mid]["step"] == pst[-1]["step"]:
-                        step = pst[0]["step"] + 1
-                        for st in pst:
-                            st["step"] = step
-                        self._update([store.flat_p], [store.flat_g], [fs["buf"]["exp_avg"]], [fs["buf"]["exp_avg_sq"]],
-                                     [fs["buf"]["max_exp_avg_sq"]] if amsgrad else None, step, lr, beta1, beta2, eps, wd, amsgrad)
-                        continue
-            todo = [p for p in group["params"] if p.grad is not None]
+            # ---- the common case of a training loop over a flattened decoder: the group holds whole FlatStores with every
+            # gradient attached -- a handful of checks and one sequence of ops on the flat buffers per store, no
+            # per-parameter pass but the step counters (the general path below walks the 2016 parameters of n_flows = 21
+            # about ten times); the group's other parameters, and any store that fails a check, take the general path
+            stores, rest = self._split_group(group)
+            general = list(rest)
+            for store in stores:
+                done = False
+                if store.attached():
+                    ps, gv, mid = store.params, store.gviews, len(store.params) // 2
+                    if ps[0].grad is gv[0] and ps[mid].grad is gv[mid] and ps[-1].grad is gv[-1]:
+                        fs = self._flat_state(store, amsgrad)
+                        pst = fs["pstates"]
+                        if pst[0]["step"] == pst[mid]["step"] == pst[-1]["step"]:
+                            step = pst[0]["step"] + 1
+                            for st in pst:
+                                st["step"] = step
+                            self._update([store.flat_p], [store.flat_g], [fs["buf"]["exp_avg"]], [fs["buf"]["exp_avg_sq"]],
+                                         [fs["buf"]["max_exp_avg_sq"]] if amsgrad else None, step, lr, beta1, beta2, eps, wd, amsgrad)
+                            done = True
+                if not done:
+                    general += store.params
+            if not general:
+                continue
+            todo = [p for p in general if p.grad is not None]
             if any(p.grad.is_sparse for p in todo):
                 raise RuntimeError("Adam does not support sparse gradients, please consider SparseAdam instead")
             in_group = set(id(p) for p in todo)
