@@ -111,6 +111,35 @@ class Adam(Optimizer):
                                          params[-1] if len(params) else None)
         return c[0], c[1]
 
+    def zero_grad(self, set_to_none=True):
+        """torch.optim.Optimizer.zero_grad, except for the FlatStores a group holds whole: their gradients are persistent
+        views of ONE buffer, so they are cleared by one fill and stay attached, whatever `set_to_none` says -- the state the
+        next backward would re-create anyway (FlatStore.attach_grads), and what `optimizer.zero_grad()` meant when the
+        reference was written (PyTorch < 2.0 zeroed in place); walking the 2016 parameters of n_flows = 21 twice per step
+        (here to drop the views, in the backward to put them back) costs ~1.2 ms of host time.  Consequence, as with
+        set_to_none=False in stock PyTorch: a step() without a backward in between updates those parameters with zero
+        gradients instead of skipping them."""
+        for group in self.param_groups:
+            stores, rest = self._split_group(group)
+            others = list(rest)
+            for store in stores:
+                ps, gv, mid = store.params, store.gviews, len(store.params) // 2
+                if store.attached() and ps[0].grad is gv[0] and ps[mid].grad is gv[mid] and ps[-1].grad is gv[-1]:
+                    store.flat_g.zero_()
+                else:
+                    others += store.params
+            for p in others:
+                if p.grad is None:
+                    continue
+                if set_to_none:
+                    p.grad = None
+                else:
+                    if p.grad.grad_fn is not None:
+                        p.grad.detach_()
+                    else:
+                        p.grad.requires_grad_(False)
+                    p.grad.zero_()
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
