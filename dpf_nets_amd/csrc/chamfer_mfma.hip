@@ -32,6 +32,7 @@
 
 #include "dpf_hip.h"
 #include "lds_attr.h"
+#include "zero_fill.h"
 
 #pragma clang fp contract(off)
 
@@ -472,7 +473,7 @@ extern "C" int dpf_pairwise_cd(int n1, int n2, int n, int m, const float *clouds
     hipStream_t s = (hipStream_t)stream;
     ma.pn2 = n2; ma.ticket = (unsigned *)workspace; ma.part = (float *)workspace + npairs; ma.cd = cds;
     // the tickets (first n1 * n2 words) start at zero; the last arriver of every pair resets its own
-    if (hipError_t e = hipMemsetAsync(workspace, 0, (size_t)npairs * sizeof(unsigned), s); e != hipSuccess) return (int)e;
+    if (hipError_t e = dpf_zero_async(workspace, (size_t)npairs * sizeof(unsigned), s); e != hipSuccess) return (int)e;
     if (qw == 16) {
         const int lds = CT * 1536 + 16 * QCAP * 64 * 6;
         static LdsLimit limit;
@@ -508,7 +509,7 @@ extern "C" int dpf_nndistance_cd(int b, int n, const float *xyz, int m, const fl
         // tickets (first b words): zero on entry -- `tickets_are_zero` = 0 makes this call clear them first -- and zero again
         // on exit, so a caller that keeps the workspace pays the memset once
         if (!tickets_are_zero)
-            if (hipError_t e = hipMemsetAsync(workspace, 0, (size_t)b * sizeof(unsigned), s); e != hipSuccess) return (int)e;
+            if (hipError_t e = dpf_zero_async(workspace, (size_t)b * sizeof(unsigned), s); e != hipSuccess) return (int)e;
         return launch_nnm(b, n, xyz, (long)n * 3, m, xyz2, (long)m * 3, result, result_i, result2, result2_i, s,
                           (float *)workspace + b, true, (unsigned *)workspace, cd);
     }

@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include "dpf_hip.h"
+#include "zero_fill.h"
 
 #pragma clang fp contract(off)
 
@@ -773,7 +774,7 @@ extern "C" int dpf_matchcost(int b, int n, int m, const float *xyz1, const float
     if (!xyz1 || !xyz2 || !match || !out) return DPF_EINVAL;
     if (b > 65535) return DPF_ENOSUP;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * b, s);
+    hipError_t e = dpf_zero_async(out, sizeof(float) * b, s);
     if (e != hipSuccess) return (int)e;
     int gx = (int)(2048 / b);
     if (gx < 1) gx = 1;

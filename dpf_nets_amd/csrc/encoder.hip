@@ -24,6 +24,7 @@
 // global_load_lds, one workgroup barrier per chunk).
 #include "flow_common.h"
 #include "encoder_layout.h"
+#include "zero_fill.h"
 
 namespace {
 
@@ -403,7 +404,7 @@ extern "C" int dpf_encoder_forward(int B, int N, int precision, const void *pack
     if (!packed || !x || !gmax) return DPF_EINVAL;
     if (B > 65535) return DPF_ENOSUP;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(gmax, 0, sizeof(float) * (size_t)B * EC4, s);
+    hipError_t e = dpf_zero_async(gmax, sizeof(float) * (size_t)B * EC4, s);
     if (e != hipSuccess) return (int)e;
     EncArgs a{(const uint8_t *)packed, x, gmax, feat, B, N};
     return ns == 1 ? launch_enc<1>(a, s) : ns == 2 ? launch_enc<2>(a, s) : launch_enc<3>(a, s);

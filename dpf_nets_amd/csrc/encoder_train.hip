@@ -934,7 +934,7 @@ extern "C" int dpf_encoder_train_forward(int B, int N, int precision, const floa
     int dev = 0;
     (void)hipGetDevice(&dev);
     k.val(dev);
-    return cache.run(k.h, (hipStream_t)stream, direct);
+    return cache.run(k, (hipStream_t)stream, direct);
 }
 
 extern "C" int dpf_encoder_train_backward(int B, int N, const float *canon, const float *x, void *ws, const float *pooled,
@@ -948,7 +948,7 @@ extern "C" int dpf_encoder_train_backward(int B, int N, const float *canon, cons
     int dev = 0;
     (void)hipGetDevice(&dev);
     k.val(dev);
-    return cache.run(k.h, (hipStream_t)stream, direct);
+    return cache.run(k, (hipStream_t)stream, direct);
 }
 
 static int encoder_train_forward_direct(int B, int N, int precision, const float *canon, const float *x, void *ws, float *pooled,

@@ -46,6 +46,7 @@
 
 #include "flow_common.h"
 #include "graph_cache.h"
+#include "zero_fill.h"
 
 namespace {
 
@@ -799,7 +800,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
     __syncthreads();
     const int nb = gridDim.x;
     if (*tk != (unsigned)(nb - 1)) return;
-    for (int j = threadIdx.x; j < 520; j += TW * 64) {
+    for (int j = threadIdx.x; j < 516; j += TW * 64) {
         float s = 0.f;
         for (int k0 = 0; k0 < nb; k0 += 8) {                               // eight loads in flight, added in order
             float v[8];
@@ -1279,7 +1280,7 @@ extern "C" int dpf_flow_train_forward(int n_layers, int B, int N, int mode, int 
     int dev = 0;
     (void)hipGetDevice(&dev);
     k.val(dev);
-    return cache.run(k.h, (hipStream_t)stream, direct);
+    return cache.run(k, (hipStream_t)stream, direct);
 }
 
 template <int NS>
@@ -1331,10 +1332,11 @@ static int backward_stack(int n_layers, int B, int N, int mode, int precision, c
     const size_t lst = (size_t)B * 3 * N, fls = dpf_flow_train_film_floats(B), fms = (size_t)4 * B * DPF_FLOW_F;
     const float *chain = nullptr;
     PrevLayer pv = {};
-    {   // pass 1's per-cloud arrival tickets start at zero (every layer leaves them there)
+    {   // pass 1's per-cloud arrival tickets start at zero (every layer leaves them there).  A fill KERNEL: as a captured
+        // memset node the clear was not reliably ordered before the first pass-1 kernel of a replay (zero_fill.h)
         TWork w;
         carve(workspace, B, N, &w);
-        if (hipError_t e = hipMemsetAsync(w.tickets, 0, (size_t)B * 4, (hipStream_t)stream); e != hipSuccess) return (int)e;
+        if (hipError_t e = dpf_zero_async(w.tickets, (size_t)B * 4, (hipStream_t)stream); e != hipSuccess) return (int)e;
     }
     for (int step = n_layers - 1; step >= 0; --step) {
         const int l = mode == DPF_MODE_DIRECT ? step : n_layers - 1 - step;
@@ -1379,7 +1381,7 @@ extern "C" int dpf_flow_train_backward(int n_layers, int B, int N, int mode, int
     int dev = 0;
     (void)hipGetDevice(&dev);
     k.val(dev);
-    return cache.run(k.h, (hipStream_t)stream, direct);
+    return cache.run(k, (hipStream_t)stream, direct);
 }
 
 // The same with one (B,3,N) gradient pointer per layer and list: autograd hands the node a gradient per output
@@ -1411,11 +1413,21 @@ extern "C" int dpf_flow_train_backward_lists(int n_layers, int B, int N, int mod
     int dev = 0;
     (void)hipGetDevice(&dev);
     k.val(dev);
-    return cache.run(k.h, (hipStream_t)stream, direct);
+    return cache.run(k, (hipStream_t)stream, direct);
 }
 
 // number of training-mode calls served by a graph replay so far in this process (csrc/graph_cache.h); diagnostics / tests
-extern "C" long dpf_train_graph_replays(void) { return dpf_graph_replay_counter().load(); }
+extern "C" long dpf_train_graph_replays(void) { return dpf_graph_stats().replays.load(); }
+// out[5] = {replays, eager calls, recordings, evictions, uncapturable keys}, process-wide
+extern "C" void dpf_train_graph_stats(long *out) {
+    if (!out) return;
+    GraphStats &g = dpf_graph_stats();
+    out[0] = g.replays.load(); out[1] = g.eager.load(); out[2] = g.records.load(); out[3] = g.evictions.load();
+    out[4] = g.uncapturable.load();
+}
+// switch recording / replay on or off at run time (the DPF_TRAIN_GRAPH environment variable sets the initial state);
+// returns the previous state.  Recorded graphs are kept while it is off.
+extern "C" int dpf_train_graph_set_enabled(int on) { return dpf_graph_enabled_flag().exchange(on ? 1 : 0); }
 
 #ifdef DPF_PROFILE
 extern "C" void dpf_debug_set_tprof(void *p) {

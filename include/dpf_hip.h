@@ -363,8 +363,14 @@ int dpf_encoder_train_backward(int B, int N, const float *canon, const float *x,
 /* The training-mode entry points (dpf_flow_train_forward / _backward[_lists], dpf_encoder_train_forward / _backward) issue
  * hundreds of small dependent launches per call; a call whose scalars AND pointers have been seen twice is recorded once
  * (stream capture) and from then on replayed as one hipGraph -- a training loop presents the same addresses every step.
- * DPF_TRAIN_GRAPH=0 in the environment switches that off.  dpf_train_graph_replays(): calls served by a replay so far. */
+ * A replay needs the stored key bytes to match, not only their hash.  Only kernel nodes are recorded (no memset nodes).
+ * DPF_TRAIN_GRAPH=0 in the environment switches that off; dpf_train_graph_set_enabled(on) does so at run time and returns
+ * the previous state.  dpf_train_graph_replays(): calls served by a replay so far.  dpf_train_graph_stats(out[5]):
+ * {replays, eager calls, recordings, evictions, keys that could not be captured} -- evictions growing while replays stand
+ * still means the loop presents more than 8 live pointer sets per entry point, or its allocator does not settle. */
 long dpf_train_graph_replays(void);
+void dpf_train_graph_stats(long *out);
+int dpf_train_graph_set_enabled(int on);
 
 /* ---- latent prior flow: GlobalRNVPDecoder on (B, G) codes, eval-mode BatchNorm ---------------
  * replaces GlobalRNVPDecoder.forward (lib/networks/decoders.py:21-38): n_steps = 2 * n_flows

@@ -265,6 +265,52 @@ def test_training_graph_replay_is_bitwise_the_eager_call():
     assert replays0 == 0 and replays1 >= 4, (replays0, replays1)      # the later steps ran as graphs (forward and backward)
 
 
+def _bench_shape_losses(nets, steps, n_flows, graph_on):
+    """Loss and gradient-norm bytes of `steps` optimizer steps at the bench shape, recording / replay on or off."""
+    from dpf_nets_amd import synthetic as SY
+    from dpf_nets_amd._lib import lib
+    prev = lib().dpf_train_graph_set_enabled(1 if graph_on else 0)
+    try:
+        torch.manual_seed(0)
+        dec = nets.LocalCondRNVPDecoder(n_flows, 64, 128).cuda().train()
+        store = dec.flatten_parameters()
+        opt = nets.Adam(list(dec.parameters()), lr=2.56e-4, weight_decay=1e-6, betas=(0.9, 0.999), amsgrad=True)
+        tgt, _, g = SY.synthetic_inputs(3, 32, 2048, 128)
+        tp, tg = torch.from_numpy(tgt).cuda(), torch.from_numpy(g).cuda()
+        pm, pl = torch.zeros(32, 3, 2048).cuda(), torch.full((32, 3, 2048), -3.6).cuda()
+        nll = nets.PointFlowNLL()
+        r0 = int(lib().dpf_train_graph_replays())
+        losses, gnorms = [], []
+        for _ in range(steps):
+            opt.zero_grad(set_to_none=True)
+            ps, mus, lvs = dec(tp, tg, mode="inverse")
+            loss = nll(ps + [tp], [pm] + mus, [pl] + lvs)
+            loss.backward()
+            gnorms.append(store.flat_g.double().norm())
+            opt.step()
+            losses.append(loss.detach())
+        out = (torch.stack(losses).cpu().numpy().tobytes(), torch.stack(gnorms).cpu().numpy().tobytes(),
+               store.flat_p.detach().clone())
+        return out, int(lib().dpf_train_graph_replays()) - r0
+    finally:
+        lib().dpf_train_graph_set_enabled(prev)
+
+
+def test_training_replay_equals_eager_at_bench_shape_with_optimizer():
+    """at B=32, N=2048, n_flows=21 (63 layers, 8 pass-1 workgroups per cloud, ~750 launches per step) the
+    hipGraph replay of the training step must stay on the eager path's trajectory bit for bit: 32 steps of the mirror Adam
+    (training.py:54-56), every loss, every gradient norm and the final weights.  (r02's replay drifted from step ~22 on: a
+    captured hipMemsetAsync node was not ordered before the first pass-1 kernel; csrc/zero_fill.h.)"""
+    nets = _gpu()
+    (l1, g1, w1), replays = _bench_shape_losses(nets, 32, 21, True)
+    (l0, g0, w0), replays0 = _bench_shape_losses(nets, 32, 21, False)
+    assert replays0 == 0 and replays >= 50, (replays0, replays)          # 2 calls per step, all but the first two replayed
+    first = next((i for i in range(32) if l1[4 * i:4 * i + 4] != l0[4 * i:4 * i + 4]), None)
+    assert first is None, "losses differ from step %d" % first
+    assert g1 == g0
+    assert torch.equal(w1, w0)
+
+
 def test_training_loop_with_optimizer_and_eval_switch():
     """A few optimizer steps the way training.py:37-56 drives the decoder (inverse flow + NLL, backward, Adam),
     plus a Chamfer term through nn_distance's backward; then eval() must see the UPDATED weights (the packed
