@@ -87,6 +87,7 @@ def allreduce_flat_gradients(store, average=True):
     if w == 1:
         return 0
     store.attach_grads()
+    store.grad_written = True            # the other ranks' average is a gradient even if this shard produced none
     dist.all_reduce(store.flat_g, op=dist.ReduceOp.SUM)
     if average:
         store.flat_g.div_(w)

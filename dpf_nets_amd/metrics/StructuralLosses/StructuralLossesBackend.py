@@ -86,15 +86,27 @@ def NNDistanceCD(set_d, set_q):
     cd = torch.empty((b,), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         nbytes = lib().dpf_nndistance_cd_workspace_bytes(b, n, m)
-        # the workspace holds one ticket per cloud that must be zero on entry and is left zero: kept per (device, stream,
-        # size) and cleared once, so a call is ONE launch (calls on one stream are ordered, so they can share it)
+        # the workspace holds one ticket per cloud that must be zero on entry and is left zero on exit.  Outside stream
+        # capture it is kept per (device, stream, size) and cleared once, so a call is ONE launch (calls on one stream
+        # are ordered, so they can share it).  Under capture (torch.cuda.graph) an entry made EARLIER, outside any
+        # capture, is ordinary memory and may be recorded; without one the call takes a workspace of its own from the
+        # graph's pool and lets the library clear the tickets first (a kernel node of that graph): nothing allocated
+        # from a graph's private pool is ever cached.  A failed call may leave a ticket nonzero: its entry is dropped.
         key = (dev, current_stream(), nbytes)
         ws = _CD_WORKSPACES.get(key)
+        tickets_are_zero = 1
         if ws is None:
-            ws = _CD_WORKSPACES[key] = torch.zeros((nbytes,), dtype=torch.uint8, device=dev)
-        check(lib().dpf_nndistance_cd(b, n, set_d.data_ptr(), m, set_q.data_ptr(), dist1.data_ptr(), idx1.data_ptr(),
-                                      dist2.data_ptr(), idx2.data_ptr(), cd.data_ptr(), ws.data_ptr(), nbytes, 1,
-                                      current_stream()), "nndistance_cd")
+            if torch.cuda.is_current_stream_capturing():
+                ws, tickets_are_zero = torch.empty((nbytes,), dtype=torch.uint8, device=dev), 0
+            else:
+                ws = _CD_WORKSPACES[key] = torch.zeros((nbytes,), dtype=torch.uint8, device=dev)
+        try:
+            check(lib().dpf_nndistance_cd(b, n, set_d.data_ptr(), m, set_q.data_ptr(), dist1.data_ptr(), idx1.data_ptr(),
+                                          dist2.data_ptr(), idx2.data_ptr(), cd.data_ptr(), ws.data_ptr(), nbytes,
+                                          tickets_are_zero, current_stream()), "nndistance_cd")
+        except Exception:
+            _CD_WORKSPACES.pop(key, None)
+            raise
     return [dist1, idx1, dist2, idx2, cd]
 
 

@@ -155,23 +155,25 @@ class _TrainPool(torch.autograd.Function):
             torch.autograd.graph.increment_version(bn.running_mean)
             torch.autograd.graph.increment_version(bn.running_var)
         torch._foreach_add_([bn.num_batches_tracked for bn in bns], 1)
-        ctx.enc_state = (canon, x, ws, B, N)
-        ctx.save_for_backward(pooled)
+        # canon, x and the workspace go through save_for_backward: version counters catch an in-place edit of x between
+        # forward and backward, and a second backward (retain_graph=True) finds them again
+        ctx.dims = (B, N)
+        ctx.save_for_backward(pooled, canon, x, ws)
         ctx.shapes = [p.shape for p in params]
         return pooled
 
     @staticmethod
     def backward(ctx, g):
-        canon, x, ws, B, N = ctx.enc_state
-        pooled, = ctx.saved_tensors
+        B, N = ctx.dims
+        pooled, canon, x, ws = ctx.saved_tensors
         dcanon = torch.empty_like(canon)
         dx = torch.empty_like(x) if ctx.needs_input_grad[1] else None
+        g32 = g.contiguous().to(torch.float32)                            # a local: it must outlive the launch's enqueue
         with torch.cuda.device(x.device):
             check(lib().dpf_encoder_train_backward(B, N, canon.data_ptr(), x.data_ptr(), ws.data_ptr(), pooled.data_ptr(),
-                                                   g.contiguous().to(torch.float32).data_ptr(), dcanon.data_ptr(),
+                                                   g32.data_ptr(), dcanon.data_ptr(),
                                                    dx.data_ptr() if dx is not None else None, current_stream()),
                   "encoder_train_backward")
-        ctx.enc_state = None
         grads, off = [], 0
         cin = _HIP_ARCH[0]
         for i, cout in enumerate((_HIP_ARCH[1],) + tuple(_HIP_ARCH[2])):

@@ -97,7 +97,11 @@ class Adam(Optimizer):
         by the list's length and end points."""
         params = group["params"]
         c = self._fast.get(id(group))
-        if c is None or c[2] != len(params) or (len(params) and (c[3] is not params[0] or c[4] is not params[-1])):
+        # stale when the list changed, or when a parameter's store was rebuilt (module.to() / .cuda() re-assign .data and
+        # the decoder builds a new FlatStore: the cached one would pin the slow path for good)
+        if c is None or c[2] != len(params) or (len(params) and (
+                c[3] is not params[0] or c[4] is not params[-1] or
+                c[5] is not getattr(params[0], "_dpf_flat", None) or c[6] is not getattr(params[-1], "_dpf_flat", None))):
             ids = set(map(id, params))
             stores, covered = [], set()
             for p in params:
@@ -108,7 +112,9 @@ class Adam(Optimizer):
             in_store = set(id(q) for st in stores for q in st.params)
             rest = [p for p in params if id(p) not in in_store]
             c = self._fast[id(group)] = (stores, rest, len(params), params[0] if len(params) else None,
-                                         params[-1] if len(params) else None)
+                                         params[-1] if len(params) else None,
+                                         getattr(params[0], "_dpf_flat", None) if len(params) else None,
+                                         getattr(params[-1], "_dpf_flat", None) if len(params) else None)
         return c[0], c[1]
 
     def zero_grad(self, set_to_none=True):
@@ -116,9 +122,11 @@ class Adam(Optimizer):
         views of ONE buffer, so they are cleared by one fill and stay attached, whatever `set_to_none` says -- the state the
         next backward would re-create anyway (FlatStore.attach_grads), and what `optimizer.zero_grad()` meant when the
         reference was written (PyTorch < 2.0 zeroed in place); walking the 2016 parameters of n_flows = 21 twice per step
-        (here to drop the views, in the backward to put them back) costs ~1.2 ms of host time.  Consequence, as with
-        set_to_none=False in stock PyTorch: a step() without a backward in between updates those parameters with zero
-        gradients instead of skipping them."""
+        (here to drop the views, in the backward to put them back) costs ~1.2 ms of host time.  The meaning of
+        `set_to_none` is kept through the store's `grad_written` flag: with set_to_none=True (the default) a step() that
+        no backward (FlatStore.accumulate), gradient exchange or attach of a foreign gradient preceded SKIPS the store,
+        as stock PyTorch skips parameters whose .grad is None (no moment decay, no weight decay, no step count); with
+        set_to_none=False the zeros count as gradients, as they do there."""
         for group in self.param_groups:
             stores, rest = self._split_group(group)
             others = list(rest)
@@ -126,6 +134,7 @@ class Adam(Optimizer):
                 ps, gv, mid = store.params, store.gviews, len(store.params) // 2
                 if store.attached() and ps[0].grad is gv[0] and ps[mid].grad is gv[mid] and ps[-1].grad is gv[-1]:
                     store.flat_g.zero_()
+                    store.grad_written = not set_to_none
                 else:
                     others += store.params
             for p in others:
@@ -160,6 +169,8 @@ class Adam(Optimizer):
                 if store.attached():
                     ps, gv, mid = store.params, store.gviews, len(store.params) // 2
                     if ps[0].grad is gv[0] and ps[mid].grad is gv[mid] and ps[-1].grad is gv[-1]:
+                        if not getattr(store, "grad_written", True):           # zero_grad(set_to_none=True) and nothing since: "grad is None"
+                            continue
                         fs = self._flat_state(store, amsgrad)
                         pst = fs["pstates"]
                         if pst[0]["step"] == pst[mid]["step"] == pst[-1]["step"]:

@@ -305,6 +305,7 @@ class PriorFlatStore:
             torch._foreach_copy_([self.flat_p[o:o + n] for o, n in slots], [t.detach().reshape(-1).to(dev) for t in params])
         self.pviews = [self.flat_p[o:o + n].view(t.shape) for (o, n), t in zip(slots, params)]
         self.gviews = [self.flat_g[o:o + n].view(t.shape) for (o, n), t in zip(slots, params)]
+        self.grad_written = any(t.grad is not None for t in params)     # see FlatStore.grad_written
         for t, pv, gv in zip(params, self.pviews, self.gviews):
             if t.grad is not None:
                 gv.copy_(t.grad)
@@ -319,6 +320,7 @@ class PriorFlatStore:
 
     def accumulate(self, dcanon):
         self.attach_grads()
+        self.grad_written = True
         self.flat_g.add_(dcanon)
 
 

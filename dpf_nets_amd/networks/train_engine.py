@@ -334,6 +334,7 @@ class FlatStore:
             ranges += [(offs[1] + k * F * G, F * G), (offs[2] + k * F, F), (offs[3] + k * F, F),
                        (offs[4] + k * F * F, F * F), (offs[5] + k * F, F)]
         self.params = cp + fp
+        had_grad = any(t.grad is not None for t in self.params)
         with torch.no_grad():
             torch._foreach_copy_([self.flat_p[o:o + n] for o, n in ranges], [t.detach().reshape(-1).to(dev) for t in self.params])
         self.pviews = [self.flat_p[o:o + n].view(t.shape) for (o, n), t in zip(ranges, self.params)]
@@ -356,6 +357,9 @@ class FlatStore:
             b.num_batches_tracked.data = self.nbt[i]
         self.nfilm = nb // 2
         self.token = torch.zeros(1, dtype=torch.float32, device=dev, requires_grad=True)
+        # a gradient was written into flat_g since the last zero_grad(set_to_none=True) -- what "p.grad is not None" means
+        # for parameters whose .grad views stay attached (networks.optimizers.Adam skips a store without one)
+        self.grad_written = had_grad
 
     def attached(self):
         """The aliasing survives in-place updates, load_state_dict and optimizer steps; module.to()/.cuda()/.float()
@@ -376,6 +380,7 @@ class FlatStore:
 
     def zero_grad(self):
         self.flat_g.zero_()
+        self.grad_written = False
         self.attach_grads(zeroed=True)
 
     def attach_grads(self, zeroed=False, full=False):
@@ -388,7 +393,9 @@ class FlatStore:
         if not zeroed:
             if all(t.grad is None for t in ps):
                 self.flat_g.zero_()
+                self.grad_written = False
             else:
+                self.grad_written = True
                 for t, v in zip(ps, gv):
                     if t.grad is None:
                         v.zero_()
@@ -399,6 +406,7 @@ class FlatStore:
 
     def accumulate(self, dcanon, dW0, dgam, dbet, dW1, db1):
         self.attach_grads()
+        self.grad_written = True
         gb = self.gblocks
         gb[0].add_(dcanon)
         gb[1].add_(dW0)

@@ -153,15 +153,59 @@ def main():
     t = tx.transpose(1, 2).contiguous()
     dl, dr = em.distChamfer(r, t)
     gold["cd_per_cloud"] = (dl.mean(1) + dr.mean(1)).numpy()
-    path = os.path.join(ROOT, "tests", "golden", "model_eval.npz")
+    write_or_check(gold, os.path.join(ROOT, "tests", "golden", "model_eval.npz"), write, "evaluating mode")
+
+    # ---- 3. TRAINING-mode golden from the REFERENCE model: one step of training.py:37-55 (forward, the four loss terms of
+    # losses.py:37-51, backward) with reparameterize's noise replaced by a fixed eps_g -- what tests/test_gpu_model.py
+    # reproduces through the HIP training kernels (encoder, prior flow, decoder, NLL) with the mirror classes only.
+    # Big enough for the HIP path's tiles (B*N a few thousand points), small enough for seconds of CPU.
+    Bt, Nt = 6, 640
+    xt, _ = MO.model_inputs(23, Bt, Nt)
+    from oracle import detrng
+    eps_g = detrng.normal_f32(detrng.key(23, "eps_g"), (Bt, cfg["g_latent_space_size"]), 0.0, 1.0)
+    cfg_t = dict(cfg, util_mode="training")
+    model, loss_fn = build(ref_models, ref_losses, cfg_t, state)
+    model.train()
+    teg = torch.from_numpy(eps_g)
+    model.reparameterize = lambda mu, logvar: teg * torch.exp(0.5 * logvar) + mu
+    txt = torch.from_numpy(xt)
+    out = model(txt, txt)
+    loss, pnll, gnll, gent = loss_fn(txt, txt, out)
+    loss.backward()
+    tg = {"x": xt, "eps_g": eps_g, "seed": np.array(11), "B": np.array(Bt), "N": np.array(Nt),
+          "loss": np.array([float(loss), float(pnll), float(gnll), float(gent)], np.float64)}
+    for k in ("g_posterior_mus", "g_posterior_logvars", "g_posterior_samples"):
+        tg[k] = out[k].detach().numpy()
+    for k in ("g_prior_samples", "p_prior_samples", "p_prior_mus", "p_prior_logvars"):
+        tg[k + "_len"] = np.array(len(out[k]))
+        for i in (0, 1, len(out[k]) // 2, len(out[k]) - 1):
+            tg["%s/%d" % (k, i)] = np.ascontiguousarray(out[k][i].detach().numpy())
+    tg["sum_p_logvars"] = sum(out["p_prior_logvars"]).detach().numpy()
+    from oracle.gen_golden import _grad_projection
+    named = [(k, p.grad) for k, p in model.named_parameters()]
+    assert all(g is not None for _, g in named)
+    for k, v in _grad_projection(named, 23).items():
+        tg["gradproj/" + k] = v
+    tg["grad_names"] = np.array([k for k, _ in named])
+    for k, b in model.named_buffers():                   # BatchNorm running statistics / counters after the step
+        tg["buffer/" + k] = b.detach().numpy().copy()
+    print("training golden: loss %.6f pnll %.6f gnll %.6f gent %.6f, %d gradients, %d buffers"
+          % (float(loss), float(pnll), float(gnll), float(gent), len(named), sum(1 for _ in model.named_buffers())))
+    write_or_check(tg, os.path.join(ROOT, "tests", "golden", "model_train.npz"), write, "training mode")
+
+
+def write_or_check(gold, path, write, what):
     if write:
         np.savez_compressed(path, **gold)
         print("wrote %s (%d arrays, %.0f KB)" % (path, len(gold), os.path.getsize(path) / 1024))
     else:
         old = np.load(path)
         for k in gold:
-            np.testing.assert_allclose(old[k], gold[k], rtol=1e-6, atol=1e-7, err_msg=k)
-        print("evaluating mode: %s is up to date (%d arrays)" % (path, len(gold)))
+            if gold[k].dtype.kind in "US":
+                assert list(old[k]) == list(gold[k]), k
+            else:
+                np.testing.assert_allclose(old[k], gold[k], rtol=1e-6, atol=1e-7, err_msg=k)
+        print("%s: %s is up to date (%d arrays)" % (what, path, len(gold)))
 
 
 if __name__ == "__main__":

@@ -5,12 +5,15 @@ TEST INFRASTRUCTURE -- the checker, never the thing measured or shipped.  Only t
 bench.py's cpu_baseline leg and __graft_entry__.smoke() may import it.
 
 Parity status: PINNED.  oracle/check_dropin.py (build container only) runs the reference's own
-lib/networks/models.py on these weights and writes tests/golden/model_eval.npz; tests/test_oracle_golden.py
-checks this file's `evaluating_forward` (over the CPU oracles) and tests/test_gpu_model.py the HIP path (over the mirror
-classes of dpf_nets_amd.networks) against it.
+lib/networks/models.py on these weights and writes tests/golden/model_eval.npz and model_train.npz;
+tests/test_oracle_golden.py checks this file's `evaluating_forward` (over the CPU oracles) and tests/test_gpu_model.py the
+HIP path (over the mirror classes of dpf_nets_amd.networks) against them -- `training_forward` + `vae_loss` with
+loss.backward() being the whole training step of training.py:37-55.
 
   Local_Cond_RNVP_MC_Global_RNVP_VAE.__init__          lib/networks/models.py:13-74   (names of the sub-modules / parameters)
   ... .forward, mode == 'evaluating'                    lib/networks/models.py:173-216
+  ... .forward, mode == 'training'                      lib/networks/models.py:125-171   (training_forward)
+  Local_Cond_RNVP_MC_Global_RNVP_VAE_Loss.forward       lib/networks/losses.py:18-51     (vae_loss)
   FeatureEncoder.forward (n_layers = 0|1, mus/logvars)  lib/networks/encoders.py:31-83
 """
 import numpy as np
@@ -90,3 +93,46 @@ def evaluating_forward(blocks, st, g_input, eps, n_sampled_points=None):
     out["p_prior_mus"] += list(buf[1])
     out["p_prior_logvars"] += list(buf[2])
     return out
+
+
+def training_forward(blocks, st, g_input, p_input, eps_g):
+    """models.py:125-171 ('fixed' base distribution, g_posterior_n_layers = 0) over `blocks` (as evaluating_forward; the
+    modules are in train() mode) and `st` = the non-block parameters (torch tensors, requires_grad where the caller wants
+    their gradients); eps_g (B,G) replaces torch.randn_like of reparameterize (models.py:76-79)."""
+    out = {}
+    B = g_input.shape[0]
+    feats = blocks["pc_encoder"](g_input)                                                    # :130
+    g_enc = torch.max(feats, dim=2)[0]                                                       # :131
+    out["g_posterior_mus"] = torch.nn.functional.linear(g_enc, st["g_posterior.mus.mu_mlp0.weight"],
+                                                        st["g_posterior.mus.mu_mlp0.bias"])               # :133
+    out["g_posterior_logvars"] = torch.nn.functional.linear(g_enc, st["g_posterior.logvars.logvar_mlp0.weight"],
+                                                            st["g_posterior.logvars.logvar_mlp0.bias"])
+    out["g_posterior_samples"] = eps_g * torch.exp(0.5 * out["g_posterior_logvars"]) + out["g_posterior_mus"]   # :134 / :76-79
+    G = out["g_posterior_mus"].shape[1]
+    out["g_prior_mus"] = [st["g0_prior_mus"].expand(B, G)]                                   # :136-137
+    out["g_prior_logvars"] = [st["g0_prior_logvars"].expand(B, G)]
+    buf_g = blocks["g_prior"](out["g_posterior_samples"], "inverse")                         # :138
+    out["g_prior_samples"] = list(buf_g[0]) + [out["g_posterior_samples"]]
+    out["g_prior_mus"] += list(buf_g[1])
+    out["g_prior_logvars"] += list(buf_g[2])
+    N = p_input.shape[2]
+    out["p_prior_mus"] = [st["p_prior_mus"].expand(B, 3, N)]                                 # :160-166 ('fixed')
+    out["p_prior_logvars"] = [st["p_prior_logvar"].expand(B, 3, N)]
+    buf_p = blocks["pc_decoder"](p_input, out["g_posterior_samples"], "inverse")             # :168
+    out["p_prior_samples"] = buf_p[0] + [p_input]                                            # list-likes: the caller's own `+`
+    out["p_prior_mus"] += buf_p[1]
+    out["p_prior_logvars"] += buf_p[2]
+    return out
+
+
+def vae_loss(out, pnll_fn, cfg=CONFIG):
+    """losses.py:37-51: (loss, pnll, gnll, gent); pnll_fn = the PointFlowNLL under test (losses.py:7-15)."""
+    import math
+    pnll = pnll_fn(out["p_prior_samples"], out["p_prior_mus"], out["p_prior_logvars"])
+    s, m, lv = out["g_prior_samples"], out["g_prior_mus"], out["g_prior_logvars"]
+    gnll = 0.5 * torch.add(torch.sum(sum(lv) + ((s[0] - m[0]) ** 2 / torch.exp(lv[0]))) / s[0].shape[0],
+                           math.log(2.0 * math.pi) * s[0].shape[1])                          # GaussianFlowNLL :18-26
+    plv = out["g_posterior_logvars"]
+    gent = 0.5 * torch.add(plv.shape[1] * (1.0 + math.log(2.0 * math.pi)), plv.sum(1).mean())   # GaussianEntropy :29-34
+    loss = cfg["pnll_weight"] * pnll + cfg["gnll_weight"] * gnll - cfg["gent_weight"] * gent
+    return loss, pnll, gnll, gent

@@ -280,6 +280,34 @@ def test_nndistance_cd_ticket_finish_under_load():
         assert int(ws[:4 * B].view(torch.int32).abs().sum()) == 0        # tickets left at zero
 
 
+def test_nndistance_cd_first_call_inside_a_graph_capture():
+    """a first call on a stream made INSIDE torch.cuda.graph must not cache a workspace from the graph's
+    private pool; the library clears the tickets itself there (a kernel node -- csrc/zero_fill.h), so replays on new data
+    stay correct, and nothing of the capture is left in the process-wide table."""
+    BK = _gpu()
+    B, n = 32, 2048
+    a, b = chamfer_inputs(4242, B, n, n)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    before = set(BK._CD_WORKSPACES)
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            outs = BK.NNDistanceCD(ta, tb)
+    assert set(BK._CD_WORKSPACES) == before                               # nothing cached from inside the capture
+    for it in range(3):
+        ta.mul_(1.0 + 0.05 * it)
+        tb.add_(0.01 * it)
+        graph.replay()
+        torch.cuda.synchronize()
+        ref = BK.NNDistance(ta, tb)
+        for x, y in zip(outs[:4], ref):
+            assert torch.equal(x, y)
+        want = ref[0].double().mean(1) + ref[2].double().mean(1)
+        assert torch.allclose(outs[4].double(), want, rtol=3e-6, atol=0)
+
+
 def test_generative_evaluation_fragment_on_the_mirror():
     """evaluating.py:245-257 with the mirror's utils: three pairwise_CD matrices on the GPU -> COV, MMD, 1-NN accuracy; JSD of
     the clouds.  The matrices against the oracle's per-pair Chamfer (expand-and-call form), the metrics computed from the

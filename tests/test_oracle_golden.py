@@ -359,3 +359,50 @@ def test_model_oracle_evaluating_forward_vs_reference_golden(golden_dir):
             np.testing.assert_allclose(out[k][i].numpy(), ref, rtol=1e-4, atol=2e-6 * max(1.0, float(np.abs(ref).max())), err_msg="%s/%d" % (k, i))
     np.testing.assert_allclose(float(FO.point_flow_nll(out["p_prior_samples"], out["p_prior_mus"], out["p_prior_logvars"])),
                                float(gold["pnll_as_losses_py"]), rtol=1e-5)
+
+
+def test_model_oracle_training_forward_vs_reference_golden(golden_dir):
+    """oracle/model_oracle.training_forward + vae_loss (models.py:125-171, losses.py:37-51 restated) over the mirror's
+    modules on their CPU tensor-op path reproduce the reference model's training step
+    (oracle/check_dropin.py -> tests/golden/model_train.npz): loss terms, outputs, all 250 gradient projections."""
+    from oracle import model_oracle as MO
+    from oracle.gen_golden import _grad_projection
+    from dpf_nets_amd import networks as nets
+    gold = np.load(os.path.join(golden_dir, "model_train.npz"))
+    cfg = MO.CONFIG
+    st = FO.to_torch(MO.make_model_state(int(gold["seed"]), cfg))
+    enc = nets.PointNetCloudEncoder(cfg["pc_enc_init_n_channels"], cfg["pc_enc_init_n_features"], cfg["pc_enc_n_features"])
+    enc.load_state_dict(FO.sub_state(st, "pc_encoder."), strict=True)
+    prior = nets.GlobalRNVPDecoder(cfg["g_prior_n_flows"], cfg["g_prior_n_features"], cfg["g_latent_space_size"])
+    prior.load_state_dict(FO.sub_state(st, "g_prior."), strict=True)
+    dec = nets.LocalCondRNVPDecoder(cfg["p_decoder_n_flows"], cfg["p_decoder_n_features"], cfg["g_latent_space_size"])
+    dec.load_state_dict(FO.sub_state(st, "pc_decoder."), strict=True)
+    enc.train(); prior.train(); dec.train()
+    gst = {k: v for k, v in st.items() if not k.startswith(("pc_encoder.", "g_prior.", "pc_decoder."))}
+    leaf = [k for k in gst if k.startswith(("g_posterior.", "g0_prior"))]
+    for k in leaf:
+        gst[k].requires_grad_(True)
+    x, eps_g = torch.from_numpy(gold["x"]), torch.from_numpy(gold["eps_g"])
+    blocks = {"pc_encoder": enc, "g_prior": lambda g, mode: prior(g, mode=mode), "pc_decoder": lambda p, g, mode: dec(p, g, mode=mode)}
+    out = MO.training_forward(blocks, gst, x, x, eps_g)
+    loss, pnll, gnll, gent = MO.vae_loss(out, nets.PointFlowNLL(), cfg)
+    loss.backward()
+    got = np.array([float(loss.detach()), float(pnll.detach()), float(gnll.detach()), float(gent.detach())])
+    np.testing.assert_allclose(got, gold["loss"], rtol=2e-6)
+    for k in ("g_prior_samples", "p_prior_samples", "p_prior_mus", "p_prior_logvars"):
+        assert len(out[k]) == int(gold[k + "_len"]), k
+        for i in (0, 1, len(out[k]) // 2, len(out[k]) - 1):
+            ref = gold["%s/%d" % (k, i)]
+            np.testing.assert_allclose(out[k][i].detach().numpy(), ref, rtol=1e-4, atol=2e-6 * max(1.0, float(np.abs(ref).max())),
+                                       err_msg="%s/%d" % (k, i))
+    grads = {}
+    for pre, mod in (("pc_encoder.", enc), ("g_prior.", prior), ("pc_decoder.", dec)):
+        for k, p in mod.named_parameters():
+            grads[pre + k] = p.grad
+    for k in leaf:
+        grads[k] = gst[k].grad
+    names = [str(k) for k in gold["grad_names"]]
+    assert sorted(grads) == sorted(names)
+    for k, v in _grad_projection([(k, grads[k]) for k in names], 23).items():
+        ref = gold["gradproj/" + k]
+        assert np.all(np.abs(v - ref) <= 2e-4 * (ref[2] + 1e-6) + 1e-6), (k, v, ref)
