@@ -22,6 +22,7 @@ RANK/LOCAL_RANK/WORLD_SIZE.  value = all ranks' points / max-over-ranks time.  R
 `roofline`, `cpu_baseline` and `parity`.
 """
 import argparse
+import ctypes
 import json
 import os
 import socket
@@ -86,6 +87,10 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra legs of the default run (bf16x6, eager, train step)")
     ap.add_argument("--train-steps", type=int, default=20, help="timed steps of the `extra.train_step` leg")
+    ap.add_argument("--model", default=None, choices=["decoder", "encoder", "autoencoder"],
+                    help="train leg: decoder = the flow decoder on given codes (default), encoder = PointNet encoder + code head + "
+                         "decoder, autoencoder = the whole Local_Cond_RNVP_MC_Global_RNVP_VAE of the workload's YAML (cfg3: "
+                         "12 972 413 parameters, the 52 MB message of SURVEY 8e)")
     ap.add_argument("--encoder", default="none", choices=["none", "hip", "tensor"],
                     help="train leg: put the training-mode PointNet encoder (+ a linear code head) in front of the decoder, as "
                          "models.py:130-140 does; hip = csrc/encoder_train.hip, tensor = the tensor-op path")
@@ -675,43 +680,123 @@ def _lib_handle():
     return lib()
 
 
-def train_step_leg(args, rank, world, dist, device, batch, layers, steps, warmup):
+# the network kwargs of the reference's YAML files, per workload (configs/generation/airplane.yaml:27-52,
+# configs/autoencoding/all_scaled.yaml:27-51; svr/all.yaml shares all_scaled's decoder / prior shapes)
+MODEL_CONFIGS = {
+    128: dict(deterministic=False, pc_enc_init_n_channels=3, pc_enc_init_n_features=64, pc_enc_n_features=[128, 256, 512],
+              g_latent_space_size=128, g_prior_n_flows=7, g_prior_n_features=128, g_posterior_n_layers=1, p_latent_space_size=3,
+              p_prior_n_layers=1, p_decoder_n_flows=21, p_decoder_n_features=64, p_decoder_base_type="free",
+              p_decoder_base_var=-3.9551, pnll_weight=1.0, gnll_weight=1.0, gent_weight=1.0, util_mode="training"),
+    512: dict(deterministic=False, pc_enc_init_n_channels=3, pc_enc_init_n_features=64, pc_enc_n_features=[128, 256, 512],
+              g_latent_space_size=512, g_prior_n_flows=7, g_prior_n_features=128, g_posterior_n_layers=1, p_latent_space_size=3,
+              p_prior_n_layers=1, p_decoder_n_flows=21, p_decoder_n_features=64, p_decoder_base_type="freevar",
+              p_decoder_base_var=-3.5960, pnll_weight=1.0, gnll_weight=1.0, gent_weight=1.0, util_mode="training"),
+}
+
+
+def build_train_workload(args, rank, device, batch, layers, model_kind):
+    """-> (step_fn factory inputs): modules, parameters, a closure computing the loss of one batch.
+    model_kind: "decoder" (the flow decoder alone on given codes: the r01/r02 leg), "encoder" (PointNet encoder + a linear
+    code head in front of it), "autoencoder" (the whole Local_Cond_RNVP_MC_Global_RNVP_VAE of the workload's YAML: encoder,
+    posterior, latent prior flow, base-distribution net, decoder, the three loss terms of losses.py:37-51)."""
     from dpf_nets_amd import networks as nets, synthetic as SY
-    from dpf_nets_amd import distributed as D
-    if layers % 3:
-        raise SystemExit("train leg: --layers must be a multiple of 3 (whole CondRealNVPFlow3DTriple's)")
     n_flows, G, N = layers // 3, args.latent, args.points
     torch.manual_seed(0)                      # same initial weights on every rank (replicas)
+    tgt, _, g = SY.synthetic_inputs(3 + rank, batch, N, G)          # every rank its own shard of clouds
+    tp, tg = torch.from_numpy(tgt).to(device), torch.from_numpy(g).to(device)
+    if model_kind == "autoencoder":
+        cfg = dict(MODEL_CONFIGS[512 if G >= 512 else 128], g_latent_space_size=G, p_decoder_n_flows=n_flows)
+        model = nets.Local_Cond_RNVP_MC_Global_RNVP_VAE(**cfg).to(device).train()
+        model.pc_encoder.hip_training = getattr(args, "encoder", "hip") != "tensor"
+        stores = model.flatten_parameters()
+        loss_fn = nets.Local_Cond_RNVP_MC_Global_RNVP_VAE_Loss(**cfg)
+
+        def compute():
+            return loss_fn(tp, tp, model(tp, tp))[0]                 # training.py:37,42
+        what = ("whole autoencoder of the workload's YAML (PointNet encoder [%s] + posterior + %d-flow latent prior + base net + "
+                "%d-layer decoder; pnll + gnll - gent)" % ("HIP" if model.pc_encoder.hip_training else "tensor ops",
+                                                           cfg["g_prior_n_flows"], layers))
+        return list(model.parameters()), compute, stores[0], what
     dec = nets.LocalCondRNVPDecoder(n_flows, 64, G).to(device).train()
     store = dec.flatten_parameters()
     params = list(dec.parameters())
     enc = head = None
-    if getattr(args, "encoder", "none") != "none":
+    if model_kind == "encoder":
         # models.py:130-140: cloud code = head(max over the points of pc_encoder(p_input)); the reference's head is a
         # FeatureEncoder (tensor ops there and here) -- its mean layer stands in for it
         enc = nets.PointNetCloudEncoder(3, 64, [128, 256, 512]).to(device).train()
         enc.hip_training = args.encoder == "hip"
         head = torch.nn.Linear(512, G).to(device)
         params += list(enc.parameters()) + list(head.parameters())
-    opt = nets.Adam(params, lr=2.56e-4, weight_decay=1e-6, betas=(0.9, 0.999), amsgrad=True)
-    tgt, _, g = SY.synthetic_inputs(3 + rank, batch, N, G)          # every rank its own shard of clouds
-    tp, tg = torch.from_numpy(tgt).to(device), torch.from_numpy(g).to(device)
     pm, pl = torch.zeros(batch, 3, N, device=device), torch.full((batch, 3, N), -3.6, device=device)
     nll = nets.PointFlowNLL()
-    ev = []
 
-    def step(record=False):
-        opt.zero_grad(set_to_none=True)
+    def compute():
         code = tg if enc is None else head(torch.max(enc(tp), dim=2)[0])
         ps, mus, lvs = dec(tp, code, mode="inverse")
-        loss = nll(ps + [tp], [pm] + mus, [pl] + lvs)                # models.py:169-171, losses.py:48
+        return nll(ps + [tp], [pm] + mus, [pl] + lvs)                # models.py:169-171, losses.py:48
+    what = ("" if enc is None else "PointNet encoder (training mode, %s) + code head + " % args.encoder) + \
+        "inverse %d-layer stack (batch-stat BN) + PointFlowNLL" % layers
+    return params, compute, store, what
+
+
+def replay_equals_eager(args, rank, device, batch, layers, model_kind, n=6):
+    """The first n optimizer steps of the leg, once with the stack's calls recorded / replayed as hipGraphs and once with
+    eager launches (fresh model, same seed): loss bytes must agree (VERDICT r02 #1).  Outside every timed region."""
+    from dpf_nets_amd import networks as nets, distributed as D
+    L_ = _lib_handle()
+    seqs, replays = [], []
+    for on in (1, 0):
+        prev = L_.dpf_train_graph_set_enabled(on)
+        try:
+            r0 = int(L_.dpf_train_graph_replays())
+            params, compute, store, _ = build_train_workload(args, rank, device, batch, layers, model_kind)
+            arena = D.GradArena(params)
+            opt = nets.Adam(params, lr=2.56e-4, weight_decay=1e-6, betas=(0.9, 0.999), amsgrad=True)
+            losses = []
+            for _ in range(n):
+                arena.zero_grad()
+                torch.manual_seed(1234 + len(losses))
+                loss = compute()
+                loss.backward()
+                opt.step()
+                losses.append(loss.detach())
+            seqs.append(torch.stack(losses).cpu().numpy().tobytes())
+            replays.append(int(L_.dpf_train_graph_replays()) - r0)
+            del params, compute, store, arena, opt, loss
+        finally:
+            L_.dpf_train_graph_set_enabled(prev)
+    return seqs[0] == seqs[1], replays[0]
+
+
+def train_step_leg(args, rank, world, dist, device, batch, layers, steps, warmup, model_kind=None):
+    from dpf_nets_amd import networks as nets
+    from dpf_nets_amd import distributed as D
+    if layers % 3:
+        raise SystemExit("train leg: --layers must be a multiple of 3 (whole CondRealNVPFlow3DTriple's)")
+    N, G = args.points, args.latent
+    if model_kind is None:
+        model_kind = getattr(args, "model", None) or ("encoder" if getattr(args, "encoder", "none") != "none" else "decoder")
+    same, check_replays = replay_equals_eager(args, rank, device, batch, layers, model_kind)
+    params, compute, store, what = build_train_workload(args, rank, device, batch, layers, model_kind)
+    arena = D.GradArena(params)                  # every gradient of the model in ONE flat buffer = the one message of the step
+    opt = nets.Adam(params, lr=2.56e-4, weight_decay=1e-6, betas=(0.9, 0.999), amsgrad=True)
+    ev = []
+    counted = []
+
+    def step(record=False):
+        arena.zero_grad()                                            # training.py:54 (one fill)
+        loss = compute()                                             # training.py:37,42
         loss.backward()                                              # training.py:55
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        n = D.allreduce_flat_gradients(store)                        # the ONE collective of the step (decoder)
-        if enc is not None and dist is not None:
-            D.allreduce_gradients(list(enc.parameters()) + list(head.parameters()))
+        if dist is not None:
+            with D.count_collectives() as cc:
+                n = arena.allreduce()                                # the ONE collective of the step
+            counted.append(cc.total())
+        else:
+            n = arena.allreduce()
         if record:
             e1.record()
             ev.append((e0, e1))
@@ -734,21 +819,31 @@ def train_step_leg(args, rank, world, dist, device, batch, layers, steps, warmup
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ar_us = float(np.median([a.elapsed_time(b) for a, b in ev])) * 1e3
-    nbytes = store.flat_g.numel() * 4
-    info = {"ms_per_step": elapsed / steps * 1e3, "value": batch * world * N / (elapsed / steps), "unit": "points/s",
+    nbytes = arena.nbytes()
+    gstats = (ctypes.c_long * 5)()
+    _lib_handle().dpf_train_graph_stats(gstats)
+    info = {"ms_per_step": elapsed / steps * 1e3, "value": batch * world * N / (elapsed / steps) if same else None, "unit": "points/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "layers": layers, "clouds_per_gpu": batch, "points_per_cloud": N,
             "latent": G, "loss": float(loss), "precision": os.environ.get("DPF_TRAIN_PRECISION", "bf16x6"),
-            "what": ("" if enc is None else "PointNet encoder (training mode, %s) + code head + " % args.encoder) +
-                    "zero_grad + inverse stack (batch-stat BN) + PointFlowNLL + backward + all-reduce(flat_g) + Adam (AMSGrad mirror)",
+            "model": model_kind,
+            "what": "zero_grad + " + what + " + backward + ONE all-reduce of the model's flat gradient + Adam (AMSGrad mirror)",
             "encoder": getattr(args, "encoder", "none"),
-            "flat_gradient_bytes": nbytes, "collectives_per_step": 1 if world > 1 else 0,
-            "graph_replays": int(_lib_handle().dpf_train_graph_replays()),
+            "parameters": int(arena.n_params), "flat_gradient_bytes": nbytes,
+            "collectives_per_step": (max(counted) if counted else 0),
+            "collectives_counted": bool(counted),
+            "replay_equals_eager": bool(same), "replay_check": "first 6 optimizer steps, hipGraph replay vs eager launches, loss "
+                                                               "bytes compared (%d calls of the check were replays)" % check_replays,
+            "graph_replays": int(gstats[0]), "graph_stats": {"replays": int(gstats[0]), "eager_calls": int(gstats[1]),
+                                                             "recordings": int(gstats[2]), "evictions": int(gstats[3]),
+                                                             "uncapturable": int(gstats[4])},
             "algorithmic_tflops": 3.0 * FLOP_PER_POINT_LAYER * layers * batch * N / (elapsed / steps) / 1e12}
+    if not same:
+        info["error"] = "graph replay and eager launches disagree: no value reported"
     if world > 1:
         bus = 2.0 * (world - 1) / world * nbytes / (ar_us * 1e-6) / 1e9
         info["allreduce"] = {"us": ar_us, "elements": int(nred), "bus_GBps": bus, "backend": dist.get_backend(),
                              "xgmi_budget_GBps": 7 * XGMI_LINK_GBS, "frac_of_xgmi_budget": bus / (7 * XGMI_LINK_GBS),
-                             "note": "HIP events on the compute stream around dist.all_reduce(flat_g) (includes the wait for the "
+                             "note": "HIP events on the compute stream around dist.all_reduce(arena.buf) (includes the wait for the "
                                      "collective's stream); bus = 2(n-1)/n * bytes / time"}
     return info
 

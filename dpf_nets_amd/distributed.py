@@ -94,6 +94,134 @@ def allreduce_flat_gradients(store, average=True):
     return store.flat_g.numel()
 
 
+class GradArena:
+    """ONE flat fp32 gradient buffer for a whole model -- what makes "a single all-reduce per step" literal.
+
+    Layout: [flat_g of every FlatStore / PriorFlatStore among the parameters (the point decoder, the latent prior flow) |
+    every other trainable parameter (encoder, posterior / prior heads, g0 prior ...) in the caller's order].  The stores'
+    gradient buffers are re-based onto their slice (FlatStore.rebase_grads); every other parameter's `.grad` becomes a
+    view of its slice, so autograd accumulates straight into the message.  `allreduce()` is then exactly one
+    `dist.all_reduce` of `buf` (sum, / world): 52 MB for the all_scaled model (12 972 413 parameters + 4 KB of layout
+    padding), nothing gathered or scattered.  Use `arena.zero_grad()` (one fill, views stay attached) in place of
+    `optimizer.zero_grad()`; a `.grad` that was dropped or replaced behind the arena's back (set_to_none) is re-attached
+    by `sync()`, which `allreduce()` calls first."""
+
+    def __init__(self, parameters):
+        params = [p for p in parameters if p.requires_grad]
+        if not params:
+            raise ValueError("GradArena: no trainable parameters")
+        ids = set(map(id, params))
+        self.stores, covered = [], set()
+        for p in params:
+            st = getattr(p, "_dpf_flat", None)
+            if st is not None and id(st) not in covered and st.attached() and all(id(q) in ids for q in st.params):
+                covered.add(id(st))
+                self.stores.append(st)
+        in_store = set(id(q) for st in self.stores for q in st.params)
+        self.others = [p for p in params if id(p) not in in_store]
+        dev = params[0].device
+        if any(p.device != dev or p.dtype != torch.float32 for p in params):
+            raise ValueError("GradArena: all parameters must be float32 on one device")
+        n_store = sum(st.flat_g.numel() for st in self.stores)
+        total = n_store + sum(p.numel() for p in self.others)
+        self.buf = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        for st in self.stores:
+            n = st.flat_g.numel()
+            st.rebase_grads(self.buf[off:off + n])
+            off += n
+        self.views = []
+        for p in self.others:
+            v = self.buf[off:off + p.numel()].view(p.shape)
+            if p.grad is not None:
+                with torch.no_grad():
+                    v.copy_(p.grad)
+            p.grad = v
+            self.views.append(v)
+            off += p.numel()
+        self.n_params = sum(p.numel() for p in params)
+
+    def nbytes(self):
+        return self.buf.numel() * 4
+
+    def sync(self):
+        """Every gradient of the model is in `buf` afterwards (missing ones as zeros), every .grad a view of it again."""
+        for st in self.stores:
+            st.attach_grads()
+        for p, v in zip(self.others, self.views):
+            if p.grad is v:
+                continue
+            with torch.no_grad():
+                if p.grad is None:
+                    v.zero_()
+                else:
+                    v.copy_(p.grad)
+            p.grad = v
+
+    def zero_grad(self):
+        """One fill for the whole model; gradient views stay attached (the stores count as "no gradient yet")."""
+        self.sync()
+        self.buf.zero_()
+        for st in self.stores:
+            st.grad_written = False
+
+    def allreduce(self, average=True):
+        """THE collective of the step.  Returns the number of elements reduced (0 in a single-process run)."""
+        rank, w = world()
+        self.sync()
+        if w == 1:
+            return 0
+        for st in self.stores:
+            st.grad_written = True
+        dist.all_reduce(self.buf, op=dist.ReduceOp.SUM)
+        if average:
+            self.buf.div_(w)
+        return self.buf.numel()
+
+
+class count_collectives:
+    """Context manager that COUNTS the collectives issued through torch.distributed while it is active (all_reduce,
+    all_gather[_into_tensor], reduce_scatter[_tensor], broadcast, reduce, all_to_all[_single]; barriers are not
+    data-path collectives and are listed separately).  bench.py reports `collectives_per_step` from it and
+    tests/dist_worker_gpu.py asserts the north star's "a single all-reduce per step" with it."""
+    NAMES = ("all_reduce", "all_gather", "all_gather_into_tensor", "reduce_scatter", "reduce_scatter_tensor", "broadcast",
+             "reduce", "all_to_all", "all_to_all_single")
+
+    def __init__(self):
+        self.calls = {}
+        self.barriers = 0
+        self._saved = {}
+
+    def total(self):
+        return sum(self.calls.values())
+
+    def __enter__(self):
+        def wrap(name, fn):
+            def counted(*a, **k):
+                self.calls[name] = self.calls.get(name, 0) + 1
+                return fn(*a, **k)
+            return counted
+        for name in self.NAMES:
+            fn = getattr(dist, name, None)
+            if fn is not None:
+                self._saved[name] = fn
+                setattr(dist, name, wrap(name, fn))
+        bar = dist.barrier
+
+        def counted_barrier(*a, **k):
+            self.barriers += 1
+            return bar(*a, **k)
+        self._saved["barrier"] = bar
+        dist.barrier = counted_barrier
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self._saved.items():
+            setattr(dist, name, fn)
+        self._saved = {}
+        return False
+
+
 def broadcast_buffers(module, src=0):
     """BatchNorm running statistics diverge across replicas (no SyncBN); broadcast rank `src`'s
     before a checkpoint so that every rank saves the same state dict."""

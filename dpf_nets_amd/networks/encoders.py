@@ -301,3 +301,41 @@ class PointNetCloudEncoder(nn.Module):
         if input.dtype != torch.float32 or input.dim() != 3 or input.shape[1] != 3:
             raise RuntimeError("PointNetCloudEncoder: expected a float32 (B,3,N) tensor")
         return PointFeatures(self, input.contiguous())
+
+
+class FeatureEncoder(nn.Module):
+    """lib/networks/encoders.py:31-83: n_layers x [Linear(no bias) . BatchNorm1d . Swish] on a (B, C) code, then a `mus`
+    head and (unless deterministic) a `logvars` head.  O(B) tensor ops on PyTorch-ROCm (SURVEY: stays host code) -- here
+    so that the whole autoencoder (networks/models.py) is built from this package and its gradients form ONE flat
+    message (distributed.GradArena).  Same sub-module / parameter names and initialisation as the reference's."""
+
+    def __init__(self, n_layers, in_features, latent_space_size, deterministic=False, batch_norm=True, mu_weight_std=0.001,
+                 mu_bias=0.0, logvar_weight_std=0.01, logvar_bias=0.0, easy_init=False):
+        super().__init__()
+        from .layers import Swish
+        self.n_layers, self.in_features, self.latent_space_size = n_layers, in_features, latent_space_size
+        self.deterministic, self.batch_norm = deterministic, batch_norm
+        if n_layers > 0:
+            self.features = nn.Sequential()
+            for i in range(n_layers):
+                self.features.add_module("mlp{}".format(i), nn.Linear(in_features, in_features, bias=False))
+                if batch_norm:
+                    self.features.add_module("mlp{}_bn".format(i), nn.BatchNorm1d(in_features))
+                self.features.add_module("mlp{}_swish".format(i), Swish())
+        self.mus = nn.Sequential(OrderedDict([("mu_mlp0", nn.Linear(in_features, latent_space_size, bias=True))]))
+        if not easy_init:
+            with torch.no_grad():
+                self.mus[-1].weight.normal_(std=mu_weight_std)
+                nn.init.constant_(self.mus[-1].bias, mu_bias)
+        if not deterministic:
+            self.logvars = nn.Sequential(OrderedDict([("logvar_mlp0", nn.Linear(in_features, latent_space_size, bias=True))]))
+            if not easy_init:
+                with torch.no_grad():
+                    self.logvars[-1].weight.normal_(std=logvar_weight_std)
+                    nn.init.constant_(self.logvars[-1].bias, logvar_bias)
+
+    def forward(self, input):
+        features = self.features(input) if self.n_layers > 0 else input
+        if self.deterministic:
+            return self.mus(features)
+        return self.mus(features), self.logvars(features)

@@ -6,6 +6,8 @@ fused HIP stack, the layer-sum was already accumulated in registers by the
 kernel and is used directly."""
 import math
 
+import numpy as np
+
 import torch
 import torch.nn as nn
 
@@ -105,3 +107,33 @@ class PointFlowNLL(nn.Module):
                 return out
         tot = total_logvar(logvars) + (s0 - mu0) ** 2 / torch.exp(lv0)
         return 0.5 * (tot.sum() / s0.shape[0] + math.log(2.0 * math.pi) * s0.shape[1] * s0.shape[2])
+
+
+class GaussianFlowNLL(nn.Module):
+    """lib/networks/losses.py:18-26 -- O(B*G) tensor ops on the latent prior flow's lists."""
+
+    def forward(self, samples, mus, logvars):
+        return 0.5 * torch.add(torch.sum(sum(logvars) + ((samples[0] - mus[0]) ** 2 / torch.exp(logvars[0]))) / samples[0].shape[0],
+                               np.log(2.0 * np.pi) * samples[0].shape[1])
+
+
+class GaussianEntropy(nn.Module):
+    """lib/networks/losses.py:29-34"""
+
+    def forward(self, logvars):
+        return 0.5 * torch.add(logvars.shape[1] * (1.0 + np.log(2.0 * np.pi)), logvars.sum(1).mean())
+
+
+class Local_Cond_RNVP_MC_Global_RNVP_VAE_Loss(nn.Module):
+    """lib/networks/losses.py:37-51: (weighted total, pnll, gnll, gent)."""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        self.pnll_weight, self.gnll_weight, self.gent_weight = kwargs.get("pnll_weight"), kwargs.get("gnll_weight"), kwargs.get("gent_weight")
+        self.PNLL, self.GNLL, self.GENT = PointFlowNLL(), GaussianFlowNLL(), GaussianEntropy()
+
+    def forward(self, g_clouds, l_clouds, outputs):
+        pnll = self.PNLL(outputs["p_prior_samples"], outputs["p_prior_mus"], outputs["p_prior_logvars"])
+        gnll = self.GNLL(outputs["g_prior_samples"], outputs["g_prior_mus"], outputs["g_prior_logvars"])
+        gent = self.GENT(outputs["g_posterior_logvars"])
+        return self.pnll_weight * pnll + self.gnll_weight * gnll - self.gent_weight * gent, pnll, gnll, gent

@@ -298,7 +298,7 @@ class PriorFlatStore:
                 net = getattr(l, "T_%s_0" % br)
                 for t in (net[0].weight, net[1].weight, net[1].bias, net[3].weight, net[3].bias):
                     params.append(t); slots.append((off, t.numel())); off += t.numel()
-        self.params, self.total = params, off
+        self.params, self.total, self._slots = params, off, slots
         self.flat_p = torch.zeros(off, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros_like(self.flat_p)
         with torch.no_grad():
@@ -317,6 +317,16 @@ class PriorFlatStore:
     def attached(self):
         a, b = self.params[0], self.params[-1]
         return a.data_ptr() == self.pviews[0].data_ptr() and b.data_ptr() == self.pviews[-1].data_ptr() and a.device == self.flat_p.device
+
+    def rebase_grads(self, buf):
+        """As FlatStore.rebase_grads: the gradient buffer becomes `buf` (a slice of distributed.GradArena's message)."""
+        assert buf.numel() == self.flat_g.numel() and buf.dtype == torch.float32 and buf.is_contiguous() and buf.device == self.flat_g.device
+        with torch.no_grad():
+            buf.copy_(self.flat_g)
+        self.flat_g = buf
+        self.gviews = [buf[o:o + n].view(t.shape) for (o, n), t in zip(self._slots, self.params)]
+        for t, gv in zip(self.params, self.gviews):
+            t.grad = gv
 
     def accumulate(self, dcanon):
         self.attach_grads()

@@ -326,6 +326,7 @@ class FlatStore:
         offs = [0]
         for n in sizes:
             offs.append(offs[-1] + n)
+        self._offs, self._shapes = offs, shapes
         self.blocks = [self.flat_p[offs[i]:offs[i + 1]].view(shapes[i]) for i in range(6)]
         self.gblocks = [self.flat_g[offs[i]:offs[i + 1]].view(shapes[i]) for i in range(6)]
         # element range of every parameter inside the flat buffers, in spec.all_params() order
@@ -333,6 +334,7 @@ class FlatStore:
         for k in range(K):
             ranges += [(offs[1] + k * F * G, F * G), (offs[2] + k * F, F), (offs[3] + k * F, F),
                        (offs[4] + k * F * F, F * F), (offs[5] + k * F, F)]
+        self._ranges = ranges
         self.params = cp + fp
         had_grad = any(t.grad is not None for t in self.params)
         with torch.no_grad():
@@ -367,6 +369,20 @@ class FlatStore:
         a, b, pv, bn = self.params[0], self.params[-1], self.pviews, self.bns[-1]
         return (a.data_ptr() == pv[0].data_ptr() and b.data_ptr() == pv[-1].data_ptr() and
                 bn.running_var.data_ptr() == self.rv[-1].data_ptr() and a.device == self.flat_p.device)
+
+    def rebase_grads(self, buf):
+        """Move the gradient buffer onto `buf` (a contiguous fp32 slice of a bigger buffer, same length): contents carried
+        over, every parameter's .grad re-pointed.  distributed.GradArena uses this to make the gradients of a whole model
+        -- this store, the prior flow's store, every other parameter -- ONE flat message."""
+        assert buf.numel() == self.flat_g.numel() and buf.dtype == torch.float32 and buf.is_contiguous() and buf.device == self.flat_g.device
+        with torch.no_grad():
+            buf.copy_(self.flat_g)
+        self.flat_g = buf
+        offs, shapes = self._offs, self._shapes
+        self.gblocks = [buf[offs[i]:offs[i + 1]].view(shapes[i]) for i in range(6)]
+        self.gviews = [buf[o:o + n].view(t.shape) for (o, n), t in zip(self._ranges, self.params)]
+        for t, gv in zip(self.params, self.gviews):
+            t.grad = gv
 
     def update_running(self, film_mean, film_uvar, flow_mean, flow_uvar, momentum):
         n = self.nfilm

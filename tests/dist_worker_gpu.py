@@ -68,9 +68,39 @@ def main():
         per_cloud = ps[-1].square().mean((1, 2))
         gathered = D.gather_clouds(per_cloud)
         assert gathered.shape[0] == B
+        # ---- the whole autoencoder (encoder + posterior + prior flow + base net + decoder, every block on its HIP training
+        # kernels): all gradients in ONE flat buffer, the step's exchange is exactly ONE all_reduce -- counted
+        from oracle import model_oracle as MO                   # (test infrastructure: the small model configuration only)
+        cfg = dict(MO.CONFIG, util_mode="training", g_posterior_n_layers=1, p_decoder_base_type="freevar", p_prior_n_layers=1)
+        torch.manual_seed(3)
+        model = nets.Local_Cond_RNVP_MC_Global_RNVP_VAE(**cfg).to(dev).train()
+        model.flatten_parameters()
+        loss_fn = nets.Local_Cond_RNVP_MC_Global_RNVP_VAE_Loss(**cfg)
+        arena = D.GradArena(model.parameters())
+        assert len(arena.stores) == 2 and arena.n_params == sum(q.numel() for q in model.parameters())
+        x = (torch.randn(4, 3, 512, generator=torch.Generator().manual_seed(50 + rank)) * 0.25).to(dev)
+        for step in range(3):
+            arena.zero_grad()
+            torch.manual_seed(7 + step)
+            loss = loss_fn(x, x, model(x, x))[0]
+            loss.backward()
+            arena.sync()
+            mine = arena.buf.clone()
+            locs = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(locs, mine)
+            with D.count_collectives() as cc:
+                n = arena.allreduce()
+            if world > 1:
+                assert cc.total() == 1 and cc.calls == {"all_reduce": 1}, cc.calls
+                assert n == arena.buf.numel()
+            else:
+                assert cc.total() == 0 and n == 0
+            want = sum(locs) / world
+            assert torch.allclose(arena.buf, want, rtol=1e-6, atol=1e-9), float((arena.buf - want).abs().max())
+            assert bool(mine.abs().sum() > 0) and torch.isfinite(mine).all()
         dist.barrier()
         if rank == 0:
-            print("DIST_OK world=%d flat=%d" % (world, store.flat_g.numel()))
+            print("DIST_OK world=%d flat=%d arena=%d" % (world, store.flat_g.numel(), arena.buf.numel()))
     finally:
         dist.destroy_process_group()
 

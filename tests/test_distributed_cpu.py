@@ -100,6 +100,75 @@ def test_shard_allreduce_gather_world2():
     assert res[0][2] == (0, 3) and res[1][2] == (3, 6)
 
 
+def _arena_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dpf_nets_amd import distributed as D
+        from dpf_nets_amd import networks as nets
+        from oracle import model_oracle as MO
+        torch.set_num_threads(2)
+        cfg = dict(MO.CONFIG, util_mode="training", g_posterior_n_layers=1, p_decoder_base_type="freevar", p_prior_n_layers=1)
+        torch.manual_seed(3)                                            # replicas: same weights on every rank
+        model = nets.Local_Cond_RNVP_MC_Global_RNVP_VAE(**cfg).train()
+        # point decoder + prior flow in their flat stores (on CPU tensors: the decoder's own flatten_parameters() wants its GPU)
+        from dpf_nets_amd.networks.flows import stack_spec
+        stack_spec(model.pc_decoder, model.pc_decoder.coupling_layers()).flatten(torch.device("cpu"))
+        model.g_prior.flatten_parameters()
+        loss_fn = nets.Local_Cond_RNVP_MC_Global_RNVP_VAE_Loss(**cfg)
+        arena = D.GradArena(model.parameters())
+        n_all = sum(p.numel() for p in model.parameters())
+        ok = len(arena.stores) == 2 and arena.n_params == n_all and arena.buf.numel() >= n_all
+        ok = ok and all(p.grad is not None and p.grad.untyped_storage().data_ptr() == arena.buf.untyped_storage().data_ptr()
+                        for p in model.parameters())                    # every gradient lives in the ONE message buffer
+        x = torch.randn(4, 3, 48, generator=torch.Generator().manual_seed(50 + rank)) * 0.25      # every rank its own clouds
+        results = []
+        for step in range(2):
+            arena.zero_grad()
+            torch.manual_seed(7 + step)                                 # reparameterize's noise: same stream on every rank
+            out = model(x, x)
+            loss = loss_fn(x, x, out)[0]
+            loss.backward()
+            arena.sync()
+            mine = arena.buf.clone()
+            both = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(both, mine)
+            with D.count_collectives() as cc:
+                n = arena.allreduce()                                   # THE collective of the step
+            ok = ok and cc.total() == 1 and cc.calls == {"all_reduce": 1} and n == arena.buf.numel()
+            ok = ok and torch.allclose(arena.buf, sum(both) / world, rtol=1e-6, atol=1e-8)
+            ok = ok and not torch.equal(both[0], both[-1]) and bool(mine.abs().sum() > 0)
+            w = model.g_posterior.mus.mu_mlp0.weight                    # a non-store parameter: its .grad IS a slice of the message
+            off = (w.grad.data_ptr() - arena.buf.data_ptr()) // 4
+            ok = ok and 0 <= off < arena.buf.numel() and torch.equal(w.grad.reshape(-1), arena.buf[off:off + w.numel()])
+            results.append(float(loss))
+        # a gradient dropped behind the arena's back (optimizer.zero_grad(set_to_none=True)) is re-attached as zeros
+        model.g0_prior_mus.grad = None
+        arena.sync()
+        ok = ok and model.g0_prior_mus.grad is not None and float(model.g0_prior_mus.grad.abs().sum()) == 0.0
+        q.put((rank, bool(ok), results))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_arena_one_collective_for_the_whole_model_world2():
+    """distributed.GradArena: the gradients of the WHOLE autoencoder (encoder, posterior / prior heads, g0 prior, prior
+    flow store, point decoder store) are one flat buffer; a step's exchange is exactly one all_reduce (counted by
+    count_collectives), after which every rank holds the mean of the ranks' gradients."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_arena_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+
+
 def test_shard_bounds_cover_batch():
     from dpf_nets_amd.distributed import shard_bounds
     for n in (1, 7, 32, 33, 64):

@@ -406,3 +406,35 @@ def test_model_oracle_training_forward_vs_reference_golden(golden_dir):
     for k, v in _grad_projection([(k, grads[k]) for k in names], 23).items():
         ref = gold["gradproj/" + k]
         assert np.all(np.abs(v - ref) <= 2e-4 * (ref[2] + 1e-6) + 1e-6), (k, v, ref)
+
+
+def test_model_mirror_training_step_vs_reference_golden(golden_dir):
+    """dpf_nets_amd.networks.Local_Cond_RNVP_MC_Global_RNVP_VAE (+ its loss class) -- the mirror of models.py:13-258 /
+    losses.py:37-51 the bench's full-model training leg is built from -- loads the reference model's state dict with
+    strict=True and reproduces the reference's training step (tests/golden/model_train.npz) on the CPU tensor-op path."""
+    from oracle import model_oracle as MO
+    from oracle.gen_golden import _grad_projection
+    from dpf_nets_amd import networks as nets
+    gold = np.load(os.path.join(golden_dir, "model_train.npz"))
+    cfg = dict(MO.CONFIG, util_mode="training")
+    model = nets.Local_Cond_RNVP_MC_Global_RNVP_VAE(**cfg)
+    model.load_state_dict(FO.to_torch(MO.make_model_state(int(gold["seed"]), cfg)), strict=True)
+    model.train()
+    eps_g = torch.from_numpy(gold["eps_g"])
+    model.reparameterize = lambda mu, logvar: eps_g * torch.exp(0.5 * logvar) + mu
+    x = torch.from_numpy(gold["x"])
+    out = model(x, x)
+    loss, pnll, gnll, gent = nets.Local_Cond_RNVP_MC_Global_RNVP_VAE_Loss(**cfg)(x, x, out)
+    loss.backward()
+    np.testing.assert_allclose(np.array([float(v.detach()) for v in (loss, pnll, gnll, gent)]), gold["loss"], rtol=2e-6)
+    names = [str(k) for k in gold["grad_names"]]
+    assert [k for k, _ in model.named_parameters()] == names
+    for k, v in _grad_projection([(k, p.grad) for k, p in model.named_parameters()], 23).items():
+        ref = gold["gradproj/" + k]
+        assert np.all(np.abs(v - ref) <= 2e-4 * (ref[2] + 1e-6) + 1e-6), (k, v, ref)
+    for k, b in model.named_buffers():
+        np.testing.assert_allclose(b.detach().numpy(), gold["buffer/" + k], rtol=1e-5, atol=1e-7, err_msg=k)
+    # the other configurations construct with the reference's parameter counts (SURVEY 8e: 12 972 413 for all_scaled)
+    big = dict(cfg, g_latent_space_size=512, g_prior_n_flows=7, g_prior_n_features=128, g_posterior_n_layers=1, p_prior_n_layers=1,
+               p_decoder_n_flows=21, p_decoder_base_type="freevar")
+    assert sum(p.numel() for p in nets.Local_Cond_RNVP_MC_Global_RNVP_VAE(**big).parameters()) == 12972413
