@@ -130,6 +130,19 @@ __device__ __forceinline__ uint32_t input_weight_slot(float w, float T, int h, i
     }
 }
 
+// all eight slots of that A operand at once (slot j = 16-bit element j of the result)
+__device__ __forceinline__ u32x4 input_weight_slots8(float w, float T, int h) {
+    float r1, r2, q1, q2, dummy;
+    const uint32_t wh = split_hi(w, r1) >> 16, wm = split_hi(r1, r2) >> 16, wl = split_hi(r2, dummy) >> 16;
+    const uint32_t Th = split_hi(T, q1) >> 16, Tm = split_hi(q1, q2) >> 16, Tl = split_hi(q2, dummy) >> 16;
+    u32x4 v;
+    v.x = wh | (wh << 16);                      // j = 0, 1
+    v.y = wm | (wh << 16);                      // j = 2, 3
+    v.z = wm | (wl << 16);                      // j = 4, 5
+    v.w = h == 0 ? (Th | (Tm << 16)) : Tl;      // j = 6, 7
+    return v;
+}
+
 // feature held by accumulator register r (0..15) of M tile t in lane half h
 __device__ __forceinline__ constexpr int acc_feature(int t, int r, int h) { return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h; }
 

@@ -149,31 +149,60 @@ __global__ __launch_bounds__(256) void tstats_x_kernel(int N, int ka, int kb, co
 // (r02: a device function run by every workgroup of tstats_h1 -- the consumer -- straight into its LDS: 2 048 partial
 // values and 8 KiB of fragments are cheaper to redo 256 times than a dependent one-workgroup launch is to wait for;
 // workgroup 0 also publishes the fragments and the statistics for the kernels that follow.  512 threads.)
-__device__ __forceinline__ void bn0_fold(int nblk, int nk, double count, const double *__restrict__ part,
-                                         const float *__restrict__ tcanon_l, uint8_t *lds_a0, uint8_t *__restrict__ packed_a0,
+// the loads of bn0_fold, to be issued BEFORE the caller's weight DMA (vector-memory results return in order: issued behind
+// 48+ KB of LDS-DMA they wait for all of it): this thread's share of the moment partials, and (threads < 128) its feature's
+// W0 / gamma / beta
+struct Bn0Loads { double v[5]; float wa, wb, gamma, beta; };
+__device__ __forceinline__ Bn0Loads bn0_loads(int nblk, int nk, const double *__restrict__ part, const float *__restrict__ tcanon_l) {
+    Bn0Loads L;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) L.v[i] = 0;
+    for (int b0 = 0; b0 < nblk; b0 += 4 * TW * 64) {
+        double ld[4][5];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = b0 + threadIdx.x + k * TW * 64;
+            const bool ok = row < nblk;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) ld[k][i] = ok ? part[(size_t)(ok ? row : 0) * 8 + i] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < 5; ++i) L.v[i] += ld[k][i];
+    }
+    const int q = threadIdx.x & 127, br = q >> 6, f = q & 63;
+    const float *cb = tcanon_l + br * T_BR;
+    L.wa = cb[T_W0 + f * nk]; L.wb = nk == 2 ? cb[T_W0 + f * 2 + 1] : 0.f; L.gamma = cb[T_G0 + f]; L.beta = cb[T_B0 + f];
+    return L;
+}
+
+__device__ __forceinline__ void bn0_fold(const Bn0Loads &L, double count, uint8_t *lds_a0, uint8_t *__restrict__ packed_a0,
                                          float *__restrict__ stats_l) {
-    __shared__ double mom[5], wsum[2][5];
+    // r03: this prologue was HALF of tstats_h1 (11.8 K of 23.6 K ticks, tools/train_kprof.py): two dependent rounds of row
+    // loads on 128 threads issued behind the weight DMA, a 16-iteration slot loop of ~80 instructions.  Now the loads are in
+    // flight before the DMA on all 512 threads (bn0_loads), and a thread builds the eight K slots of one (set, branch, tile,
+    // lane) -- one 16-byte store.
+    __shared__ double mom[5], wsum[TW][5];
     __shared__ float fold[2][64][4];
     __shared__ float foldn[2][64][4];
-    {   // fixed-order tree over the per-workgroup partials (the first two waves, as before)
-        if (threadIdx.x < 128) {
-            double v[5] = {0, 0, 0, 0, 0};
-            for (int b = threadIdx.x; b < nblk; b += 128)
-                for (int i = 0; i < 5; ++i) v[i] += part[(size_t)b * 8 + i];
+    {   // fixed-order sum of the per-workgroup partials: thread -> rows tid, tid + 512, ...; wave butterflies; waves in order
+        double v[5] = {L.v[0], L.v[1], L.v[2], L.v[3], L.v[4]};
 #pragma unroll
-            for (int i = 0; i < 5; ++i)
-                for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
-            if ((threadIdx.x & 63) == 0)
-                for (int i = 0; i < 5; ++i) wsum[threadIdx.x >> 6][i] = v[i];
-        }
+        for (int i = 0; i < 5; ++i)
+            for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
+        if ((threadIdx.x & 63) == 0)
+            for (int i = 0; i < 5; ++i) wsum[threadIdx.x >> 6][i] = v[i];
         __syncthreads();
-        if (threadIdx.x < 5) mom[threadIdx.x] = (wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) / count;
+        if (threadIdx.x < 5) {
+            const int i = threadIdx.x;
+            mom[i] = (((wsum[0][i] + wsum[1][i]) + (wsum[2][i] + wsum[3][i])) + ((wsum[4][i] + wsum[5][i]) + (wsum[6][i] + wsum[7][i]))) / count;
+        }
         __syncthreads();
     }
     if (threadIdx.x < 128) {
     const int br = threadIdx.x >> 6, f = threadIdx.x & 63;
-    const float *cb = tcanon_l + br * T_BR;
-    const double wa = cb[T_W0 + f * nk], wb = nk == 2 ? cb[T_W0 + f * 2 + 1] : 0.0;
+    const double wa = L.wa, wb = L.wb;
     const double ea = mom[0], eb = mom[1];
     const double caa = mom[2] - ea * ea, cbb = mom[3] - eb * eb, cab = mom[4] - ea * eb;
     if (threadIdx.x == 0 && stats_l != nullptr) {
@@ -184,7 +213,7 @@ __device__ __forceinline__ void bn0_fold(int nblk, int nk, double count, const d
     double var = wa * wa * caa + wb * wb * cbb + 2.0 * wa * wb * cab;     // biased, as BatchNorm normalises with
     if (var < 0) var = 0;
     const float rstd = (float)(1.0 / sqrt(var + (double)BN_EPS));
-    const float gamma = cb[T_G0 + f], beta = cb[T_B0 + f];
+    const float gamma = L.gamma, beta = L.beta;
     if (stats_l != nullptr) {
     float *st = stats_l + br * ST_BR;
     st[0 * 64 + f] = (float)mean;
@@ -196,27 +225,37 @@ __device__ __forceinline__ void bn0_fold(int nblk, int nk, double count, const d
     foldn[br][f][0] = rstd * (float)wa; foldn[br][f][1] = rstd * (float)wb; foldn[br][f][2] = -(float)mean * rstd;
     }
     __syncthreads();
-    uint16_t *a0 = (uint16_t *)lds_a0, *a0n = (uint16_t *)(lds_a0 + 4096);
-    uint16_t *g0 = (uint16_t *)packed_a0, *g0n = (uint16_t *)(packed_a0 + 4096);
-    for (int idx = threadIdx.x; idx < 2 * 2 * 64 * 8; idx += blockDim.x) {
-        const int j = idx & 7, lane = (idx >> 3) & 63, t = (idx >> 9) & 1, b2 = idx >> 10;
+    static_assert(TW * 64 == 512, "one thread per (set, branch, tile, lane)");
+    {
+        const int set = threadIdx.x >> 8, rem = threadIdx.x & 255, b2 = rem >> 7, t = (rem >> 6) & 1, lane = rem & 63;
         const int ff = 32 * t + (lane & 31), h = lane >> 5;
-        const uint16_t v = (uint16_t)input_weight_slot(fold[b2][ff][h], fold[b2][ff][2], h, j);
-        const uint16_t vn = (uint16_t)input_weight_slot(foldn[b2][ff][h], foldn[b2][ff][2], h, j);
-        a0[idx] = v; a0n[idx] = vn;
-        if (packed_a0 != nullptr) { g0[idx] = v; g0n[idx] = vn; }
+        const float (*fo)[64][4] = set ? foldn : fold;
+        const u32x4 v = input_weight_slots8(fo[b2][ff][h], fo[b2][ff][2], h);
+        const int off = set * 4096 + ((b2 * 2 + t) * 64 + lane) * 16;
+        *(u32x4 *)(lds_a0 + off) = v;
+        if (packed_a0 != nullptr) *(u32x4 *)(packed_a0 + off) = v;
     }
 }
 
 // column sums of a (nrows, J) fp32 matrix of per-workgroup partials, in a fixed order, as doubles.
 // workgroup = 32 columns x 32 row groups
-__global__ __launch_bounds__(1024) void tcolsum_kernel(int nrows, int J, const float *__restrict__ part, double *__restrict__ out) {
+// dcanon_l (optional): the dW1 totals (columns 128 .. 4223 of each branch's P2_J) go straight to the layer's gradient block
+// as floats (r03: formerly a grid-stride loop in the prologue of every workgroup of the next pass 1)
+__global__ __launch_bounds__(1024) void tcolsum_kernel(int nrows, int J, const float *__restrict__ part, double *__restrict__ out,
+                                                       float *__restrict__ dcanon_l, int p2j) {
     __shared__ double acc[32][33];
     const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int j = blockIdx.x * 32 + c;
     double s = 0;
-    if (j < J)
-        for (int r = rg; r < nrows; r += 32) s += part[(size_t)r * J + j];
+    if (j < J) {
+        int r = rg;
+        for (; r + 96 < nrows; r += 128) {                                 // four rows in flight, added in row order
+            const float v0 = part[(size_t)r * J + j], v1 = part[(size_t)(r + 32) * J + j], v2 = part[(size_t)(r + 64) * J + j],
+                        v3 = part[(size_t)(r + 96) * J + j];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; r < nrows; r += 32) s += part[(size_t)r * J + j];
+    }
     acc[rg][c] = s;
     __syncthreads();
     if (rg == 0 && j < J) {
@@ -224,6 +263,10 @@ __global__ __launch_bounds__(1024) void tcolsum_kernel(int nrows, int J, const f
 #pragma unroll
         for (int r = 0; r < 32; ++r) t += acc[r][c];
         out[j] = t;
+        if (dcanon_l != nullptr) {
+            const int b2 = j / p2j, jj = j - b2 * p2j;
+            if (jj >= 128 && jj < 128 + 4096) dcanon_l[b2 * T_BR + T_W1 + jj - 128] = (float)t;
+        }
     }
 }
 
@@ -408,6 +451,13 @@ __device__ __forceinline__ int reduced_feature(int pl, int h) {
 }
 
 
+#ifdef DPF_PROFILE
+__device__ unsigned long long *g_kprof = nullptr;            // [kernel id][8] s_memtime stamps of workgroup 0, wave 0
+#define KP(kid, i) { __builtin_amdgcn_sched_barrier(0); if (g_kprof != nullptr && blockIdx.x == 1 && blockIdx.y == 3 && threadIdx.x == 0) g_kprof[(kid) * 8 + (i)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define KP(kid, i)
+#endif
+
 struct TArgs {
     const uint8_t *packed_l;     // pt_bytes(NS) of this layer
     const float *tcanon_l;       // T_LAYER floats
@@ -428,19 +478,24 @@ __global__ __launch_bounds__(TW * 64) void tstats_h1_kernel(TArgs a, float *__re
     __shared__ float acc_s[TW][2][2][64];                                 // per-wave slots (LDS float atomics are slow)
     const int bi = blockIdx.y, lane = threadIdx.x & 63, h = lane >> 5, pl = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    stage_bytes(a.packed_l, smem, NS * P_A1_PART, wave, lane);            // A1; the A0 fragments are folded right here
-    {
-        const bool first = blockIdx.x == 0 && blockIdx.y == 0;
-        bn0_fold(nblk_x, a.kb >= 0 ? 2 : 1, count, xpart, a.tcanon_l, smem + pt_a0(NS), first ? packed_a0 : nullptr,
-                 first ? const_cast<float *>(a.stats_l) : nullptr);
-    }
+    KP(0, 0)
+    // every small load first, then the weight DMA (results return in order)
+    const Bn0Loads bl = bn0_loads(nblk_x, a.kb >= 0 ? 2 : 1, xpart, a.tcanon_l);
     const int N = a.N, n = (blockIdx.x * TW + wave) * TILE + pl;
     const bool valid = n < N;
     const float *pc = a.p_in + (size_t)bi * 3 * N;
     const int nc = valid ? n : N - 1;
     const float xa = pc[(size_t)a.ka * N + nc], xb = a.kb >= 0 ? pc[(size_t)a.kb * N + nc] : 0.f;
+    asm volatile("" ::: "memory");
+    stage_bytes(a.packed_l, smem, NS * P_A1_PART, wave, lane);            // A1; the A0 fragments are folded right here
+    {
+        const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+        bn0_fold(bl, count, smem + pt_a0(NS), first ? packed_a0 : nullptr, first ? const_cast<float *>(a.stats_l) : nullptr);
+    }
     const u32x4 b0 = input_fragment(h ? xb : xa, h);
+    KP(0, 1)
     __syncthreads();
+    KP(0, 2)
 #pragma unroll
     for (int br = 0; br < 2; ++br) {
         f32x16 acc0[2], acc1[2] = {zero16(), zero16()};
@@ -466,6 +521,7 @@ __global__ __launch_bounds__(TW * 64) void tstats_h1_kernel(TArgs a, float *__re
             }
         }
     }
+    KP(0, 3)
     __syncthreads();
     if (threadIdx.x < 256) {
         float t = 0.f;
@@ -473,6 +529,7 @@ __global__ __launch_bounds__(TW * 64) void tstats_h1_kernel(TArgs a, float *__re
         for (int w = 0; w < TW; ++w) t += ((const float *)acc_s)[w * 256 + threadIdx.x];
         part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x] = t;
     }
+    KP(0, 4)
 }
 
 // BN1 batch statistics from tstats_h1's per-workgroup partials, then this step's FiLM fold:
@@ -555,23 +612,33 @@ constexpr int P2_J = 4352;       // floats of a workgroup's pass-2 partial row p
 // left in LDS (`coef`, 8 floats; `acc` is 8 KiB of scratch); EVERY workgroup of the caller runs this (128 threads of double
 // arithmetic, same operations in the same order, so the same bits), workgroup 0 also writes d gamma0 / d beta0 / dW0 and
 // the dW1 totals are converted by whoever comes first (grid-stride).  Ends with a workgroup barrier.
-__device__ __forceinline__ void bwd3_coefs(int blk, int nblk, int nk, double count, const double *__restrict__ tot,
-                                           const float *__restrict__ tcanon_l, const float *__restrict__ stats_l,
-                                           float *__restrict__ dcanon_l, double (*acc)[4][128], float *coef) {
-    const int nth = blockDim.x;
-    for (int i = blk * nth + threadIdx.x; i < 2 * 4096; i += nblk * nth) {   // dW1: (2, 4096) totals -> dcanon
-        const int b2 = i >> 12, j = i & 4095;
-        dcanon_l[b2 * T_BR + T_W1 + j] = (float)tot[(size_t)b2 * P2_J + 128 + j];
-    }
+struct CoefLoads { double Sg, S, Sa, Sb; float ea, eb, caa, cbb, cab, wa, wb, gamma, rstd0, mean0; };
+// the loads of bwd3_coefs (threads < 128), to be issued BEFORE the caller's weight DMA
+__device__ __forceinline__ CoefLoads bwd3_loads(int nk, const double *__restrict__ tot, const float *__restrict__ tcanon_l,
+                                                const float *__restrict__ stats_l) {
+    CoefLoads L;
+    const int q = threadIdx.x & 127, br = q >> 6, f = q & 63;
+    const double *t = tot + (size_t)br * P2_J;
+    const float *cb = tcanon_l + br * T_BR;
+    L.Sg = t[f]; L.S = t[64 + f]; L.Sa = t[4224 + f]; L.Sb = t[4288 + f];
+    const float *m = stats_l + ST_MOM;
+    L.ea = m[0]; L.eb = m[1]; L.caa = m[2]; L.cbb = m[3]; L.cab = m[4];
+    L.wa = cb[T_W0 + f * nk]; L.wb = nk == 2 ? cb[T_W0 + f * 2 + 1] : 0.f; L.gamma = cb[T_G0 + f];
+    L.rstd0 = stats_l[br * ST_BR + 64 + f]; L.mean0 = stats_l[br * ST_BR + f];
+    return L;
+}
+__device__ __forceinline__ void bwd3_coefs(const CoefLoads &L, int blk, int nk, double count, float *__restrict__ dcanon_l,
+                                           double (*acc)[8], float *coef) {
+    // r03: 8.9 K of tbwd1's 31 K ticks were this prologue (tools/train_kprof.py): loads issued behind the weight DMA, eight
+    // serial 128-term double sums out of LDS by eight threads, three barriers, and a grid-stride dW1 conversion loop.  Now:
+    // loads in flight before the DMA (bwd3_loads), wave butterflies, two partials per value, one barrier; tcolsum converts
+    // dW1 itself.  acc: [2][8] doubles of scratch.
     if (threadIdx.x < 128) {
         const int br = threadIdx.x >> 6, f = threadIdx.x & 63;
-        const double *t = tot + (size_t)br * P2_J;
-        const float *cb = tcanon_l + br * T_BR;
-        const double Sg = t[f], S = t[64 + f], Sa = t[4224 + f], Sb = t[4288 + f];
-        const float *m = stats_l + ST_MOM;
-        const double ea = m[0], eb = m[1], caa = m[2], cbb = m[3], cab = m[4];
-        const double wa = cb[T_W0 + f * nk], wb = nk == 2 ? cb[T_W0 + f * 2 + 1] : 0.0, gamma = cb[T_G0 + f];
-        const double rstd0 = stats_l[br * ST_BR + 64 + f], mean0 = stats_l[br * ST_BR + f];
+        const double Sg = L.Sg, S = L.S, Sa = L.Sa, Sb = L.Sb;
+        const double ea = L.ea, eb = L.eb, caa = L.caa, cbb = L.cbb, cab = L.cab;
+        const double wa = L.wa, wb = L.wb, gamma = L.gamma;
+        const double rstd0 = L.rstd0, mean0 = L.mean0;
         const double A = S / count, Bc = Sg / count;
         const double hxa = rstd0 * (wa * caa + wb * cab), hxb = rstd0 * (wa * cab + wb * cbb);     // E[h0n x_k]
         const double sc = rstd0 * gamma;
@@ -583,27 +650,29 @@ __device__ __forceinline__ void bwd3_coefs(int blk, int nblk, int nk, double cou
             else dcanon_l[br * T_BR + T_W0 + 64 + f] = 0.f;
         }
         const double ck[2] = {wa * sc, wb * sc};
+        double v[8];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            acc[k][0][threadIdx.x] = ck[k] * A;
-            acc[k][1][threadIdx.x] = ck[k] * Bc * rstd0 * wa;
-            acc[k][2][threadIdx.x] = ck[k] * Bc * rstd0 * wb;
-            acc[k][3][threadIdx.x] = ck[k] * Bc * rstd0 * mean0;
+            v[4 * k + 0] = ck[k] * A;
+            v[4 * k + 1] = ck[k] * Bc * rstd0 * wa;
+            v[4 * k + 2] = ck[k] * Bc * rstd0 * wb;
+            v[4 * k + 3] = ck[k] * Bc * rstd0 * mean0;
         }
-    }
-    __syncthreads();
-    if (threadIdx.x < 8) {
-        const int k = threadIdx.x >> 2, q = threadIdx.x & 3;
-        double s = 0;
-        for (int i = 0; i < 128; ++i) s += acc[k][q][i];
-        acc[k][q][0] = s;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
+        if (f == 0)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[br][i] = v[i];
     }
     __syncthreads();
     if (threadIdx.x < 2) {
         const int k = threadIdx.x;
-        coef[k * 4 + 0] = (float)(acc[k][0][0] - acc[k][3][0]);
-        coef[k * 4 + 1] = (float)acc[k][1][0];
-        coef[k * 4 + 2] = (float)acc[k][2][0];
+        const double s0 = acc[0][4 * k + 0] + acc[1][4 * k + 0], s1 = acc[0][4 * k + 1] + acc[1][4 * k + 1];
+        const double s2 = acc[0][4 * k + 2] + acc[1][4 * k + 2], s3 = acc[0][4 * k + 3] + acc[1][4 * k + 3];
+        coef[k * 4 + 0] = (float)(s0 - s3);
+        coef[k * 4 + 1] = (float)s1;
+        coef[k * 4 + 2] = (float)s2;
     }
     __syncthreads();
 }
@@ -642,6 +711,10 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int h4 = 4 * h;                   // opaque to the optimiser: feature offsets stay "lane base + immediate"
     asm volatile("" : "+v"(h4));      // (as known bits they become OR-ed constants, one live register each)
+    KP(1, 0)
+    CoefLoads cl = {};
+    if (pv.has) cl = bwd3_loads(pv.kb >= 0 ? 2 : 1, pv.tot, pv.tcanon_l, pv.stats_l);    // before the DMA: results return in order
+    asm volatile("" ::: "memory");
     stage_bytes(a.packed_l, smem + L_PACK, pt_a0n(NS), wave, lane);
     stage_bytes((const uint8_t *)(a.film_l + (size_t)bi * 512), smem + L_FILM, 2048, wave, lane);
     stage_bytes((const uint8_t *)(a.filmb_l + (size_t)bi * FB_CLOUD), smem + L_FILMB, 2048, wave, lane);
@@ -649,8 +722,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
     if (threadIdx.x < 256) w2s[threadIdx.x] = a.tcanon_l[(threadIdx.x >> 7) * T_BR + T_W2 + (threadIdx.x & 127)];
     float *pcoef = w2s + 256 + TW * 64;                                         // 8 floats behind the per-wave scratch
     if (pv.has)   // the previous backward layer's pass 3, under the weight DMA (scratch: the reduction slots, free until the end)
-        bwd3_coefs(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, pv.kb >= 0 ? 2 : 1, pv.count, pv.tot, pv.tcanon_l,
-                   pv.stats_l, pv.dcanon_l, (double (*)[4][128])red, pcoef);
+        bwd3_coefs(cl, blockIdx.y * gridDim.x + blockIdx.x, pv.kb >= 0 ? 2 : 1, pv.count, pv.dcanon_l, (double (*)[8])red, pcoef);
     const int N = a.N, n = (blockIdx.x * TW + wave) * TILE + pl;
     const bool valid = n < N;
     const int nc = valid ? n : N - 1;
@@ -683,7 +755,9 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
     }
     const float xa = sel3(a.ka, p[0], p[1], p[2]), xb = a.kb >= 0 ? sel3(a.kb, p[0], p[1], p[2]) : 0.f;
     const u32x4 b0 = input_fragment(h ? xb : xa, h);
+    KP(1, 1)
     __syncthreads();
+    KP(1, 2)
     const float *film = (const float *)(smem + L_FILM);
     const float *filmb = (const float *)(smem + L_FILMB);
     // ---- coupling transform and its derivative (flows.py:96-115)
@@ -779,6 +853,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();                                   // the scratch is rewritten for the next branch
     }
+    KP(1, 3)
     __syncthreads();
     const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
     for (int i = threadIdx.x; i < 516; i += TW * 64) {
@@ -799,6 +874,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
         *tk = __hip_atomic_fetch_add(&tickets[bi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const int nb = gridDim.x;
+    KP(1, 4)
     if (*tk != (unsigned)(nb - 1)) return;
     for (int j = threadIdx.x; j < 516; j += TW * 64) {
         float s = 0.f;
@@ -838,6 +914,10 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
                                                         const float *__restrict__ dout,
                                                         float *__restrict__ ubuf, float *__restrict__ part2) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+#ifdef DPF_PROFILE
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
+    KP(2, 0)
     constexpr int L_FILM = l_film(NS), L_FILMB = l_filmb(NS), L_RED = l_red(NS);
     float *cf = (float *)(smem + L_RED) + 256;                             // c_fk [2 br][2][64]   (first 1 KB of the region: spare)
     float *redw = (float *)(smem + L_RED + 4096);                          // per-wave slots (8 KB) of the workgroup reduction; their head is the wave's per-point scratch before that
@@ -845,14 +925,30 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int h4 = 4 * h;                   // opaque to the optimiser: feature offsets stay "lane base + immediate"
     asm volatile("" : "+v"(h4));      // (as known bits they become OR-ed constants, one live register each)
-    stage_bytes(a.packed_l, smem + L_PACK, pt_bytes(NS), wave, lane);
-    stage_bytes((const uint8_t *)(a.film_l + (size_t)bi * 512), smem + L_FILM, 2048, wave, lane);
-    stage_bytes((const uint8_t *)(a.filmb_l + (size_t)bi * FB_CLOUD), smem + L_FILMB, 2048, wave, lane);
+    KP(3, 0)
+    // r03: the loads of the prologue's tiny reductions are issued BEFORE the 92 KB weight DMA -- vector-memory results
+    // return in order, so issued behind it they waited for all of it (tools/train_kprof.py: 5.8 K ticks for 24 loads)
+    const int mq = threadIdx.x & 127, mbr = mq >> 6, mf = mq & 63, mg4 = threadIdx.x >> 7;     // means: (branch, feature) x clouds mg4, mg4 + 4, ...
+    float m_av[8], m_q3[8], m_q2[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const int b = mg4 + 4 * jj;
+        const bool ok = b < a.B;
+        const float *qq = pcs + (size_t)(ok ? b : 0) * 520 + mbr * 256;
+        m_av[jj] = ok ? a.filmb_l[(size_t)b * FB_CLOUD + mbr * FB_BR + mf] : 0.f;
+        m_q3[jj] = ok ? qq[3 * 64 + mf] : 0.f;
+        m_q2[jj] = ok ? qq[2 * 64 + mf] : 0.f;
+    }
+    // ... and so are the small table / per-point loads (registers now, LDS writes after the DMA is issued)
+    float cf_w = 0.f, cf_r = 0.f, cf_g = 0.f, w2_v = 0.f;
     if (threadIdx.x < 256) {                                               // c_fk = W0[f][k] * rstd0_f * gamma0_f
         const int br = threadIdx.x >> 7, k = (threadIdx.x >> 6) & 1, f = threadIdx.x & 63;
         const float *cb = a.tcanon_l + br * T_BR;
         const int nk = a.kb >= 0 ? 2 : 1;
-        cf[threadIdx.x] = (k < nk ? cb[T_W0 + f * nk + k] : 0.f) * a.stats_l[br * ST_BR + 64 + f] * cb[T_G0 + f];
+        cf_w = k < nk ? cb[T_W0 + f * nk + k] : 0.f; cf_r = a.stats_l[br * ST_BR + 64 + f]; cf_g = cb[T_G0 + f];
+    } else {
+        const int i = threadIdx.x - 256;
+        w2_v = a.tcanon_l[(i >> 7) * T_BR + T_W2 + (i & 127)];
     }
     const int N = a.N, n = (blockIdx.x * TW + wave) * TILE + pl;
     const bool valid = n < N;
@@ -861,41 +957,62 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
     const float xa = pc[(size_t)a.ka * N + nc], xb = a.kb >= 0 ? pc[(size_t)a.kb * N + nc] : 0.f;
     const float *dq = dout + (size_t)bi * 4 * N + nc;
     const float dov[2][2] = {{dq[0], dq[N]}, {dq[2 * (size_t)N], dq[3 * (size_t)N]}};
+    asm volatile("" ::: "memory");
+    stage_bytes(a.packed_l, smem + L_PACK, pt_bytes(NS), wave, lane);
+    stage_bytes((const uint8_t *)(a.film_l + (size_t)bi * 512), smem + L_FILM, 2048, wave, lane);
+    stage_bytes((const uint8_t *)(a.filmb_l + (size_t)bi * FB_CLOUD), smem + L_FILMB, 2048, wave, lane);
+    KP(3, 1)
     const u32x4 b0 = input_fragment(h ? xb : xa, h);
     const float *film = (const float *)(smem + L_FILM);
     const float *filmb = (const float *)(smem + L_FILMB);
     const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
     float *s12s = cf + 256;                                                // [2 br][2][64] BN1 backward means
     float *w2s = s12s + 256;                                               // [2 br][2][64] raw sd2.weight
-    if (threadIdx.x >= 256) {
-        const int i = threadIdx.x - 256;
-        w2s[i] = a.tcanon_l[(i >> 7) * T_BR + T_W2 + (i & 127)];
-    }
+    if (threadIdx.x < 256) cf[threadIdx.x] = cf_w * cf_r * cf_g;
+    else w2s[threadIdx.x - 256] = w2_v;
+    KP(3, 2)
     {   // BN1-backward means s12[br][2][64] = (sum dh1n, sum dh1n*h1n) / P over the per-cloud totals of pass 1 -- what
         // the one-workgroup tfinish1 kernel did, recomputed by every workgroup (same sums in the same order, under the
         // weight DMA; a dependent tiny launch costs ~4.5 us); workgroup 0 also writes dW2 / db2.  Scratch: redw.
         double (*acc)[5][128] = (double (*)[5][128])redw;
-        const int q = threadIdx.x & 127, br_ = q >> 6, f_ = q & 63;
+        const int q = mq, br_ = mbr, f_ = mf, g4 = mg4;
         const bool first = blockIdx.x == 0 && blockIdx.y == 0;
-        for (int gg = threadIdx.x >> 7; gg < 8; gg += TW / 2) {
-            double S1 = 0, S2 = 0, w2a = 0, w2b = 0, bb = 0;
-            for (int b = gg; b < a.B; b += 8) {
-                const float *qq = pcs + (size_t)b * 520 + br_ * 256;
-                const double av = a.filmb_l[(size_t)b * FB_CLOUD + br_ * FB_BR + f_];
-                S1 += av * qq[3 * 64 + f_];                                    // dh1n = a * dh2a
-                S2 += av * qq[2 * 64 + f_];                                    // dh1n * h1n
-                if (first) {
+        double S1 = 0, S2 = 0, w2a = 0, w2b = 0, bb = 0;
+        for (int b0 = 0; b0 < a.B; b0 += 32) {
+            if (b0 > 0) {                                                      // more than 32 clouds: further rounds (rare)
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int b = b0 + g4 + 4 * jj;
+                    const bool ok = b < a.B;
+                    const float *qq = pcs + (size_t)(ok ? b : 0) * 520 + br_ * 256;
+                    m_av[jj] = ok ? a.filmb_l[(size_t)b * FB_CLOUD + br_ * FB_BR + f_] : 0.f;
+                    m_q3[jj] = ok ? qq[3 * 64 + f_] : 0.f;
+                    m_q2[jj] = ok ? qq[2 * 64 + f_] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                S1 += (double)m_av[jj] * m_q3[jj];                             // dh1n = a * dh2a
+                S2 += (double)m_av[jj] * m_q2[jj];                             // dh1n * h1n
+            }
+            if (first)
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int b = b0 + g4 + 4 * jj;
+                    if (b >= a.B) break;
+                    const float *qq = pcs + (size_t)b * 520 + br_ * 256;
                     w2a += qq[0 * 64 + f_]; w2b += qq[1 * 64 + f_];
                     if (f_ < 2) bb += pcs[(size_t)b * 520 + 512 + br_ * 2 + f_];
                 }
-            }
-            acc[gg][0][q] = S1; acc[gg][1][q] = S2; acc[gg][2][q] = w2a; acc[gg][3][q] = w2b; acc[gg][4][q] = bb;
         }
+        KP(3, 3)
+        acc[g4][0][q] = S1; acc[g4][1][q] = S2; acc[g4][2][q] = w2a; acc[g4][3][q] = w2b; acc[g4][4][q] = bb;
+        KP(3, 4)
         __syncthreads();
+        KP(3, 5)
         if (threadIdx.x < 128) {
             double S1 = 0, S2 = 0, w2a = 0, w2b = 0, bb = 0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { S1 += acc[k][0][q]; S2 += acc[k][1][q]; w2a += acc[k][2][q]; w2b += acc[k][3][q]; bb += acc[k][4][q]; }
+            for (int k = 0; k < 4; ++k) { S1 += acc[k][0][q]; S2 += acc[k][1][q]; w2a += acc[k][2][q]; w2b += acc[k][3][q]; bb += acc[k][4][q]; }
             s12s[(br_ * 2 + 0) * 64 + f_] = (float)(S1 / count);
             s12s[(br_ * 2 + 1) * 64 + f_] = (float)(S2 / count);
             if (first) {
@@ -906,6 +1023,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
         }
     }
     float ua = 0.f, ub = 0.f;
+    KP(2, 1)
 #ifdef DPF_PROFILE
     unsigned long long tt[12];
     tt[11] = __builtin_amdgcn_s_memtime();
@@ -1094,14 +1212,20 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
         TP(10)
     }
 #ifdef DPF_PROFILE
-    if (g_tprof != nullptr && lane == 0 && blk < 2)
-        for (int i = 0; i < 12; ++i) g_tprof[(blk * TW + wave) * 12 + i] = tt[i];
 #endif
     ua += __shfl_xor(ua, 32); ub += __shfl_xor(ub, 32);
     if (valid && h == 0) {
         ubuf[((size_t)bi * 2 + 0) * N + n] = ua;
         ubuf[((size_t)bi * 2 + 1) * N + n] = ub;
     }
+    KP(2, 2)
+#ifdef DPF_PROFILE
+    if (g_tprof != nullptr && lane == 0 && blk < 2) {
+        for (int i = 0; i < 12; ++i) g_tprof[(blk * TW + wave) * 14 + i] = tt[i];
+        g_tprof[(blk * TW + wave) * 14 + 12] = t_entry;
+        g_tprof[(blk * TW + wave) * 14 + 13] = __builtin_amdgcn_s_memtime();
+    }
+#endif
 }
 
 // (tbwd3f_kernel below) Totals of pass 2 -> d gamma0, d beta0, dW1, dW0 and the coefficients of the input gradient.
@@ -1119,9 +1243,9 @@ __global__ __launch_bounds__(256) void tbwd3f_kernel(int N, int ka, int kb, int 
                                                      const float *__restrict__ tcanon_l, const float *__restrict__ stats_l,
                                                      float *__restrict__ dcanon_l, const float *__restrict__ p_in,
                                                      const float *__restrict__ ubuf, float *__restrict__ dp_in) {
-    __shared__ double acc[2][4][128];
+    __shared__ double acc[2][8];
     __shared__ float coef[8];
-    bwd3_coefs(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, nk, count, tot, tcanon_l, stats_l, dcanon_l, acc, coef);
+    bwd3_coefs(bwd3_loads(nk, tot, tcanon_l, stats_l), blockIdx.y * gridDim.x + blockIdx.x, nk, count, dcanon_l, acc, coef);
     const int bi = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     const float *pc = p_in + (size_t)bi * 3 * N;
@@ -1304,7 +1428,7 @@ static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb
     hipLaunchKernelGGL(tbwd1_kernel<NS>, grid, dim3(TW * 64), lds1, s, a, g_p, g_p2, g_mu, g_lv, mu_l, lv_l, dp_in, w.dout, w.part1, *pv,
                        w.tickets, w.pc, dfm_l);
     hipLaunchKernelGGL(tbwd2_kernel<NS>, grid, dim3(TW * 64), lds2, s, a, w.pc, count, dcanon_l, w.dout, w.ubuf, w.part2);
-    hipLaunchKernelGGL(tcolsum_kernel, dim3((2 * P2_J + 31) / 32), dim3(1024), 0, s, nblk, 2 * P2_J, w.part2, w.tot2);
+    hipLaunchKernelGGL(tcolsum_kernel, dim3((2 * P2_J + 31) / 32), dim3(1024), 0, s, nblk, 2 * P2_J, w.part2, w.tot2, dcanon_l, P2_J);
     // pass 3 (the conditioner path of d(input points), d gamma0 / d beta0 / dW0 / dW1 from the totals): folded into the NEXT
     // backward layer's pass 1, which needs that gradient anyway; only the last layer of the call launches it
     if (last)
@@ -1430,6 +1554,11 @@ extern "C" void dpf_train_graph_stats(long *out) {
 extern "C" int dpf_train_graph_set_enabled(int on) { return dpf_graph_enabled_flag().exchange(on ? 1 : 0); }
 
 #ifdef DPF_PROFILE
+__global__ void kprof_set_kernel(unsigned long long *p) { g_kprof = p; }
+extern "C" void dpf_debug_set_kprof(void *p) {
+    hipLaunchKernelGGL(kprof_set_kernel, dim3(1), dim3(1), 0, 0, (unsigned long long *)p);
+    hipDeviceSynchronize();
+}
 extern "C" void dpf_debug_set_tprof(void *p) {
     hipLaunchKernelGGL(tprof_set_kernel, dim3(1), dim3(1), 0, 0, (unsigned long long *)p);
     hipDeviceSynchronize();

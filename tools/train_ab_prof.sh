@@ -12,13 +12,22 @@ for so in "$@"; do
   rm -rf $OUT/kt_$so
   python3 - "$OUT/trace_$so.txt" "$so" <<'PY'
 import sys
-tot = 0.0; rows = []
+tot = 0.0; rows = []; base = None
+names = ("tbwd2_kernel", "tbwd1_kernel", "tstats_h1_kernel", "flow_kernel", "tfold_kernel", "tcolsum_kernel", "tbwd3f", "tstats_x", "dpf_zero_words")
+found = {}
 for l in open(sys.argv[1]):
     p = l.split()
-    if len(p) > 4 and p[1].isdigit() and int(p[1]) in (1008, 2016, 1024, 992, 3024):
-        calls, avg = int(p[1]), float(p[2])
-        tot += calls / 1008.0 * avg / 1e3
-        rows.append("%s x%d %.1f" % (p[0][18:34], calls // 1008 if calls >= 1008 else 1, avg / 1e3))
+    if len(p) > 4 and p[1].isdigit():
+        for n in names:
+            if n in p[0]:
+                found[n] = (int(p[1]), float(p[2]))
+base = found["tbwd2_kernel"][0]
+for n in names:
+    if n in found:
+        calls, avg = found[n]
+        per = calls / base * avg / 1e3
+        tot += per
+        rows.append("%s %.2f" % (n.replace("_kernel", ""), per))
 print(sys.argv[2], "per-layer kernel sum %.1f us |" % tot, "; ".join(rows))
 PY
 done

@@ -16,7 +16,7 @@ names = ["loop top", "sync+zero", "fwd recompute", "dh1", "T chain + mask", "red
          "LDS atomics", "sync", "write out"]
 for prec in ("bf16x3", "bf16x6"):
     train_engine.TRAIN_PRECISION = prec
-    prof = torch.zeros((16, 12), dtype=torch.int64, device="cuda")
+    prof = torch.zeros((16, 14), dtype=torch.int64, device="cuda")
     for it in range(3):
         if it == 2: h.dpf_debug_set_tprof(prof.data_ptr())
         x = torch.from_numpy(tgt).cuda().requires_grad_(True)
@@ -26,6 +26,7 @@ for prec in ("bf16x3", "bf16x6"):
     h.dpf_debug_set_tprof(None)
     t = prof.cpu().numpy()
     d = np.diff(t[:, :11], axis=1)
-    print(prec, "entry->loop:", np.median(t[:, 0] - t[:, 11]))
+    print(prec, "kernel entry -> after the prologue:", np.median(t[:, 11] - t[:, 12]), " prologue end -> loop:", np.median(t[:, 0] - t[:, 11]),
+          " branch 0:", np.median(t[:, 10] - t[:, 0]), " whole kernel (this wave):", np.median(t[:, 13] - t[:, 12]))
     for i in range(10):
         print("   %-16s median %8.0f  max %8.0f" % (names[i + 1], np.median(d[:, i]), d[:, i].max()))
