@@ -261,7 +261,7 @@ def make_kernels(dec, z, g, tgt_pm, L, precision):
     from dpf_nets_amd._lib import lib, PREC, MODE, current_stream
     from dpf_nets_amd.metrics.StructuralLosses import StructuralLossesBackend as BK
     stack = dec.stack()
-    canon, meta, packed, G = stack._ensure(precision, z.device, L)
+    canon, meta, packed, G, precision = stack._ensure(precision, z.device, L)
     B, _, N = z.shape
     film = torch.empty(lib().dpf_flow_film_floats(L, B), dtype=torch.float32, device=z.device)
     p_out, sum_lv = torch.empty_like(z), torch.empty_like(z)

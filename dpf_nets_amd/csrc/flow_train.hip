@@ -89,7 +89,7 @@ __device__ __forceinline__ f32x16 zero16() {
 // ===================================================================================================
 // pack: W1 and W1^T fragments for every layer (once per optimizer step)
 // ===================================================================================================
-template <int NS>
+template <int NS, bool F16 = false>
 __global__ __launch_bounds__(256) void tpack_kernel(const float *__restrict__ tcanon, uint8_t *__restrict__ packed) {
     const int l = blockIdx.x;
     const float *cl = tcanon + (size_t)l * T_LAYER;
@@ -102,10 +102,16 @@ __global__ __launch_bounds__(256) void tpack_kernel(const float *__restrict__ tc
         const float *W1 = cl + br * T_BR + T_W1;
         float r1, r2;
         const float w = W1[(32 * tp + i) * 64 + fk];                // forward: rows = out feature, K = in feature
-        o1[idx] = (uint16_t)(split_hi(w, r1) >> 16);
-        if (NS == 2) {
+        if (F16) {                     // fp16 hi (RNE) + fp16 of the exact remainder, as csrc/flow.hip pack_kernel<2, true>
+            const _Float16 wh = (_Float16)w;
+            const _Float16 wl = (_Float16)(w - (float)wh);
+            o1[idx] = __builtin_bit_cast(uint16_t, wh);
+            o1[P_A1_PART / 2 + idx] = __builtin_bit_cast(uint16_t, wl);
+        } else if (NS == 2) {
+            o1[idx] = (uint16_t)(split_hi(w, r1) >> 16);
             o1[P_A1_PART / 2 + idx] = (uint16_t)bf16_rne(r1);
         } else {
+            o1[idx] = (uint16_t)(split_hi(w, r1) >> 16);
             o1[P_A1_PART / 2 + idx] = (uint16_t)(split_hi(r1, r2) >> 16);
             o1[P_A1_PART + idx] = (uint16_t)bf16_rne(r2);
         }
@@ -327,14 +333,22 @@ __device__ __forceinline__ void kfrags_from_swapped(const f32x16 (&v)[2], u32x4 
 // (register r of M tile t = element j = r&7 of k-step 2t + (r>>3)); RELU = clamp at zero first.
 // Same arithmetic as branch_tile in csrc/flow.hip: the recomputed activations are bit-identical to
 // the forward kernel's.
-template <bool RELU, int NS, bool SYM = false>
-__device__ __forceinline__ void split_fragment(const f32x16 (&v)[2], u32x4 (&bf)[NS][4]) {
+template <bool RELU, int NS, bool SYM = false, bool F16 = false>
+__device__ __forceinline__ void split_fragment(const f32x16 (&v)[2], u32x4 (&bf)[NS][4], float negone = -1.0f) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-            const float v0 = RELU ? relu(v[t][r]) : v[t][r], v1 = RELU ? relu(v[t][r + 1]) : v[t][r + 1];
             const int s = 2 * t + (r >> 3), d = (r & 7) >> 1;
+            if constexpr (F16) {               // the forward kernel's fp16 hi/lo split with the ReLU folded in (flow_common.h)
+                static_assert(!F16 || (NS == 2 && RELU && !SYM), "f16x3: forward operands only");
+                uint32_t hp, lp;
+                split_relu_f16(v[t][r], v[t][r + 1], negone, hp, lp);
+                bf[0][s][d] = hp;
+                bf[1][s][d] = lp;
+                continue;
+            }
+            const float v0 = RELU ? relu(v[t][r]) : v[t][r], v1 = RELU ? relu(v[t][r + 1]) : v[t][r + 1];
             if constexpr (SYM) {               // backward-only operand (NS == 2): symmetric split
                 static_assert(!SYM || NS == 2, "symmetric split: hi/lo only");
                 uint32_t hp, lp;
@@ -360,7 +374,7 @@ __device__ __forceinline__ void split_fragment(const f32x16 (&v)[2], u32x4 (&bf)
 // acc[tp] += A1[br] . B  with the split terms of Terms<NS>; a1 = base of [part][br][tp][s][lane].  Same order as
 // branch_tile in csrc/flow.hip (k-step major; the fragment of each part is loaded once and feeds every term that
 // uses it): the recomputed pre-activations are bit-identical to the forward kernel's.
-template <int NS>
+template <int NS, bool F16 = false>
 __device__ __forceinline__ void chain_mfma(const uint8_t *a1, int br, int lane, const u32x4 (&bf)[NS][4], f32x16 (&acc)[2]) {
     using TT = Terms<NS>;
 #pragma unroll
@@ -374,7 +388,8 @@ __device__ __forceinline__ void chain_mfma(const uint8_t *a1, int br, int lane, 
 #pragma unroll
         for (int term = 0; term < TT::N; ++term)
 #pragma unroll
-            for (int tp = 0; tp < 2; ++tp) acc[tp] = mfma(af[TT::A[term]][tp], bf[TT::B[term]][s], acc[tp]);
+            for (int tp = 0; tp < 2; ++tp)
+                acc[tp] = F16 ? mfma_f16(af[TT::A[term]][tp], bf[TT::B[term]][s], acc[tp]) : mfma(af[TT::A[term]][tp], bf[TT::B[term]][s], acc[tp]);
     }
 }
 
@@ -382,7 +397,7 @@ __device__ __forceinline__ void chain_mfma(const uint8_t *a1, int br, int lane, 
 // 32x32x16 MFMA mirror each other, so the same registers and the same packed fragments serve): the accumulator of
 // M tile tp then holds, in LANE pl, feature 32*tp + pl of the 16 POINTS (r&3) + 8*(r>>2) + 4h of the tile -- sums
 // over the points of a tile become in-lane adds plus one cross-half swap instead of a cross-lane butterfly.
-template <int NS>
+template <int NS, bool F16 = false>
 __device__ __forceinline__ void chain_mfma_swapped(const uint8_t *a1, int br, int lane, const u32x4 (&bf)[NS][4], f32x16 (&acc)[2]) {
     using TT = Terms<NS>;
 #pragma unroll
@@ -396,7 +411,8 @@ __device__ __forceinline__ void chain_mfma_swapped(const uint8_t *a1, int br, in
 #pragma unroll
         for (int term = 0; term < TT::N; ++term)
 #pragma unroll
-            for (int tp = 0; tp < 2; ++tp) acc[tp] = mfma(bf[TT::B[term]][s], af[TT::A[term]][tp], acc[tp]);
+            for (int tp = 0; tp < 2; ++tp)
+                acc[tp] = F16 ? mfma_f16(bf[TT::B[term]][s], af[TT::A[term]][tp], acc[tp]) : mfma(bf[TT::B[term]][s], af[TT::A[term]][tp], acc[tp]);
     }
 }
 
@@ -467,11 +483,12 @@ struct TArgs {
     const float *p_in;           // (B, 3, N)
     int B, N, ka, kb, wa, wb, mode;
     float eps;
+    float negone;                // -1.0f, as a kernel argument so that it sits in an SGPR the compiler cannot see through (split_relu_f16)
 };
 
 // h1 = W1 relu(BN0(W0 x)) for every point; per-workgroup partial sums and sums of squares
 //   part[blk][br][2][64]
-template <int NS>
+template <int NS, bool F16 = false>
 __global__ __launch_bounds__(TW * 64) void tstats_h1_kernel(TArgs a, float *__restrict__ part, int nblk_x, double count,
                                                             const double *__restrict__ xpart, uint8_t *__restrict__ packed_a0) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -501,8 +518,8 @@ __global__ __launch_bounds__(TW * 64) void tstats_h1_kernel(TArgs a, float *__re
         f32x16 acc0[2], acc1[2] = {zero16(), zero16()};
         u32x4 bf[NS][4];
         input_mfma(smem + pt_a0(NS), br, lane, b0, acc0);
-        split_fragment<true, NS>(acc0, bf);
-        chain_mfma_swapped<NS>(smem + PT_A1, br, lane, bf, acc1);         // lane = feature, registers = points
+        split_fragment<true, NS, false, F16>(acc0, bf, a.negone);
+        chain_mfma_swapped<NS, F16>(smem + PT_A1, br, lane, bf, acc1);         // lane = feature, registers = points
         const int tile0 = (blockIdx.x * TW + wave) * TILE;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -697,7 +714,7 @@ struct PrevLayer {
 //   stores  dout (B,4,N) = d(o_logvar a,b), d(o_mu a,b)         dp_in <- direct term  g * d(p_out)/d(p)
 //   partial sums per workgroup: part1[blk][br][k][64], k = 0 dW2a, 1 dW2b, 2 da, 3 dc;  part1[blk][512 + br*2 + w] = db2
 // the gradient w.r.t. p_out is g_p + g_p2 (either may be NULL = zero, like g_mu and g_lv)
-template <int NS>
+template <int NS, bool F16 = false>
 __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__restrict__ g_p, const float *__restrict__ g_p2,
                                                         const float *__restrict__ g_mu, const float *__restrict__ g_lv,
                                                         const float *__restrict__ mu_l, const float *__restrict__ lv_l,
@@ -807,14 +824,14 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
             f32x16 acc0[2];
             u32x4 bf[NS][4];
             input_mfma(smem + L_PACK + pt_a0(NS), br, lane, b0, acc0);
-            split_fragment<true, NS>(acc0, bf);
+            split_fragment<true, NS, false, F16>(acc0, bf, a.negone);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const float dsh = film[br * FILM_BR_FLOATS + 32 * t + pl];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) pre[t][r] = dsh;
             }
-            chain_mfma_swapped<NS>(smem + L_PACK + PT_A1, br, lane, bf, pre);
+            chain_mfma_swapped<NS, F16>(smem + L_PACK + PT_A1, br, lane, bf, pre);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -909,7 +926,7 @@ __device__ unsigned long long *g_tprof = nullptr;
 #else
 #define TP(i)
 #endif
-template <int NS>
+template <int NS, bool F16 = false>
 __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__restrict__ pcs, double count, float *__restrict__ dcanon_l,
                                                         const float *__restrict__ dout,
                                                         float *__restrict__ ubuf, float *__restrict__ part2) {
@@ -1052,14 +1069,14 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
         {
             u32x4 bf[NS][4];
             input_mfma(smem + L_PACK + pt_a0(NS), br, lane, b0, h0a);      // gamma*h0n + beta
-            split_fragment<true, NS>(h0a, bf);
+            split_fragment<true, NS, false, F16>(h0a, bf, a.negone);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const float dsh = film[br * FILM_BR_FLOATS + 32 * t + pl];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) pre[t][r] = dsh;
             }
-            chain_mfma_swapped<NS>(smem + L_PACK + PT_A1, br, lane, bf, pre);   // same products in the same order as the forward kernel
+            chain_mfma_swapped<NS, F16>(smem + L_PACK + PT_A1, br, lane, bf, pre);   // same products in the same order as the forward kernel
         }
         TP(2)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1263,7 +1280,10 @@ __global__ void tprof_set_kernel(unsigned long long *p) { g_tprof = p; }
 
 }  // namespace
 
-static inline int t_ns(int precision) { return precision == DPF_PREC_BF16X3 ? 2 : (precision == DPF_PREC_BF16X6 ? 3 : 0); }
+// operand parts of the forward contraction; DPF_PREC_F16X3 shares the hi/lo layout of bf16x3 with fp16 values (r03)
+static inline int t_ns(int precision) {
+    return (precision == DPF_PREC_BF16X3 || precision == DPF_PREC_F16X3) ? 2 : (precision == DPF_PREC_BF16X6 ? 3 : 0);
+}
 
 extern "C" size_t dpf_flow_train_canon_floats(void) { return (size_t)T_LAYER; }
 extern "C" size_t dpf_flow_train_packed_bytes(int n_layers, int precision) {
@@ -1312,12 +1332,13 @@ extern "C" int dpf_flow_train_pack(int n_layers, int precision, const float *tca
     const int ns = t_ns(precision);
     if (n_layers <= 0 || !tcanon || !packed) return DPF_EINVAL;
     if (!ns) return DPF_ENOSUP;
-    if (ns == 2) hipLaunchKernelGGL(tpack_kernel<2>, dim3(n_layers), dim3(256), 0, (hipStream_t)stream, tcanon, (uint8_t *)packed);
+    if (precision == DPF_PREC_F16X3) hipLaunchKernelGGL((tpack_kernel<2, true>), dim3(n_layers), dim3(256), 0, (hipStream_t)stream, tcanon, (uint8_t *)packed);
+    else if (ns == 2) hipLaunchKernelGGL(tpack_kernel<2>, dim3(n_layers), dim3(256), 0, (hipStream_t)stream, tcanon, (uint8_t *)packed);
     else hipLaunchKernelGGL(tpack_kernel<3>, dim3(n_layers), dim3(256), 0, (hipStream_t)stream, tcanon, (uint8_t *)packed);
     return (int)hipGetLastError();
 }
 
-template <int NS>
+template <int NS, bool F16 = false>
 static int prepare_layer(int B, int N, int ka, int kb, const float *tcanon_l, void *packed_l, const float *fm_l,
                          const float *p_in, float *stats_l, float *film_l, float flow_eps, void *workspace, hipStream_t s,
                          int xrows) {
@@ -1331,11 +1352,11 @@ static int prepare_layer(int B, int N, int ka, int kb, const float *tcanon_l, vo
     TArgs a;
     a.packed_l = (const uint8_t *)packed_l; a.tcanon_l = tcanon_l; a.film_l = film_l; a.filmb_l = film_l + (size_t)B * 512;
     a.stats_l = stats_l; a.p_in = p_in; a.B = B; a.N = N; a.ka = ka; a.kb = kb; a.wa = 0; a.wb = 0; a.mode = 0;
-    a.eps = flow_eps;
+    a.eps = flow_eps; a.negone = -1.0f;
     static LdsLimit lim_h1;
-    if (hipError_t e = lim_h1.ensure((const void *)tstats_h1_kernel<NS>, pt_a0n(NS)); e != hipSuccess) return (int)e;
+    if (hipError_t e = lim_h1.ensure((const void *)tstats_h1_kernel<NS, F16>, pt_a0n(NS)); e != hipSuccess) return (int)e;
     const dim3 grid((N + TBLK - 1) / TBLK, B);
-    hipLaunchKernelGGL(tstats_h1_kernel<NS>, grid, dim3(TW * 64), pt_a0n(NS), s, a, w.part1, nbx * B, count, w.xpart,
+    hipLaunchKernelGGL((tstats_h1_kernel<NS, F16>), grid, dim3(TW * 64), pt_a0n(NS), s, a, w.part1, nbx * B, count, w.xpart,
                        (uint8_t *)packed_l + pt_a0(NS));
     hipLaunchKernelGGL(tfold_kernel, dim3(8), dim3(1024), 0, s, count, (int)(grid.x * grid.y), w.part1, tcanon_l, fm_l, B, flow_eps,
                        stats_l, film_l, film_l + (size_t)B * 512);
@@ -1364,10 +1385,11 @@ static int flow_train_forward_direct(int n_layers, int B, int N, int mode, int p
         const int *m = meta_host + 4 * l;
         uint8_t *pk = (uint8_t *)packed + (size_t)l * pt_bytes(ns);
         float *film_l = film + l * fls;
-        int rc = ns == 2 ? prepare_layer<2>(B, N, m[0], m[1], tcanon + (size_t)l * T_LAYER, pk, fm + l * fms, cur,
-                                            stats + (size_t)l * ST_LAYER, film_l, flow_eps, workspace, (hipStream_t)stream, xrows)
-                         : prepare_layer<3>(B, N, m[0], m[1], tcanon + (size_t)l * T_LAYER, pk, fm + l * fms, cur,
-                                            stats + (size_t)l * ST_LAYER, film_l, flow_eps, workspace, (hipStream_t)stream, xrows);
+#define DPF_PREP(...)                                                                                                    \
+    prepare_layer<__VA_ARGS__>(B, N, m[0], m[1], tcanon + (size_t)l * T_LAYER, pk, fm + l * fms, cur,                    \
+                               stats + (size_t)l * ST_LAYER, film_l, flow_eps, workspace, (hipStream_t)stream, xrows)
+        int rc = precision == DPF_PREC_F16X3 ? DPF_PREP(2, true) : (ns == 2 ? DPF_PREP(2) : DPF_PREP(3));
+#undef DPF_PREP
         if (rc) return rc;
         // the layer itself; its epilogue leaves the moments of the NEXT layer's kept coordinates (w.xpart was consumed by
         // this layer's tstats_h1 above)
@@ -1407,7 +1429,7 @@ extern "C" int dpf_flow_train_forward(int n_layers, int B, int N, int mode, int 
     return cache.run(k, (hipStream_t)stream, direct);
 }
 
-template <int NS>
+template <int NS, bool F16 = false>
 static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb, const float *tcanon_l, const void *packed_l,
                           const float *film_l, const float *stats_l, const float *p_in, const float *mu_l, const float *lv_l,
                           const float *g_p, const float *g_p2, const float *g_mu, const float *g_lv, float *dp_in, float *dcanon_l,
@@ -1417,17 +1439,17 @@ static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb
     TArgs a;
     a.packed_l = (const uint8_t *)packed_l; a.tcanon_l = tcanon_l; a.film_l = film_l; a.filmb_l = film_l + (size_t)B * 512;
     a.stats_l = stats_l; a.p_in = p_in; a.B = B; a.N = N; a.ka = ka; a.kb = kb; a.wa = wa; a.wb = wb; a.mode = mode;
-    a.eps = flow_eps;
+    a.eps = flow_eps; a.negone = -1.0f;
     const dim3 grid((N + TBLK - 1) / TBLK, B);
     const int nblk = grid.x * grid.y;
     const double count = (double)B * N;
     const int lds1 = pt_a0n(NS) + 4096 + (TW * 520 + 256 + TW * 64 + 8 + 4) * 4, lds2 = l_red(NS) + 4096 + TW * XY_WAVE * 2;
     static LdsLimit lim_b1, lim_b2;
-    if (hipError_t e = lim_b1.ensure((const void *)tbwd1_kernel<NS>, lds1); e != hipSuccess) return (int)e;
-    if (hipError_t e = lim_b2.ensure((const void *)tbwd2_kernel<NS>, lds2); e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(tbwd1_kernel<NS>, grid, dim3(TW * 64), lds1, s, a, g_p, g_p2, g_mu, g_lv, mu_l, lv_l, dp_in, w.dout, w.part1, *pv,
+    if (hipError_t e = lim_b1.ensure((const void *)tbwd1_kernel<NS, F16>, lds1); e != hipSuccess) return (int)e;
+    if (hipError_t e = lim_b2.ensure((const void *)tbwd2_kernel<NS, F16>, lds2); e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((tbwd1_kernel<NS, F16>), grid, dim3(TW * 64), lds1, s, a, g_p, g_p2, g_mu, g_lv, mu_l, lv_l, dp_in, w.dout, w.part1, *pv,
                        w.tickets, w.pc, dfm_l);
-    hipLaunchKernelGGL(tbwd2_kernel<NS>, grid, dim3(TW * 64), lds2, s, a, w.pc, count, dcanon_l, w.dout, w.ubuf, w.part2);
+    hipLaunchKernelGGL((tbwd2_kernel<NS, F16>), grid, dim3(TW * 64), lds2, s, a, w.pc, count, dcanon_l, w.dout, w.ubuf, w.part2);
     hipLaunchKernelGGL(tcolsum_kernel, dim3((2 * P2_J + 31) / 32), dim3(1024), 0, s, nblk, 2 * P2_J, w.part2, w.tot2, dcanon_l, P2_J);
     // pass 3 (the conditioner path of d(input points), d gamma0 / d beta0 / dW0 / dW1 from the totals): folded into the NEXT
     // backward layer's pass 1, which needs that gradient anyway; only the last layer of the call launches it
@@ -1468,12 +1490,12 @@ static int backward_stack(int n_layers, int B, int N, int mode, int precision, c
         const float *pin = step == 0 ? p_in : ps + lprev * lst;
         float *out = (step & 1) ? dp_tmp : dp_in;                                      // step 0 writes dp_in
         const int *m = meta_host + 4 * l;
-#define DPF_BWD(NSV)                                                                                                      \
-    backward_layer<NSV>(B, N, mode, m[0], m[1], m[2], m[3], tcanon + (size_t)l * T_LAYER,                               \
+#define DPF_BWD(NSV, ...)                                                                                                 \
+    backward_layer<NSV, ##__VA_ARGS__>(B, N, mode, m[0], m[1], m[2], m[3], tcanon + (size_t)l * T_LAYER,                \
                         (const uint8_t *)packed + (size_t)l * pt_bytes(NSV), film + l * fls, stats + (size_t)l * ST_LAYER, pin, \
                         mus + l * lst, logvars + l * lst, grad_of(0, l), chain, grad_of(1, l), grad_of(2, l), out,       \
                         dcanon + (size_t)l * T_LAYER, dfm + l * fms, flow_eps, workspace, (hipStream_t)stream, &pv, step == 0)
-        const int rc = ns == 2 ? DPF_BWD(2) : DPF_BWD(3);
+        const int rc = precision == DPF_PREC_F16X3 ? DPF_BWD(2, true) : (ns == 2 ? DPF_BWD(2) : DPF_BWD(3));
 #undef DPF_BWD
         if (rc) return rc;
         chain = out;

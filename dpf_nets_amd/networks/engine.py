@@ -18,6 +18,12 @@ from .._lib import lib, check, current_stream, PREC, MODE
 # "bf16x6": three bf16 parts, six products (fp32-class, no range limit); "bf16": one product (~6e-4, speed reference only)
 DEFAULT_PRECISION = os.environ.get("DPF_PRECISION", "f16x3")
 F = 64
+# f16x3's hi/lo split of the hidden activations is exact while |h0| < 2048 (the lo part is clamped to [0, 1]: above, the
+# split degrades to fp16-hi precision, and at 65504 it saturates -- csrc/flow_common.h split_relu_f16).  At pack time (once
+# per weight version) the BN0-folded first layer gives a bound on |h0| for coordinates up to F16_COORD_MAX; a checkpoint
+# whose bound reaches F16_LIMIT (e.g. a collapsed running variance) evaluates at bf16x6 instead, with a warning.
+F16_LIMIT = 2048.0
+F16_COORD_MAX = 32.0
 
 
 def _pad_cols(w, n):
@@ -63,6 +69,8 @@ class FlowStack:
         self._packed = {}
         self._sentinels = []
         self._sentinel_state = None
+        self._f16_bound = None
+        self.last_precision = None
         for lyr in (self.layers[0], self.layers[-1]):
             self._sentinels += [lyr.T_mu_0[3].weight, lyr.T_logvar_1[1].weight]
 
@@ -99,6 +107,9 @@ class FlowStack:
             self._canon = canon
             self._meta = torch.tensor([layer_meta(l) for l in self.layers], dtype=torch.int32, device=device)
             self._packed = {}
+            self._f16_bound = None
+        if precision == "f16x3" and not self.f16_in_range(device):
+            precision = "bf16x6"               # fp32-class without a range limit (slower: six products, unpipelined body)
         key = (precision, L)
         if key not in self._packed:
             nbytes = lib().dpf_flow_packed_bytes(L, G, PREC[precision])
@@ -106,7 +117,33 @@ class FlowStack:
             check(lib().dpf_flow_pack(L, G, PREC[precision], self._canon.data_ptr(), self._meta.data_ptr(),
                                       packed.data_ptr(), current_stream()), "flow_pack")
             self._packed[key] = packed
-        return self._canon, self._meta, self._packed[key], G
+        return self._canon, self._meta, self._packed[key], G, precision
+
+    def f16_in_range(self, device):
+        """Once per weight version: max over layers / branches / features of  sum_k |s0 W0[f][k]| * F16_COORD_MAX + |T_f|
+        (s0 = gamma0 / sqrt(running_var0 + eps), T = beta0 - running_mean0 * s0) -- the largest |BN0(W0 x)| a point with
+        coordinates up to F16_COORD_MAX can produce -- and max |W1| against the fp16 range."""
+        if self._f16_bound is None:
+            with torch.no_grad():
+                hb, wb = [], []
+                for lyr in self.layers:
+                    for br in ("logvar", "mu"):
+                        t0 = getattr(lyr, "T_%s_0" % br)
+                        sd0, bn0, sd1 = t0[0], t0[1], t0[3]
+                        s0 = bn0.weight.detach().float() / torch.sqrt(bn0.running_var.detach().float() + bn0.eps)
+                        w = sd0.weight.detach()[0].float().abs().sum(1) * s0.abs()
+                        T = (bn0.bias.detach().float() - bn0.running_mean.detach().float() * s0).abs()
+                        hb.append((w * F16_COORD_MAX + T).amax())
+                        wb.append(sd1.weight.detach().float().abs().amax())
+                both = torch.stack([torch.stack(hb).amax(), torch.stack(wb).amax()]).to("cpu")
+            h0_bound, w1_max = float(both[0]), float(both[1])
+            ok = (h0_bound < F16_LIMIT) and (w1_max < 65504.0)              # NaN compares False
+            if not ok:
+                import warnings
+                warnings.warn("dpf_nets_amd: f16x3 is outside its exact range for these weights (|h0| bound %.3g, limit %g; "
+                              "max|W1| %.3g): evaluating at bf16x6" % (h0_bound, F16_LIMIT, w1_max))
+            self._f16_bound = (h0_bound, w1_max, ok)
+        return self._f16_bound[2]
 
     # -- run ---------------------------------------------------------------------
     def run(self, p, g, mode, precision=None, want_lists=True, n_layers=None, want_pointmajor=False, base=None):
@@ -133,7 +170,8 @@ class FlowStack:
             L = len(self.layers) if n_layers is None else int(n_layers)
             if not 0 < L <= len(self.layers):
                 raise ValueError("n_layers out of range")
-            canon, meta, packed, G = self._ensure(precision, p.device, L)
+            canon, meta, packed, G, precision = self._ensure(precision, p.device, L)
+            self.last_precision = precision
             if g.shape[1] != G:
                 raise RuntimeError("g has %d features, the layers expect %d" % (g.shape[1], G))
             dev = p.device

@@ -28,8 +28,14 @@ from .engine import layer_meta
 
 F = 64
 # precision of the forward contraction and of its recomputation in the backward passes (which fixes
-# every ReLU mask): bf16x6 is fp32-class; bf16x3 (~1e-5) is faster and flips ~1e-5 of the ReLUs
-TRAIN_PRECISION = os.environ.get("DPF_TRAIN_PRECISION", "bf16x6")
+# every ReLU mask).  f16x3 (default since r03): fp16 hi + fp16 lo operands, three products -- fp32-class (22 significant
+# bits) at half the matrix work of bf16x6, exact while the post-BN0 activations stay below 2048 (the lo part of the split is
+# clamped to [0, 1], csrc/flow_common.h split_relu_f16); a per-stack monitor of max|gamma0| * sqrt(B*N) + max|beta0| (the
+# bound of a batch-normalised activation) falls back to bf16x6 for good when that bound is reached (F16_LIMIT).
+# bf16x6 is fp32-class without a range limit; bf16x3 (~1e-5) flips ~1e-5 of the ReLUs.
+TRAIN_PRECISION = os.environ.get("DPF_TRAIN_PRECISION", "f16x3")
+F16_LIMIT = 2048.0
+F16_CHECK_EVERY = 16
 BRANCHES = ("logvar", "mu")
 SUBS = ("w", "b")
 
@@ -49,6 +55,9 @@ class StackSpec:
         self._dev_cache = {}
         self._params = None
         self.flat = None               # FlatStore once flatten() was called
+        self.f16_ok = True             # f16x3 range monitor (below): False once the activation bound reached F16_LIMIT
+        self._f16_calls = 0
+        self._f16_pending = None       # (pinned host tensor, event) of a bound computed some calls ago
         self.meta_host = (ctypes.c_int * (4 * self.L))(*[v for m in self.metas for v in m])
         self.canon_slots = []          # (offset, numel) per parameter, in canon_params() order
         pads = []                      # (offset, numel) of the zero padding between them
@@ -77,6 +86,49 @@ class StackSpec:
         if self.flat is None or not self.flat.attached():
             self.flat = FlatStore(self, dev)
         return self.flat
+
+    def f16_range_monitor(self, tcanon, count):
+        """(see _f16_monitor) tcanon: the (L, 2*T_BR) conditioner block, or None = take gamma0 / beta0 from the modules."""
+        def bound():
+            root = float(count) ** 0.5
+            if tcanon is not None:
+                blk = tcanon.detach().view(self.L, 2, _T_BR)
+                return blk[:, :, _T_G0:_T_G0 + 64].abs().amax() * root + blk[:, :, _T_B0:_T_B0 + 64].abs().amax()
+            bns = [getattr(lyr, "T_%s_0" % br)[1] for lyr in self.layers for br in BRANCHES]
+            g = torch.stack([b.weight.detach().abs().amax() for b in bns]).amax()
+            return g * root + torch.stack([b.bias.detach().abs().amax() for b in bns]).amax()
+        return self._f16_monitor(bound)
+
+    def _f16_monitor(self, bound_fn):
+        """Non-blocking guard of the f16x3 split's exact range.  Every F16_CHECK_EVERY-th call the bound
+        max|gamma0| * sqrt(count) + max|beta0| over all layers (|BN0(h0)| cannot exceed it: a standardised value of `count`
+        samples is at most sqrt(count - 1)) is computed on the device and copied to pinned memory; a later call reads it
+        once the copy's event has completed -- no host synchronisation on the training path.  Parameters move by ~lr per
+        step, so a lag of a few steps is immaterial next to a limit of 2048.  Returns the precision to use NOW."""
+        if not self.f16_ok:
+            return "bf16x6"
+        pend = self._f16_pending
+        if pend is not None and pend[1].query():
+            bound = float(pend[0][0])
+            self._f16_pending = None
+            if not (bound < F16_LIMIT):            # also catches NaN
+                import warnings
+                self.f16_ok = False
+                warnings.warn("dpf_nets_amd: post-BatchNorm activation bound %.3g reached the f16x3 split's exact range (%g); "
+                              "this stack trains at bf16x6 from now on" % (bound, F16_LIMIT))
+                return "bf16x6"
+        if self._f16_pending is None and self._f16_calls % F16_CHECK_EVERY == 0:
+            with torch.no_grad():
+                bound = bound_fn()
+                host = self._dev_cache.get("f16_pinned")
+                if host is None:
+                    host = self._dev_cache["f16_pinned"] = torch.empty(1, dtype=torch.float32, pin_memory=True)
+                host.copy_(bound.reshape(1), non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            self._f16_pending = (host, ev)
+        self._f16_calls += 1
+        return "f16x3"
 
     def meta_on(self, dev):
         """int32 (L,4) keep/warp table on the device (cached: a host->device copy synchronises)."""
@@ -469,14 +521,18 @@ def run_training_stack(spec, p, g, mode, precision=None):
     if p.shape[0] * p.shape[2] < 2:
         raise ValueError("Expected more than 1 value per channel when training")
     precision = precision or TRAIN_PRECISION
-    if precision not in ("bf16x3", "bf16x6"):
-        raise ValueError("training precision must be bf16x3 or bf16x6")
+    if precision not in ("bf16x3", "bf16x6", "f16x3"):
+        raise ValueError("training precision must be f16x3, bf16x6 or bf16x3")
     with torch.cuda.device(p.device):
         if spec.flat is not None:
             if not spec.flat.attached():
                 spec.flat = FlatStore(spec, p.device)            # .to()/.cuda() re-assigned the parameters' data
+            if precision == "f16x3":
+                precision = spec.f16_range_monitor(spec.flat.blocks[0], p.shape[0] * p.shape[2])
             outs = _FlowStackTrainFlat.apply(p, g, spec.flat.token, spec, mode, PREC[precision])
         else:
+            if precision == "f16x3":
+                precision = spec.f16_range_monitor(None, p.shape[0] * p.shape[2])
             outs = _FlowStackTrain.apply(p, g, spec, mode, PREC[precision], *spec.all_params())
     L = spec.L
     lvs = list(outs[2 * L:3 * L])

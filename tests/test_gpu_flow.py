@@ -155,11 +155,13 @@ def test_ragged_sizes_vs_oracle(shape):
         assert torch.isfinite(ps.stacked).all()
 
 
-def test_full_size_properties():
-    """BASELINE.json cfg-2 (B=32, N=2048, 63 layers): direct then inverse returns the input up to the
-    reference's own sqrt(1+eps) keep-channel drift; outputs independent of batch composition."""
+@pytest.mark.parametrize("B,G", [(32, 128), (64, 512), (32, 512)], ids=["configs1_B32_G128", "configs2_B64_G512", "configs3_B32_G512"])
+def test_full_size_properties(B, G):
+    """BASELINE.json configs[1] (B=32, G=128), configs[2] (all-classes model: B=64, G=512) and configs[3] (SVR decoder
+    shapes: B=32, G=512), all N=2048 and 63 layers, at FULL size: direct then inverse returns the input up to the
+    reference's own sqrt(1+eps) keep-channel drift; outputs independent of batch composition; two clouds against the oracle."""
     nets = _gpu()
-    B, N, G, nf = 32, 2048, 128, 21
+    N, nf = 2048, 21
     state = FO.make_decoder_state(5, nf, 64, G)
     dec = nets.LocalCondRNVPDecoder(nf, 64, G)
     dec.load_state_dict(FO.to_torch(state), strict=True)
@@ -194,6 +196,64 @@ def test_full_size_properties():
         assert rel(ps3[-1][:2], rps[-1]) <= REL[prec] and rel(lvs3.total()[:2], sum(rlvs)) <= REL[prec]
         assert_elementwise(ps3[-1][:2], rps[-1], prec, "full size, 63 layers: points")
         assert_elementwise(lvs3.total()[:2], sum(rlvs), prec, "full size, 63 layers: sum of logvars")
+
+
+def test_f16x3_range_guard_falls_back_on_a_collapsed_batchnorm_variance():
+    """VERDICT r02 missing #6 / ADVICE: f16x3's hi/lo split is exact below 2048 and saturates at 65504.  A checkpoint whose
+    BN0 running variance collapsed (1e-12: the folded first layer gains a factor 316) must not be evaluated at f16x3
+    silently: the pack-time bound trips, a warning is issued and the stack runs at bf16x6 (fp32-class, no range limit) --
+    finite, and equal to the tensor-op path; a healthy checkpoint keeps f16x3."""
+    nets = _gpu()
+    import warnings
+    state = FO.to_torch(FO.make_decoder_state(61, 2, 64, 128))
+    tgt, z, g = FO.synthetic_inputs(61, 3, 200, 128)
+    tz, tg = torch.from_numpy(z).cuda(), torch.from_numpy(g).cuda()
+    dec = nets.LocalCondRNVPDecoder(2, 64, 128)
+    dec.load_state_dict(state, strict=True)
+    dec = dec.cuda().eval()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                                   # healthy weights: no warning, f16x3
+        with torch.no_grad():
+            dec(tz, tg, mode="direct")
+    assert dec.stack().last_precision == "f16x3"
+    bad = {k: v.clone() for k, v in state.items()}
+    for k in bad:
+        if k.endswith("sd0_bn.running_var"):
+            bad[k].fill_(1e-12)
+    dec2 = nets.LocalCondRNVPDecoder(2, 64, 128)
+    dec2.load_state_dict(bad, strict=True)
+    dec2 = dec2.cuda().eval()
+    with pytest.warns(UserWarning, match="f16x3 is outside its exact range"):
+        with torch.no_grad():
+            ps, mus, lvs = dec2(tz, tg, mode="direct")
+    assert dec2.stack().last_precision == "bf16x6"
+    with torch.no_grad():
+        rps, _, rlvs = dec2.forward_torch(tz, tg, mode="direct")
+    assert torch.isfinite(ps[-1]).all()
+    assert rel(ps[-1], rps[-1]) <= 1e-4 and rel(lvs.total(), sum(rlvs)) <= 1e-4     # under a x316 first layer
+
+
+def test_f16x3_large_activations_stay_fp32_class_below_the_limit():
+    """a case with LARGE hidden activations.  gamma0 scaled so that |h0| reaches the hundreds (bound < 2048: the
+    guard keeps f16x3): the fp16 hi + lo split must still be fp32-class against the tensor-op path."""
+    nets = _gpu()
+    state = FO.to_torch(FO.make_decoder_state(62, 2, 64, 128))
+    for k in state:
+        if k.endswith("sd0_bn.weight") or k.endswith("sd0_bn.bias"):
+            state[k] = state[k] * 40.0                                       # gamma0, beta0
+        if k.endswith("_sd1.weight"):
+            state[k] = state[k] / 40.0                                       # keep the layer's output scale
+    dec = nets.LocalCondRNVPDecoder(2, 64, 128)
+    dec.load_state_dict(state, strict=True)
+    dec = dec.cuda().eval()
+    tgt, z, g = FO.synthetic_inputs(62, 3, 300, 128)
+    tz, tg = torch.from_numpy(z).cuda(), torch.from_numpy(g).cuda()
+    with torch.no_grad():
+        ps, mus, lvs = dec(tz, tg, mode="direct")
+        rps, _, rlvs = dec.forward_torch(tz.double().float(), tg, mode="direct")
+    st = dec.stack()
+    assert st.last_precision == "f16x3" and 100.0 < st._f16_bound[0] < 2048.0, st._f16_bound
+    assert rel(ps[-1], rps[-1]) <= 1e-5 and rel(lvs.total(), sum(rlvs)) <= 1e-5
 
 
 def test_module_semantics():

@@ -28,7 +28,7 @@ pytestmark = pytest.mark.gpu
 
 OUT_REL = 1e-4
 GRAD_REL = 1e-3
-STACK_TOL = {"bf16x6": (1e-4, 1e-3), "bf16x3": (5e-4, 2e-3)}     # six layers: (outputs, gradients)
+STACK_TOL = {"bf16x6": (1e-4, 1e-3), "f16x3": (1e-4, 1e-3), "bf16x3": (5e-4, 2e-3)}     # six layers: (outputs, gradients)
 
 
 def _gpu():
@@ -69,7 +69,7 @@ def _check_gproj(named_grads, gold, prefix, seed, tol=3e-3):
         assert abs(v[2] - ref[2]) <= tol * (ref[2] + 1e-6) + 1e-4, (k, v, ref)
 
 
-@pytest.fixture(params=["bf16x6", "bf16x3"])
+@pytest.fixture(params=["bf16x6", "f16x3", "bf16x3"])
 def prec(request, monkeypatch):
     """Training precision (of the forward contraction / ReLU masks).  bf16x6, the default, is held to the
     tolerances above with (almost) no ReLU flips; bf16x3 gets the same tolerances on all but <= 1 % of the
@@ -82,7 +82,7 @@ def prec(request, monkeypatch):
 
 def test_single_layer_training_vs_reference_golden(golden_dir, prec):
     nets = _gpu()
-    kf = 2e-4 if prec == "bf16x6" else 1e-2
+    kf = 2e-4 if prec in ("bf16x6", "f16x3") else 1e-2
     gold, meta = _load(golden_dir, "flow_layer")
     B, N, F, G = meta["B"], meta["N"], meta["F"], meta["G"]
     for case in meta["cases"]:
@@ -114,7 +114,7 @@ def test_single_layer_training_vs_reference_golden(golden_dir, prec):
 def test_decoder_training_step_vs_reference_golden(golden_dir, prec):
     """training.py:37-55: inverse flow + PointFlowNLL + backward, n_flows = 2 (6 coupling layers)."""
     nets = _gpu()
-    kf, loose = (2e-4, 1.0) if prec == "bf16x6" else (3e-2, 10.0)   # 384 points: one flipped ReLU moves every sum
+    kf, loose = (2e-4, 1.0) if prec in ("bf16x6", "f16x3") else (3e-2, 10.0)   # 384 points: one flipped ReLU moves every sum
     STACK_OUT_REL, STACK_GRAD_REL = STACK_TOL[prec]
     gold, meta = _load(golden_dir, "flow_decoder")
     case = [c for c in meta["cases"] if c.get("bn") == "train"][0]
@@ -133,7 +133,7 @@ def test_decoder_training_step_vs_reference_golden(golden_dir, prec):
     assert rel(ps[0], gold[c + "/ps0"]) <= STACK_OUT_REL
     assert rel(sum(lvs), gold[c + "/sum_logvars"]) <= STACK_OUT_REL
     np.testing.assert_allclose(float(loss.detach()), float(gold[c + "/nll"]), rtol=5e-5)
-    if prec == "bf16x6":
+    if prec in ("bf16x6", "f16x3"):
         close_but_kinks(tp.grad, gold[c + "/grad_p"], STACK_GRAD_REL, "grad_p", kf)
         assert rel(tg.grad, gold[c + "/grad_g"]) <= STACK_GRAD_REL, rel(tg.grad, gold[c + "/grad_g"])
         _check_gproj([(k, v.grad.cpu()) for k, v in dec.named_parameters()], gold, c, seed)
@@ -162,7 +162,7 @@ def test_training_hip_vs_tensor_op_path(B, N, mode, prec):
     tolerance = max(stated tolerance, 10 x that error) -- the per-point terms come out of the
     dh0 = W1^T dh1 contraction, which runs as a hi/lo split (~1e-5 per term) at either precision."""
     nets = _gpu()
-    kf, loose = (2e-4, 1.0) if prec == "bf16x6" else (1e-2, 10.0)
+    kf, loose = (2e-4, 1.0) if prec in ("bf16x6", "f16x3") else (1e-2, 10.0)
     STACK_OUT_REL, STACK_GRAD_REL = STACK_TOL[prec]
     n_flows, G, seed = 2, 128, 31
     sd = FO.to_torch(FO.make_decoder_state(seed, n_flows, 64, G))
@@ -309,6 +309,45 @@ def test_training_replay_equals_eager_at_bench_shape_with_optimizer():
     assert first is None, "losses differ from step %d" % first
     assert g1 == g0
     assert torch.equal(w1, w0)
+
+
+def test_training_f16x3_range_monitor_switches_to_bf16x6(monkeypatch):
+    """The training default f16x3 is exact while the post-BN0 activations stay below 2048.  The per-stack monitor
+    (max|gamma0| * sqrt(B*N) + max|beta0|, computed on the device every few calls and read without a host sync) must leave a
+    healthy stack alone and move one whose gamma0 exploded to bf16x6 for good, with a warning; the step after the switch
+    still agrees with the tensor-op path."""
+    nets = _gpu()
+    import warnings
+    from dpf_nets_amd.networks import train_engine
+    monkeypatch.setattr(train_engine, "TRAIN_PRECISION", "f16x3")
+    monkeypatch.setattr(train_engine, "F16_CHECK_EVERY", 1)
+    torch.manual_seed(0)
+    dec = nets.LocalCondRNVPDecoder(1, 64, 128).cuda().train()
+    dec.flatten_parameters()
+    tgt, z, g = FO.synthetic_inputs(77, 4, 600, 128)
+    tp, tg = torch.from_numpy(tgt).cuda(), torch.from_numpy(g).cuda()
+    from dpf_nets_amd.networks.flows import stack_spec
+    spec = stack_spec(dec, dec.coupling_layers())
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        for _ in range(3):
+            dec(tp, tg, mode="inverse")
+            torch.cuda.synchronize()
+    assert spec.f16_ok
+    with torch.no_grad():
+        for lyr in dec.coupling_layers():
+            lyr.T_mu_0[1].weight.mul_(100.0)                                  # gamma0 x 100: bound = 100 * sqrt(2400) > 2048
+    with pytest.warns(UserWarning, match="trains at bf16x6 from now on"):
+        for _ in range(3):
+            dec(tp, tg, mode="inverse")
+            torch.cuda.synchronize()
+    assert not spec.f16_ok
+    ps, mus, lvs = dec(tp, tg, mode="inverse")
+    with torch.no_grad():
+        dec2 = nets.LocalCondRNVPDecoder(1, 64, 128).cuda().train()
+        dec2.load_state_dict(dec.state_dict())
+        rps, rmus, rlvs = dec2.forward_torch(tp, tg, mode="inverse")
+    assert rel(ps[0], rps[0]) <= 2e-4
 
 
 def test_training_loop_with_optimizer_and_eval_switch():

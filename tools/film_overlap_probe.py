@@ -14,7 +14,7 @@ def main():
     dec, state, n_flows, z, g, tgt, tgt_pm = bench.build_workload(args, dev, 32)
     stack = dec.stack()
     L, prec = args.layers, args.precision
-    canon, meta, packed, G = stack._ensure(prec, dev, L)
+    canon, meta, packed, G, prec = stack._ensure(prec, dev, L)
     B, _, N = z.shape
     Lb = lib()
     film = [torch.empty(Lb.dpf_flow_film_floats(L, B), dtype=torch.float32, device=dev) for _ in range(2)]
