@@ -471,7 +471,7 @@ __device__ __forceinline__ int reduced_feature(int pl, int h) {
 __device__ unsigned long long *g_kprof = nullptr;            // [kernel id][8] s_memtime stamps of workgroup 0, wave 0
 #define KP(kid, i) { __builtin_amdgcn_sched_barrier(0); if (g_kprof != nullptr && blockIdx.x == 1 && blockIdx.y == 3 && threadIdx.x == 0) g_kprof[(kid) * 8 + (i)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
 #else
-#define KP(kid, i)
+#define KP(kid, i) {}
 #endif
 
 struct TArgs {
@@ -1118,30 +1118,38 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
                     dn[t] = mfma(xl[t][j2], eye[j2], dn[t]);
                 }
             }
+            if (br == 0) KP(4, 0)
             split_fragment<false, 2, true>(dn, bg);
+            if (br == 0) KP(4, 1)
         }
         {
             f32x16 dh0a[2] = {zero16(), zero16()};
             chain_mfma<2>(smem + L_PACK + pt_a1t(NS), br, lane, bg, dh0a);
+            if (br == 0) KP(4, 2)
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dh0a[t][r] = h0a[t][r] > 0.f ? dh0a[t][r] : 0.f;
-            // u_k (table reads tied to the chain's last result and chunked: see the r02 note on scratch spills)
+            // u_k: the per-feature coefficients as 16-byte LDS reads (4 consecutive features = registers 4q .. 4q+3), tied to
+            // the chain's last result and chunked (see the r02 note on scratch spills)
             int h4u = h4;
             asm volatile("" : "+v"(h4u) : "v"(dh0a[1][15]));
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int rh = 0; rh < 2; ++rh) {
-                    const float *c0 = cf + br * 128 + h4u;
+                    const float *c0 = cf + br * 128 + h4u + 32 * t;
 #pragma unroll
-                    for (int r = 8 * rh; r < 8 * rh + 8; ++r) {
-                        const int F0 = acc_feature(t, r, 0);
-                        ua += c0[F0] * dh0a[t][r]; ub += c0[64 + F0] * dh0a[t][r];
+                    for (int q = 2 * rh; q < 2 * rh + 2; ++q) {
+                        const f32x4 ca = *(const f32x4 *)(c0 + 8 * q), cb = *(const f32x4 *)(c0 + 64 + 8 * q);
+                        ua += ca.x * dh0a[t][4 * q + 0]; ub += cb.x * dh0a[t][4 * q + 0];
+                        ua += ca.y * dh0a[t][4 * q + 1]; ub += cb.y * dh0a[t][4 * q + 1];
+                        ua += ca.z * dh0a[t][4 * q + 2]; ub += cb.z * dh0a[t][4 * q + 2];
+                        ua += ca.w * dh0a[t][4 * q + 3]; ub += cb.w * dh0a[t][4 * q + 3];
                     }
                     asm volatile("" : "+v"(h4u) : "v"(ua), "v"(ub));
                 }
+            if (br == 0) KP(4, 3)
         }
         TP(4)
         float rsum[2][4];                                                  // [feature tile][k]: sums over the tile's points, lanes h = 0
@@ -1186,27 +1194,37 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
                     }
         }
         TP(6)
-        // ---- workgroup reduction through per-wave LDS slots (plain stores: LDS float atomics are ~1000 cycles
-        // per wave instruction), two rounds of 32 accumulator registers, then the four per-feature sums
+        // ---- workgroup reduction through per-wave LDS slots (plain stores: LDS float atomics are ~1000 cycles per wave
+        // instruction), two rounds of 32 accumulator registers, then the four per-feature sums.  r03: 16-byte LDS accesses --
+        // a lane stores its registers 4g .. 4g+3 as one quad (8 ds_write_b128 per round instead of 32 ds_write_b32), a thread
+        // sums ONE quad over the 8 waves (8 ds_read_b128 instead of 32 ds_read_b32); same sums in the same (wave) order
         float *o = part2 + (blk * 2 + br) * P2_J;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             __syncthreads();                                               // X / Y (or the previous round) are free
-            float *slot = redw + wave * 2048 + lane;
+            f32x4 *slot = (f32x4 *)(redw + wave * 2048) + lane;            // quad (g, lane) at [g * 64 + lane]
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) slot[(16 * nt + r) * 64] = dw[mt][nt][r];
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = {dw[mt][nt][4 * g + 0], dw[mt][nt][4 * g + 1], dw[mt][nt][4 * g + 2], dw[mt][nt][4 * g + 3]};
+                    slot[(4 * nt + g) * 64] = v;
+                }
             __syncthreads();
+            {
+                const int e = threadIdx.x;                                 // quad index: (nt, g, lane)
+                f32x4 t = *((const f32x4 *)redw + e);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int e = threadIdx.x + 512 * k;                       // (nt, r, lane) of the fragment element
-                float t = 0.f;
-#pragma unroll
-                for (int w = 0; w < TW; ++w) t += redw[w * 2048 + e];
-                const int ln = e & 63, rr = (e >> 6) & 15, nt = e >> 10;
-                const int fo = 32 * mt + (rr & 3) + 8 * (rr >> 2) + 4 * (ln >> 5), fi = 32 * nt + (ln & 31);
-                o[128 + fo * 64 + fi] = t;
+                for (int w = 1; w < TW; ++w) {
+                    const f32x4 v = *((const f32x4 *)(redw + w * 2048) + e);
+                    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+                }
+                const int ln = e & 63, g = (e >> 6) & 3, nt = e >> 8;
+                const int fo = 32 * mt + 8 * g + 4 * (ln >> 5), fi = 32 * nt + (ln & 31);
+                o[128 + (fo + 0) * 64 + fi] = t.x;
+                o[128 + (fo + 1) * 64 + fi] = t.y;
+                o[128 + (fo + 2) * 64 + fi] = t.z;
+                o[128 + (fo + 3) * 64 + fi] = t.w;
             }
         }
         TP(7)

@@ -34,7 +34,8 @@ names = {0: ("tstats_h1", ["entry", "prologue issued (bn0_fold, loads)", "first 
          1: ("tbwd1", ["entry", "prologue issued (coefs of pass 3, loads)", "first barrier passed", "main part done", "row published, ticket taken"]),
          2: ("tbwd2", ["entry", "prologue done (BN1-backward means)", "exit"]),
          3: ("tbwd2 prologue", ["address setup done", "DMA pieces issued", "cf table / point loads / w2s issued", "means: loads back, sums done",
-                                "partials in LDS", "barrier passed"])}
+                                "partials in LDS", "barrier passed"]),
+         4: ("tbwd2, branch 0, dh0 phase", ["dh1 transposed back (8 identity MFMAs)", "symmetric split (bg)", "W1^T chain (24 MFMAs)", "relu mask + u_k"])}
 for kid, (name, labels) in names.items():
     print(name)
     for i in range(1, len(labels)):
