@@ -837,6 +837,41 @@ def train_step_leg(args, rank, world, dist, device, batch, layers, steps, warmup
         elapsed = float(t.item())
     ar_us = float(np.median([a.elapsed_time(b) for a, b in ev])) * 1e3
     nbytes = arena.nbytes()
+    # ---- per-kernel durations of the decoder stack (outside the timed region): HIP events around every launch, eager
+    kernels = None
+    try:
+        L_ = _lib_handle()
+        ksteps = 3
+        L_.dpf_train_kernel_times(1, None, None)
+        for _ in range(ksteps):
+            step()
+        us, calls = (ctypes.c_double * 8)(), (ctypes.c_long * 8)()
+        L_.dpf_train_kernel_times(0, us, calls)
+        P = batch * N
+        # FLOPs a kernel executes per layer for P points (both branches): conditioner forward 2 x (2*F*|K| + 2*F*F) ~ 16 896 / pt
+        # (|K| ~ 1.5 on average), output layer 2 x 2*|W|*F ~ 384, W1^T dh1 and dh1 h0^T 2 x 2*F*F = 16 384 each
+        fwd, out_l, sq = 16896.0 * P, 384.0 * P, 16384.0 * P
+        flop = {"tstats_h1": fwd, "flow_kernel(L=1)": fwd + out_l, "tbwd1": fwd + out_l, "tbwd2": fwd + 2 * sq, "tfold": 0.0, "tcolsum": 0.0,
+                "tstats_x": 0.0, "tbwd3f": 0.0}
+        names = ["tstats_x", "tstats_h1", "tfold", "flow_kernel(L=1)", "tbwd1", "tbwd2", "tcolsum", "tbwd3f"]
+        kernels, per_layer = {}, 0.0
+        for i, nm in enumerate(names):
+            if calls[i] == 0:
+                continue
+            t_us = us[i] / calls[i]
+            per = us[i] / (ksteps * layers)
+            per_layer += per
+            kernels[nm] = {"us": t_us, "launches_per_step": calls[i] / ksteps, "us_per_layer": per,
+                           "gflop": flop[nm] / 1e9, "tflops": (flop[nm] / (t_us * 1e-6) / 1e12) if flop[nm] else None,
+                           "frac_of_mfma_peak": (flop[nm] / (t_us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TF) if flop[nm] else None}
+        kernels["sum_us_per_layer"] = per_layer
+        kernels["note"] = ("HIP events around every launch of the stack's kernels, %d eager steps (dpf_train_kernel_times): event to "
+                           "event, i.e. kernel duration + the ~1.5 us launch gap of an eager launch -- the rocprofv3 kernel durations of "
+                           "the same command are in profiles/r03_train_kernel_trace.txt; gflop = "
+                           "what the kernel executes per launch incl. the recomputation of the conditioner; tfold / tcolsum / "
+                           "tstats_x / tbwd3f are reductions (latency-bound, no matrix work)" % ksteps)
+    except Exception as e:       # noqa: BLE001
+        kernels = {"error": repr(e)}
     gstats = (ctypes.c_long * 5)()
     _lib_handle().dpf_train_graph_stats(gstats)
     info = {"ms_per_step": elapsed / steps * 1e3, "value": batch * world * N / (elapsed / steps) if same else None, "unit": "points/s",
@@ -853,7 +888,8 @@ def train_step_leg(args, rank, world, dist, device, batch, layers, steps, warmup
             "graph_replays": int(gstats[0]), "graph_stats": {"replays": int(gstats[0]), "eager_calls": int(gstats[1]),
                                                              "recordings": int(gstats[2]), "evictions": int(gstats[3]),
                                                              "uncapturable": int(gstats[4])},
-            "algorithmic_tflops": 3.0 * FLOP_PER_POINT_LAYER * layers * batch * N / (elapsed / steps) / 1e12}
+            "algorithmic_tflops": 3.0 * FLOP_PER_POINT_LAYER * layers * batch * N / (elapsed / steps) / 1e12,
+            "kernels": kernels}
     if not same:
         info["error"] = "graph replay and eager launches disagree: no value reported"
     if world > 1:
@@ -885,7 +921,8 @@ def leg_train(args, rank, world, dist, device):
             "roofline": {"kernel": "training step (tbwd2/tbwd1/tstats_h1/flow kernels, csrc/flow_train.hip)", "bound": "mfma",
                          "achieved": tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TF,
                          "traffic": None, "note": "whole step incl. host: 3 x forward FLOPs (forward + two backward contractions) "
-                                                  "/ step time"},
+                                                  "/ step time",
+                         "kernels": info.get("kernels")},
             "train_step": info, "cpu_baseline": None, "parity": None}
     return line, {}
 

@@ -63,6 +63,7 @@ SIGNATURES = {
     "dpf_train_graph_replays": (_l, []),
     "dpf_train_graph_stats": (None, [_vp]),
     "dpf_train_graph_set_enabled": (_i, [_i]),
+    "dpf_train_kernel_times": (_i, [_i, _vp, _vp]),
     "dpf_encoder_train_workspace_bytes": (_sz, [_i, _i]),
     "dpf_encoder_train_forward": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp]),
     "dpf_encoder_train_backward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

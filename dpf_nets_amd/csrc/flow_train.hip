@@ -44,6 +44,10 @@
 // contractions themselves (dh0 = W1^T dh1, dW1 = dh1 h0^T) use hi/lo splits (3 products).
 #include <stdlib.h>
 
+#include <atomic>
+#include <mutex>
+#include <vector>
+
 #include "flow_common.h"
 #include "graph_cache.h"
 #include "zero_fill.h"
@@ -1356,6 +1360,62 @@ extern "C" int dpf_flow_train_pack(int n_layers, int precision, const float *tca
     return (int)hipGetLastError();
 }
 
+// ---- per-kernel timing of the training stack (diagnostics: bench.py's `roofline.kernels`) ---------------------------
+// dpf_train_kernel_times(1, ...) switches it on: every launch of the per-layer kernels is bracketed by two HIP events on the
+// launch stream (graph recording / replay is bypassed while it is on); (0, us, calls) synchronises, returns the summed
+// event-to-event time (us) and the number of launches per kernel id, and switches it off.  ids: 0 tstats_x, 1 tstats_h1,
+// 2 tfold, 3 the layer's flow_kernel (L = 1), 4 tbwd1, 5 tbwd2, 6 tcolsum, 7 tbwd3f.
+namespace {
+constexpr int KT_N = 8;
+struct KTimer {
+    std::atomic<int> on{0};
+    std::mutex mu;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[KT_N];
+    hipEvent_t begin(int id, hipStream_t s) {
+        hipEvent_t a = nullptr, b = nullptr;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return nullptr;
+        (void)hipEventRecord(a, s);
+        std::lock_guard<std::mutex> lock(mu);
+        ev[id].push_back({a, b});
+        return b;
+    }
+};
+KTimer &ktimer() { static KTimer t; return t; }
+struct KScope {       // brackets the launches issued during its lifetime
+    hipEvent_t stop = nullptr;
+    hipStream_t s;
+    KScope(int id, hipStream_t st) : s(st) { if (ktimer().on.load(std::memory_order_relaxed)) stop = ktimer().begin(id, st); }
+    ~KScope() { if (stop) (void)hipEventRecord(stop, s); }
+};
+}  // namespace
+
+extern "C" int dpf_train_kernel_times(int enable, double *us_out, long *calls_out) {
+    KTimer &t = ktimer();
+    static int graph_was = 1;
+    if (enable) {
+        std::lock_guard<std::mutex> lock(t.mu);
+        for (auto &v : t.ev) { for (auto &p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); } v.clear(); }
+        if (!t.on.load()) graph_was = dpf_graph_enabled_flag().exchange(0);      // events cannot sit inside a replayed graph
+        t.on.store(1);
+        return 0;
+    }
+    if (t.on.exchange(0)) dpf_graph_enabled_flag().store(graph_was);
+    if (hipError_t e = hipDeviceSynchronize(); e != hipSuccess) return (int)e;
+    std::lock_guard<std::mutex> lock(t.mu);
+    for (int i = 0; i < KT_N; ++i) {
+        double us = 0;
+        for (auto &p : t.ev[i]) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) us += 1e3 * ms;
+            (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second);
+        }
+        if (us_out) us_out[i] = us;
+        if (calls_out) calls_out[i] = (long)t.ev[i].size();
+        t.ev[i].clear();
+    }
+    return 0;
+}
+
 template <int NS, bool F16 = false>
 static int prepare_layer(int B, int N, int ka, int kb, const float *tcanon_l, void *packed_l, const float *fm_l,
                          const float *p_in, float *stats_l, float *film_l, float flow_eps, void *workspace, hipStream_t s,
@@ -1366,7 +1426,7 @@ static int prepare_layer(int B, int N, int ka, int kb, const float *tcanon_l, vo
     // computed here for the first layer of the call
     const int nbx = xrows > 0 ? xrows : (N + 255) / 256;
     const double count = (double)B * N;
-    if (xrows <= 0) hipLaunchKernelGGL(tstats_x_kernel, dim3(nbx, B), dim3(256), 0, s, N, ka, kb, p_in, w.xpart);
+    if (xrows <= 0) { KScope ks(0, s); hipLaunchKernelGGL(tstats_x_kernel, dim3(nbx, B), dim3(256), 0, s, N, ka, kb, p_in, w.xpart); }
     TArgs a;
     a.packed_l = (const uint8_t *)packed_l; a.tcanon_l = tcanon_l; a.film_l = film_l; a.filmb_l = film_l + (size_t)B * 512;
     a.stats_l = stats_l; a.p_in = p_in; a.B = B; a.N = N; a.ka = ka; a.kb = kb; a.wa = 0; a.wb = 0; a.mode = 0;
@@ -1374,10 +1434,12 @@ static int prepare_layer(int B, int N, int ka, int kb, const float *tcanon_l, vo
     static LdsLimit lim_h1;
     if (hipError_t e = lim_h1.ensure((const void *)tstats_h1_kernel<NS, F16>, pt_a0n(NS)); e != hipSuccess) return (int)e;
     const dim3 grid((N + TBLK - 1) / TBLK, B);
+    { KScope ks(1, s);
     hipLaunchKernelGGL((tstats_h1_kernel<NS, F16>), grid, dim3(TW * 64), pt_a0n(NS), s, a, w.part1, nbx * B, count, w.xpart,
-                       (uint8_t *)packed_l + pt_a0(NS));
+                       (uint8_t *)packed_l + pt_a0(NS)); }
+    { KScope ks(2, s);
     hipLaunchKernelGGL(tfold_kernel, dim3(8), dim3(1024), 0, s, count, (int)(grid.x * grid.y), w.part1, tcanon_l, fm_l, B, flow_eps,
-                       stats_l, film_l, film_l + (size_t)B * 512);
+                       stats_l, film_l, film_l + (size_t)B * 512); }
     return (int)hipGetLastError();
 }
 
@@ -1412,6 +1474,7 @@ static int flow_train_forward_direct(int n_layers, int B, int N, int mode, int p
         // the layer itself; its epilogue leaves the moments of the NEXT layer's kept coordinates (w.xpart was consumed by
         // this layer's tstats_h1 above)
         xrows = 0;
+        KScope ks_flow(3, (hipStream_t)stream);
         if (step + 1 < n_layers) {
             const int *mnext = meta_host + 4 * (mode == DPF_MODE_DIRECT ? l + 1 : l - 1);
             rc = flow_forward_xstats(B, N, mode, precision, pk, meta_dev + 4 * l, film_l, cur, ps + l * lst, mus + l * lst,
@@ -1465,15 +1528,20 @@ static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb
     static LdsLimit lim_b1, lim_b2;
     if (hipError_t e = lim_b1.ensure((const void *)tbwd1_kernel<NS, F16>, lds1); e != hipSuccess) return (int)e;
     if (hipError_t e = lim_b2.ensure((const void *)tbwd2_kernel<NS, F16>, lds2); e != hipSuccess) return (int)e;
+    { KScope ks(4, s);
     hipLaunchKernelGGL((tbwd1_kernel<NS, F16>), grid, dim3(TW * 64), lds1, s, a, g_p, g_p2, g_mu, g_lv, mu_l, lv_l, dp_in, w.dout, w.part1, *pv,
-                       w.tickets, w.pc, dfm_l);
-    hipLaunchKernelGGL((tbwd2_kernel<NS, F16>), grid, dim3(TW * 64), lds2, s, a, w.pc, count, dcanon_l, w.dout, w.ubuf, w.part2);
-    hipLaunchKernelGGL(tcolsum_kernel, dim3((2 * P2_J + 31) / 32), dim3(1024), 0, s, nblk, 2 * P2_J, w.part2, w.tot2, dcanon_l, P2_J);
+                       w.tickets, w.pc, dfm_l); }
+    { KScope ks(5, s);
+    hipLaunchKernelGGL((tbwd2_kernel<NS, F16>), grid, dim3(TW * 64), lds2, s, a, w.pc, count, dcanon_l, w.dout, w.ubuf, w.part2); }
+    { KScope ks(6, s);
+    hipLaunchKernelGGL(tcolsum_kernel, dim3((2 * P2_J + 31) / 32), dim3(1024), 0, s, nblk, 2 * P2_J, w.part2, w.tot2, dcanon_l, P2_J); }
     // pass 3 (the conditioner path of d(input points), d gamma0 / d beta0 / dW0 / dW1 from the totals): folded into the NEXT
     // backward layer's pass 1, which needs that gradient anyway; only the last layer of the call launches it
-    if (last)
+    if (last) {
+        KScope ks(7, s);
         hipLaunchKernelGGL(tbwd3f_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, N, ka, kb, kb >= 0 ? 2 : 1, count, w.tot2,
                            tcanon_l, stats_l, dcanon_l, p_in, w.ubuf, dp_in);
+    }
     pv->tot = w.tot2; pv->tcanon_l = tcanon_l; pv->stats_l = stats_l; pv->ubuf = w.ubuf; pv->x = p_in; pv->dcanon_l = dcanon_l;
     pv->count = count; pv->ka = ka; pv->kb = kb; pv->has = 1;
     return (int)hipGetLastError();

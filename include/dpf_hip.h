@@ -371,6 +371,11 @@ int dpf_encoder_train_backward(int B, int N, const float *canon, const float *x,
 long dpf_train_graph_replays(void);
 void dpf_train_graph_stats(long *out);
 int dpf_train_graph_set_enabled(int on);
+/* Diagnostics: per-kernel time of the training stack's launches.  (1, NULL, NULL) starts collecting -- every launch of the
+ * per-layer kernels is bracketed by HIP events on its stream; graph recording / replay is off while it collects --,
+ * (0, us[8], calls[8]) synchronises the device, returns the summed time in microseconds and the number of launches per kernel
+ * id and stops.  ids: 0 tstats_x, 1 tstats_h1, 2 tfold, 3 flow_kernel (L = 1), 4 tbwd1, 5 tbwd2, 6 tcolsum, 7 tbwd3f. */
+int dpf_train_kernel_times(int enable, double *us_out, long *calls_out);
 
 /* ---- latent prior flow: GlobalRNVPDecoder on (B, G) codes, eval-mode BatchNorm ---------------
  * replaces GlobalRNVPDecoder.forward (lib/networks/decoders.py:21-38): n_steps = 2 * n_flows
