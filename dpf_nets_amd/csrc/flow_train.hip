@@ -259,10 +259,12 @@ __global__ __launch_bounds__(1024) void tcolsum_kernel(int nrows, int J, const f
     double s = 0;
     if (j < J) {
         int r = rg;
-        for (; r + 96 < nrows; r += 128) {                                 // four rows in flight, added in row order
-            const float v0 = part[(size_t)r * J + j], v1 = part[(size_t)(r + 32) * J + j], v2 = part[(size_t)(r + 64) * J + j],
-                        v3 = part[(size_t)(r + 96) * J + j];
-            s += v0; s += v1; s += v2; s += v3;
+        for (; r + 224 < nrows; r += 256) {                                // eight rows in flight (one round of loads at 256 rows), added in row order
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = part[(size_t)(r + 32 * k) * J + j];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
         }
         for (; r < nrows; r += 32) s += part[(size_t)r * J + j];
     }
@@ -571,7 +573,15 @@ __global__ __launch_bounds__(1024) void tfold_kernel(double count, int nrows, co
         const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
         const int col = (br * 2 + (c >> 4)) * 64 + f0 + (c & 15);
         double s = 0;
-        for (int r = rg; r < nrows; r += 32) s += part[(size_t)r * 256 + col];
+        int r = rg;
+        for (; r + 224 < nrows; r += 256) {                                // eight rows in flight, added in row order (r03)
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = part[(size_t)(r + 32 * k) * 256 + col];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+        for (; r < nrows; r += 32) s += part[(size_t)r * 256 + col];
         acc[rg][c] = s;
         __syncthreads();
         if (rg == 0) {
