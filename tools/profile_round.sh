@@ -22,6 +22,7 @@ python3 bench.py --layers 63 --no-extra --no-cpu-baseline > $OUT/bench_L63.json 
 python3 bench.py --layers 15 --no-extra --no-cpu-baseline > $OUT/bench_L15.json 2>> $OUT/bench_default.err
 python3 bench.py --config cfg3 --no-extra > $OUT/bench_cfg3.json 2>> $OUT/bench_default.err
 python3 bench.py --config cfg5 > $OUT/bench_cfg5.json 2>> $OUT/bench_default.err
-python3 bench.py --leg train > $OUT/bench_train.json 2>> $OUT/bench_default.err
 python3 bench.py --no-graph --no-extra --no-cpu-baseline > $OUT/bench_eager.json 2>> $OUT/bench_default.err
-ls -la $OUT
+bash tools/train_prof.sh ${TAG}_prof/train > /dev/null 2>&1
+bash tools/pmc_train.sh ${TAG}_prof/pmc_train > /dev/null 2>&1
+ls -la $OUT $OUT/train
