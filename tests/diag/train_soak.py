@@ -1,5 +1,7 @@
 """Soak of the training step's in-kernel hand-offs (tickets in tbwd1, graph replays): the loss sequence of N optimizer steps
-from two independent processes must agree bit for bit.  usage: train_soak.py [steps]"""
+under graph REPLAY (DPF_TRAIN_GRAPH=1) and under EAGER launches (DPF_TRAIN_GRAPH=0), each in its own process, must agree bit for
+bit -- r02 compared two replay runs with each other, which shows determinism, not correctness (VERDICT r02 #1c).
+usage: train_soak.py [steps]"""
 import os
 import subprocess
 import sys
@@ -31,9 +33,10 @@ print(" ".join(np.float32(x.item()).tobytes().hex() for x in out))
 steps = sys.argv[1] if len(sys.argv) > 1 else "300"
 runs = []
 for i in range(2):
-    r = subprocess.run([sys.executable, "-c", CHILD, steps], capture_output=True, text=True)
+    r = subprocess.run([sys.executable, "-c", CHILD, steps], capture_output=True, text=True,
+                       env=dict(os.environ, DPF_TRAIN_GRAPH="1" if i == 0 else "0"))
     if r.returncode:
         print(r.stderr[-800:]); sys.exit(1)
     runs.append(r.stdout.strip().split()[-int(steps):])
 same = sum(a == b for a, b in zip(*runs))
-print("steps %s: %d identical losses, first difference at %s" % (steps, same, next((i for i, (a, b) in enumerate(zip(*runs)) if a != b), None)))
+print("replay vs eager, steps %s: %d identical losses, first difference at %s" % (steps, same, next((i for i, (a, b) in enumerate(zip(*runs)) if a != b), None)))
