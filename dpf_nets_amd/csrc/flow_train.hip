@@ -569,6 +569,15 @@ __global__ __launch_bounds__(1024) void tfold_kernel(double count, int nrows, co
     __shared__ double acc[32][33];
     __shared__ double tot[32];
     const int br = blockIdx.x >> 2, f0 = (blockIdx.x & 3) * 16;
+    const float *cbp = tcanon_l + br * T_BR;
+    // r03: the fold's own operands (this step's FiLM vectors, W2 rows) do not depend on the column sums: requested first, so
+    // that the kernel is ONE global round trip deep instead of two
+    float pre_cw = 0.f, pre_cb = 0.f, pre_w2a = 0.f, pre_w2b = 0.f;
+    if ((int)threadIdx.x < B * 16) {
+        const int b = threadIdx.x >> 4, f = f0 + (threadIdx.x & 15);
+        pre_cw = fm_l[((size_t)(br * 2 + 0) * B + b) * 64 + f]; pre_cb = fm_l[((size_t)(br * 2 + 1) * B + b) * 64 + f];
+        pre_w2a = cbp[T_W2 + f]; pre_w2b = cbp[T_W2 + 64 + f];
+    }
     {
         const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
         const int col = (br * 2 + (c >> 4)) * 64 + f0 + (c & 15);
@@ -587,12 +596,11 @@ __global__ __launch_bounds__(1024) void tfold_kernel(double count, int nrows, co
         if (rg == 0) {
             double t = 0;
 #pragma unroll
-            for (int r = 0; r < 32; ++r) t += acc[r][c];
+            for (int r2 = 0; r2 < 32; ++r2) t += acc[r2][c];
             tot[c] = t;
         }
         __syncthreads();
     }
-    const float *cbp = tcanon_l + br * T_BR;
     for (int item = threadIdx.x; item < B * 16; item += 1024) {
         const int b = item >> 4, fl = item & 15, f = f0 + fl;
         const double mean = tot[fl] / count;
@@ -605,13 +613,16 @@ __global__ __launch_bounds__(1024) void tfold_kernel(double count, int nrows, co
             st[3 * 64 + f] = rstd;
             st[5 * 64 + f] = (float)(var * (count / (count > 1 ? count - 1 : 1)));
         }
-        const float cw = fm_l[((size_t)(br * 2 + 0) * B + b) * 64 + f], cb = fm_l[((size_t)(br * 2 + 1) * B + b) * 64 + f];
+        const bool first = item == (int)threadIdx.x;
+        const float cw = first ? pre_cw : fm_l[((size_t)(br * 2 + 0) * B + b) * 64 + f];
+        const float cb = first ? pre_cb : fm_l[((size_t)(br * 2 + 1) * B + b) * 64 + f];
+        const float w2a_v = first ? pre_w2a : cbp[T_W2 + f], w2b_v = first ? pre_w2b : cbp[T_W2 + 64 + f];
         const float av = eps + expf(cw);
         const float FA = av * rstd, FC = -av * (float)mean * rstd + cb;
         float *o = film_l + (size_t)b * (FILM_BYTES / 4) + br * FILM_BR_FLOATS;
         o[f] = FC / FA;
-        o[64 + f] = cbp[T_W2 + f] * FA;
-        o[128 + f] = cbp[T_W2 + 64 + f] * FA;
+        o[64 + f] = w2a_v * FA;
+        o[128 + f] = w2b_v * FA;
         if (f < 2) film_l[(size_t)b * (FILM_BYTES / 4) + FILM_B2_OFF + br * 2 + f] = cbp[T_B2 + f];
         float *ob = filmb_l + (size_t)b * FB_CLOUD + br * FB_BR;
         ob[0 * 64 + f] = av;
