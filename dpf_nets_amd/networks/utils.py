@@ -36,8 +36,9 @@ def f_score(predicted_clouds, true_clouds, threshold=0.001):
     if ld.is_cuda and not (torch.is_grad_enabled() and (ld.requires_grad or rd.requires_grad)):
         from .._lib import lib, check, current_stream
         out = torch.empty((ld.shape[0],), dtype=torch.float32, device=ld.device)
+        ldc, rdc = ld.contiguous(), rd.contiguous()                       # locals: they must outlive the launch's enqueue
         with torch.cuda.device(ld.device):
-            check(lib().dpf_fscore_reduce(ld.shape[0], ld.shape[1], rd.shape[1], ld.contiguous().data_ptr(), rd.contiguous().data_ptr(),
+            check(lib().dpf_fscore_reduce(ld.shape[0], ld.shape[1], rd.shape[1], ldc.data_ptr(), rdc.data_ptr(),
                                           float(threshold), out.data_ptr(), current_stream()), "fscore_reduce")
         return out
     precision = 100.0 * (rd < threshold).float().mean(1)
