@@ -10,14 +10,19 @@ decoder runs in HIP.  Here the SAME operations, in the same order, run
     entries are views of flat state buffers, so `state_dict()` keeps the reference's layout);
   * as multi-tensor (`torch._foreach_*`) ops over everything else.
 
-SURVEY 8(f) rank 4 asks for a fused optimizer step; this one stays on PyTorch-ROCm ops (north star: the optimizer is
-host code), which is enough to take it off the critical path.
+SURVEY 8(f) rank 4 asks for a fused AMSGrad-Adam step: on CUDA tensors the flat-store update is ONE launch of
+`dpf_adam_step` (csrc/adam.hip; r03) -- the same operations with the same roundings as the op sequence, bit for bit
+(tests/test_gpu_adam.py), 36 B per parameter in one pass instead of ~12 passes; `DPF_FUSED_ADAM=0` keeps the op sequence.
+Everything else (CPU tensors, parameters outside a store) runs the op sequence / the multi-tensor ops.
 """
 import math
+import os
 
 import numpy as np
 import torch
 from torch.optim import Optimizer
+
+FUSED_ADAM = os.environ.get("DPF_FUSED_ADAM", "1") != "0"
 
 
 class Adam(Optimizer):
@@ -28,6 +33,22 @@ class Adam(Optimizer):
         self._fast = {}          # id(param group) -> (its whole FlatStores, its other parameters, len, first, last)
 
     # ---- the update of optimizers.py:52-74 on lists of tensors (lists of one flat tensor for a FlatStore)
+    @staticmethod
+    def _update_flat(p, grad, exp_avg, exp_avg_sq, max_sq, step, lr, beta1, beta2, eps, weight_decay, amsgrad):
+        """The update of ONE flat fp32 CUDA buffer: the fused HIP kernel when it applies (-> True), else False."""
+        if not (FUSED_ADAM and p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and grad.is_contiguous()
+                and p.data_ptr() % 16 == 0 and grad.data_ptr() % 16 == 0):
+            return False
+        bc1, bc2 = 1 - beta1 ** step, math.sqrt(1 - beta2 ** step)
+        if bc1 == 0.0 or bc2 == 0.0:
+            return False
+        from .._lib import lib, check, current_stream
+        with torch.cuda.device(p.device):
+            check(lib().dpf_adam_step(p.numel(), p.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                      max_sq.data_ptr() if amsgrad else None, lr, beta1, beta2, eps, weight_decay, bc1, bc2,
+                                      current_stream()), "adam_step")
+        return True
+
     @staticmethod
     def _update(ps, grads, exp_avgs, exp_avg_sqs, max_sqs, step, lr, beta1, beta2, eps, weight_decay, amsgrad):
         torch._foreach_mul_(exp_avgs, beta1)
@@ -177,8 +198,10 @@ class Adam(Optimizer):
                             step = pst[0]["step"] + 1
                             for st in pst:
                                 st["step"] = step
-                            self._update([store.flat_p], [store.flat_g], [fs["buf"]["exp_avg"]], [fs["buf"]["exp_avg_sq"]],
-                                         [fs["buf"]["max_exp_avg_sq"]] if amsgrad else None, step, lr, beta1, beta2, eps, wd, amsgrad)
+                            if not self._update_flat(store.flat_p, store.flat_g, fs["buf"]["exp_avg"], fs["buf"]["exp_avg_sq"],
+                                                     fs["buf"]["max_exp_avg_sq"] if amsgrad else None, step, lr, beta1, beta2, eps, wd, amsgrad):
+                                self._update([store.flat_p], [store.flat_g], [fs["buf"]["exp_avg"]], [fs["buf"]["exp_avg_sq"]],
+                                             [fs["buf"]["max_exp_avg_sq"]] if amsgrad else None, step, lr, beta1, beta2, eps, wd, amsgrad)
                             done = True
                 if not done:
                     general += store.params
@@ -206,8 +229,10 @@ class Adam(Optimizer):
                 for q in store.params:
                     self.state[q]["step"] = step
                     flat_ids.add(id(q))
-                self._update([store.flat_p], [store.flat_g], [fs["buf"]["exp_avg"]], [fs["buf"]["exp_avg_sq"]],
-                             [fs["buf"]["max_exp_avg_sq"]] if amsgrad else None, step, lr, beta1, beta2, eps, wd, amsgrad)
+                if not self._update_flat(store.flat_p, store.flat_g, fs["buf"]["exp_avg"], fs["buf"]["exp_avg_sq"],
+                                         fs["buf"]["max_exp_avg_sq"] if amsgrad else None, step, lr, beta1, beta2, eps, wd, amsgrad):
+                    self._update([store.flat_p], [store.flat_g], [fs["buf"]["exp_avg"]], [fs["buf"]["exp_avg_sq"]],
+                                 [fs["buf"]["max_exp_avg_sq"]] if amsgrad else None, step, lr, beta1, beta2, eps, wd, amsgrad)
             # ---- everything else, multi-tensor, grouped by step count (and device / dtype)
             buckets = {}
             for p in todo:

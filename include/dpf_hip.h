@@ -377,6 +377,16 @@ int dpf_train_graph_set_enabled(int on);
  * id and stops.  ids: 0 tstats_x, 1 tstats_h1, 2 tfold, 3 flow_kernel (L = 1), 4 tbwd1, 5 tbwd2, 6 tcolsum, 7 tbwd3f. */
 int dpf_train_kernel_times(int enable, double *us_out, long *calls_out);
 
+/* ---- fused AMSGrad-Adam step over one flat fp32 buffer -----------------------------------------
+ * replaces the per-parameter update of the reference's optimizer, lib/networks/optimizers.py:52-74 (state['step'] and the
+ * bias corrections :48, :63-64 stay with the caller): exp_avg / exp_avg_sq / max_exp_avg_sq / p updated in place in ONE pass,
+ * with the roundings of the reference's op sequence as PyTorch-ROCm executes it (bit-identical, csrc/adam.hip).
+ * max_exp_avg_sq = NULL: plain Adam (:59).  The hyper-parameters are the Python doubles of the parameter group;
+ * bias_correction1 = 1 - beta1^step, bias_correction2 = sqrt(1 - beta2^step) (both non-zero).  Buffers 16-byte aligned. */
+int dpf_adam_step(size_t n, float *p, const float *g, float *exp_avg, float *exp_avg_sq, float *max_exp_avg_sq, double lr,
+                  double beta1, double beta2, double eps, double weight_decay, double bias_correction1, double bias_correction2,
+                  dpf_stream_t stream);
+
 /* ---- latent prior flow: GlobalRNVPDecoder on (B, G) codes, eval-mode BatchNorm ---------------
  * replaces GlobalRNVPDecoder.forward (lib/networks/decoders.py:21-38): n_steps = 2 * n_flows
  * RealNVPFlow steps (lib/networks/flows.py:198-213) in ONE launch, both modes.
