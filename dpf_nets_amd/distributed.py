@@ -145,25 +145,40 @@ class GradArena:
         return self.buf.numel() * 4
 
     def sync(self):
-        """Every gradient of the model is in `buf` afterwards (missing ones as zeros), every .grad a view of it again."""
+        """Every gradient of the model is in `buf` afterwards (missing ones as zeros), every .grad a view of it again.
+        Fresh gradients (autograd hands a parameter whose .grad is None its gradient tensor without a kernel) are moved into
+        the message with ONE multi-tensor copy."""
         for st in self.stores:
             st.attach_grads()
+        src, dst, zero = [], [], []
         for p, v in zip(self.others, self.views):
             if p.grad is v:
                 continue
-            with torch.no_grad():
-                if p.grad is None:
-                    v.zero_()
-                else:
-                    v.copy_(p.grad)
+            if p.grad is None:
+                zero.append(v)
+            else:
+                src.append(p.grad); dst.append(v)
+        with torch.no_grad():
+            if zero:
+                torch._foreach_zero_(zero)
+            if dst:
+                torch._foreach_copy_(dst, src)
+        for p, v in zip(self.others, self.views):
             p.grad = v
 
     def zero_grad(self):
-        """One fill for the whole model; gradient views stay attached (the stores count as "no gradient yet")."""
-        self.sync()
-        self.buf.zero_()
+        """One fill for the stores (their gradient views stay attached; they count as "no gradient yet"); the other
+        parameters' gradients are dropped (set_to_none): autograd then hands each its gradient without an add kernel and
+        `sync()` gathers them with one multi-tensor copy -- 30 in-place adds less per step for the autoencoder."""
+        n_store = 0
         for st in self.stores:
+            st.attach_grads()
             st.grad_written = False
+            n_store += st.flat_g.numel()
+        if n_store:
+            self.buf[:n_store].zero_()
+        for p in self.others:
+            p.grad = None
 
     def allreduce(self, average=True):
         """THE collective of the step.  Returns the number of elements reduced (0 in a single-process run)."""

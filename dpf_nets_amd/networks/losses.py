@@ -113,7 +113,8 @@ class GaussianFlowNLL(nn.Module):
     """lib/networks/losses.py:18-26 -- O(B*G) tensor ops on the latent prior flow's lists."""
 
     def forward(self, samples, mus, logvars):
-        return 0.5 * torch.add(torch.sum(sum(logvars) + ((samples[0] - mus[0]) ** 2 / torch.exp(logvars[0]))) / samples[0].shape[0],
+        # total_logvar: sum(logvars), taken from the stack's own layer-sum when the list is `[base] + <the prior flow's list>`
+        return 0.5 * torch.add(torch.sum(total_logvar(logvars) + ((samples[0] - mus[0]) ** 2 / torch.exp(logvars[0]))) / samples[0].shape[0],
                                np.log(2.0 * np.pi) * samples[0].shape[1])
 
 

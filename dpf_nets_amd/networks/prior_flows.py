@@ -432,7 +432,15 @@ def run_training_prior(module, layers, g, mode):
             torch._foreach_mul_(rvs, 1.0 - m)
             torch._foreach_add_(rvs, uvars, alpha=m)
             torch._foreach_add_([b.num_batches_tracked for b in bns], 1)
-    return list(gs.unbind(0)), list(mus.unbind(0)), list(lvs.unbind(0))
+    lv_list = list(lvs.unbind(0))
+    # the layer-sum of the log-variances, which is all GaussianFlowNLL wants of them (losses.py:22): one reduction over the
+    # (S,B,G) block and one expand in the backward instead of S - 1 adds and S gradient slices stacked back; tagged like the
+    # point decoder's list (networks.losses.total_logvar recognises the whole list)
+    token = object()
+    for i, v in enumerate(lv_list):
+        v._dpf_pos = (token, i)
+    lv_list[-1]._dpf_total = (token, len(lv_list), lvs.sum(0))
+    return list(gs.unbind(0)), list(mus.unbind(0)), lv_list
 
 
 class GPriorStack:
