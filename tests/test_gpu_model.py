@@ -154,3 +154,58 @@ def test_training_forward_backward_through_hip_vs_reference_model_golden(golden_
             assert nbuf + 2 == sum(1 for k in gold.files if k.startswith("buffer/"))      # + p_prior_mus, p_prior_logvar
         del out, loss, pnll, gnll, gent, grads          # as a training loop: nothing of step k is alive in step k + 1
     assert int(lib().dpf_train_graph_replays()) - replays0 >= 2, "none of the later calls was served by graph replays"
+
+
+@pytest.mark.parametrize("overlap", [True, False], ids=["prior_beside_decoder", "prior_in_line"])
+def test_model_mirror_training_step_on_gpu_vs_reference_golden(golden_dir, overlap):
+    """The mirror of the model class itself (networks/models.py: what `bench.py --leg train --model autoencoder` and the
+    data-parallel worker run) on the GPU, every block on its HIP training kernels, the latent prior flow on a side stream
+    BESIDE the point decoder (forward and backward) or in line: four steps against the reference model's golden training
+    step (tests/golden/model_train.npz) -- loss terms, all 250 gradient projections -- through a GradArena, whose flat buffer
+    must hold exactly those gradients after `sync()`; both schedules must give bit-identical gradients."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from dpf_nets_amd import networks as nets, distributed as D
+    from oracle.gen_golden import _grad_projection
+    gold = np.load(os.path.join(golden_dir, "model_train.npz"))
+    cfg = dict(MO.CONFIG, util_mode="training")
+    dev = torch.device("cuda", 0)
+    model = nets.Local_Cond_RNVP_MC_Global_RNVP_VAE(**cfg)
+    model.load_state_dict(FO.to_torch(MO.make_model_state(int(gold["seed"]), cfg)), strict=True)
+    model = model.to(dev).train()
+    model.overlap_prior = overlap
+    model.flatten_parameters()
+    loss_fn = nets.Local_Cond_RNVP_MC_Global_RNVP_VAE_Loss(**cfg)
+    eps_g = torch.from_numpy(gold["eps_g"]).to(dev)
+    model.reparameterize = lambda mu, logvar: eps_g * torch.exp(0.5 * logvar) + mu
+    x = torch.from_numpy(gold["x"]).to(dev)
+    arena = D.GradArena(model.parameters())
+    names = [str(k) for k in gold["grad_names"]]
+    assert [k for k, _ in model.named_parameters()] == names
+    state0 = {k: v.clone() for k, v in model.state_dict().items()}
+    bufs = []
+    for call in range(4):
+        model.load_state_dict(state0)                     # the same step again (running statistics rewound)
+        arena.zero_grad()
+        out = model(x, x)
+        loss, pnll, gnll, gent = loss_fn(x, x, out)
+        loss.backward()
+        arena.allreduce()                                 # single process: sync() only
+        got = np.array([float(v.detach()) for v in (loss, pnll, gnll, gent)])
+        np.testing.assert_allclose(got, gold["loss"], rtol=5e-5, err_msg="call %d" % call)
+        for k, v in _grad_projection([(k, p.grad.detach().cpu()) for k, p in model.named_parameters()], 23).items():
+            ref = gold["gradproj/" + k]
+            for j in range(3):
+                assert abs(v[j] - ref[j]) <= 3e-3 * (ref[2] + 1e-6) + 1e-4, (call, k, j, v, ref)
+        for k, p in model.named_parameters():             # every .grad lives in the ONE message buffer
+            assert p.grad.untyped_storage().data_ptr() == arena.buf.untyped_storage().data_ptr(), k
+        bufs.append(arena.buf.clone())
+        del out, loss, pnll, gnll, gent
+    for b in bufs[1:]:
+        assert torch.equal(b, bufs[0])                    # deterministic, eager or replayed, whatever the streams' timing
+    test_model_mirror_training_step_on_gpu_vs_reference_golden.bufs = getattr(
+        test_model_mirror_training_step_on_gpu_vs_reference_golden, "bufs", {})
+    test_model_mirror_training_step_on_gpu_vs_reference_golden.bufs[overlap] = bufs[0].cpu()
+    both = test_model_mirror_training_step_on_gpu_vs_reference_golden.bufs
+    if len(both) == 2:
+        assert torch.equal(both[True], both[False])       # the side-stream schedule changes nothing but the timing
