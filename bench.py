@@ -992,6 +992,8 @@ def main(argv=None):
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    if os.environ.get("DPF_BENCH_SHARE_GPU") == "1":      # test mode: the ranks share cuda:0 (with DPF_BENCH_BACKEND=gloo; RCCL wants one device per rank)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 

@@ -28,9 +28,17 @@ def local_step(dec, store, p, g):
 
 def main():
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+    # DPF_TEST_BACKEND=gloo + DPF_TEST_SHARE_GPU=1: the ranks are real processes that SHARE cuda:0 and exchange through gloo --
+    # how a 1-GPU box runs the 2-rank path (RCCL refuses two ranks on one device); everything but the transport is the same
+    backend = os.environ.get("DPF_TEST_BACKEND", "nccl")
+    if os.environ.get("DPF_TEST_SHARE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist.init_process_group("nccl", device_id=dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend)
     try:
         B, N, G, nf = 4 * world, 256, 128, 2
         state = SY.make_decoder_state(9, nf, 64, G)
@@ -100,7 +108,7 @@ def main():
             assert bool(mine.abs().sum() > 0) and torch.isfinite(mine).all()
         dist.barrier()
         if rank == 0:
-            print("DIST_OK world=%d flat=%d arena=%d" % (world, store.flat_g.numel(), arena.buf.numel()))
+            print("DIST_OK world=%d backend=%s flat=%d arena=%d" % (world, backend, store.flat_g.numel(), arena.buf.numel()))
     finally:
         dist.destroy_process_group()
 
