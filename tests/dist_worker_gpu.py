@@ -76,6 +76,15 @@ def main():
         per_cloud = ps[-1].square().mean((1, 2))
         gathered = D.gather_clouds(per_cloud)
         assert gathered.shape[0] == B
+        # pairwise_CD sharded by rows ("shards by rows with an all-gather at the end"): every rank computes its block of
+        # the (N1, N2) matrix, the gathered matrix equals the one a single process computes, bit for bit
+        from dpf_nets_amd.networks.utils import pairwise_CD
+        gen = torch.Generator().manual_seed(4)
+        c1 = (torch.rand(5, 300, 3, generator=gen) - 0.5).to(dev)
+        c2 = (torch.rand(7, 257, 3, generator=gen) - 0.5).to(dev)
+        full = pairwise_CD(c1, c2)
+        mine_rows = pairwise_CD(c1, c2, shard_rows=True)
+        assert mine_rows.shape == (5, 7) and torch.equal(mine_rows, full)
         # ---- the whole autoencoder (encoder + posterior + prior flow + base net + decoder, every block on its HIP training
         # kernels): all gradients in ONE flat buffer, the step's exchange is exactly ONE all_reduce -- counted
         from oracle import model_oracle as MO                   # (test infrastructure: the small model configuration only)
