@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: points/s through the L-layer per-point flow + Chamfer.
 
-  python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg3|cfg5] [--layers 14|15|63] [--leg eval|train]
+  python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg3|cfg4|cfg5] [--layers 14|15|63] [--leg eval|train]
+                  [--model decoder|encoder|autoencoder]
 
 One "step" (leg eval, the BASELINE metric) = one pass of the hot path over one synthetic batch resident in HBM:
   FiLM conditioner (all layers) -> fused L-layer coupling stack, mode 'direct', eval-BN
@@ -13,8 +14,11 @@ Workloads (BASELINE.json `configs`):
   cfg4            configs[3]: single-view reconstruction shapes (G=512, B=32 per GPU) + the f_score pass; weak scaling
   cfg5            configs[4]: 16 clouds of N=M=8192 in total, nn_distance + match_cost (approx-EMD); strong scaling
 Leg train (also reported as `extra.train_step` of the default run): inverse stack in training mode (batch-statistics
-BatchNorm) + PointFlowNLL + backward on a flattened decoder -> ONE all-reduce of the flat gradient (RCCL) -> Adam
-(lib/networks/training.py:37-56 with the collective between :55 and :56).
+BatchNorm) + PointFlowNLL + backward on a flattened decoder -> ONE all-reduce of the model's flat gradient (RCCL; counted) ->
+Adam (lib/networks/training.py:37-56 with the collective between :55 and :56); `--model autoencoder` = the whole
+Local_Cond_RNVP_MC_Global_RNVP_VAE of the workload's YAML (cfg3: 12 972 413 parameters, one 51.9 MB message).  The leg first
+runs 6 steps with graph replay and 6 with eager launches and refuses to report a value if their losses differ.
+The default run also carries `extra.configs`: short legs of L = 63 / 15, cfg3, cfg4 and cfg5 measured in the same process.
 
 N GPUs: one process per GPU.  `--gpus N` without a torchrun environment starts the N ranks itself (children are
 created before this process touches the GPU); under `python -m torch.distributed.run` the ranks read
