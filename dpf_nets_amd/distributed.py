@@ -122,14 +122,23 @@ class GradArena:
         dev = params[0].device
         if any(p.device != dev or p.dtype != torch.float32 for p in params):
             raise ValueError("GradArena: all parameters must be float32 on one device")
-        n_store = sum(st.flat_g.numel() for st in self.stores)
-        total = n_store + sum(p.numel() for p in self.others)
+        # every store's slice starts on a 256-byte boundary (the fused Adam step and the kernels' 16-byte accesses want their
+        # buffers aligned); the few padding words are zeros and travel with the message
+        def up(n):
+            return (n + 63) // 64 * 64
+        n_store = 0
+        for st in self.stores:
+            n_store = up(n_store) + st.flat_g.numel()
+        total = up(n_store) + sum(p.numel() for p in self.others)
         self.buf = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.n_store = up(n_store)
         off = 0
         for st in self.stores:
+            off = up(off)
             n = st.flat_g.numel()
             st.rebase_grads(self.buf[off:off + n])
             off += n
+        off = up(off)
         self.views = []
         for p in self.others:
             v = self.buf[off:off + p.numel()].view(p.shape)
@@ -170,13 +179,11 @@ class GradArena:
         """One fill for the stores (their gradient views stay attached; they count as "no gradient yet"); the other
         parameters' gradients are dropped (set_to_none): autograd then hands each its gradient without an add kernel and
         `sync()` gathers them with one multi-tensor copy -- 30 in-place adds less per step for the autoencoder."""
-        n_store = 0
         for st in self.stores:
             st.attach_grads()
             st.grad_written = False
-            n_store += st.flat_g.numel()
-        if n_store:
-            self.buf[:n_store].zero_()
+        if self.n_store:
+            self.buf[:self.n_store].zero_()
         for p in self.others:
             p.grad = None
 
