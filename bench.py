@@ -635,10 +635,14 @@ def leg_cfg5(args, rank, world, dist, device):
     # (B,m,n) `match` read-modified-written on each of 9 levels): this implementation keeps the level state in a workspace
     # and writes `match` once, so it does not move those bytes -- dividing them by the time measured nothing (r02: a fraction
     # of 1.56).  What bounds it is the transcendental issue rate: 36 v_exp_f32 per pair (27 level passes + the materialise /
-    # cost pass), quarter rate = 16 lanes per SIMD-clock.  The HBM side is reported against what the algorithm must write:
-    # 4*n*m B per cloud (`match`, once) -- counter bytes from the committed --pmc pass, when present.
+    # cost pass).  A wave64 v_exp_f32 occupies its SIMD for 8.1-8.5 cycles on this part (profiles/r02_mfma_fill.txt, rows
+    # `exp`): 8 lanes per SIMD-clock, half the plain-VALU rate.  The quarter-rate figure VERDICT r02 #8 priced it at is
+    # reported beside it.  (r03's first lines carried 256*4*16*2.4e9 here -- the FULL VALU lane rate, a slip: frac 0.14.)
+    # The HBM side is reported against what the algorithm must write: 4*n*m B per cloud (`match`, once) -- counter bytes
+    # from the committed --pmc pass, when present.
     exp_total = 36.0 * batch * N * N
-    exp_peak = 256 * 4 * 16 * 2.4e9                     # CUs x SIMDs x quarter-rate lanes x 2.4 GHz = 9.83e12 exp/s
+    exp_peak = 256 * 4 * 8 * 2.4e9                      # CUs x SIMDs x 8 lanes per clock x 2.4 GHz = 1.966e13 exp/s
+    exp_peak_quarter = 256 * 4 * 4 * 2.4e9              # 9.83e12 exp/s
     ach = exp_total / (t_emd * 1e-6)
     must_write = 4.0 * batch * N * N
     traffic, tsrc = read_traffic("approxmatch_cost/B%d_N%d" % (batch, N))
@@ -650,7 +654,10 @@ def leg_cfg5(args, rank, world, dist, device):
                     "counter_bytes_over_algorithmic": (traffic / must_write) if traffic else None,
                     "note": "algorithmic bytes = 4*n*m per cloud: `match` written once; the reference's own RMW form would move "
                             "80*n*m (SURVEY 8d), which this implementation does not"},
-            "note": "bound = v_exp_f32 issue (quarter rate): 36 exp per pair; MFMA / HBM are not the limit of this op",
+            "frac_at_quarter_rate_peak": min(1.0, ach / exp_peak_quarter),
+            "note": "bound = v_exp_f32 issue, measured 8.1-8.5 cycles per wave64 instruction (half rate): 36 exp per pair; the "
+                    "kernel issues ~7 VALU slots per pair and pass in all, i.e. it sits at the SIMDs' issue rate -- MFMA / HBM "
+                    "are not the limit of this op",
             "kernels_us": {"nn_distance": t_nn, "approxmatch_cost": t_emd},
             "chamfer_pair_evals_per_s": 2.0 * batch * N * N / (t_nn * 1e-6),
             "emd_exp_per_s": ach}

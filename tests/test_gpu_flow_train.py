@@ -152,7 +152,8 @@ def test_decoder_training_step_vs_reference_golden(golden_dir, prec):
             assert int(sd[k]) == 1, k
 
 
-@pytest.mark.parametrize("B,N,mode", [(3, 1000, "inverse"), (8, 2048, "direct"), (2, 40, "inverse")])
+# (40, 300): more than 32 clouds -- the second round of the per-cloud totals in the backward prologues -- and ragged tiles
+@pytest.mark.parametrize("B,N,mode", [(3, 1000, "inverse"), (8, 2048, "direct"), (2, 40, "inverse"), (40, 300, "inverse"), (33, 64, "direct")])
 def test_training_hip_vs_tensor_op_path(B, N, mode, prec):
     """Same module, same inputs: HIP kernels vs forward_torch + autograd on the GPU, in float64 (the
     yardstick) and in fp32 (PyTorch-ROCm ops) -- every output, every input gradient, every parameter

@@ -12,7 +12,7 @@ import bench  # noqa: E402
 sys.argv = [sys.argv[0]]
 args = bench.parse()
 device = torch.device("cuda", 0)
-dec, state, n_flows, z, g, tgt, tgt_pm = bench.build_workload(args, device)
+dec, state, n_flows, z, g, tgt, tgt_pm = bench.build_workload(args, device, 32)
 step = bench.make_step(dec, z, g, tgt_pm, args.layers)
 for _ in range(3):
     step()
@@ -46,4 +46,4 @@ for ns in (1, 2, 3, 4, 1, 2, 3, 4):
     run(400, ns)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 400
-    print("%d stream(s): %.1f us/step  %.3e points/s" % (ns, dt * 1e6, args.batch * args.points / dt))
+    print("%d stream(s): %.1f us/step  %.3e points/s" % (ns, dt * 1e6, 32 * args.points / dt))

@@ -14,7 +14,7 @@ dec = nets.LocalCondRNVPDecoder(1, 64, G).cuda().train()
 tgt, z, g = SY.synthetic_inputs(3, B, N, G)
 names = ["loop top", "sync+zero", "fwd recompute", "dh1", "T chain + mask", "reductions", "dW1 rounds", "sync+zero redw",
          "LDS atomics", "sync", "write out"]
-for prec in ("bf16x3", "bf16x6"):
+for prec in ("f16x3", "bf16x6"):
     train_engine.TRAIN_PRECISION = prec
     prof = torch.zeros((16, 14), dtype=torch.int64, device="cuda")
     for it in range(3):
