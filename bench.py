@@ -154,11 +154,14 @@ def init_ranks(args):
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     backend = os.environ.get("DPF_BENCH_BACKEND", "nccl")     # "gloo": the launcher/selftest path of the CPU tests
+    import datetime
+    # a collective nobody else joins must end the job in minutes, not after the default half hour
+    pg_timeout = datetime.timedelta(seconds=int(os.environ.get("DPF_BENCH_PG_TIMEOUT", "300")))
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=pg_timeout)
     else:
-        dist.init_process_group(backend)
+        dist.init_process_group(backend, timeout=pg_timeout)
     return rank, local_rank, world, dist
 
 
@@ -805,10 +808,24 @@ def train_step_leg(args, rank, world, dist, device, batch, layers, steps, warmup
     N, G = args.points, args.latent
     if model_kind is None:
         model_kind = getattr(args, "model", None) or ("encoder" if getattr(args, "encoder", "none") != "none" else "decoder")
-    same, check_replays = replay_equals_eager(args, rank, device, batch, layers, model_kind)
-    params, compute, store, what = build_train_workload(args, rank, device, batch, layers, model_kind)
-    arena = D.GradArena(params)                  # every gradient of the model in ONE flat buffer = the one message of the step
-    opt = nets.Adam(params, lr=2.56e-4, weight_decay=1e-6, betas=(0.9, 0.999), amsgrad=True)
+    # Everything that can fail on ONE rank (allocation, the replay check) happens before the first collective, and the ranks
+    # vote on it: a rank that raised here while the others entered the step's all-reduce would hang the job until the
+    # process group's time-out and cost the headline line.
+    setup_error = None
+    try:
+        same, check_replays = replay_equals_eager(args, rank, device, batch, layers, model_kind)
+        params, compute, store, what = build_train_workload(args, rank, device, batch, layers, model_kind)
+        arena = D.GradArena(params)              # every gradient of the model in ONE flat buffer = the one message of the step
+        opt = nets.Adam(params, lr=2.56e-4, weight_decay=1e-6, betas=(0.9, 0.999), amsgrad=True)
+    except Exception as e:       # noqa: BLE001
+        setup_error = e
+    if dist is not None:
+        ok = torch.tensor([0.0 if setup_error is not None else 1.0], device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) == 0.0 and setup_error is None:
+            setup_error = RuntimeError("another rank failed to set the training leg up")
+    if setup_error is not None:
+        raise setup_error
     ev = []
     counted = []
 

@@ -159,6 +159,13 @@ __global__ __launch_bounds__(256) void tstats_x_kernel(int N, int ka, int kb, co
 // (r02: a device function run by every workgroup of tstats_h1 -- the consumer -- straight into its LDS: 2 048 partial
 // values and 8 KiB of fragments are cheaper to redo 256 times than a dependent one-workgroup launch is to wait for;
 // workgroup 0 also publishes the fragments and the statistics for the kernels that follow.  512 threads.)
+#ifdef DPF_PROFILE
+__device__ unsigned long long *g_kprof = nullptr;            // [kernel id][8] s_memtime stamps of workgroup 0, wave 0
+#define KP(kid, i) { __builtin_amdgcn_sched_barrier(0); if (g_kprof != nullptr && blockIdx.x == 1 && blockIdx.y == 3 && threadIdx.x == 0) g_kprof[(kid) * 8 + (i)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define KP(kid, i) {}
+#endif
+
 // the loads of bn0_fold, to be issued BEFORE the caller's weight DMA (vector-memory results return in order: issued behind
 // 48+ KB of LDS-DMA they wait for all of it): this thread's share of the moment partials, and (threads < 128) its feature's
 // W0 / gamma / beta
@@ -201,9 +208,11 @@ __device__ __forceinline__ void bn0_fold(const Bn0Loads &L, double count, uint8_
 #pragma unroll
         for (int i = 0; i < 5; ++i)
             for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
+        KP(0, 5)
         if ((threadIdx.x & 63) == 0)
             for (int i = 0; i < 5; ++i) wsum[threadIdx.x >> 6][i] = v[i];
         __syncthreads();
+        KP(0, 6)
         if (threadIdx.x < 5) {
             const int i = threadIdx.x;
             mom[i] = (((wsum[0][i] + wsum[1][i]) + (wsum[2][i] + wsum[3][i])) + ((wsum[4][i] + wsum[5][i]) + (wsum[6][i] + wsum[7][i]))) / count;
@@ -234,6 +243,7 @@ __device__ __forceinline__ void bn0_fold(const Bn0Loads &L, double count, uint8_
     fold[br][f][0] = s0 * (float)wa; fold[br][f][1] = s0 * (float)wb; fold[br][f][2] = beta - (float)mean * s0;
     foldn[br][f][0] = rstd * (float)wa; foldn[br][f][1] = rstd * (float)wb; foldn[br][f][2] = -(float)mean * rstd;
     }
+    KP(0, 7)
     __syncthreads();
     static_assert(TW * 64 == 512, "one thread per (set, branch, tile, lane)");
     {
@@ -472,13 +482,6 @@ __device__ __forceinline__ int reduced_feature(int pl, int h) {
     return acc_feature(R >> 4, R & 15, h);
 }
 
-
-#ifdef DPF_PROFILE
-__device__ unsigned long long *g_kprof = nullptr;            // [kernel id][8] s_memtime stamps of workgroup 0, wave 0
-#define KP(kid, i) { __builtin_amdgcn_sched_barrier(0); if (g_kprof != nullptr && blockIdx.x == 1 && blockIdx.y == 3 && threadIdx.x == 0) g_kprof[(kid) * 8 + (i)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-#else
-#define KP(kid, i) {}
-#endif
 
 struct TArgs {
     const uint8_t *packed_l;     // pt_bytes(NS) of this layer

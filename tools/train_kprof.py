@@ -31,6 +31,7 @@ for it in range(6):
 h.dpf_debug_set_kprof(None)
 t = np.median(np.stack(rows), axis=0)
 names = {0: ("tstats_h1", ["entry", "prologue issued (bn0_fold, loads)", "first barrier passed", "both branches done", "exit"]),
+         5: ("tstats_h1 prologue (stamps 0, 5, 6, 7, 1 of kernel 0)", None),
          1: ("tbwd1", ["entry", "prologue issued (coefs of pass 3, loads)", "first barrier passed", "main part done", "row published, ticket taken"]),
          2: ("tbwd2", ["entry", "prologue done (BN1-backward means)", "exit"]),
          3: ("tbwd2 prologue", ["address setup done", "DMA pieces issued", "cf table / point loads / w2s issued", "means: loads back, sums done",
@@ -38,6 +39,11 @@ names = {0: ("tstats_h1", ["entry", "prologue issued (bn0_fold, loads)", "first 
          4: ("tbwd2, branch 0, dh0 phase", ["dh1 transposed back (8 identity MFMAs)", "symmetric split (bg)", "W1^T chain (24 MFMAs)", "relu mask + u_k"])}
 for kid, (name, labels) in names.items():
     print(name)
+    if labels is None:
+        seq = [("entry", 0), ("loads back, butterflies done", 5), ("first barrier", 6), ("fold (double) done", 7), ("fragments stored, DMA issued", 1)]
+        for (la, ia), (lb, ib) in zip(seq[:-1], seq[1:]):
+            print("   %-48s %8.0f ticks" % (la + " -> " + lb, t[0, ib] - t[0, ia]))
+        continue
     for i in range(1, len(labels)):
         print("   %-48s %8.0f ticks" % (labels[i - 1] + " -> " + labels[i], t[kid, i] - t[kid, i - 1]))
     print("   %-48s %8.0f ticks" % ("total", t[kid, len(labels) - 1] - t[kid, 0]))

@@ -14,7 +14,7 @@ dec = nets.LocalCondRNVPDecoder(1, 64, G).cuda().train()
 tgt, z, g = SY.synthetic_inputs(3, B, N, G)
 names = ["loop top", "sync+zero", "fwd recompute", "dh1", "T chain + mask", "reductions", "dW1 rounds", "sync+zero redw",
          "LDS atomics", "sync", "write out"]
-for prec in ("f16x3", "bf16x6"):
+for prec in ("f16x3",):
     train_engine.TRAIN_PRECISION = prec
     prof = torch.zeros((16, 14), dtype=torch.int64, device="cuda")
     for it in range(3):
@@ -29,4 +29,7 @@ for prec in ("f16x3", "bf16x6"):
     print(prec, "kernel entry -> after the prologue:", np.median(t[:, 11] - t[:, 12]), " prologue end -> loop:", np.median(t[:, 0] - t[:, 11]),
           " branch 0:", np.median(t[:, 10] - t[:, 0]), " whole kernel (this wave):", np.median(t[:, 13] - t[:, 12]))
     for i in range(10):
-        print("   %-16s median %8.0f  max %8.0f" % (names[i + 1], np.median(d[:, i]), d[:, i].max()))
+        print("   %-16s median %8.0f  min %8.0f  max %8.0f   per wave of workgroup 0: %s" % (names[i + 1], np.median(d[:, i]), d[:, i].min(), d[:, i].max(), " ".join("%5d" % v for v in d[:8, i])))
+    print("   arrival at the phase boundaries relative to the workgroup's first wave (workgroup 0):")
+    for i in range(11):
+        print("      TP(%2d) %s" % (i, " ".join("%6d" % (v - t[:8, i].min()) for v in t[:8, i])))
