@@ -1090,7 +1090,8 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
         __syncthreads();                                                   // staging landed / previous branch flushed
         TP(1)
         // per-point values every lane needs in the swapped orientation (registers = points): d(o) of this branch, x_a, x_b
-        if (!h) { pts[pl] = dov[br][0]; pts[32 + pl] = dov[br][1]; pts[64 + pl] = xa; pts[96 + pl] = xb; }
+        // (dov[br][..] with the loop's br as a run-time index put the four values in scratch memory: a scratch load at the top of every branch)
+        if (!h) { pts[pl] = br ? dov[1][0] : dov[0][0]; pts[32 + pl] = br ? dov[1][1] : dov[0][1]; pts[64 + pl] = xa; pts[96 + pl] = xb; }
         // ---- forward: h0 (lane = point) -> fragments; pre = h1 + D in the SWAPPED orientation (lane = feature 32 t + pl,
         // register r = point (r & 3) + 8 (r >> 2) + 4 h): per-feature constants become per-lane, sums over the points in-lane
         f32x16 h0a[2], pre[2];
