@@ -530,12 +530,18 @@ __global__ __launch_bounds__(TW * 64) void tstats_h1_kernel(TArgs a, float *__re
         split_fragment<true, NS, false, F16>(acc0, bf, a.negone);
         chain_mfma_swapped<NS, F16>(smem + PT_A1, br, lane, bf, acc1);         // lane = feature, registers = points
         const int tile0 = (blockIdx.x * TW + wave) * TILE;
+        if (tile0 + TILE > N) {                  // ragged last tile of a cloud (wave-uniform, rare): padding points do not count
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[t][r] = tile0 + (r & 3) + 8 * (r >> 2) + 4 * h < N ? acc1[t][r] : 0.f;
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = tile0 + (r & 3) + 8 * (r >> 2) + 4 * h < N ? acc1[t][r] : 0.f;   // padding points do not count
+                const float v = acc1[t][r];
                 s1 += v;
                 s2 = __builtin_fmaf(v, v, s2);
             }
@@ -1127,8 +1133,14 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
                     const float g2 = dh2a_of(pre[t][r], w2a, w2b, doa4[r >> 2][r & 3], dob4[r >> 2][r & 3]);
                     const float h1n = pre[t][r] * rstd1 - ca;
                     const float v = rstd1 * (av * g2 - m1 - h1n * m2);
-                    pre[t][r] = tile0 + (r & 3) + 8 * (r >> 2) + 4 * h < N ? v : 0.f;
+                    pre[t][r] = v;
                 }
+            }
+            if (tile0 + TILE > N) {              // ragged last tile of a cloud (wave-uniform, rare): no gradient from padding points
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pre[t][r] = tile0 + (r & 3) + 8 * (r >> 2) + 4 * h < N ? pre[t][r] : 0.f;
             }
             kfrags_from_swapped<false>(pre, xh, xl);
         }
