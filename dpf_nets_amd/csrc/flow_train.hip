@@ -879,17 +879,19 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
             const float fa = filmb[br * FB_BR + 0 * 64 + fo] * filmb[br * FB_BR + 2 * 64 + fo];      // h2 = FA * relu(pa)
             const float rstd1 = filmb[br * FB_BR + 2 * 64 + fo], ca = filmb[br * FB_BR + 3 * 64 + fo];
             const float w2a = w2s[br * 128 + fo], w2b = w2s[br * 128 + 64 + fo];
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            // r03: 8 VALU per element instead of 11 (the kernel is bound by VALU issue): the per-lane factor FA leaves the loop,
+            // and sum dh2a * pa = sum lin * relu(pa) = W2a * sum do_a relu(pa) + W2b * sum do_b relu(pa) needs no loop at all
+            float s0 = 0.f, s1 = 0.f, s3 = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float da = doa4[r >> 2][r & 3], db = dob4[r >> 2][r & 3];
-                const float g = dh2a_of(pre[t][r], w2a, w2b, da, db);                         // [pa > 0] sum_w W2[w]*do_w
-                const float h2 = relu(pre[t][r]) * fa;
-                s0 += da * h2;                                                                 // dW2[w] = sum do_w * h2
-                s1 += db * h2;
-                s2 += g * (pre[t][r] * rstd1 - ca);                                            // da = sum dh2a * h1n
-                s3 += g;
+                const float rp = relu(pre[t][r]);
+                s0 = __builtin_fmaf(da, rp, s0);                                               // dW2[w] = FA * sum do_w * relu(pa)
+                s1 = __builtin_fmaf(db, rp, s1);
+                s3 += dh2a_of(pre[t][r], w2a, w2b, da, db);                                    // dc = sum dh2a,  dh2a = [pa > 0] sum_w W2[w]*do_w
             }
+            float s2 = rstd1 * (w2a * s0 + w2b * s1) - ca * s3;                                // da = sum dh2a * h1n,  h1n = pa * rstd1 - c/a
+            s0 *= fa; s1 *= fa;
             s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32); s3 += __shfl_xor(s3, 32);
             if (!h) {
                 rw[(br * 4 + 0) * 64 + fo] = s0;
@@ -1090,6 +1092,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
             eye[j2][d] = (pl == p0 ? 0x3F80u : 0u) | (pl == p1 ? 0x3F800000u : 0u);
         }
     float *pts = redw + wave * 2048;                                     // per-wave scratch (free until the reduction): [4][32] per-point values
+    const bool two_kept = a.kb >= 0;
     const int tile0 = (blockIdx.x * TW + wave) * TILE;
     for (int br = 0; br < 2; ++br) {
         TP(0)
@@ -1128,12 +1131,14 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
                 const float av = filmb[br * FB_BR + 0 * 64 + fo], rstd1 = filmb[br * FB_BR + 2 * 64 + fo], ca = filmb[br * FB_BR + 3 * 64 + fo];
                 const float w2a = w2s[br * 128 + fo], w2b = w2s[br * 128 + 64 + fo];
                 const float m1 = s12s[br * 128 + fo], m2 = s12s[br * 128 + 64 + fo];
+                // r03: the per-lane constants folded (6 VALU per element instead of 8):
+                //   rstd1 (a dh2a - m1 - h1n m2) = [pa > 0] (K1 do_a + K2 do_b) + C1 pa + C0
+                const float K1 = rstd1 * av * w2a, K2 = rstd1 * av * w2b, C1 = -(rstd1 * rstd1) * m2, C0 = rstd1 * (ca * m2 - m1);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float g2 = dh2a_of(pre[t][r], w2a, w2b, doa4[r >> 2][r & 3], dob4[r >> 2][r & 3]);
-                    const float h1n = pre[t][r] * rstd1 - ca;
-                    const float v = rstd1 * (av * g2 - m1 - h1n * m2);
-                    pre[t][r] = v;
+                    const float base = __builtin_fmaf(pre[t][r], C1, C0);
+                    const float lin = __builtin_fmaf(K2, dob4[r >> 2][r & 3], K1 * doa4[r >> 2][r & 3]);
+                    pre[t][r] = pre[t][r] > 0.f ? base + lin : base;
                 }
             }
             if (tile0 + TILE > N) {              // ragged last tile of a cloud (wave-uniform, rare): no gradient from padding points
@@ -1149,18 +1154,26 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
         // orientations: lane = point for the per-point u_k, lane = feature for the per-feature sums
         u32x4 bg[2][4];
         {
-            f32x16 dn[2];
+            // r03: the hi and the lo parts are transposed SEPARATELY -- each result is a bf16 value in an fp32 register, so
+            // the B fragments of the next contraction are two byte permutes per pair instead of a second symmetric split
+            // of hi + lo (6 VALU per pair); same 8 MFMAs
+            f32x16 dnh[2], dnl[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                dn[t] = zero16();
-#pragma unroll
-                for (int j2 = 0; j2 < 2; ++j2) {
-                    dn[t] = mfma(xh[t][j2], eye[j2], dn[t]);
-                    dn[t] = mfma(xl[t][j2], eye[j2], dn[t]);
-                }
+                dnh[t] = mfma(xh[t][0], eye[0], zero16());
+                dnl[t] = mfma(xl[t][0], eye[0], zero16());
+                dnh[t] = mfma(xh[t][1], eye[1], dnh[t]);
+                dnl[t] = mfma(xl[t][1], eye[1], dnl[t]);
             }
             if (br == 0) KP(4, 0)
-            split_fragment<false, 2, true>(dn, bg);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int s = 2 * t + (r >> 3), d = (r & 7) >> 1;          // as split_fragment
+                    bg[0][s][d] = pack_bf16_trunc(dnh[t][r], dnh[t][r + 1]);
+                    bg[1][s][d] = pack_bf16_trunc(dnl[t][r], dnl[t][r + 1]);
+                }
             if (br == 0) KP(4, 1)
         }
         {
@@ -1182,11 +1195,18 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
                     const float *c0 = cf + br * 128 + h4u + 32 * t;
 #pragma unroll
                     for (int q = 2 * rh; q < 2 * rh + 2; ++q) {
-                        const f32x4 ca = *(const f32x4 *)(c0 + 8 * q), cb = *(const f32x4 *)(c0 + 64 + 8 * q);
-                        ua += ca.x * dh0a[t][4 * q + 0]; ub += cb.x * dh0a[t][4 * q + 0];
-                        ua += ca.y * dh0a[t][4 * q + 1]; ub += cb.y * dh0a[t][4 * q + 1];
-                        ua += ca.z * dh0a[t][4 * q + 2]; ub += cb.z * dh0a[t][4 * q + 2];
-                        ua += ca.w * dh0a[t][4 * q + 3]; ub += cb.w * dh0a[t][4 * q + 3];
+                        const f32x4 ca = *(const f32x4 *)(c0 + 8 * q);
+                        ua += ca.x * dh0a[t][4 * q + 0];
+                        ua += ca.y * dh0a[t][4 * q + 1];
+                        ua += ca.z * dh0a[t][4 * q + 2];
+                        ua += ca.w * dh0a[t][4 * q + 3];
+                        if (two_kept) {                                    // wave-uniform: layers of pattern 1 keep one channel
+                            const f32x4 cb = *(const f32x4 *)(c0 + 64 + 8 * q);
+                            ub += cb.x * dh0a[t][4 * q + 0];
+                            ub += cb.y * dh0a[t][4 * q + 1];
+                            ub += cb.z * dh0a[t][4 * q + 2];
+                            ub += cb.w * dh0a[t][4 * q + 3];
+                        }
                     }
                     asm volatile("" : "+v"(h4u) : "v"(ua), "v"(ub));
                 }
@@ -1210,7 +1230,8 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float d = h0s[t][r] > 0.f ? dh0s[t][r] : 0.f;
-                    s0 += d * h0n[t][r]; s1 += d; s2 += d * xa4[r >> 2][r & 3]; s3 += d * xb4[r >> 2][r & 3];
+                    s0 += d * h0n[t][r]; s1 += d; s2 += d * xa4[r >> 2][r & 3];
+                    if (two_kept) s3 += d * xb4[r >> 2][r & 3];
                 }
                 rsum[t][0] = s0 + __shfl_xor(s0, 32); rsum[t][1] = s1 + __shfl_xor(s1, 32);
                 rsum[t][2] = s2 + __shfl_xor(s2, 32); rsum[t][3] = s3 + __shfl_xor(s3, 32);
