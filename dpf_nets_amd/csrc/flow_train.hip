@@ -166,15 +166,32 @@ __device__ unsigned long long *g_kprof = nullptr;            // [kernel id][8] s
 #define KP(kid, i) {}
 #endif
 
+// a workgroup barrier that orders LDS traffic only (see stage_load below)
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // the loads of bn0_fold, to be issued BEFORE the caller's weight DMA (vector-memory results return in order: issued behind
 // 48+ KB of LDS-DMA they wait for all of it): this thread's share of the moment partials, and (threads < 128) its feature's
 // W0 / gamma / beta
-struct Bn0Loads { double v[5]; float wa, wb, gamma, beta; };
+struct Bn0Loads { double ld[4][5]; double v[5]; float wa, wb, gamma, beta; };
 __device__ __forceinline__ Bn0Loads bn0_loads(int nblk, int nk, const double *__restrict__ part, const float *__restrict__ tcanon_l) {
     Bn0Loads L;
+    // the first 4 x 512 rows (all of them up to B * N / 256 = 2048): requested here, CONSUMED in bn0_fold.  r03: summing them
+    // here, inside a run-time loop over row blocks, had put an `s_waitcnt vmcnt(0)` in front of the caller's weight DMA --
+    // the cold round trip of these loads and the weight DMA ran one after the other
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int row = threadIdx.x + k * TW * 64;
+        const bool ok = row < nblk;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) L.ld[k][i] = ok ? part[(size_t)(ok ? row : 0) * 8 + i] : 0.0;
+    }
 #pragma unroll
     for (int i = 0; i < 5; ++i) L.v[i] = 0;
-    for (int b0 = 0; b0 < nblk; b0 += 4 * TW * 64) {
+    for (int b0 = 4 * TW * 64; b0 < nblk; b0 += 4 * TW * 64) {             // more rows than that (rare): summed here, after the first block in bn0_fold
         double ld[4][5];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -204,20 +221,22 @@ __device__ __forceinline__ void bn0_fold(const Bn0Loads &L, double count, uint8_
     __shared__ float fold[2][64][4];
     __shared__ float foldn[2][64][4];
     {   // fixed-order sum of the per-workgroup partials: thread -> rows tid, tid + 512, ...; wave butterflies; waves in order
-        double v[5] = {L.v[0], L.v[1], L.v[2], L.v[3], L.v[4]};
+        double v[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) v[i] = (((L.ld[0][i] + L.ld[1][i]) + L.ld[2][i]) + L.ld[3][i]) + L.v[i];   // rows tid, tid + 512, ... in order
 #pragma unroll
         for (int i = 0; i < 5; ++i)
             for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
         KP(0, 5)
         if ((threadIdx.x & 63) == 0)
             for (int i = 0; i < 5; ++i) wsum[threadIdx.x >> 6][i] = v[i];
-        __syncthreads();
+        lds_barrier();
         KP(0, 6)
         if (threadIdx.x < 5) {
             const int i = threadIdx.x;
             mom[i] = (((wsum[0][i] + wsum[1][i]) + (wsum[2][i] + wsum[3][i])) + ((wsum[4][i] + wsum[5][i]) + (wsum[6][i] + wsum[7][i]))) / count;
         }
-        __syncthreads();
+        lds_barrier();
     }
     if (threadIdx.x < 128) {
     const int br = threadIdx.x >> 6, f = threadIdx.x & 63;
@@ -244,7 +263,7 @@ __device__ __forceinline__ void bn0_fold(const Bn0Loads &L, double count, uint8_
     foldn[br][f][0] = rstd * (float)wa; foldn[br][f][1] = rstd * (float)wb; foldn[br][f][2] = -(float)mean * rstd;
     }
     KP(0, 7)
-    __syncthreads();
+    lds_barrier();
     static_assert(TW * 64 == 512, "one thread per (set, branch, tile, lane)");
     {
         const int set = threadIdx.x >> 8, rem = threadIdx.x & 255, b2 = rem >> 7, t = (rem >> 6) & 1, lane = rem & 63;
@@ -295,11 +314,43 @@ __global__ __launch_bounds__(1024) void tcolsum_kernel(int nrows, int J, const f
 // ---------------------------------------------------------------------------------------------------
 // shared tile machinery (one 32-point tile per wave, weights staged in LDS)
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void stage_bytes(const uint8_t *src, uint8_t *lds, int nbytes, int wave, int lane) {
-    for (int c = wave; c * 1024 < nbytes; c += TW)
-        __builtin_amdgcn_global_load_lds((glb_void *)(src + c * 1024 + lane * 16), (lds_void *)(lds + c * 1024), 16, 0, 0);
+// Staging a layer's packed block into LDS THROUGH REGISTERS, in two halves: stage_load issues a wave's 16-byte loads (a
+// compile-time number of them; a piece index past the end is clamped to the last piece: the same bytes to the same place),
+// stage_store writes them to LDS.  r03: these prologues used LDS-DMA (global_load_lds).  The compiler counts LDS-DMA and
+// ordinary loads as different kinds of vector-memory events, so once both were in flight EVERY wait became
+// `s_waitcnt vmcnt(0)`, and any LDS access behind a DMA waited for it as a possible alias: the small reductions of the
+// prologues (BN0 fold, pass-3 coefficients, BN1-backward means) ran only after the whole weight block had landed, and in
+// tstats_h1 the weight DMA was not even issued until the moment rows were back.  With plain loads everything is one
+// in-order stream: the compiler waits for exactly the loads a value needs, the weights land while the reductions run.
+// (tools/ubench/stage_rate.hip: load + ds_write is as fast as the DMA.)  lds_barrier: a workgroup barrier that orders LDS
+// traffic only -- __syncthreads() would wait for every outstanding load.
+template <int NBYTES>
+struct StageRegs {
+    static constexpr int NPIECES = (NBYTES + 1023) / 1024, PER_WAVE = (NPIECES + TW - 1) / TW;
+    u32x4 v[PER_WAVE];
+};
+template <int NBYTES>
+__device__ __forceinline__ StageRegs<NBYTES> stage_load(const uint8_t *src, int wave, int lane) {
+    using R = StageRegs<NBYTES>;
+    R r;
+#pragma unroll
+    for (int i = 0; i < R::PER_WAVE; ++i) {
+        int c = wave + TW * i;
+        if (TW * i + TW > R::NPIECES) c = c < R::NPIECES ? c : R::NPIECES - 1;
+        r.v[i] = *(const u32x4 *)(src + c * 1024 + lane * 16);
+    }
+    return r;
 }
-
+template <int NBYTES>
+__device__ __forceinline__ void stage_store(const StageRegs<NBYTES> &r, uint8_t *lds, int wave, int lane) {
+    using R = StageRegs<NBYTES>;
+#pragma unroll
+    for (int i = 0; i < R::PER_WAVE; ++i) {
+        int c = wave + TW * i;
+        if (TW * i + TW > R::NPIECES) c = c < R::NPIECES ? c : R::NPIECES - 1;
+        *(u32x4 *)(lds + c * 1024 + lane * 16) = r.v[i];
+    }
+}
 // input MFMA of one branch: acc[t] = A0[br][t] . b0   (t = M tile)
 __device__ __forceinline__ void input_mfma(const uint8_t *a0, int br, int lane, u32x4 b0, f32x16 (&acc)[2]) {
 #pragma unroll
@@ -506,19 +557,24 @@ __global__ __launch_bounds__(TW * 64) void tstats_h1_kernel(TArgs a, float *__re
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     KP(0, 0)
     // every small load first, then the weight DMA (results return in order)
-    const Bn0Loads bl = bn0_loads(nblk_x, a.kb >= 0 ? 2 : 1, xpart, a.tcanon_l);
+    Bn0Loads bl = bn0_loads(nblk_x, a.kb >= 0 ? 2 : 1, xpart, a.tcanon_l);
     const int N = a.N, n = (blockIdx.x * TW + wave) * TILE + pl;
     const bool valid = n < N;
     const float *pc = a.p_in + (size_t)bi * 3 * N;
     const int nc = valid ? n : N - 1;
     const float xa = pc[(size_t)a.ka * N + nc], xb = a.kb >= 0 ? pc[(size_t)a.kb * N + nc] : 0.f;
     asm volatile("" ::: "memory");
-    stage_bytes(a.packed_l, smem, NS * P_A1_PART, wave, lane);            // A1; the A0 fragments are folded right here
+    const StageRegs<NS * P_A1_PART> wregs = stage_load<NS * P_A1_PART>(a.packed_l, wave, lane);   // A1; the A0 fragments are folded right here
+#pragma unroll
+    for (int k = 0; k < 4; ++k)                                           // pin the consumers of the moment rows BEHIND the weight loads' issue
+#pragma unroll
+        for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(bl.ld[k][i]));
     {
         const bool first = blockIdx.x == 0 && blockIdx.y == 0;
         bn0_fold(bl, count, smem + pt_a0(NS), first ? packed_a0 : nullptr, first ? const_cast<float *>(a.stats_l) : nullptr);
     }
     const u32x4 b0 = input_fragment(h ? xb : xa, h);
+    stage_store(wregs, smem, wave, lane);
     KP(0, 1)
     __syncthreads();
     KP(0, 2)
@@ -716,7 +772,7 @@ __device__ __forceinline__ void bwd3_coefs(const CoefLoads &L, int blk, int nk, 
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[br][i] = v[i];
     }
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x < 2) {
         const int k = threadIdx.x;
         const double s0 = acc[0][4 * k + 0] + acc[1][4 * k + 0], s1 = acc[0][4 * k + 1] + acc[1][4 * k + 1];
@@ -725,7 +781,7 @@ __device__ __forceinline__ void bwd3_coefs(const CoefLoads &L, int blk, int nk, 
         coef[k * 4 + 1] = (float)s1;
         coef[k * 4 + 2] = (float)s2;
     }
-    __syncthreads();
+    lds_barrier();
 }
 
 // u_k - C_k - alpha_k x_a - beta_k x_b, every operation rounded on its own (no contraction: pass 3 as its own launch
@@ -763,22 +819,18 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
     int h4 = 4 * h;                   // opaque to the optimiser: feature offsets stay "lane base + immediate"
     asm volatile("" : "+v"(h4));      // (as known bits they become OR-ed constants, one live register each)
     KP(1, 0)
-    CoefLoads cl = {};
-    if (pv.has) cl = bwd3_loads(pv.kb >= 0 ? 2 : 1, pv.tot, pv.tcanon_l, pv.stats_l);    // before the DMA: results return in order
+    // (unconditional: the host hands valid pointers even when there is no layer above -- `cl = {}` merged with the loaded
+    // values cost register copies, i.e. a wait for the loads right here)
+    CoefLoads cl = bwd3_loads(pv.kb >= 0 ? 2 : 1, pv.tot, pv.tcanon_l, pv.stats_l);      // first: results return in order
     asm volatile("" ::: "memory");
-    stage_bytes(a.packed_l, smem + L_PACK, pt_a0n(NS), wave, lane);
-    stage_bytes((const uint8_t *)(a.film_l + (size_t)bi * 512), smem + L_FILM, 2048, wave, lane);
-    stage_bytes((const uint8_t *)(a.filmb_l + (size_t)bi * FB_CLOUD), smem + L_FILMB, 2048, wave, lane);
-    float *w2s = red + TW * 520;                                                // [2 br][2][64] raw sd2.weight
-    if (threadIdx.x < 256) w2s[threadIdx.x] = a.tcanon_l[(threadIdx.x >> 7) * T_BR + T_W2 + (threadIdx.x & 127)];
-    float *pcoef = w2s + 256 + TW * 64;                                         // 8 floats behind the per-wave scratch
-    if (pv.has)   // the previous backward layer's pass 3, under the weight DMA (scratch: the reduction slots, free until the end)
-        bwd3_coefs(cl, blockIdx.y * gridDim.x + blockIdx.x, pv.kb >= 0 ? 2 : 1, pv.count, pv.dcanon_l, (double (*)[8])red, pcoef);
+    // every load of the prologue is requested here, in the order its consumer comes: the pass-3 totals (above), this thread's
+    // point (inputs, the layer's stored outputs, the gradients that reach it), then the weights -- one in-order stream
+    const float w2_v = threadIdx.x < 256 ? a.tcanon_l[(threadIdx.x >> 7) * T_BR + T_W2 + (threadIdx.x & 127)] : 0.f;
     const int N = a.N, n = (blockIdx.x * TW + wave) * TILE + pl;
     const bool valid = n < N;
     const int nc = valid ? n : N - 1;
     const size_t cloud = (size_t)bi * 3 * N;
-    float p[3], gp[3], gm[3], gl[3], mus[3], lvs[3];
+    float p[3], gp[3], gm[3], gl[3], mus[3], lvs[3], gp1[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const size_t o = cloud + (size_t)c * N + nc;
@@ -788,22 +840,40 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
         gp[c] = g_p2 ? g_p2[o] : 0.f;                                       // what the layer above passes down (direct term so far)
         gm[c] = valid && g_mu ? g_mu[o] : 0.f;
         gl[c] = valid && g_lv ? g_lv[o] : 0.f;
+        gp1[c] = g_p ? g_p[o] : 0.f;
     }
-    if (pv.has) {   // + the conditioner path of the layer above: dx_k = u_k - C_k - alpha_k x_a - beta_k x_b on ITS kept channels
+    float xa2 = 0.f, xb2 = 0.f, u2a = 0.f, u2b = 0.f;
+    if (pv.has) {
         const float *xc = pv.x + cloud;
-        const float xa2 = xc[(size_t)pv.ka * N + nc], xb2 = pv.kb >= 0 ? xc[(size_t)pv.kb * N + nc] : 0.f;
+        xa2 = xc[(size_t)pv.ka * N + nc]; xb2 = pv.kb >= 0 ? xc[(size_t)pv.kb * N + nc] : 0.f;
+        u2a = pv.ubuf[((size_t)bi * 2 + 0) * N + nc]; u2b = pv.kb >= 0 ? pv.ubuf[((size_t)bi * 2 + 1) * N + nc] : 0.f;
+    }
+    const StageRegs<pt_a0n(NS)> wregs = stage_load<pt_a0n(NS)>(a.packed_l, wave, lane);
+    const StageRegs<2048> fregs = stage_load<2048>((const uint8_t *)(a.film_l + (size_t)bi * 512), wave, lane);
+    const StageRegs<2048> fbregs = stage_load<2048>((const uint8_t *)(a.filmb_l + (size_t)bi * FB_CLOUD), wave, lane);
+    // pin the consumers of the pass-3 totals BEHIND the issue of everything else (the compiler had started on them right
+    // behind their loads: a cold round trip before the point and weight loads were even requested)
+    asm volatile("" : "+v"(cl.Sg), "+v"(cl.S), "+v"(cl.Sa), "+v"(cl.Sb));
+    asm volatile("" : "+v"(cl.ea), "+v"(cl.eb), "+v"(cl.caa), "+v"(cl.cbb), "+v"(cl.cab));
+    asm volatile("" : "+v"(cl.wa), "+v"(cl.wb), "+v"(cl.gamma), "+v"(cl.rstd0), "+v"(cl.mean0));
+    float *w2s = red + TW * 520;                                                // [2 br][2][64] raw sd2.weight
+    if (threadIdx.x < 256) w2s[threadIdx.x] = w2_v;
+    float *pcoef = w2s + 256 + TW * 64;                                         // 8 floats behind the per-wave scratch
+    if (pv.has)   // the previous backward layer's pass 3, while the weights land (scratch: the reduction slots, free until the end)
+        bwd3_coefs(cl, blockIdx.y * gridDim.x + blockIdx.x, pv.kb >= 0 ? 2 : 1, pv.count, pv.dcanon_l, (double (*)[8])red, pcoef);
+    if (pv.has) {   // + the conditioner path of the layer above: dx_k = u_k - C_k - alpha_k x_a - beta_k x_b on ITS kept channels
         // every operation rounded on its own, in tbwd3f_kernel's order (the two launch forms give the same bits)
-        const float ta = cond_path(pv.ubuf[((size_t)bi * 2 + 0) * N + nc], pcoef[0], pcoef[1], pcoef[2], xa2, xb2);
-        const float tb = pv.kb >= 0 ? cond_path(pv.ubuf[((size_t)bi * 2 + 1) * N + nc], pcoef[4], pcoef[5], pcoef[6], xa2, xb2) : 0.f;
+        const float ta = cond_path(u2a, pcoef[0], pcoef[1], pcoef[2], xa2, xb2);
+        const float tb = pv.kb >= 0 ? cond_path(u2b, pcoef[4], pcoef[5], pcoef[6], xa2, xb2) : 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c)
             if (c == pv.ka || c == pv.kb) gp[c] = __fadd_rn(gp[c], c == pv.ka ? ta : tb);
     }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const size_t o = cloud + (size_t)c * N + nc;
-        gp[c] = valid ? __fadd_rn(g_p ? g_p[o] : 0.f, gp[c]) : 0.f;
-    }
+    for (int c = 0; c < 3; ++c) gp[c] = valid ? __fadd_rn(gp1[c], gp[c]) : 0.f;
+    stage_store(wregs, smem + L_PACK, wave, lane);
+    stage_store(fregs, smem + L_FILM, wave, lane);
+    stage_store(fbregs, smem + L_FILMB, wave, lane);
     const float xa = sel3(a.ka, p[0], p[1], p[2]), xb = a.kb >= 0 ? sel3(a.kb, p[0], p[1], p[2]) : 0.f;
     const u32x4 b0 = input_fragment(h ? xb : xa, h);
     KP(1, 1)
@@ -983,24 +1053,43 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
     // return in order, so issued behind it they waited for all of it (tools/train_kprof.py: 5.8 K ticks for 24 loads)
     const int mq = threadIdx.x & 127, mbr = mq >> 6, mf = mq & 63, mg4 = threadIdx.x >> 7;     // means: (branch, feature) x clouds mg4, mg4 + 4, ...
     float m_av[8], m_q3[8], m_q2[8];
+    float f_wa[8], f_wb[8], f_bb[8];      // workgroup (0, 0) only: the dW2 / db2 totals it writes (r03: these were 8 dependent round trips
+                                          // of loads inside the means' loop -- the one workgroup every launch waited for)
+    const bool first_wg = blockIdx.x == 0 && blockIdx.y == 0;
+    // branch-free: a cloud index past the batch is clamped and the value dropped where it is used (predicated loads became
+    // exec-masked branches whose joins waited for everything in flight)
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {
-        const int b = mg4 + 4 * jj;
-        const bool ok = b < a.B;
-        const float *qq = pcs + (size_t)(ok ? b : 0) * 520 + mbr * 256;
-        m_av[jj] = ok ? a.filmb_l[(size_t)b * FB_CLOUD + mbr * FB_BR + mf] : 0.f;
-        m_q3[jj] = ok ? qq[3 * 64 + mf] : 0.f;
-        m_q2[jj] = ok ? qq[2 * 64 + mf] : 0.f;
+        const int b = mg4 + 4 * jj, bc = b < a.B ? b : 0;
+        const float *qq = pcs + (size_t)bc * 520 + mbr * 256;
+        m_av[jj] = a.filmb_l[(size_t)bc * FB_CLOUD + mbr * FB_BR + mf];
+        m_q3[jj] = qq[3 * 64 + mf];
+        m_q2[jj] = qq[2 * 64 + mf];
+    }
+    if (first_wg) {                       // (wave-uniform)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int b = mg4 + 4 * jj, bc = b < a.B ? b : 0;
+            const float *qq = pcs + (size_t)bc * 520 + mbr * 256;
+            f_wa[jj] = qq[0 * 64 + mf];
+            f_wb[jj] = qq[1 * 64 + mf];
+            f_bb[jj] = pcs[(size_t)bc * 520 + 512 + mbr * 2 + (mf & 1)];
+        }
+    } else {
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) f_wa[jj] = f_wb[jj] = f_bb[jj] = 0.f;
     }
     // ... and so are the small table / per-point loads (registers now, LDS writes after the DMA is issued)
-    float cf_w = 0.f, cf_r = 0.f, cf_g = 0.f, w2_v = 0.f;
-    if (threadIdx.x < 256) {                                               // c_fk = W0[f][k] * rstd0_f * gamma0_f
-        const int br = threadIdx.x >> 7, k = (threadIdx.x >> 6) & 1, f = threadIdx.x & 63;
+    // (both halves of the workgroup load both tables, branch-free: an if / else around the loads shared a register between
+    // a pending load and a constant, and the compiler put `s_waitcnt vmcnt(0)` in front of the weights' issue)
+    float cf_w, cf_r, cf_g, w2_v;
+    {
+        const int i = threadIdx.x & 255;
+        const int br = i >> 7, k = (i >> 6) & 1, f = i & 63;                 // c_fk = W0[f][k] * rstd0_f * gamma0_f
         const float *cb = a.tcanon_l + br * T_BR;
         const int nk = a.kb >= 0 ? 2 : 1;
-        cf_w = k < nk ? cb[T_W0 + f * nk + k] : 0.f; cf_r = a.stats_l[br * ST_BR + 64 + f]; cf_g = cb[T_G0 + f];
-    } else {
-        const int i = threadIdx.x - 256;
+        cf_w = cb[T_W0 + f * nk + (k < nk ? k : 0)]; cf_r = a.stats_l[br * ST_BR + 64 + f]; cf_g = cb[T_G0 + f];
+        if (k >= nk) cf_g = 0.f;
         w2_v = a.tcanon_l[(i >> 7) * T_BR + T_W2 + (i & 127)];
     }
     const int N = a.N, n = (blockIdx.x * TW + wave) * TILE + pl;
@@ -1011,9 +1100,12 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
     const float *dq = dout + (size_t)bi * 4 * N + nc;
     const float dov[2][2] = {{dq[0], dq[N]}, {dq[2 * (size_t)N], dq[3 * (size_t)N]}};
     asm volatile("" ::: "memory");
-    stage_bytes(a.packed_l, smem + L_PACK, pt_bytes(NS), wave, lane);
-    stage_bytes((const uint8_t *)(a.film_l + (size_t)bi * 512), smem + L_FILM, 2048, wave, lane);
-    stage_bytes((const uint8_t *)(a.filmb_l + (size_t)bi * FB_CLOUD), smem + L_FILMB, 2048, wave, lane);
+    const StageRegs<pt_bytes(NS)> wregs = stage_load<pt_bytes(NS)>(a.packed_l, wave, lane);
+    const StageRegs<2048> fregs = stage_load<2048>((const uint8_t *)(a.film_l + (size_t)bi * 512), wave, lane);
+    const StageRegs<2048> fbregs = stage_load<2048>((const uint8_t *)(a.filmb_l + (size_t)bi * FB_CLOUD), wave, lane);
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj)        // pin the consumers of the small loads BEHIND the issue of the weight loads (else the sums are scheduled
+        asm volatile("" : "+v"(m_av[jj]), "+v"(m_q3[jj]), "+v"(m_q2[jj]), "+v"(f_wa[jj]), "+v"(f_wb[jj]), "+v"(f_bb[jj]));   // right behind each load: 8 serial round trips)
     KP(3, 1)
     const u32x4 b0 = input_fragment(h ? xb : xa, h);
     const float *film = (const float *)(smem + L_FILM);
@@ -1031,22 +1123,34 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
         const int q = mq, br_ = mbr, f_ = mf, g4 = mg4;
         const bool first = blockIdx.x == 0 && blockIdx.y == 0;
         double S1 = 0, S2 = 0, w2a = 0, w2b = 0, bb = 0;
-        for (int b0 = 0; b0 < a.B; b0 += 32) {
-            if (b0 > 0) {                                                      // more than 32 clouds: further rounds (rare)
+        // the first 32 clouds from the registers loaded at the top (straight-line code: inside the loop below the compiler
+        // cannot tell these loads from the loop's own and waits for everything in flight, the weights included) ...
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) {
-                    const int b = b0 + g4 + 4 * jj;
-                    const bool ok = b < a.B;
-                    const float *qq = pcs + (size_t)(ok ? b : 0) * 520 + br_ * 256;
-                    m_av[jj] = ok ? a.filmb_l[(size_t)b * FB_CLOUD + br_ * FB_BR + f_] : 0.f;
-                    m_q3[jj] = ok ? qq[3 * 64 + f_] : 0.f;
-                    m_q2[jj] = ok ? qq[2 * 64 + f_] : 0.f;
-                }
+        for (int jj = 0; jj < 8; ++jj) {
+            const bool ok = g4 + 4 * jj < a.B;
+            const float av = ok ? m_av[jj] : 0.f;
+            S1 += (double)av * m_q3[jj];                                       // dh1n = a * dh2a
+            S2 += (double)av * m_q2[jj];                                       // dh1n * h1n
+            w2a += ok ? f_wa[jj] : 0.f;                                        // (zeros unless workgroup (0, 0))
+            w2b += ok ? f_wb[jj] : 0.f;
+            bb += ok && f_ < 2 ? f_bb[jj] : 0.f;
+        }
+        // ... and further rounds of 32 for bigger batches, in the same order
+        for (int b0 = 32; b0 < a.B; b0 += 32) {
+            float r_av[8], r_q3[8], r_q2[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int b = b0 + g4 + 4 * jj;
+                const bool ok = b < a.B;
+                const float *qq = pcs + (size_t)(ok ? b : 0) * 520 + br_ * 256;
+                r_av[jj] = ok ? a.filmb_l[(size_t)b * FB_CLOUD + br_ * FB_BR + f_] : 0.f;
+                r_q3[jj] = ok ? qq[3 * 64 + f_] : 0.f;
+                r_q2[jj] = ok ? qq[2 * 64 + f_] : 0.f;
             }
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
-                S1 += (double)m_av[jj] * m_q3[jj];                             // dh1n = a * dh2a
-                S2 += (double)m_av[jj] * m_q2[jj];                             // dh1n * h1n
+                S1 += (double)r_av[jj] * r_q3[jj];
+                S2 += (double)r_av[jj] * r_q2[jj];
             }
             if (first)
                 for (int jj = 0; jj < 8; ++jj) {
@@ -1060,7 +1164,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
         KP(3, 3)
         acc[g4][0][q] = S1; acc[g4][1][q] = S2; acc[g4][2][q] = w2a; acc[g4][3][q] = w2b; acc[g4][4][q] = bb;
         KP(3, 4)
-        __syncthreads();
+        lds_barrier();
         KP(3, 5)
         if (threadIdx.x < 128) {
             double S1 = 0, S2 = 0, w2a = 0, w2b = 0, bb = 0;
@@ -1075,6 +1179,9 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
             }
         }
     }
+    stage_store(wregs, smem + L_PACK, wave, lane);                        // the weights, landed while the means were formed
+    stage_store(fregs, smem + L_FILM, wave, lane);
+    stage_store(fbregs, smem + L_FILMB, wave, lane);
     float ua = 0.f, ub = 0.f;
     KP(2, 1)
 #ifdef DPF_PROFILE
@@ -1622,6 +1729,13 @@ static int backward_stack(int n_layers, int B, int N, int mode, int precision, c
     const size_t lst = (size_t)B * 3 * N, fls = dpf_flow_train_film_floats(B), fms = (size_t)4 * B * DPF_FLOW_F;
     const float *chain = nullptr;
     PrevLayer pv = {};
+    {   // no layer above the first one (has = 0), but pointers its pass 1 can load from unconditionally
+        TWork w0;
+        carve(workspace, B, N, &w0);
+        const int l0 = mode == DPF_MODE_DIRECT ? n_layers - 1 : 0;
+        pv.tot = w0.tot2; pv.tcanon_l = tcanon + (size_t)l0 * T_LAYER; pv.stats_l = stats + (size_t)l0 * ST_LAYER;
+        pv.ka = 0; pv.kb = -1;
+    }
     {   // pass 1's per-cloud arrival tickets start at zero (every layer leaves them there).  A fill KERNEL: as a captured
         // memset node the clear was not reliably ordered before the first pass-1 kernel of a replay (zero_fill.h)
         TWork w;
