@@ -240,6 +240,7 @@ __global__ __launch_bounds__(e_waves(NS) * 64) void enc_kernel(EncArgs a) {
     for (int k = wave; k < 8; k += EW)
         __builtin_amdgcn_global_load_lds((glb_void *)(a.packed + k * 1024 + lane * 16), (lds_void *)(smem + k * 1024), 16, 0, 0);
     stage_chunk<NS>(a.packed, 0, l_buf, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces have landed (explicit: __syncthreads() alone emits no vmcnt wait on gfx950)
     __syncthreads();
 
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -277,6 +278,7 @@ __global__ __launch_bounds__(e_waves(NS) * 64) void enc_kernel(EncArgs a) {
     auto chunk_of = [&](int slot) -> const uint8_t * {       // slot: wave-uniform
         const int c = slot / S;
         if (c != cur) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // chunk c's pieces (issued a chunk ago) have landed
             __syncthreads();
             cur = c;
             if (c + 1 < NCH) stage_chunk<NS>(a.packed, c + 1, l_buf + ((c + 1) & 1) * CHB, wave, lane);

@@ -782,6 +782,7 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
     };
     int ka, kb, wa, wb;
     layer_meta(lfirst, ka, kb, wa, wb);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the first layers' weights (and everything above) have landed
     __syncthreads();
 
     for (int step = 0; step < L; ++step) {
@@ -850,6 +851,14 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
         }
         p0 = pn[0]; p1 = pn[1]; p2 = pn[2];
         s0 += lv[0]; s1 += lv[1]; s2 += lv[2];
+        // r03: the ring's protocol says "the DMA of layer n + 1, issued after barrier n - 1, was waited for by its issuers
+        // before they arrive at barrier n" -- but nothing in the compiled loop did: __syncthreads() emits no vmcnt wait on
+        // gfx950 (back-off barrier) and the compiler's LDS-DMA alias wait did not appear in this loop (ISA: no `vmcnt` between
+        // the loop's top and bottom), so a landed DMA was a matter of timing (a layer takes ~3 us, the DMA ~1).  Explicit now,
+        // and placed BEFORE this layer's list stores so that it waits only for operations issued a layer ago (free).
+        if constexpr (SKEW) {
+            if (!lag) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         if (a.ps != nullptr && valid) {   // per-layer lists in DIRECT order (decoders.py:61-70); halves share the rows
             const size_t base = (size_t)li * list_stride + cloud + n;
             float *dst[5]; float val[5];
@@ -874,7 +883,10 @@ __global__ __launch_bounds__(FW * 64, 2) void flow_kernel(FlowArgs a) {
                 stage_step(step + 2);
             }
         } else {
-            if (within == LPB - 1) __syncthreads();   // the next buffer's weights have landed; everyone is done with this one
+            if (within == LPB - 1) {   // the next buffer's weights have landed (explicitly: see above); everyone is done with this one
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
         }
 #ifdef DPF_PROFILE
         DPF_T(7)
