@@ -306,7 +306,10 @@ def _backward_core(spec, mode, prec, saved, grads, need_dg):
     dxh = dy * gam
     du = rstd * (dxh - dxh.mean(1, keepdim=True) - xhat * (dxh * xhat).mean(1, keepdim=True))
     dW0 = torch.matmul(du.transpose(1, 2), g.unsqueeze(0))             # (K, F, G)
-    dg = torch.matmul(du.permute(1, 0, 2).reshape(B, K * F), W0.reshape(K * F, G)) if need_dg else None
+    # d g = sum_k du[k] @ W0[k].  As ONE (B, K*F) x (K*F, G) product (K*F = 16 128) the library picks a 32x32 tile kernel with
+    # four workgroups that each walk the whole K: 119 us at B = 32 (tools/experiments/ae_gemm_shapes.py); as K small products
+    # and a sum over K it is ~12 us
+    dg = torch.bmm(du, W0).sum(0) if need_dg else None
     return chain, dg, dcanon, dW0, dgam, dbet, dW1, db1
 
 
