@@ -1,0 +1,100 @@
+"""Properties of the COMPILED kernels that the r03 performance work depends on, checked on the ISA the cross-compiler emits
+(hipcc runs without a GPU).  Each of them was found by reading `hipcc -S` output, cost measurable time when it was violated,
+and is invisible to every numerical test:
+
+* flow.hip / flow_train.hip carry no packed-f32 VALU (v_pk_fma/add/mul_f32: +16 cycles each beside MFMAs on gfx950 -- the SLP
+  vectoriser creates them under plain -O3, hence -fno-slp-vectorize in the Makefile) and no scratch memory (a run-time index
+  into a small array had put `tbwd2`'s per-point values there);
+* the training kernels stage their weights through registers, not LDS-DMA (the compiler turns every wait behind a
+  global_load_lds into vmcnt(0) and treats every later LDS access as its alias);
+* the skewed eval kernel's layer loop contains an explicit `s_waitcnt vmcnt(0)` (the compiler emits none at its barriers:
+  a landed weight DMA used to be a matter of timing).
+Skipped when hipcc is absent."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "dpf_nets_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _isa(tmp_path_factory, name):
+    if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
+        pytest.skip("no hipcc")
+    out = tmp_path_factory.mktemp("isa") / (name + ".s")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-fno-slp-vectorize",
+           "-S", "--cuda-device-only", "-o", str(out), os.path.join(CSRC, name + ".hip")]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return out.read_text()
+
+
+@pytest.fixture(scope="module")
+def isa_flow_train(tmp_path_factory):
+    return _isa(tmp_path_factory, "flow_train")
+
+
+@pytest.fixture(scope="module")
+def isa_flow(tmp_path_factory):
+    return _isa(tmp_path_factory, "flow")
+
+
+def _kernels(isa):
+    """{mangled name: body} of every kernel of an assembly listing"""
+    parts = re.split(r"^(_Z[A-Za-z0-9_]+):[^\n]*$", isa, flags=re.M)
+    return {parts[i]: parts[i + 1].split("s_endpgm")[0] for i in range(1, len(parts) - 1, 2)}
+
+
+HOT_EVAL = "flow_kernelILi2ELi8ELi1ELb1ELb1ELb1E"          # NS = 2, 8 waves, LPB = 1, pipelined, fp16 operands, skewed ring
+HOT_TRAIN = ("tstats_h1_kernel", "tbwd1_kernel", "tbwd2_kernel")
+
+
+def test_makefile_compiles_the_flow_stack_without_the_slp_vectoriser():
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    for target in ("flow.o", "flow_train.o"):
+        rule = mk[mk.index(target + ":"):]
+        assert "$(FLOWFLAGS)" in rule.split("\n\n")[0].split("\n", 2)[1], target
+    assert "FLOWFLAGS := -fno-slp-vectorize" in mk
+
+
+def test_no_packed_f32_and_no_scratch_in_the_flow_kernels(isa_flow, isa_flow_train):
+    hot = {n: b for n, b in _kernels(isa_flow).items() if HOT_EVAL in n}
+    hot.update({n: b for n, b in _kernels(isa_flow_train).items() if any(k in n for k in HOT_TRAIN)})
+    assert len(hot) >= 2 + 9, sorted(hot)                      # direct / inverse of the eval kernel, 3 precisions of 3 training kernels
+    for name, body in hot.items():
+        assert not re.search(r"\bv_pk_(fma|add|mul)_f32\b", body), name
+        assert "scratch_" not in body, name
+    for name, isa in (("flow.hip", isa_flow), ("flow_train.hip", isa_flow_train)):
+        assert "scratch_" not in isa, name
+        spills = [int(x) for x in re.findall(r"\.vgpr_spill_count:\s+(\d+)", isa)]
+        assert spills and max(spills) == 0, (name, spills)
+
+
+def test_training_kernels_stage_weights_through_registers(isa_flow_train):
+    assert "global_load_lds" not in isa_flow_train
+    ks = _kernels(isa_flow_train)
+    for key in HOT_TRAIN:
+        bodies = [b for n, b in ks.items() if key in n]
+        assert bodies, key
+        for b in bodies:
+            # the prologue waits for its loads one group at a time: partial vmcnt waits, not only vmcnt(0)
+            partial = [int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", b) if int(x) > 0]
+            assert len(partial) >= 3, (key, partial)
+
+
+def test_skewed_eval_kernel_waits_for_its_weight_dma_inside_the_layer_loop(isa_flow):
+    ks = _kernels(isa_flow)
+    skew = [b for n, b in ks.items() if HOT_EVAL in n]
+    assert skew
+    for b in skew:
+        lines = b.split("\n")
+        dma = [i for i, l in enumerate(lines) if "global_load_lds" in l]
+        waits = [i for i, l in enumerate(lines) if re.search(r"s_waitcnt vmcnt\(0\)\s*$", l)]
+        # the DMA of the loop's bottom (after the prologue's two layers) and, before it in program order, the explicit wait
+        loop_dma = [i for i in dma if i > len(lines) // 2]
+        assert loop_dma, "no in-loop DMA found"
+        assert any(len(lines) // 4 < w < loop_dma[0] for w in waits), "no vmcnt(0) between the loop's top and its DMA issue"
