@@ -421,25 +421,27 @@ __device__ __forceinline__ void branch_tile(const uint8_t *lb, int br, int lane,
     // partial sums over NATURAL register pairs -- two consecutive accumulator registers against the two consecutive
     // weights of one f32x4 load -- so that no operand pair has to be assembled with v_mov (the SLP vectoriser paired
     // the scalar chain across the two M tiles and spent ~1.5 v_mov per v_pk_fma_f32 doing so).
-    f32x2 oa2 = {0.f, 0.f}, ob2 = {0.f, 0.f};
+    // (r03: scalar again, as in layer_pipe -- a packed-f32 instruction costs +16 cycles beside the SIMD partner's MFMAs;
+    // two partial sums per output keep the rounding order of the packed form: even / odd registers)
+    float oa0 = 0.f, oa1 = 0.f, ob0 = 0.f, ob1 = 0.f;
     load_w(1, wva[1], wvb[1]);
 #pragma unroll
     for (int tp = 0; tp < 2; ++tp)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x2 v01 = {relu(acc1[tp][4 * q + 0]), relu(acc1[tp][4 * q + 1])};
-            const f32x2 v23 = {relu(acc1[tp][4 * q + 2]), relu(acc1[tp][4 * q + 3])};
+            const float v0 = relu(acc1[tp][4 * q + 0]), v1 = relu(acc1[tp][4 * q + 1]);
+            const float v2 = relu(acc1[tp][4 * q + 2]), v3 = relu(acc1[tp][4 * q + 3]);
             const f32x4 wa4 = wva[tp][q];
-            oa2 = __builtin_elementwise_fma(f32x2{wa4.x, wa4.y}, v01, oa2);
-            oa2 = __builtin_elementwise_fma(f32x2{wa4.z, wa4.w}, v23, oa2);
+            oa0 = __builtin_fmaf(wa4.x, v0, oa0); oa1 = __builtin_fmaf(wa4.y, v1, oa1);
+            oa0 = __builtin_fmaf(wa4.z, v2, oa0); oa1 = __builtin_fmaf(wa4.w, v3, oa1);
             if (TWO) {
                 const f32x4 wb4 = wvb[tp][q];
-                ob2 = __builtin_elementwise_fma(f32x2{wb4.x, wb4.y}, v01, ob2);
-                ob2 = __builtin_elementwise_fma(f32x2{wb4.z, wb4.w}, v23, ob2);
+                ob0 = __builtin_fmaf(wb4.x, v0, ob0); ob1 = __builtin_fmaf(wb4.y, v1, ob1);
+                ob0 = __builtin_fmaf(wb4.z, v2, ob0); ob1 = __builtin_fmaf(wb4.w, v3, ob1);
             }
         }
-    oa = oa2.x + oa2.y;
-    ob = ob2.x + ob2.y;
+    oa = oa0 + oa1;
+    ob = ob0 + ob1;
 }
 
 // ---------------------------------------------------------------------------------------------------------
