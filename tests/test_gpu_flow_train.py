@@ -624,3 +624,34 @@ def test_c_abi_backward_block_form_equals_the_pointer_list_form(mode):
         for x, y, name in zip(a, b, ("dp_in", "dcanon", "dfm")):
             assert torch.isfinite(x).all() and float(x.abs().max()) > 0, name
             assert torch.equal(x, y), (name, with_ml)
+
+
+def test_training_more_moment_rows_than_one_round_of_the_bn0_prologue():
+    """B * N / 256 > 2048 rows of input-moment partials: `bn0_loads` takes its first 2048 rows in registers and the rest in a
+    loop (r03 rewrote both).  One triple at B = 36, N = 16 384 (2 304 rows) against the tensor-op path in fp32 on the same
+    GPU: outputs, batch statistics and the input gradient."""
+    nets = _gpu()
+    B, N, G, seed = 36, 16384, 128, 77
+    sd = FO.to_torch(FO.make_decoder_state(seed, 1, 64, G))
+    tgt, z, g = FO.synthetic_inputs(seed, B, N, G)
+    res = {}
+    for impl in ("hip", "torch"):
+        dec = nets.LocalCondRNVPDecoder(1, 64, G, weight_std=0.01)
+        dec.load_state_dict(sd, strict=True)
+        dec = dec.cuda().train()
+        tp = torch.from_numpy(tgt.copy()).cuda().requires_grad_(True)
+        tg = torch.from_numpy(g.copy()).cuda()
+        ps, mus, lvs = dec(tp, tg, mode="inverse") if impl == "hip" else dec.forward_torch(tp, tg, mode="inverse")
+        loss = (ps[0] * ps[0]).mean() + sum(lvs).mean() + 0.1 * (ps[1] * mus[2]).mean()
+        loss.backward()
+        res[impl] = dict(ps=[x.detach() for x in ps], lvs=[x.detach() for x in lvs], gp=tp.grad.detach(), loss=float(loss),
+                         stats={k: v.detach().clone() for k, v in dec.state_dict().items() if "running" in k})
+        del dec, tp, tg, ps, mus, lvs, loss
+        torch.cuda.empty_cache()
+    h, t = res["hip"], res["torch"]
+    for a, b in zip(h["ps"] + h["lvs"], t["ps"] + t["lvs"]):
+        assert rel(a, b) <= 2e-4, rel(a, b)
+    assert abs(h["loss"] - t["loss"]) <= 1e-4 * abs(t["loss"])
+    close_but_kinks(h["gp"], t["gp"], 2e-3, "grad_p", 2e-4)
+    for k in t["stats"]:
+        np.testing.assert_allclose(h["stats"][k].cpu().numpy(), t["stats"][k].cpu().numpy(), rtol=2e-4, atol=1e-5, err_msg=k)
