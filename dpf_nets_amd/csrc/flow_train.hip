@@ -173,15 +173,15 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// the loads of bn0_fold, to be issued BEFORE the caller's weight DMA (vector-memory results return in order: issued behind
-// 48+ KB of LDS-DMA they wait for all of it): this thread's share of the moment partials, and (threads < 128) its feature's
+// the loads of bn0_fold, to be issued BEFORE the caller's weight loads (vector-memory results return in order: issued behind
+// 48+ KB of weights they wait for all of it): this thread's share of the moment partials, and (threads < 128) its feature's
 // W0 / gamma / beta
 struct Bn0Loads { double ld[4][5]; double v[5]; float wa, wb, gamma, beta; };
 __device__ __forceinline__ Bn0Loads bn0_loads(int nblk, int nk, const double *__restrict__ part, const float *__restrict__ tcanon_l) {
     Bn0Loads L;
     // the first 4 x 512 rows (all of them up to B * N / 256 = 2048): requested here, CONSUMED in bn0_fold.  r03: summing them
-    // here, inside a run-time loop over row blocks, had put an `s_waitcnt vmcnt(0)` in front of the caller's weight DMA --
-    // the cold round trip of these loads and the weight DMA ran one after the other
+    // here, inside a run-time loop over row blocks, had put an `s_waitcnt vmcnt(0)` in front of the caller's weight staging --
+    // the cold round trip of these loads and the weight staging ran one after the other
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int row = threadIdx.x + k * TW * 64;
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(TW * 64) void tstats_h1_kernel(TArgs a, float *__re
     const int bi = blockIdx.y, lane = threadIdx.x & 63, h = lane >> 5, pl = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     KP(0, 0)
-    // every small load first, then the weight DMA (results return in order)
+    // every small load first, then the weight loads (results return in order)
     Bn0Loads bl = bn0_loads(nblk_x, a.kb >= 0 ? 2 : 1, xpart, a.tcanon_l);
     const int N = a.N, n = (blockIdx.x * TW + wave) * TILE + pl;
     const bool valid = n < N;
@@ -720,7 +720,7 @@ constexpr int P2_J = 4352;       // floats of a workgroup's pass-2 partial row p
 // arithmetic, same operations in the same order, so the same bits), workgroup 0 also writes d gamma0 / d beta0 / dW0 and
 // the dW1 totals are converted by whoever comes first (grid-stride).  Ends with a workgroup barrier.
 struct CoefLoads { double Sg, S, Sa, Sb; float ea, eb, caa, cbb, cab, wa, wb, gamma, rstd0, mean0; };
-// the loads of bwd3_coefs (threads < 128), to be issued BEFORE the caller's weight DMA
+// the loads of bwd3_coefs (threads < 128), to be issued BEFORE the caller's weight loads
 __device__ __forceinline__ CoefLoads bwd3_loads(int nk, const double *__restrict__ tot, const float *__restrict__ tcanon_l,
                                                 const float *__restrict__ stats_l) {
     CoefLoads L;
@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
     int h4 = 4 * h;                   // opaque to the optimiser: feature offsets stay "lane base + immediate"
     asm volatile("" : "+v"(h4));      // (as known bits they become OR-ed constants, one live register each)
     KP(3, 0)
-    // r03: the loads of the prologue's tiny reductions are issued BEFORE the 92 KB weight DMA -- vector-memory results
+    // r03: the loads of the prologue's tiny reductions are issued BEFORE the 76-92 KB of weight loads -- vector-memory results
     // return in order, so issued behind it they waited for all of it (tools/train_kprof.py: 5.8 K ticks for 24 loads)
     const int mq = threadIdx.x & 127, mbr = mq >> 6, mf = mq & 63, mg4 = threadIdx.x >> 7;     // means: (branch, feature) x clouds mg4, mg4 + 4, ...
     float m_av[8], m_q3[8], m_q2[8];
@@ -1079,7 +1079,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) f_wa[jj] = f_wb[jj] = f_bb[jj] = 0.f;
     }
-    // ... and so are the small table / per-point loads (registers now, LDS writes after the DMA is issued)
+    // ... and so are the small table / per-point loads (registers now, LDS writes after the weight loads are issued)
     // (both halves of the workgroup load both tables, branch-free: an if / else around the loads shared a register between
     // a pending load and a constant, and the compiler put `s_waitcnt vmcnt(0)` in front of the weights' issue)
     float cf_w, cf_r, cf_g, w2_v;
