@@ -76,6 +76,9 @@ SIGNATURES = {
     "dpf_gprior_train_backward": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _f, _f, _vp]),
     "dpf_adam_step": (_i, [_sz, _vp, _vp, _vp, _vp, _vp] + [ctypes.c_double] * 7 + [_vp]),
+    "dpf_film_train_max_batch": (_i, []),
+    "dpf_film_train_forward": (_i, [_i, _i, _i] + [_vp] * 6 + [_f] + [_vp] * 5 + [_vp]),
+    "dpf_film_train_backward": (_i, [_i, _i, _i] + [_vp] * 14 + [_i, _vp]),
     "dpf_pointflow_nll_workspace_floats": (_sz, []),
     "dpf_pointflow_nll": (_i, [_i, _i, _i, _vp, _vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _vp, _vp, _vp]),
     "dpf_pointflow_nll_backward": (_i, [_i, _i, _i, _vp, _vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _vp, _vp, _vp, _vp, _vp]),

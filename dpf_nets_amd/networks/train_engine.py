@@ -210,16 +210,26 @@ def _forward_core(p, g, spec, mode, prec, tcanon, W0, gam, bet, W1, b1, flat=Non
     if B < 2:
         raise ValueError("Expected more than 1 value per channel when training")      # as nn.BatchNorm1d
     mods = spec.film_modules()
-    # ---- FiLM conditioner nets, batched over the K = 4L nets (flows.py:33-45, 68-80)
-    u = torch.matmul(g.unsqueeze(0), W0.transpose(1, 2))               # (K, B, F)
-    var, mean = torch.var_mean(u, dim=1, unbiased=False, keepdim=True)
-    rstd = torch.rsqrt(var + mods[0][1].eps)
-    xhat = (u - mean) * rstd
-    y = xhat * gam + bet
-    sig = torch.sigmoid(y)
-    sw = y * sig
-    fm = torch.baddbmm(b1, sw, W1.transpose(1, 2)).view(L, 2, 2, B, F).contiguous()
-    film_mean, film_uvar = mean.view(K, F), var.view(K, F) * (B / (B - 1.0))
+    # ---- FiLM conditioner nets, all K = 4L of them (flows.py:33-45, 68-80)
+    if film_fused_ok(B, G, W0, gam, bet, W1, b1):
+        # r03: ONE launch (csrc/film_train.hip) instead of ~12 tensor ops; the backward recomputes y / sigmoid / swish
+        fm = torch.empty((L, 2, 2, B, F), dtype=torch.float32, device=dev)
+        xhat = torch.empty((K, B, F), dtype=torch.float32, device=dev)
+        rstd, film_mean, film_uvar = (torch.empty((K, F), dtype=torch.float32, device=dev) for _ in range(3))
+        check(L_.dpf_film_train_forward(K, B, G, g.data_ptr(), W0.data_ptr(), gam.data_ptr(), bet.data_ptr(), W1.data_ptr(),
+                                        b1.data_ptr(), float(mods[0][1].eps), fm.data_ptr(), xhat.data_ptr(), rstd.data_ptr(),
+                                        film_mean.data_ptr(), film_uvar.data_ptr(), stream), "film_train_forward")
+        y = sig = sw = None
+    else:                                                              # batched tensor ops (B > 64, or non-contiguous blocks)
+        u = torch.matmul(g.unsqueeze(0), W0.transpose(1, 2))           # (K, B, F)
+        var, mean = torch.var_mean(u, dim=1, unbiased=False, keepdim=True)
+        rstd = torch.rsqrt(var + mods[0][1].eps)
+        xhat = (u - mean) * rstd
+        y = xhat * gam + bet
+        sig = torch.sigmoid(y)
+        sw = y * sig
+        fm = torch.baddbmm(b1, sw, W1.transpose(1, 2)).view(L, 2, 2, B, F).contiguous()
+        film_mean, film_uvar = mean.view(K, F), var.view(K, F) * (B / (B - 1.0))
     # ---- the layers
     packed = torch.empty(L_.dpf_flow_train_packed_bytes(L, prec), dtype=torch.uint8, device=dev)
     check(L_.dpf_flow_train_pack(L, prec, tcanon.data_ptr(), packed.data_ptr(), stream), "flow_train_pack")
@@ -243,7 +253,7 @@ def _forward_core(p, g, spec, mode, prec, tcanon, W0, gam, bet, W1, b1, flat=Non
     # 3L output tensors (autograd hands back one gradient each) + the layer-sum of the log-variances, which is what
     # PointFlowNLL wants of them (losses.py:13): one reduction here instead of L-1 adds and L-1 backward nodes there
     outs = ps.unbind(0) + mus.unbind(0) + lvs.unbind(0) + (lvs.sum(0),)
-    return outs, (p, g, tcanon, packed, film, stats, ps, W0, gam, W1, xhat, rstd, y, sig, sw, mus, lvs)
+    return outs, (p, g, tcanon, packed, film, stats, ps, W0, gam, W1, xhat, rstd, y, sig, sw, mus, lvs, bet)
 
 
 def _grad_table(grads, shape, keep):
@@ -267,10 +277,16 @@ def _grad_table(grads, shape, keep):
     return (ctypes.c_void_p * len(ptrs))(*ptrs)
 
 
-def _backward_core(spec, mode, prec, saved, grads, need_dg):
+def film_fused_ok(B, G, *blocks):
+    """The fused FiLM-net kernels take B <= 64 clouds, G % 4 == 0 and contiguous fp32 parameter blocks."""
+    return 2 <= B <= lib().dpf_film_train_max_batch() and G % 4 == 0 and \
+        all(t.is_contiguous() and t.dtype == torch.float32 for t in blocks)
+
+
+def _backward_core(spec, mode, prec, saved, grads, need_dg, into_flat=False):
     """grads: the 3L gradients of (ps, mus, lvs), None where an output is unused.
     -> (dL/dp, dL/dg, d canon block, dW0, dgamma, dbeta, dW1, db1), the last five batched over the K FiLM nets."""
-    p, g, tcanon, packed, film, stats, ps, W0, gam, W1, xhat, rstd, y, sig, sw, mus, lvs = saved
+    p, g, tcanon, packed, film, stats, ps, W0, gam, W1, xhat, rstd, y, sig, sw, mus, lvs, bet = saved
     L, G = spec.L, spec.G
     B, _, N = p.shape
     dev = p.device
@@ -294,8 +310,25 @@ def _backward_core(spec, mode, prec, saved, grads, need_dg):
                                            ws.data_ptr(), stream),
           "flow_train_backward_lists")
     del keep
-    # ---- FiLM nets backward (batched)
+    # ---- FiLM nets backward
     K = 4 * L
+    if y is None:                                                      # the forward took the fused kernel: so does the backward
+        into = spec.flat.film_grad_blocks() if into_flat else None
+        if into is None:
+            dW0, dW1 = torch.empty_like(W0), torch.empty_like(W1)
+            dgam, dbet, db1 = (torch.empty((K, F), dtype=torch.float32, device=dev) for _ in range(3))
+        else:
+            dW0, dgam, dbet, dW1, db1 = into
+        dg_part = torch.empty((K, B, G), dtype=torch.float32, device=dev) if need_dg else None
+        check(L_.dpf_film_train_backward(K, B, G, g.data_ptr(), W0.data_ptr(), gam.data_ptr(), bet.data_ptr(), W1.data_ptr(),
+                                         xhat.data_ptr(), rstd.data_ptr(), dfm.data_ptr(), dW0.data_ptr(), dgam.data_ptr(),
+                                         dbet.data_ptr(), dW1.data_ptr(), db1.data_ptr(),
+                                         dg_part.data_ptr() if need_dg else None, 1 if into is not None else 0, stream),
+              "film_train_backward")
+        dg = dg_part.sum(0) if need_dg else None
+        if into is not None:
+            return chain, dg, dcanon, None, None, None, None, None
+        return chain, dg, dcanon, dW0, dgam, dbet, dW1, db1
     dout = dfm.view(K, B, F)
     db1 = dout.sum(1)
     dW1 = torch.matmul(dout.transpose(1, 2), sw)                       # (K, F, F)
@@ -341,7 +374,7 @@ class _FlowStackTrain(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        saved, params = ctx.saved_tensors[:17], ctx.saved_tensors[17:]
+        saved, params = ctx.saved_tensors[:18], ctx.saved_tensors[18:]
         spec = ctx.spec
         chain, dg, dcanon, dW0, dgam, dbet, dW1, db1 = _backward_core(spec, ctx.mode, ctx.prec, saved, grads,
                                                                       ctx.needs_input_grad[1])
@@ -475,11 +508,19 @@ class FlatStore:
         for t, v in zip(ps, gv):
             t.grad = v
 
+    def film_grad_blocks(self):
+        """The five FiLM-net gradient blocks of flat_g for the fused backward kernel to ADD into (views attached first)."""
+        self.attach_grads()
+        gb = self.gblocks
+        return gb[1], gb[2], gb[3], gb[4], gb[5]
+
     def accumulate(self, dcanon, dW0, dgam, dbet, dW1, db1):
         self.attach_grads()
         self.grad_written = True
         gb = self.gblocks
         gb[0].add_(dcanon)
+        if dW0 is None:                       # the fused FiLM backward has added its five blocks in place
+            return
         gb[1].add_(dW0)
         gb[2].add_(dgam.unsqueeze(1))
         gb[3].add_(dbet.unsqueeze(1))
@@ -502,7 +543,8 @@ class _FlowStackTrainFlat(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         spec = ctx.spec
-        chain, dg, *dparams = _backward_core(spec, ctx.mode, ctx.prec, ctx.saved_tensors, grads, ctx.needs_input_grad[1])
+        chain, dg, *dparams = _backward_core(spec, ctx.mode, ctx.prec, ctx.saved_tensors, grads, ctx.needs_input_grad[1],
+                                             into_flat=True)
         spec.flat.accumulate(*dparams)
         return (chain if ctx.needs_input_grad[0] else None, dg, None, None, None, None)
 

@@ -456,6 +456,27 @@ int dpf_gprior_train_backward(int n_steps, int B, int G, int n_features, int mod
                               float *dcanon, float *workspace, float bn_eps, float eps,
                               dpf_stream_t stream);
 
+/* ---- FiLM conditioner nets of the coupling stack, training mode (csrc/film_train.hip) ---------------------
+ * Replaces, for model.train(), the K = 4 n_layers per-cloud conditioner sub-nets of CondRealNVPFlow3D
+ * (lib/networks/flows.py:33-45, 68-80: Linear(G, 64, bias=False) . BatchNorm1d over the B clouds . Swish . Linear(64, 64))
+ * and what autograd derives from them (lib/networks/training.py:55) -- ~12 tensor-op launches forward and ~25 backward per
+ * optimizer step in the reference's formulation, ONE launch each way here.  All arrays fp32, contiguous:
+ *   g (B, G); W0 (K, 64, G); gamma, beta (K, 64); W1 (K, 64, 64) [out][in]; b1 (K, 64)
+ * forward:  fm (K, B, 64) = the stack's conditioner input (dpf_flow_train_forward's `fm`); saved for the backward: xhat
+ *   (K, B, 64) and rstd (K, 64); mean / uvar (K, 64) = batch mean and UNBIASED batch variance for the running-statistics
+ *   update (nn.BatchNorm1d, momentum 0.1).
+ * backward: dfm (K, B, 64) -> dW0 (K, 64, G), dgamma, dbeta (K, 64), dW1 (K, 64, 64), db1 (K, 64): overwritten, or added to
+ *   (accumulate != 0: the flat gradient store); dg_part (K, B, G) or NULL: every sub-net's share of d loss / d g (the caller
+ *   sums over K).  B <= dpf_film_train_max_batch() and G % 4 == 0, else DPF_ENOSUP (the caller keeps the tensor ops). */
+int dpf_film_train_max_batch(void);
+int dpf_film_train_forward(int K, int B, int G, const float *g, const float *W0, const float *gamma, const float *beta,
+                           const float *W1, const float *b1, float bn_eps, float *fm, float *xhat, float *rstd,
+                           float *mean, float *uvar, dpf_stream_t stream);
+int dpf_film_train_backward(int K, int B, int G, const float *g, const float *W0, const float *gamma, const float *beta,
+                            const float *W1, const float *xhat, const float *rstd, const float *dfm, float *dW0,
+                            float *dgamma, float *dbeta, float *dW1, float *db1, float *dg_part, int accumulate,
+                            dpf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
