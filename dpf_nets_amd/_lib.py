@@ -76,6 +76,7 @@ SIGNATURES = {
     "dpf_gprior_train_backward": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _f, _f, _vp]),
     "dpf_adam_step": (_i, [_sz, _vp, _vp, _vp, _vp, _vp] + [ctypes.c_double] * 7 + [_vp]),
+    "dpf_flow_train_update_running": (_i, [_i, ctypes.c_double] + [_vp] * 7),
     "dpf_film_train_max_batch": (_i, []),
     "dpf_film_train_forward": (_i, [_i, _i, _i] + [_vp] * 6 + [_f] + [_vp] * 5 + [_vp]),
     "dpf_film_train_backward": (_i, [_i, _i, _i] + [_vp] * 14 + [_i, _vp]),

@@ -1821,6 +1821,41 @@ extern "C" int dpf_flow_train_backward_lists(int n_layers, int B, int N, int mod
 }
 
 // number of training-mode calls served by a graph replay so far in this process (csrc/graph_cache.h); diagnostics / tests
+// BatchNorm running statistics of a training step, all 8 L BatchNorm1d layers of the stack in one launch:
+//   running = (1 - momentum) * running + momentum * batch      (nn.BatchNorm1d; unbiased batch variance)
+// rows [0, 4L): the FiLM nets (batch statistics from dpf_film_train_forward or the caller's tensor ops), rows [4L, 8L): the
+// conditioner stacks' BN0 / BN1 of (layer, branch), read from the `stats` block of dpf_flow_train_forward.  The arithmetic is
+// the tensor ops' (`mul_` then `add_(batch, alpha=momentum)` = one rounding, then one fused multiply-add): same bits.
+namespace {
+__global__ __launch_bounds__(256) void trunning_kernel(int n_layers, float keep, float mom, const float *__restrict__ film_mean,
+                                                       const float *__restrict__ film_uvar, const float *__restrict__ stats,
+                                                       float *__restrict__ rm, float *__restrict__ rv, long long *__restrict__ nbt) {
+    const int i = blockIdx.x * 256 + threadIdx.x, r = i >> 6, f = i & 63, nf = 4 * n_layers;
+    if (r >= 2 * nf) return;
+    float bm, bv;
+    if (r < nf) {
+        bm = film_mean[i]; bv = film_uvar[i];
+    } else {
+        const int j = r - nf, l = j >> 2, br = (j >> 1) & 1, which = j & 1;
+        const float *st = stats + (size_t)l * ST_LAYER + br * ST_BR;
+        bm = st[(which ? 2 : 0) * 64 + f]; bv = st[(which ? 5 : 4) * 64 + f];
+    }
+    rm[i] = __fmaf_rn(mom, bm, __fmul_rn(rm[i], keep));
+    rv[i] = __fmaf_rn(mom, bv, __fmul_rn(rv[i], keep));
+    if (f == 0) nbt[r] += 1;
+}
+}  // namespace
+
+extern "C" int dpf_flow_train_update_running(int n_layers, double momentum, const float *film_mean, const float *film_uvar,
+                                             const float *stats, float *running_mean, float *running_var,
+                                             long long *num_batches_tracked, dpf_stream_t stream) {
+    if (n_layers <= 0 || !film_mean || !film_uvar || !stats || !running_mean || !running_var || !num_batches_tracked) return DPF_EINVAL;
+    const int n = 8 * n_layers * 64;
+    hipLaunchKernelGGL(trunning_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_layers, (float)(1.0 - momentum),
+                       (float)momentum, film_mean, film_uvar, stats, running_mean, running_var, num_batches_tracked);
+    return (int)hipGetLastError();
+}
+
 extern "C" long dpf_train_graph_replays(void) { return dpf_graph_stats().replays.load(); }
 // out[5] = {replays, eager calls, recordings, evictions, uncapturable keys}, process-wide
 extern "C" void dpf_train_graph_stats(long *out) {

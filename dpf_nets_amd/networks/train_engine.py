@@ -243,9 +243,16 @@ def _forward_core(p, g, spec, mode, prec, tcanon, W0, gam, bet, W1, b1, flat=Non
                                     lvs.data_ptr(), stats.data_ptr(), film.data_ptr(), spec.eps, ws.data_ptr(), stream),
           "flow_train_forward")
     # ---- BatchNorm running statistics: FiLM nets, then the conditioner stacks
-    sv = stats[:, :2 * 6 * F].view(L, 2, 6, F)
-    flow_mean, flow_uvar = sv[:, :, (0, 2)].reshape(4 * L, F), sv[:, :, (4, 5)].reshape(4 * L, F)
-    if flat is not None:
+    if flat is not None and film_mean.is_contiguous() and film_uvar.is_contiguous() and flat.rm.is_contiguous() and \
+            flat.nbt.dtype == torch.int64:
+        flat.update_running_fused(L, film_mean, film_uvar, stats, mods[0][1].momentum)
+        sv = None
+    else:
+        sv = stats[:, :2 * 6 * F].view(L, 2, 6, F)
+        flow_mean, flow_uvar = sv[:, :, (0, 2)].reshape(4 * L, F), sv[:, :, (4, 5)].reshape(4 * L, F)
+    if sv is None:
+        pass
+    elif flat is not None:
         flat.update_running(film_mean, film_uvar, flow_mean, flow_uvar, mods[0][1].momentum)
     else:
         _update_running([m[1] for m in mods], list(film_mean.unbind(0)), list(film_uvar.unbind(0)))
@@ -471,6 +478,12 @@ class FlatStore:
         self.gviews = [buf[o:o + n].view(t.shape) for (o, n), t in zip(self._ranges, self.params)]
         for t, gv in zip(self.params, self.gviews):
             t.grad = gv
+
+    def update_running_fused(self, L, film_mean, film_uvar, stats, momentum):
+        """All 8 L running-statistics updates in one launch (r03: ~9 tensor-op launches before); same arithmetic, same bits."""
+        check(lib().dpf_flow_train_update_running(L, float(momentum), film_mean.data_ptr(), film_uvar.data_ptr(), stats.data_ptr(),
+                                                  self.rm.data_ptr(), self.rv.data_ptr(), self.nbt.data_ptr(), current_stream()),
+              "flow_train_update_running")
 
     def update_running(self, film_mean, film_uvar, flow_mean, flow_uvar, momentum):
         n = self.nfilm

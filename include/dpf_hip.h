@@ -456,6 +456,15 @@ int dpf_gprior_train_backward(int n_steps, int B, int G, int n_features, int mod
                               float *dcanon, float *workspace, float bn_eps, float eps,
                               dpf_stream_t stream);
 
+/* BatchNorm running statistics after a training-mode forward (nn.BatchNorm1d: running = (1 - momentum) * running +
+ * momentum * batch, unbiased batch variance; lib/networks/flows.py:27,30,35,42 in train()): all 8 n_layers BatchNorm1d layers
+ * of the stack in one launch.  running_mean / running_var (8 n_layers, 64) and num_batches_tracked (8 n_layers, int64): rows
+ * [0, 4 n_layers) the FiLM nets in (layer, branch, w|b) order with batch statistics film_mean / film_uvar (4 n_layers, 64),
+ * rows [4 n_layers, 8 n_layers) BN0, BN1 of (layer, branch) from the `stats` block of dpf_flow_train_forward. */
+int dpf_flow_train_update_running(int n_layers, double momentum, const float *film_mean, const float *film_uvar,
+                                  const float *stats, float *running_mean, float *running_var,
+                                  long long *num_batches_tracked, dpf_stream_t stream);
+
 /* ---- FiLM conditioner nets of the coupling stack, training mode (csrc/film_train.hip) ---------------------
  * Replaces, for model.train(), the K = 4 n_layers per-cloud conditioner sub-nets of CondRealNVPFlow3D
  * (lib/networks/flows.py:33-45, 68-80: Linear(G, 64, bias=False) . BatchNorm1d over the B clouds . Swish . Linear(64, 64))

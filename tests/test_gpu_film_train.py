@@ -81,3 +81,29 @@ def test_fused_film_nets_refuse_what_they_are_not_built_for():
     assert L_.dpf_film_train_forward(1, 65, 128, p, p, p, p, p, p, 1e-5, p, p, p, p, p, current_stream()) == -2      # DPF_ENOSUP
     assert L_.dpf_film_train_forward(1, 8, 126, p, p, p, p, p, p, 1e-5, p, p, p, p, p, current_stream()) == -2
     assert L_.dpf_film_train_forward(1, 1, 128, p, p, p, p, p, p, 1e-5, p, p, p, p, p, current_stream()) == -1       # DPF_EINVAL
+
+
+def test_fused_running_statistics_update_has_the_tensor_ops_bits():
+    """dpf_flow_train_update_running against `rm.mul_(1 - m); rm.add_(batch, alpha=m)` (FlatStore.update_running) bit for bit."""
+    L_, check, current_stream = _gpu()
+    L, m = 5, 0.1
+    st_floats = int(L_.dpf_flow_train_stats_floats())
+    gen = torch.Generator().manual_seed(5)
+    dev = "cuda"
+    film_mean, film_uvar = torch.randn(4 * L, F, generator=gen).to(dev), torch.rand(4 * L, F, generator=gen).to(dev)
+    stats = torch.randn(L, st_floats, generator=gen).to(dev)
+    rm0, rv0 = torch.randn(8 * L, F, generator=gen).to(dev), (0.5 + torch.rand(8 * L, F, generator=gen)).to(dev)
+    nbt0 = torch.arange(8 * L, dtype=torch.int64, device=dev)
+    # the tensor-op form
+    rm, rv, nbt = rm0.clone(), rv0.clone(), nbt0.clone()
+    sv = stats[:, :2 * 6 * F].view(L, 2, 6, F)
+    flow_mean, flow_uvar = sv[:, :, (0, 2)].reshape(4 * L, F), sv[:, :, (4, 5)].reshape(4 * L, F)
+    rm.mul_(1.0 - m); rv.mul_(1.0 - m)
+    rm[:4 * L].add_(film_mean, alpha=m); rm[4 * L:].add_(flow_mean, alpha=m)
+    rv[:4 * L].add_(film_uvar, alpha=m); rv[4 * L:].add_(flow_uvar, alpha=m)
+    nbt.add_(1)
+    # the kernel
+    rm2, rv2, nbt2 = rm0.clone(), rv0.clone(), nbt0.clone()
+    check(L_.dpf_flow_train_update_running(L, m, film_mean.data_ptr(), film_uvar.data_ptr(), stats.data_ptr(), rm2.data_ptr(),
+                                           rv2.data_ptr(), nbt2.data_ptr(), current_stream()), "update_running")
+    assert torch.equal(rm, rm2) and torch.equal(rv, rv2) and torch.equal(nbt, nbt2)
