@@ -655,3 +655,36 @@ def test_training_more_moment_rows_than_one_round_of_the_bn0_prologue():
     close_but_kinks(h["gp"], t["gp"], 2e-3, "grad_p", 2e-4)
     for k in t["stats"]:
         np.testing.assert_allclose(h["stats"][k].cpu().numpy(), t["stats"][k].cpu().numpy(), rtol=2e-4, atol=1e-5, err_msg=k)
+
+
+def test_steady_state_training_step_copies_nothing_from_the_host():
+    """r03: `sv[:, :, (0, 2)]` in the running-statistics update was ADVANCED indexing -- an index tensor built on the host and copied
+    to the device from pageable memory every step, which blocks the host until the stream has drained (0.6 ms per step, invisible
+    in every kernel trace).  A steady-state step of the flattened decoder must issue no host-to-device copy and no `aten::index`,
+    `aten::item` or `_local_scalar_dense` at all."""
+    nets = _gpu()
+    from torch.profiler import profile, ProfilerActivity
+    B, N, G = 8, 1024, 128
+    dec = nets.LocalCondRNVPDecoder(2, 64, G).cuda().train()
+    dec.flatten_parameters()
+    opt = nets.Adam(list(dec.parameters()), lr=1e-4, amsgrad=True)
+    tgt, _, g = FO.synthetic_inputs(3, B, N, G)
+    tp, tg = torch.from_numpy(tgt).cuda(), torch.from_numpy(g).cuda()
+    pm, pl = torch.zeros(B, 3, N).cuda(), torch.full((B, 3, N), -3.6).cuda()
+    nll = nets.PointFlowNLL()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        ps, mus, lvs = dec(tp, tg, mode="inverse")
+        nll(ps + [tp], [pm] + mus, [pl] + lvs).backward()
+        opt.step()
+    for _ in range(6):
+        step()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+    keys = {e.key: e.count for e in prof.key_averages()}
+    bad = {k: c for k, c in keys.items() if "HtoD" in k or "Host -> Device" in k or k in ("aten::index", "aten::item", "aten::_local_scalar_dense", "aten::nonzero")}
+    assert not bad, bad
