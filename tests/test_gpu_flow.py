@@ -327,3 +327,35 @@ def test_pointflow_nll_fused_reduction():
     out = nll(ps + [p], [pm] + mus, [plg] + lvs)
     out.backward()
     assert plg.grad is not None and abs(float(out.detach()) - float(want)) <= 1e-5 * abs(float(want))
+
+
+def test_steady_state_evaluation_step_copies_nothing_between_host_and_device():
+    """The evaluation hot path as a caller of the mirror uses it -- decoder forward (direct, eval-BN) + nn_distance + the CD
+    reduction, eager launches -- must not copy between host and device or read a scalar back once the weights are packed
+    (the range guard of the fp16 operands reads one scalar per WEIGHT VERSION, not per call)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from torch.profiler import profile, ProfilerActivity
+    from dpf_nets_amd import networks as nets
+    from dpf_nets_amd.metrics.StructuralLosses.nn_distance import nn_distance
+    B, N, G = 8, 1024, 128
+    dec = nets.LocalCondRNVPDecoder(2, 64, G).cuda().eval()
+    tgt, z, g = FO.synthetic_inputs(5, B, N, G)
+    tz, tg, tt = torch.from_numpy(z).cuda(), torch.from_numpy(g).cuda(), torch.from_numpy(np.ascontiguousarray(tgt.transpose(0, 2, 1))).cuda()
+
+    def step():
+        with torch.no_grad():
+            ps, mus, lvs = dec(tz, tg, mode="direct")
+            d1, d2 = nn_distance(ps[-1].transpose(1, 2).contiguous(), tt)
+            return (d1.mean(1) + d2.mean(1)).mean()
+    for _ in range(4):
+        step()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+    keys = {e.key: e.count for e in prof.key_averages()}
+    bad = {k: c for k, c in keys.items() if "HtoD" in k or "Host -> Device" in k or "DtoH" in k or
+           k in ("aten::index", "aten::item", "aten::_local_scalar_dense", "aten::nonzero")}
+    assert not bad, bad
