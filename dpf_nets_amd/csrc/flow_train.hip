@@ -33,8 +33,8 @@
 //
 // Activations are RECOMPUTED from the layer input in both backward passes (MFMA work is cheap);
 // nothing of size (B*N, 64) ever goes to HBM -- between the passes travel 4 + 2 floats per point.
-// The per-cloud FiLM conditioner nets (B x 64 tensors) stay on PyTorch-ROCm, batched over all
-// layers; they enter here as the tensor `fm` and leave as `dfm`.
+// The per-cloud FiLM conditioner nets (B x 64 tensors) are computed outside this file (csrc/film_train.hip: all 4 L of
+// them in one launch each way; batched tensor ops for B > 64); they enter here as the tensor `fm` and leave as `dfm`.
 //
 // Precision: the forward contraction h1 = W1 relu(h0) -- and its recomputation in the backward passes,
 // which decides every ReLU mask -- runs at the precision the caller asks for: bf16x3 (hi/lo split,

@@ -9,10 +9,11 @@ p, g and every parameter of the layers:
   forward   gather the conditioner parameters into the (L, 8968) block of the C ABI with one
             torch.cat (each parameter appears flattened exactly as stored, see dpf_hip.h);
             evaluate the 4L per-cloud FiLM nets (B x 64 tensors; batch-stat BatchNorm over the B
-            clouds) batched as two bmm's on PyTorch-ROCm -- they are O(B), not O(B*N);
+            clouds): one launch of dpf_film_train_forward (r03; B > 64: two bmm's and a dozen tensor ops);
             per layer dpf_flow_train_prepare_layer + dpf_flow_forward(n_layers=1);
-  backward  per layer dpf_flow_train_backward_layer in reverse order; the FiLM nets' backward as
-            batched tensor ops; one multi-tensor copy hands every parameter its gradient.
+  backward  per layer dpf_flow_train_backward_layer in reverse order; the FiLM nets' backward as one launch of
+            dpf_film_train_backward (adding into the flat store) or batched tensor ops; one multi-tensor copy hands
+            every parameter its gradient (per-parameter path).
 
 A model of n_flows=21 has 2016 parameter tensors on this path; letting autograd slice, stack and
 accumulate them one by one costs more host time than all the kernels together, which is why the
