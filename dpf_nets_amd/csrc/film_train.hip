@@ -87,13 +87,13 @@ __global__ __launch_bounds__(T) void film_train_fwd_kernel(FwdArgs a) {
         __syncthreads();
         for (int c = 0; c < gw; c += 4) {
             const f32x4 w = *(const f32x4 *)(ws + f * WP + c);
+            // (a cloud index past the batch is clamped, its sum never used: `if (b < B)` around the body became eight
+            // exec-masked blocks per step, each waiting for its own LDS read -- 16 of the launch's 25 us)
 #pragma unroll
             for (int bi = 0; bi < NB; ++bi) {
-                const int b = q + 4 * bi;
-                if (b < B) {
-                    const f32x4 x = *(const f32x4 *)(gs + (size_t)b * GT + c);          // same address in the whole wave: broadcast
-                    acc[bi] = __builtin_fmaf(w.w, x.w, __builtin_fmaf(w.z, x.z, __builtin_fmaf(w.y, x.y, __builtin_fmaf(w.x, x.x, acc[bi]))));
-                }
+                const int b = q + 4 * bi < B ? q + 4 * bi : B - 1;
+                const f32x4 x = *(const f32x4 *)(gs + (size_t)b * GT + c);              // same address in the whole wave: broadcast
+                acc[bi] = __builtin_fmaf(w.w, x.w, __builtin_fmaf(w.z, x.z, __builtin_fmaf(w.y, x.y, __builtin_fmaf(w.x, x.x, acc[bi]))));
             }
         }
     }
@@ -135,16 +135,14 @@ __global__ __launch_bounds__(T) void film_train_fwd_kernel(FwdArgs a) {
     const float b1 = a.b1[(size_t)k * F + f];
 #pragma unroll
     for (int bi = 0; bi < NB; ++bi) {
-        const int b = q + 4 * bi;
-        if (b < B) {
-            float o = b1;
+        const int b = q + 4 * bi, bc = b < B ? b : B - 1;
+        float o = b1;
 #pragma unroll
-            for (int i = 0; i < F / 4; ++i) {
-                const f32x4 x = *(const f32x4 *)(us + (size_t)b * F + 4 * i);
-                o = __builtin_fmaf(w1[i].w, x.w, __builtin_fmaf(w1[i].z, x.z, __builtin_fmaf(w1[i].y, x.y, __builtin_fmaf(w1[i].x, x.x, o))));
-            }
-            a.fm[((size_t)k * B + b) * F + f] = o;
+        for (int i = 0; i < F / 4; ++i) {
+            const f32x4 x = *(const f32x4 *)(us + (size_t)bc * F + 4 * i);
+            o = __builtin_fmaf(w1[i].w, x.w, __builtin_fmaf(w1[i].z, x.z, __builtin_fmaf(w1[i].y, x.y, __builtin_fmaf(w1[i].x, x.x, o))));
         }
+        if (b < B) a.fm[((size_t)k * B + b) * F + f] = o;
     }
 }
 
@@ -245,22 +243,19 @@ __global__ __launch_bounds__(T) void film_train_bwd_kernel(BwdArgs a) {
         float pg = 0.f, pb = 0.f, p1 = 0.f, p2 = 0.f;
 #pragma unroll
         for (int bi = 0; bi < NB; ++bi) {
-            const int b = q + 4 * bi;
-            float dxh = 0.f;
-            if (b < B) {
-                float ds = 0.f;
+            const int b = q + 4 * bi, bc = b < B ? b : B - 1;          // (clamped, branch-free: see the forward kernel)
+            float ds = 0.f;
 #pragma unroll
-                for (int i = 0; i < F / 4; ++i) {
-                    const f32x4 x = *(const f32x4 *)(d0 + (size_t)b * F + 4 * i);
-                    ds = __builtin_fmaf(x.w, w1c[4 * i + 3], __builtin_fmaf(x.z, w1c[4 * i + 2], __builtin_fmaf(x.y, w1c[4 * i + 1], __builtin_fmaf(x.x, w1c[4 * i], ds))));
-                }
-                const float dy = ds * (sg[bi] * (1.0f + yv[bi] * (1.0f - sg[bi])));
-                pg = __builtin_fmaf(dy, xh[bi], pg);
-                pb += dy;
-                dxh = dy * gam;
-                p1 += dxh;
-                p2 = __builtin_fmaf(dxh, xh[bi], p2);
+            for (int i = 0; i < F / 4; ++i) {
+                const f32x4 x = *(const f32x4 *)(d0 + (size_t)bc * F + 4 * i);
+                ds = __builtin_fmaf(x.w, w1c[4 * i + 3], __builtin_fmaf(x.z, w1c[4 * i + 2], __builtin_fmaf(x.y, w1c[4 * i + 1], __builtin_fmaf(x.x, w1c[4 * i], ds))));
             }
+            const float dy = b < B ? ds * (sg[bi] * (1.0f + yv[bi] * (1.0f - sg[bi]))) : 0.f;      // xh = y = sigmoid = 0 past the batch anyway
+            pg = __builtin_fmaf(dy, xh[bi], pg);
+            pb += dy;
+            const float dxh = dy * gam;
+            p1 += dxh;
+            p2 = __builtin_fmaf(dxh, xh[bi], p2);
             du[bi] = dxh;
         }
         const float tg = group_sum(pg, red, f, q);
@@ -317,16 +312,14 @@ __global__ __launch_bounds__(T) void film_train_bwd_kernel(BwdArgs a) {
             for (int r = 0; r < F; ++r) wc[r] = j < G ? a.W0[((size_t)k * F + r) * G + j] : 0.f;      // coalesced over j
 #pragma unroll
             for (int bi = 0; bi < NB; ++bi) {
-                const int b = q + 4 * bi;
-                if (b < B && j < G) {
-                    float s = 0.f;
+                const int b = q + 4 * bi, bc = b < B ? b : B - 1;
+                float s = 0.f;
 #pragma unroll
-                    for (int i = 0; i < F / 4; ++i) {
-                        const f32x4 x = *(const f32x4 *)(d0 + (size_t)b * F + 4 * i);
-                        s = __builtin_fmaf(x.w, wc[4 * i + 3], __builtin_fmaf(x.z, wc[4 * i + 2], __builtin_fmaf(x.y, wc[4 * i + 1], __builtin_fmaf(x.x, wc[4 * i], s))));
-                    }
-                    a.dg_part[((size_t)k * B + b) * G + j] = s;
+                for (int i = 0; i < F / 4; ++i) {
+                    const f32x4 x = *(const f32x4 *)(d0 + (size_t)bc * F + 4 * i);
+                    s = __builtin_fmaf(x.w, wc[4 * i + 3], __builtin_fmaf(x.z, wc[4 * i + 2], __builtin_fmaf(x.y, wc[4 * i + 1], __builtin_fmaf(x.x, wc[4 * i], s))));
                 }
+                if (b < B && j < G) a.dg_part[((size_t)k * B + b) * G + j] = s;
             }
         }
     }
