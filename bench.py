@@ -865,16 +865,20 @@ def train_step_leg(args, rank, world, dist, device, batch, layers, steps, warmup
         elapsed = float(t.item())
     ar_us = float(np.median([a.elapsed_time(b) for a, b in ev])) * 1e3
     nbytes = arena.nbytes()
+    gstats = (ctypes.c_long * 5)()
+    _lib_handle().dpf_train_graph_stats(gstats)          # of the timed region: read before the eager per-kernel pass below
     # ---- per-kernel durations of the decoder stack (outside the timed region): HIP events around every launch, eager
     kernels = None
     try:
         L_ = _lib_handle()
         ksteps = 3
-        L_.dpf_train_kernel_times(1, None, None)
-        for _ in range(ksteps):
-            step()
         us, calls = (ctypes.c_double * 8)(), (ctypes.c_long * 8)()
-        L_.dpf_train_kernel_times(0, us, calls)
+        L_.dpf_train_kernel_times(1, None, None)        # turns graph recording / replay off process-wide ...
+        try:
+            for _ in range(ksteps):
+                step()
+        finally:
+            L_.dpf_train_kernel_times(0, us, calls)     # ... and only this call restores it: also when a step raises
         P = batch * N
         # FLOPs a kernel executes per layer for P points (both branches): conditioner forward 2 x (2*F*|K| + 2*F*F) ~ 16 896 / pt
         # (|K| ~ 1.5 on average), output layer 2 x 2*|W|*F ~ 384, W1^T dh1 and dh1 h0^T 2 x 2*F*F = 16 384 each
@@ -900,8 +904,6 @@ def train_step_leg(args, rank, world, dist, device, batch, layers, steps, warmup
                            "tstats_x / tbwd3f are reductions (latency-bound, no matrix work)" % ksteps)
     except Exception as e:       # noqa: BLE001
         kernels = {"error": repr(e)}
-    gstats = (ctypes.c_long * 5)()
-    _lib_handle().dpf_train_graph_stats(gstats)
     info = {"ms_per_step": elapsed / steps * 1e3, "value": batch * world * N / (elapsed / steps) if same else None, "unit": "points/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "layers": layers, "clouds_per_gpu": batch, "points_per_cloud": N,
             "latent": G, "loss": float(loss.detach()), "precision": _train_precision(),

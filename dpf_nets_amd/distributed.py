@@ -153,18 +153,25 @@ class GradArena:
     def nbytes(self):
         return self.buf.numel() * 4
 
-    def sync(self):
+    def sync(self, keep_none=False):
         """Every gradient of the model is in `buf` afterwards (missing ones as zeros), every .grad a view of it again.
         Fresh gradients (autograd hands a parameter whose .grad is None its gradient tensor without a kernel) are moved into
-        the message with ONE multi-tensor copy."""
+        the message with ONE multi-tensor copy.  keep_none (what `allreduce()` passes in a single-process run): a parameter
+        that took no part in the backward keeps `.grad is None` -- its slice of the message is zeroed all the same -- so that
+        the optimizer skips it as the reference's does (`if p.grad is None: continue`, optimizers.py:40-41): no moment
+        decay, no weight decay, no step count.  With more than one rank such a parameter receives the other ranks' average
+        (zeros if nobody used it) and is stepped -- the DistributedDataParallel behaviour; that difference is inherent to
+        a fixed-layout message."""
         for st in self.stores:
             st.attach_grads()
-        src, dst, zero = [], [], []
+        src, dst, zero, none = [], [], [], set()
         for p, v in zip(self.others, self.views):
             if p.grad is v:
                 continue
             if p.grad is None:
                 zero.append(v)
+                if keep_none:
+                    none.add(id(p))
             else:
                 src.append(p.grad); dst.append(v)
         with torch.no_grad():
@@ -173,7 +180,8 @@ class GradArena:
             if dst:
                 torch._foreach_copy_(dst, src)
         for p, v in zip(self.others, self.views):
-            p.grad = v
+            if id(p) not in none:
+                p.grad = v
 
     def zero_grad(self):
         """One fill for the stores (their gradient views stay attached; they count as "no gradient yet"); the other
@@ -190,7 +198,7 @@ class GradArena:
     def allreduce(self, average=True):
         """THE collective of the step.  Returns the number of elements reduced (0 in a single-process run)."""
         rank, w = world()
-        self.sync()
+        self.sync(keep_none=(w == 1))
         if w == 1:
             return 0
         for st in self.stores:

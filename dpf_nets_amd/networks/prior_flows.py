@@ -312,6 +312,8 @@ class PriorFlatStore:
             t.data = pv
             t.grad = gv
             t._dpf_flat = self
+        from .train_engine import hook_grad_written
+        hook_grad_written(params)
         self.token = torch.zeros(1, dtype=torch.float32, device=dev, requires_grad=True)
 
     def attached(self):

@@ -108,6 +108,13 @@ class StackSpec:
         step, so a lag of a few steps is immaterial next to a limit of 2048.  Returns the precision to use NOW."""
         if not self.f16_ok:
             return "bf16x6"
+        if torch.cuda.is_current_stream_capturing():
+            # the caller is capturing this step into a torch.cuda.graph: an event query is illegal during capture, an event
+            # recorded inside it cannot be queried by a later eager call, and a replay re-runs none of this host code -- the
+            # precision chosen now is frozen into the graph.  Neither record nor query; a bound that was requested before
+            # the capture began stays pending for the next eager call.  (Under whole-step capture run one eager step every
+            # few hundred replays so that the range guard still sees the weights: INTEGRATION.md.)
+            return "f16x3"
         pend = self._f16_pending
         if pend is not None and pend[1].query():
             bound = float(pend[0][0])
@@ -397,6 +404,25 @@ class _FlowStackTrain(torch.autograd.Function):
         return (chain if ctx.needs_input_grad[0] else None, dg, None, None, None, *grads)
 
 
+def _mark_grad_written(p):
+    st = getattr(p, "_dpf_flat", None)
+    if st is not None:
+        st.grad_written = True
+
+
+def hook_grad_written(params):
+    """`grad_written` is a HINT that the store's own writers keep up to date (accumulate, attach_grads, the exchanges);
+    gradients that reach flat_g by ordinary autograd -- AccumulateGrad adding in place into the attached views: the
+    tensor-op path of a flattened decoder (DPF_TRAIN_IMPL=torch, forward_torch), an eval-mode decoder under autograd,
+    forward(n_layers=...), a single flow module's own forward -- set it through a post-accumulate hook on every parameter
+    (registered once per Parameter object; the store is looked up at call time, so a rebuilt store is found).  The hooks
+    never fire on the flat path, whose node writes flat_g itself."""
+    for t in params:
+        if not getattr(t, "_dpf_gw_hook", False):
+            t.register_post_accumulate_grad_hook(_mark_grad_written)
+            t._dpf_gw_hook = True
+
+
 class FlatStore:
     """ONE fp32 buffer that owns the storage of every parameter of the stack, laid out as the kernels and the batched
     FiLM ops consume it -- [conditioner block (L, 2*T_BR) | W0 (K,F,G) | gamma (K,F) | beta (K,F) | W1 (K,F,F) | b1 (K,F)] --
@@ -445,6 +471,7 @@ class FlatStore:
             t.data = pv
             t.grad = gv
             t._dpf_flat = self              # networks.optimizers.Adam updates a whole store at once
+        hook_grad_written(self.params)
         # BatchNorm running statistics: [FiLM nets (4L) | conditioner stacks (4L)]
         self.bns = [m[1] for m in spec.film_modules()] + spec.flow_bns()
         nb = len(self.bns)

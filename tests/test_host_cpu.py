@@ -364,6 +364,56 @@ def test_mirror_adam_skips_a_flat_store_without_a_gradient_like_grad_none():
     assert id(fs2) in opt._flat                                          # the fast path was taken for the new store
 
 
+def test_mirror_adam_steps_a_flat_store_whose_gradients_came_by_ordinary_autograd():
+    """`grad_written` is a hint.  Gradients that reach flat_g through AccumulateGrad -- the tensor-op
+    path of a flattened decoder (forward_torch / DPF_TRAIN_IMPL=torch), a single flow module's own forward -- must make
+    the next step() update the store: zero_grad (views stay attached, flag cleared), backward, step -> the parameters moved,
+    the step counters advanced.  Both stores (point decoder, latent prior flow)."""
+    import torch
+    from dpf_nets_amd import networks as nets
+    from dpf_nets_amd.networks.train_engine import StackSpec
+    torch.manual_seed(8)
+    dec = nets.LocalCondRNVPDecoder(1, 64, 16)
+    fs = StackSpec(dec.coupling_layers()).flatten(torch.device("cpu"))
+    opt = nets.Adam(dec.parameters(), lr=1e-2, betas=(0.9, 0.99), amsgrad=True)
+    p, g = torch.randn(3, 3, 20), torch.randn(3, 16)
+    for it in range(2):
+        opt.zero_grad()
+        assert not fs.grad_written and dec.flows[0].nvp1.T_mu_0[3].weight.grad is fs.gviews[dec_index(fs, dec.flows[0].nvp1.T_mu_0[3].weight)]
+        before = fs.flat_p.clone()
+        ps, mus, lvs = dec.forward_torch(p, g, mode="inverse")           # tensor ops: autograd accumulates into the views
+        (ps[0].square().mean() + sum(lvs).mean()).backward()
+        assert fs.grad_written and float(fs.flat_g.abs().sum()) > 0
+        opt.step()
+        assert not torch.equal(fs.flat_p, before)
+        assert opt.state[dec.flows[0].nvp1.T_mu_0[3].weight]["step"] == it + 1
+    # one flow module alone (only ITS parameters receive gradients): the store still steps
+    opt.zero_grad()
+    before = fs.flat_p.clone()
+    out = dec.flows[0].nvp2.forward_torch(p, g, mode="direct") if hasattr(dec.flows[0].nvp2, "forward_torch") else dec.flows[0].nvp2(p, g, mode="direct")
+    out[0].square().mean().backward()
+    assert fs.grad_written
+    opt.step()
+    assert not torch.equal(fs.flat_p, before)
+    # the latent prior flow's store
+    prior = nets.GlobalRNVPDecoder(2, 8, 6, weight_std=0.1)
+    store = prior.flatten_parameters()
+    o2 = nets.Adam(prior.parameters(), lr=1e-2, amsgrad=True)
+    gl = torch.randn(5, 6)
+    o2.zero_grad()
+    assert not store.grad_written
+    before = store.flat_p.clone()
+    gs, mus, lvs = prior(gl, mode="inverse")                             # CPU tensors: tensor-op path
+    (gs[0].square().mean() + sum(lvs).mean()).backward()
+    assert store.grad_written
+    o2.step()
+    assert not torch.equal(store.flat_p, before)
+
+
+def dec_index(fs, param):
+    return next(i for i, q in enumerate(fs.params) if q is param)
+
+
 def test_prior_flat_store_aliases_parameters_and_takes_the_flat_adam_path():
     """GlobalRNVPDecoder.flatten_parameters() on CPU tensors (no kernels involved): names, shapes and values unchanged,
     .data / .grad are views of the two flat buffers in the parameters-only canonical layout of include/dpf_hip.h, gradients
