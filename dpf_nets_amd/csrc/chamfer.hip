@@ -22,8 +22,10 @@
 //  d = (dx*dx + dy*dy) + dz*dz, dx = candidate - query, every operation rounded
 //  separately: this file is compiled with -ffp-contract=off.
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 
 #include "dpf_hip.h"
+#include "nn_refscan.h"
 
 #pragma clang fp contract(off)
 
@@ -120,6 +122,23 @@ __global__ __launch_bounds__(NWAVES * 64) void nn_kernel(NNArgs args) {
     f2 best = {INF, INF};
     int bc0 = kbeg, bc1 = kbeg;
     int k = kbeg;
+    // Non-finite candidates (NaN / Inf) never show in a running minimum, but the reference's result depends on them
+    // (nn_refscan.h).  One vector load per loop iteration re-reads the slice's floats 64 at a time -- the scan itself uses
+    // scalar loads -- and keeps the largest (bits << 1): an all-ones exponent is a value >= 0xFF000000.  ~3 of the ~160
+    // instructions of an iteration; the value loaded in one iteration is consumed in the next.
+    const float *__restrict__ cs = c + (size_t)kbeg * 3;
+    const int nfl = (kend - kbeg) * 3, nrow = (nfl + 63) >> 6;
+    uint32_t cexp = 0;
+    float pend = 0.f;
+    int row = 0;
+#define DPF_NF_STEP()                                                            \
+    {                                                                            \
+        cexp = max(cexp, __builtin_bit_cast(uint32_t, pend) << 1);               \
+        const int fi_ = row * 64 + lane;                                         \
+        const float v_ = cs[min(fi_, nfl - 1)];                                  \
+        pend = v_;                                                               \
+        ++row;                                                                   \
+    }
     const int nfull = (kend - kbeg) / CH;          // whole chunks in this slice
     if (nfull > 0) {
         // Software-pipelined scalar loads, ping-pong between two SGPR sets so
@@ -144,6 +163,7 @@ __global__ __launch_bounds__(NWAVES * 64) void nn_kernel(NNArgs args) {
         DPF_LOAD_CHUNK(bufA, k);
         int it = 0;
         for (; it + 2 <= nfull; it += 2, k += 2 * CH) {
+            DPF_NF_STEP()
             {
                 DPF_EVAL_HEAD(bufA);
                 __builtin_amdgcn_sched_barrier(0);
@@ -181,6 +201,13 @@ __global__ __launch_bounds__(NWAVES * 64) void nn_kernel(NNArgs args) {
         if (dm.y < best.y) { best.y = dm.y; bc1 = k; }
     }
 
+    if (nfl > 0) {                              // the rows the main loop did not reach, and the last pending value
+        while (row < nrow) DPF_NF_STEP()
+        cexp = max(cexp, __builtin_bit_cast(uint32_t, pend) << 1);
+    }
+#undef DPF_NF_STEP
+    const bool cbad = __any(cexp >= 0xFF000000u);   // wave-uniform: this wave's candidate slice holds a NaN / Inf
+
     // recover the FIRST index inside the winning chunk (descending scan, last hit wins)
     int i0 = bc0, i1 = bc1;
 #pragma unroll
@@ -192,11 +219,14 @@ __global__ __launch_bounds__(NWAVES * 64) void nn_kernel(NNArgs args) {
         if (d1 == best.y && bc1 + u < kend) i1 = bc1 + u;
     }
 
+    bool anybad = cbad;
     if constexpr (KS > 1) {
         __shared__ float sd[NWAVES][QPW];
         __shared__ int si[NWAVES][QPW];
+        __shared__ int sbad[NWAVES];
         sd[wave][lane] = best.x; sd[wave][lane + 64] = best.y;
         si[wave][lane] = i0;     si[wave][lane + 64] = i1;
+        if (lane == 0) sbad[wave] = cbad ? 1 : 0;
         __syncthreads();
         if (ks != 0) return;
 #pragma unroll
@@ -204,8 +234,13 @@ __global__ __launch_bounds__(NWAVES * 64) void nn_kernel(NNArgs args) {
             const float e0 = sd[wave + s][lane], e1 = sd[wave + s][lane + 64];
             if (e0 < best.x) { best.x = e0; i0 = si[wave + s][lane]; }
             if (e1 < best.y) { best.y = e1; i1 = si[wave + s][lane + 64]; }
+            anybad = anybad || sbad[wave + s] != 0;
         }
     }
+    // non-finite input: a NaN / Inf among the candidates (wave-uniform), or a query whose minimum never left +inf (its own
+    // coordinates are NaN / Inf, or every distance overflowed): those queries get the reference's own scan (nn_refscan.h)
+    if (anybad || nn_not_finite(best.x)) { float r; nn_reference_scan(c, nc, qx.x, qy.x, qz.x, r, i0); best.x = r; }
+    if (anybad || nn_not_finite(best.y)) { float r; nn_reference_scan(c, nc, qx.y, qy.y, qz.y, r, i1); best.y = r; }
     if (j0 < nq) { A.dist[(size_t)bi * nq + j0] = best.x; A.idx[(size_t)bi * nq + j0] = i0; }
     if (j1 < nq) { A.dist[(size_t)bi * nq + j1] = best.y; A.idx[(size_t)bi * nq + j1] = i1; }
 }

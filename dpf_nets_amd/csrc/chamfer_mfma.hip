@@ -33,6 +33,7 @@
 #include "dpf_hip.h"
 #include "lds_attr.h"
 #include "zero_fill.h"
+#include "nn_refscan.h"
 
 #pragma clang fp contract(off)
 
@@ -242,14 +243,21 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
     // R2 >= |c - mu|^2 of every candidate and |q - mu|^2 of this workgroup's queries (the surrogate's error bound is
     // per pair): the queries now, the candidates while their fragments are built (the first pass covers them all
     // when nc <= 2048; otherwise a pre-scan)
+    // Non-finite input (NaN / Inf coordinates, or norms that overflow) poisons R2 with +inf -- fmaxf alone would drop a NaN --
+    // and the whole workgroup then takes the reference's own scan (nn_refscan.h) instead of the filter, whose bounds mean
+    // nothing there: the result is the reference's for ANY input.
+    const float INF_ = __builtin_inff();
     float r2 = j < nq ? (qcx * qcx + qcy * qcy) + qcz * qcz : 0.f;
+    r2 = nn_not_finite(r2) ? INF_ : r2;
     if (nct > CT)
         for (int p = tid; p < nc; p += QW * 64) {
             const float *src = cpts + (size_t)p * 3;
             const float x = src[0] - mux, y = src[1] - muy, z = src[2] - muz;
-            r2 = fmaxf(r2, (x * x + y * y) + z * z);
+            const float cn = (x * x + y * y) + z * z;
+            r2 = nn_not_finite(cn) ? INF_ : fmaxf(r2, cn);
         }
     float tau = 0.f;
+    bool slow = false;
 
     unsigned short *myq = qtile + (size_t)wave * QCAP * 64;
     float *mym = qmin + (size_t)wave * QCAP * 64;
@@ -276,7 +284,10 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
                 sfrag[t * 64 + 32 + i] = f1;
                 // original coordinates for the exact evaluation; padding far away (its distance is +inf)
                 spts[t * 32 + i] = live ? make_float4(x, y, z, 0.f) : make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
-                if (pass == 0) r2 = fmaxf(r2, (cx * cx + cy * cy) + cz * cz);
+                if (pass == 0) {
+                    const float cn = (cx * cx + cy * cy) + cz * cz;
+                    r2 = nn_not_finite(cn) ? INF_ : fmaxf(r2, cn);
+                }
             }
         }
         if (pass == 0) {
@@ -289,6 +300,7 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
 #pragma unroll
             for (int w = 1; w < QW; ++w) m = fmaxf(m, s_r2[w]);
             tau = m * 2.44140625e-4f;                                         // 2^-12 * R2
+            if (nn_not_finite(m)) { slow = true; break; }                     // workgroup-uniform: m comes from LDS
         }
         if (wave_live) {
             // hit = smin + tau and low = smin - tau are kept up to date where smin changes -- inside the hit path (a new
@@ -345,6 +357,8 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
             qcount = 0;                                                       // the queue is per pass; smin carries over
         }
     }
+    if (slow && wave_live)          // both lane halves scan for their query: the merge below then finds them equal
+        nn_reference_scan(cpts, nc, qx, qy, qz, best, bidx);
     if (!wave_live && !sums) return;
     // merge the two lane halves of each query
     const float od = __shfl_xor(best, 32);

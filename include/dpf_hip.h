@@ -37,7 +37,16 @@ typedef void *dpf_stream_t; /* hipStream_t */
 /* replaces nndistance(...)      src/nndistance.cuh:1, nndistance.cu:125-128.
  * result[b,j]  = min_k |xyz[b,j]-xyz2[b,k]|^2, result_i = its FIRST argmin;
  * result2/_i the same with the clouds swapped.  Bit-exact contract:
- * d = (dx*dx + dy*dy) + dz*dz, dx = xyz2 - xyz, no FMA contraction. */
+ * d = (dx*dx + dy*dy) + dz*dz, dx = xyz2 - xyz, no FMA contraction.
+ * Non-finite input (NaN / Inf coordinates, or coordinates whose squared
+ * distances overflow): the result of the reference's own loop,
+ * nndistance.cu:5-122 -- candidates in batches of 512, the first of a batch
+ * taken unconditionally, strict '<' inside a batch (:26, 116), strict '>'
+ * across batches (:120) -- so a NaN distance at candidate 0 gives (NaN, 0), at
+ * candidate 512k it makes batch k lose, elsewhere it is skipped.  Every
+ * implementation below (scan, matrix-core filter, strided, _cd, pairwise)
+ * detects such input and runs that loop for the affected queries
+ * (csrc/nn_refscan.h); NaN payloads are not specified. */
 int dpf_nndistance(int b, int n, const float *xyz, int m, const float *xyz2,
                    float *result, int *result_i, float *result2, int *result2_i,
                    dpf_stream_t stream);

@@ -136,3 +136,123 @@ def vae_loss(out, pnll_fn, cfg=CONFIG):
     gent = 0.5 * torch.add(plv.shape[1] * (1.0 + math.log(2.0 * math.pi)), plv.sum(1).mean())   # GaussianEntropy :29-34
     loss = cfg["pnll_weight"] * pnll + cfg["gnll_weight"] * gnll - cfg["gent_weight"] * gent
     return loss, pnll, gnll, gent
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Single-view reconstruction model: Local_Cond_RNVP_MC_Global_RNVP_VAE_IC (lib/networks/models.py:261-464).
+# The ResNet image encoder (models.py:287, resnet.py) is OUT of the hot path and stays the reference's own PyTorch code:
+# the fixtures carry its output `img_features` (B, G), computed by the reference in the build container, and everything
+# downstream of it -- g0_prior, the latent prior flow, p_prior, the point decoder, Chamfer and f_score -- is what the tests
+# reproduce.
+#   ... .forward, mode == 'predicting'                   lib/networks/models.py:417-462   (predicting_forward)
+#   ... .forward, mode == 'training'                     lib/networks/models.py:326-371   (svr_training_forward)
+#   evaluate(), predicting branch                        lib/networks/evaluating.py:198-205, utils.py:38-42
+# ---------------------------------------------------------------------------------------------------------------------
+# configs/svr/all.yaml:62-88 at reduced width (same structure: one hidden layer in every FeatureEncoder, 'freevar' base)
+SVR_CONFIG_SMALL = dict(util_mode="predicting", deterministic=False, pc_enc_init_n_channels=3, pc_enc_init_n_features=64,
+                        pc_enc_n_features=[128, 256, 512], g_latent_space_size=64, g_prior_n_layers=1, g_prior_n_flows=2,
+                        g_prior_n_features=32, g_posterior_n_layers=1, p_latent_space_size=3, p_prior_n_layers=1,
+                        p_decoder_n_flows=2, p_decoder_n_features=64, p_decoder_base_type="freevar", p_decoder_base_var=0.0,
+                        pnll_weight=1.0, gnll_weight=1.0, gent_weight=1.0)
+# configs/svr/all.yaml:62-88 as shipped (G = 512, 7 prior flows of 128 features, 21 decoder triples = 63 coupling layers)
+SVR_CONFIG = dict(SVR_CONFIG_SMALL, g_latent_space_size=512, g_prior_n_flows=7, g_prior_n_features=128, p_decoder_n_flows=21)
+SVR_BATCH, SVR_CLOUD = 50, 2500               # configs/svr/all.yaml:10, :6
+
+
+def _feature_encoder_state(seed, name, n_layers, C, L, deterministic, mu_std, lv_std):
+    """FeatureEncoder (encoders.py:31-83) with the reference's sub-module names; BatchNorm running statistics non-trivial."""
+    st = {}
+    for i in range(n_layers):
+        p = "%s.features.mlp%d" % (name, i)
+        st[p + ".weight"] = detrng.normal_f32(detrng.key(seed, p + ".w"), (C, C), 0.0, 1.0 / np.sqrt(C))
+        st[p + "_bn.weight"] = detrng.uniform_f32(detrng.key(seed, p + ".g"), (C,), 0.7, 1.3)
+        st[p + "_bn.bias"] = detrng.normal_f32(detrng.key(seed, p + ".b"), (C,), 0.0, 0.1)
+        st[p + "_bn.running_mean"] = detrng.normal_f32(detrng.key(seed, p + ".rm"), (C,), 0.0, 0.1)
+        st[p + "_bn.running_var"] = detrng.uniform_f32(detrng.key(seed, p + ".rv"), (C,), 0.5, 1.5)
+        st[p + "_bn.num_batches_tracked"] = np.array(3, np.int64)
+    st[name + ".mus.mu_mlp0.weight"] = detrng.normal_f32(detrng.key(seed, name + ".mu.w"), (L, C), 0.0, mu_std)
+    st[name + ".mus.mu_mlp0.bias"] = detrng.normal_f32(detrng.key(seed, name + ".mu.b"), (L,), 0.0, mu_std)
+    if not deterministic:
+        st[name + ".logvars.logvar_mlp0.weight"] = detrng.normal_f32(detrng.key(seed, name + ".lv.w"), (L, C), 0.0, lv_std)
+        st[name + ".logvars.logvar_mlp0.bias"] = detrng.normal_f32(detrng.key(seed, name + ".lv.b"), (L,), 0.0, lv_std)
+    return st
+
+
+def make_svr_state(seed, cfg=SVR_CONFIG_SMALL):
+    """numpy state dict of the IC model WITHOUT its ResNet (models.py:287-320): reference parameter / buffer names."""
+    G, C = cfg["g_latent_space_size"], cfg["pc_enc_n_features"][-1]
+    assert cfg["p_decoder_base_type"] == "freevar"
+    st = {}
+    for k, v in EO.make_encoder_state(seed + 1, cfg["pc_enc_init_n_channels"], cfg["pc_enc_init_n_features"],
+                                      tuple(cfg["pc_enc_n_features"])).items():
+        st["pc_encoder." + k] = v
+    for k, v in GO.make_gprior_state(seed + 2, cfg["g_prior_n_flows"], cfg["g_prior_n_features"], G).items():
+        st["g_prior." + k] = v
+    for k, v in FO.make_decoder_state(seed + 3, cfg["p_decoder_n_flows"], cfg["p_decoder_n_features"], G).items():
+        st["pc_decoder." + k] = v
+    st.update(_feature_encoder_state(seed + 4, "g0_prior", cfg["g_prior_n_layers"], G, G, False, 0.05, 0.03))
+    st.update(_feature_encoder_state(seed + 5, "g_posterior", cfg["g_posterior_n_layers"], C, G, False, 0.05, 0.03))
+    st.update(_feature_encoder_state(seed + 6, "p_prior", cfg["p_prior_n_layers"], G, cfg["p_latent_space_size"], True, 0.05, 0.0))
+    st["p_prior_mus"] = np.zeros((1, cfg["p_latent_space_size"], 1), np.float32)
+    return st
+
+
+def svr_inputs(seed, B, N, G, S=None):
+    """clouds (B,3,N) for the encoder / the training decoder, base noise eps (B,3,S) for the sampled cloud, the noise of
+    the latent reparameterisation eps_g (B,G).  Images are made by oracle/check_dropin.py (they only feed the ResNet)."""
+    S = N if S is None else S
+    x = detrng.normal_f32(detrng.key(seed, "cloud"), (B, 3, N), 0.0, 0.25)
+    eps = detrng.normal_f32(detrng.key(seed, "eps"), (B, 3, S), 0.0, 1.0)
+    eps_g = detrng.normal_f32(detrng.key(seed, "eps_g"), (B, G), 0.0, 1.0)
+    return x, eps, eps_g
+
+
+def feature_encoder(st, name, x, n_layers, deterministic, training=False, stats_out=None):
+    """FeatureEncoder.forward (encoders.py:75-83) on state tensors: n_layers x [Linear . BatchNorm1d . Swish], heads."""
+    f = x
+    for i in range(n_layers):
+        p = "%s.features.mlp%d" % (name, i)
+        f = torch.nn.functional.linear(f, st[p + ".weight"])
+        if training:
+            var, mean = torch.var_mean(f, dim=0, unbiased=False)
+            if stats_out is not None:
+                stats_out[p + "_bn"] = (mean.detach(), var.detach() * (f.shape[0] / (f.shape[0] - 1.0)))
+        else:
+            mean, var = st[p + "_bn.running_mean"], st[p + "_bn.running_var"]
+        f = (f - mean) / torch.sqrt(var + 1e-5) * st[p + "_bn.weight"] + st[p + "_bn.bias"]
+        f = f * torch.sigmoid(f)                                                              # Swish, layers.py:9-10
+    mu = torch.nn.functional.linear(f, st[name + ".mus.mu_mlp0.weight"], st[name + ".mus.mu_mlp0.bias"])
+    if deterministic:
+        return mu
+    return mu, torch.nn.functional.linear(f, st[name + ".logvars.logvar_mlp0.weight"], st[name + ".logvars.logvar_mlp0.bias"])
+
+
+def predicting_forward(blocks, img_features, eps, cfg=SVR_CONFIG_SMALL):
+    """models.py:417-462 ('freevar' base) over `blocks` = dict(g0_prior=f(x)->(mu, logvar), g_prior=f(g, mode)->3 lists,
+    p_prior=f(g)->(B,3), pc_decoder=f(p, g, mode)->3 lists) and `p_prior_mus` (1,3,1); img_features (B,G) is the ResNet's
+    output (models.py:418); eps (B,3,S) replaces torch.randn_like of reparameterize (:76-79 / :456)."""
+    out = {}
+    B, S = eps.shape[0], eps.shape[2]
+    mu0, lv0 = blocks["g0_prior"](img_features)                                              # :420
+    out["g_prior_mus"], out["g_prior_logvars"] = [mu0], [lv0]
+    out["g_prior_samples"] = [mu0]                                                           # :422
+    buf_g = blocks["g_prior"](mu0, "direct")                                                 # :423
+    out["g_prior_samples"] += list(buf_g[0])
+    out["g_prior_mus"] += list(buf_g[1])
+    out["g_prior_logvars"] += list(buf_g[2])
+    g = out["g_prior_samples"][-1]
+    out["p_prior_mus"] = [blocks["p_prior_mus"].expand(B, 3, S)]                             # :438-441 ('freevar')
+    out["p_prior_logvars"] = [blocks["p_prior"](g).unsqueeze(2).expand(B, 3, S)]             # :442-444
+    z = eps * torch.exp(0.5 * out["p_prior_logvars"][0]) + out["p_prior_mus"][0]             # :456
+    out["p_prior_samples"] = [z]
+    buf_p = blocks["pc_decoder"](z.contiguous(), g, "direct")                                # :458
+    out["p_prior_samples"] += list(buf_p[0])
+    out["p_prior_mus"] += list(buf_p[1])
+    out["p_prior_logvars"] += list(buf_p[2])
+    return out
+
+
+def svr_target(seed, B, S, std):
+    """Ground-truth clouds of the predicting-mode evaluation fixture: N(0, std) points, (B,3,S) -- independent of the model, at
+    the density where nearest-neighbour distances straddle f_score's 0.001 threshold (utils.py:38)."""
+    return detrng.normal_f32(detrng.key(seed, "target"), (B, 3, S), 0.0, std)

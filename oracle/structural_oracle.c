@@ -14,7 +14,9 @@
  *                     returns indices; this file IS the index oracle
  *                     (SURVEY.md section 8c): fp32, d=(dx*dx+dy*dy)+dz*dz with
  *                     dx = x2 - x1, no FMA contraction, k ascending, strict '<'
- *                     => lowest index among ties (nndistance.cu:22-26,116).
+ *                     => lowest index among ties (nndistance.cu:22-26,116),
+ *                     in the reference's batches of 512 candidates (:2-10,
+ *                     120), which decides what non-finite input produces.
  *   approx-EMD:       PARITY UNPINNED -- the reference has no CPU
  *                     implementation, test or golden vector for it, and its
  *                     kernels use __expf; this restatement follows
@@ -27,7 +29,20 @@
 #include <stdlib.h>
 #include <string.h>
 
-/* ---- Chamfer: nndistance.cu:2-128 -------------------------------------- */
+/* ---- Chamfer: nndistance.cu:2-128 --------------------------------------
+ * The reference walks the candidates in batches of 512 staged through shared
+ * memory (:2-3, 5-10): inside a batch the first candidate is taken
+ * unconditionally and every later one under a strict '<' (:26, 35, 44, 53,
+ * 116: "k==0 || d<best" where k is the index INSIDE the batch); across batches
+ * the running result is replaced under a strict '>' (:120: "k2==0 ||
+ * result>best").  For finite distances that is "the first global minimum" and
+ * the batch structure is invisible.  For non-finite input it is not: every
+ * comparison with a NaN is false, so a NaN distance at the first candidate of
+ * batch 0 latches (NaN, 0); at the first candidate of a later batch it makes
+ * that whole batch lose; anywhere else the candidate is skipped.  The
+ * restatement keeps the batch structure so that it is the oracle for any
+ * input. */
+#define NN_BATCH 512
 static void nn_one_direction(int b, int n, const float *xyz, int m, const float *xyz2,
                              float *result, int *result_i) {
     for (int i = 0; i < b; i++) {
@@ -35,21 +50,30 @@ static void nn_one_direction(int b, int n, const float *xyz, int m, const float 
         const float *c = xyz2 + (size_t)i * m * 3;
         for (int j = 0; j < n; j++) {
             const float x1 = q[j * 3 + 0], y1 = q[j * 3 + 1], z1 = q[j * 3 + 2];
-            float best = 0.0f;
-            int best_i = 0;
-            for (int k = 0; k < m; k++) {
-                const float x2 = c[k * 3 + 0] - x1;          /* nndistance.cu:22-24 */
-                const float y2 = c[k * 3 + 1] - y1;
-                const float z2 = c[k * 3 + 2] - z1;
-                const float xx = x2 * x2, yy = y2 * y2, zz = z2 * z2;
-                const float d = (xx + yy) + zz;              /* :25, no contraction */
-                if (k == 0 || d < best) {                    /* :26 and :116: first minimum wins */
-                    best = d;
-                    best_i = k;
+            float res = 0.0f;
+            int res_i = 0;
+            for (int k2 = 0; k2 < m; k2 += NN_BATCH) {       /* :5 */
+                const int end_k = (m < k2 + NN_BATCH ? m : k2 + NN_BATCH) - k2;   /* :6 */
+                float best = 0.0f;                           /* :16-17 */
+                int best_i = 0;
+                for (int k = 0; k < end_k; k++) {
+                    const float x2 = c[(k2 + k) * 3 + 0] - x1;   /* nndistance.cu:22-24 */
+                    const float y2 = c[(k2 + k) * 3 + 1] - y1;
+                    const float z2 = c[(k2 + k) * 3 + 2] - z1;
+                    const float xx = x2 * x2, yy = y2 * y2, zz = z2 * z2;
+                    const float d = (xx + yy) + zz;          /* :25, no contraction */
+                    if (k == 0 || d < best) {                /* :26 and :116: first minimum of the batch wins */
+                        best = d;
+                        best_i = k + k2;
+                    }
+                }
+                if (k2 == 0 || res > best) {                 /* :120 */
+                    res = best;
+                    res_i = best_i;
                 }
             }
-            result[(size_t)i * n + j] = best;
-            result_i[(size_t)i * n + j] = best_i;
+            result[(size_t)i * n + j] = res;
+            result_i[(size_t)i * n + j] = res_i;
         }
     }
 }

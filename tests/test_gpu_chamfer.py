@@ -87,6 +87,85 @@ def test_pruned_search_adversarial_distributions(kind, impl):
     _assert_bit_exact(_run(BK, a, b, impl), S.nndistance(a, b), kind)
 
 
+def _assert_same_with_nans(got, ref, tag):
+    """bit-exact where the reference value is a number; NaN where it is NaN (the payload / sign of a NaN differs between
+    x86 and gfx950 arithmetic, its position does not)"""
+    for g, r, name in zip(got, ref, ("dist1", "idx1", "dist2", "idx2")):
+        assert g.dtype == r.dtype and g.shape == r.shape, (tag, name)
+        if g.dtype == np.float32:
+            rn = np.isnan(r)
+            assert np.array_equal(np.isnan(g), rn), (tag, name, int((np.isnan(g) != rn).sum()))
+            assert np.array_equal(g.view(np.uint32)[~rn], r.view(np.uint32)[~rn]), (tag, name, int((g[~rn] != r[~rn]).sum()))
+        else:
+            assert np.array_equal(g, r), (tag, name, int((g != r).sum()), np.argwhere(g != r)[:4].tolist())
+
+
+NONFINITE_SHAPES = [(8, 700, 1100), (12, 2048, 2048), (8, 2500, 4100), (9, 100, 37)]
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("shape", NONFINITE_SHAPES)
+def test_nonfinite_input_gives_the_reference_result(shape, impl):
+    """NaN / Inf coordinates.  The reference's scan (nndistance.cu:5-122) takes the first candidate of every
+    batch of 512 unconditionally and compares with strict '<' / '>', so a NaN at candidate 0 latches (NaN, 0), at candidate
+    512 k it makes batch k lose, elsewhere it is skipped; an Inf coordinate gives d = inf or NaN.  The oracle restates that
+    loop; every implementation must return the same (values bit for bit where they are numbers, NaN where NaN, indices
+    exactly) -- one scenario per cloud of the batch, the other clouds of the same launch staying finite."""
+    BK = _gpu()
+    B, n, m = shape
+    a, b = chamfer_inputs(4000 + n + m, B, n, m)
+    nan, inf = np.float32(np.nan), np.float32(np.inf)
+    def at(k, size):
+        return min(k, size - 1)
+    b[0, 0, 1] = nan                                   # candidate 0 of direction 0 (= query 0 of direction 1)
+    b[1, at(5, m), 0] = nan                            # mid-batch candidate
+    b[2, at(512, m), 2] = nan                          # first candidate of batch 1
+    b[2, at(513, m), 0] = nan
+    a[3, at(512, n), 0] = nan; a[3, at(1024, n), 1] = nan; a[3, n - 1, 2] = nan
+    a[4, at(7, n), 0] = inf; b[4, at(9, m), 1] = -inf  # infinities on both sides
+    b[5, 0, 0] = inf                                   # d = inf at candidate 0: replaced by any finite d
+    a[5, 0, :] = inf                                   # a query at infinity: inf - inf = NaN against b[5, 0]
+    a[6] *= np.float32(3.0e19); b[6] *= np.float32(3.0e19)   # finite coordinates, every squared distance overflows
+    a[7, at(3, n)] = nan; b[7, at(3, m)] = nan; b[7, at(600, m), 0] = inf
+    if B > 8:
+        b[8, :, 0] = nan                               # every candidate NaN
+    with np.errstate(all="ignore"):
+        ref = S.nndistance(a, b)
+    assert np.isnan(ref[0][0]).all() and (ref[1][0] == 0).all()          # the latch of nndistance.cu:26 at work
+    _assert_same_with_nans(_run(BK, a, b, impl), ref, (shape, impl))
+
+
+def test_nonfinite_input_through_the_cd_and_pairwise_entry_points():
+    """The same contract through dpf_nndistance_cd (the benchmark step's Chamfer call: distances, indices and the
+    per-cloud CD, NaN where the reference's `dl.mean(1) + dr.mean(1)` is NaN) and dpf_pairwise_cd."""
+    BK = _gpu()
+    B, n, m = 32, 2048, 2048
+    a, b = chamfer_inputs(4500, B, n, m)
+    b[3, 0, 0] = np.nan; a[7, 100, 1] = np.inf; b[9, 512, 2] = np.nan
+    with np.errstate(all="ignore"):
+        ref = S.nndistance(a, b)
+        ref_cd = ref[0].mean(1, dtype=np.float64) + ref[2].mean(1, dtype=np.float64)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    d1, i1, d2, i2, cd = BK.NNDistanceCD(ta, tb)
+    torch.cuda.synchronize()
+    _assert_same_with_nans((d1.cpu().numpy(), i1.cpu().numpy(), d2.cpu().numpy(), i2.cpu().numpy()), ref, "cd")
+    cd = cd.cpu().numpy()
+    bad = ~np.isfinite(ref_cd)
+    assert bad.sum() >= 2 and np.array_equal(~np.isfinite(cd), bad)
+    np.testing.assert_allclose(cd[~bad], ref_cd[~bad], rtol=2e-6)
+    from dpf_nets_amd.networks.utils import pairwise_CD
+    mat = pairwise_CD(ta[:6], tb[:5]).cpu().numpy()
+    with np.errstate(all="ignore"):
+        for i in range(6):
+            for j in range(5):
+                r = S.nndistance(a[i:i + 1], b[j:j + 1])
+                want = r[0].mean(dtype=np.float64) + r[2].mean(dtype=np.float64)
+                if np.isfinite(want):
+                    assert abs(mat[i, j] - want) <= 2e-6 * abs(want), (i, j)
+                else:
+                    assert not np.isfinite(mat[i, j]), (i, j)
+
+
 def test_nndistance_first_minimum_on_exact_ties():
     BK = _gpu()
     B, n, m = 2, 197, 530
@@ -251,6 +330,12 @@ def test_nndistance_cd_fused_reduction():
         ref = d1.double().mean(1) + d2.double().mean(1)
         assert torch.allclose(cd.double(), ref, rtol=2e-6, atol=0)
         assert torch.equal(cd, BK.NNDistanceCD(ta, tb)[4])              # deterministic
+        ws = BK.CDWorkspace(B, n, m, ta.device)                          # caller-owned scratch: same bits, tickets back at zero
+        for _ in range(3):
+            assert torch.equal(cd, BK.NNDistanceCD(ta, tb, ws)[4])
+        assert int(ws.tickets().abs().sum()) == 0 and not ws.dirty
+    with pytest.raises(RuntimeError):
+        BK.NNDistanceCD(ta, tb, BK.CDWorkspace(B + 1, n, m, ta.device))
 
 
 def test_nndistance_cd_ticket_finish_under_load():
@@ -265,37 +350,42 @@ def test_nndistance_cd_ticket_finish_under_load():
     side = torch.cuda.Stream()
     junk = torch.randn(4096, 4096, device="cuda")
     bad = 0
+    ws = BK.CDWorkspace(B, n, n, "cuda:0")
     for it in range(150):
         a = (base * (1.0 + 0.01 * it)).contiguous()
         b = (other + 0.003 * it).contiguous()
         if it % 3 == 0:
             with torch.cuda.stream(side):
                 junk2 = junk @ junk                      # uneven load on part of the chip while the call runs
-        d1, i1, d2, i2, cd = BK.NNDistanceCD(a, b)
+        d1, i1, d2, i2, cd = BK.NNDistanceCD(a, b, ws if it % 5 else None)     # every fifth call: fresh scratch, cleared in-call
         ref = d1.double().mean(1) + d2.double().mean(1)
         bad += int((~torch.isclose(cd.double(), ref, rtol=3e-6, atol=0)).sum())
     torch.cuda.synchronize()
     assert bad == 0, bad
-    for ws in BK._CD_WORKSPACES.values():
-        assert int(ws[:4 * B].view(torch.int32).abs().sum()) == 0        # tickets left at zero
+    assert int(ws.tickets().abs().sum()) == 0                             # tickets left at zero
+    # a workspace left dirty (a call that raised, a ticket that a fault left behind) is cleared by the next call
+    ws.tickets().fill_(3)
+    ws.dirty = True
+    d1, i1, d2, i2, cd = BK.NNDistanceCD(a, b, ws)
+    assert torch.allclose(cd.double(), d1.double().mean(1) + d2.double().mean(1), rtol=3e-6, atol=0)
+    assert int(ws.tickets().abs().sum()) == 0 and not ws.dirty
 
 
 def test_nndistance_cd_first_call_inside_a_graph_capture():
-    """a first call on a stream made INSIDE torch.cuda.graph must not cache a workspace from the graph's
-    private pool; the library clears the tickets itself there (a kernel node -- csrc/zero_fill.h), so replays on new data
-    stay correct, and nothing of the capture is left in the process-wide table."""
+    """A call without a caller-owned workspace INSIDE torch.cuda.graph takes its scratch from the graph's private pool and
+    the library clears the tickets itself (a kernel node -- csrc/zero_fill.h), so replays on new data stay correct; nothing
+    is cached anywhere (r04: there is no process-wide table any more)."""
     BK = _gpu()
     B, n = 32, 2048
     a, b = chamfer_inputs(4242, B, n, n)
     ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
-    before = set(BK._CD_WORKSPACES)
+    assert not hasattr(BK, "_CD_WORKSPACES")
     side = torch.cuda.Stream()
     graph = torch.cuda.CUDAGraph()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         with torch.cuda.graph(graph, stream=side):
             outs = BK.NNDistanceCD(ta, tb)
-    assert set(BK._CD_WORKSPACES) == before                               # nothing cached from inside the capture
     for it in range(3):
         ta.mul_(1.0 + 0.05 * it)
         tb.add_(0.01 * it)
