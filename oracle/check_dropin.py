@@ -302,8 +302,12 @@ def svr_sections(ref_models, ref_losses, mir_models, mir_losses, em, write):
     for u, v, name in zip(l1, l2, ("loss", "pnll", "gnll", "gent")):
         assert abs(float(u) - float(v)) <= 2e-5 * max(1.0, abs(float(u))), (name, float(u), float(v))
     assert set(g1) == set(g2)
-    for k in g1:
-        assert float((g1[k] - g2[k]).abs().max() / (g1[k].abs().max() + 1e-30)) < 2e-3, ("svr grad", k)
+    # relative to the tensor's own largest entry, floored at 1e-5 of the largest gradient entry of the model (a BatchNorm bias
+    # in front of another BatchNorm has a gradient of pure rounding noise: ~1e-6 here)
+    gmax = max(float(v.abs().max()) for v in g1.values())
+    gerr = {k: float((g1[k] - g2[k]).abs().max() / max(float(g1[k].abs().max()), 1e-5 * gmax)) for k in g1}
+    bad = sorted(((e, k, float(g1[k].abs().max())) for k, e in gerr.items() if e >= 2e-3), reverse=True)
+    assert not bad, ("svr grad", bad[:8])
     for k in b1:
         assert torch.allclose(b1[k].float(), b2[k].float(), rtol=1e-4, atol=1e-6), ("svr buffer", k)
     print("SVR model, training mode: %d output entries, 4 loss terms, %d gradients, %d buffers agree (worst output rel err %.2e)"

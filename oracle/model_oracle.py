@@ -155,7 +155,10 @@ SVR_CONFIG_SMALL = dict(util_mode="predicting", deterministic=False, pc_enc_init
                         p_decoder_n_flows=2, p_decoder_n_features=64, p_decoder_base_type="freevar", p_decoder_base_var=0.0,
                         pnll_weight=1.0, gnll_weight=1.0, gent_weight=1.0)
 # configs/svr/all.yaml:62-88 as shipped (G = 512, 7 prior flows of 128 features, 21 decoder triples = 63 coupling layers)
-SVR_CONFIG = dict(SVR_CONFIG_SMALL, g_latent_space_size=512, g_prior_n_flows=7, g_prior_n_features=128, p_decoder_n_flows=21)
+# (`oracle_final_std`: read by make_svr_state only -- the std of the decoder's last SharedDots; 0.01 is the reference's own
+# weight_std (decoders.py:42), which keeps a 63-layer stack of deterministic weights near the data's scale)
+SVR_CONFIG = dict(SVR_CONFIG_SMALL, g_latent_space_size=512, g_prior_n_flows=7, g_prior_n_features=128, p_decoder_n_flows=21,
+                  oracle_final_std=0.01)
 SVR_BATCH, SVR_CLOUD = 50, 2500               # configs/svr/all.yaml:10, :6
 
 
@@ -188,11 +191,16 @@ def make_svr_state(seed, cfg=SVR_CONFIG_SMALL):
         st["pc_encoder." + k] = v
     for k, v in GO.make_gprior_state(seed + 2, cfg["g_prior_n_flows"], cfg["g_prior_n_features"], G).items():
         st["g_prior." + k] = v
-    for k, v in FO.make_decoder_state(seed + 3, cfg["p_decoder_n_flows"], cfg["p_decoder_n_features"], G).items():
+    kw = {"final_std": cfg["oracle_final_std"]} if "oracle_final_std" in cfg else {}
+    for k, v in FO.make_decoder_state(seed + 3, cfg["p_decoder_n_flows"], cfg["p_decoder_n_features"], G, **kw).items():
         st["pc_decoder." + k] = v
     st.update(_feature_encoder_state(seed + 4, "g0_prior", cfg["g_prior_n_layers"], G, G, False, 0.05, 0.03))
     st.update(_feature_encoder_state(seed + 5, "g_posterior", cfg["g_posterior_n_layers"], C, G, False, 0.05, 0.03))
     st.update(_feature_encoder_state(seed + 6, "p_prior", cfg["p_prior_n_layers"], G, cfg["p_latent_space_size"], True, 0.05, 0.0))
+    # the 'freevar' base distribution's log-variance head around the autoencoder configs' fixed value (-3.5960,
+    # configs/autoencoding/all_scaled.yaml:51): sampled clouds then have the extent at which nearest-neighbour distances
+    # straddle f_score's 0.001 threshold
+    st["p_prior.mus.mu_mlp0.bias"] = (st["p_prior.mus.mu_mlp0.bias"] - np.float32(3.596)).astype(np.float32)
     st["p_prior_mus"] = np.zeros((1, cfg["p_latent_space_size"], 1), np.float32)
     return st
 

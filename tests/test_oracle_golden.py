@@ -361,6 +361,64 @@ def test_model_oracle_evaluating_forward_vs_reference_golden(golden_dir):
                                float(gold["pnll_as_losses_py"]), rtol=1e-5)
 
 
+def _svr_eval_metrics(final, tgt):
+    """evaluating.py:198-205 over the oracle's Chamfer: per-cloud CD and f_score (utils.py:38-42, threshold 0.001)."""
+    from oracle import structural as S
+    r = np.ascontiguousarray(final.transpose(0, 2, 1))
+    t = np.ascontiguousarray(tgt.transpose(0, 2, 1))
+    d1, _, d2, _ = S.nndistance(r, t)
+    cd = d1.mean(1, dtype=np.float64) + d2.mean(1, dtype=np.float64)
+    prec = 100.0 * (d2 < 0.001).mean(1, dtype=np.float64)
+    rec = 100.0 * (d1 < 0.001).mean(1, dtype=np.float64)
+    return cd, 2.0 * prec * rec / (prec + rec + 1e-7), (d1, d2)
+
+
+@pytest.mark.parametrize("which", ["small", "predict"])
+def test_model_oracle_svr_predicting_forward_vs_reference_golden(golden_dir, which):
+    """oracle/model_oracle.predicting_forward (models.py:417-462 restated) over the CPU oracles
+    reproduces what the reference's own Local_Cond_RNVP_MC_Global_RNVP_VAE_IC produced in `predicting` mode
+    (oracle/check_dropin.py -> tests/golden/model_svr_small.npz; model_svr_predict.npz = the shipped shapes of
+    configs/svr/all.yaml: B = 50, 2500 points, G = 512, 63 layers -- there only the first clouds, a few seconds of CPU),
+    and the evaluation of evaluating.py:198-205 -- per-cloud CD and f_score -- over the oracle's Chamfer reproduces the
+    reference's utils.f_score / distChamfer values."""
+    from oracle import model_oracle as MO, gprior_oracle as GO
+    gold = np.load(os.path.join(golden_dir, "model_svr_%s.npz" % which))
+    cfg = MO.SVR_CONFIG_SMALL if which == "small" else MO.SVR_CONFIG
+    seed, B, S = int(gold["seed"]), int(gold["B"]), int(gold["S"])
+    st = FO.to_torch(MO.make_svr_state(seed, cfg))
+    G = cfg["g_latent_space_size"]
+    _, eps, _ = MO.svr_inputs(seed, B, S, G)
+    nb = B if which == "small" else gold["final_first"].shape[0]          # the 63-layer CPU oracle on 6 of the 50 clouds
+    blocks = {
+        "g0_prior": lambda x: MO.feature_encoder(st, "g0_prior", x, cfg["g_prior_n_layers"], False),
+        "g_prior": lambda g, mode: GO.global_rnvp_decoder(FO.sub_state(st, "g_prior."), cfg["g_prior_n_flows"], g, mode),
+        "p_prior": lambda g: MO.feature_encoder(st, "p_prior", g, cfg["p_prior_n_layers"], True),
+        "p_prior_mus": st["p_prior_mus"],
+        "pc_decoder": lambda p, g, mode: FO.decoder(FO.sub_state(st, "pc_decoder."), cfg["p_decoder_n_flows"], p, g, mode),
+    }
+    with torch.no_grad():
+        out = MO.predicting_forward(blocks, torch.from_numpy(gold["img_features"][:nb]), torch.from_numpy(eps[:nb]), cfg)
+    for k in ("g_prior_samples", "g_prior_mus", "g_prior_logvars"):
+        assert len(out[k]) == int(gold[k + "_len"]), k
+        for i in (0, 1, len(out[k]) - 1):
+            ref = gold["%s/%d" % (k, i)][:nb]
+            np.testing.assert_allclose(out[k][i].numpy(), ref, rtol=1e-4, atol=3e-6 * max(1.0, float(np.abs(ref).max())), err_msg="%s/%d" % (k, i))
+    assert len(out["p_prior_samples"]) == int(gold["p_prior_samples_len"]) == 3 * cfg["p_decoder_n_flows"] + 1
+    np.testing.assert_allclose(out["p_prior_logvars"][0][:, :, 0].numpy(), gold["p_base_logvar"][:nb], rtol=1e-4, atol=1e-5)
+    final = out["p_prior_samples"][-1].numpy()
+    ref = gold["final_first"][:nb]
+    np.testing.assert_allclose(final[:ref.shape[0]], ref, rtol=1e-4, atol=2e-5 * float(np.abs(ref).max()))
+    np.testing.assert_allclose(sum(out["p_prior_logvars"][1:]).numpy()[:ref.shape[0]], gold["sum_p_logvars_first"][:nb],
+                               rtol=1e-4, atol=2e-5 * float(np.abs(gold["sum_p_logvars_first"]).max()))
+    np.testing.assert_allclose(np.abs(final).sum((1, 2), dtype=np.float64), gold["final_abs_sum"][:nb], rtol=2e-5)
+    tgt = MO.svr_target(seed, B, S, float(gold["target_std"]))[:nb]
+    cd, f1, _ = _svr_eval_metrics(final, tgt)
+    np.testing.assert_allclose(cd, gold["cd_per_cloud"][:nb], rtol=2e-4)
+    # f_score counts points under a threshold: a distance within rounding of 0.001 may fall either side (the reference's
+    # distChamfer is the expanded form); one flipped point of S moves precision or recall by 100 / S
+    assert np.all(np.abs(f1 - gold["f_score"][:nb]) <= 3 * 100.0 / S + 1e-3 * gold["f_score"][:nb]), (f1, gold["f_score"][:nb])
+
+
 def test_model_oracle_training_forward_vs_reference_golden(golden_dir):
     """oracle/model_oracle.training_forward + vae_loss (models.py:125-171, losses.py:37-51 restated) over the mirror's
     modules on their CPU tensor-op path reproduce the reference model's training step
