@@ -271,29 +271,6 @@ __global__ __launch_bounds__(512) void film_kernel(int L, int B, int G, const fl
 // ===========================================================================
 // the fused stack
 // ===========================================================================
-struct FlowArgs {
-    const uint8_t *packed;
-    const int *meta;
-    const float *film;
-    const float *p_in;
-    float *p_out, *p_out_pm, *sum_lv, *ps, *mus, *lvs;
-    int L, B, N, mode;
-    float eps;
-    // optional prologue (direct mode, models.py:76-79 + :212): p_in is the NOISE and the stack starts from
-    // z = p_in * exp(0.5 * lv0) + mu0, the base distribution read through its (batch, channel, point) strides -- the
-    // reference's stride-0 expansions (models.py:153-158, 203-209) are never materialised; z_out (optional) receives z
-    const float *base_mu, *base_lv;
-    long mu_sb, mu_sc, mu_sn, lv_sb, lv_sc, lv_sn;
-    float *z_out;
-    // optional epilogue (training forward, csrc/flow_train.hip): moments of the output's channels xs_ka / xs_kb -- the
-    // NEXT layer's kept coordinates -- per workgroup, in tstats_x_kernel's layout: xs_part[workgroup][8] doubles
-    double *xs_part;
-    int xs_ka, xs_kb;
-#ifdef DPF_PROFILE
-    unsigned long long *prof;
-#endif
-};
-
 // Stream one layer (packed weights + this cloud's FiLM vectors) into an LDS
 // buffer: 1 KiB per wave-instruction, straight to LDS (no VGPR staging).
 // Issuing a piece blocks the issuing wave for ~60-180 cycles (MI355X_MICROARCH.md, "LDS-DMA piece issue cost").  In an
@@ -982,9 +959,15 @@ int launch_flow_prec(int precision, const FlowArgs &a, hipStream_t s) {
 
 extern "C" size_t dpf_flow_canon_floats(int G) { return (size_t)c_layer_floats(G); }
 
+// bytes of the MFMA-fragment weights in front of the conditioner weights: the 32-point-tile layout of every layer, then
+// (f16x3 only) the 16-point-tile layout of every layer (csrc/flow16.hip)
+static size_t packed_frag_bytes(int n_layers, int precision) {
+    return (size_t)n_layers * (p_layer_bytes(ns_of(precision)) + (precision == DPF_PREC_F16X3 ? P16_LAYER : 0));
+}
+
 extern "C" size_t dpf_flow_packed_bytes(int n_layers, int G, int precision) {
     const int ns = ns_of(precision);
-    return ns ? (size_t)n_layers * p_layer_bytes(ns) + fw_total_floats(n_layers, G) * sizeof(float) : 0;
+    return ns ? packed_frag_bytes(n_layers, precision) + fw_total_floats(n_layers, G) * sizeof(float) : 0;
 }
 
 extern "C" size_t dpf_flow_film_floats(int n_layers, int B) { return (size_t)n_layers * B * (FILM_BYTES / 4); }
@@ -1003,7 +986,9 @@ extern "C" int dpf_flow_pack(int n_layers, int G, int precision, const float *ca
     if (precision == DPF_PREC_F16X3)
         hipLaunchKernelGGL((pack_kernel<2, true>), dim3(n_layers), dim3(256), 0, s, G, canon, (uint8_t *)packed);
     if (ns == 3) hipLaunchKernelGGL(pack_kernel<3>, dim3(n_layers), dim3(256), 0, s, G, canon, (uint8_t *)packed);
-    float *fw = (float *)((uint8_t *)packed + (size_t)n_layers * p_layer_bytes(ns));
+    if (precision == DPF_PREC_F16X3)
+        if (int rc = flow16_pack(n_layers, G, canon, (uint8_t *)packed + (size_t)n_layers * p_layer_bytes(ns), s)) return rc;
+    float *fw = (float *)((uint8_t *)packed + packed_frag_bytes(n_layers, precision));
     hipLaunchKernelGGL(pack_film_kernel, dim3(n_layers * 4), dim3(256), 0, s, n_layers, G, canon, fw);
     return (int)hipGetLastError();
 }
@@ -1015,7 +1000,7 @@ extern "C" int dpf_flow_film(int n_layers, int B, int G, int precision, const vo
     if (n_layers == 0 || B == 0) return 0;
     if (!packed || !g || !film) return DPF_EINVAL;
     if (G % 16 != 0 || G > 2048) return DPF_ENOSUP;
-    const float *fw = (const float *)((const uint8_t *)packed + (size_t)n_layers * p_layer_bytes(ns));
+    const float *fw = (const float *)((const uint8_t *)packed + packed_frag_bytes(n_layers, precision));
     const int lds = (FILM_CLOUDS * G + (2 * 4 + 2 + 1) * FILM_CLOUDS * 64) * (int)sizeof(float);
     static LdsLimit film_limit;
     if (lds > 65536)
@@ -1030,7 +1015,7 @@ static int flow_forward_impl(int n_layers, int B, int N, int mode, int precision
                              float *p_out_pointmajor, float *sum_logvar, float *ps, float *mus, float *logvars,
                              float flow_eps, dpf_stream_t stream, const float *base_mu, const long *mu_strides,
                              const float *base_lv, const long *lv_strides, float *z_out, double *xs_part = nullptr,
-                             int xs_ka = 0, int xs_kb = -1, int *xs_rows = nullptr) {
+                             int xs_ka = 0, int xs_kb = -1, int *xs_rows = nullptr, bool packed16_ok = true) {
     const int ns = ns_of(precision);
     if (!ns || n_layers <= 0 || B < 0 || N <= 0 || (mode != DPF_MODE_DIRECT && mode != DPF_MODE_INVERSE)) return DPF_EINVAL;
     if (B == 0) return 0;
@@ -1044,6 +1029,7 @@ static int flow_forward_impl(int n_layers, int B, int N, int mode, int precision
     a.base_mu = base_mu; a.base_lv = base_lv; a.z_out = z_out;
     a.xs_part = xs_part; a.xs_ka = xs_ka; a.xs_kb = xs_kb;
     a.mu_sb = a.mu_sc = a.mu_sn = a.lv_sb = a.lv_sc = a.lv_sn = 0;
+    a.prof = nullptr;
 #ifdef DPF_PROFILE
     a.prof = g_prof;
 #endif
@@ -1052,6 +1038,12 @@ static int flow_forward_impl(int n_layers, int B, int N, int mode, int precision
         a.lv_sb = lv_strides[0]; a.lv_sc = lv_strides[1]; a.lv_sn = lv_strides[2];
     }
     hipStream_t s = (hipStream_t)stream;
+    // small batches (at most one 16-point tile per SIMD of the chip): the 16-point-tile kernel, csrc/flow16.hip
+    a.packed16 = nullptr;
+    if (packed16_ok && flow16_serves(n_layers, B, N, precision, xs_part != nullptr)) {
+        a.packed16 = (const uint8_t *)packed + (size_t)n_layers * p_layer_bytes(ns);
+        return flow16_launch(&a, s);
+    }
     // 8-wave workgroups (256 points of one cloud) unless that leaves CUs without a workgroup
     static const int force_fw = getenv("DPF_FLOW_WAVES") ? atoi(getenv("DPF_FLOW_WAVES")) : 0;
     // waves (32-point tiles) per workgroup: as many as possible (each workgroup streams the layer
@@ -1091,7 +1083,8 @@ int flow_forward_xstats(int B, int N, int mode, int precision, const void *packe
                         const float *p_in, float *ps, float *mus, float *logvars, float flow_eps, dpf_stream_t stream,
                         double *xs_part, int xs_ka, int xs_kb, int *xs_rows) {
     return flow_forward_impl(1, B, N, mode, precision, packed, meta, film, p_in, ps, nullptr, nullptr, ps, mus, logvars, flow_eps,
-                             stream, nullptr, nullptr, nullptr, nullptr, nullptr, xs_part, xs_ka, xs_kb, xs_rows);
+                             stream, nullptr, nullptr, nullptr, nullptr, nullptr, xs_part, xs_ka, xs_kb, xs_rows,
+                             /*packed16_ok=*/false);    // this block was packed by flow_train.hip's tpack_kernel: 32-point layout only
 }
 
 // dpf_flow_forward in DIRECT mode with the reparameterisation of the base sample fused into its prologue

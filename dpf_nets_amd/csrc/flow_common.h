@@ -146,10 +146,50 @@ __device__ __forceinline__ u32x4 input_weight_slots8(float w, float T, int h) {
 // feature held by accumulator register r (0..15) of M tile t in lane half h
 __device__ __forceinline__ constexpr int acc_feature(int t, int r, int h) { return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+struct FlowArgs {
+    const uint8_t *packed;
+    const int *meta;
+    const float *film;
+    const float *p_in;
+    float *p_out, *p_out_pm, *sum_lv, *ps, *mus, *lvs;
+    int L, B, N, mode;
+    float eps;
+    // optional prologue (direct mode, models.py:76-79 + :212): p_in is the NOISE and the stack starts from
+    // z = p_in * exp(0.5 * lv0) + mu0, the base distribution read through its (batch, channel, point) strides -- the
+    // reference's stride-0 expansions (models.py:153-158, 203-209) are never materialised; z_out (optional) receives z
+    const float *base_mu, *base_lv;
+    long mu_sb, mu_sc, mu_sn, lv_sb, lv_sc, lv_sn;
+    float *z_out;
+    // optional epilogue (training forward, csrc/flow_train.hip): moments of the output's channels xs_ka / xs_kb -- the
+    // NEXT layer's kept coordinates -- per workgroup, in tstats_x_kernel's layout: xs_part[workgroup][8] doubles
+    double *xs_part;
+    int xs_ka, xs_kb;
+    unsigned long long *prof;       // -DDPF_PROFILE builds: phase stamps; nullptr otherwise
+    // 16-point-tile fragments of the same weights (csrc/flow16.hip; f16x3 only), or nullptr
+    const uint8_t *packed16;
+};
+
+// ---- packed layout of the 16-point-tile kernel (csrc/flow16.hip; v_mfma_f32_16x16x32_{f16,bf16}) ----------------------
+// per layer: A1 [part2][br2][t'4][s2][lane64][8 f16] (32 KiB): element j of lane (i = lane & 15, g = lane >> 4) =
+//            W1[br][16 t' + i][feat(s, g, j)],  feat = 16 (2 s + (j >> 2)) + 4 g + (j & 3)
+//            -- the feature register (j & 3) of M tile 2 s + (j >> 2) of the h0 accumulator holds in lane group g;
+//            A0 [br2][t4][lane64][8 bf16] (8 KiB): the BN0-folded input layer's 3-way split in the K slots of lane groups
+//            0 (kept channel a) and 1 (kept channel b), zeros in groups 2 and 3
+constexpr int P16_A1_PART = 16384;
+constexpr int P16_A1 = 2 * P16_A1_PART;
+constexpr int P16_A0 = 8192;
+constexpr int P16_LAYER = P16_A1 + P16_A0;
+
+
 }  // namespace
 
 // csrc-internal: defined in flow.hip, used by flow_train.hip (see there)
 int flow_forward_xstats(int B, int N, int mode, int precision, const void *packed, const int *meta, const float *film,
                         const float *p_in, float *ps, float *mus, float *logvars, float flow_eps, dpf_stream_t stream,
                         double *xs_part, int xs_ka, int xs_kb, int *xs_rows);
+// csrc-internal: defined in flow16.hip, called by flow.hip's dispatcher.  Returns a HIP error code, or -1000 when the
+// 16-point kernel does not serve the call (the caller then takes the 32-point kernel).
+int flow16_launch(const void *flow_args, hipStream_t stream);
+bool flow16_serves(int n_layers, int B, int N, int precision, bool has_xs);
+int flow16_pack(int n_layers, int G, const float *canon, void *packed16, hipStream_t s);
 #endif  // DPF_FLOW_COMMON_H

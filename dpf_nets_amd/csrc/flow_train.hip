@@ -1645,8 +1645,10 @@ static int flow_train_forward_direct(int n_layers, int B, int N, int mode, int p
             rc = flow_forward_xstats(B, N, mode, precision, pk, meta_dev + 4 * l, film_l, cur, ps + l * lst, mus + l * lst,
                                      logvars + l * lst, flow_eps, stream, w.xpart, mnext[0], mnext[1], &xrows);
         } else {
-            rc = dpf_flow_forward(1, B, N, mode, precision, pk, meta_dev + 4 * l, film_l, cur, ps + l * lst, nullptr, nullptr,
-                                  ps + l * lst, mus + l * lst, logvars + l * lst, flow_eps, stream);
+            // (the csrc-internal entry, not dpf_flow_forward: `pk` is tpack_kernel's 32-point-tile block -- the public entry
+            // would hand a small batch to the 16-point-tile kernel, whose fragments dpf_flow_pack lays out)
+            rc = flow_forward_xstats(B, N, mode, precision, pk, meta_dev + 4 * l, film_l, cur, ps + l * lst, mus + l * lst,
+                                     logvars + l * lst, flow_eps, stream, nullptr, 0, -1, nullptr);
         }
         if (rc) return rc;
         cur = ps + l * lst;

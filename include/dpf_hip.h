@@ -250,6 +250,14 @@ int dpf_flow_forward_base(int n_layers, int B, int N, int precision, const void 
                           float *p_out_pointmajor, float *sum_logvar, float *ps, float *mus, float *logvars,
                           float flow_eps, dpf_stream_t stream);
 
+/* Tiling of dpf_flow_forward / _base (results agree to rounding; both are held to the same goldens):
+ * a wave owns 32 points (v_mfma_f32_32x32x16, csrc/flow.hip) or, for small per-GPU batches at f16x3 -- at most one tile per
+ * SIMD of the chip, B * ceil(N / 16) <= 1024, e.g. the 4 clouds a rank of an 8-GPU job holds of BASELINE's 32 -- 16 points
+ * (v_mfma_f32_16x16x32, csrc/flow16.hip).  mode: -1 = by size (default; env DPF_FLOW_TILE16), 0 = never, 1 = whenever
+ * the precision allows.  Returns the previous mode.  Process-wide; meant for tests and measurements. */
+int dpf_flow_set_tile16(int mode);
+long dpf_flow_tile16_launches(void);   /* calls of dpf_flow_forward / _base served by the 16-point kernel so far */
+
 /* ---------------------------------------------------------------------------
  * Training mode (model.train()) of one coupling layer: batch-statistics
  * BatchNorm in both conditioner SharedDot stacks (flows.py:27,30,62,65), and the

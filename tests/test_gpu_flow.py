@@ -46,12 +46,26 @@ def rel(got, ref):
     return float(np.abs(got.astype(np.float64) - ref).max() / (np.abs(ref).max() + 1e-30))
 
 
+@pytest.fixture(params=["tile32", "tile16"])
+def tiling(request):
+    """Run a test once per tiling of the fused eval kernel: 32-point tiles (csrc/flow.hip) and, forced, 16-point tiles
+    (csrc/flow16.hip: the small-batch variant; by default it serves B * ceil(N / 16) <= 1024 at f16x3)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from dpf_nets_amd._lib import lib
+    old = lib().dpf_flow_set_tile16(1 if request.param == "tile16" else 0)
+    yield request.param
+    lib().dpf_flow_set_tile16(old)
+
+
 def _load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name + ".npz")), json.load(open(os.path.join(golden_dir, name + ".json")))
 
 
 @pytest.mark.parametrize("prec", ["f16x3", "bf16x3", "bf16x6", "bf16"])
-def test_single_layer_vs_reference_golden(golden_dir, prec):
+def test_single_layer_vs_reference_golden(golden_dir, prec, tiling):
+    if tiling == "tile16" and prec != "f16x3":
+        pytest.skip("16-point tiles exist for f16x3 only")
     nets = _gpu()
     gold, meta = _load(golden_dir, "flow_layer")
     B, N, F, G = meta["B"], meta["N"], meta["F"], meta["G"]
@@ -79,7 +93,9 @@ def test_single_layer_vs_reference_golden(golden_dir, prec):
 
 
 @pytest.mark.parametrize("prec", ["f16x3", "bf16x3", "bf16x6"])
-def test_decoder_vs_reference_golden(golden_dir, prec):
+def test_decoder_vs_reference_golden(golden_dir, prec, tiling):
+    if tiling == "tile16" and prec != "f16x3":
+        pytest.skip("16-point tiles exist for f16x3 only")
     nets = _gpu()
     gold, meta = _load(golden_dir, "flow_decoder")
     for case in meta["cases"]:
@@ -116,7 +132,7 @@ def test_decoder_vs_reference_golden(golden_dir, prec):
         assert len(acc) == 3 * nf + 1 and acc[1] is lvs[0]
 
 
-def test_l14_truncated_stack_vs_reference_golden(golden_dir):
+def test_l14_truncated_stack_vs_reference_golden(golden_dir, tiling):
     """The BASELINE metric's L=14 = first 14 direct-order layers of n_flows=5."""
     nets = _gpu()
     gold, _ = _load(golden_dir, "flow_decoder")
@@ -135,8 +151,8 @@ def test_l14_truncated_stack_vs_reference_golden(golden_dir):
 
 
 @pytest.mark.parametrize("shape", [(1, 1, 128), (3, 31, 128), (2, 33, 128), (2, 129, 512), (5, 257, 128), (2, 2500, 512)])
-def test_ragged_sizes_vs_oracle(shape):
-    """N not a multiple of the 32-point tile / 128-point workgroup, B = 1, G = 512."""
+def test_ragged_sizes_vs_oracle(shape, tiling):
+    """N not a multiple of the 32- / 16-point tile or of the workgroup's points, B = 1, G = 512."""
     nets = _gpu()
     B, N, G = shape
     nf = 2
@@ -156,8 +172,10 @@ def test_ragged_sizes_vs_oracle(shape):
 
 
 @pytest.mark.parametrize("B,G", [(32, 128), (64, 512), (32, 512)], ids=["configs1_B32_G128", "configs2_B64_G512", "configs3_B32_G512"])
-def test_full_size_properties(B, G):
-    """BASELINE.json configs[1] (B=32, G=128), configs[2] (all-classes model: B=64, G=512) and configs[3] (SVR decoder
+def test_full_size_properties(B, G, tiling):
+    """(once per tiling of the eval kernel: the per-point independence below is bit-exact INSIDE a tiling; across tilings
+    the matrix cores add their 16 / 32 K-slots in a different order -- test_tile16_* holds the two to the oracle.)
+    BASELINE.json configs[1] (B=32, G=128), configs[2] (all-classes model: B=64, G=512) and configs[3] (SVR decoder
     shapes: B=32, G=512), all N=2048 and 63 layers, at FULL size: direct then inverse returns the input up to the
     reference's own sqrt(1+eps) keep-channel drift; outputs independent of batch composition; two clouds against the oracle."""
     nets = _gpu()
@@ -196,6 +214,55 @@ def test_full_size_properties(B, G):
         assert rel(ps3[-1][:2], rps[-1]) <= REL[prec] and rel(lvs3.total()[:2], sum(rlvs)) <= REL[prec]
         assert_elementwise(ps3[-1][:2], rps[-1], prec, "full size, 63 layers: points")
         assert_elementwise(lvs3.total()[:2], sum(rlvs), prec, "full size, 63 layers: sum of logvars")
+
+
+@pytest.mark.parametrize("B", [4, 8])
+def test_tile16_serves_a_rank_sized_batch_by_default_and_matches_oracle_and_tile32(B):
+    """a rank of an 8-GPU job holds 4 (BASELINE's B = 32) or 8 (configs[2]: B = 64) clouds of 2048 points.
+    Such a batch is served by the 16-point-tile kernel WITHOUT being asked (dpf_flow_tile16_launches moves); its results
+    meet the oracle at the 32-point kernel's bars -- norm-wise and elementwise, direct and inverse, L = 14 and the real depth
+    L = 63, with the per-layer lists -- and agree with the 32-point kernel's to rounding."""
+    nets = _gpu()
+    from dpf_nets_amd._lib import lib
+    N, G, nf = 2048, 128, 21
+    state = FO.make_decoder_state(9, nf, 64, G)
+    dec = nets.LocalCondRNVPDecoder(nf, 64, G)
+    dec.load_state_dict(FO.to_torch(state), strict=True)
+    dec = dec.cuda().eval()
+    tgt, z, g = FO.synthetic_inputs(9, B, N, G)
+    tz, tt, tg = torch.from_numpy(z).cuda(), torch.from_numpy(tgt).cuda(), torch.from_numpy(g).cuda()
+    before = lib().dpf_flow_tile16_launches()
+    with torch.no_grad():
+        ps, mus, lvs = dec(tz, tg, mode="direct")
+        p14, _, lv14 = dec(tz, tg, mode="direct", n_layers=14)
+        inv, imus, ilvs = dec(tt, tg, mode="inverse")
+    assert lib().dpf_flow_tile16_launches() == before + 3                     # all three calls took the 16-point kernel
+    old = lib().dpf_flow_set_tile16(0)
+    try:
+        with torch.no_grad():
+            ps32, mus32, lvs32 = dec(tz, tg, mode="direct")
+            inv32, _, ilvs32 = dec(tt, tg, mode="inverse")
+    finally:
+        lib().dpf_flow_set_tile16(old)
+    assert lib().dpf_flow_tile16_launches() == before + 3
+    with torch.no_grad():
+        rps, rmus, rlvs = FO.decoder(FO.to_torch(state), nf, torch.from_numpy(z[:2]), torch.from_numpy(g[:2]), "direct")
+        rinv, _, rilvs = FO.decoder(FO.to_torch(state), nf, torch.from_numpy(tgt[:2]), torch.from_numpy(g[:2]), "inverse")
+    for k in (0, 13, 31, 62):
+        for name, got, ref in (("ps", ps, rps), ("mus", mus, rmus), ("logvars", lvs, rlvs)):
+            assert rel(got[k][:2], ref[k]) <= REL["f16x3"], (name, k)
+            assert_elementwise(got[k][:2], ref[k], "f16x3", (name, k))
+    assert rel(p14[-1][:2], rps[13]) <= REL["f16x3"] and rel(lv14.total()[:2], sum(rlvs[:14])) <= REL["f16x3"]
+    assert rel(lvs.total()[:2], sum(rlvs)) <= REL["f16x3"]
+    assert rel(inv[0][:2], rinv[0]) <= REL["f16x3"] and rel(ilvs.total()[:2], sum(rilvs)) <= REL["f16x3"]
+    assert_elementwise(inv[0][:2], rinv[0], "f16x3", "inverse, 63 layers")
+    # the two tilings against each other, every cloud
+    assert rel(ps[-1], ps32[-1].cpu().numpy()) <= 2 * REL["f16x3"] and rel(inv[0], inv32[0].cpu().numpy()) <= 2 * REL["f16x3"]
+    assert rel(lvs.total(), lvs32.total().cpu().numpy()) <= 2 * REL["f16x3"]
+    # a per-point map: a sub-batch of two clouds (served by the same kernel) gives the same bits
+    with torch.no_grad():
+        sub, _, _ = dec(tz[1:3].contiguous(), tg[1:3].contiguous(), mode="direct")
+    assert torch.equal(sub[-1], ps[-1][1:3]) and torch.equal(sub[20], ps[20][1:3])
 
 
 def test_f16x3_range_guard_falls_back_on_a_collapsed_batchnorm_variance():
