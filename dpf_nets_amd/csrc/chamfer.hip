@@ -23,18 +23,26 @@
 //  separately: this file is compiled with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "dpf_hip.h"
 #include "nn_refscan.h"
 
 #pragma clang fp contract(off)
 
+// -DDPF_NN_ABLATE=<mask>: timing experiments of tools/nn_ablate.py (results are garbage): 1 no candidate exponent check,
+// 2 no first-index rescan, 4 no scan loop, 8 no query loads
+#ifndef DPF_NN_ABLATE
+#define DPF_NN_ABLATE 0
+#endif
+
 namespace {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u4a __attribute__((ext_vector_type(4), aligned(4)));   // 16 bytes at dword alignment (one global_load_dwordx4)
 
 constexpr int CH = 8;            // candidates per min-chunk
-constexpr int NWAVES = 4;        // waves per workgroup
+constexpr int NWAVES = 4;        // waves per workgroup (default; the small-problem variants use 8 and 16)
 constexpr int QPW = 128;         // query points per wave (2 per lane)
 
 struct NNDir {
@@ -93,7 +101,7 @@ __device__ __forceinline__ float one_dist(float cx, float cy, float cz, float qx
     return (dx * dx + dy * dy) + dz * dz;
 }
 
-template <int KS>
+template <int KS, int NWAVES = 4>
 __global__ __launch_bounds__(NWAVES * 64) void nn_kernel(NNArgs args) {
     constexpr int QG = NWAVES / KS;          // query groups per workgroup
     const NNDir A = args.d[blockIdx.z];
@@ -109,9 +117,10 @@ __global__ __launch_bounds__(NWAVES * 64) void nn_kernel(NNArgs args) {
     const int j0 = (blockIdx.x * QG + qg) * QPW + lane;
     const int j1 = j0 + 64;
     const int j0c = min(j0, nq - 1), j1c = min(j1, nq - 1);
-    const f2 qx = {q[j0c * 3 + 0], q[j1c * 3 + 0]};
-    const f2 qy = {q[j0c * 3 + 1], q[j1c * 3 + 1]};
-    const f2 qz = {q[j0c * 3 + 2], q[j1c * 3 + 2]};
+    f2 qx = {q[j0c * 3 + 0], q[j1c * 3 + 0]};
+    f2 qy = {q[j0c * 3 + 1], q[j1c * 3 + 1]};
+    f2 qz = {q[j0c * 3 + 2], q[j1c * 3 + 2]};
+    if (DPF_NN_ABLATE & 8) { qx.x = lane * 0.001f; qx.y = qx.x + 0.1f; qy = qx * 0.5f; qz = qx * 0.25f; }
 
     // candidate slice of this wave, aligned to whole chunks
     const int nchunk = (nc + CH - 1) / CH;
@@ -123,24 +132,24 @@ __global__ __launch_bounds__(NWAVES * 64) void nn_kernel(NNArgs args) {
     int bc0 = kbeg, bc1 = kbeg;
     int k = kbeg;
     // Non-finite candidates (NaN / Inf) never show in a running minimum, but the reference's result depends on them
-    // (nn_refscan.h).  One vector load per loop iteration re-reads the slice's floats 64 at a time -- the scan itself uses
-    // scalar loads -- and keeps the largest (bits << 1): an all-ones exponent is a value >= 0xFF000000.  ~3 of the ~160
-    // instructions of an iteration; the value loaded in one iteration is consumed in the next.
-    const float *__restrict__ cs = c + (size_t)kbeg * 3;
-    const int nfl = (kend - kbeg) * 3, nrow = (nfl + 63) >> 6;
+    // (nn_refscan.h).  The scan loop below is unrolled into groups of four iterations (64 candidates); at the top of a group
+    // one 16-byte vector load per lane re-reads 256 of the slice's floats -- the scan itself uses scalar loads -- and at the
+    // bottom the largest (bits << 1) is kept: an all-ones exponent is a value >= 0xFF000000.  Nothing is pending across
+    // the loop's back-edge (a rotating pair of pending registers made the compiler wait vmcnt(0) at every latch: 7 % of the
+    // scan at B = 32, r04), the load has ~2400 cycles to land, and the bookkeeping lives in VGPRs (`fi` = the float index of
+    // this lane's next load; limits recomputed from kbeg / kend): the kernel sits at 78-79 SGPRs and a 256-thread block
+    // loses a residency slot per CU above 80.
     uint32_t cexp = 0;
-    float pend = 0.f;
-    int row = 0;
-#define DPF_NF_STEP()                                                            \
-    {                                                                            \
-        cexp = max(cexp, __builtin_bit_cast(uint32_t, pend) << 1);               \
-        const int fi_ = row * 64 + lane;                                         \
-        const float v_ = cs[min(fi_, nfl - 1)];                                  \
-        pend = v_;                                                               \
-        ++row;                                                                   \
-    }
+    int fi = kbeg * 3 + lane * 4;
+    auto nf_load = [&]() -> u4a {
+        u4a v = {0u, 0u, 0u, 0u};
+        if (kend - kbeg >= 2) v = *(const u4a *)(c + min(fi, kend * 3 - 4));
+        fi += 256;
+        return v;
+    };
+    auto nf_fold = [&](u4a v) { cexp = max(max(cexp, v.x << 1), max(v.y << 1, max(v.z << 1, v.w << 1))); };
     const int nfull = (kend - kbeg) / CH;          // whole chunks in this slice
-    if (nfull > 0) {
+    if (nfull > 0 && !(DPF_NN_ABLATE & 4)) {
         // Software-pipelined scalar loads, ping-pong between two SGPR sets so
         // that chunk i+1's 24 floats are in flight while chunk i runs on the VALU.
         const int klast = kbeg + (nfull - 1) * CH;  // last whole chunk (prefetch clamp, never out of bounds)
@@ -161,26 +170,35 @@ __global__ __launch_bounds__(NWAVES * 64) void nn_kernel(NNArgs args) {
         // issued right AFTER the first use of the other buffer (its wait) and
         // has one whole chunk of VALU work to land.
         DPF_LOAD_CHUNK(bufA, k);
-        int it = 0;
-        for (; it + 2 <= nfull; it += 2, k += 2 * CH) {
-            DPF_NF_STEP()
-            {
-                DPF_EVAL_HEAD(bufA);
-                __builtin_amdgcn_sched_barrier(0);
-                DPF_LOAD_CHUNK(bufB, k + CH);
-                __builtin_amdgcn_sched_barrier(0);
-                DPF_EVAL_TAIL(bufA, k);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                DPF_EVAL_HEAD(bufB);
-                __builtin_amdgcn_sched_barrier(0);
-                DPF_LOAD_CHUNK(bufA, min(k + 2 * CH, klast));
-                __builtin_amdgcn_sched_barrier(0);
-                DPF_EVAL_TAIL(bufB, k + CH);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+#define DPF_ITER2()                                                              \
+        {                                                                        \
+            {                                                                    \
+                DPF_EVAL_HEAD(bufA);                                             \
+                __builtin_amdgcn_sched_barrier(0);                               \
+                DPF_LOAD_CHUNK(bufB, k + CH);                                    \
+                __builtin_amdgcn_sched_barrier(0);                               \
+                DPF_EVAL_TAIL(bufA, k);                                          \
+            }                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                   \
+            {                                                                    \
+                DPF_EVAL_HEAD(bufB);                                             \
+                __builtin_amdgcn_sched_barrier(0);                               \
+                DPF_LOAD_CHUNK(bufA, min(k + 2 * CH, klast));                    \
+                __builtin_amdgcn_sched_barrier(0);                               \
+                DPF_EVAL_TAIL(bufB, k + CH);                                     \
+            }                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                   \
+            k += 2 * CH;                                                         \
         }
+        int it = 0;
+        if (!(DPF_NN_ABLATE & 1))
+            for (; it + 8 <= nfull; it += 8) {       // 64 candidates scanned, 256 floats (85 candidates) checked
+                const u4a v = nf_load();
+                DPF_ITER2() DPF_ITER2() DPF_ITER2() DPF_ITER2()
+                nf_fold(v);
+            }
+        for (; it + 2 <= nfull; it += 2) DPF_ITER2()
+#undef DPF_ITER2
         if (it < nfull) {
             DPF_EVAL_HEAD(bufA);
             DPF_EVAL_TAIL(bufA, k);
@@ -201,15 +219,16 @@ __global__ __launch_bounds__(NWAVES * 64) void nn_kernel(NNArgs args) {
         if (dm.y < best.y) { best.y = dm.y; bc1 = k; }
     }
 
-    if (nfl > 0) {                              // the rows the main loop did not reach, and the last pending value
-        while (row < nrow) DPF_NF_STEP()
-        cexp = max(cexp, __builtin_bit_cast(uint32_t, pend) << 1);
+    if (kend > kbeg && !(DPF_NN_ABLATE & 1)) {  // the rows the main loop did not reach
+        while (__any(fi - lane * 4 < kend * 3)) nf_fold(nf_load());
+        if (kend - kbeg < 2)                   // a slice of one candidate: three floats, by hand
+            for (int e = 0; e < 3; ++e) cexp = max(cexp, __builtin_bit_cast(uint32_t, c[kbeg * 3 + e]) << 1);
     }
-#undef DPF_NF_STEP
     const bool cbad = __any(cexp >= 0xFF000000u);   // wave-uniform: this wave's candidate slice holds a NaN / Inf
 
     // recover the FIRST index inside the winning chunk (descending scan, last hit wins)
     int i0 = bc0, i1 = bc1;
+    if (!(DPF_NN_ABLATE & 2))
 #pragma unroll
     for (int u = CH - 1; u >= 0; --u) {
         const int k0 = min(bc0 + u, nc - 1), k1 = min(bc1 + u, nc - 1);
@@ -380,6 +399,19 @@ extern "C" int dpf_nndistance_strided(int b, int n, const float *xyz, long xyz_s
     // pick the candidate split so that the launch has >= ~2 waves per SIMD on 256 CUs
     const long waves1 = (long)b * ((n + QPW - 1) / QPW + (m + QPW - 1) / QPW);
     hipStream_t s = (hipStream_t)stream;
+    // Small problems (a rank's 4-8 clouds of 2048 points): with one wave per SIMD the scan is bound by the LATENCY of its
+    // scalar loads (one chunk of prefetch covers ~300 cycles of VALU work, an L2-served s_load takes longer), so the
+    // candidates are split over MORE waves -- 8 or 16 slices merged in LDS in ascending order -- until every SIMD has two
+    static const int ks_env = getenv("DPF_NN_KS") ? atoi(getenv("DPF_NN_KS")) : 0;
+    const int minc = n < m ? n : m;
+    int ks_small = ks_env;
+    if (!ks_small && waves1 < 512 && minc >= 1024) ks_small = 8;    // r04, B=4 N=2048: 4 slices 18.4 us, 8: 15.3, 16: 16.8
+    if (ks_small == 16 || ks_small == 8) {
+        dim3 grid((nmax + QPW - 1) / QPW, b, 2);
+        if (ks_small == 16) hipLaunchKernelGGL((nn_kernel<16, 16>), grid, dim3(16 * 64), 0, s, a);
+        else hipLaunchKernelGGL((nn_kernel<8, 8>), grid, dim3(8 * 64), 0, s, a);
+        return (int)hipGetLastError();
+    }
     if (waves1 >= 2048 || (n < 64 && m < 64)) {
         dim3 grid((nmax + NWAVES * QPW - 1) / (NWAVES * QPW), b, 2);
         hipLaunchKernelGGL(nn_kernel<1>, grid, dim3(NWAVES * 64), 0, s, a);

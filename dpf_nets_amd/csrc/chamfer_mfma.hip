@@ -417,7 +417,12 @@ static int launch_nnm(int b, int n, const float *xyz, long xyz_stride, int m, co
     ma.d[0] = MDir{xyz, xyz2, result, result_i, n, m, xyz_stride, xyz2_stride};       // nndistance.cu:126
     ma.d[1] = MDir{xyz2, xyz, result2, result2_i, m, n, xyz2_stride, xyz_stride};     // nndistance.cu:127
     const int nmax = n > m ? n : m;
-    return (force16 || nnm_workgroups(b, n, m, 16) >= 128) ? launch_nnm_qw<16>(ma, b, nmax, s) : launch_nnm_qw<8>(ma, b, nmax, s);
+    static const int qw_env = getenv("DPF_NNM_QW") ? atoi(getenv("DPF_NNM_QW")) : 0;      // experiments: 4 | 8 | 16
+    if (force16 || qw_env == 16) return launch_nnm_qw<16>(ma, b, nmax, s);
+    if (qw_env == 8) return launch_nnm_qw<8>(ma, b, nmax, s);
+    if (qw_env == 4) return launch_nnm_qw<4>(ma, b, nmax, s);
+    if (nnm_workgroups(b, n, m, 16) >= 128) return launch_nnm_qw<16>(ma, b, nmax, s);
+    return nnm_workgroups(b, n, m, 8) >= 128 ? launch_nnm_qw<8>(ma, b, nmax, s) : launch_nnm_qw<4>(ma, b, nmax, s);
 }
 
 // enough pairs to amortise building the fragments and enough workgroups to fill the chip (r01, tools/nn_impl_sweep.py:
