@@ -794,6 +794,7 @@ __device__ __forceinline__ float cond_path(float u, float c0, float c1, float c2
 struct PrevLayer {
     const double *tot;           // its pass-2 totals
     const float *tcanon_l, *stats_l, *ubuf;
+    const float *ubuf2;          // second plane of u_k (branch-split pass 2: ubuf = logvar branch, ubuf2 = mu branch), or NULL
     const float *x;              // its input points = the output of the layer at hand
     float *dcanon_l;
     double count;
@@ -847,6 +848,10 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
         const float *xc = pv.x + cloud;
         xa2 = xc[(size_t)pv.ka * N + nc]; xb2 = pv.kb >= 0 ? xc[(size_t)pv.kb * N + nc] : 0.f;
         u2a = pv.ubuf[((size_t)bi * 2 + 0) * N + nc]; u2b = pv.kb >= 0 ? pv.ubuf[((size_t)bi * 2 + 1) * N + nc] : 0.f;
+        if (pv.ubuf2 != nullptr) {     // (wave-uniform) the mu branch's share, added once: the same rounding in tbwd3f_kernel
+            u2a = __fadd_rn(u2a, pv.ubuf2[((size_t)bi * 2 + 0) * N + nc]);
+            if (pv.kb >= 0) u2b = __fadd_rn(u2b, pv.ubuf2[((size_t)bi * 2 + 1) * N + nc]);
+        }
     }
     const StageRegs<pt_a0n(NS)> wregs = stage_load<pt_a0n(NS)>(a.packed_l, wave, lane);
     const StageRegs<2048> fregs = stage_load<2048>((const uint8_t *)(a.film_l + (size_t)bi * 512), wave, lane);
@@ -1032,7 +1037,11 @@ __device__ unsigned long long *g_tprof = nullptr;
 #else
 #define TP(i)
 #endif
-template <int NS, bool F16 = false>
+// SPLIT (small batches: at most half a workgroup per CU, i.e. B * N / 256 <= 128): the two conditioner branches of a tile run
+// in TWO workgroups (blockIdx.z = branch) -- the kernel's time is one wave's latency through both branches, and the chip is
+// half empty.  Each writes its own rows of part2 (they are per branch anyway) and its own plane of ubuf (u_k of its branch's
+// features; the consumer adds the two planes).
+template <int NS, bool F16 = false, bool SPLIT = false>
 __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__restrict__ pcs, double count, float *__restrict__ dcanon_l,
                                                         const float *__restrict__ dout,
                                                         float *__restrict__ ubuf, float *__restrict__ part2) {
@@ -1055,7 +1064,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
     float m_av[8], m_q3[8], m_q2[8];
     float f_wa[8], f_wb[8], f_bb[8];      // workgroup (0, 0) only: the dW2 / db2 totals it writes (r03: these were 8 dependent round trips
                                           // of loads inside the means' loop -- the one workgroup every launch waited for)
-    const bool first_wg = blockIdx.x == 0 && blockIdx.y == 0;
+    const bool first_wg = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
     // branch-free: a cloud index past the batch is clamped and the value dropped where it is used (predicated loads became
     // exec-masked branches whose joins waited for everything in flight)
 #pragma unroll
@@ -1121,7 +1130,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
         // weight DMA; a dependent tiny launch costs ~4.5 us); workgroup 0 also writes dW2 / db2.  Scratch: redw.
         double (*acc)[5][128] = (double (*)[5][128])redw;
         const int q = mq, br_ = mbr, f_ = mf, g4 = mg4;
-        const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+        const bool first = first_wg;
         double S1 = 0, S2 = 0, w2a = 0, w2b = 0, bb = 0;
         // the first 32 clouds from the registers loaded at the top (straight-line code: inside the loop below the compiler
         // cannot tell these loads from the loop's own and waits for everything in flight, the weights included) ...
@@ -1201,7 +1210,9 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
     float *pts = redw + wave * 2048;                                     // per-wave scratch (free until the reduction): [4][32] per-point values
     const bool two_kept = a.kb >= 0;
     const int tile0 = (blockIdx.x * TW + wave) * TILE;
-    for (int br = 0; br < 2; ++br) {
+    const int br_lo = SPLIT ? (int)blockIdx.z : 0, br_hi = SPLIT ? (int)blockIdx.z + 1 : 2;
+    if (SPLIT) ubuf += (size_t)blockIdx.z * a.B * 2 * N;                   // this branch's plane of u_k
+    for (int br = br_lo; br < br_hi; ++br) {
         TP(0)
         __syncthreads();                                                   // staging landed / previous branch flushed
         TP(1)
@@ -1446,7 +1457,8 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
 __global__ __launch_bounds__(256) void tbwd3f_kernel(int N, int ka, int kb, int nk, double count, const double *__restrict__ tot,
                                                      const float *__restrict__ tcanon_l, const float *__restrict__ stats_l,
                                                      float *__restrict__ dcanon_l, const float *__restrict__ p_in,
-                                                     const float *__restrict__ ubuf, float *__restrict__ dp_in) {
+                                                     const float *__restrict__ ubuf, const float *__restrict__ ubuf2,
+                                                     float *__restrict__ dp_in) {
     __shared__ double acc[2][8];
     __shared__ float coef[8];
     bwd3_coefs(bwd3_loads(nk, tot, tcanon_l, stats_l), blockIdx.y * gridDim.x + blockIdx.x, nk, count, dcanon_l, acc, coef);
@@ -1455,9 +1467,14 @@ __global__ __launch_bounds__(256) void tbwd3f_kernel(int N, int ka, int kb, int 
     const float *pc = p_in + (size_t)bi * 3 * N;
     float *d = dp_in + (size_t)bi * 3 * N;
     const float xa = pc[(size_t)ka * N + n], xb = kb >= 0 ? pc[(size_t)kb * N + n] : 0.f;
-    d[(size_t)ka * N + n] = __fadd_rn(d[(size_t)ka * N + n], cond_path(ubuf[((size_t)bi * 2 + 0) * N + n], coef[0], coef[1], coef[2], xa, xb));
+    float ua = ubuf[((size_t)bi * 2 + 0) * N + n], ub = kb >= 0 ? ubuf[((size_t)bi * 2 + 1) * N + n] : 0.f;
+    if (ubuf2 != nullptr) {            // branch-split pass 2: the mu branch's plane (as in tbwd1_kernel's prologue)
+        ua = __fadd_rn(ua, ubuf2[((size_t)bi * 2 + 0) * N + n]);
+        if (kb >= 0) ub = __fadd_rn(ub, ubuf2[((size_t)bi * 2 + 1) * N + n]);
+    }
+    d[(size_t)ka * N + n] = __fadd_rn(d[(size_t)ka * N + n], cond_path(ua, coef[0], coef[1], coef[2], xa, xb));
     if (kb >= 0)
-        d[(size_t)kb * N + n] = __fadd_rn(d[(size_t)kb * N + n], cond_path(ubuf[((size_t)bi * 2 + 1) * N + n], coef[4], coef[5], coef[6], xa, xb));
+        d[(size_t)kb * N + n] = __fadd_rn(d[(size_t)kb * N + n], cond_path(ub, coef[4], coef[5], coef[6], xa, xb));
 }
 
 
@@ -1499,7 +1516,7 @@ static size_t carve(void *ws, int B, int N, TWork *w) {
     uint8_t *s12 = take(256 * 4);
     uint8_t *part2 = take(nblk * 2 * P2_J * 4);
     uint8_t *dout = take((size_t)B * 4 * N * 4);
-    uint8_t *ubuf = take((size_t)B * 2 * N * 4);
+    uint8_t *ubuf = take((size_t)2 * B * 2 * N * 4);                     // two planes (branch-split pass 2 writes one per branch)
     uint8_t *coef = take(8 * 4);
     if (w) {
         w->xpart = (double *)xpart; w->sums = (double *)sums; w->tot2 = (double *)tot2; w->part1 = (float *)part1;
@@ -1698,8 +1715,18 @@ static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb
     { KScope ks(4, s);
     hipLaunchKernelGGL((tbwd1_kernel<NS, F16>), grid, dim3(TW * 64), lds1, s, a, g_p, g_p2, g_mu, g_lv, mu_l, lv_l, dp_in, w.dout, w.part1, *pv,
                        w.tickets, w.pc, dfm_l); }
+    // small batches: the two branches of pass 2 in two workgroups (at most half a workgroup per CU otherwise)
+    static const int split_env = getenv("DPF_TRAIN_SPLIT") ? atoi(getenv("DPF_TRAIN_SPLIT")) : -1;
+    const bool split2 = split_env >= 0 ? split_env != 0 : nblk <= 128;
+    static LdsLimit lim_b2s;
+    if (split2)
+        if (hipError_t e = lim_b2s.ensure((const void *)tbwd2_kernel<NS, F16, true>, lds2); e != hipSuccess) return (int)e;
     { KScope ks(5, s);
-    hipLaunchKernelGGL((tbwd2_kernel<NS, F16>), grid, dim3(TW * 64), lds2, s, a, w.pc, count, dcanon_l, w.dout, w.ubuf, w.part2); }
+    if (split2)
+        hipLaunchKernelGGL((tbwd2_kernel<NS, F16, true>), dim3(grid.x, grid.y, 2), dim3(TW * 64), lds2, s, a, w.pc, count, dcanon_l, w.dout, w.ubuf, w.part2);
+    else
+        hipLaunchKernelGGL((tbwd2_kernel<NS, F16>), grid, dim3(TW * 64), lds2, s, a, w.pc, count, dcanon_l, w.dout, w.ubuf, w.part2); }
+    const float *ubuf2 = split2 ? w.ubuf + (size_t)B * 2 * N : nullptr;
     { KScope ks(6, s);
     hipLaunchKernelGGL(tcolsum_kernel, dim3((2 * P2_J + 31) / 32), dim3(1024), 0, s, nblk, 2 * P2_J, w.part2, w.tot2, dcanon_l, P2_J); }
     // pass 3 (the conditioner path of d(input points), d gamma0 / d beta0 / dW0 / dW1 from the totals): folded into the NEXT
@@ -1707,9 +1734,9 @@ static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb
     if (last) {
         KScope ks(7, s);
         hipLaunchKernelGGL(tbwd3f_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, N, ka, kb, kb >= 0 ? 2 : 1, count, w.tot2,
-                           tcanon_l, stats_l, dcanon_l, p_in, w.ubuf, dp_in);
+                           tcanon_l, stats_l, dcanon_l, p_in, w.ubuf, ubuf2, dp_in);
     }
-    pv->tot = w.tot2; pv->tcanon_l = tcanon_l; pv->stats_l = stats_l; pv->ubuf = w.ubuf; pv->x = p_in; pv->dcanon_l = dcanon_l;
+    pv->tot = w.tot2; pv->tcanon_l = tcanon_l; pv->stats_l = stats_l; pv->ubuf = w.ubuf; pv->ubuf2 = ubuf2; pv->x = p_in; pv->dcanon_l = dcanon_l;
     pv->count = count; pv->ka = ka; pv->kb = kb; pv->has = 1;
     return (int)hipGetLastError();
 }
