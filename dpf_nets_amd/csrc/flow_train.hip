@@ -721,13 +721,21 @@ constexpr int P2_J = 4352;       // floats of a workgroup's pass-2 partial row p
 // the dW1 totals are converted by whoever comes first (grid-stride).  Ends with a workgroup barrier.
 struct CoefLoads { double Sg, S, Sa, Sb; float ea, eb, caa, cbb, cab, wa, wb, gamma, rstd0, mean0; };
 // the loads of bwd3_coefs (threads < 128), to be issued BEFORE the caller's weight loads
+template <bool AGENT = false>
 __device__ __forceinline__ CoefLoads bwd3_loads(int nk, const double *__restrict__ tot, const float *__restrict__ tcanon_l,
                                                 const float *__restrict__ stats_l) {
     CoefLoads L;
     const int q = threadIdx.x & 127, br = q >> 6, f = q & 63;
     const double *t = tot + (size_t)br * P2_J;
     const float *cb = tcanon_l + br * T_BR;
-    L.Sg = t[f]; L.S = t[64 + f]; L.Sa = t[4224 + f]; L.Sb = t[4288 + f];
+    if (AGENT) {       // written by other workgroups of THIS launch (colsum_role): past this CU's L1 and the XCD's L2
+        L.Sg = __hip_atomic_load(&t[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        L.S = __hip_atomic_load(&t[64 + f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        L.Sa = __hip_atomic_load(&t[4224 + f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        L.Sb = __hip_atomic_load(&t[4288 + f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        L.Sg = t[f]; L.S = t[64 + f]; L.Sa = t[4224 + f]; L.Sb = t[4288 + f];
+    }
     const float *m = stats_l + ST_MOM;
     L.ea = m[0]; L.eb = m[1]; L.caa = m[2]; L.cbb = m[3]; L.cab = m[4];
     L.wa = cb[T_W0 + f * nk]; L.wb = nk == 2 ? cb[T_W0 + f * 2 + 1] : 0.f; L.gamma = cb[T_G0 + f];
@@ -799,30 +807,133 @@ struct PrevLayer {
     float *dcanon_l;
     double count;
     int ka, kb, has;
+    int fused_launches;          // host side: pass-1 launches of this call that carried the layer above's column sums so far
 };
+
+// r04: the column sums of the layer ABOVE's pass-2 partials (the former tcolsum launch between two backward layers) ride in
+// this launch as extra workgroups -- blockIdx.y < cs.rows, dispatched first -- so that the launch boundary
+// tbwd2 -> tcolsum -> tbwd1 becomes tbwd2 -> tbwd1.  The 16 of them that own the 512 totals pass 1 needs (sum dh0a h0n,
+// sum dh0a, sum dh0a x_a, sum dh0a x_b per branch and feature) come first, publish their totals with agent-scope stores and
+// raise a counter; the ordinary workgroups recompute the layer's pre-activations first (that needs nothing from above),
+// then wait for the counter (one lane polls), read the totals past their L1 / L2 (agent scope) and go on.  The other 256
+// column workgroups (the dW1 totals) are waited for by nobody.  If the counter does not arrive (HIP promises no dispatch
+// order; observed: ascending), a workgroup gives up polling and sums the 512 columns itself, in the same order.
+struct ColsumJob {
+    const float *part2;          // (nrows, 2 * P2_J) pass-2 partial rows of the layer above
+    double *tot;                 // 2 * P2_J totals
+    float *dcanon_prev;          // the layer above's gradient block (receives dW1)
+    unsigned *flag;              // arrivals of the critical column workgroups, monotonic over the call
+    unsigned target;             // value of *flag once this launch's 16 have arrived
+    int nrows, rows;             // partial rows; rows of the grid taken by the column workgroups (0 = none in this launch)
+};
+constexpr int CS_CRIT = 16;      // column workgroups (32 columns each) that own the totals pass 1 waits for
+// column block of column workgroup `id`: the critical ones first
+__device__ __forceinline__ int cs_block_of(int id) {
+    constexpr int PB = P2_J / 32;                      // 136 blocks per branch
+    if (id < CS_CRIT) { const int b = id >> 3, k = id & 7; return b * PB + (k < 4 ? k : PB - 8 + k); }
+    int r = id - CS_CRIT;                              // the others in ascending order, skipping those
+    const int b = r >= PB - 8, q = r - b * (PB - 8);
+    return b * PB + 4 + q;
+}
+// one column of the partials, summed exactly as tcolsum_kernel does: 32 row groups (row r in group r & 31, ascending), then
+// the groups in order
+__device__ __forceinline__ void colsum_role(const ColsumJob &cs, int id, uint8_t *smem) {
+    double (*acc)[33] = (double (*)[33])smem;
+    const int J = 2 * P2_J, c = threadIdx.x & 31, rg0 = threadIdx.x >> 5;       // 512 threads: row groups rg0 and rg0 + 16
+    const int j = cs_block_of(id) * 32 + c;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int rg = rg0 + 16 * half;
+        double s = 0;
+        int r = rg;
+        for (; r + 224 < cs.nrows; r += 256) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = cs.part2[(size_t)(r + 32 * k) * J + j];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+        for (; r < cs.nrows; r += 32) s += cs.part2[(size_t)r * J + j];
+        acc[rg][c] = s;
+    }
+    __syncthreads();
+    if (rg0 == 0) {
+        double t = 0;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) t += acc[r][c];
+        __hip_atomic_store(&cs.tot[j], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int b2 = j / P2_J, jj = j - b2 * P2_J;
+        if (jj >= 128 && jj < 128 + 4096) cs.dcanon_prev[b2 * T_BR + T_W1 + jj - 128] = (float)t;
+    }
+    if (id < CS_CRIT) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the totals have left this CU before the counter moves
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(cs.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// ordinary workgroups: wait until the critical totals are there (or produce them)
+__device__ __forceinline__ void colsum_wait(const ColsumJob &cs, int *lds_word) {
+    if (threadIdx.x == 0) {
+        int ok = 0;
+        for (int it = 0; it < (1 << 16); ++it) {
+            if (__hip_atomic_load(cs.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= cs.target) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        *lds_word = ok;
+    }
+    __syncthreads();
+    if (*lds_word) return;
+    // the column workgroups have not run (they were not dispatched first and there is no room beside us): their work for the
+    // 512 columns pass 1 needs, by this workgroup -- one thread per column, the same 32 ordered group sums
+    {
+        const int J = 2 * P2_J, i = threadIdx.x, b = i >> 8, q = i & 255;
+        const int j = b * P2_J + (q < 128 ? q : 4224 - 128 + q);
+        double t = 0;
+        for (int k = 0; k < 32; ++k) {         // (a rolled loop with one accumulator: this path must not cost the kernel registers)
+            double gk = 0;
+            for (int r = k; r < cs.nrows; r += 32) gk += cs.part2[(size_t)r * J + j];
+            t += gk;
+        }
+        __hip_atomic_store(&cs.tot[j], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the same bits the column workgroup writes
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+}
 
 // Pass 1: recompute the layer to h2, differentiate the coupling transform and the output SharedDot.
 //   stores  dout (B,4,N) = d(o_logvar a,b), d(o_mu a,b)         dp_in <- direct term  g * d(p_out)/d(p)
 //   partial sums per workgroup: part1[blk][br][k][64], k = 0 dW2a, 1 dW2b, 2 da, 3 dc;  part1[blk][512 + br*2 + w] = db2
 // the gradient w.r.t. p_out is g_p + g_p2 (either may be NULL = zero, like g_mu and g_lv)
+// (min 4 waves per SIMD = two workgroups per CU: the column workgroups of ColsumJob must find room BESIDE the ordinary ones)
 template <int NS, bool F16 = false>
-__global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__restrict__ g_p, const float *__restrict__ g_p2,
-                                                        const float *__restrict__ g_mu, const float *__restrict__ g_lv,
-                                                        const float *__restrict__ mu_l, const float *__restrict__ lv_l,
-                                                        float *__restrict__ dp_in, float *__restrict__ dout,
-                                                        float *__restrict__ part1, PrevLayer pv, unsigned *__restrict__ tickets,
-                                                        float *__restrict__ pc, float *__restrict__ dfm_l) {
+__global__ __launch_bounds__(TW * 64, 4) void tbwd1_kernel(TArgs a, const float *__restrict__ g_p, const float *__restrict__ g_p2,
+                                                           const float *__restrict__ g_mu, const float *__restrict__ g_lv,
+                                                           const float *__restrict__ mu_l, const float *__restrict__ lv_l,
+                                                           float *__restrict__ dp_in, float *__restrict__ dout,
+                                                           float *__restrict__ part1, PrevLayer pv, unsigned *__restrict__ tickets,
+                                                           float *__restrict__ pc, float *__restrict__ dfm_l, ColsumJob cs) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int L_FILM = pt_a0n(NS), L_FILMB = L_FILM + 2048, L_RED = L_FILMB + 2048;
+    // grid rows [0, cs.rows): the 16 critical column workgroups (dispatched first); rows [cs.rows, cs.rows + B): the clouds;
+    // rows behind them: the other column workgroups (dW1 totals: nobody in this launch waits for them)
+    if (cs.rows > 0 && ((int)blockIdx.y < cs.rows || (int)blockIdx.y >= cs.rows + a.B)) {
+        const int id = (int)blockIdx.y < cs.rows ? (int)(blockIdx.y * gridDim.x + blockIdx.x)
+                                                 : CS_CRIT + (int)((blockIdx.y - cs.rows - a.B) * gridDim.x + blockIdx.x);
+        const bool crit_row = (int)blockIdx.y < cs.rows;
+        if ((crit_row && id < CS_CRIT) || (!crit_row && id < 2 * P2_J / 32)) colsum_role(cs, id, smem);
+        return;
+    }
     float *red = (float *)(smem + L_RED);                                  // per wave [2 br][4][64] + [2][2] (+4 pad)
-    const int bi = blockIdx.y, lane = threadIdx.x & 63, h = lane >> 5, pl = lane & 31;
+    const int bi = (int)blockIdx.y - cs.rows, lane = threadIdx.x & 63, h = lane >> 5, pl = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int h4 = 4 * h;                   // opaque to the optimiser: feature offsets stay "lane base + immediate"
     asm volatile("" : "+v"(h4));      // (as known bits they become OR-ed constants, one live register each)
     KP(1, 0)
     // (unconditional: the host hands valid pointers even when there is no layer above -- `cl = {}` merged with the loaded
     // values cost register copies, i.e. a wait for the loads right here)
-    CoefLoads cl = bwd3_loads(pv.kb >= 0 ? 2 : 1, pv.tot, pv.tcanon_l, pv.stats_l);      // first: results return in order
+    // (with the column sums in this launch -- cs.rows > 0 -- the totals do not exist yet: loaded behind the wait below)
+    CoefLoads cl = {};
+    if (cs.rows == 0) cl = bwd3_loads(pv.kb >= 0 ? 2 : 1, pv.tot, pv.tcanon_l, pv.stats_l);      // first: results return in order
     asm volatile("" ::: "memory");
     // every load of the prologue is requested here, in the order its consumer comes: the pass-3 totals (above), this thread's
     // point (inputs, the layer's stored outputs, the gradients that reach it), then the weights -- one in-order stream
@@ -864,18 +975,23 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
     float *w2s = red + TW * 520;                                                // [2 br][2][64] raw sd2.weight
     if (threadIdx.x < 256) w2s[threadIdx.x] = w2_v;
     float *pcoef = w2s + 256 + TW * 64;                                         // 8 floats behind the per-wave scratch
-    if (pv.has)   // the previous backward layer's pass 3, while the weights land (scratch: the reduction slots, free until the end)
-        bwd3_coefs(cl, blockIdx.y * gridDim.x + blockIdx.x, pv.kb >= 0 ? 2 : 1, pv.count, pv.dcanon_l, (double (*)[8])red, pcoef);
-    if (pv.has) {   // + the conditioner path of the layer above: dx_k = u_k - C_k - alpha_k x_a - beta_k x_b on ITS kept channels
-        // every operation rounded on its own, in tbwd3f_kernel's order (the two launch forms give the same bits)
-        const float ta = cond_path(u2a, pcoef[0], pcoef[1], pcoef[2], xa2, xb2);
-        const float tb = pv.kb >= 0 ? cond_path(u2b, pcoef[4], pcoef[5], pcoef[6], xa2, xb2) : 0.f;
+    const bool fused = cs.rows > 0;       // (kernel argument: uniform)
+    const int wg_lin = bi * gridDim.x + blockIdx.x;
+    auto finish_gp = [&](const CoefLoads &c3) {
+        if (pv.has)   // the previous backward layer's pass 3 (scratch: the reduction slots, free until the end)
+            bwd3_coefs(c3, wg_lin, pv.kb >= 0 ? 2 : 1, pv.count, pv.dcanon_l, (double (*)[8])red, pcoef);
+        if (pv.has) {   // + the conditioner path of the layer above: dx_k = u_k - C_k - alpha_k x_a - beta_k x_b on ITS kept channels
+            // every operation rounded on its own, in tbwd3f_kernel's order (the two launch forms give the same bits)
+            const float ta = cond_path(u2a, pcoef[0], pcoef[1], pcoef[2], xa2, xb2);
+            const float tb = pv.kb >= 0 ? cond_path(u2b, pcoef[4], pcoef[5], pcoef[6], xa2, xb2) : 0.f;
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-            if (c == pv.ka || c == pv.kb) gp[c] = __fadd_rn(gp[c], c == pv.ka ? ta : tb);
-    }
+            for (int c = 0; c < 3; ++c)
+                if (c == pv.ka || c == pv.kb) gp[c] = __fadd_rn(gp[c], c == pv.ka ? ta : tb);
+        }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) gp[c] = valid ? __fadd_rn(gp1[c], gp[c]) : 0.f;
+        for (int c = 0; c < 3; ++c) gp[c] = valid ? __fadd_rn(gp1[c], gp[c]) : 0.f;
+    };
+    if (!fused) finish_gp(cl);            // the totals were there at launch: while the weights land
     stage_store(wregs, smem + L_PACK, wave, lane);
     stage_store(fregs, smem + L_FILM, wave, lane);
     stage_store(fbregs, smem + L_FILMB, wave, lane);
@@ -886,6 +1002,29 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
     KP(1, 2)
     const float *film = (const float *)(smem + L_FILM);
     const float *filmb = (const float *)(smem + L_FILMB);
+    // the pre-activations h1 + D of one branch in the SWAPPED orientation (see below); needs nothing from the layer above
+    auto recompute_pre = [&](int br, f32x16 (&pre)[2]) {
+        f32x16 acc0[2];
+        u32x4 bf[NS][4];
+        input_mfma(smem + L_PACK + pt_a0(NS), br, lane, b0, acc0);
+        split_fragment<true, NS, false, F16>(acc0, bf, a.negone);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float dsh = film[br * FILM_BR_FLOATS + 32 * t + pl];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pre[t][r] = dsh;
+        }
+        chain_mfma_swapped<NS, F16>(smem + L_PACK + PT_A1, br, lane, bf, pre);
+    };
+    f32x16 pre0[2];
+    if (fused) {
+        // branch 0's recomputation first: by the time it is done the critical column workgroups of this launch have long
+        // published their totals (they read 512 columns of the partials; this is ~1 400 instructions)
+        recompute_pre(0, pre0);
+        colsum_wait(cs, (int *)(pcoef + 12));
+        const CoefLoads c3 = bwd3_loads<true>(pv.kb >= 0 ? 2 : 1, pv.tot, pv.tcanon_l, pv.stats_l);
+        finish_gp(c3);
+    }
     // ---- coupling transform and its derivative (flows.py:96-115)
     const bool inverse = a.mode == DPF_MODE_INVERSE;
     float dmu_w[2] = {0.f, 0.f}, dlv_w[2] = {0.f, 0.f};
@@ -929,19 +1068,8 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
         const float doa = br == 0 ? dlv_w[0] : dmu_w[0], dob = br == 0 ? dlv_w[1] : dmu_w[1];
         if (!h) { pts[pl] = doa; pts[32 + pl] = dob; }
         f32x16 pre[2];
-        {
-            f32x16 acc0[2];
-            u32x4 bf[NS][4];
-            input_mfma(smem + L_PACK + pt_a0(NS), br, lane, b0, acc0);
-            split_fragment<true, NS, false, F16>(acc0, bf, a.negone);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const float dsh = film[br * FILM_BR_FLOATS + 32 * t + pl];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) pre[t][r] = dsh;
-            }
-            chain_mfma_swapped<NS, F16>(smem + L_PACK + PT_A1, br, lane, bf, pre);
-        }
+        if (fused && br == 0) { pre[0] = pre0[0]; pre[1] = pre0[1]; }
+        else recompute_pre(br, pre);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         f32x4 doa4[4], dob4[4];
@@ -983,7 +1111,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd1_kernel(TArgs a, const float *__
     }
     KP(1, 3)
     __syncthreads();
-    const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const size_t blk = (size_t)wg_lin;
     for (int i = threadIdx.x; i < 516; i += TW * 64) {
         float t = 0.f;
 #pragma unroll
@@ -1512,7 +1640,7 @@ static size_t carve(void *ws, int B, int N, TWork *w) {
     uint8_t *tot2 = take(2 * P2_J * sizeof(double));
     uint8_t *part1 = take(nblk * 520 * 4);
     uint8_t *pc = take((size_t)B * 520 * 4);
-    uint8_t *tickets = take((size_t)B * 4);
+    uint8_t *tickets = take((size_t)(B + 16) * 4);                      // + the arrival counter of the fused column sums (word B)
     uint8_t *s12 = take(256 * 4);
     uint8_t *part2 = take(nblk * 2 * P2_J * 4);
     uint8_t *dout = take((size_t)B * 4 * N * 4);
@@ -1708,13 +1836,24 @@ static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb
     const dim3 grid((N + TBLK - 1) / TBLK, B);
     const int nblk = grid.x * grid.y;
     const double count = (double)B * N;
-    const int lds1 = pt_a0n(NS) + 4096 + (TW * 520 + 256 + TW * 64 + 8 + 4) * 4, lds2 = l_red(NS) + 4096 + TW * XY_WAVE * 2;
+    const int lds1 = pt_a0n(NS) + 4096 + (TW * 520 + 256 + TW * 64 + 8 + 24) * 4, lds2 = l_red(NS) + 4096 + TW * XY_WAVE * 2;
     static LdsLimit lim_b1, lim_b2;
     if (hipError_t e = lim_b1.ensure((const void *)tbwd1_kernel<NS, F16>, lds1); e != hipSuccess) return (int)e;
     if (hipError_t e = lim_b2.ensure((const void *)tbwd2_kernel<NS, F16>, lds2); e != hipSuccess) return (int)e;
+    // r04: the column sums of the layer above's pass-2 partials ride in this launch (ColsumJob) instead of a tcolsum launch
+    // of their own between the two layers; DPF_TRAIN_FUSE_COLSUM=0 keeps the separate launch
+    static const int fuse_env = getenv("DPF_TRAIN_FUSE_COLSUM") ? atoi(getenv("DPF_TRAIN_FUSE_COLSUM")) : 1;
+    ColsumJob cs = {};
+    dim3 grid1 = grid;
+    if (fuse_env && pv->has) {
+        cs.part2 = w.part2; cs.tot = w.tot2; cs.dcanon_prev = pv->dcanon_l; cs.flag = w.tickets + B; cs.nrows = nblk;
+        cs.target = (unsigned)CS_CRIT * (unsigned)(++pv->fused_launches);
+        cs.rows = (CS_CRIT + (int)grid.x - 1) / (int)grid.x;
+        grid1.y = cs.rows + B + (2 * P2_J / 32 - CS_CRIT + grid.x - 1) / grid.x;
+    }
     { KScope ks(4, s);
-    hipLaunchKernelGGL((tbwd1_kernel<NS, F16>), grid, dim3(TW * 64), lds1, s, a, g_p, g_p2, g_mu, g_lv, mu_l, lv_l, dp_in, w.dout, w.part1, *pv,
-                       w.tickets, w.pc, dfm_l); }
+    hipLaunchKernelGGL((tbwd1_kernel<NS, F16>), grid1, dim3(TW * 64), lds1, s, a, g_p, g_p2, g_mu, g_lv, mu_l, lv_l, dp_in, w.dout, w.part1, *pv,
+                       w.tickets, w.pc, dfm_l, cs); }
     // small batches: the two branches of pass 2 in two workgroups (at most half a workgroup per CU otherwise)
     static const int split_env = getenv("DPF_TRAIN_SPLIT") ? atoi(getenv("DPF_TRAIN_SPLIT")) : -1;
     const bool split2 = split_env >= 0 ? split_env != 0 : nblk <= 128;
@@ -1727,8 +1866,10 @@ static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb
     else
         hipLaunchKernelGGL((tbwd2_kernel<NS, F16>), grid, dim3(TW * 64), lds2, s, a, w.pc, count, dcanon_l, w.dout, w.ubuf, w.part2); }
     const float *ubuf2 = split2 ? w.ubuf + (size_t)B * 2 * N : nullptr;
-    { KScope ks(6, s);
-    hipLaunchKernelGGL(tcolsum_kernel, dim3((2 * P2_J + 31) / 32), dim3(1024), 0, s, nblk, 2 * P2_J, w.part2, w.tot2, dcanon_l, P2_J); }
+    if (!fuse_env || last) {              // (fused: the next backward layer's pass 1 sums these partials; the last layer has none)
+        KScope ks(6, s);
+        hipLaunchKernelGGL(tcolsum_kernel, dim3((2 * P2_J + 31) / 32), dim3(1024), 0, s, nblk, 2 * P2_J, w.part2, w.tot2, dcanon_l, P2_J);
+    }
     // pass 3 (the conditioner path of d(input points), d gamma0 / d beta0 / dW0 / dW1 from the totals): folded into the NEXT
     // backward layer's pass 1, which needs that gradient anyway; only the last layer of the call launches it
     if (last) {
@@ -1769,7 +1910,7 @@ static int backward_stack(int n_layers, int B, int N, int mode, int precision, c
         // memset node the clear was not reliably ordered before the first pass-1 kernel of a replay (zero_fill.h)
         TWork w;
         carve(workspace, B, N, &w);
-        if (hipError_t e = dpf_zero_async(w.tickets, (size_t)B * 4, (hipStream_t)stream); e != hipSuccess) return (int)e;
+        if (hipError_t e = dpf_zero_async(w.tickets, (size_t)(B + 16) * 4, (hipStream_t)stream); e != hipSuccess) return (int)e;
     }
     for (int step = n_layers - 1; step >= 0; --step) {
         const int l = mode == DPF_MODE_DIRECT ? step : n_layers - 1 - step;
