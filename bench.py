@@ -70,6 +70,11 @@ def parse(argv=None):
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--leg", default="eval", choices=["eval", "train"])
     ap.add_argument("--batch", type=int, default=None, help="clouds per GPU (overrides the config)")
+    ap.add_argument("--strong", action="store_true",
+                    help="STRONG scaling of a per-GPU config (cfg2 / cfg4): the config's 32 clouds are the GLOBAL batch, sharded "
+                         "over the ranks (4 per rank at 8 GPUs) -- what an 8-GPU job does to BASELINE's B=32; the default line is "
+                         "weak scaling (32 clouds per rank)")
+    ap.add_argument("--no-proxy", action="store_true", help="skip `extra.per_rank_proxy` of the default run")
     ap.add_argument("--points", type=int, default=None)
     ap.add_argument("--layers", type=int, default=None, help="coupling layers: 14 (BASELINE metric), 15, 63; train leg default 63")
     ap.add_argument("--latent", type=int, default=None)
@@ -187,7 +192,7 @@ def clouds_of_rank(args, rank, world):
     cfg = CONFIGS[args.config]
     if args.batch is not None:
         return args.batch, args.batch * world
-    if cfg["per_gpu"]:
+    if cfg["per_gpu"] and not getattr(args, "strong", False):
         return cfg["clouds"], cfg["clouds"] * world
     from dpf_nets_amd.distributed import shard_bounds
     lo, hi = shard_bounds(cfg["clouds"], rank, world)
@@ -498,6 +503,12 @@ def leg_eval(args, rank, world, dist, device):
     kt_alone = kernel_timings(dec, z, g, tgt_pm, L, args.precision)
     kt = kernel_timings_in_flight(dec, z, g, tgt_pm, L, args.precision, S) if S > 1 else kt_alone
     from dpf_nets_amd.metrics.StructuralLosses import StructuralLossesBackend as BK
+    from dpf_nets_amd._lib import lib as _dpf_lib
+    n16 = _dpf_lib().dpf_flow_tile16_launches()
+    step()
+    torch.cuda.synchronize()
+    tile16 = _dpf_lib().dpf_flow_tile16_launches() > n16      # which tiling of the fused stack serves this batch size
+    flow_name = ("flow16_kernel<%s> (16-point tiles, csrc/flow16.hip)" if tile16 else "flow_kernel<%s>") % args.precision
     dom = max(("flow_kernel", "nn_kernel"), key=lambda k: kt[k])
     flow_flops = FLOP_PER_POINT_LAYER * L * B * N
     flow_ach = flow_flops / (kt["flow_kernel"] * 1e-6) / 1e12
@@ -505,7 +516,7 @@ def leg_eval(args, rank, world, dist, device):
     nn_ach = nn_bytes / (kt["nn_kernel"] * 1e-6) / 1e9
     traffic, tsrc = read_traffic("%s/B%d_N%d_L%d_%s" % (dom, B, N, L, args.precision))
     if dom == "flow_kernel":
-        roof = {"kernel": "flow_kernel<%s>" % args.precision, "bound": "mfma", "achieved": flow_ach,
+        roof = {"kernel": flow_name, "bound": "mfma", "achieved": flow_ach,
                 "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": flow_ach / MFMA_BF16_PEAK_TF,
                 "traffic": traffic,
                 "note": "algorithmic FLOPs (17152/pt/layer) per launch / HIP-event launch duration; the split precision "
@@ -532,13 +543,13 @@ def leg_eval(args, rank, world, dist, device):
         "metric": "points/sec through %d-layer flow + Chamfer, B=%d N=%d" % (L, B, N),
         "value": pts_per_step / (elapsed / args.steps), "unit": "points/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-        "scaling": cfg["scaling"] if args.batch is None else "weak", "vs_baseline": None,
+        "scaling": ("strong" if getattr(args, "strong", False) else cfg["scaling"]) if args.batch is None else "weak", "vs_baseline": None,
         "dtype": args.precision + " MFMA operands, fp32 accumulate/points",
         "data": "synthetic",
         "config": {"workload": "%s: %d coupling layers (first %d of LocalCondRNVPDecoder(n_flows=%d)), direct/eval-BN, + "
                                "nn_distance both directions + CD reduction" % (cfg["name"], L, L, n_flows),
                    "clouds_per_gpu": B, "points_per_cloud": N, "hidden": 64, "latent": args.latent,
-                   "global_clouds": pts_per_step // N, "per_layer_lists": bool(args.lists),
+                   "global_clouds": pts_per_step // N, "per_layer_lists": bool(args.lists), "flow_kernel": flow_name,
                    "launch": ("eager" if args.no_graph else "hipGraph replay, %d step(s) per graph" % G) +
                    (", consecutive steps round-robin over %d streams with their own buffers" % S if S > 1 else ""),
                    "steps_in_flight": S, "settle_steps": args.settle, "parallelism": "clouds sharded, no collective",
@@ -951,7 +962,8 @@ def leg_train(args, rank, world, dist, device):
     tf = info["algorithmic_tflops"]
     line = {"metric": "points/sec through a training step of the %d-layer flow decoder, B=%d N=%d" % (args.layers, batch, args.points),
             "value": info["value"], "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": info["ms_per_step"], "higher_is_better": True, "scaling": cfg["scaling"] if args.batch is None else "weak",
+            "ms_per_step": info["ms_per_step"], "higher_is_better": True,
+            "scaling": ("strong" if getattr(args, "strong", False) else cfg["scaling"]) if args.batch is None else "weak",
             "vs_baseline": None, "dtype": info["precision"] + " MFMA operands, fp32 accumulate/points/gradients",
             "data": "synthetic",
             "config": {"workload": cfg["name"] + ": " + info["what"], "clouds_per_gpu": batch, "points_per_cloud": args.points,
@@ -1002,6 +1014,55 @@ def extra_config_legs(args, rank, world, device):
         except Exception as e:       # noqa: BLE001 -- an extra must never cost the headline line
             out[name + "_error"] = repr(e)
         torch.cuda.empty_cache()
+    return out
+
+
+def per_rank_proxy(args, device):
+    """what ONE rank of an 8-GPU STRONG-scaling run does, measured on this one GPU (the pool has no 8-GPU
+    node for the builder; the driver's SCALE run supplies the real curve): the eval step (FiLM + fused stack + Chamfer + CD)
+    at the 4 clouds a rank holds of BASELINE's B = 32 and at 8 clouds, and the 63-layer training step at the 8 clouds (G = 512) a
+    rank holds of configs[2]'s B = 64 (configs/autoencoding/all_scaled.yaml:5,9).  Projection for 8 GPUs = B_global * N /
+    (t(B_local) + all-reduce): the eval path has no collective; the training step's all-reduce of the flat gradient is
+    MODELLED (not measured here) two ways from SURVEY 8(e)'s link budget -- a ring bound by one 153 GB/s xGMI link, and a
+    direct reduce-scatter + all-gather over all 7 links."""
+    import copy
+    out = {"what": "1-GPU stand-ins for one rank of an 8-GPU strong-scaling job; projections, not measurements of 8 GPUs",
+           "eval": {}, "train": {}}
+    for bl in (4, 8):
+        try:
+            a2 = copy.copy(args)
+            a2.batch, a2.strong = bl, False
+            a2.no_extra, a2.no_cpu_baseline, a2.pipelined, a2.streams = True, True, 0, 1
+            a2.steps, a2.warmup, a2.settle = 400, 100, 200
+            line, _ = leg_eval(a2, 0, 1, None, device)
+            t = line["ms_per_step"] * 1e-3
+            out["eval"]["B_local_%d" % bl] = {
+                "ms_per_step": line["ms_per_step"], "points_per_s_this_gpu": line["value"],
+                "kernels_us": line["roofline"].get("kernels_us"),
+                "flow_kernel": line["config"].get("flow_kernel"),
+                "projected_8gpu_points_per_s": 8 * bl * args.points / t,
+                "global_batch": 8 * bl, "collectives": 0, "parity": line.get("parity")}
+        except Exception as e:       # noqa: BLE001 -- an extra must never cost the headline line
+            out["eval"]["B_local_%d_error" % bl] = repr(e)
+        torch.cuda.empty_cache()
+    try:
+        a3 = copy.copy(args)
+        a3.latent, a3.batch, a3.strong = 512, 8, False
+        info = train_step_leg(a3, 0, 1, None, device, 8, 63, 24, 12)
+        t = info["ms_per_step"] * 1e-3
+        nbytes = info["flat_gradient_bytes"]
+        ring = 2.0 * 7 / 8 * nbytes / (XGMI_LINK_GBS * 1e9)
+        direct = 2.0 * (nbytes / 8) / (XGMI_LINK_GBS * 1e9)
+        out["train"]["B_local_8_G512_L63"] = {
+            "ms_per_step": info["ms_per_step"], "points_per_s_this_gpu": info["value"], "flat_gradient_bytes": nbytes,
+            "replay_equals_eager": info.get("replay_equals_eager"),
+            "kernels_us_per_layer": {k: v.get("us_per_layer") for k, v in (info.get("kernels") or {}).items() if isinstance(v, dict)},
+            "allreduce_model_ms": {"ring_one_link": ring * 1e3, "all_links": direct * 1e3},
+            "projected_8gpu_points_per_s": {"ring_one_link": 64 * args.points / (t + ring), "all_links": 64 * args.points / (t + direct)},
+            "global_batch": 64, "collectives": 1}
+    except Exception as e:       # noqa: BLE001
+        out["train"]["B_local_8_G512_L63_error"] = repr(e)
+    torch.cuda.empty_cache()
     return out
 
 
@@ -1057,6 +1118,11 @@ def main(argv=None):
                 extra["train_step"] = train_step_leg(args, rank, world, dist, device, batch, 63, args.train_steps, 16)
             except Exception as e:       # noqa: BLE001 -- never lose the headline line to an extra
                 extra["train_step_error"] = repr(e)
+        if not args.no_extra and not args.no_proxy and world == 1 and args.config == "cfg2" and args.layers == 14 and args.batch is None:
+            try:                                         # rank-local, no collective: the single-GPU run only
+                extra["per_rank_proxy"] = per_rank_proxy(args, device)
+            except Exception as e:       # noqa: BLE001
+                extra["per_rank_proxy_error"] = repr(e)
     if rank == 0:
         if extra:
             line["extra"] = extra
