@@ -72,7 +72,9 @@ constexpr int PT_A1 = 0;                                                   // W1
 __host__ __device__ constexpr int pt_a0(int NS) { return NS * P_A1_PART; }           // input MFMA, gamma*rstd0 / beta
 __host__ __device__ constexpr int pt_a0n(int NS) { return pt_a0(NS) + 4096; }        // input MFMA -> NORMALISED h0
 __host__ __device__ constexpr int pt_a1t(int NS) { return pt_a0(NS) + 8192; }        // W1^T fragments, hi | lo
-__host__ __device__ constexpr int pt_bytes(int NS) { return pt_a1t(NS) + 2 * P_A1_PART; }
+__host__ __device__ constexpr int pt_tail(int NS) { return pt_a1t(NS) + 2 * P_A1_PART; }   // 1 KiB (a whole staging piece): [br] 2^-kw of the fp16 W1^T
+// (the two-part precisions only: with three forward parts pass 2 already uses all 160 KiB of LDS, and bf16x6 does not read it)
+__host__ __device__ constexpr int pt_bytes(int NS) { return pt_tail(NS) + (NS == 2 ? 1024 : 0); }
 
 // ---- per-layer saved statistics (floats) ---------------------------------------------------------
 // stats[br][k][64]: k = 0 mean0, 1 rstd0, 2 mean1, 3 rstd1, 4 batch var0 (unbiased), 5 batch var1 (unbiased)
@@ -99,6 +101,24 @@ __global__ __launch_bounds__(256) void tpack_kernel(const float *__restrict__ tc
     const float *cl = tcanon + (size_t)l * T_LAYER;
     uint16_t *o1 = (uint16_t *)(packed + (size_t)l * pt_bytes(NS) + PT_A1);
     uint16_t *oT = (uint16_t *)(packed + (size_t)l * pt_bytes(NS) + pt_a1t(NS));
+    __shared__ float wmax[2][256], wscale[2];
+    {   // largest |W1| per branch -> the power-of-two scale of the fp16 W1^T fragments (1 when the branch is all zeros)
+#pragma unroll
+        for (int br = 0; br < 2; ++br) {
+            float m = 0.f;
+            for (int i = threadIdx.x; i < 4096; i += 256) m = fmaxf(m, fabsf(cl[br * T_BR + T_W1 + i]));
+            wmax[br][threadIdx.x] = m;
+        }
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            float m = 0.f;
+            for (int i = 0; i < 256; ++i) m = fmaxf(m, wmax[threadIdx.x][i]);
+            int e = (int)((f2u(m) >> 23) & 0xFFu) - 127;                   // m in [2^e, 2^(e+1))
+            const bool ok = m > 0.f && e > -100 && e < 100;
+            wscale[threadIdx.x] = ok ? u2f((uint32_t)(127 + 13 - e) << 23) : 1.0f;
+        }
+        __syncthreads();
+    }
     for (int idx = threadIdx.x; idx < 2 * 2 * 4 * 64 * 8; idx += blockDim.x) {
         const int j = idx & 7, lane = (idx >> 3) & 63, s = (idx >> 9) & 3, tp = (idx >> 11) & 1, br = idx >> 12;
         const int i = lane & 31, h = lane >> 5;
@@ -120,9 +140,22 @@ __global__ __launch_bounds__(256) void tpack_kernel(const float *__restrict__ tc
             o1[P_A1_PART + idx] = (uint16_t)bf16_rne(r2);
         }
         const float wt = W1[fk * 64 + (32 * tp + i)];               // transposed: rows = in feature, K = out feature
-        oT[idx] = (uint16_t)(split_hi(wt, r1) >> 16);
-        oT[P_A1_PART / 2 + idx] = (uint16_t)bf16_rne(r1);
+        if (F16) {
+            // r04: the gradient contractions of an f16x3 stack take fp16 hi + fp16 lo operands (22 significant bits instead of
+            // the 16 of a bf16 hi/lo pair).  W1 is scaled by a power of two per (layer, branch) so that its largest entry sits in
+            // [2^13, 2^14): hi AND lo are normal fp16 numbers for every entry within 2^-11 of the largest (at the init scale
+            // of 0.01 the unscaled remainders were fp16 subnormals: ~17 bits); the consumer multiplies by 2^-kw (exact).
+            const float ws = wt * wscale[br];
+            const _Float16 wh = (_Float16)ws;
+            const _Float16 wl = (_Float16)(ws - (float)wh);
+            oT[idx] = __builtin_bit_cast(uint16_t, wh);
+            oT[P_A1_PART / 2 + idx] = __builtin_bit_cast(uint16_t, wl);
+        } else {
+            oT[idx] = (uint16_t)(split_hi(wt, r1) >> 16);
+            oT[P_A1_PART / 2 + idx] = (uint16_t)bf16_rne(r1);
+        }
     }
+    if (NS == 2 && threadIdx.x < 2) ((float *)(packed + (size_t)l * pt_bytes(NS) + pt_tail(NS)))[threadIdx.x] = 1.0f / wscale[threadIdx.x];
 }
 
 // ===================================================================================================
@@ -377,6 +410,33 @@ __device__ __forceinline__ void input_mfma_swapped(const uint8_t *a0, int br, in
 __device__ __forceinline__ void split_pair_sym(float v0, float v1, uint32_t &hi, uint32_t &lo) {
     hi = pack_bf16_rne(v0, v1);
     lo = pack_bf16_rne(v0 - u2f(hi << 16), v1 - u2f(hi & 0xFFFF0000u));
+}
+
+// the same for fp16 hi/lo operands (r04: the gradient contractions of an f16x3 stack): hi = fp16(x) and lo = fp16(x - hi), both
+// round-to-nearest-even -- one v_cvt_pk_f16_f32 and the two v_fma_mix*_f16 of split_relu_f16 (`negone`: see there).  x must
+// be scaled into fp16's range by the caller; 11 + 11 bits for |x| >= 2^-3, the absolute 2^-24 of fp16's subnormals below.
+__device__ __forceinline__ void split_pair_sym_f16(float v0, float v1, float negone, uint32_t &hi, uint32_t &lo) {
+    const f32x2 v = {v0, v1};
+    const f16x2 h = __builtin_convertvector(v, f16x2);
+    const f16x2 l = {(_Float16)__builtin_fmaf((float)h[0], negone, v0), (_Float16)__builtin_fmaf((float)h[1], negone, v1)};
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+template <bool RELU>
+__device__ __forceinline__ void kfrags_from_swapped_f16(const f32x16 (&v)[2], float scale, float negone, u32x4 (&hi)[2][2], u32x4 (&lo)[2][2]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const float v0 = (RELU ? relu(v[t][8 * j2 + 2 * d]) : v[t][8 * j2 + 2 * d]) * scale;
+                const float v1 = (RELU ? relu(v[t][8 * j2 + 2 * d + 1]) : v[t][8 * j2 + 2 * d + 1]) * scale;
+                uint32_t hp, lp;
+                split_pair_sym_f16(v0, v1, negone, hp, lp);
+                hi[t][j2][d] = hp;
+                lo[t][j2][d] = lp;
+            }
 }
 
 template <bool RELU>
@@ -1333,7 +1393,8 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const int p0 = ((2 * d) & 3) + 8 * (2 * j2 + ((2 * d) >> 2)) + 4 * h, p1 = p0 + 1;
-            eye[j2][d] = (pl == p0 ? 0x3F80u : 0u) | (pl == p1 ? 0x3F800000u : 0u);
+            eye[j2][d] = F16 ? ((pl == p0 ? 0x3C00u : 0u) | (pl == p1 ? 0x3C000000u : 0u))     // 1.0 as fp16 / as bf16
+                             : ((pl == p0 ? 0x3F80u : 0u) | (pl == p1 ? 0x3F800000u : 0u));
         }
     float *pts = redw + wave * 2048;                                     // per-wave scratch (free until the reduction): [4][32] per-point values
     const bool two_kept = a.kb >= 0;
@@ -1367,6 +1428,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
         __builtin_amdgcn_wave_barrier();
         // ---- dh1 = rstd1 * (dh1n - mean(dh1n) - h1n * mean(dh1n*h1n)),  dh1n = a*dh2a,  h1n = pre*rstd1 - c/a   (in place)
         u32x4 xh[2][2], xl[2][2];                                          // dh1 as K = points fragments [feature tile][k-step]
+        float gscale = 1.0f, ginv = 1.0f;                                  // F16: power-of-two scale of this tile's dh1 and its inverse
         {
             f32x4 doa4[4], dob4[4];
 #pragma unroll
@@ -1393,7 +1455,25 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
 #pragma unroll
                     for (int r = 0; r < 16; ++r) pre[t][r] = tile0 + (r & 3) + 8 * (r >> 2) + 4 * h < N ? pre[t][r] : 0.f;
             }
-            kfrags_from_swapped<false>(pre, xh, xl);
+            if constexpr (F16) {
+                // fp16 operands need the values in fp16's range: the largest |dh1| of this wave's tile (64 features x 32 points)
+                // goes to [2^13, 2^14) -- a power of two, so scaling and unscaling are exact and every element within 2^16 of the
+                // largest keeps 22 significant bits
+                float m = 0.f;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(pre[t][r]));
+                for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+                const uint32_t mb = __builtin_amdgcn_readfirstlane(f2u(m));
+                const int e = (int)((mb >> 23) & 0xFFu) - 127;
+                const bool ok = mb != 0u && e > -100 && e < 100;           // (zero, denormal-tiny, Inf / NaN tiles: no scaling)
+                gscale = ok ? u2f((uint32_t)(127 + 13 - e) << 23) : 1.0f;
+                ginv = ok ? u2f((uint32_t)(127 - 13 + e) << 23) : 1.0f;
+                kfrags_from_swapped_f16<false>(pre, gscale, a.negone, xh, xl);
+            } else {
+                kfrags_from_swapped<false>(pre, xh, xl);
+            }
         }
         TP(3)
         // ---- dh1 back to lane = point (an MFMA against the identity: hi + lo is exact), split, dh0 = W1^T dh1 in BOTH
@@ -1406,10 +1486,17 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
             f32x16 dnh[2], dnl[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                dnh[t] = mfma(xh[t][0], eye[0], zero16());
-                dnl[t] = mfma(xl[t][0], eye[0], zero16());
-                dnh[t] = mfma(xh[t][1], eye[1], dnh[t]);
-                dnl[t] = mfma(xl[t][1], eye[1], dnl[t]);
+                if constexpr (F16) {
+                    dnh[t] = mfma_f16(xh[t][0], eye[0], zero16());
+                    dnl[t] = mfma_f16(xl[t][0], eye[0], zero16());
+                    dnh[t] = mfma_f16(xh[t][1], eye[1], dnh[t]);
+                    dnl[t] = mfma_f16(xl[t][1], eye[1], dnl[t]);
+                } else {
+                    dnh[t] = mfma(xh[t][0], eye[0], zero16());
+                    dnl[t] = mfma(xl[t][0], eye[0], zero16());
+                    dnh[t] = mfma(xh[t][1], eye[1], dnh[t]);
+                    dnl[t] = mfma(xl[t][1], eye[1], dnl[t]);
+                }
             }
             if (br == 0) KP(4, 0)
 #pragma unroll
@@ -1417,14 +1504,19 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const int s = 2 * t + (r >> 3), d = (r & 7) >> 1;          // as split_fragment
-                    bg[0][s][d] = pack_bf16_trunc(dnh[t][r], dnh[t][r + 1]);
-                    bg[1][s][d] = pack_bf16_trunc(dnl[t][r], dnl[t][r + 1]);
+                    if constexpr (F16) {            // each value IS an fp16 number: the conversion is exact
+                        bg[0][s][d] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(dnh[t][r], dnh[t][r + 1]));
+                        bg[1][s][d] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(dnl[t][r], dnl[t][r + 1]));
+                    } else {
+                        bg[0][s][d] = pack_bf16_trunc(dnh[t][r], dnh[t][r + 1]);
+                        bg[1][s][d] = pack_bf16_trunc(dnl[t][r], dnl[t][r + 1]);
+                    }
                 }
             if (br == 0) KP(4, 1)
         }
         {
             f32x16 dh0a[2] = {zero16(), zero16()};
-            chain_mfma<2>(smem + L_PACK + pt_a1t(NS), br, lane, bg, dh0a);
+            chain_mfma<2, F16>(smem + L_PACK + pt_a1t(NS), br, lane, bg, dh0a);
             if (br == 0) KP(4, 2)
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -1434,6 +1526,8 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
             // the chain's last result and chunked (see the r02 note on scratch spills)
             int h4u = h4;
             asm volatile("" : "+v"(h4u) : "v"(dh0a[1][15]));
+            // (F16: dh0a carries the tile's scale and W1^T's; this branch's share of u_k is summed on its own and unscaled once)
+            float uas = F16 ? 0.f : ua, ubs = F16 ? 0.f : ub;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -1442,20 +1536,26 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
 #pragma unroll
                     for (int q = 2 * rh; q < 2 * rh + 2; ++q) {
                         const f32x4 ca = *(const f32x4 *)(c0 + 8 * q);
-                        ua += ca.x * dh0a[t][4 * q + 0];
-                        ua += ca.y * dh0a[t][4 * q + 1];
-                        ua += ca.z * dh0a[t][4 * q + 2];
-                        ua += ca.w * dh0a[t][4 * q + 3];
+                        uas += ca.x * dh0a[t][4 * q + 0];
+                        uas += ca.y * dh0a[t][4 * q + 1];
+                        uas += ca.z * dh0a[t][4 * q + 2];
+                        uas += ca.w * dh0a[t][4 * q + 3];
                         if (two_kept) {                                    // wave-uniform: layers of pattern 1 keep one channel
                             const f32x4 cb = *(const f32x4 *)(c0 + 64 + 8 * q);
-                            ub += cb.x * dh0a[t][4 * q + 0];
-                            ub += cb.y * dh0a[t][4 * q + 1];
-                            ub += cb.z * dh0a[t][4 * q + 2];
-                            ub += cb.w * dh0a[t][4 * q + 3];
+                            ubs += cb.x * dh0a[t][4 * q + 0];
+                            ubs += cb.y * dh0a[t][4 * q + 1];
+                            ubs += cb.z * dh0a[t][4 * q + 2];
+                            ubs += cb.w * dh0a[t][4 * q + 3];
                         }
                     }
-                    asm volatile("" : "+v"(h4u) : "v"(ua), "v"(ub));
+                    asm volatile("" : "+v"(h4u) : "v"(uas), "v"(ubs));
                 }
+            if constexpr (F16) {
+                const float un = ginv * *(const float *)(smem + L_PACK + pt_tail(NS) + 4 * br);
+                ua += uas * un; ub += ubs * un;
+            } else {
+                ua = uas; ub = ubs;
+            }
             if (br == 0) KP(4, 3)
         }
         TP(4)
@@ -1464,7 +1564,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
         {
             input_mfma_swapped(smem + L_PACK + pt_a0(NS), br, lane, b0, h0s);
             f32x16 dh0s[2] = {zero16(), zero16()};
-            chain_mfma_swapped<2>(smem + L_PACK + pt_a1t(NS), br, lane, bg, dh0s);
+            chain_mfma_swapped<2, F16>(smem + L_PACK + pt_a1t(NS), br, lane, bg, dh0s);
             f32x16 h0n[2];
             input_mfma_swapped(smem + L_PACK + pt_a0n(NS), br, lane, b0, h0n);   // normalised h0
             f32x4 xa4[4], xb4[4];
@@ -1479,6 +1579,10 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
                     s0 += d * h0n[t][r]; s1 += d; s2 += d * xa4[r >> 2][r & 3];
                     if (two_kept) s3 += d * xb4[r >> 2][r & 3];
                 }
+                if constexpr (F16) {            // dh0s carries the tile's scale and W1^T's (powers of two: exact)
+                    const float un = ginv * *(const float *)(smem + L_PACK + pt_tail(NS) + 4 * br);
+                    s0 *= un; s1 *= un; s2 *= un; s3 *= un;
+                }
                 rsum[t][0] = s0 + __shfl_xor(s0, 32); rsum[t][1] = s1 + __shfl_xor(s1, 32);
                 rsum[t][2] = s2 + __shfl_xor(s2, 32); rsum[t][3] = s3 + __shfl_xor(s3, 32);
             }
@@ -1489,17 +1593,34 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
         f32x16 dw[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};     // [fo tile][fi tile]
         {
             u32x4 yh[2][2], yl[2][2];
-            kfrags_from_swapped<true>(h0s, yh, yl);
+            // F16: relu(h0) x 16 as fp16 hi/lo (|BN0(h0)| < 2048 is what the f16x3 range monitor guarantees: 32768 < 65504)
+            if constexpr (F16) kfrags_from_swapped_f16<true>(h0s, 16.0f, a.negone, yh, yl);
+            else kfrags_from_swapped<true>(h0s, yh, yl);
 #pragma unroll
             for (int j2 = 0; j2 < 2; ++j2)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
-                        dw[mt][nt] = mfma(xl[mt][j2], yh[nt][j2], dw[mt][nt]);
-                        dw[mt][nt] = mfma(xh[mt][j2], yl[nt][j2], dw[mt][nt]);
-                        dw[mt][nt] = mfma(xh[mt][j2], yh[nt][j2], dw[mt][nt]);
+                        if constexpr (F16) {
+                            dw[mt][nt] = mfma_f16(xl[mt][j2], yh[nt][j2], dw[mt][nt]);
+                            dw[mt][nt] = mfma_f16(xh[mt][j2], yl[nt][j2], dw[mt][nt]);
+                            dw[mt][nt] = mfma_f16(xh[mt][j2], yh[nt][j2], dw[mt][nt]);
+                        } else {
+                            dw[mt][nt] = mfma(xl[mt][j2], yh[nt][j2], dw[mt][nt]);
+                            dw[mt][nt] = mfma(xh[mt][j2], yl[nt][j2], dw[mt][nt]);
+                            dw[mt][nt] = mfma(xh[mt][j2], yh[nt][j2], dw[mt][nt]);
+                        }
                     }
+            if constexpr (F16) {                 // back to the true scale before the waves' tiles are added (each has its own)
+                const float un = ginv * 0.0625f;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) dw[mt][nt][r] *= un;
+            }
         }
         TP(6)
         // ---- workgroup reduction through per-wave LDS slots (plain stores: LDS float atomics are ~1000 cycles per wave

@@ -14,6 +14,11 @@ from oracle import model_oracle as MO
 
 pytestmark = pytest.mark.gpu
 
+# elementwise-relative error the whole model's parameter gradients are held to through their (sum, random projection, 1-norm)
+# goldens (tests/gradcheck.py): decoder f16x3 with fp16 hi/lo gradient operands, encoder / prior flow at their own split
+# precisions, one training step of the reference's model
+MODEL_GRAD_TOL = 1e-3
+
 
 def _build(nets, cfg, st):
     dev = torch.device("cuda", 0)
@@ -199,12 +204,10 @@ def test_training_forward_backward_through_hip_vs_reference_model_golden(golden_
         grads = named_grads()
         assert sorted(grads) == sorted(names) and all(g is not None for g in grads.values())
         worst = 0.0
-        for k, v in _grad_projection([(k, grads[k].detach().cpu()) for k in names], 23).items():
-            ref = gold["gradproj/" + k]
-            for j in range(3):
-                err = abs(v[j] - ref[j]) / (ref[2] + 1e-6)
-                worst = max(worst, err)
-                assert abs(v[j] - ref[j]) <= 3e-3 * (ref[2] + 1e-6) + 1e-4, (tag, k, j, v, ref)
+        from tests.gradcheck import check_projections
+        cpu_grads = {k: grads[k].detach().cpu() for k in names}
+        check_projections(cpu_grads, _grad_projection([(k, cpu_grads[k]) for k in names], 23), lambda k: gold["gradproj/" + k],
+                          MODEL_GRAD_TOL, tag)
         # ---- BatchNorm running statistics / counters after ONE step (the first call)
         if call == 0:
             nbuf = 0
@@ -258,10 +261,10 @@ def test_model_mirror_training_step_on_gpu_vs_reference_golden(golden_dir, overl
         arena.allreduce()                                 # single process: sync() only
         got = np.array([float(v.detach()) for v in (loss, pnll, gnll, gent)])
         np.testing.assert_allclose(got, gold["loss"], rtol=5e-5, err_msg="call %d" % call)
-        for k, v in _grad_projection([(k, p.grad.detach().cpu()) for k, p in model.named_parameters()], 23).items():
-            ref = gold["gradproj/" + k]
-            for j in range(3):
-                assert abs(v[j] - ref[j]) <= 3e-3 * (ref[2] + 1e-6) + 1e-4, (call, k, j, v, ref)
+        from tests.gradcheck import check_projections
+        cpu_grads = {k: p.grad.detach().cpu() for k, p in model.named_parameters()}
+        check_projections(cpu_grads, _grad_projection(list(cpu_grads.items()), 23), lambda k: gold["gradproj/" + k],
+                          MODEL_GRAD_TOL, "call %d" % call)
         for k, p in model.named_parameters():             # every .grad lives in the ONE message buffer
             assert p.grad.untyped_storage().data_ptr() == arena.buf.untyped_storage().data_ptr(), k
         bufs.append(arena.buf.clone())
