@@ -11,7 +11,7 @@
 // split of the candidate (cx,cy,cz) against the hi/lo split of -2q (4 product
 // terms per coordinate) and a 3-way split of |c|^2 against 1.  s differs from
 // the true distance by at most E = 2^-14 * R2 (R2 = largest squared norm of the
-// two clouds; derivation in DESIGN.md 4.3), so the fp32-exact minimiser -- and
+// two clouds; derivation in docs/DESIGN_history_r01_r03.md 4.3), so the fp32-exact minimiser -- and
 // every exact tie -- has s <= s_min + tau with tau = 2^-12 * R2.  ONE sweep over
 // the candidate tiles: per tile one MFMA and a v_min3 tree over the accumulator
 // fragment (0.5 VALU op per pair); a tile whose minimum is within tau of the

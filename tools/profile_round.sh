@@ -26,3 +26,8 @@ python3 bench.py --no-graph --no-extra --no-cpu-baseline > $OUT/bench_eager.json
 bash tools/train_prof.sh ${TAG}_prof/train > /dev/null 2>&1
 bash tools/pmc_train.sh ${TAG}_prof/pmc_train > /dev/null 2>&1
 ls -la $OUT $OUT/train
+# r04: the rank-sized batch (4 clouds: what a rank of an 8-GPU job holds of BASELINE's 32) -- kernel trace and the two SQ counter
+# passes of the 16-point-tile stack (csrc/flow16.hip) and the small-batch Chamfer scan
+bash tools/kt_run.sh ${TAG}_prof/kernel_trace_stats_b4 --batch 4 --no-cpu-baseline --no-extra --pipelined 0 --steps 300 --warmup 50 --settle 100 > /dev/null 2>&1
+bash tools/pmc_run.sh ${TAG}_prof/pmc_b4 --batch 4 > /dev/null 2>&1
+ls -la $OUT
