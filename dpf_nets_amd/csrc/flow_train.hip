@@ -608,6 +608,7 @@ struct TArgs {
 
 // h1 = W1 relu(BN0(W0 x)) for every point; per-workgroup partial sums and sums of squares
 //   part[blk][br][2][64]
+// (gridDim.z == 2, small batches -- at most half a workgroup per CU: one conditioner branch per workgroup, as tbwd2_kernel)
 template <int NS, bool F16 = false>
 __global__ __launch_bounds__(TW * 64) void tstats_h1_kernel(TArgs a, float *__restrict__ part, int nblk_x, double count,
                                                             const double *__restrict__ xpart, uint8_t *__restrict__ packed_a0) {
@@ -630,7 +631,7 @@ __global__ __launch_bounds__(TW * 64) void tstats_h1_kernel(TArgs a, float *__re
 #pragma unroll
         for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(bl.ld[k][i]));
     {
-        const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+        const bool first = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
         bn0_fold(bl, count, smem + pt_a0(NS), first ? packed_a0 : nullptr, first ? const_cast<float *>(a.stats_l) : nullptr);
     }
     const u32x4 b0 = input_fragment(h ? xb : xa, h);
@@ -638,8 +639,9 @@ __global__ __launch_bounds__(TW * 64) void tstats_h1_kernel(TArgs a, float *__re
     KP(0, 1)
     __syncthreads();
     KP(0, 2)
-#pragma unroll
-    for (int br = 0; br < 2; ++br) {
+    const bool split = gridDim.z == 2;
+    const int br_lo = split ? (int)blockIdx.z : 0, br_hi = split ? (int)blockIdx.z + 1 : 2;
+    for (int br = br_lo; br < br_hi; ++br) {
         f32x16 acc0[2], acc1[2] = {zero16(), zero16()};
         u32x4 bf[NS][4];
         input_mfma(smem + pt_a0(NS), br, lane, b0, acc0);
@@ -671,7 +673,7 @@ __global__ __launch_bounds__(TW * 64) void tstats_h1_kernel(TArgs a, float *__re
     }
     KP(0, 3)
     __syncthreads();
-    if (threadIdx.x < 256) {
+    if (threadIdx.x < 256 && (int)(threadIdx.x >> 7) >= br_lo && (int)(threadIdx.x >> 7) < br_hi) {     // this workgroup's branch(es) of the row
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < TW; ++w) t += ((const float *)acc_s)[w * 256 + threadIdx.x];
@@ -965,7 +967,7 @@ __device__ __forceinline__ void colsum_wait(const ColsumJob &cs, int *lds_word) 
 //   partial sums per workgroup: part1[blk][br][k][64], k = 0 dW2a, 1 dW2b, 2 da, 3 dc;  part1[blk][512 + br*2 + w] = db2
 // the gradient w.r.t. p_out is g_p + g_p2 (either may be NULL = zero, like g_mu and g_lv)
 // (min 4 waves per SIMD = two workgroups per CU: the column workgroups of ColsumJob must find room BESIDE the ordinary ones)
-template <int NS, bool F16 = false>
+template <int NS, bool F16 = false, bool BSPLIT = false>
 __global__ __launch_bounds__(TW * 64, 4) void tbwd1_kernel(TArgs a, const float *__restrict__ g_p, const float *__restrict__ g_p2,
                                                            const float *__restrict__ g_mu, const float *__restrict__ g_lv,
                                                            const float *__restrict__ mu_l, const float *__restrict__ lv_l,
@@ -976,7 +978,10 @@ __global__ __launch_bounds__(TW * 64, 4) void tbwd1_kernel(TArgs a, const float 
     constexpr int L_FILM = pt_a0n(NS), L_FILMB = L_FILM + 2048, L_RED = L_FILMB + 2048;
     // grid rows [0, cs.rows): the 16 critical column workgroups (dispatched first); rows [cs.rows, cs.rows + B): the clouds;
     // rows behind them: the other column workgroups (dW1 totals: nobody in this launch waits for them)
+    // BSPLIT (gridDim.z == 2), small batches: one conditioner branch per workgroup (blockIdx.z), as tbwd2_kernel
+    const int br_lo = BSPLIT ? (int)blockIdx.z : 0, br_hi = BSPLIT ? (int)blockIdx.z + 1 : 2;
     if (cs.rows > 0 && ((int)blockIdx.y < cs.rows || (int)blockIdx.y >= cs.rows + a.B)) {
+        if (blockIdx.z != 0) return;
         const int id = (int)blockIdx.y < cs.rows ? (int)(blockIdx.y * gridDim.x + blockIdx.x)
                                                  : CS_CRIT + (int)((blockIdx.y - cs.rows - a.B) * gridDim.x + blockIdx.x);
         const bool crit_row = (int)blockIdx.y < cs.rows;
@@ -1039,7 +1044,7 @@ __global__ __launch_bounds__(TW * 64, 4) void tbwd1_kernel(TArgs a, const float 
     const int wg_lin = bi * gridDim.x + blockIdx.x;
     auto finish_gp = [&](const CoefLoads &c3) {
         if (pv.has)   // the previous backward layer's pass 3 (scratch: the reduction slots, free until the end)
-            bwd3_coefs(c3, wg_lin, pv.kb >= 0 ? 2 : 1, pv.count, pv.dcanon_l, (double (*)[8])red, pcoef);
+            bwd3_coefs(c3, wg_lin + (int)blockIdx.z, pv.kb >= 0 ? 2 : 1, pv.count, pv.dcanon_l, (double (*)[8])red, pcoef);   // (its writer: workgroup 0 of z = 0)
         if (pv.has) {   // + the conditioner path of the layer above: dx_k = u_k - C_k - alpha_k x_a - beta_k x_b on ITS kept channels
             // every operation rounded on its own, in tbwd3f_kernel's order (the two launch forms give the same bits)
             const float ta = cond_path(u2a, pcoef[0], pcoef[1], pcoef[2], xa2, xb2);
@@ -1078,9 +1083,9 @@ __global__ __launch_bounds__(TW * 64, 4) void tbwd1_kernel(TArgs a, const float 
     };
     f32x16 pre0[2];
     if (fused) {
-        // branch 0's recomputation first: by the time it is done the critical column workgroups of this launch have long
-        // published their totals (they read 512 columns of the partials; this is ~1 400 instructions)
-        recompute_pre(0, pre0);
+        // the first branch's recomputation first: by the time it is done the critical column workgroups of this launch have
+        // long published their totals (they read 512 columns of the partials; this is ~1 400 instructions)
+        recompute_pre(br_lo, pre0);
         colsum_wait(cs, (int *)(pcoef + 12));
         const CoefLoads c3 = bwd3_loads<true>(pv.kb >= 0 ? 2 : 1, pv.tot, pv.tcanon_l, pv.stats_l);
         finish_gp(c3);
@@ -1108,12 +1113,12 @@ __global__ __launch_bounds__(TW * 64, 4) void tbwd1_kernel(TArgs a, const float 
             dmu = gm[c] + gp[c];
             dlv = gl[c] + gp[c] * p[c] * (0.5f * e / s);
         }
-        if (valid && h == 0) dp_in[cloud + (size_t)c * N + n] = dpc;       // direct term; pass 3 adds the conditioner path
+        if (valid && h == 0 && blockIdx.z == 0) dp_in[cloud + (size_t)c * N + n] = dpc;       // direct term; pass 3 adds the conditioner path
         const float dsoft = (1.0f - fabsf(lv)) * (1.0f - fabsf(lv));
         if (isa) { dmu_w[0] = dmu; dlv_w[0] = dlv * dsoft; }
         if (isb) { dmu_w[1] = dmu; dlv_w[1] = dlv * dsoft; }
     }
-    if (valid) {                                                           // half 0 stores the logvar pair, half 1 the mu pair
+    if (valid && blockIdx.z == 0) {                                        // half 0 stores the logvar pair, half 1 the mu pair
         float *d = dout + ((size_t)bi * 4 + 2 * h) * N + n;
         d[0] = h ? dmu_w[0] : dlv_w[0];
         d[N] = h ? dmu_w[1] : dlv_w[1];
@@ -1123,12 +1128,11 @@ __global__ __launch_bounds__(TW * 64, 4) void tbwd1_kernel(TArgs a, const float 
     // the same bits) -- the per-feature constants are per-lane and the sums over the tile's points are in-lane adds plus one
     // cross-half add, where the lane = point layout needed four 31-shuffle butterflies per branch
     float *pts = w2s + 256 + wave * 64;                                    // per-wave scratch: d(o) of the tile's 32 points [2][32]
-#pragma unroll
-    for (int br = 0; br < 2; ++br) {
+    auto branch_sums = [&](const int br) {
         const float doa = br == 0 ? dlv_w[0] : dmu_w[0], dob = br == 0 ? dlv_w[1] : dmu_w[1];
         if (!h) { pts[pl] = doa; pts[32 + pl] = dob; }
         f32x16 pre[2];
-        if (fused && br == 0) { pre[0] = pre0[0]; pre[1] = pre0[1]; }
+        if (fused && br == br_lo) { pre[0] = pre0[0]; pre[1] = pre0[1]; }
         else recompute_pre(br, pre);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1168,11 +1172,19 @@ __global__ __launch_bounds__(TW * 64, 4) void tbwd1_kernel(TArgs a, const float 
         if (lane == 0) { rw[512 + br * 2 + 0] = sa; rw[512 + br * 2 + 1] = sb; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();                                   // the scratch is rewritten for the next branch
+    };
+    if constexpr (BSPLIT) {
+        branch_sums((int)blockIdx.z);
+    } else {
+        branch_sums(0);
+        branch_sums(1);
     }
     KP(1, 3)
     __syncthreads();
     const size_t blk = (size_t)wg_lin;
     for (int i = threadIdx.x; i < 516; i += TW * 64) {
+        const int ibr = i < 512 ? i >> 8 : (i - 512) >> 1;                 // the branch entry i belongs to
+        if (ibr < br_lo || ibr >= br_hi) continue;                         // (branch split: the other workgroup's half of the row)
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < TW; ++w) t += red[w * 520 + i];
@@ -1191,7 +1203,7 @@ __global__ __launch_bounds__(TW * 64, 4) void tbwd1_kernel(TArgs a, const float 
     __syncthreads();
     const int nb = gridDim.x;
     KP(1, 4)
-    if (*tk != (unsigned)(nb - 1)) return;
+    if (*tk != (unsigned)(nb * (int)gridDim.z - 1)) return;               // (branch split: two arrivals per row)
     for (int j = threadIdx.x; j < 516; j += TW * 64) {
         float s = 0.f;
         for (int k0 = 0; k0 < nb; k0 += 8) {                               // eight loads in flight, added in order
@@ -1865,8 +1877,12 @@ static int prepare_layer(int B, int N, int ka, int kb, const float *tcanon_l, vo
     static LdsLimit lim_h1;
     if (hipError_t e = lim_h1.ensure((const void *)tstats_h1_kernel<NS, F16>, pt_a0n(NS)); e != hipSuccess) return (int)e;
     const dim3 grid((N + TBLK - 1) / TBLK, B);
+    static const int split_env = getenv("DPF_TRAIN_SPLIT") ? atoi(getenv("DPF_TRAIN_SPLIT")) : -1;
+    // one branch per workgroup for small batches (r04, B = 8: 9.5 -> 8.7 us; at 128 workgroups -- B = 16 -- passes 1 and the
+    // statistics are better off unsplit, only pass 2 gains)
+    const bool split = split_env >= 0 ? split_env != 0 : (int)(grid.x * grid.y) <= 64;
     { KScope ks(1, s);
-    hipLaunchKernelGGL((tstats_h1_kernel<NS, F16>), grid, dim3(TW * 64), pt_a0n(NS), s, a, w.part1, nbx * B, count, w.xpart,
+    hipLaunchKernelGGL((tstats_h1_kernel<NS, F16>), dim3(grid.x, grid.y, split ? 2 : 1), dim3(TW * 64), pt_a0n(NS), s, a, w.part1, nbx * B, count, w.xpart,
                        (uint8_t *)packed_l + pt_a0(NS)); }
     { KScope ks(2, s);
     hipLaunchKernelGGL(tfold_kernel, dim3(8), dim3(1024), 0, s, count, (int)(grid.x * grid.y), w.part1, tcanon_l, fm_l, B, flow_eps,
@@ -1960,6 +1976,8 @@ static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb
     const int lds1 = pt_a0n(NS) + 4096 + (TW * 520 + 256 + TW * 64 + 8 + 24) * 4, lds2 = l_red(NS) + 4096 + TW * XY_WAVE * 2;
     static LdsLimit lim_b1, lim_b2;
     if (hipError_t e = lim_b1.ensure((const void *)tbwd1_kernel<NS, F16>, lds1); e != hipSuccess) return (int)e;
+    static LdsLimit lim_b1s;
+    if (hipError_t e = lim_b1s.ensure((const void *)tbwd1_kernel<NS, F16, true>, lds1); e != hipSuccess) return (int)e;
     if (hipError_t e = lim_b2.ensure((const void *)tbwd2_kernel<NS, F16>, lds2); e != hipSuccess) return (int)e;
     // r04: the column sums of the layer above's pass-2 partials ride in this launch (ColsumJob) instead of a tcolsum launch
     // of their own between the two layers; DPF_TRAIN_FUSE_COLSUM=0 keeps the separate launch
@@ -1972,12 +1990,18 @@ static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb
         cs.rows = (CS_CRIT + (int)grid.x - 1) / (int)grid.x;
         grid1.y = cs.rows + B + (2 * P2_J / 32 - CS_CRIT + grid.x - 1) / grid.x;
     }
-    { KScope ks(4, s);
-    hipLaunchKernelGGL((tbwd1_kernel<NS, F16>), grid1, dim3(TW * 64), lds1, s, a, g_p, g_p2, g_mu, g_lv, mu_l, lv_l, dp_in, w.dout, w.part1, *pv,
-                       w.tickets, w.pc, dfm_l, cs); }
-    // small batches: the two branches of pass 2 in two workgroups (at most half a workgroup per CU otherwise)
+    // small batches: the two branches of passes 1 and 2 in two workgroups each (at most half a workgroup per CU otherwise)
     static const int split_env = getenv("DPF_TRAIN_SPLIT") ? atoi(getenv("DPF_TRAIN_SPLIT")) : -1;
     const bool split2 = split_env >= 0 ? split_env != 0 : nblk <= 128;
+    const bool split1 = split_env >= 0 ? split_env != 0 : nblk <= 64;      // (B = 16: tbwd1 15.7 us unsplit, 18.1 split)
+    grid1.z = split1 ? 2 : 1;
+    { KScope ks(4, s);
+    if (split1)
+        hipLaunchKernelGGL((tbwd1_kernel<NS, F16, true>), grid1, dim3(TW * 64), lds1, s, a, g_p, g_p2, g_mu, g_lv, mu_l, lv_l, dp_in, w.dout, w.part1, *pv,
+                           w.tickets, w.pc, dfm_l, cs);
+    else
+        hipLaunchKernelGGL((tbwd1_kernel<NS, F16>), grid1, dim3(TW * 64), lds1, s, a, g_p, g_p2, g_mu, g_lv, mu_l, lv_l, dp_in, w.dout, w.part1, *pv,
+                           w.tickets, w.pc, dfm_l, cs); }
     static LdsLimit lim_b2s;
     if (split2)
         if (hipError_t e = lim_b2s.ensure((const void *)tbwd2_kernel<NS, F16, true>, lds2); e != hipSuccess) return (int)e;
