@@ -40,6 +40,7 @@ SIGNATURES = {
     "dpf_flow_film_floats": (_sz, [_i, _i]),
     "dpf_flow_pack": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "dpf_flow_film": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _f, _vp]),
+    "dpf_nn_small_mode": (_i, [_i]),
     "dpf_flow_set_tile16": (_i, [_i]),
     "dpf_flow_tile16_launches": (ctypes.c_long, []),
     "dpf_flow_forward": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp]),

@@ -26,6 +26,8 @@
 #include <stdlib.h>
 
 #include "dpf_hip.h"
+#include "lds_attr.h"
+#include "zero_fill.h"
 #include "nn_refscan.h"
 
 #pragma clang fp contract(off)
@@ -56,6 +58,11 @@ struct NNDir {
 
 struct NNArgs {
     NNDir d[2];
+    // nn_small_kernel only (dpf_nn_small_cd): per-workgroup sums of the distances, one ticket per cloud, cd (B,) -- the
+    // per-cloud Chamfer reduction finished inside the search launch, as nnm_kernel does it (chamfer_mfma.hip)
+    float *part = nullptr;
+    unsigned *ticket = nullptr;
+    float *cd = nullptr;
 };
 
 __device__ __forceinline__ f2 pair_dist(float sx, float sy, float sz, f2 qx, f2 qy, f2 qz) {
@@ -264,6 +271,158 @@ __global__ __launch_bounds__(NWAVES * 64) void nn_kernel(NNArgs args) {
     if (j1 < nq) { A.dist[(size_t)bi * nq + j1] = best.y; A.idx[(size_t)bi * nq + j1] = i1; }
 }
 
+// ---- small problems: candidates staged in LDS, one query per lane (r04) ---------------------------------------------------
+// A rank of an 8-GPU job holds 4-8 clouds of 2048 points: 16 384 - 32 768 queries per direction pair, 128 - 256 of nn_kernel's
+// 128-query waves.  There the scan is bound by the LATENCY of its scalar loads (an L2-served s_load outlasts the ~300 cycles
+// of VALU work one chunk of prefetch covers) and half the CUs have no workgroup.  This kernel is built for that regime:
+//   * a workgroup = 64 queries (ONE per lane) x KSW candidate slices (one wave each), so 4 clouds give every CU a workgroup;
+//   * the workgroup stages the cloud's candidates once, structure-of-arrays, in LDS (12 B per candidate; coalesced vector
+//     loads; the NaN / Inf exponent test of nn_refscan.h rides on them); a chunk of 8 candidates is six broadcast
+//     ds_read_b128 (every lane reads the same address), double-buffered in registers;
+//   * the packed f32 math runs over PAIRS OF CANDIDATES against the lane's splatted query -- (c0x, c1x) - (qx, qx) ... --
+//     4 packed instructions per candidate and 64 queries instead of 4.8, same formula, every operation rounded on its own;
+//   * the rest is nn_kernel's: running minimum per chunk, first chunk that achieved it, one re-scan of that chunk for the
+//     first index, slices merged in LDS in ascending order with strict '<', the reference's own loop for non-finite input.
+// Bit-identical results (tests/test_gpu_chamfer.py runs every case through it: DPF_NN_SMALL / dpf_nn_small_mode).
+template <int KSW>
+__global__ __launch_bounds__(KSW * 64) void nn_small_kernel(NNArgs args) {
+    extern __shared__ __attribute__((aligned(16))) float lds_c[];
+    __shared__ float sd[KSW][64];
+    __shared__ int si[KSW][64];
+    __shared__ int sbad[KSW];
+    const NNDir A = args.d[blockIdx.z];
+    const int nq = A.nq, nc = A.nc;
+    const int bi = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int ks = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // wave 0 of every workgroup of the launch: publish the sum of this tile's distances; the cloud's last arriver adds the
+    // 2 * gridDim.x sums in a fixed order (lane x takes tiles x, x + 64, ..; butterfly) and writes cd.  Payload and ticket
+    // go through agent-scope accesses on both sides (the XCDs' L2s are not coherent with each other); tickets end at zero.
+    auto publish = [&](float mine) {
+        float t = mine;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) t += __shfl_xor(t, d);
+        const unsigned nwg2 = 2u * gridDim.x;
+        float *p = args.part + (size_t)bi * nwg2;
+        unsigned old = 0;
+        if (lane == 0) {
+            __hip_atomic_store(&p[blockIdx.z * gridDim.x + blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the sum has left this CU before the ticket is taken
+            old = __hip_atomic_fetch_add(&args.ticket[bi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        old = __shfl(old, 0);
+        if (old != nwg2 - 1) return;
+        float s1 = 0.f, s2 = 0.f;
+        for (unsigned x = lane; x < gridDim.x; x += 64) {
+            s1 += __hip_atomic_load(&p[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s2 += __hip_atomic_load(&p[gridDim.x + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { s1 += __shfl_xor(s1, d); s2 += __shfl_xor(s2, d); }
+        if (lane == 0) {
+            args.cd[bi] = s1 / (float)args.d[0].nq + s2 / (float)args.d[1].nq;
+            __hip_atomic_store(&args.ticket[bi], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    if ((int)blockIdx.x * 64 >= nq) {
+        if (args.part != nullptr && ks == 0) publish(0.f);
+        return;
+    }
+    const float *__restrict__ q = A.q + (size_t)bi * A.qstride;
+    const float *__restrict__ c = A.c + (size_t)bi * A.cstride;
+    const int ncp = (nc + 7) & ~7;
+    float *cx = lds_c, *cy = lds_c + ncp, *cz = lds_c + 2 * ncp;
+    const int j = blockIdx.x * 64 + lane, jc = min(j, nq - 1);
+    const float qx = q[jc * 3 + 0], qy = q[jc * 3 + 1], qz = q[jc * 3 + 2];
+    uint32_t cexp = 0;
+    constexpr int SB = 8;                                 // candidates per thread in flight: all loads of a batch, then the stores
+    for (int base = 0; base < ncp; base += SB * KSW * 64) {
+        float x[SB], y[SB], z[SB];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {                    // padding: a point so far away that its distance is +inf
+            const int k = base + u * KSW * 64 + tid, kc = min(k, nc - 1);
+            x[u] = c[kc * 3 + 0]; y[u] = c[kc * 3 + 1]; z[u] = c[kc * 3 + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int k = base + u * KSW * 64 + tid;
+            cexp = max(cexp, max(__builtin_bit_cast(uint32_t, x[u]) << 1, max(__builtin_bit_cast(uint32_t, y[u]) << 1, __builtin_bit_cast(uint32_t, z[u]) << 1)));
+            if (k >= nc) x[u] = y[u] = z[u] = 3.0e38f;
+            if (k < ncp) { cx[k] = x[u]; cy[k] = y[u]; cz[k] = z[u]; }
+        }
+    }
+    const bool cbad = __any(cexp >= 0xFF000000u);
+    if (lane == 0) sbad[ks] = cbad ? 1 : 0;
+    __syncthreads();
+    const int nchunk = ncp / CH;
+    const int kbeg = (int)((long)nchunk * ks / KSW) * CH, kend = (int)((long)nchunk * (ks + 1) / KSW) * CH;
+    const float INF = __builtin_inff();
+    const f2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
+    float best = INF;
+    int bc = kbeg;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    auto chunk_min = [&](const f4 (&v)[6]) {              // v: x[0..3], x[4..7], y.., z..
+        float dm = INF;
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            const f2 xa = {v[hlf][0], v[hlf][1]}, xb = {v[hlf][2], v[hlf][3]};
+            const f2 ya = {v[2 + hlf][0], v[2 + hlf][1]}, yb = {v[2 + hlf][2], v[2 + hlf][3]};
+            const f2 za = {v[4 + hlf][0], v[4 + hlf][1]}, zb = {v[4 + hlf][2], v[4 + hlf][3]};
+            const f2 dxa = xa - qx2, dya = ya - qy2, dza = za - qz2;
+            const f2 dxb = xb - qx2, dyb = yb - qy2, dzb = zb - qz2;
+            const f2 da = (dxa * dxa + dya * dya) + dza * dza;
+            const f2 db = (dxb * dxb + dyb * dyb) + dzb * dzb;
+            dm = fminf(fminf(dm, da.x), da.y);
+            dm = fminf(fminf(dm, db.x), db.y);
+        }
+        return dm;
+    };
+    auto load_chunk = [&](int k, f4 (&v)[6]) {
+        v[0] = *(const f4 *)(cx + k); v[1] = *(const f4 *)(cx + k + 4);
+        v[2] = *(const f4 *)(cy + k); v[3] = *(const f4 *)(cy + k + 4);
+        v[4] = *(const f4 *)(cz + k); v[5] = *(const f4 *)(cz + k + 4);
+    };
+    if (kend > kbeg) {
+        f4 va[6], vb[6];
+        load_chunk(kbeg, va);
+        int k = kbeg;
+        for (; k + 2 * CH <= kend; k += 2 * CH) {
+            load_chunk(k + CH, vb);
+            const float d0 = chunk_min(va);
+            if (d0 < best) { best = d0; bc = k; }
+            load_chunk(min(k + 2 * CH, kend - CH), va);
+            const float d1 = chunk_min(vb);
+            if (d1 < best) { best = d1; bc = k + CH; }
+        }
+        if (k < kend) {
+            const float d0 = chunk_min(va);
+            if (d0 < best) { best = d0; bc = k; }
+        }
+    }
+    // the FIRST index inside the winning chunk (descending scan, last hit wins); padding never matches a finite minimum
+    int i0 = bc;
+#pragma unroll
+    for (int u = CH - 1; u >= 0; --u) {
+        const int kk = bc + u;
+        const float d0 = one_dist(cx[kk], cy[kk], cz[kk], qx, qy, qz);
+        if (d0 == best && kk < nc) i0 = kk;
+    }
+    sd[ks][lane] = best;
+    si[ks][lane] = i0;
+    __syncthreads();
+    if (ks != 0) return;
+    bool anybad = false;
+#pragma unroll
+    for (int s2 = 0; s2 < KSW; ++s2) anybad = anybad || sbad[s2] != 0;
+#pragma unroll
+    for (int s2 = 1; s2 < KSW; ++s2) {       // ascending slices + strict '<' == global first minimum
+        const float e0 = sd[s2][lane];
+        if (e0 < best) { best = e0; i0 = si[s2][lane]; }
+    }
+    if (anybad || nn_not_finite(best)) nn_reference_scan(c, nc, qx, qy, qz, best, i0);
+    if (j < nq) { A.dist[(size_t)bi * nq + j] = best; A.idx[(size_t)bi * nq + j] = i0; }
+    if (args.part != nullptr) publish(j < nq ? best : 0.f);
+}
+
 // ---- backward -------------------------------------------------------------
 // grad_xyz1[b,j] = 2*gd1[b,j]*(x1_j - x2[idx1_j])  -  sum_{l: idx2_l = j} 2*gd2[b,l]*(x2_l - x1_j)
 // (nndistance.cu:139-145, both launches of :152-153).  The first term of each
@@ -364,6 +523,58 @@ __global__ __launch_bounds__(RT) void fscore_kernel(int n, int m, const float *_
 
 }  // namespace
 
+// -1 (default): by size; 0: never; 1: whenever the clouds fit (tests / measurements).  env DPF_NN_SMALL.
+static int g_nn_small_mode = getenv("DPF_NN_SMALL") ? atoi(getenv("DPF_NN_SMALL")) : -1;
+extern "C" int dpf_nn_small_mode(int mode) {
+    const int old = g_nn_small_mode;
+    g_nn_small_mode = mode < 0 ? -1 : (mode ? 1 : 0);
+    return old;
+}
+
+// rank-sized batches of mid-sized clouds: the LDS-staged kernel.  One workgroup per CU or fewer (B = 4 clouds of 2048 points:
+// 10.4 us against the scalar-load scan's 14.9); with more the CUs that hold two workgroups set the pace and the scan that
+// streams its candidates through SGPRs is as fast (B = 8: 16.0 vs 15.9 us; r04_small/sweep.txt).
+static bool nn_small_serves(int b, int n, int m) {
+    const int nmax = n > m ? n : m, minc = n < m ? n : m;
+    if (g_nn_small_mode == 0 || nmax > 8192 || b > 65535) return false;
+    if (g_nn_small_mode == 1) return true;
+    return minc >= 1024 && (long)((nmax + 63) / 64) * b * 2 <= 256;
+}
+static int nn_small_launch(const NNArgs &a, int b, int nmax, hipStream_t s) {
+    const int lds = 3 * ((nmax + 7) & ~7) * (int)sizeof(float);
+    // candidate slices per workgroup: enough waves for two per SIMD (a lone wave is bound by its own issue rate)
+    static const int ksw_env = getenv("DPF_NN_KSW") ? atoi(getenv("DPF_NN_KSW")) : 0;
+    const long wgs = (long)((nmax + 63) / 64) * b * 2;
+    const int ksw = ksw_env ? ksw_env : (wgs * 4 >= 2048 ? 4 : 8);
+    const dim3 grid((nmax + 63) / 64, b, 2);
+    static LdsLimit limit4, limit8, limit16;
+    if (ksw == 4) {
+        if (hipError_t e = limit4.ensure((const void *)nn_small_kernel<4>, lds); e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(nn_small_kernel<4>, grid, dim3(4 * 64), lds, s, a);
+    } else if (ksw == 8) {
+        if (hipError_t e = limit8.ensure((const void *)nn_small_kernel<8>, lds); e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(nn_small_kernel<8>, grid, dim3(8 * 64), lds, s, a);
+    } else {
+        if (hipError_t e = limit16.ensure((const void *)nn_small_kernel<16>, lds); e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(nn_small_kernel<16>, grid, dim3(16 * 64), lds, s, a);
+    }
+    return (int)hipGetLastError();
+}
+
+// dpf_nndistance_cd's fast path for the same problems (chamfer_mfma.hip): DPF_ENOSUP when the kernel does not serve them.
+// workspace layout as there: b tickets (zero on entry and on exit), then 2 * ceil(nmax / 64) sums per cloud.
+int nn_small_cd(int b, int n, const float *xyz, int m, const float *xyz2, float *result, int *result_i, float *result2,
+                int *result2_i, float *cd, void *workspace, int tickets_are_zero, hipStream_t s) {
+    if (!nn_small_serves(b, n, m)) return DPF_ENOSUP;
+    if (!tickets_are_zero)
+        if (hipError_t e = dpf_zero_async(workspace, (size_t)b * sizeof(unsigned), s); e != hipSuccess) return (int)e;
+    NNArgs a;
+    a.d[0] = NNDir{xyz, xyz2, result, result_i, n, m, (long)n * 3, (long)m * 3};
+    a.d[1] = NNDir{xyz2, xyz, result2, result2_i, m, n, (long)m * 3, (long)n * 3};
+    a.ticket = (unsigned *)workspace; a.part = (float *)workspace + b; a.cd = cd;
+    return nn_small_launch(a, b, n > m ? n : m, s);
+}
+
 extern "C" int dpf_fscore_reduce(int b, int n, int m, const float *dist1, const float *dist2, float threshold, float *out,
                                  dpf_stream_t stream) {
     if (b < 0 || n <= 0 || m <= 0) return DPF_EINVAL;
@@ -404,6 +615,7 @@ extern "C" int dpf_nndistance_strided(int b, int n, const float *xyz, long xyz_s
     // candidates are split over MORE waves -- 8 or 16 slices merged in LDS in ascending order -- until every SIMD has two
     static const int ks_env = getenv("DPF_NN_KS") ? atoi(getenv("DPF_NN_KS")) : 0;
     const int minc = n < m ? n : m;
+    if (nn_small_serves(b, n, m) && !ks_env) return nn_small_launch(a, b, nmax, s);
     int ks_small = ks_env;
     if (!ks_small && waves1 < 512 && minc >= 1024) ks_small = 8;    // r04, B=4 N=2048: 4 slices 18.4 us, 8: 15.3, 16: 16.8
     if (ks_small == 16 || ks_small == 8) {

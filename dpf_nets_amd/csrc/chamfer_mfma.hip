@@ -514,8 +514,11 @@ extern "C" int dpf_pairwise_cd(int n1, int n2, int n, int m, const float *clouds
 // otherwise dpf_nndistance + dpf_chamfer_reduce.  The two reductions associate differently (last-bit differences in cd).
 extern "C" size_t dpf_nndistance_cd_workspace_bytes(int b, int n, int m) {
     const int nmax = n > m ? n : m;
-    return (size_t)(b > 0 ? b : 0) * (2 * ((nmax + 511) / 512) + 1) * sizeof(float) + 16;    // sums + one ticket per cloud
+    // sums (one per 64-query workgroup of nn_small_kernel, the finest tiling) + one ticket per cloud
+    return (size_t)(b > 0 ? b : 0) * (2 * ((nmax + 63) / 64) + 1) * sizeof(float) + 16;
 }
+int nn_small_cd(int b, int n, const float *xyz, int m, const float *xyz2, float *result, int *result_i, float *result2,
+                int *result2_i, float *cd, void *workspace, int tickets_are_zero, hipStream_t s);      // chamfer.hip
 extern "C" int dpf_nndistance_cd(int b, int n, const float *xyz, int m, const float *xyz2, float *result, int *result_i,
                                  float *result2, int *result2_i, float *cd, void *workspace, size_t workspace_bytes,
                                  int tickets_are_zero, dpf_stream_t stream) {
@@ -531,6 +534,11 @@ extern "C" int dpf_nndistance_cd(int b, int n, const float *xyz, int m, const fl
             if (hipError_t e = dpf_zero_async(workspace, (size_t)b * sizeof(unsigned), s); e != hipSuccess) return (int)e;
         return launch_nnm(b, n, xyz, (long)n * 3, m, xyz2, (long)m * 3, result, result_i, result2, result2_i, s,
                           (float *)workspace + b, true, (unsigned *)workspace, cd);
+    }
+    if (workspace && workspace_bytes >= dpf_nndistance_cd_workspace_bytes(b, n, m) && !nnm_pays(b, n, m)) {
+        // a rank's handful of clouds: the LDS-staged scan finishes the reduction the same way (chamfer.hip nn_small_kernel)
+        const int rc = nn_small_cd(b, n, xyz, m, xyz2, result, result_i, result2, result2_i, cd, workspace, tickets_are_zero, s);
+        if (rc != DPF_ENOSUP) return rc;
     }
     int rc = dpf_nndistance_auto(b, n, xyz, m, xyz2, result, result_i, result2, result2_i, stream);
     if (rc) return rc;

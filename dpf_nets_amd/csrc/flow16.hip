@@ -770,7 +770,7 @@ int flow16_launch(const void *flow_args, hipStream_t stream) {
     ++g_tile16_launches;
     static const int cw_env = getenv("DPF_FLOW16_CW") ? atoi(getenv("DPF_FLOW16_CW")) : 0;
     // compute waves per workgroup (the loaders share their SIMDs): 4 = one per SIMD; 2 when that is what gives every CU a
-    // workgroup
+    // workgroup (8 + 4 waves would have to live in 168 registers each: the kernel spills there, so it is not built)
     int cw = cw_env ? cw_env : 4;
     if (!cw_env && (long)a.B * ((a.N + 63) / 64) < 160) cw = 2;
     const bool inv = a.mode == DPF_MODE_INVERSE;
@@ -780,7 +780,6 @@ int flow16_launch(const void *flow_args, hipStream_t stream) {
     if (split) {
         return inv ? launch16s<4, 4, true>(a, stream) : launch16s<4, 4, false>(a, stream);
     }
-    if (cw >= 8) return inv ? launch16<8, 4, true>(a, stream) : launch16<8, 4, false>(a, stream);
     if (cw >= 4) return inv ? launch16<4, 4, true>(a, stream) : launch16<4, 4, false>(a, stream);
     return inv ? launch16<2, 2, true>(a, stream) : launch16<2, 2, false>(a, stream);
 }

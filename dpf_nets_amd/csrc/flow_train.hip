@@ -966,9 +966,11 @@ __device__ __forceinline__ void colsum_wait(const ColsumJob &cs, int *lds_word) 
 //   stores  dout (B,4,N) = d(o_logvar a,b), d(o_mu a,b)         dp_in <- direct term  g * d(p_out)/d(p)
 //   partial sums per workgroup: part1[blk][br][k][64], k = 0 dW2a, 1 dW2b, 2 da, 3 dc;  part1[blk][512 + br*2 + w] = db2
 // the gradient w.r.t. p_out is g_p + g_p2 (either may be NULL = zero, like g_mu and g_lv)
-// (min 4 waves per SIMD = two workgroups per CU: the column workgroups of ColsumJob must find room BESIDE the ordinary ones)
+// (min 4 waves per SIMD = two workgroups per CU: the column workgroups of ColsumJob must find room BESIDE the ordinary ones;
+// the branch-split form serves B * N / 256 <= 64 only -- 128 ordinary + 16 critical column workgroups have a CU each -- and
+// is one register short at 128)
 template <int NS, bool F16 = false, bool BSPLIT = false>
-__global__ __launch_bounds__(TW * 64, 4) void tbwd1_kernel(TArgs a, const float *__restrict__ g_p, const float *__restrict__ g_p2,
+__global__ __launch_bounds__(TW * 64, BSPLIT ? 2 : 4) void tbwd1_kernel(TArgs a, const float *__restrict__ g_p, const float *__restrict__ g_p2,
                                                            const float *__restrict__ g_mu, const float *__restrict__ g_lv,
                                                            const float *__restrict__ mu_l, const float *__restrict__ lv_l,
                                                            float *__restrict__ dp_in, float *__restrict__ dout,
@@ -991,8 +993,6 @@ __global__ __launch_bounds__(TW * 64, 4) void tbwd1_kernel(TArgs a, const float 
     float *red = (float *)(smem + L_RED);                                  // per wave [2 br][4][64] + [2][2] (+4 pad)
     const int bi = (int)blockIdx.y - cs.rows, lane = threadIdx.x & 63, h = lane >> 5, pl = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int h4 = 4 * h;                   // opaque to the optimiser: feature offsets stay "lane base + immediate"
-    asm volatile("" : "+v"(h4));      // (as known bits they become OR-ed constants, one live register each)
     KP(1, 0)
     // (unconditional: the host hands valid pointers even when there is no layer above -- `cl = {}` merged with the loaded
     // values cost register copies, i.e. a wait for the loads right here)
@@ -1017,18 +1017,26 @@ __global__ __launch_bounds__(TW * 64, 4) void tbwd1_kernel(TArgs a, const float 
         gp[c] = g_p2 ? g_p2[o] : 0.f;                                       // what the layer above passes down (direct term so far)
         gm[c] = valid && g_mu ? g_mu[o] : 0.f;
         gl[c] = valid && g_lv ? g_lv[o] : 0.f;
-        gp1[c] = g_p ? g_p[o] : 0.f;
     }
+    const bool fused = cs.rows > 0;       // (kernel argument: uniform)
+    // what only finish_gp reads: the other gradient term and the layer above's point values.  With the column sums in this
+    // launch finish_gp runs BEHIND the first branch's recomputation: requested there (the wait for the totals covers the
+    // round trip), so that seven registers are not carried -- spilled, at the 128 this kernel may use -- across it
     float xa2 = 0.f, xb2 = 0.f, u2a = 0.f, u2b = 0.f;
-    if (pv.has) {
-        const float *xc = pv.x + cloud;
-        xa2 = xc[(size_t)pv.ka * N + nc]; xb2 = pv.kb >= 0 ? xc[(size_t)pv.kb * N + nc] : 0.f;
-        u2a = pv.ubuf[((size_t)bi * 2 + 0) * N + nc]; u2b = pv.kb >= 0 ? pv.ubuf[((size_t)bi * 2 + 1) * N + nc] : 0.f;
-        if (pv.ubuf2 != nullptr) {     // (wave-uniform) the mu branch's share, added once: the same rounding in tbwd3f_kernel
-            u2a = __fadd_rn(u2a, pv.ubuf2[((size_t)bi * 2 + 0) * N + nc]);
-            if (pv.kb >= 0) u2b = __fadd_rn(u2b, pv.ubuf2[((size_t)bi * 2 + 1) * N + nc]);
+    auto load_prev = [&]() {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gp1[c] = g_p ? g_p[cloud + (size_t)c * N + nc] : 0.f;
+        if (pv.has) {
+            const float *xc = pv.x + cloud;
+            xa2 = xc[(size_t)pv.ka * N + nc]; xb2 = pv.kb >= 0 ? xc[(size_t)pv.kb * N + nc] : 0.f;
+            u2a = pv.ubuf[((size_t)bi * 2 + 0) * N + nc]; u2b = pv.kb >= 0 ? pv.ubuf[((size_t)bi * 2 + 1) * N + nc] : 0.f;
+            if (pv.ubuf2 != nullptr) {     // (wave-uniform) the mu branch's share, added once: the same rounding in tbwd3f_kernel
+                u2a = __fadd_rn(u2a, pv.ubuf2[((size_t)bi * 2 + 0) * N + nc]);
+                if (pv.kb >= 0) u2b = __fadd_rn(u2b, pv.ubuf2[((size_t)bi * 2 + 1) * N + nc]);
+            }
         }
-    }
+    };
+    if (!fused) load_prev();
     const StageRegs<pt_a0n(NS)> wregs = stage_load<pt_a0n(NS)>(a.packed_l, wave, lane);
     const StageRegs<2048> fregs = stage_load<2048>((const uint8_t *)(a.film_l + (size_t)bi * 512), wave, lane);
     const StageRegs<2048> fbregs = stage_load<2048>((const uint8_t *)(a.filmb_l + (size_t)bi * FB_CLOUD), wave, lane);
@@ -1040,7 +1048,6 @@ __global__ __launch_bounds__(TW * 64, 4) void tbwd1_kernel(TArgs a, const float 
     float *w2s = red + TW * 520;                                                // [2 br][2][64] raw sd2.weight
     if (threadIdx.x < 256) w2s[threadIdx.x] = w2_v;
     float *pcoef = w2s + 256 + TW * 64;                                         // 8 floats behind the per-wave scratch
-    const bool fused = cs.rows > 0;       // (kernel argument: uniform)
     const int wg_lin = bi * gridDim.x + blockIdx.x;
     auto finish_gp = [&](const CoefLoads &c3) {
         if (pv.has)   // the previous backward layer's pass 3 (scratch: the reduction slots, free until the end)
@@ -1086,6 +1093,7 @@ __global__ __launch_bounds__(TW * 64, 4) void tbwd1_kernel(TArgs a, const float 
         // the first branch's recomputation first: by the time it is done the critical column workgroups of this launch have
         // long published their totals (they read 512 columns of the partials; this is ~1 400 instructions)
         recompute_pre(br_lo, pre0);
+        load_prev();
         colsum_wait(cs, (int *)(pcoef + 12));
         const CoefLoads c3 = bwd3_loads<true>(pv.kb >= 0 ? 2 : 1, pv.tot, pv.tcanon_l, pv.stats_l);
         finish_gp(c3);
@@ -1137,6 +1145,10 @@ __global__ __launch_bounds__(TW * 64, 4) void tbwd1_kernel(TArgs a, const float 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         f32x4 doa4[4], dob4[4];
+        // opaque to the optimiser: the offsets stay "lane base + immediate" (as known bits they become OR-ed constants, one
+        // live register each); made here from the thread index, not carried through the recomputation above
+        int h4 = 4 * (int)((threadIdx.x >> 5) & 1);
+        asm volatile("" : "+v"(h4));
 #pragma unroll
         for (int q = 0; q < 4; ++q) { doa4[q] = *(const f32x4 *)(pts + 8 * q + h4); dob4[q] = *(const f32x4 *)(pts + 32 + 8 * q + h4); }
         float *rw = red + wave * 520;

@@ -51,6 +51,11 @@ int dpf_nndistance(int b, int n, const float *xyz, int m, const float *xyz2,
                    float *result, int *result_i, float *result2, int *result2_i,
                    dpf_stream_t stream);
 
+/* Which kernel serves dpf_nndistance(_strided) for rank-sized batches of 1024..8192-point clouds (< 512 waves of the scan):
+ * the LDS-staged one-query-per-lane kernel (csrc/chamfer.hip nn_small_kernel, r04) or the scalar-load scan.  Same bits.
+ * mode: -1 = by size (default; env DPF_NN_SMALL), 0 = never, 1 = whenever the clouds fit.  Returns the previous mode. */
+int dpf_nn_small_mode(int mode);
+
 /* dpf_nndistance with explicit strides (in floats) between consecutive clouds of
  * each set; stride 0 broadcasts one cloud over the batch -- the "expand +
  * contiguous" copy of pairwise_CD (lib/networks/utils.py:104-107) disappears. */

@@ -19,16 +19,20 @@ def _gpu():
     return BK
 
 
-IMPLS = ["auto", "mfma", "brute"]
+# "small" = the LDS-staged one-query-per-lane kernel of rank-sized batches, forced for every shape whose clouds fit in LDS
+IMPLS = ["auto", "mfma", "brute", "small"]
 
 
 def _run(BK, a, b, impl=None):
+    from dpf_nets_amd._lib import lib
     old = BK.NN_IMPL
-    BK.NN_IMPL = impl or old
+    BK.NN_IMPL = "brute" if impl == "small" else (impl or old)
+    old_small = lib().dpf_nn_small_mode(1 if impl == "small" else -1)
     try:
         d1, i1, d2, i2 = BK.NNDistance(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
     finally:
         BK.NN_IMPL = old
+        lib().dpf_nn_small_mode(old_small)
     torch.cuda.synchronize()
     return d1.cpu().numpy(), i1.cpu().numpy(), d2.cpu().numpy(), i2.cpu().numpy()
 
@@ -58,7 +62,7 @@ def test_nndistance_bit_exact_vs_oracle(shape, impl):
     _assert_bit_exact(_run(BK, a, b, impl), S.nndistance(a, b), shape)
 
 
-@pytest.mark.parametrize("impl", ["mfma", "brute"])
+@pytest.mark.parametrize("impl", ["mfma", "brute", "small"])
 @pytest.mark.parametrize("kind", ["same_x", "two_planes", "line", "clustered", "surface", "far_offset", "all_equal",
                                   "big_coords"])
 def test_pruned_search_adversarial_distributions(kind, impl):
@@ -321,7 +325,8 @@ def test_nndistance_cd_fused_reduction():
     """dpf_nndistance_cd: the same four outputs as NNDistance, bit for bit, and cd = dist1.mean(1) + dist2.mean(1) -- on the
     matrix-core path (workgroup sums + finish) and on the fallback (small problem: scan + chamfer_reduce)."""
     BK = _gpu()
-    for (B, n, m) in ((32, 2048, 2048), (3, 257, 300), (8, 2500, 2048)):
+    # (4, 2048, 2048), (2, 2048, 1500): a rank's share of an 8-GPU job -- the LDS-staged scan with its own in-kernel finish
+    for (B, n, m) in ((32, 2048, 2048), (3, 257, 300), (8, 2500, 2048), (4, 2048, 2048), (2, 2048, 1500), (1, 1024, 4000)):
         a, b = chamfer_inputs(900 + n, B, n, m)
         ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
         d1, i1, d2, i2, cd = BK.NNDistanceCD(ta, tb)
@@ -338,12 +343,13 @@ def test_nndistance_cd_fused_reduction():
         BK.NNDistanceCD(ta, tb, BK.CDWorkspace(B + 1, n, m, ta.device))
 
 
-def test_nndistance_cd_ticket_finish_under_load():
+@pytest.mark.parametrize("B", [32, 4])
+def test_nndistance_cd_ticket_finish_under_load(B):
     """The in-kernel finish of dpf_nndistance_cd reads other workgroups' sums (other CUs, other XCDs, lines that held the
     PREVIOUS call's sums): 150 calls on changing data, the same workspace, a second stream keeping the chip unevenly busy --
     every cd must equal the mean of the distances the same call wrote, and the tickets must be back at zero."""
     BK = _gpu()
-    B, n = 32, 2048
+    n = 2048                 # B = 32: the matrix-core kernel's finish; B = 4: the LDS-staged scan's (64 sums per cloud)
     g = torch.Generator(device="cuda").manual_seed(7)
     base = torch.randn(B, n, 3, device="cuda", generator=g) * 0.2
     other = torch.randn(B, n, 3, device="cuda", generator=g) * 0.2

@@ -43,10 +43,17 @@ def isa_flow(tmp_path_factory):
     return _isa(tmp_path_factory, "flow")
 
 
+@pytest.fixture(scope="module")
+def isa_flow16(tmp_path_factory):
+    return _isa(tmp_path_factory, "flow16")
+
+
 def _kernels(isa):
     """{mangled name: body} of every kernel of an assembly listing"""
     parts = re.split(r"^(_Z[A-Za-z0-9_]+):[^\n]*$", isa, flags=re.M)
-    return {parts[i]: parts[i + 1].split("s_endpgm")[0] for i in range(1, len(parts) - 1, 2)}
+    # (up to the function's end label, not its first s_endpgm: a kernel whose workgroups take roles -- tbwd1's column sums --
+    # has an early exit)
+    return {parts[i]: re.split(r"^\.Lfunc_end\d+:", parts[i + 1], flags=re.M)[0] for i in range(1, len(parts) - 1, 2)}
 
 
 HOT_EVAL = "flow_kernelILi2ELi8ELi1ELb1ELb1ELb1E"          # NS = 2, 8 waves, LPB = 1, pipelined, fp16 operands, skewed ring
@@ -72,6 +79,19 @@ def test_no_packed_f32_and_no_scratch_in_the_flow_kernels(isa_flow, isa_flow_tra
         assert "scratch_" not in isa, name
         spills = [int(x) for x in re.findall(r"\.vgpr_spill_count:\s+(\d+)", isa)]
         assert spills and max(spills) == 0, (name, spills)
+
+
+def test_tile16_kernels_keep_their_registers(isa_flow16):
+    """r04: the 16-point-tile kernels hold a layer's accumulators, the ring's addresses and the next head in registers; the
+    first versions spilled (an `if` around the head prefetch kept two copies alive; ~100 hoisted LDS addresses) -- the
+    launder-the-base idiom of flow16.hip is what keeps them under the cap, and nothing numerical would notice its loss."""
+    ks = {n: b for n, b in _kernels(isa_flow16).items() if "flow16_kernel" in n or "flow16s_kernel" in n}
+    assert len(ks) >= 4, sorted(ks)
+    for name, body in ks.items():
+        assert "scratch_" not in body, name
+        assert "v_mfma_f32_16x16x32_f16" in body, name
+    spills = [int(x) for x in re.findall(r"\.vgpr_spill_count:\s+(\d+)", isa_flow16)]
+    assert spills and max(spills) == 0, spills
 
 
 def test_training_kernels_stage_weights_through_registers(isa_flow_train):

@@ -25,7 +25,13 @@ def main():
         i1 = torch.empty((B, N), dtype=torch.int32, device="cuda"); i2 = torch.empty((B, M), dtype=torch.int32, device="cuda")
         args = (B, N, a.data_ptr(), M, b.data_ptr(), d1.data_ptr(), i1.data_ptr(), d2.data_ptr(), i2.data_ptr())
         res, outs = {}, {}
-        for name, fn in (("brute", lambda: L.dpf_nndistance(*args, current_stream())),
+        def scan(mode):
+            def f():
+                L.dpf_nn_small_mode(mode)
+                L.dpf_nndistance(*args, current_stream())
+                L.dpf_nn_small_mode(-1)
+            return f
+        for name, fn in (("brute", scan(0)), ("lds", scan(1)),
                          ("mfma", lambda: L.dpf_nndistance_mfma(*args, None, 0, current_stream())),
                          ("auto", lambda: L.dpf_nndistance_auto(*args, current_stream()))):
             fn()
@@ -33,8 +39,9 @@ def main():
             outs[name] = (d1.clone(), i1.clone(), d2.clone(), i2.clone())
             res[name] = bench.time_kernel(fn)
         same = all(torch.equal(x, y) for x, y in zip(outs["brute"], outs["mfma"]))
-        print("QW=%s B=%d N=%d M=%d: brute %.1f us  mfma %.1f us  auto %.1f us  identical: %s"
-              % (os.environ.get("DPF_NNM_QW", "auto"), B, N, M, res["brute"], res["mfma"], res["auto"], same), flush=True)
+        same = same and all(torch.equal(x, y) for x, y in zip(outs["brute"], outs["lds"]))
+        print("QW=%s B=%d N=%d M=%d: brute %.1f us  lds %.1f us  mfma %.1f us  auto %.1f us  identical: %s"
+              % (os.environ.get("DPF_NNM_QW", "auto"), B, N, M, res["brute"], res["lds"], res["mfma"], res["auto"], same), flush=True)
 
 
 if __name__ == "__main__":
