@@ -39,6 +39,11 @@ def _c(a, dt=np.float32):
     return np.ascontiguousarray(a, dtype=dt)
 
 
+def set_threads(n):
+    """host threads of the Chamfer restatement (independent queries; the results do not depend on it).  Default 1."""
+    lib().oracle_set_threads(int(n))
+
+
 def nndistance(xyz1, xyz2):
     """(B,n,3),(B,m,3) -> dist1 (B,n), idx1 (B,n) int32, dist2 (B,m), idx2 (B,m)."""
     xyz1, xyz2 = _c(xyz1), _c(xyz2)

@@ -43,12 +43,18 @@
  * restatement keeps the batch structure so that it is the oracle for any
  * input. */
 #define NN_BATCH 512
+/* Queries are independent: with -fopenmp (oracle/Makefile) the (cloud, query) loop is shared among oracle_set_threads()
+ * host threads -- every query still runs the reference's serial loop, so the results do not depend on the thread count.
+ * (r04: bench.py's cpu_baseline had timed this leg on ONE thread beside a 32-thread flow leg.) */
+static int g_threads = 1;
+void oracle_set_threads(int n) { g_threads = n > 0 ? n : 1; }
 static void nn_one_direction(int b, int n, const float *xyz, int m, const float *xyz2,
                              float *result, int *result_i) {
+#pragma omp parallel for collapse(2) schedule(static) num_threads(g_threads)
     for (int i = 0; i < b; i++) {
-        const float *q = xyz + (size_t)i * n * 3;
-        const float *c = xyz2 + (size_t)i * m * 3;
         for (int j = 0; j < n; j++) {
+            const float *q = xyz + (size_t)i * n * 3;
+            const float *c = xyz2 + (size_t)i * m * 3;
             const float x1 = q[j * 3 + 0], y1 = q[j * 3 + 1], z1 = q[j * 3 + 2];
             float res = 0.0f;
             int res_i = 0;
