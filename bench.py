@@ -188,6 +188,15 @@ def timed_region(run_steps, args, dist, device):
     return elapsed
 
 
+def device_clock_mhz():
+    """The GPU's current shader clock (MHz) or None.  Context for a line, not part of any rate: r04 saw boxes of the pool run
+    the same kernels 1.1-1.5x apart (VALU-bound kernels most), and the clock read right behind the timed loop tells which."""
+    try:
+        return int(torch.cuda.clock_rate())
+    except Exception:
+        return None
+
+
 def clouds_of_rank(args, rank, world):
     cfg = CONFIGS[args.config]
     if args.batch is not None:
@@ -481,6 +490,7 @@ def leg_eval(args, rank, world, dist, device):
 
     run_steps(args.settle)
     elapsed = timed_region(run_steps, args, dist, device)
+    sclk = device_clock_mhz()            # right behind the timed region: the shader clock the steps ran at (boxes differ)
 
     pipelined = None
     if S_all > S:                        # the same steps with S_all of them in flight, reported beside the headline
@@ -557,6 +567,7 @@ def leg_eval(args, rank, world, dist, device):
                    "chamfer_impl": BK.NN_IMPL + (" (matrix-core filtered exact search at this size)" if BK.NN_IMPL == "auto" and
                                                  2.0 * B * N * N >= 1e8 and B * 2 * ((N + 255) // 256) >= 64 else "")},
         "roofline": roof,
+        "device": {"name": torch.cuda.get_device_name(device), "sclk_mhz_behind_timed_region": sclk},
     }
     if pipelined is not None:
         line["pipelined"] = {
