@@ -662,19 +662,25 @@ __global__ __launch_bounds__((CW + LW) * 64) void flow16s_kernel(FlowArgs a) {
         const int ln = inverse ? (li > 0 ? li - 1 : 0) : (li + 1 < L ? li + 1 : li);
         uint32_t w1, w0, fb;
         slot_bases(step, w1, w0, fb);
+        unsigned long long tt[8];
+        (void)tt;
+        DPF16_T(0)
         int nka, nkb, nwa, nwb;
         layer_meta(ln, nka, nkb, nwa, nwb);
         const float xa = sel3(ka, p0, p1, p2);
         const float xb = kb < 0 ? 0.f : sel3(kb, p0, p1, p2);
         u32x4 b0 = input_fragment(g == 1 ? xb : xa, g == 1 ? 1 : 0);
         if (g >= 2) { b0.x = 0u; b0.y = 0u; b0.z = 0u; b0.w = 0u; }
+        DPF16_T(1)
 
         float mine0, mine1;
         if (wb < 0) branch16<false>(smem, w1, fb, bias_a, 0.f, hd, b0, negone, mine0, mine1);
         else branch16<true>(smem, w1, fb, bias_a, bias_b, hd, b0, negone, mine0, mine1);
+        DPF16_T(2)
         float *xw = xbuf + (((step & 1) * T + tile) * 2 + br) * 32;
         if (g == 0) { xw[pl] = mine0; xw[16 + pl] = mine1; }
         __syncthreads();       // barrier `step`: outputs exchanged; this layer's slot is free; the next layer has landed
+        DPF16_T(3)
         fetch(step + 1);       // (unconditional, as in flow16_kernel)
         const float *xr = xbuf + (((step & 1) * T + tile) * 2 + (br ^ 1)) * 32;
         const float their0 = xr[pl], their1 = xr[16 + pl];
@@ -710,6 +716,14 @@ __global__ __launch_bounds__((CW + LW) * 64) void flow16s_kernel(FlowArgs a) {
             const float v2 = br ? mu[2] : (g == 0 ? pn[2] : lv[2]);
             if (!(br && g == 1)) { dst[base] = v0; dst[base + N] = v1; dst[base + 2 * (size_t)N] = v2; }
         }
+        DPF16_T(4)
+#ifdef DPF_PROFILE
+        if (a.prof != nullptr && lane == 0 && blockIdx.x < 2 && blockIdx.y == 0) {
+            unsigned long long *o2 = a.prof + (((size_t)(blockIdx.x * CW + wave)) * L + step) * 8;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) o2[i] = tt[i];
+        }
+#endif
         ka = nka; kb = nkb; wa = nwa; wb = nwb;
     }
     if (valid) {
