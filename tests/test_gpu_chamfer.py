@@ -433,3 +433,31 @@ def test_generative_evaluation_fragment_on_the_mirror():
         assert U.KNN(gg, gt, tt, k) == U.KNN(o[0], o[1], o[2], k)
     jsd = U.JSD(tg.cpu().numpy(), tr.cpu().numpy(), warning=False)
     assert 0.0 < jsd < 1.0
+
+
+def test_compiled_extension_gives_the_python_backends_bits():
+    """csrc/torch_ext/structural_losses_backend.cpp -- the five functions of the reference's pybind module, compiled over the C
+    ABI -- against the ctypes module of the same names: identical tensors for Chamfer forward / backward, identical match /
+    cost / gradients for approx-EMD; a non-contiguous or mistyped tensor is refused as the reference refuses it."""
+    BK = _gpu()
+    from dpf_nets_amd.metrics.StructuralLosses import StructuralLossesBackend_native as native
+    a, b = chamfer_inputs(77, 6, 700, 1100)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    got, ref = native.NNDistance(ta, tb), BK.NNDistance(ta, tb)
+    for x, y in zip(got, ref):
+        assert x.dtype == y.dtype and torch.equal(x, y)
+    _assert_bit_exact([t.cpu().numpy() for t in got], S.nndistance(a, b), "native")
+    g1, g2 = torch.rand_like(got[0]), torch.rand_like(got[2])
+    for x, y in zip(native.NNDistanceGrad(ta, tb, got[1], got[3], g1, g2), BK.NNDistanceGrad(ta, tb, ref[1], ref[3], g1, g2)):
+        assert torch.allclose(x, y, rtol=1e-5, atol=1e-7)          # (the scattered term is added with float atomics: last bits vary)
+    sa, sb = ta[:3, :256].contiguous(), tb[:3, :320].contiguous()
+    m1, t1 = native.ApproxMatch(sa, sb)
+    m2, t2 = BK.ApproxMatch(sa, sb)
+    assert torch.equal(m1, m2) and m1.shape == (3, 320, 256) and t1.shape == (3, 2 * (256 + 320))
+    assert torch.allclose(native.MatchCost(sa, sb, m1), BK.MatchCost(sa, sb, m2), rtol=2e-6, atol=0)      # (partial sums meet in a different order)
+    for x, y in zip(native.MatchCostGrad(sa, sb, m1), BK.MatchCostGrad(sa, sb, m2)):
+        assert torch.allclose(x, y, rtol=1e-5, atol=1e-7)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        native.NNDistance(ta[:, ::2], tb)
+    with pytest.raises(RuntimeError, match="float32"):
+        native.NNDistance(ta.double(), tb)

@@ -448,3 +448,22 @@ def test_prior_flat_store_aliases_parameters_and_takes_the_flat_adam_path():
     for (k, a), b in zip(ref.state_dict().items(), flat.state_dict().values()):
         assert torch.equal(a, b), k
     assert o_f.state[w]["step"] == 3 and torch.equal(o_f.state[w]["exp_avg"], o_r.state[ref.flows[0].nvp1.T_mu_0[0].weight]["exp_avg"])
+
+
+def test_compiled_structural_losses_extension_builds_and_exports_the_reference_names():
+    """pybind/bind.cpp:9-15 of the reference registers five functions; csrc/torch_ext/structural_losses_backend.cpp is the
+    same module compiled against libdpf_hip.so's C ABI (no compute here: a CPU tensor is refused with the reference's
+    message, structural_loss.cpp:10)."""
+    import importlib.util
+    import os
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("dpf_ext_build", os.path.join(root, "dpf_nets_amd", "csrc", "torch_ext", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.build()
+    from dpf_nets_amd.metrics.StructuralLosses import StructuralLossesBackend_native as native
+    for name in ("ApproxMatch", "MatchCost", "MatchCostGrad", "NNDistance", "NNDistanceGrad"):
+        assert callable(getattr(native, name)), name
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        native.NNDistance(torch.zeros(1, 4, 3), torch.zeros(1, 4, 3))
