@@ -45,7 +45,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // waves per workgroup (32 queries each): template parameter QW = 16, or 8 when that is what fills the chip
 constexpr int CT = 64;           // candidate tiles resident in LDS at a time (64 KiB of fragments + 32 KiB of points)
-constexpr int QCAP = 8;          // queued candidate tiles per lane (compacted when full)
+constexpr int SCH = 32;          // tiles per sweep chunk: their surrogate minima stay in registers until the chunk's threshold is known
+constexpr int WCAP = SCH * 64 / 8;   // work items of a wave per chunk: their 8-byte results reuse the survivor lists' 2 KiB
+__host__ __device__ constexpr int nnm_lds_bytes(int qw) { return CT * 1536 + qw * SCH * 64 + qw * WCAP * 2; }    // fragments + points + survivor lists / results + work lists
 
 __device__ __forceinline__ uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
 __device__ __forceinline__ float u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
@@ -166,6 +168,31 @@ __device__ __forceinline__ void exact_tile(P cp, int nc, int t, int tl, int h, f
     }
 }
 
+// the same evaluation for ANOTHER lane's query (the wave-wide work list of nnm_kernel): minimum and lowest index of the 16
+// candidates lane half `h` sees in tile `t`, for the owner to merge under the (d, index) rule (INT_MAX: no candidate)
+template <class P>
+__device__ __forceinline__ void exact_tile_mk(P cp, int nc, int t, int tl, int h, float qx, float qy, float qz, float &m, int &kmin) {
+    float d[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float4 v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = cp[(size_t)tl * 32 + 8 * g + 4 * h + e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[4 * g + e] = dist3(v[e].x, v[e].y, v[e].z, qx, qy, qz);
+    }
+    m = fminf(fminf(d[0], d[1]), d[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) m = fminf(fminf(m, d[r]), d[r + 1]);
+    m = fminf(m, d[15]);
+    kmin = INT_MAX;
+#pragma unroll
+    for (int r = 15; r >= 0; --r) {
+        const int k = t * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+        kmin = (d[r] == m && k < nc) ? k : kmin;
+    }
+}
+
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
 
@@ -178,8 +205,7 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint4 *sfrag = (uint4 *)lds;                                  // [CT][64]
     float4 *spts = (float4 *)(lds + CT * 1024);                    // [CT][32]
-    unsigned short *qtile = (unsigned short *)(lds + CT * 1536);   // [QW][QCAP][64]
-    float *qmin = (float *)(lds + CT * 1536 + QW * QCAP * 64 * 2); // [QW][QCAP][64]
+    unsigned char *qtile = (unsigned char *)(lds + CT * 1536);     // [QW][SCH][64]: a lane's surviving tiles of the current chunk
     __shared__ float s_r2[QW];
     const bool pairwise = args.pn2 > 0;
     const int dir = pairwise ? (int)(blockIdx.z & 1) : (int)blockIdx.z;
@@ -259,11 +285,10 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
     float tau = 0.f;
     bool slow = false;
 
-    unsigned short *myq = qtile + (size_t)wave * QCAP * 64;
-    float *mym = qmin + (size_t)wave * QCAP * 64;
+    unsigned char *myq = qtile + (size_t)wave * SCH * 64;
+    unsigned short *wl = (unsigned short *)(lds + CT * 1536 + QW * SCH * 64) + (size_t)wave * WCAP;      // (source lane << 8) | tile
+    uint2 *res = (uint2 *)myq;                                     // (distance bits, index) per work item, once the lists are consumed
     float smin = __builtin_inff();
-    int qcount = 0, q0t = 0;
-    float q0m = 0.f;
     float best = __builtin_inff();
     int bidx = INT_MAX;
     const int npass = (nct + CT - 1) / CT;
@@ -303,58 +328,96 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
             if (nn_not_finite(m)) { slow = true; break; }                     // workgroup-uniform: m comes from LDS
         }
         if (wave_live) {
-            // hit = smin + tau and low = smin - tau are kept up to date where smin changes -- inside the hit path (a new
-            // minimum is a hit) -- so a tile that is not a hit costs one compare, and telling a clear new minimum from a
-            // near-tie another one.  low = +inf at the start of a pass: its first hit becomes the head of the empty queue.
-            float hit = smin + tau, low = __builtin_inff();
-            // Queue of a lane: the head (q0t, q0m) lives in registers, near-ties of it in LDS slots 0..qcount-2.  The
-            // common event -- a new minimum that undercuts the old one by more than tau, which puts every queued tile
-            // (all >= smin) out of range -- is three register moves.
-            auto visit = [&](int t, float m) {
-                if (m <= hit) {                                               // record low or near-tie of the running minimum
-                    if (m < low) {
-                        q0t = t; q0m = m; qcount = 1;
-                    } else if (qcount < QCAP) {
-                        myq[(qcount - 1) * 64 + lane] = (unsigned short)t; mym[(qcount - 1) * 64 + lane] = m; ++qcount;
-                    } else {
-                        // full of near-ties (duplicate points, lattice data): settle the head exactly now -- evaluation
-                        // order does not matter for the (d, index) rule -- and put the newcomer in its place
-                        exact_tile(spts, nc, t0 + q0t, q0t, h, qx, qy, qz, best, bidx);
-                        q0t = t; q0m = m;
+            // r04: the sweep keeps NO queue.  r01-r03 visited every tile with the running minimum (a hit test, a head in
+            // registers, near-ties in LDS, an overflow path): ~13 VALU + two exec-mask branches per tile beside the 10 of the
+            // v_min3 tree, and with 64 lanes some lane hits in almost every tile -- ~94 cycles per tile against the MFMA's 32.
+            // Now a chunk of SCH tiles leaves only its surrogate minima in registers (MFMAs issued one group ahead of the trees
+            // that read them: no wait states), then the threshold is known -- running minimum so far + tau: the final one can
+            // only be lower, so the survivors are a superset -- and a branch-free pass lists the lane's survivors (write-always
+            // slot, counter += predicate); they are evaluated exactly as before.
+            for (int c0 = 0; c0 < tn; c0 += SCH) {
+                const int cn = min(SCH, tn - c0);                             // wave-uniform
+                float mt[SCH];
+                // (a ragged last chunk repeats its last tile: a repeated survivor is evaluated twice, which changes nothing)
+                auto frag = [&](int u) { return sfrag[(c0 + min(u, cn - 1)) * 64 + lane]; };
+                {
+                    f32x16 a = mfma(frag(0), bq);
+#pragma unroll
+                    for (int u = 0; u < SCH; u += 2) {
+                        const f32x16 b = mfma(frag(u + 1), bq);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mt[u] = tile_min(a);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (u + 2 < SCH) a = mfma(frag(u + 2), bq);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mt[u + 1] = tile_min(b);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    smin = fminf(smin, m);
-                    hit = smin + tau;
-                    low = smin - tau;
                 }
-            };
-            int t = 0;
-            for (; t + 4 <= tn; t += 4) {                                     // four independent MFMAs in flight
-                const f32x16 s0 = mfma(sfrag[(t + 0) * 64 + lane], bq), s1 = mfma(sfrag[(t + 1) * 64 + lane], bq);
-                const f32x16 s2 = mfma(sfrag[(t + 2) * 64 + lane], bq), s3 = mfma(sfrag[(t + 3) * 64 + lane], bq);
-                const float m0 = tile_min(s0), m1 = tile_min(s1), m2 = tile_min(s2), m3 = tile_min(s3);
-                visit(t + 0, m0); visit(t + 1, m1); visit(t + 2, m2); visit(t + 3, m3);
-            }
-            for (; t < tn; ++t) visit(t, tile_min(mfma(sfrag[t * 64 + lane], bq)));
-            // exact evaluation of this pass's surviving tiles against the pass-local threshold (the
-            // global minimum can only be lower, so this is a superset; extra exact evaluations are harmless)
-            const float thr = fminf(smin, __shfl_xor(smin, 32)) + tau;
-            {
+                float cm = fminf(fminf(mt[0], mt[1]), mt[2]);
+#pragma unroll
+                for (int u = 3; u + 1 < SCH; u += 2) cm = fminf(fminf(cm, mt[u]), mt[u + 1]);
+                cm = fminf(cm, mt[SCH - 1]);
+                smin = fminf(smin, cm);
+                const float thr = fminf(smin, __shfl_xor(smin, 32)) + tau;
                 int nsurv = 0;
-                for (int e = 0; e + 1 < QCAP; ++e)                            // near-ties first (compacted in place) ...
-                    if (e + 1 < qcount && mym[e * 64 + lane] <= thr) { myq[nsurv * 64 + lane] = myq[e * 64 + lane]; ++nsurv; }
-                if (qcount > 0 && q0m <= thr) { myq[nsurv * 64 + lane] = (unsigned short)q0t; ++nsurv; }   // ... then the head
+#pragma unroll
+                for (int u = 0; u < SCH; ++u) {                               // nsurv <= u: the slot is always inside the list
+                    myq[nsurv * 64 + lane] = (unsigned char)u;
+                    nsurv += mt[u] <= thr ? 1 : 0;
+                }
                 int smax = nsurv;
                 for (int d = 32; d > 0; d >>= 1) smax = max(smax, __shfl_xor(smax, d));
                 smax = __builtin_amdgcn_readfirstlane(smax);
-                for (int e = 0; e < smax; ++e) {
-                    const bool take = e < nsurv;
-                    const int tl = take ? myq[e * 64 + lane] : 0;
-                    float b2 = best; int i2 = bidx;
-                    exact_tile(spts, nc, t0 + tl, tl, h, qx, qy, qz, b2, i2);
-                    if (take) { best = b2; bidx = i2; }
+                // Exact evaluation.  A lane has 1-2 survivors per chunk on average but the wave's maximum is ~4, and a
+                // round of the per-lane loop costs a whole exact_tile for every lane: instead the wave's survivors go into
+                // ONE lane-major work list (exclusive scan of the counts), 64 items are evaluated per round by whichever
+                // lane comes -- the owner's query arrives by shuffle -- and the owners merge their own results under the
+                // (d, index) rule, which does not care about order.  (An adversarial chunk with more than WCAP items keeps
+                // the per-lane loop.)
+                int off = nsurv;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(off, d); off += lane >= d ? v : 0; }
+                const int W = __builtin_amdgcn_readlane(off, 63);
+                off -= nsurv;
+                if (W <= WCAP) {
+                    for (int e = 0; e < smax; ++e)
+                        if (e < nsurv) wl[off + e] = (unsigned short)((lane << 8) | myq[e * 64 + lane]);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    for (int i0 = 0; i0 < W; i0 += 64) {
+                        const int i = i0 + lane;
+                        const unsigned item = wl[min(i, W - 1)];
+                        const int sl = (int)(item >> 8), tl = c0 + (int)(item & 255u);
+                        const float sx = __shfl(qx, sl), sy = __shfl(qy, sl), sz = __shfl(qz, sl);
+                        float m; int k;
+                        exact_tile_mk(spts, nc, t0 + tl, tl, sl >> 5, sx, sy, sz, m, k);
+                        if (i < W) res[i] = make_uint2(__float_as_uint(m), (unsigned)k);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    for (int e = 0; e < smax; ++e) {
+                        if (e < nsurv) {
+                            const uint2 r = res[off + e];
+                            const float m = __uint_as_float(r.x);
+                            const int k = (int)r.y;
+                            const bool better = k != INT_MAX && (m < best || (m == best && k < bidx));
+                            best = better ? m : best;
+                            bidx = better ? k : bidx;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();                      // the results' space is the next chunk's lists
+                } else {
+                    for (int e = 0; e < smax; ++e) {
+                        const bool take = e < nsurv;
+                        const int tl = c0 + (take ? (int)myq[e * 64 + lane] : 0);
+                        float b2 = best; int i2 = bidx;
+                        exact_tile(spts, nc, t0 + tl, tl, h, qx, qy, qz, b2, i2);
+                        if (take) { best = b2; bidx = i2; }
+                    }
                 }
             }
-            qcount = 0;                                                       // the queue is per pass; smin carries over
         }
     }
     if (slow && wave_live)          // both lane halves scan for their query: the merge below then finds them equal
@@ -400,7 +463,7 @@ static long nnm_workgroups(int b, int n, int m, int qw) {
 template <int QW>
 static int launch_nnm_qw(const MArgs &ma, int b, int nmax, hipStream_t s) {
     // (the grid's x extent is the stride of the partial sums when ma.part is set)
-    const int lds = CT * 1536 + QW * QCAP * 64 * 6;
+    const int lds = nnm_lds_bytes(QW);
     static LdsLimit limit;
     if (hipError_t e = limit.ensure((const void *)nnm_kernel<QW>, lds); e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(nnm_kernel<QW>, dim3((nmax + QW * 32 - 1) / (QW * 32), b, 2), dim3(QW * 64), lds, s, ma);
@@ -494,12 +557,12 @@ extern "C" int dpf_pairwise_cd(int n1, int n2, int n, int m, const float *clouds
     // the tickets (first n1 * n2 words) start at zero; the last arriver of every pair resets its own
     if (hipError_t e = dpf_zero_async(workspace, (size_t)npairs * sizeof(unsigned), s); e != hipSuccess) return (int)e;
     if (qw == 16) {
-        const int lds = CT * 1536 + 16 * QCAP * 64 * 6;
+        const int lds = nnm_lds_bytes(16);
         static LdsLimit limit;
         if (hipError_t e = limit.ensure((const void *)nnm_kernel<16>, lds); e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(nnm_kernel<16>, dim3(nwg, n2, 2 * n1), dim3(16 * 64), lds, s, ma);
     } else {
-        const int lds = CT * 1536 + 8 * QCAP * 64 * 6;
+        const int lds = nnm_lds_bytes(8);
         static LdsLimit limit;
         if (hipError_t e = limit.ensure((const void *)nnm_kernel<8>, lds); e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(nnm_kernel<8>, dim3(nwg, n2, 2 * n1), dim3(8 * 64), lds, s, ma);

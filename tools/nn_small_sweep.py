@@ -8,6 +8,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from dpf_nets_amd import _lib as _L                             # noqa: E402
+if os.environ.get("DPF_LIB"):                                    # a timing-experiment build of the library
+    _L.lib_path = lambda: os.path.join(ROOT, "dpf_nets_amd", os.environ["DPF_LIB"])
 import bench                                                     # noqa: E402
 from dpf_nets_amd import synthetic as SY                         # noqa: E402
 from dpf_nets_amd._lib import lib, current_stream                # noqa: E402
