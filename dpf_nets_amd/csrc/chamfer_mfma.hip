@@ -172,14 +172,20 @@ __device__ __forceinline__ void exact_tile(P cp, int nc, int t, int tl, int h, f
 // candidates lane half `h` sees in tile `t`, for the owner to merge under the (d, index) rule (INT_MAX: no candidate)
 template <class P>
 __device__ __forceinline__ void exact_tile_mk(P cp, int nc, int t, int tl, int h, float qx, float qy, float qz, float &m, int &kmin) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
     float d[16];
+    const f2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         float4 v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = cp[(size_t)tl * 32 + 8 * g + 4 * h + e];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) d[4 * g + e] = dist3(v[e].x, v[e].y, v[e].z, qx, qy, qz);
+        for (int e = 0; e < 4; e += 2) {     // two candidates per packed instruction; every operation rounded on its own, as dist3
+            const f2 dx = f2{v[e].x, v[e + 1].x} - qx2, dy = f2{v[e].y, v[e + 1].y} - qy2, dz = f2{v[e].z, v[e + 1].z} - qz2;
+            const f2 dd = (dx * dx + dy * dy) + dz * dz;
+            d[4 * g + e] = dd.x; d[4 * g + e + 1] = dd.y;
+        }
     }
     m = fminf(fminf(d[0], d[1]), d[2]);
 #pragma unroll
@@ -338,9 +344,33 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
             for (int c0 = 0; c0 < tn; c0 += SCH) {
                 const int cn = min(SCH, tn - c0);                             // wave-uniform
                 float mt[SCH];
-                // (a ragged last chunk repeats its last tile: a repeated survivor is evaluated twice, which changes nothing)
-                auto frag = [&](int u) { return sfrag[(c0 + min(u, cn - 1)) * 64 + lane]; };
-                {
+                if (QW < 16 && cn == SCH) {
+                    // fragments two tiles ahead of their MFMA (one ds_read_b128 each, immediate offsets), MFMAs one tile ahead
+                    // of the tree that reads them.  (Smaller workgroups only: they serve small launches, where a wave has few
+                    // neighbours to hide its LDS latency -- B = 12: 14.6 -> 13.3 us; the 16-wave form has four waves per SIMD,
+                    // no use for it (B = 32: 20.6 vs 20.5) and no registers: it must fit 128.)
+                    const uint4 *fr = sfrag + c0 * 64 + lane;
+                    uint4 fa = fr[0], fb = fr[64];
+                    f32x16 a = mfma(fa, bq);
+                    fa = fr[2 * 64];
+#pragma unroll
+                    for (int u = 0; u < SCH; u += 2) {
+                        const f32x16 b = mfma(fb, bq);
+                        if (u + 3 < SCH) fb = fr[(u + 3) * 64];
+                        __builtin_amdgcn_sched_barrier(0);
+                        mt[u] = tile_min(a);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (u + 2 < SCH) {
+                            a = mfma(fa, bq);
+                            if (u + 4 < SCH) fa = fr[(u + 4) * 64];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        mt[u + 1] = tile_min(b);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+                    // (a ragged last chunk repeats its last tile: a repeated survivor is evaluated twice, which changes nothing)
+                    auto frag = [&](int u) { return sfrag[(c0 + min(u, cn - 1)) * 64 + lane]; };
                     f32x16 a = mfma(frag(0), bq);
 #pragma unroll
                     for (int u = 0; u < SCH; u += 2) {
