@@ -129,7 +129,9 @@ __device__ __forceinline__ float tile_min(const f32x16 &s) {
     m = fminf(fminf(m, s[3]), s[4]);   m = fminf(fminf(m, s[5]), s[6]);
     m = fminf(fminf(m, s[7]), s[8]);   m = fminf(fminf(m, s[9]), s[10]);
     m = fminf(fminf(m, s[11]), s[12]); m = fminf(fminf(m, s[13]), s[14]);
-    return fminf(m, s[15]);
+    // eight v_min3: the last one takes s[0] again rather than being a two-input minimum, whose operands the compiler
+    // canonicalises with two extra instructions (it cannot know that an MFMA result is not a signalling NaN)
+    return fminf(fminf(m, s[15]), s[0]);
 }
 __device__ __forceinline__ float dist3(float cx, float cy, float cz, float qx, float qy, float qz) {
     const float dx = cx - qx, dy = cy - qy, dz = cz - qz;
@@ -301,9 +303,11 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
     for (int pass = 0; pass < npass; ++pass) {
         const int t0 = pass * CT, tn = min(CT, nct - t0);
         if (pass > 0) __syncthreads();                                        // everyone is done with the previous pass
+        int tidp = tid;                    // opaque: the build's LDS addresses are made here, per pass, not carried through the sweep
+        asm volatile("" : "+v"(tidp));
 #pragma unroll
         for (int k = 0; k < CT * 32 / (QW * 64); ++k) {                       // two candidates per thread
-            const int pl = tid + k * QW * 64, t = pl >> 5, i = pl & 31, p = t0 * 32 + pl;
+            const int pl = tidp + k * QW * 64, t = pl >> 5, i = pl & 31, p = t0 * 32 + pl;
             if (t < tn) {
                 const bool live = p < nc;
                 float x = 0.f, y = 0.f, z = 0.f;
@@ -344,29 +348,44 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
             for (int c0 = 0; c0 < tn; c0 += SCH) {
                 const int cn = min(SCH, tn - c0);                             // wave-uniform
                 float mt[SCH];
-                if (QW < 16 && cn == SCH) {
-                    // fragments two tiles ahead of their MFMA (one ds_read_b128 each, immediate offsets), MFMAs one tile ahead
-                    // of the tree that reads them.  (Smaller workgroups only: they serve small launches, where a wave has few
-                    // neighbours to hide its LDS latency -- B = 12: 14.6 -> 13.3 us; the 16-wave form has four waves per SIMD,
-                    // no use for it (B = 32: 20.6 vs 20.5) and no registers: it must fit 128.)
-                    const uint4 *fr = sfrag + c0 * 64 + lane;
-                    uint4 fa = fr[0], fb = fr[64];
-                    f32x16 a = mfma(fa, bq);
-                    fa = fr[2 * 64];
+                if (cn == SCH) {
+                    const uint4 *fr = sfrag + c0 * 64 + lane;                 // tile u at fr[64 u]: immediate offsets
+                    if constexpr (QW < 16) {
+                        // fragments two tiles ahead of their MFMA, MFMAs one tile ahead of the tree that reads them.  (Smaller
+                        // workgroups only: they serve small launches, where a wave has few neighbours to hide its LDS
+                        // latency -- B = 12: 14.6 -> 13.3 us; the 16-wave form has four waves per SIMD, no use for it
+                        // (B = 32: 20.6 vs 20.5) and no registers: it must fit 128.)
+                        uint4 fa = fr[0], fb = fr[64];
+                        f32x16 a = mfma(fa, bq);
+                        fa = fr[2 * 64];
 #pragma unroll
-                    for (int u = 0; u < SCH; u += 2) {
-                        const f32x16 b = mfma(fb, bq);
-                        if (u + 3 < SCH) fb = fr[(u + 3) * 64];
-                        __builtin_amdgcn_sched_barrier(0);
-                        mt[u] = tile_min(a);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (u + 2 < SCH) {
-                            a = mfma(fa, bq);
-                            if (u + 4 < SCH) fa = fr[(u + 4) * 64];
+                        for (int u = 0; u < SCH; u += 2) {
+                            const f32x16 b = mfma(fb, bq);
+                            if (u + 3 < SCH) fb = fr[(u + 3) * 64];
+                            __builtin_amdgcn_sched_barrier(0);
+                            mt[u] = tile_min(a);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (u + 2 < SCH) {
+                                a = mfma(fa, bq);
+                                if (u + 4 < SCH) fa = fr[(u + 4) * 64];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            mt[u + 1] = tile_min(b);
+                            __builtin_amdgcn_sched_barrier(0);
                         }
-                        __builtin_amdgcn_sched_barrier(0);
-                        mt[u + 1] = tile_min(b);
-                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+                        f32x16 a = mfma(fr[0], bq);
+#pragma unroll
+                        for (int u = 0; u < SCH; u += 2) {
+                            const f32x16 b = mfma(fr[(u + 1) * 64], bq);
+                            __builtin_amdgcn_sched_barrier(0);
+                            mt[u] = tile_min(a);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (u + 2 < SCH) a = mfma(fr[(u + 2) * 64], bq);
+                            __builtin_amdgcn_sched_barrier(0);
+                            mt[u + 1] = tile_min(b);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
                 } else {
                     // (a ragged last chunk repeats its last tile: a repeated survivor is evaluated twice, which changes nothing)
@@ -457,16 +476,21 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
     const float od = __shfl_xor(best, 32);
     const int oi = __shfl_xor(bidx, 32);
     if (od < best || (od == best && oi < bidx)) { best = od; bidx = oi; }
+    // (the query index is made again from the thread index: carried from the top of the kernel it is the one value that does not
+    // fit the 16-wave form's 128 registers)
+    int tid_out = threadIdx.x;
+    asm volatile("" : "+v"(tid_out));
+    const int j_out = (blockIdx.x * QW + (tid_out >> 6)) * 32 + (tid_out & 31);
     if (!pairwise) {
-        if (wave_live && h == 0 && j < nq) {
-            A.dist[(size_t)bi * nq + j] = best;
-            A.idx[(size_t)bi * nq + j] = bidx;
+        if (wave_live && h == 0 && j_out < nq) {
+            A.dist[(size_t)bi * nq + j_out] = best;
+            A.idx[(size_t)bi * nq + j_out] = bidx;
         }
         if (!sums) return;
     }
     // sum of this workgroup's distances in a fixed order -- butterfly over the 32 queries of a wave, waves in
     // ascending order -- so that the result does not depend on scheduling
-    float sum = (wave_live && h == 0 && j < nq) ? best : 0.f;
+    float sum = (wave_live && h == 0 && j_out < nq) ? best : 0.f;
     for (int d = 16; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
     __syncthreads();                                   // s_r2 is free again (every wave has read tau's inputs long ago)
     if (lane == 0) s_r2[wave] = sum;
