@@ -448,6 +448,14 @@ __device__ __forceinline__ void layer_pipe(const uint8_t *lb, int lane, int h, u
     constexpr int A0OFF = p_a0_off(NS), FILMOFF = p_layer_bytes(NS);
     typedef Terms<NS> TT;
     const float *film = (const float *)(lb + FILMOFF);
+    // The FiLM vectors' reads are "slot + constant + 16 h": left alone the compiler keeps the lane part (16 h) in one register,
+    // puts slot + constant into 32 SGPRs and spends a v_add_u32 per read -- 32 VALU per layer in a kernel bound by VALU issue.
+    // One LDS pointer per layer, opaque to the optimiser, makes every read that register + a 16-bit immediate (r04).
+    typedef __attribute__((address_space(3))) const uint8_t lds_u8;
+    typedef __attribute__((address_space(3))) const f32x4 lds_f4;
+    lds_u8 *fl3 = (lds_u8 *)(lb + FILMOFF + 16 * h);
+    asm volatile("" : "+v"(fl3));
+    auto film4 = [&](int float_index) { return *(lds_f4 *)(fl3 + 4 * float_index); };      // floats film[i + 4 h .. i + 4 h + 3]
     const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 acc0[2][2], acc1[2][2];
     u32x4 bfrag[2][NS][4];
@@ -469,7 +477,7 @@ __device__ __forceinline__ void layer_pipe(const uint8_t *lb, int lane, int h, u
         if (DPF_ABLATE & 512) { acc1[br][tp] = z16; return; }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 dv = *(const f32x4 *)(film + br * FILM_BR_FLOATS + 32 * tp + 8 * q + 4 * h);
+            const f32x4 dv = film4(br * FILM_BR_FLOATS + 32 * tp + 8 * q);
             acc1[br][tp][4 * q + 0] = dv.x; acc1[br][tp][4 * q + 1] = dv.y;
             acc1[br][tp][4 * q + 2] = dv.z; acc1[br][tp][4 * q + 3] = dv.w;
         }
@@ -521,13 +529,12 @@ __device__ __forceinline__ void layer_pipe(const uint8_t *lb, int lane, int h, u
     float pa[2][2], pb[2][2];                                      // [br][even/odd]
     f32x4 cwa[2][4], cwb[2][4];                                    // [slot][q]: slot = (br + tp) & 1 alternates
     auto ld_cw = [&](int br, int tp) {
-        const float *wa = film + br * FILM_BR_FLOATS + 64, *wb2 = wa + 64;
         const int sl = (br * 2 + tp) & 1;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int f0 = 32 * tp + 8 * q + 4 * h;
-            cwa[sl][q] = *(const f32x4 *)(wa + f0);
-            if (TWO) cwb[sl][q] = *(const f32x4 *)(wb2 + f0);
+            const int f0 = br * FILM_BR_FLOATS + 64 + 32 * tp + 8 * q;
+            cwa[sl][q] = film4(f0);
+            if (TWO) cwb[sl][q] = film4(f0 + 64);
         }
     };
     auto contract = [&](int br, int tp, int q0 = 0, int q1 = 4) {   // features 8 q0 .. 8 q1 of M tile tp
