@@ -213,7 +213,7 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint4 *sfrag = (uint4 *)lds;                                  // [CT][64]
     float4 *spts = (float4 *)(lds + CT * 1024);                    // [CT][32]
-    unsigned char *qtile = (unsigned char *)(lds + CT * 1536);     // [QW][SCH][64]: a lane's surviving tiles of the current chunk
+    unsigned char *qtile = (unsigned char *)(lds + CT * 1536);     // [QW][WCAP] 8-byte results of the wave-wide work list
     __shared__ float s_r2[QW];
     const bool pairwise = args.pn2 > 0;
     const int dir = pairwise ? (int)(blockIdx.z & 1) : (int)blockIdx.z;
@@ -293,9 +293,8 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
     float tau = 0.f;
     bool slow = false;
 
-    unsigned char *myq = qtile + (size_t)wave * SCH * 64;
     unsigned short *wl = (unsigned short *)(lds + CT * 1536 + QW * SCH * 64) + (size_t)wave * WCAP;      // (source lane << 8) | tile
-    uint2 *res = (uint2 *)myq;                                     // (distance bits, index) per work item, once the lists are consumed
+    uint2 *res = (uint2 *)(qtile + (size_t)wave * SCH * 64);       // (distance bits, index) per work item of the wave
     float smin = __builtin_inff();
     float best = __builtin_inff();
     int bidx = INT_MAX;
@@ -343,8 +342,8 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
             // v_min3 tree, and with 64 lanes some lane hits in almost every tile -- ~94 cycles per tile against the MFMA's 32.
             // Now a chunk of SCH tiles leaves only its surrogate minima in registers (MFMAs issued one group ahead of the trees
             // that read them: no wait states), then the threshold is known -- running minimum so far + tau: the final one can
-            // only be lower, so the survivors are a superset -- and a branch-free pass lists the lane's survivors (write-always
-            // slot, counter += predicate); they are evaluated exactly as before.
+            // only be lower, so the survivors are a superset -- and a branch-free pass marks the lane's survivors in a bit mask
+            // (compare, shift-or); they are evaluated exactly, from a wave-wide work list (below).
             for (int c0 = 0; c0 < tn; c0 += SCH) {
                 const int cn = min(SCH, tn - c0);                             // wave-uniform
                 float mt[SCH];
@@ -409,12 +408,11 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
                 cm = fminf(cm, mt[SCH - 1]);
                 smin = fminf(smin, cm);
                 const float thr = fminf(smin, __shfl_xor(smin, 32)) + tau;
-                int nsurv = 0;
+                // the lane's survivors as a bit mask (tile u at bit SCH - 1 - u): a compare and a shift-or per tile, no list
+                unsigned smask = 0;
 #pragma unroll
-                for (int u = 0; u < SCH; ++u) {                               // nsurv <= u: the slot is always inside the list
-                    myq[nsurv * 64 + lane] = (unsigned char)u;
-                    nsurv += mt[u] <= thr ? 1 : 0;
-                }
+                for (int u = 0; u < SCH; ++u) smask = (smask << 1) | (mt[u] <= thr ? 1u : 0u);
+                const int nsurv = __builtin_popcount(smask);
                 int smax = nsurv;
                 for (int d = 32; d > 0; d >>= 1) smax = max(smax, __shfl_xor(smax, d));
                 smax = __builtin_amdgcn_readfirstlane(smax);
@@ -430,8 +428,13 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
                 const int W = __builtin_amdgcn_readlane(off, 63);
                 off -= nsurv;
                 if (W <= WCAP) {
-                    for (int e = 0; e < smax; ++e)
-                        if (e < nsurv) wl[off + e] = (unsigned short)((lane << 8) | myq[e * 64 + lane]);
+                    {
+                        unsigned mk = smask;
+                        for (int e = 0; e < smax; ++e) {
+                            if (mk != 0) wl[off + e] = (unsigned short)((lane << 8) | (SCH - 1 - __builtin_ctz(mk)));
+                            mk &= mk - 1;
+                        }
+                    }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     for (int i0 = 0; i0 < W; i0 += 64) {
@@ -456,11 +459,13 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
                         }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();                      // the results' space is the next chunk's lists
+                    __builtin_amdgcn_wave_barrier();                      // the results' space is the next chunk's
                 } else {
+                    unsigned mk = smask;
                     for (int e = 0; e < smax; ++e) {
-                        const bool take = e < nsurv;
-                        const int tl = c0 + (take ? (int)myq[e * 64 + lane] : 0);
+                        const bool take = mk != 0;
+                        const int tl = c0 + (take ? SCH - 1 - __builtin_ctz(mk) : 0);
+                        mk &= mk - 1;
                         float b2 = best; int i2 = bidx;
                         exact_tile(spts, nc, t0 + tl, tl, h, qx, qy, qz, b2, i2);
                         if (take) { best = b2; bidx = i2; }
