@@ -411,7 +411,9 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
                 // the lane's survivors as a bit mask (tile u at bit SCH - 1 - u): a compare and a shift-or per tile, no list
                 unsigned smask = 0;
 #pragma unroll
-                for (int u = 0; u < SCH; ++u) smask = (smask << 1) | (mt[u] <= thr ? 1u : 0u);
+                for (int u = 0; u < SCH; ++u)          // smask = 2 smask + (mt[u] <= thr): a compare and an add-with-carry (the compiler's
+                                                       // own form is compare, select, shift, or)
+                    asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(smask) : "v"(mt[u]), "v"(thr) : "vcc");
                 const int nsurv = __builtin_popcount(smask);
                 int smax = nsurv;
                 for (int d = 32; d > 0; d >>= 1) smax = max(smax, __shfl_xor(smax, d));
