@@ -534,7 +534,7 @@ extern "C" int dpf_nn_small_mode(int mode) {
 // rank-sized batches of mid-sized clouds: the LDS-staged kernel.  One workgroup per CU or fewer (B = 4 clouds of 2048 points:
 // 10.4 us against the scalar-load scan's 14.9); with more the CUs that hold two workgroups set the pace and the scan that
 // streams its candidates through SGPRs is as fast (B = 8: 16.0 vs 15.9 us; r04_small/sweep.txt).
-static bool nn_small_serves(int b, int n, int m) {
+bool nn_small_serves(int b, int n, int m) {       // (also asked by chamfer_mfma.hip's choice of kernel)
     const int nmax = n > m ? n : m, minc = n < m ? n : m;
     if (g_nn_small_mode == 0 || nmax > 8192 || b > 65535) return false;
     if (g_nn_small_mode == 1) return true;

@@ -552,10 +552,17 @@ static int launch_nnm(int b, int n, const float *xyz, long xyz_stride, int m, co
 // enough pairs to amortise building the fragments and enough workgroups to fill the chip (r01, tools/nn_impl_sweep.py:
 // 25 vs 52 us at B=32, n=m=2048; 76 vs 190 us at B=8, n=m=8192; 50 vs 64 us at B=2, n=m=8192); small clouds and small
 // batches are launch-bound either way and few workgroups leave the matrix cores idle
+// r04, after the filter's bookkeeping was rebuilt (see nnm_kernel): it also wins for mid-sized batches of clouds whose
+// fragments fit one pass -- B = 6 / 8 / 10 clouds of 2048: 13.4 / 12.0 / 12.1 us against the scans' 15.2 / 15.3 / 24.4; 16 clouds
+// of 1024: 8.2 vs 10.0 -- but not where the LDS-staged scan serves (one workgroup per CU or fewer: B = 4: 10.4 vs 13.3) and not
+// for clouds a little over one pass (B = 4, N = 2500: 22.8 vs 17.3).
+bool nn_small_serves(int b, int n, int m);      // chamfer.hip
 static bool nnm_pays(int b, int n, int m) {
     if (b <= 0 || n <= 0 || m <= 0 || b > 65535 || n > 65535 * 32 || m > 65535 * 32) return false;
+    if (nnm_workgroups(b, n, m, 8) < 64) return false;                // B=1, n=m=8192: 48 vs 57 us
     const double pairs = 2.0 * (double)b * (double)n * (double)m;
-    return pairs >= 1.0e8 && nnm_workgroups(b, n, m, 8) >= 64;      // B=1, n=m=8192: 48 vs 57 us
+    if (pairs >= 1.0e8) return true;
+    return pairs >= 3.0e7 && (n > m ? n : m) <= CT * 32 && !nn_small_serves(b, n, m);
 }
 
 extern "C" int dpf_nndistance_mfma(int b, int n, const float *xyz, int m, const float *xyz2, float *result,
@@ -650,14 +657,14 @@ extern "C" int dpf_nndistance_cd(int b, int n, const float *xyz, int m, const fl
     if (b == 0) return 0;
     if (!xyz || !xyz2 || !result || !result_i || !result2 || !result2_i || !cd) return DPF_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (workspace && workspace_bytes >= dpf_nndistance_cd_workspace_bytes(b, n, m) && nnm_pays(b, n, m) &&
-        nnm_workgroups(b, n, m, 16) >= 128) {
+    if (workspace && workspace_bytes >= dpf_nndistance_cd_workspace_bytes(b, n, m) && nnm_pays(b, n, m)) {
         // tickets (first b words): zero on entry -- `tickets_are_zero` = 0 makes this call clear them first -- and zero again
         // on exit, so a caller that keeps the workspace pays the memset once
         if (!tickets_are_zero)
             if (hipError_t e = dpf_zero_async(workspace, (size_t)b * sizeof(unsigned), s); e != hipSuccess) return (int)e;
+        // (the workgroup size is launch_nnm's choice: the scratch has room for the finest tiling's sums)
         return launch_nnm(b, n, xyz, (long)n * 3, m, xyz2, (long)m * 3, result, result_i, result2, result2_i, s,
-                          (float *)workspace + b, true, (unsigned *)workspace, cd);
+                          (float *)workspace + b, false, (unsigned *)workspace, cd);
     }
     if (workspace && workspace_bytes >= dpf_nndistance_cd_workspace_bytes(b, n, m) && !nnm_pays(b, n, m)) {
         // a rank's handful of clouds: the LDS-staged scan finishes the reduction the same way (chamfer.hip nn_small_kernel)
