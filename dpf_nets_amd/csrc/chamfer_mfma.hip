@@ -14,15 +14,16 @@
 // two clouds; derivation in docs/DESIGN_history_r01_r03.md 4.3), so the fp32-exact minimiser -- and
 // every exact tie -- has s <= s_min + tau with tau = 2^-12 * R2.  ONE sweep over
 // the candidate tiles: per tile one MFMA and a v_min3 tree over the accumulator
-// fragment (0.5 VALU op per pair); a tile whose minimum is within tau of the
-// RUNNING minimum is queued per lane; a new minimum that undercuts the old one by
-// more than tau empties the queue first (everything in it is then out of range),
-// so the queue holds genuine near-ties only and is a superset of what the final
-// threshold selects.  Afterwards the queue is filtered with the final s_min
-// and only those few tiles are evaluated with the exact formula and the
-// (d, index) lexicographic rule.  When a lane's queue is full of genuine near-ties
-// (duplicate points, lattice data) its oldest entry is settled exactly on the spot,
-// so the result is exact for any finite input and the cost degrades gracefully.
+// fragment (0.5 VALU op per pair).  Since r04 the sweep keeps no queue: a chunk of
+// 32 tiles leaves its surrogate minima in registers, then every tile within tau of
+// the minimum SO FAR is marked in a per-lane bit mask -- the final minimum can only
+// be lower, so the marked tiles are a superset of what the final threshold selects
+// -- and only those few tiles are evaluated with the exact formula and the
+// (d, index) lexicographic rule, 64 at a time from one wave-wide work list (a lane
+// has 1-2 of them, the wave's maximum is ~4: the per-lane loop of r01-r03 paid a
+// whole evaluation per lane and round).  A chunk that is full of genuine near-ties
+// (duplicate points, lattice data: more than 256 items per wave) keeps the per-lane
+// loop, so the result is exact for any finite input and the cost degrades gracefully.
 // The surrogate works on coordinates translated to the mean of the first 64
 // candidates: tau then scales with the extent of the data, not with its offset.
 #include <hip/hip_runtime.h>
