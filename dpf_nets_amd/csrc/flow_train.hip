@@ -25,7 +25,7 @@
 //                          recomputes them rather than wait for a one-workgroup kernel); recompute; BN1
 //                          backward; dh0 = W1^T dh1 and dW1 = dh1 h0^T on the matrix cores; per point
 //                          u_k = sum_f c_fk dh0a[f] (2 floats, stored); per feature sums of
-//                          dh0a * {1, h0n, x_a, x_b}
+//                          dh0a * {1, x_a - E x_a, x_b - E x_b}  (sum dh0a * h0n follows from them: h0n is linear in x)
 //            tcolsum       per-workgroup partials -> totals
 //            (tbwd3f       pass 3 as its own launch: last layer of a call only)
 // (every dependent launch costs ~4.5 us on this part however small the kernel, so the tiny finishing steps are
@@ -46,6 +46,7 @@
 
 #include <atomic>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "flow_common.h"
@@ -70,7 +71,7 @@ constexpr int T_LAYER = 2 * T_BR;
 // ---- packed per-layer training block (bytes); its head is the eval layer format of precision NS ---
 constexpr int PT_A1 = 0;                                                   // W1 fragments, NS parts x 16384
 __host__ __device__ constexpr int pt_a0(int NS) { return NS * P_A1_PART; }           // input MFMA, gamma*rstd0 / beta
-__host__ __device__ constexpr int pt_a0n(int NS) { return pt_a0(NS) + 4096; }        // input MFMA -> NORMALISED h0
+__host__ __device__ constexpr int pt_a0n(int NS) { return pt_a0(NS) + 4096; }        // 4 KiB nobody fills (r01-r04: a second input-MFMA set for the normalised h0); in LDS: pass 2's dh1 fragments
 __host__ __device__ constexpr int pt_a1t(int NS) { return pt_a0(NS) + 8192; }        // W1^T fragments, hi | lo
 __host__ __device__ constexpr int pt_tail(int NS) { return pt_a1t(NS) + 2 * P_A1_PART; }   // 1 KiB (a whole staging piece): [br] 2^-kw of the fp16 W1^T
 // (the two-part precisions only: with three forward parts pass 2 already uses all 160 KiB of LDS, and bf16x6 does not read it)
@@ -86,6 +87,16 @@ constexpr int ST_LAYER = ST_MOM + 8;
 // ---- backward FiLM block per (layer, cloud) (floats): [br][k][64], k = 0 a, 1 c, 2 rstd1, 3 c/a ---
 constexpr int FB_BR = 4 * 64;
 constexpr int FB_CLOUD = 2 * FB_BR;
+
+// floats of a workgroup's pass-2 partial row per branch (written by tbwd2_kernel).  r05: the sum of dh0a * h0n is no longer a
+// column -- h0n = rstd0 (w_a (x_a - E x_a) + w_b (x_b - E x_b)) is linear in x, so it follows from the two CENTRED input sums
+// (bwd3_coefs), which also frees them of the cancellation against E x
+constexpr int P2_S = 0;          // [64]   sum dh0a                       (d beta0)
+constexpr int P2_W = 64;         // [4096] dW1, row = out feature
+constexpr int P2_A = 4160;       // [64]   sum dh0a * (x_a - E x_a)
+constexpr int P2_B = 4224;       // [64]   sum dh0a * (x_b - E x_b)
+constexpr int P2_J = 4288;
+static_assert(P2_J % 32 == 0 && P2_W % 32 == 0 && P2_A % 32 == 0, "column workgroups own 32 columns");
 
 __device__ __forceinline__ f32x16 zero16() {
     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -185,9 +196,9 @@ __global__ __launch_bounds__(256) void tstats_x_kernel(int N, int ka, int kb, co
             (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-// BN0 batch statistics (analytic: h0 = W0 x is linear in x) and the two folded input-MFMA fragment
-// sets of the layer.  One workgroup, thread = (branch, feature).
-// 512 threads: the moments and the per-feature folds need 128 of them, the 2 x 2048 fragment slots they feed take all
+// BN0 batch statistics (analytic: h0 = W0 x is linear in x) and the folded input-MFMA fragments of the layer.
+// One workgroup, thread = (branch, feature).
+// 512 threads: the moment rows take all of them, the per-feature folds 128, the 2048 fragment slots 256
 // (with 128 threads the slot loop alone was 16 serial iterations of ~80 instructions: 9.3 us for the kernel)
 // (r02: a device function run by every workgroup of tstats_h1 -- the consumer -- straight into its LDS: 2 048 partial
 // values and 8 KiB of fragments are cheaper to redo 256 times than a dependent one-workgroup launch is to wait for;
@@ -248,11 +259,10 @@ __device__ __forceinline__ void bn0_fold(const Bn0Loads &L, double count, uint8_
                                          float *__restrict__ stats_l) {
     // r03: this prologue was HALF of tstats_h1 (11.8 K of 23.6 K ticks, tools/train_kprof.py): two dependent rounds of row
     // loads on 128 threads issued behind the weight DMA, a 16-iteration slot loop of ~80 instructions.  Now the loads are in
-    // flight before the DMA on all 512 threads (bn0_loads), and a thread builds the eight K slots of one (set, branch, tile,
+    // flight before the DMA on all 512 threads (bn0_loads), and a thread builds the eight K slots of one (branch, tile,
     // lane) -- one 16-byte store.
     __shared__ double mom[5], wsum[TW][5];
     __shared__ float fold[2][64][4];
-    __shared__ float foldn[2][64][4];
     {   // fixed-order sum of the per-workgroup partials: thread -> rows tid, tid + 512, ...; wave butterflies; waves in order
         double v[5];
 #pragma unroll
@@ -293,17 +303,14 @@ __device__ __forceinline__ void bn0_fold(const Bn0Loads &L, double count, uint8_
     }
     const float s0 = gamma * rstd;
     fold[br][f][0] = s0 * (float)wa; fold[br][f][1] = s0 * (float)wb; fold[br][f][2] = beta - (float)mean * s0;
-    foldn[br][f][0] = rstd * (float)wa; foldn[br][f][1] = rstd * (float)wb; foldn[br][f][2] = -(float)mean * rstd;
     }
     KP(0, 7)
     lds_barrier();
-    static_assert(TW * 64 == 512, "one thread per (set, branch, tile, lane)");
-    {
-        const int set = threadIdx.x >> 8, rem = threadIdx.x & 255, b2 = rem >> 7, t = (rem >> 6) & 1, lane = rem & 63;
+    if (threadIdx.x < 256) {               // one thread per (branch, tile, lane)
+        const int b2 = threadIdx.x >> 7, t = (threadIdx.x >> 6) & 1, lane = threadIdx.x & 63;
         const int ff = 32 * t + (lane & 31), h = lane >> 5;
-        const float (*fo)[64][4] = set ? foldn : fold;
-        const u32x4 v = input_weight_slots8(fo[b2][ff][h], fo[b2][ff][2], h);
-        const int off = set * 4096 + ((b2 * 2 + t) * 64 + lane) * 16;
+        const u32x4 v = input_weight_slots8(fold[b2][ff][h], fold[b2][ff][2], h);
+        const int off = ((b2 * 2 + t) * 64 + lane) * 16;
         *(u32x4 *)(lds_a0 + off) = v;
         if (packed_a0 != nullptr) *(u32x4 *)(packed_a0 + off) = v;
     }
@@ -311,7 +318,7 @@ __device__ __forceinline__ void bn0_fold(const Bn0Loads &L, double count, uint8_
 
 // column sums of a (nrows, J) fp32 matrix of per-workgroup partials, in a fixed order, as doubles.
 // workgroup = 32 columns x 32 row groups
-// dcanon_l (optional): the dW1 totals (columns 128 .. 4223 of each branch's P2_J) go straight to the layer's gradient block
+// dcanon_l (optional): the dW1 totals (columns P2_W .. P2_W + 4095 of each branch's P2_J) go straight to the layer's gradient block
 // as floats (r03: formerly a grid-stride loop in the prologue of every workgroup of the next pass 1)
 __global__ __launch_bounds__(1024) void tcolsum_kernel(int nrows, int J, const float *__restrict__ part, double *__restrict__ out,
                                                        float *__restrict__ dcanon_l, int p2j) {
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(1024) void tcolsum_kernel(int nrows, int J, const f
         out[j] = t;
         if (dcanon_l != nullptr) {
             const int b2 = j / p2j, jj = j - b2 * p2j;
-            if (jj >= 128 && jj < 128 + 4096) dcanon_l[b2 * T_BR + T_W1 + jj - 128] = (float)t;
+            if (jj >= P2_W && jj < P2_W + 4096) dcanon_l[b2 * T_BR + T_W1 + jj - P2_W] = (float)t;
         }
     }
 }
@@ -422,7 +429,7 @@ __device__ __forceinline__ void split_pair_sym_f16(float v0, float v1, float neg
     hi = __builtin_bit_cast(uint32_t, h);
     lo = __builtin_bit_cast(uint32_t, l);
 }
-template <bool RELU>
+template <bool RELU, bool SCALE = true>
 __device__ __forceinline__ void kfrags_from_swapped_f16(const f32x16 (&v)[2], float scale, float negone, u32x4 (&hi)[2][2], u32x4 (&lo)[2][2]) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -430,8 +437,9 @@ __device__ __forceinline__ void kfrags_from_swapped_f16(const f32x16 (&v)[2], fl
         for (int j2 = 0; j2 < 2; ++j2)
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                const float v0 = (RELU ? relu(v[t][8 * j2 + 2 * d]) : v[t][8 * j2 + 2 * d]) * scale;
-                const float v1 = (RELU ? relu(v[t][8 * j2 + 2 * d + 1]) : v[t][8 * j2 + 2 * d + 1]) * scale;
+                float v0 = RELU ? relu(v[t][8 * j2 + 2 * d]) : v[t][8 * j2 + 2 * d];
+                float v1 = RELU ? relu(v[t][8 * j2 + 2 * d + 1]) : v[t][8 * j2 + 2 * d + 1];
+                if constexpr (SCALE) { v0 *= scale; v1 *= scale; }
                 uint32_t hp, lp;
                 split_pair_sym_f16(v0, v1, negone, hp, lp);
                 hi[t][j2][d] = hp;
@@ -775,13 +783,12 @@ __device__ __forceinline__ float dh2a_of(float pre, float w2a, float w2b, float 
     return pre > 0.f ? w2a * doa + w2b * dob : 0.f;
 }
 
-constexpr int P2_J = 4352;       // floats of a workgroup's pass-2 partial row per branch (layout: tbwd2_kernel)
 // Totals of pass 2 of a layer -> the coefficients of the conditioner path of its input gradient,
 //   dx_k[pt] = u_k[pt] - coef[4k] - coef[4k+1] x_a - coef[4k+2] x_b   (see tbwd3f_kernel),
 // left in LDS (`coef`, 8 floats; `acc` is 8 KiB of scratch); EVERY workgroup of the caller runs this (128 threads of double
 // arithmetic, same operations in the same order, so the same bits), workgroup 0 also writes d gamma0 / d beta0 / dW0 and
 // the dW1 totals are converted by whoever comes first (grid-stride).  Ends with a workgroup barrier.
-struct CoefLoads { double Sg, S, Sa, Sb; float ea, eb, caa, cbb, cab, wa, wb, gamma, rstd0, mean0; };
+struct CoefLoads { double S, Sa, Sb; float caa, cbb, cab, wa, wb, gamma, rstd0, mean0; };
 // the loads of bwd3_coefs (threads < 128), to be issued BEFORE the caller's weight loads
 template <bool AGENT = false>
 __device__ __forceinline__ CoefLoads bwd3_loads(int nk, const double *__restrict__ tot, const float *__restrict__ tcanon_l,
@@ -791,15 +798,14 @@ __device__ __forceinline__ CoefLoads bwd3_loads(int nk, const double *__restrict
     const double *t = tot + (size_t)br * P2_J;
     const float *cb = tcanon_l + br * T_BR;
     if (AGENT) {       // written by other workgroups of THIS launch (colsum_role): past this CU's L1 and the XCD's L2
-        L.Sg = __hip_atomic_load(&t[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        L.S = __hip_atomic_load(&t[64 + f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        L.Sa = __hip_atomic_load(&t[4224 + f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        L.Sb = __hip_atomic_load(&t[4288 + f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        L.S = __hip_atomic_load(&t[P2_S + f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        L.Sa = __hip_atomic_load(&t[P2_A + f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        L.Sb = __hip_atomic_load(&t[P2_B + f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-        L.Sg = t[f]; L.S = t[64 + f]; L.Sa = t[4224 + f]; L.Sb = t[4288 + f];
+        L.S = t[P2_S + f]; L.Sa = t[P2_A + f]; L.Sb = t[P2_B + f];
     }
     const float *m = stats_l + ST_MOM;
-    L.ea = m[0]; L.eb = m[1]; L.caa = m[2]; L.cbb = m[3]; L.cab = m[4];
+    L.caa = m[2]; L.cbb = m[3]; L.cab = m[4];
     L.wa = cb[T_W0 + f * nk]; L.wb = nk == 2 ? cb[T_W0 + f * 2 + 1] : 0.f; L.gamma = cb[T_G0 + f];
     L.rstd0 = stats_l[br * ST_BR + 64 + f]; L.mean0 = stats_l[br * ST_BR + f];
     return L;
@@ -812,18 +818,19 @@ __device__ __forceinline__ void bwd3_coefs(const CoefLoads &L, int blk, int nk, 
     // dW1 itself.  acc: [2][8] doubles of scratch.
     if (threadIdx.x < 128) {
         const int br = threadIdx.x >> 6, f = threadIdx.x & 63;
-        const double Sg = L.Sg, S = L.S, Sa = L.Sa, Sb = L.Sb;
-        const double ea = L.ea, eb = L.eb, caa = L.caa, cbb = L.cbb, cab = L.cab;
+        const double S = L.S, Sa = L.Sa, Sb = L.Sb;                                                // Sa, Sb: against the CENTRED inputs
+        const double caa = L.caa, cbb = L.cbb, cab = L.cab;
         const double wa = L.wa, wb = L.wb, gamma = L.gamma;
         const double rstd0 = L.rstd0, mean0 = L.mean0;
+        const double Sg = rstd0 * (wa * Sa + wb * Sb);                                             // sum dh0a * h0n
         const double A = S / count, Bc = Sg / count;
         const double hxa = rstd0 * (wa * caa + wb * cab), hxb = rstd0 * (wa * cab + wb * cbb);     // E[h0n x_k]
         const double sc = rstd0 * gamma;
         if (blk == 0) {
             dcanon_l[br * T_BR + T_G0 + f] = (float)Sg;
             dcanon_l[br * T_BR + T_B0 + f] = (float)S;
-            dcanon_l[br * T_BR + T_W0 + f * nk] = (float)(sc * (Sa - A * ea * count - Bc * hxa * count));
-            if (nk == 2) dcanon_l[br * T_BR + T_W0 + f * 2 + 1] = (float)(sc * (Sb - A * eb * count - Bc * hxb * count));
+            dcanon_l[br * T_BR + T_W0 + f * nk] = (float)(sc * (Sa - Bc * hxa * count));          // (Sa + E x_a S) - A E x_a P = Sa
+            if (nk == 2) dcanon_l[br * T_BR + T_W0 + f * 2 + 1] = (float)(sc * (Sb - Bc * hxb * count));
             else dcanon_l[br * T_BR + T_W0 + 64 + f] = 0.f;
         }
         const double ck[2] = {wa * sc, wb * sc};
@@ -874,11 +881,11 @@ struct PrevLayer {
 
 // r04: the column sums of the layer ABOVE's pass-2 partials (the former tcolsum launch between two backward layers) ride in
 // this launch as extra workgroups -- blockIdx.y < cs.rows, dispatched first -- so that the launch boundary
-// tbwd2 -> tcolsum -> tbwd1 becomes tbwd2 -> tbwd1.  The 16 of them that own the 512 totals pass 1 needs (sum dh0a h0n,
-// sum dh0a, sum dh0a x_a, sum dh0a x_b per branch and feature) come first, publish their totals with agent-scope stores and
+// tbwd2 -> tcolsum -> tbwd1 becomes tbwd2 -> tbwd1.  The 12 of them that own the 384 totals pass 1 needs (sum dh0a and the
+// two centred input sums per branch and feature: P2_S, P2_A, P2_B) come first, publish their totals with agent-scope stores and
 // raise a counter; the ordinary workgroups recompute the layer's pre-activations first (that needs nothing from above),
-// then wait for the counter (one lane polls), read the totals past their L1 / L2 (agent scope) and go on.  The other 256
-// column workgroups (the dW1 totals) are waited for by nobody.  If the counter does not arrive (HIP promises no dispatch
+// then wait for the counter (one lane polls; see colsum_wait for the ordering), read the totals past
+// their L1 / L2 (agent scope) and go on.  The other 256 column workgroups (the dW1 totals) are waited for by nobody.  If the counter does not arrive (HIP promises no dispatch
 // order; observed: ascending), a workgroup gives up polling and sums the 512 columns itself, in the same order.
 struct ColsumJob {
     const float *part2;          // (nrows, 2 * P2_J) pass-2 partial rows of the layer above
@@ -888,14 +895,14 @@ struct ColsumJob {
     unsigned target;             // value of *flag once this launch's 16 have arrived
     int nrows, rows;             // partial rows; rows of the grid taken by the column workgroups (0 = none in this launch)
 };
-constexpr int CS_CRIT = 16;      // column workgroups (32 columns each) that own the totals pass 1 waits for
+constexpr int CS_CRIT = 12;      // column workgroups (32 columns each) that own the totals pass 1 waits for: P2_S, P2_A, P2_B of both branches
 // column block of column workgroup `id`: the critical ones first
 __device__ __forceinline__ int cs_block_of(int id) {
-    constexpr int PB = P2_J / 32;                      // 136 blocks per branch
-    if (id < CS_CRIT) { const int b = id >> 3, k = id & 7; return b * PB + (k < 4 ? k : PB - 8 + k); }
+    constexpr int PB = P2_J / 32;                      // 134 blocks per branch: 2 (P2_S) + 128 (dW1) + 4 (P2_A, P2_B)
+    if (id < CS_CRIT) { const int b = id / 6, k = id - 6 * b; return b * PB + (k < 2 ? k : PB - 6 + k); }
     int r = id - CS_CRIT;                              // the others in ascending order, skipping those
-    const int b = r >= PB - 8, q = r - b * (PB - 8);
-    return b * PB + 4 + q;
+    const int b = r >= PB - 6, q = r - b * (PB - 6);
+    return b * PB + 2 + q;
 }
 // one column of the partials, summed exactly as tcolsum_kernel does: 32 row groups (row r in group r & 31, ascending), then
 // the groups in order
@@ -925,38 +932,52 @@ __device__ __forceinline__ void colsum_role(const ColsumJob &cs, int id, uint8_t
         for (int r = 0; r < 32; ++r) t += acc[r][c];
         __hip_atomic_store(&cs.tot[j], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int b2 = j / P2_J, jj = j - b2 * P2_J;
-        if (jj >= 128 && jj < 128 + 4096) cs.dcanon_prev[b2 * T_BR + T_W1 + jj - 128] = (float)t;
+        if (jj >= P2_W && jj < P2_W + 4096) cs.dcanon_prev[b2 * T_BR + T_W1 + jj - P2_W] = (float)t;
     }
     if (id < CS_CRIT) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the totals have left this CU before the counter moves
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(cs.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(cs.flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 // ordinary workgroups: wait until the critical totals are there (or produce them)
+// (the poll is bounded: 256 round trips to the memory side, ~0.2 ms -- a column workgroup takes ~3 us; the fallbacks taken are
+// counted process-wide, dpf_train_colsum_fallbacks(): tests/test_gpu_flow_train.py checks the `dispatched first` assumption)
+__device__ unsigned g_colsum_fallbacks = 0;
 __device__ __forceinline__ void colsum_wait(const ColsumJob &cs, int *lds_word) {
     if (threadIdx.x == 0) {
         int ok = 0;
-        for (int it = 0; it < (1 << 16); ++it) {
+        // Relaxed polls and NO acquire fence behind them.  r05 measured both (same box, tools/train_ab_prof.sh): an acquire on the
+        // poll invalidates this CU's caches on every round trip, and ONE agent-scope acquire fence after the successful poll
+        // (buffer_inv sc1 + vmcnt(0)) still costs 1.6 us per layer (tbwd1 15.4 -> 17.0 us) -- it throws away the L2 lines of the
+        // weights the workgroup is about to read.  What orders the hand-off instead: the producer's totals are write-through
+        // stores that have left its CU (vmcnt(0)) before its RELEASE increment; the consumer issues its loads of the totals only
+        // after it has SEEN the counter (program order on one in-order memory pipe) and those loads are agent-scope atomics
+        // themselves -- they are served past the L1 and the XCD's L2, where the stores are.
+        for (int it = 0; it < 256; ++it) {
             if (__hip_atomic_load(cs.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= cs.target) { ok = 1; break; }
             __builtin_amdgcn_s_sleep(2);
         }
+        if (!ok) __hip_atomic_fetch_add(&g_colsum_fallbacks, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *lds_word = ok;
     }
     __syncthreads();
     if (*lds_word) return;
     // the column workgroups have not run (they were not dispatched first and there is no room beside us): their work for the
-    // 512 columns pass 1 needs, by this workgroup -- one thread per column, the same 32 ordered group sums
+    // 384 columns pass 1 needs, by this workgroup -- one thread per column, the same 32 ordered group sums
     {
-        const int J = 2 * P2_J, i = threadIdx.x, b = i >> 8, q = i & 255;
-        const int j = b * P2_J + (q < 128 ? q : 4224 - 128 + q);
-        double t = 0;
-        for (int k = 0; k < 32; ++k) {         // (a rolled loop with one accumulator: this path must not cost the kernel registers)
-            double gk = 0;
-            for (int r = k; r < cs.nrows; r += 32) gk += cs.part2[(size_t)r * J + j];
-            t += gk;
+        const int J = 2 * P2_J, i = threadIdx.x;
+        if (i < 384) {
+            const int b = i / 192, q = i - 192 * b;
+            const int j = b * P2_J + (q < 64 ? P2_S + q : P2_A - 64 + q);
+            double t = 0;
+            for (int k = 0; k < 32; ++k) {         // (a rolled loop with one accumulator: this path must not cost the kernel registers)
+                double gk = 0;
+                for (int r = k; r < cs.nrows; r += 32) gk += cs.part2[(size_t)r * J + j];
+                t += gk;
+            }
+            __hip_atomic_store(&cs.tot[j], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the same bits the column workgroup writes
         }
-        __hip_atomic_store(&cs.tot[j], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the same bits the column workgroup writes
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -1042,8 +1063,8 @@ __global__ __launch_bounds__(TW * 64, BSPLIT ? 2 : 4) void tbwd1_kernel(TArgs a,
     const StageRegs<2048> fbregs = stage_load<2048>((const uint8_t *)(a.filmb_l + (size_t)bi * FB_CLOUD), wave, lane);
     // pin the consumers of the pass-3 totals BEHIND the issue of everything else (the compiler had started on them right
     // behind their loads: a cold round trip before the point and weight loads were even requested)
-    asm volatile("" : "+v"(cl.Sg), "+v"(cl.S), "+v"(cl.Sa), "+v"(cl.Sb));
-    asm volatile("" : "+v"(cl.ea), "+v"(cl.eb), "+v"(cl.caa), "+v"(cl.cbb), "+v"(cl.cab));
+    asm volatile("" : "+v"(cl.S), "+v"(cl.Sa), "+v"(cl.Sb));
+    asm volatile("" : "+v"(cl.caa), "+v"(cl.cbb), "+v"(cl.cab));
     asm volatile("" : "+v"(cl.wa), "+v"(cl.wb), "+v"(cl.gamma), "+v"(cl.rstd0), "+v"(cl.mean0));
     float *w2s = red + TW * 520;                                                // [2 br][2][64] raw sd2.weight
     if (threadIdx.x < 256) w2s[threadIdx.x] = w2_v;
@@ -1238,22 +1259,90 @@ __global__ __launch_bounds__(TW * 64, BSPLIT ? 2 : 4) void tbwd1_kernel(TArgs a,
 
 // (the BN1-backward means and dW2 / db2 -- formerly a one-workgroup tfinish1 kernel -- are computed in tbwd2's prologue)
 
-// Pass 2: BN1 backward, dh0 = W1^T dh1 (matrix cores), dW1 = dh1 h0^T (matrix cores, contraction over the
-// tile's 32 points through an LDS transpose), relu backward.
-//   part2[blk][br][P2_J]: [0..63] sum dh0a*h0n (d gamma0), [64..127] sum dh0a (d beta0), [128..4223] dW1
-//                         (row = out feature), [4224..4287] sum dh0a*x_a, [4288..4351] sum dh0a*x_b
-//   ubuf (B,2,N): u_k = sum over both branches and all features of W0[f][k]*rstd0*gamma0 * dh0a[f]
+// Pass 2: BN1 backward, dh0 = W1^T dh1 (matrix cores), dW1 = dh1 h0^T (matrix cores, contraction over the tile's 32 points: both
+// operands are K = points fragments straight from swapped-orientation accumulators), relu backward.
+//   part2[blk][br][P2_J]: P2_S sum dh0a (d beta0), P2_W dW1 (row = out feature), P2_A / P2_B sum dh0a * (x_k - E x_k)
+//   ubuf (2, B, 2, N): plane br = u_k of branch br's features, u_k = sum_f W0[f][k]*rstd0*gamma0 * dh0a[f]; the consumer adds the planes
+//
+// r05 -- a wave owns ONE conditioner branch.  Until r04 a wave ran both branches of one 32-point tile one after the other and
+// every branch ended in a workgroup-wide reduction of its 64 x 64 dW1 tile: 12 barriers per kernel.  The stamps
+// (tools/train_phase_prof.py, profiles/r04) showed what they cost: of the two waves of a SIMD the older one wins the issue
+// arbitration and gets through a branch in 11.6 K ticks, its partner in 14.3 K, and the older then WAITS 6 K ticks at the
+// reduction's barriers -- twice per kernel -- only to start the next branch phase-aligned with its partner again (matrix
+// phases beside matrix phases, which serialise on the SIMD's one matrix pipe).  PAIR: waves 0-3 run the logvar branch of
+// tiles w and w + 4 of the workgroup's eight, waves 4-7 the mu branch of the same tiles.  dW1 of a branch accumulates over the
+// wave's two tiles in the MFMA accumulators themselves, there is no barrier between the prologue and the one reduction at
+// the end (four waves per branch instead of eight: half the LDS traffic, 5 barriers instead of 12), and the skew the
+// arbitration creates is kept: a wave's VALU stretches run beside its partner's MFMA chains for the whole kernel.
+// !PAIR (small batches: at most half a workgroup per CU, i.e. B * N / 256 <= 128): one branch per WORKGROUP (blockIdx.z), a
+// tile per wave, as r04's SPLIT.
+// The instruction diet that came with it (the kernel is bound by vector issue): the BN1-backward formula's point-dependent
+// part K1[f] do_a[pt] + K2[f] do_b[pt] + C0[f] is ONE input-style MFMA per feature tile (3-way bf16 splits in the 16 K slots:
+// fp32-accurate, as the layer's input contraction) instead of 3 VALU per element; sum dh0a * h0n is derived from the two
+// centred input sums (bwd3_coefs) -- one input MFMA pair and an FMA per element gone; relu(h0) arrives scaled by 16 from an
+// input fragment scaled by 16 (exact) -- no multiply per element in front of its fp16 split; dW1 is unscaled by the reducer
+// (an FMA where it had an add) instead of 64 multiplies per wave and tile.
 #ifdef DPF_PROFILE
 __device__ unsigned long long *g_tprof = nullptr;
-#define TP(i) { __builtin_amdgcn_sched_barrier(0); if (br == 0) tt[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#define TP(i) { __builtin_amdgcn_sched_barrier(0); if (ti == 0) tt[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
 #else
-#define TP(i)
+// (the phase boundaries fence the instruction scheduler in every build: left free it starts a phase's loads and conversions
+// inside the previous one, and the kernel -- at the 256 registers two waves per SIMD may have -- spills)
+#define TP(i) __builtin_amdgcn_sched_barrier(0);
 #endif
-// SPLIT (small batches: at most half a workgroup per CU, i.e. B * N / 256 <= 128): the two conditioner branches of a tile run
-// in TWO workgroups (blockIdx.z = branch) -- the kernel's time is one wave's latency through both branches, and the chip is
-// half empty.  Each writes its own rows of part2 (they are per branch anyway) and its own plane of ubuf (u_k of its branch's
-// features; the consumer adds the two planes).
-template <int NS, bool F16 = false, bool SPLIT = false>
+// x of lane (i ^ 32) + x of lane i, on the VALU (v_permlane32_swap; __shfl_xor is an LDS round trip)
+__device__ __forceinline__ float half_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(f2u(x), f2u(x), false, false);
+    return u2f(r[0]) + u2f(r[1]);
+}
+// the same for the two 16-lane rows of each wave half
+__device__ __forceinline__ float row_pair_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(f2u(x), f2u(x), false, false);
+    return u2f(r[0]) + u2f(r[1]);
+}
+// x as seen through a DPP lane pattern (the compiler folds the move into the consuming VALU instruction)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) { return u2f(__builtin_amdgcn_update_dpp(0u, f2u(x), CTRL, 0xF, 0xF, true)); }
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_ROW_MIRROR = 0x140, DPP_ROW_HALF_MIRROR = 0x141;
+// Sums over the 32 lanes of a wave half for 16 registers at once (swapped orientation: lanes = features, registers = the
+// half's 16 points): recursive halving -- a lane keeps one half of its registers, its partner the other, each adds what the
+// other sends; 15 exchanges instead of 16 x 5, every one a DPP operand of the add (no LDS, no v_mov).  The partners: 15 - i
+// within a row (row_mirror: flips lane bit 3), 7 - i within a half row (flips bit 2, keeps bit 3: the two hold the same
+// registers), i ^ 2, i ^ 1, then the other row of the half.  On return w[0] of lane i is the total of register i & 15.
+template <int CTRL, int NH>
+__device__ __forceinline__ void halve_stage(float (&w)[16], bool up) {
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        const float keep = up ? w[i + NH] : w[i], send = up ? w[i] : w[i + NH];
+        w[i] = keep + dpp_f<CTRL>(send);
+    }
+}
+__device__ __forceinline__ float reduce_lanes16(float (&w)[16], int lane) {
+    halve_stage<DPP_ROW_MIRROR, 8>(w, (lane >> 3) & 1);
+    halve_stage<DPP_ROW_HALF_MIRROR, 4>(w, (lane >> 2) & 1);
+    halve_stage<DPP_XOR2, 2>(w, (lane >> 1) & 1);
+    halve_stage<DPP_XOR1, 1>(w, lane & 1);
+    return row_pair_sum(w[0]);
+}
+// the largest of a non-negative x over the wave, as its bit pattern in a scalar register: four DPP maxima within the rows
+// (each row ends up uniform), then the four rows on the scalar unit (non-negative floats order like their bit patterns)
+__device__ __forceinline__ uint32_t wave_max_bits(float x) {
+    x = fmaxf(x, dpp_f<DPP_XOR1>(x));
+    x = fmaxf(x, dpp_f<DPP_XOR2>(x));
+    x = fmaxf(x, dpp_f<DPP_ROW_HALF_MIRROR>(x));
+    x = fmaxf(x, dpp_f<DPP_ROW_MIRROR>(x));
+    const uint32_t a = __builtin_amdgcn_readlane(f2u(x), 0), b = __builtin_amdgcn_readlane(f2u(x), 16);
+    const uint32_t c = __builtin_amdgcn_readlane(f2u(x), 32), d = __builtin_amdgcn_readlane(f2u(x), 48);
+    const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+// B operand of an input-style MFMA whose point values are scaled by 16 (exact: every split part and the bias slots scale)
+__device__ __forceinline__ u32x4 input_fragment_x16(float x, int h) {
+    u32x4 b0 = input_fragment(x * 16.0f, h);
+    b0.w = h ? 0x00004180u : 0x41804180u;   // e6 = 16, e7 = 16 (h == 0)
+    return b0;
+}
+template <int NS, bool F16 = false, bool PAIR = true>
 __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__restrict__ pcs, double count, float *__restrict__ dcanon_l,
                                                         const float *__restrict__ dout,
                                                         float *__restrict__ ubuf, float *__restrict__ part2) {
@@ -1262,15 +1351,21 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
 #endif
     KP(2, 0)
+    constexpr int NT = PAIR ? 2 : 1;          // tiles per wave
+    constexpr int NWB = PAIR ? 4 : 8;         // waves per branch
+    constexpr int NB = PAIR ? 2 : 1;          // branches this workgroup works on
     constexpr int L_FILM = l_film(NS), L_FILMB = l_filmb(NS), L_RED = l_red(NS);
-    float *cf = (float *)(smem + L_RED) + 256;                             // c_fk [2 br][2][64]   (first 1 KB of the region: spare)
+    constexpr int L_GFR = L_PACK + pt_a0n(NS);                             // dh1 input-style fragments [br][t][lane] (4 KiB, built below)
+    float *uns = (float *)(smem + L_RED);                                  // per wave: what its dW1 accumulators are multiplied by at the end
+    float *cf = (float *)(smem + L_RED) + 256;                             // c_fk [2 br][2][64]
     float *redw = (float *)(smem + L_RED + 4096);                          // per-wave slots (8 KB) of the workgroup reduction; their head is the wave's per-point scratch before that
     const int bi = blockIdx.y, lane = threadIdx.x & 63, h = lane >> 5, pl = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int br = PAIR ? wave >> 2 : (int)blockIdx.z;                     // this wave's branch (wave-uniform)
     int h4 = 4 * h;                   // opaque to the optimiser: feature offsets stay "lane base + immediate"
     asm volatile("" : "+v"(h4));      // (as known bits they become OR-ed constants, one live register each)
     KP(3, 0)
-    // r03: the loads of the prologue's tiny reductions are issued BEFORE the 76-92 KB of weight loads -- vector-memory results
+    // r03: the loads of the prologue's tiny reductions are issued BEFORE the 70-90 KB of weight loads -- vector-memory results
     // return in order, so issued behind it they waited for all of it (tools/train_kprof.py: 5.8 K ticks for 24 loads)
     const int mq = threadIdx.x & 127, mbr = mq >> 6, mf = mq & 63, mg4 = threadIdx.x >> 7;     // means: (branch, feature) x clouds mg4, mg4 + 4, ...
     float m_av[8], m_q3[8], m_q2[8];
@@ -1306,29 +1401,38 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
     float cf_w, cf_r, cf_g, w2_v;
     {
         const int i = threadIdx.x & 255;
-        const int br = i >> 7, k = (i >> 6) & 1, f = i & 63;                 // c_fk = W0[f][k] * rstd0_f * gamma0_f
-        const float *cb = a.tcanon_l + br * T_BR;
+        const int b2 = i >> 7, k = (i >> 6) & 1, f = i & 63;                 // c_fk = W0[f][k] * rstd0_f * gamma0_f
+        const float *cb = a.tcanon_l + b2 * T_BR;
         const int nk = a.kb >= 0 ? 2 : 1;
-        cf_w = cb[T_W0 + f * nk + (k < nk ? k : 0)]; cf_r = a.stats_l[br * ST_BR + 64 + f]; cf_g = cb[T_G0 + f];
+        cf_w = cb[T_W0 + f * nk + (k < nk ? k : 0)]; cf_r = a.stats_l[b2 * ST_BR + 64 + f]; cf_g = cb[T_G0 + f];
         if (k >= nk) cf_g = 0.f;
         w2_v = a.tcanon_l[(i >> 7) * T_BR + T_W2 + (i & 127)];
     }
-    const int N = a.N, n = (blockIdx.x * TW + wave) * TILE + pl;
-    const bool valid = n < N;
-    const int nc = valid ? n : N - 1;
-    const float *pc = a.p_in + (size_t)bi * 3 * N;
-    const float xa = pc[(size_t)a.ka * N + nc], xb = a.kb >= 0 ? pc[(size_t)a.kb * N + nc] : 0.f;
-    const float *dq = dout + (size_t)bi * 4 * N + nc;
-    const float dov[2][2] = {{dq[0], dq[N]}, {dq[2 * (size_t)N], dq[3 * (size_t)N]}};
+    // this wave's points: the kept coordinates and d(o) of ITS branch, for each of its tiles
+    const int N = a.N;
+    float xa_t[NT], xb_t[NT], doa_t[NT], dob_t[NT];
+    {
+        const float *pc = a.p_in + (size_t)bi * 3 * N;
+        const float *dq = dout + ((size_t)bi * 4 + 2 * br) * N;
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+            const int tile = PAIR ? (wave & 3) + 4 * ti : wave;
+            const int n = (blockIdx.x * TW + tile) * TILE + pl, nc = n < N ? n : N - 1;
+            xa_t[ti] = pc[(size_t)a.ka * N + nc]; xb_t[ti] = a.kb >= 0 ? pc[(size_t)a.kb * N + nc] : 0.f;
+            doa_t[ti] = dq[nc]; dob_t[ti] = dq[(size_t)N + nc];
+        }
+    }
+    const float ea = a.stats_l[ST_MOM + 0], eb = a.stats_l[ST_MOM + 1];   // batch means of the kept coordinates (scalar loads)
     asm volatile("" ::: "memory");
-    const StageRegs<pt_bytes(NS)> wregs = stage_load<pt_bytes(NS)>(a.packed_l, wave, lane);
+    // the packed block without the 4 KiB nobody fills (pt_a0n): [0, pt_a0n) = W1 fragments + input fragments, [pt_a1t, end) = W1^T
+    const StageRegs<pt_a0n(NS)> wregs = stage_load<pt_a0n(NS)>(a.packed_l, wave, lane);
+    const StageRegs<pt_bytes(NS) - pt_a1t(NS)> wregs_t = stage_load<pt_bytes(NS) - pt_a1t(NS)>(a.packed_l + pt_a1t(NS), wave, lane);
     const StageRegs<2048> fregs = stage_load<2048>((const uint8_t *)(a.film_l + (size_t)bi * 512), wave, lane);
     const StageRegs<2048> fbregs = stage_load<2048>((const uint8_t *)(a.filmb_l + (size_t)bi * FB_CLOUD), wave, lane);
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj)        // pin the consumers of the small loads BEHIND the issue of the weight loads (else the sums are scheduled
         asm volatile("" : "+v"(m_av[jj]), "+v"(m_q3[jj]), "+v"(m_q2[jj]), "+v"(f_wa[jj]), "+v"(f_wb[jj]), "+v"(f_bb[jj]));   // right behind each load: 8 serial round trips)
     KP(3, 1)
-    const u32x4 b0 = input_fragment(h ? xb : xa, h);
     const float *film = (const float *)(smem + L_FILM);
     const float *filmb = (const float *)(smem + L_FILMB);
     const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
@@ -1339,7 +1443,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
     KP(3, 2)
     {   // BN1-backward means s12[br][2][64] = (sum dh1n, sum dh1n*h1n) / P over the per-cloud totals of pass 1 -- what
         // the one-workgroup tfinish1 kernel did, recomputed by every workgroup (same sums in the same order, under the
-        // weight DMA; a dependent tiny launch costs ~4.5 us); workgroup 0 also writes dW2 / db2.  Scratch: redw.
+        // weight loads; a dependent tiny launch costs ~4.5 us); workgroup 0 also writes dW2 / db2.  Scratch: redw.
         double (*acc)[5][128] = (double (*)[5][128])redw;
         const int q = mq, br_ = mbr, f_ = mf, g4 = mg4;
         const bool first = first_wg;
@@ -1401,9 +1505,21 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
         }
     }
     stage_store(wregs, smem + L_PACK, wave, lane);                        // the weights, landed while the means were formed
+    stage_store(wregs_t, smem + L_PACK + pt_a1t(NS), wave, lane);
     stage_store(fregs, smem + L_FILM, wave, lane);
     stage_store(fbregs, smem + L_FILMB, wave, lane);
-    float ua = 0.f, ub = 0.f;
+    __syncthreads();                                                       // weights, FiLM blocks, means, tables: all in LDS
+    // BN1 backward per element:  dh1 = rstd1 (a dh2a - m1 - h1n m2) = C1 pa + ([pa > 0] ? G : C0),  C1 = -rstd1^2 m2,
+    //   G[f][pt] = K1[f] do_a[pt] + K2[f] do_b[pt] + C0[f],  K_w = rstd1 a W2[w],  C0 = rstd1 (c/a m2 - m1)
+    // G is an input-style contraction (two point values, a bias): its per-feature side as MFMA fragments, built once here
+    if (threadIdx.x < 256) {
+        const int b2 = threadIdx.x >> 7, t = (threadIdx.x >> 6) & 1, ln = threadIdx.x & 63, ff = 32 * t + (ln & 31), hh = ln >> 5;
+        const float av = filmb[b2 * FB_BR + 0 * 64 + ff], rstd1 = filmb[b2 * FB_BR + 2 * 64 + ff], ca = filmb[b2 * FB_BR + 3 * 64 + ff];
+        const float m1 = s12s[b2 * 128 + ff], m2 = s12s[b2 * 128 + 64 + ff];
+        const float kw = rstd1 * av * w2s[b2 * 128 + 64 * hh + ff];
+        *(u32x4 *)(smem + L_GFR + ((b2 * 2 + t) * 64 + ln) * 16) = input_weight_slots8(kw, rstd1 * (ca * m2 - m1), hh);
+    }
+    lds_barrier();
     KP(2, 1)
 #ifdef DPF_PROFILE
     unsigned long long tt[12];
@@ -1420,22 +1536,37 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
             eye[j2][d] = F16 ? ((pl == p0 ? 0x3C00u : 0u) | (pl == p1 ? 0x3C000000u : 0u))     // 1.0 as fp16 / as bf16
                              : ((pl == p0 ? 0x3F80u : 0u) | (pl == p1 ? 0x3F800000u : 0u));
         }
-    float *pts = redw + wave * 2048;                                     // per-wave scratch (free until the reduction): [4][32] per-point values
+    float *pts = redw + wave * 2048;                                     // per-wave scratch (free until the reduction): [2][32] centred inputs
     const bool two_kept = a.kb >= 0;
-    const int tile0 = (blockIdx.x * TW + wave) * TILE;
-    const int br_lo = SPLIT ? (int)blockIdx.z : 0, br_hi = SPLIT ? (int)blockIdx.z + 1 : 2;
-    if (SPLIT) ubuf += (size_t)blockIdx.z * a.B * 2 * N;                   // this branch's plane of u_k
-    for (int br = br_lo; br < br_hi; ++br) {
+    float *uplane = ubuf + (size_t)br * a.B * 2 * N;                       // this branch's plane of u_k
+    // (the per-lane constants of the wave's branch are re-read from LDS where a tile needs them: held across the loop they
+    // are eight registers of a kernel that sits at the 256 two waves per SIMD may have)
+    const float winv = F16 ? u2f(__builtin_amdgcn_readfirstlane(f2u(*(const float *)(smem + L_PACK + pt_tail(NS) + 4 * br)))) : 1.0f;   // 2^-kw of the fp16 W1^T fragments
+    f32x16 dw[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};       // dW1 of this branch over this wave's tiles [fo tile][fi tile]
+    float rs[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};                  // [feature tile][k]: per-feature sums over this wave's tiles (both lane halves)
+    int e_dw = 0;                                                          // F16: dw carries 2^e_dw * 16
+#pragma unroll 1
+    for (int ti = 0; ti < NT; ++ti) {
         TP(0)
-        __syncthreads();                                                   // staging landed / previous branch flushed
+        if constexpr (PAIR) {
+            // the older wave of a SIMD wins the issue arbitration (r04 stamps: 10 K against 13 K ticks per tile): the first tile
+            // is the older four's, the second the younger four's -- both halves of the workgroup reach the reduction together
+            if (ti) { if (wave >> 2) __builtin_amdgcn_s_setprio(1); }
+        }
+        const int tile = PAIR ? (wave & 3) + 4 * ti : wave;
+        const int tile0 = (blockIdx.x * TW + tile) * TILE;
+        // (selects, not xa_t[ti]: a run-time index puts the array in scratch memory)
+        const float xa = ti ? xa_t[NT - 1] : xa_t[0], xb = ti ? xb_t[NT - 1] : xb_t[0];
+        const float doa = ti ? doa_t[NT - 1] : doa_t[0], dob = ti ? dob_t[NT - 1] : dob_t[0];
+        const u32x4 b0 = input_fragment(h ? xb : xa, h);
         TP(1)
-        // per-point values every lane needs in the swapped orientation (registers = points): d(o) of this branch, x_a, x_b
-        // (dov[br][..] with the loop's br as a run-time index put the four values in scratch memory: a scratch load at the top of every branch)
-        if (!h) { pts[pl] = br ? dov[1][0] : dov[0][0]; pts[32 + pl] = br ? dov[1][1] : dov[0][1]; pts[64 + pl] = xa; pts[96 + pl] = xb; }
+        // the centred inputs every lane needs in the swapped orientation (registers = points)
+        if (!h) { pts[pl] = xa - ea; pts[32 + pl] = xb - eb; }
         // ---- forward: h0 (lane = point) -> fragments; pre = h1 + D in the SWAPPED orientation (lane = feature 32 t + pl,
         // register r = point (r & 3) + 8 (r >> 2) + 4 h): per-feature constants become per-lane, sums over the points in-lane
-        f32x16 h0a[2], pre[2];
+        f32x16 pre[2];
         {
+            f32x16 h0a[2];
             u32x4 bf[NS][4];
             input_mfma(smem + L_PACK + pt_a0(NS), br, lane, b0, h0a);      // gamma*h0n + beta
             split_fragment<true, NS, false, F16>(h0a, bf, a.negone);
@@ -1448,30 +1579,20 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
             chain_mfma_swapped<NS, F16>(smem + L_PACK + PT_A1, br, lane, bf, pre);   // same products in the same order as the forward kernel
         }
         TP(2)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // ---- dh1 = rstd1 * (dh1n - mean(dh1n) - h1n * mean(dh1n*h1n)),  dh1n = a*dh2a,  h1n = pre*rstd1 - c/a   (in place)
-        u32x4 xh[2][2], xl[2][2];                                          // dh1 as K = points fragments [feature tile][k-step]
-        float gscale = 1.0f, ginv = 1.0f;                                  // F16: power-of-two scale of this tile's dh1 and its inverse
+        // ---- dh1 (in place), then as K = points fragments [feature tile][k-step]
+        u32x4 xh[2][2], xl[2][2];
+        float ginv = 1.0f;                                                 // F16: inverse of this tile's power-of-two scale
         {
-            f32x4 doa4[4], dob4[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { doa4[q] = *(const f32x4 *)(pts + 8 * q + h4); dob4[q] = *(const f32x4 *)(pts + 32 + 8 * q + h4); }
+            const u32x4 bd = input_fragment(h ? dob : doa, h);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const int fo = 32 * t + pl;
-                const float av = filmb[br * FB_BR + 0 * 64 + fo], rstd1 = filmb[br * FB_BR + 2 * 64 + fo], ca = filmb[br * FB_BR + 3 * 64 + fo];
-                const float w2a = w2s[br * 128 + fo], w2b = w2s[br * 128 + 64 + fo];
+                const f32x16 G = mfma(bd, *(const u32x4 *)(smem + L_GFR + ((br * 2 + t) * 64 + lane) * 16), zero16());
+                const int fo = 32 * t + pl;                                 // this lane's feature (swapped orientation)
+                const float rstd1 = filmb[br * FB_BR + 2 * 64 + fo], ca = filmb[br * FB_BR + 3 * 64 + fo];
                 const float m1 = s12s[br * 128 + fo], m2 = s12s[br * 128 + 64 + fo];
-                // r03: the per-lane constants folded (6 VALU per element instead of 8):
-                //   rstd1 (a dh2a - m1 - h1n m2) = [pa > 0] (K1 do_a + K2 do_b) + C1 pa + C0
-                const float K1 = rstd1 * av * w2a, K2 = rstd1 * av * w2b, C1 = -(rstd1 * rstd1) * m2, C0 = rstd1 * (ca * m2 - m1);
+                const float C1 = -(rstd1 * rstd1) * m2, C0 = rstd1 * (ca * m2 - m1);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float base = __builtin_fmaf(pre[t][r], C1, C0);
-                    const float lin = __builtin_fmaf(K2, dob4[r >> 2][r & 3], K1 * doa4[r >> 2][r & 3]);
-                    pre[t][r] = pre[t][r] > 0.f ? base + lin : base;
-                }
+                for (int r = 0; r < 16; ++r) pre[t][r] = __builtin_fmaf(pre[t][r], C1, pre[t][r] > 0.f ? G[r] : C0);
             }
             if (tile0 + TILE > N) {              // ragged last tile of a cloud (wave-uniform, rare): no gradient from padding points
 #pragma unroll
@@ -1488,137 +1609,130 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(pre[t][r]));
-                for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-                const uint32_t mb = __builtin_amdgcn_readfirstlane(f2u(m));
+                const uint32_t mb = wave_max_bits(m);                      // (a NaN anywhere may or may not surface here: its tile is lost either way)
                 const int e = (int)((mb >> 23) & 0xFFu) - 127;
-                const bool ok = mb != 0u && e > -100 && e < 100;           // (zero, denormal-tiny, Inf / NaN tiles: no scaling)
-                gscale = ok ? u2f((uint32_t)(127 + 13 - e) << 23) : 1.0f;
-                ginv = ok ? u2f((uint32_t)(127 - 13 + e) << 23) : 1.0f;
-                kfrags_from_swapped_f16<false>(pre, gscale, a.negone, xh, xl);
+                const bool ok = mb != 0u && e > -100 && e < 100;           // (zero, denormal-tiny, Inf / NaN tiles: no scaling of their own)
+                int e_t = ok ? 13 - e : (ti ? e_dw : 0);                   // this tile's scale 2^e_t
+                if (ti) {
+                    // dW1 accumulates over the wave's tiles in ONE set of accumulators: bring what is there to this tile's scale
+                    // (exact, a power of two).  A later tile more than 2^60 below the earlier one keeps a smaller scale than
+                    // its own (its products are then beneath the earlier tile's rounding anyway); scaling DOWN is not capped
+                    // short of fp32's range, where the earlier tile's share is gone for the same reason.
+                    e_t = e_t < e_dw + 60 ? e_t : e_dw + 60;
+                    const int de = e_t - e_dw > -120 ? e_t - e_dw : -120;
+                    if (de != 0) {
+                        const float ratio = u2f((uint32_t)(127 + de) << 23);
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) dw[mt][nt][r] *= ratio;
+                    }
+                }
+                e_dw = e_t;
+                ginv = u2f((uint32_t)(127 - e_t) << 23);
+                kfrags_from_swapped_f16<false>(pre, u2f((uint32_t)(127 + e_t) << 23), a.negone, xh, xl);
             } else {
                 kfrags_from_swapped<false>(pre, xh, xl);
             }
         }
         TP(3)
-        // ---- dh1 back to lane = point (an MFMA against the identity: hi + lo is exact), split, dh0 = W1^T dh1 in BOTH
-        // orientations: lane = point for the per-point u_k, lane = feature for the per-feature sums
+        // ---- dh1 back to lane = point (an MFMA against the identity: hi + lo is exact) as the A fragments of dh0 = W1^T dh1
         u32x4 bg[2][4];
         {
-            // r03: the hi and the lo parts are transposed SEPARATELY -- each result is a bf16 value in an fp32 register, so
-            // the B fragments of the next contraction are two byte permutes per pair instead of a second symmetric split
-            // of hi + lo (6 VALU per pair); same 8 MFMAs
-            f32x16 dnh[2], dnl[2];
+            // r03: the hi and the lo parts are transposed SEPARATELY -- each result is a bf16 / fp16 value in an fp32 register, so
+            // the fragments of the next contraction are one conversion per pair instead of a second symmetric split; 8 MFMAs
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if constexpr (F16) {
-                    dnh[t] = mfma_f16(xh[t][0], eye[0], zero16());
-                    dnl[t] = mfma_f16(xl[t][0], eye[0], zero16());
-                    dnh[t] = mfma_f16(xh[t][1], eye[1], dnh[t]);
-                    dnl[t] = mfma_f16(xl[t][1], eye[1], dnl[t]);
-                } else {
-                    dnh[t] = mfma(xh[t][0], eye[0], zero16());
-                    dnl[t] = mfma(xl[t][0], eye[0], zero16());
-                    dnh[t] = mfma(xh[t][1], eye[1], dnh[t]);
-                    dnl[t] = mfma(xl[t][1], eye[1], dnl[t]);
-                }
-            }
-            if (br == 0) KP(4, 0)
+            for (int part = 0; part < 2; ++part) {
+                f32x16 dn[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const int s = 2 * t + (r >> 3), d = (r & 7) >> 1;          // as split_fragment
-                    if constexpr (F16) {            // each value IS an fp16 number: the conversion is exact
-                        bg[0][s][d] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(dnh[t][r], dnh[t][r + 1]));
-                        bg[1][s][d] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(dnl[t][r], dnl[t][r + 1]));
+                for (int t = 0; t < 2; ++t) {
+                    const u32x4 (&xp)[2][2] = part ? xl : xh;
+                    if constexpr (F16) {
+                        dn[t] = mfma_f16(xp[t][0], eye[0], zero16());
+                        dn[t] = mfma_f16(xp[t][1], eye[1], dn[t]);
                     } else {
-                        bg[0][s][d] = pack_bf16_trunc(dnh[t][r], dnh[t][r + 1]);
-                        bg[1][s][d] = pack_bf16_trunc(dnl[t][r], dnl[t][r + 1]);
+                        dn[t] = mfma(xp[t][0], eye[0], zero16());
+                        dn[t] = mfma(xp[t][1], eye[1], dn[t]);
                     }
                 }
-            if (br == 0) KP(4, 1)
-        }
-        {
-            f32x16 dh0a[2] = {zero16(), zero16()};
-            chain_mfma<2, F16>(smem + L_PACK + pt_a1t(NS), br, lane, bg, dh0a);
-            if (br == 0) KP(4, 2)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dh0a[t][r] = h0a[t][r] > 0.f ? dh0a[t][r] : 0.f;
-            // u_k: the per-feature coefficients as 16-byte LDS reads (4 consecutive features = registers 4q .. 4q+3), tied to
-            // the chain's last result and chunked (see the r02 note on scratch spills)
-            int h4u = h4;
-            asm volatile("" : "+v"(h4u) : "v"(dh0a[1][15]));
-            // (F16: dh0a carries the tile's scale and W1^T's; this branch's share of u_k is summed on its own and unscaled once)
-            float uas = F16 ? 0.f : ua, ubs = F16 ? 0.f : ub;
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int rh = 0; rh < 2; ++rh) {
-                    const float *c0 = cf + br * 128 + h4u + 32 * t;
-#pragma unroll
-                    for (int q = 2 * rh; q < 2 * rh + 2; ++q) {
-                        const f32x4 ca = *(const f32x4 *)(c0 + 8 * q);
-                        uas += ca.x * dh0a[t][4 * q + 0];
-                        uas += ca.y * dh0a[t][4 * q + 1];
-                        uas += ca.z * dh0a[t][4 * q + 2];
-                        uas += ca.w * dh0a[t][4 * q + 3];
-                        if (two_kept) {                                    // wave-uniform: layers of pattern 1 keep one channel
-                            const f32x4 cb = *(const f32x4 *)(c0 + 64 + 8 * q);
-                            ubs += cb.x * dh0a[t][4 * q + 0];
-                            ubs += cb.y * dh0a[t][4 * q + 1];
-                            ubs += cb.z * dh0a[t][4 * q + 2];
-                            ubs += cb.w * dh0a[t][4 * q + 3];
-                        }
+                    for (int r = 0; r < 16; r += 2) {
+                        const int s = 2 * t + (r >> 3), d = (r & 7) >> 1;          // as split_fragment
+                        if constexpr (F16) bg[part][s][d] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(dn[t][r], dn[t][r + 1]));   // each value IS an fp16 number: exact
+                        else bg[part][s][d] = pack_bf16_trunc(dn[t][r], dn[t][r + 1]);
                     }
-                    asm volatile("" : "+v"(h4u) : "v"(uas), "v"(ubs));
-                }
-            if constexpr (F16) {
-                const float un = ginv * *(const float *)(smem + L_PACK + pt_tail(NS) + 4 * br);
-                ua += uas * un; ub += ubs * un;
-            } else {
-                ua = uas; ub = ubs;
             }
-            if (br == 0) KP(4, 3)
         }
         TP(4)
-        float rsum[2][4];                                                  // [feature tile][k]: sums over the tile's points, lanes h = 0
-        f32x16 h0s[2];                                                     // h0 pre-activation, lane = feature
+        // ---- dh0 = W1^T dh1 in the swapped orientation (lane = in-feature 32 t + pl, registers = the half's 16 points), relu
+        // mask, then everything that hangs on it: the per-feature sums (in-lane adds), u_k (a sum over the FEATURES = over the
+        // lanes: reduce_lanes16) and, below, dW1.  r01-r04 ran this contraction a second time with lane = point for u_k -- 24 + 2
+        // MFMAs, a second mask, 128 FMAs fed by 16 dependent LDS reads of the coefficient table; the butterfly is 2 x 47 VALU.
+        const float un = F16 ? ginv * winv : 1.0f;                         // dh0 carries the tile's scale and W1^T's (powers of two: exact)
+        f32x16 h0s[2];                                                     // h0 pre-activation (x 16 for F16), lane = feature
         {
-            input_mfma_swapped(smem + L_PACK + pt_a0(NS), br, lane, b0, h0s);
+            input_mfma_swapped(smem + L_PACK + pt_a0(NS), br, lane, F16 ? input_fragment_x16(h ? xb : xa, h) : b0, h0s);
             f32x16 dh0s[2] = {zero16(), zero16()};
             chain_mfma_swapped<2, F16>(smem + L_PACK + pt_a1t(NS), br, lane, bg, dh0s);
-            f32x16 h0n[2];
-            input_mfma_swapped(smem + L_PACK + pt_a0n(NS), br, lane, b0, h0n);   // normalised h0
-            f32x4 xa4[4], xb4[4];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const float cka[2] = {cf[br * 128 + pl], cf[br * 128 + 32 + pl]}, ckb[2] = {cf[br * 128 + 64 + pl], cf[br * 128 + 96 + pl]};   // c_fk of this lane's features
+            float ua, ub = 0.f;
+            // (two code paths, chosen per wave: layers of pattern 1 keep ONE channel -- no x_b sum, no u_b)
+            auto sums_and_u = [&](auto two) {
+                constexpr bool TWO = decltype(two)::value;
+                float wa[16], wb[16];                                      // c_fa dh0a, c_fb dh0a of this lane's two features, per point
+                float sm[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { xa4[q] = *(const f32x4 *)(pts + 64 + 8 * q + h4); xb4[q] = *(const f32x4 *)(pts + 96 + 8 * q + h4); }
+                for (int q = 0; q < 4; ++q) {                              // four of the half's points at a time: one 16-byte read per input
+                    const f32x4 xa4 = *(const f32x4 *)(pts + 8 * q + h4);
+                    f32x4 xb4 = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (TWO) xb4 = *(const f32x4 *)(pts + 32 + 8 * q + h4);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                    for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float d = h0s[t][r] > 0.f ? dh0s[t][r] : 0.f;
-                    s0 += d * h0n[t][r]; s1 += d; s2 += d * xa4[r >> 2][r & 3];
-                    if (two_kept) s3 += d * xb4[r >> 2][r & 3];
+                        for (int i = 0; i < 4; ++i) {
+                            const int r = 4 * q + i;
+                            const float d = h0s[t][r] > 0.f ? dh0s[t][r] : 0.f;
+                            sm[t][0] += d; sm[t][1] = __builtin_fmaf(d, xa4[i], sm[t][1]);
+                            wa[r] = t ? __builtin_fmaf(cka[1], d, wa[r]) : cka[0] * d;
+                            if constexpr (TWO) {
+                                sm[t][2] = __builtin_fmaf(d, xb4[i], sm[t][2]);
+                                wb[r] = t ? __builtin_fmaf(ckb[1], d, wb[r]) : ckb[0] * d;
+                            }
+                        }
                 }
-                if constexpr (F16) {            // dh0s carries the tile's scale and W1^T's (powers of two: exact)
-                    const float un = ginv * *(const float *)(smem + L_PACK + pt_tail(NS) + 4 * br);
-                    s0 *= un; s1 *= un; s2 *= un; s3 *= un;
-                }
-                rsum[t][0] = s0 + __shfl_xor(s0, 32); rsum[t][1] = s1 + __shfl_xor(s1, 32);
-                rsum[t][2] = s2 + __shfl_xor(s2, 32); rsum[t][3] = s3 + __shfl_xor(s3, 32);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int k = 0; k < (TWO ? 3 : 2); ++k) rs[t][k] = __builtin_fmaf(sm[t][k], un, rs[t][k]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();                           // the scratch is rewritten for the next tile
+                // u_k[pt] = sum over this branch's features of c_fk dh0a[f][pt].  Lane i of each row ends up with point
+                // (i & 3) + 8 ((i & 15) >> 2) + 4 h of the tile; plane `br`
+                // (tried: the butterfly in the shadow of dW1's 24 MFMAs, which need nothing from it -- sched_group_barrier 1 : 4 --
+                // the interleaved live ranges cost 130 registers of scratch at the 256 this kernel may use)
+                ua = reduce_lanes16(wa, lane) * un;
+                if constexpr (TWO) ub = reduce_lanes16(wb, lane) * un;
+            };
+            if (two_kept) sums_and_u(std::true_type{}); else sums_and_u(std::false_type{});
+            const int pu = tile0 + (lane & 3) + 8 * ((lane & 15) >> 2) + 4 * h;
+            if ((lane & 16) == 0 && pu < N) {
+                uplane[((size_t)bi * 2 + 0) * N + pu] = ua;
+                uplane[((size_t)bi * 2 + 1) * N + pu] = ub;
             }
         }
         TP(5)
         // ---- dW1[fo][fi] += sum_points dh1[fo][pt] * h0[fi][pt]: both operands are K = points fragments straight from
         // the swapped accumulators; hi/lo split like every other contraction: hi.hi, hi.lo, lo.hi
-        f32x16 dw[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};     // [fo tile][fi tile]
         {
             u32x4 yh[2][2], yl[2][2];
             // F16: relu(h0) x 16 as fp16 hi/lo (|BN0(h0)| < 2048 is what the f16x3 range monitor guarantees: 32768 < 65504)
-            if constexpr (F16) kfrags_from_swapped_f16<true>(h0s, 16.0f, a.negone, yh, yl);
+            if constexpr (F16) kfrags_from_swapped_f16<true, false>(h0s, 1.0f, a.negone, yh, yl);
             else kfrags_from_swapped<true>(h0s, yh, yl);
 #pragma unroll
             for (int j2 = 0; j2 < 2; ++j2)
@@ -1636,77 +1750,72 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
                             dw[mt][nt] = mfma(xh[mt][j2], yh[nt][j2], dw[mt][nt]);
                         }
                     }
-            if constexpr (F16) {                 // back to the true scale before the waves' tiles are added (each has its own)
-                const float un = ginv * 0.0625f;
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) dw[mt][nt][r] *= un;
-            }
         }
         TP(6)
-        // ---- workgroup reduction through per-wave LDS slots (plain stores: LDS float atomics are ~1000 cycles per wave
-        // instruction), two rounds of 32 accumulator registers, then the four per-feature sums.  r03: 16-byte LDS accesses --
-        // a lane stores its registers 4g .. 4g+3 as one quad (8 ds_write_b128 per round instead of 32 ds_write_b32), a thread
-        // sums ONE quad over the 8 waves (8 ds_read_b128 instead of 32 ds_read_b32); same sums in the same (wave) order
-        float *o = part2 + (blk * 2 + br) * P2_J;
+    }
+    // ---- the one workgroup reduction: dW1 through per-wave LDS slots (plain stores: LDS float atomics are ~1000 cycles per wave
+    // instruction), two rounds of 32 accumulator registers, then the three per-feature sums.  16-byte LDS accesses: a lane stores
+    // its registers 4g .. 4g+3 as one quad, a thread sums ONE quad over the branch's waves in wave order, each wave's share
+    // times the power of two that takes it back to the true scale (an FMA where r04 had a multiply per element and an add)
+    KP(2, 2)
+    if (lane == 0) uns[wave] = F16 ? u2f((uint32_t)(127 - e_dw - 4) << 23) : 1.0f;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            __syncthreads();                                               // X / Y (or the previous round) are free
-            f32x4 *slot = (f32x4 *)(redw + wave * 2048) + lane;            // quad (g, lane) at [g * 64 + lane]
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+        for (int k = 0; k < 3; ++k) rs[t][k] = half_sum(rs[t][k]);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 v = {dw[mt][nt][4 * g + 0], dw[mt][nt][4 * g + 1], dw[mt][nt][4 * g + 2], dw[mt][nt][4 * g + 3]};
-                    slot[(4 * nt + g) * 64] = v;
-                }
-            __syncthreads();
-            {
-                const int e = threadIdx.x;                                 // quad index: (nt, g, lane)
-                f32x4 t = *((const f32x4 *)redw + e);
+    for (int mt = 0; mt < 2; ++mt) {
+        __syncthreads();                                                   // every wave is through with its scratch / the previous round has been read
+        f32x4 *slot = (f32x4 *)(redw + wave * 2048) + lane;                // quad (g, lane) at [g * 64 + lane]
 #pragma unroll
-                for (int w = 1; w < TW; ++w) {
-                    const f32x4 v = *((const f32x4 *)(redw + w * 2048) + e);
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {dw[mt][nt][4 * g + 0], dw[mt][nt][4 * g + 1], dw[mt][nt][4 * g + 2], dw[mt][nt][4 * g + 3]};
+                slot[(4 * nt + g) * 64] = v;
+            }
+        __syncthreads();
+        const int e = threadIdx.x;                                         // quad index: (nt, g, lane)
+        const int ln = e & 63, g = (e >> 6) & 3, nt = e >> 8;
+        const int fo = 32 * mt + 8 * g + 4 * (ln >> 5), fi = 32 * nt + (ln & 31);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int w0 = PAIR ? 4 * b : 0;
+            f32x4 t = *((const f32x4 *)(redw + w0 * 2048) + e);
+            if constexpr (F16) { const float u = uns[w0]; t.x *= u; t.y *= u; t.z *= u; t.w *= u; }
+#pragma unroll
+            for (int w = 1; w < NWB; ++w) {
+                const f32x4 v = *((const f32x4 *)(redw + (w0 + w) * 2048) + e);
+                if constexpr (F16) {
+                    const float u = uns[w0 + w];
+                    t.x = __builtin_fmaf(v.x, u, t.x); t.y = __builtin_fmaf(v.y, u, t.y); t.z = __builtin_fmaf(v.z, u, t.z); t.w = __builtin_fmaf(v.w, u, t.w);
+                } else {
                     t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
                 }
-                const int ln = e & 63, g = (e >> 6) & 3, nt = e >> 8;
-                const int fo = 32 * mt + 8 * g + 4 * (ln >> 5), fi = 32 * nt + (ln & 31);
-                o[128 + (fo + 0) * 64 + fi] = t.x;
-                o[128 + (fo + 1) * 64 + fi] = t.y;
-                o[128 + (fo + 2) * 64 + fi] = t.z;
-                o[128 + (fo + 3) * 64 + fi] = t.w;
             }
+            float *o = part2 + (blk * 2 + (PAIR ? b : (int)blockIdx.z)) * P2_J + P2_W;
+            o[(fo + 0) * 64 + fi] = t.x;
+            o[(fo + 1) * 64 + fi] = t.y;
+            o[(fo + 2) * 64 + fi] = t.z;
+            o[(fo + 3) * 64 + fi] = t.w;
         }
-        TP(7)
-        __syncthreads();
-        if (!h) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) redw[wave * 256 + k * 64 + 32 * t + pl] = rsum[t][k];
-        }
-        TP(8)
-        __syncthreads();
-        TP(9)
-        if (threadIdx.x < 256) {
-            float t = 0.f;
-#pragma unroll
-            for (int w = 0; w < TW; ++w) t += redw[w * 256 + threadIdx.x];
-            o[threadIdx.x < 128 ? threadIdx.x : 4224 - 128 + threadIdx.x] = t;
-        }
-        TP(10)
     }
-#ifdef DPF_PROFILE
-#endif
-    ua += __shfl_xor(ua, 32); ub += __shfl_xor(ub, 32);
-    if (valid && h == 0) {
-        ubuf[((size_t)bi * 2 + 0) * N + n] = ua;
-        ubuf[((size_t)bi * 2 + 1) * N + n] = ub;
+    __syncthreads();
+    if (!h) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) redw[wave * 256 + k * 64 + 32 * t + pl] = rs[t][k];
     }
-    KP(2, 2)
+    __syncthreads();
+    if (threadIdx.x < NB * 192) {
+        const int b = threadIdx.x / 192, i = threadIdx.x - 192 * b, w0 = PAIR ? 4 * b : 0;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWB; ++w) t += redw[(w0 + w) * 256 + i];
+        part2[(blk * 2 + (PAIR ? b : (int)blockIdx.z)) * P2_J + (i < 64 ? P2_S + i : P2_A - 64 + i)] = t;
+    }
+    KP(2, 3)
 #ifdef DPF_PROFILE
     if (g_tprof != nullptr && lane == 0 && blk < 2) {
         for (int i = 0; i < 12; ++i) g_tprof[(blk * TW + wave) * 14 + i] = tt[i];
@@ -1990,7 +2099,8 @@ static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb
     if (hipError_t e = lim_b1.ensure((const void *)tbwd1_kernel<NS, F16>, lds1); e != hipSuccess) return (int)e;
     static LdsLimit lim_b1s;
     if (hipError_t e = lim_b1s.ensure((const void *)tbwd1_kernel<NS, F16, true>, lds1); e != hipSuccess) return (int)e;
-    if (hipError_t e = lim_b2.ensure((const void *)tbwd2_kernel<NS, F16>, lds2); e != hipSuccess) return (int)e;
+    if constexpr (NS == 2)
+        if (hipError_t e = lim_b2.ensure((const void *)tbwd2_kernel<NS, F16, true>, lds2); e != hipSuccess) return (int)e;
     // r04: the column sums of the layer above's pass-2 partials ride in this launch (ColsumJob) instead of a tcolsum launch
     // of their own between the two layers; DPF_TRAIN_FUSE_COLSUM=0 keeps the separate launch
     static const int fuse_env = getenv("DPF_TRAIN_FUSE_COLSUM") ? atoi(getenv("DPF_TRAIN_FUSE_COLSUM")) : 1;
@@ -2004,7 +2114,8 @@ static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb
     }
     // small batches: the two branches of passes 1 and 2 in two workgroups each (at most half a workgroup per CU otherwise)
     static const int split_env = getenv("DPF_TRAIN_SPLIT") ? atoi(getenv("DPF_TRAIN_SPLIT")) : -1;
-    const bool split2 = split_env >= 0 ? split_env != 0 : nblk <= 128;
+    // (bf16x6's three forward parts do not leave the one-branch-per-wave form its registers: that precision keeps one branch per workgroup)
+    const bool split2 = NS == 3 || (split_env >= 0 ? split_env != 0 : nblk <= 128);
     const bool split1 = split_env >= 0 ? split_env != 0 : nblk <= 64;      // (B = 16: tbwd1 15.7 us unsplit, 18.1 split)
     grid1.z = split1 ? 2 : 1;
     { KScope ks(4, s);
@@ -2016,13 +2127,13 @@ static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb
                            w.tickets, w.pc, dfm_l, cs); }
     static LdsLimit lim_b2s;
     if (split2)
-        if (hipError_t e = lim_b2s.ensure((const void *)tbwd2_kernel<NS, F16, true>, lds2); e != hipSuccess) return (int)e;
+        if (hipError_t e = lim_b2s.ensure((const void *)tbwd2_kernel<NS, F16, false>, lds2); e != hipSuccess) return (int)e;
     { KScope ks(5, s);
-    if (split2)
-        hipLaunchKernelGGL((tbwd2_kernel<NS, F16, true>), dim3(grid.x, grid.y, 2), dim3(TW * 64), lds2, s, a, w.pc, count, dcanon_l, w.dout, w.ubuf, w.part2);
-    else
-        hipLaunchKernelGGL((tbwd2_kernel<NS, F16>), grid, dim3(TW * 64), lds2, s, a, w.pc, count, dcanon_l, w.dout, w.ubuf, w.part2); }
-    const float *ubuf2 = split2 ? w.ubuf + (size_t)B * 2 * N : nullptr;
+    if (split2)      // one branch per workgroup, a tile per wave
+        hipLaunchKernelGGL((tbwd2_kernel<NS, F16, false>), dim3(grid.x, grid.y, 2), dim3(TW * 64), lds2, s, a, w.pc, count, dcanon_l, w.dout, w.ubuf, w.part2);
+    else if constexpr (NS == 2)      // one branch per wave, two tiles per wave
+        hipLaunchKernelGGL((tbwd2_kernel<NS, F16, true>), grid, dim3(TW * 64), lds2, s, a, w.pc, count, dcanon_l, w.dout, w.ubuf, w.part2); }
+    const float *ubuf2 = w.ubuf + (size_t)B * 2 * N;                      // u_k comes in two planes (one per branch) either way
     if (!fuse_env || last) {              // (fused: the next backward layer's pass 1 sums these partials; the last layer has none)
         KScope ks(6, s);
         hipLaunchKernelGGL(tcolsum_kernel, dim3((2 * P2_J + 31) / 32), dim3(1024), 0, s, nblk, 2 * P2_J, w.part2, w.tot2, dcanon_l, P2_J);
@@ -2181,6 +2292,13 @@ extern "C" int dpf_flow_train_update_running(int n_layers, double momentum, cons
     hipLaunchKernelGGL(trunning_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_layers, (float)(1.0 - momentum),
                        (float)momentum, film_mean, film_uvar, stats, running_mean, running_var, num_batches_tracked);
     return (int)hipGetLastError();
+}
+
+// workgroups of pass 1 that gave up waiting for the fused column sums and summed the critical columns themselves (process-wide)
+extern "C" long dpf_train_colsum_fallbacks(void) {
+    unsigned v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_colsum_fallbacks), sizeof(v)) != hipSuccess) return -1;
+    return (long)v;
 }
 
 extern "C" long dpf_train_graph_replays(void) { return dpf_graph_stats().replays.load(); }

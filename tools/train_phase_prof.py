@@ -12,8 +12,8 @@ h = _lib.lib()
 h.dpf_debug_set_tprof.argtypes = [ctypes.c_void_p]
 dec = nets.LocalCondRNVPDecoder(1, 64, G).cuda().train()
 tgt, z, g = SY.synthetic_inputs(3, B, N, G)
-names = ["loop top", "sync+zero", "fwd recompute", "dh1", "T chain + mask", "reductions", "dW1 rounds", "sync+zero redw",
-         "LDS atomics", "sync", "write out"]
+# r05 stamps (first tile of every wave): TP(0) tile top .. TP(6) dW1 issued; [11] prologue done, [12] entry, [13] exit
+names = ["tile top", "input fragment", "fwd recompute", "dh1 + fragments", "transposes, W1^T chain, mask, u_k", "swapped chain + sums", "dW1"]
 for prec in ("f16x3",):
     train_engine.TRAIN_PRECISION = prec
     prof = torch.zeros((16, 14), dtype=torch.int64, device="cuda")
@@ -25,11 +25,12 @@ for prec in ("f16x3",):
     torch.cuda.synchronize()
     h.dpf_debug_set_tprof(None)
     t = prof.cpu().numpy()
-    d = np.diff(t[:, :11], axis=1)
+    d = np.diff(t[:, :7], axis=1)
     print(prec, "kernel entry -> after the prologue:", np.median(t[:, 11] - t[:, 12]), " prologue end -> loop:", np.median(t[:, 0] - t[:, 11]),
-          " branch 0:", np.median(t[:, 10] - t[:, 0]), " whole kernel (this wave):", np.median(t[:, 13] - t[:, 12]))
-    for i in range(10):
+          " first tile:", np.median(t[:, 6] - t[:, 0]), " first tile done -> exit (second tile + reduction):", np.median(t[:, 13] - t[:, 6]),
+          " whole kernel (this wave):", np.median(t[:, 13] - t[:, 12]))
+    for i in range(6):
         print("   %-16s median %8.0f  min %8.0f  max %8.0f   per wave of workgroup 0: %s" % (names[i + 1], np.median(d[:, i]), d[:, i].min(), d[:, i].max(), " ".join("%5d" % v for v in d[:8, i])))
     print("   arrival at the phase boundaries relative to the workgroup's first wave (workgroup 0):")
-    for i in range(11):
+    for i in range(7):
         print("      TP(%2d) %s" % (i, " ".join("%6d" % (v - t[:8, i].min()) for v in t[:8, i])))
