@@ -784,11 +784,11 @@ __device__ __forceinline__ float dh2a_of(float pre, float w2a, float w2b, float 
 }
 
 // Totals of pass 2 of a layer -> the coefficients of the conditioner path of its input gradient,
-//   dx_k[pt] = u_k[pt] - coef[4k] - coef[4k+1] x_a - coef[4k+2] x_b   (see tbwd3f_kernel),
+//   dx_k[pt] = u_k[pt] - coef[4k] - coef[4k+1] (x_a - E x_a) - coef[4k+2] (x_b - E x_b)   (see tbwd3f_kernel; coef[3], coef[7] = E x_a, E x_b),
 // left in LDS (`coef`, 8 floats; `acc` is 8 KiB of scratch); EVERY workgroup of the caller runs this (128 threads of double
 // arithmetic, same operations in the same order, so the same bits), workgroup 0 also writes d gamma0 / d beta0 / dW0 and
 // the dW1 totals are converted by whoever comes first (grid-stride).  Ends with a workgroup barrier.
-struct CoefLoads { double S, Sa, Sb; float caa, cbb, cab, wa, wb, gamma, rstd0, mean0; };
+struct CoefLoads { double S, Sa, Sb; float ea, eb, caa, cbb, cab, wa, wb, gamma, rstd0; };
 // the loads of bwd3_coefs (threads < 128), to be issued BEFORE the caller's weight loads
 template <bool AGENT = false>
 __device__ __forceinline__ CoefLoads bwd3_loads(int nk, const double *__restrict__ tot, const float *__restrict__ tcanon_l,
@@ -805,9 +805,9 @@ __device__ __forceinline__ CoefLoads bwd3_loads(int nk, const double *__restrict
         L.S = t[P2_S + f]; L.Sa = t[P2_A + f]; L.Sb = t[P2_B + f];
     }
     const float *m = stats_l + ST_MOM;
-    L.caa = m[2]; L.cbb = m[3]; L.cab = m[4];
+    L.ea = m[0]; L.eb = m[1]; L.caa = m[2]; L.cbb = m[3]; L.cab = m[4];
     L.wa = cb[T_W0 + f * nk]; L.wb = nk == 2 ? cb[T_W0 + f * 2 + 1] : 0.f; L.gamma = cb[T_G0 + f];
-    L.rstd0 = stats_l[br * ST_BR + 64 + f]; L.mean0 = stats_l[br * ST_BR + f];
+    L.rstd0 = stats_l[br * ST_BR + 64 + f];
     return L;
 }
 __device__ __forceinline__ void bwd3_coefs(const CoefLoads &L, int blk, int nk, double count, float *__restrict__ dcanon_l,
@@ -821,7 +821,7 @@ __device__ __forceinline__ void bwd3_coefs(const CoefLoads &L, int blk, int nk, 
         const double S = L.S, Sa = L.Sa, Sb = L.Sb;                                                // Sa, Sb: against the CENTRED inputs
         const double caa = L.caa, cbb = L.cbb, cab = L.cab;
         const double wa = L.wa, wb = L.wb, gamma = L.gamma;
-        const double rstd0 = L.rstd0, mean0 = L.mean0;
+        const double rstd0 = L.rstd0;
         const double Sg = rstd0 * (wa * Sa + wb * Sb);                                             // sum dh0a * h0n
         const double A = S / count, Bc = Sg / count;
         const double hxa = rstd0 * (wa * caa + wb * cab), hxb = rstd0 * (wa * cab + wb * cbb);     // E[h0n x_k]
@@ -834,29 +834,27 @@ __device__ __forceinline__ void bwd3_coefs(const CoefLoads &L, int blk, int nk, 
             else dcanon_l[br * T_BR + T_W0 + 64 + f] = 0.f;
         }
         const double ck[2] = {wa * sc, wb * sc};
-        double v[8];
+        double v[6];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            v[4 * k + 0] = ck[k] * A;
-            v[4 * k + 1] = ck[k] * Bc * rstd0 * wa;
-            v[4 * k + 2] = ck[k] * Bc * rstd0 * wb;
-            v[4 * k + 3] = ck[k] * Bc * rstd0 * mean0;
+            v[3 * k + 0] = ck[k] * A;
+            v[3 * k + 1] = ck[k] * Bc * rstd0 * wa;
+            v[3 * k + 2] = ck[k] * Bc * rstd0 * wb;
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 6; ++i)
             for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
         if (f == 0)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[br][i] = v[i];
+            for (int i = 0; i < 6; ++i) acc[br][i] = v[i];
     }
     lds_barrier();
     if (threadIdx.x < 2) {
         const int k = threadIdx.x;
-        const double s0 = acc[0][4 * k + 0] + acc[1][4 * k + 0], s1 = acc[0][4 * k + 1] + acc[1][4 * k + 1];
-        const double s2 = acc[0][4 * k + 2] + acc[1][4 * k + 2], s3 = acc[0][4 * k + 3] + acc[1][4 * k + 3];
-        coef[k * 4 + 0] = (float)(s0 - s3);
-        coef[k * 4 + 1] = (float)s1;
-        coef[k * 4 + 2] = (float)s2;
+        coef[k * 4 + 0] = (float)(acc[0][3 * k + 0] + acc[1][3 * k + 0]);
+        coef[k * 4 + 1] = (float)(acc[0][3 * k + 1] + acc[1][3 * k + 1]);
+        coef[k * 4 + 2] = (float)(acc[0][3 * k + 2] + acc[1][3 * k + 2]);
+        coef[k * 4 + 3] = k ? L.eb : L.ea;                                  // the batch means the consumer centres the inputs with
     }
     lds_barrier();
 }
@@ -1064,8 +1062,8 @@ __global__ __launch_bounds__(TW * 64, BSPLIT ? 2 : 4) void tbwd1_kernel(TArgs a,
     // pin the consumers of the pass-3 totals BEHIND the issue of everything else (the compiler had started on them right
     // behind their loads: a cold round trip before the point and weight loads were even requested)
     asm volatile("" : "+v"(cl.S), "+v"(cl.Sa), "+v"(cl.Sb));
-    asm volatile("" : "+v"(cl.caa), "+v"(cl.cbb), "+v"(cl.cab));
-    asm volatile("" : "+v"(cl.wa), "+v"(cl.wb), "+v"(cl.gamma), "+v"(cl.rstd0), "+v"(cl.mean0));
+    asm volatile("" : "+v"(cl.ea), "+v"(cl.eb), "+v"(cl.caa), "+v"(cl.cbb), "+v"(cl.cab));
+    asm volatile("" : "+v"(cl.wa), "+v"(cl.wb), "+v"(cl.gamma), "+v"(cl.rstd0));
     float *w2s = red + TW * 520;                                                // [2 br][2][64] raw sd2.weight
     if (threadIdx.x < 256) w2s[threadIdx.x] = w2_v;
     float *pcoef = w2s + 256 + TW * 64;                                         // 8 floats behind the per-wave scratch
@@ -1075,8 +1073,9 @@ __global__ __launch_bounds__(TW * 64, BSPLIT ? 2 : 4) void tbwd1_kernel(TArgs a,
             bwd3_coefs(c3, wg_lin + (int)blockIdx.z, pv.kb >= 0 ? 2 : 1, pv.count, pv.dcanon_l, (double (*)[8])red, pcoef);   // (its writer: workgroup 0 of z = 0)
         if (pv.has) {   // + the conditioner path of the layer above: dx_k = u_k - C_k - alpha_k x_a - beta_k x_b on ITS kept channels
             // every operation rounded on its own, in tbwd3f_kernel's order (the two launch forms give the same bits)
-            const float ta = cond_path(u2a, pcoef[0], pcoef[1], pcoef[2], xa2, xb2);
-            const float tb = pv.kb >= 0 ? cond_path(u2b, pcoef[4], pcoef[5], pcoef[6], xa2, xb2) : 0.f;
+            const float xa2c = __fsub_rn(xa2, pcoef[3]), xb2c = __fsub_rn(xb2, pcoef[7]);
+            const float ta = cond_path(u2a, pcoef[0], pcoef[1], pcoef[2], xa2c, xb2c);
+            const float tb = pv.kb >= 0 ? cond_path(u2b, pcoef[4], pcoef[5], pcoef[6], xa2c, xb2c) : 0.f;
 #pragma unroll
             for (int c = 0; c < 3; ++c)
                 if (c == pv.ka || c == pv.kb) gp[c] = __fadd_rn(gp[c], c == pv.ka ? ta : tb);
@@ -1336,6 +1335,39 @@ __device__ __forceinline__ uint32_t wave_max_bits(float x) {
     const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
     return ab > cd ? ab : cd;
 }
+// The operands of an input-style MFMA (flow_common.h: input_fragment / input_weight_slots8) with ROUND-TO-NEAREST parts.  The
+// truncating split of the forward path gives every part the sign of the value, so the three cross terms the 16 K slots have no
+// room for (mid x lo, lo x mid, lo x lo: ~2^-24 of the product) all have the product's sign -- a bias that survives a sum over
+// 65 536 points.  A gradient whose terms cancel to 1e-3 of their magnitudes (the biases of the later layers) sees it: with the
+// truncating parts nvp3's mu bias at (8, 2048, direct) moved from 4 x to 8 x the fp32 tensor ops' own error.  Rounded parts
+// leave remainders of either sign.
+__device__ __forceinline__ void split3_rne(float x, uint32_t &hi, uint32_t &mid, uint32_t &lo) {
+    hi = bf16_rne(x);
+    const float r1 = x - u2f(hi << 16);
+    mid = bf16_rne(r1);
+    lo = bf16_rne(r1 - u2f(mid << 16));
+}
+__device__ __forceinline__ u32x4 input_fragment_rne(float x, int h) {
+    uint32_t xh, xm, xl;
+    split3_rne(x, xh, xm, xl);
+    u32x4 b0;
+    b0.x = xh | (xm << 16);                 // e0 = xh, e1 = xm
+    b0.y = xh | (xl << 16);                 // e2 = xh, e3 = xl
+    b0.z = xm | (xh << 16);                 // e4 = xm, e5 = xh
+    b0.w = h ? 0x00003F80u : 0x3F803F80u;   // e6 = 1, e7 = (h == 0)
+    return b0;
+}
+__device__ __forceinline__ u32x4 input_weight_slots8_rne(float w, float T, int h) {
+    uint32_t wh, wm, wl, Th, Tm, Tl;
+    split3_rne(w, wh, wm, wl);
+    split3_rne(T, Th, Tm, Tl);
+    u32x4 v;
+    v.x = wh | (wh << 16);                      // j = 0, 1
+    v.y = wm | (wh << 16);                      // j = 2, 3
+    v.z = wm | (wl << 16);                      // j = 4, 5
+    v.w = h == 0 ? (Th | (Tm << 16)) : Tl;      // j = 6, 7
+    return v;
+}
 // B operand of an input-style MFMA whose point values are scaled by 16 (exact: every split part and the bias slots scale)
 __device__ __forceinline__ u32x4 input_fragment_x16(float x, int h) {
     u32x4 b0 = input_fragment(x * 16.0f, h);
@@ -1517,7 +1549,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
         const float av = filmb[b2 * FB_BR + 0 * 64 + ff], rstd1 = filmb[b2 * FB_BR + 2 * 64 + ff], ca = filmb[b2 * FB_BR + 3 * 64 + ff];
         const float m1 = s12s[b2 * 128 + ff], m2 = s12s[b2 * 128 + 64 + ff];
         const float kw = rstd1 * av * w2s[b2 * 128 + 64 * hh + ff];
-        *(u32x4 *)(smem + L_GFR + ((b2 * 2 + t) * 64 + ln) * 16) = input_weight_slots8(kw, rstd1 * (ca * m2 - m1), hh);
+        *(u32x4 *)(smem + L_GFR + ((b2 * 2 + t) * 64 + ln) * 16) = input_weight_slots8_rne(kw, rstd1 * (ca * m2 - m1), hh);
     }
     lds_barrier();
     KP(2, 1)
@@ -1583,7 +1615,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
         u32x4 xh[2][2], xl[2][2];
         float ginv = 1.0f;                                                 // F16: inverse of this tile's power-of-two scale
         {
-            const u32x4 bd = input_fragment(h ? dob : doa, h);
+            const u32x4 bd = input_fragment_rne(h ? dob : doa, h);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const f32x16 G = mfma(bd, *(const u32x4 *)(smem + L_GFR + ((br * 2 + t) * 64 + lane) * 16), zero16());
@@ -1829,7 +1861,9 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
 //   tot[br][P2_J] doubles.  BN0 backward:  dh0pre = rstd0*gamma0*(dh0a - A - h0n*Bc),  A = S/P,  Bc = Sg/P
 //   dW0[f][k] = sum_pt dh0pre * x_k = rstd0*gamma0*(Sk - A*sum x_k - Bc * sum h0n*x_k), and h0n is linear in x:
 //   sum_pt h0n_f x_k / P = rstd0_f (w_fa cov(a,k) + w_fb cov(b,k)) + (mean of h0n = 0) * E[x_k]
-//   dx_k[pt] = u_k[pt] - C_k - (alpha_k x_a + beta_k x_b - delta_k):  coef[k] = {C_k - delta_k, alpha_k, beta_k}
+//   dx_k[pt] = u_k[pt] - C_k - alpha_k (x_a - E x_a) - beta_k (x_b - E x_b):  coef[k] = {C_k, alpha_k, beta_k, E x_k}
+//   (r05: centred -- the r01-r04 form alpha_k x_a + beta_k x_b - delta_k cancelled delta_k = sum_f c_fk Bc_f rstd0_f mean0_f against
+//   the products per point, in fp32; h0n = rstd0 (w_a (x_a - E x_a) + w_b (x_b - E x_b)) has no such term)
 
 // Pass 3: the conditioner path of d(input points), elementwise
 // tfinish2 + tbwd3 in one launch (a tiny dependent kernel costs ~4.5 us here whatever it does): EVERY workgroup
@@ -1854,9 +1888,10 @@ __global__ __launch_bounds__(256) void tbwd3f_kernel(int N, int ka, int kb, int 
         ua = __fadd_rn(ua, ubuf2[((size_t)bi * 2 + 0) * N + n]);
         if (kb >= 0) ub = __fadd_rn(ub, ubuf2[((size_t)bi * 2 + 1) * N + n]);
     }
-    d[(size_t)ka * N + n] = __fadd_rn(d[(size_t)ka * N + n], cond_path(ua, coef[0], coef[1], coef[2], xa, xb));
+    const float xac = __fsub_rn(xa, coef[3]), xbc = __fsub_rn(xb, coef[7]);
+    d[(size_t)ka * N + n] = __fadd_rn(d[(size_t)ka * N + n], cond_path(ua, coef[0], coef[1], coef[2], xac, xbc));
     if (kb >= 0)
-        d[(size_t)kb * N + n] = __fadd_rn(d[(size_t)kb * N + n], cond_path(ub, coef[4], coef[5], coef[6], xa, xb));
+        d[(size_t)kb * N + n] = __fadd_rn(d[(size_t)kb * N + n], cond_path(ub, coef[4], coef[5], coef[6], xac, xbc));
 }
 
 
