@@ -19,10 +19,10 @@
 //                          backward in closed form: h0n is linear in x, so its sums over points follow from the x
 //                          moments -- and the conditioner path of its input gradient, u_k - affine(x), added to the
 //                          gradient this layer receives); recompute to h2; d(outputs) -> d(o) (4 floats/point,
-//                          stored), dW2, db2, per-cloud d FiLM(a, c): per-workgroup partials, finished per cloud by
-//                          the cloud's last workgroup (ticket)
-//            tbwd2         (prologue: BN1 backward means, dW2, db2 from those totals -- every workgroup
-//                          recomputes them rather than wait for a one-workgroup kernel); recompute; BN1
+//                          stored), dW2, db2, per-cloud d FiLM(a, c): per-workgroup partial rows
+//            tbwd2         (17 role workgroups at the front of the grid: rows -> per-cloud totals -> d FiLM, dW2, db2 and
+//                          the BN1-backward means, published behind a counter; the others wait for it behind their
+//                          weight staging); recompute; BN1
 //                          backward; dh0 = W1^T dh1 and dW1 = dh1 h0^T on the matrix cores; per point
 //                          u_k = sum_f c_fk dh0a[f] (2 floats, stored); per feature sums of
 //                          dh0a * {1, x_a - E x_a, x_b - E x_b}  (sum dh0a * h0n follows from them: h0n is linear in x)
@@ -206,8 +206,10 @@ __global__ __launch_bounds__(256) void tstats_x_kernel(int N, int ka, int kb, co
 #ifdef DPF_PROFILE
 __device__ unsigned long long *g_kprof = nullptr;            // [kernel id][8] s_memtime stamps of workgroup 0, wave 0
 #define KP(kid, i) { __builtin_amdgcn_sched_barrier(0); if (g_kprof != nullptr && blockIdx.x == 1 && blockIdx.y == 3 && threadIdx.x == 0) g_kprof[(kid) * 8 + (i)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#define KPR(i) { __builtin_amdgcn_sched_barrier(0); if (g_kprof != nullptr && id == 1 && threadIdx.x == 0) g_kprof[6 * 8 + (i)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
 #else
 #define KP(kid, i) {}
+#define KPR(i) {}
 #endif
 
 // a workgroup barrier that orders LDS traffic only (see stage_load below)
@@ -875,6 +877,8 @@ struct PrevLayer {
     double count;
     int ka, kb, has;
     int fused_launches;          // host side: pass-1 launches of this call that carried the layer above's column sums so far
+    // (this struct is a kernel argument of pass 1, which runs at its register cap: its size and layout are part of that kernel's
+    // code generation -- r05: one more int here, 8 bytes with padding, cost pass 1 0.8 us; host-only state goes to BackwardCall)
 };
 
 // r04: the column sums of the layer ABOVE's pass-2 partials (the former tcolsum launch between two backward layers) ride in
@@ -1220,9 +1224,15 @@ __global__ __launch_bounds__(TW * 64, BSPLIT ? 2 : 4) void tbwd1_kernel(TArgs a,
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < TW; ++w) t += red[w * 520 + i];
-        // written through (agent scope): the last workgroup of this cloud reads it below, possibly from another XCD
+        // written through (agent scope): with the ticket below, the last workgroup of this cloud reads it, possibly from another XCD
         __hip_atomic_store(&part1[blk * 520 + i], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    KP(1, 4)
+    // Who finishes pass 1 (the per-cloud totals of these rows, the FiLM gradients, and -- for pass 2 -- the BN1-backward means)?
+    // r05 measured both forms (same box, tools/train_ab_prof.sh).  tickets == nullptr: 17 role workgroups at the
+    // front of pass 2's launch do it once (MeansJob) and this kernel ends with its row -- 2.0 us shorter; pass 2 needs one CU per
+    // workgroup, so the role workgroups pay only where CUs are idle (small batches: <= 239 workgroups).  Otherwise, as r02-r04:
+    if (tickets == nullptr) return;
     // ---- per-cloud totals of pass 1 and the FiLM gradients of the cloud (formerly the tcloudsum launch), by whichever of the
     // cloud's workgroups arrives last: partial rows published with write-through stores, a ticket per cloud, rows read back
     // with agent-scope loads (per-XCD L2s are not coherent) and added in workgroup order -- the same sums in the same order
@@ -1234,7 +1244,6 @@ __global__ __launch_bounds__(TW * 64, BSPLIT ? 2 : 4) void tbwd1_kernel(TArgs a,
         *tk = __hip_atomic_fetch_add(&tickets[bi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const int nb = gridDim.x;
-    KP(1, 4)
     if (*tk != (unsigned)(nb * (int)gridDim.z - 1)) return;               // (branch split: two arrivals per row)
     for (int j = threadIdx.x; j < 516; j += TW * 64) {
         float s = 0.f;
@@ -1281,6 +1290,112 @@ __global__ __launch_bounds__(TW * 64, BSPLIT ? 2 : 4) void tbwd1_kernel(TArgs a,
 // centred input sums (bwd3_coefs) -- one input MFMA pair and an FMA per element gone; relu(h0) arrives scaled by 16 from an
 // input fragment scaled by 16 (exact) -- no multiply per element in front of its fp16 split; dW1 is unscaled by the reducer
 // (an FMA where it had an add) instead of 64 multiplies per wave and tile.
+// r05: what stands between pass 1 and pass 2 -- the per-cloud totals of pass 1's rows, the FiLM gradients, dW2 / db2 and the
+// BN1-backward means over the batch -- is done ONCE, by 17 role workgroups dispatched at the front of pass 2's grid (32 of
+// the row's 516 columns each), instead of r02-r04's per-cloud ticket at the end of pass 1 (write-through row, vmcnt(0), atomic
+// round trip, the last arriver reads the cloud's rows back: 2.6 us of every pass 1) plus a recomputation of the means by
+// every workgroup of pass 2.  The ordinary workgroups stage their 70 KB of weights first -- that needs nothing from pass 1 --
+// and then wait for the role workgroups' counter (they are ~3 us of loads and sums; the staging takes ~5); the 256 means
+// are read past the L1 / L2 (agent scope).  Same pattern, same ordering argument and the same bounded poll as the column
+// sums inside pass 1 (colsum_wait); a workgroup whose poll runs out sums the 256 columns it needs itself, in the role
+// workgroups' order (all workgroups of a launch must hold the same bits).
+struct MeansJob {
+    const float *part1;          // (B * nb, 520) rows of pass 1
+    const float *pc;             // (B, 520) the per-cloud totals, when pass 1 finished them itself (no role workgroups: rows == 0)
+    float *dfm_l;                // FiLM gradients of the layer [br][sub][B][64]
+    float *s12;                  // [br][2][64]: mean dh1n, mean dh1n * h1n -- published by the role workgroups
+    unsigned *flag;              // arrivals of the role workgroups, monotonic over the call
+    unsigned target;             // value of *flag once this launch's have arrived
+    int nb;                      // rows (workgroups of pass 1) per cloud
+    int rows;                    // rows of the grid taken by the role workgroups
+};
+constexpr int MJ_ROLES = (516 + 31) / 32;
+// total of column j of cloud b's rows, in row order, eight loads in flight
+__device__ __forceinline__ float cloud_col_total(const float *__restrict__ part1, int nb, int b, int j) {
+    float s = 0.f;
+    for (int k0 = 0; k0 < nb; k0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = k0 + i < nb ? part1[((size_t)b * nb + k0 + i) * 520 + j] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[i];
+    }
+    return s;
+}
+__device__ __forceinline__ void means_role(const TArgs &a, const MeansJob &mj, int id, double count, float *__restrict__ dcanon_l, uint8_t *smem) {
+    double (*acc)[33] = (double (*)[33])smem;
+    KPR(0)
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5, j = id * 32 + c;       // 512 threads: 32 columns x 16 cloud groups
+    const bool col = j < 512;
+    const int brj = col ? j >> 8 : (j - 512) >> 1, k = col ? (j >> 6) & 3 : 4, f = j & 63;
+    double s = 0;
+    if (j < 516)
+        for (int b0 = rg; b0 < a.B; b0 += 32) {       // two clouds per round: their rows' loads are all in flight together
+            const int b1 = b0 + 16;
+            const bool two = b1 < a.B;
+            const float av0 = k == 2 || k == 3 ? a.filmb_l[(size_t)b0 * FB_CLOUD + brj * FB_BR + f] : 1.0f;
+            const float av1 = two && (k == 2 || k == 3) ? a.filmb_l[(size_t)b1 * FB_CLOUD + brj * FB_BR + f] : 1.0f;
+            const float pc0 = cloud_col_total(mj.part1, mj.nb, b0, j);
+            const float pc1 = two ? cloud_col_total(mj.part1, mj.nb, b1, j) : 0.f;
+            if (k == 2 || k == 3) {       // da, dc of the cloud's FiLM vectors; their a-weighted batch sums are the BN1-backward means
+                mj.dfm_l[((size_t)(brj * 2 + (k == 2 ? 0 : 1)) * a.B + b0) * 64 + f] = k == 2 ? pc0 * (av0 - a.eps) : pc0;
+                if (two) mj.dfm_l[((size_t)(brj * 2 + (k == 2 ? 0 : 1)) * a.B + b1) * 64 + f] = k == 2 ? pc1 * (av1 - a.eps) : pc1;
+            }
+            s += (double)av0 * pc0;       // (dW2 / db2: plain batch totals, av = 1)
+            if (two) s += (double)av1 * pc1;
+        }
+    KPR(1)
+    acc[rg][c] = s;
+    __syncthreads();
+    KPR(2)
+    if (rg == 0 && j < 516) {
+        double t = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[r][c];
+        if (k == 3) __hip_atomic_store(&mj.s12[(brj * 2 + 0) * 64 + f], (float)(t / count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // dh1n = a * dh2a
+        else if (k == 2) __hip_atomic_store(&mj.s12[(brj * 2 + 1) * 64 + f], (float)(t / count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // dh1n * h1n
+        else if (k < 2) dcanon_l[brj * T_BR + T_W2 + k * 64 + f] = (float)t;
+        else { dcanon_l[brj * T_BR + T_B2 + (j & 1)] = (float)t; dcanon_l[brj * T_BR + T_B2 + 2 + (j & 1)] = 0.f; }
+    }
+    // (the threads that stored are the first 32: one wave -- its own vmcnt(0) covers them all, no barrier)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the means have left this CU before the counter moves
+    KPR(3)
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(mj.flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    KPR(4)
+}
+// ordinary workgroups: the 256 means into LDS (s12s), from the role workgroups or -- if they have not run -- by this workgroup
+__device__ unsigned g_means_fallbacks = 0;
+__device__ __forceinline__ void means_wait(const TArgs &a, const MeansJob &mj, double count, float *s12s, int *lds_word) {
+    if (threadIdx.x == 0) {
+        int ok = 0;
+        for (int it = 0; it < 256; ++it) {       // (relaxed polls, no fence: see colsum_wait)
+            if (__hip_atomic_load(mj.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= mj.target) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (!ok) __hip_atomic_fetch_add(&g_means_fallbacks, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *lds_word = ok;
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int i = threadIdx.x;
+        float v;
+        if (*lds_word) {
+            v = __hip_atomic_load(&mj.s12[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {      // the role workgroups' sums for this thread's column, in their order: 16 cloud groups, clouds ascending within a group
+            const int brj = i >> 7, k = (i >> 6) & 1 ? 2 : 3, f = i & 63, j = brj * 256 + k * 64 + f;
+            double t = 0;
+            for (int rg = 0; rg < 16; ++rg) {
+                double sg = 0;
+                for (int b = rg; b < a.B; b += 16)
+                    sg += (double)a.filmb_l[(size_t)b * FB_CLOUD + brj * FB_BR + f] * cloud_col_total(mj.part1, mj.nb, b, j);
+                t += sg;
+            }
+            v = (float)(t / count);
+        }
+        s12s[i] = v;
+    }
+}
+
 #ifdef DPF_PROFILE
 __device__ unsigned long long *g_tprof = nullptr;
 #define TP(i) { __builtin_amdgcn_sched_barrier(0); if (ti == 0) tt[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
@@ -1374,8 +1489,8 @@ __device__ __forceinline__ u32x4 input_fragment_x16(float x, int h) {
     b0.w = h ? 0x00004180u : 0x41804180u;   // e6 = 16, e7 = 16 (h == 0)
     return b0;
 }
-template <int NS, bool F16 = false, bool PAIR = true>
-__global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__restrict__ pcs, double count, float *__restrict__ dcanon_l,
+template <int NS, bool F16 = false, bool PAIR = true, bool ROLES = false>
+__global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, MeansJob mj, double count, float *__restrict__ dcanon_l,
                                                         const float *__restrict__ dout,
                                                         float *__restrict__ ubuf, float *__restrict__ part2) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1391,7 +1506,13 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
     float *uns = (float *)(smem + L_RED);                                  // per wave: what its dW1 accumulators are multiplied by at the end
     float *cf = (float *)(smem + L_RED) + 256;                             // c_fk [2 br][2][64]
     float *redw = (float *)(smem + L_RED + 4096);                          // per-wave slots (8 KB) of the workgroup reduction; their head is the wave's per-point scratch before that
-    const int bi = blockIdx.y, lane = threadIdx.x & 63, h = lane >> 5, pl = lane & 31;
+    // ROLES: grid rows [0, mj.rows) are the role workgroups (dispatched first); the rows behind them: the clouds
+    if (ROLES && (int)blockIdx.y < mj.rows) {
+        const int id = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+        if (blockIdx.z == 0 && id < MJ_ROLES) means_role(a, mj, id, count, dcanon_l, smem);
+        return;
+    }
+    const int bi = (int)blockIdx.y - (ROLES ? mj.rows : 0), lane = threadIdx.x & 63, h = lane >> 5, pl = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int br = PAIR ? wave >> 2 : (int)blockIdx.z;                     // this wave's branch (wave-uniform)
     int h4 = 4 * h;                   // opaque to the optimiser: feature offsets stay "lane base + immediate"
@@ -1404,17 +1525,18 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
     float f_wa[8], f_wb[8], f_bb[8];      // workgroup (0, 0) only: the dW2 / db2 totals it writes (r03: these were 8 dependent round trips
                                           // of loads inside the means' loop -- the one workgroup every launch waited for)
     const bool first_wg = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+    const float *pcs = mj.pc;             // !ROLES: the per-cloud totals pass 1 finished by ticket
     // branch-free: a cloud index past the batch is clamped and the value dropped where it is used (predicated loads became
     // exec-masked branches whose joins waited for everything in flight)
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {
         const int b = mg4 + 4 * jj, bc = b < a.B ? b : 0;
         const float *qq = pcs + (size_t)bc * 520 + mbr * 256;
-        m_av[jj] = a.filmb_l[(size_t)bc * FB_CLOUD + mbr * FB_BR + mf];
-        m_q3[jj] = qq[3 * 64 + mf];
-        m_q2[jj] = qq[2 * 64 + mf];
+        m_av[jj] = ROLES ? 0.f : a.filmb_l[(size_t)bc * FB_CLOUD + mbr * FB_BR + mf];
+        m_q3[jj] = ROLES ? 0.f : qq[3 * 64 + mf];
+        m_q2[jj] = ROLES ? 0.f : qq[2 * 64 + mf];
     }
-    if (first_wg) {                       // (wave-uniform)
+    if (!ROLES && first_wg) {             // (wave-uniform)
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             const int b = mg4 + 4 * jj, bc = b < a.B ? b : 0;
@@ -1461,18 +1583,21 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
     const StageRegs<pt_bytes(NS) - pt_a1t(NS)> wregs_t = stage_load<pt_bytes(NS) - pt_a1t(NS)>(a.packed_l + pt_a1t(NS), wave, lane);
     const StageRegs<2048> fregs = stage_load<2048>((const uint8_t *)(a.film_l + (size_t)bi * 512), wave, lane);
     const StageRegs<2048> fbregs = stage_load<2048>((const uint8_t *)(a.filmb_l + (size_t)bi * FB_CLOUD), wave, lane);
+    if constexpr (!ROLES) {
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj)        // pin the consumers of the small loads BEHIND the issue of the weight loads (else the sums are scheduled
-        asm volatile("" : "+v"(m_av[jj]), "+v"(m_q3[jj]), "+v"(m_q2[jj]), "+v"(f_wa[jj]), "+v"(f_wb[jj]), "+v"(f_bb[jj]));   // right behind each load: 8 serial round trips)
+        for (int jj = 0; jj < 8; ++jj)    // pin the consumers of the small loads BEHIND the issue of the weight loads (else the sums are scheduled
+            asm volatile("" : "+v"(m_av[jj]), "+v"(m_q3[jj]), "+v"(m_q2[jj]), "+v"(f_wa[jj]), "+v"(f_wb[jj]), "+v"(f_bb[jj]));   // right behind each load: 8 serial round trips)
+    }
     KP(3, 1)
     const float *film = (const float *)(smem + L_FILM);
     const float *filmb = (const float *)(smem + L_FILMB);
-    const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const size_t blk = (size_t)bi * gridDim.x + blockIdx.x;
     float *s12s = cf + 256;                                                // [2 br][2][64] BN1 backward means
     float *w2s = s12s + 256;                                               // [2 br][2][64] raw sd2.weight
     if (threadIdx.x < 256) cf[threadIdx.x] = cf_w * cf_r * cf_g;
     else w2s[threadIdx.x - 256] = w2_v;
     KP(3, 2)
+    if constexpr (!ROLES)
     {   // BN1-backward means s12[br][2][64] = (sum dh1n, sum dh1n*h1n) / P over the per-cloud totals of pass 1 -- what
         // the one-workgroup tfinish1 kernel did, recomputed by every workgroup (same sums in the same order, under the
         // weight loads; a dependent tiny launch costs ~4.5 us); workgroup 0 also writes dW2 / db2.  Scratch: redw.
@@ -1540,6 +1665,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, const float *__
     stage_store(wregs_t, smem + L_PACK + pt_a1t(NS), wave, lane);
     stage_store(fregs, smem + L_FILM, wave, lane);
     stage_store(fbregs, smem + L_FILMB, wave, lane);
+    if constexpr (ROLES) means_wait(a, mj, count, s12s, (int *)uns + 16);  // the BN1-backward means: from the role workgroups at the front of this launch
     __syncthreads();                                                       // weights, FiLM blocks, means, tables: all in LDS
     // BN1 backward per element:  dh1 = rstd1 (a dh2a - m1 - h1n m2) = C1 pa + ([pa > 0] ? G : C0),  C1 = -rstd1^2 m2,
     //   G[f][pt] = K1[f] do_a[pt] + K2[f] do_b[pt] + C0[f],  K_w = rstd1 a W2[w],  C0 = rstd1 (c/a m2 - m1)
@@ -1918,7 +2044,7 @@ static inline int t_nblk(int B, int N) { return B * ((N + TBLK - 1) / TBLK); }
 struct TWork {
     double *xpart, *sums, *tot2;
     float *part1, *pc, *s12, *part2, *dout, *ubuf, *coef;
-    unsigned *tickets;           // per cloud: arrivals of pass-1 workgroups (zero between layers)
+    unsigned *tickets;           // the arrival counters of the role workgroups: word B = column sums in pass 1, word B + 1 = means in pass 2 (words [0, B): unused since r05)
 };
 static size_t carve(void *ws, int B, int N, TWork *w) {
     const size_t nblk = (size_t)t_nblk(B, N), nbx = (size_t)B * ((N + TILE - 1) / TILE);   // the flow kernel's smallest workgroup is one tile
@@ -2119,7 +2245,7 @@ template <int NS, bool F16 = false>
 static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb, const float *tcanon_l, const void *packed_l,
                           const float *film_l, const float *stats_l, const float *p_in, const float *mu_l, const float *lv_l,
                           const float *g_p, const float *g_p2, const float *g_mu, const float *g_lv, float *dp_in, float *dcanon_l,
-                          float *dfm_l, float flow_eps, void *workspace, hipStream_t s, PrevLayer *pv, bool last) {
+                          float *dfm_l, float flow_eps, void *workspace, hipStream_t s, PrevLayer *pv, int *pass2_launches, bool last) {
     TWork w;
     carve(workspace, B, N, &w);
     TArgs a;
@@ -2130,12 +2256,10 @@ static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb
     const int nblk = grid.x * grid.y;
     const double count = (double)B * N;
     const int lds1 = pt_a0n(NS) + 4096 + (TW * 520 + 256 + TW * 64 + 8 + 24) * 4, lds2 = l_red(NS) + 4096 + TW * XY_WAVE * 2;
-    static LdsLimit lim_b1, lim_b2;
+    static LdsLimit lim_b1;
     if (hipError_t e = lim_b1.ensure((const void *)tbwd1_kernel<NS, F16>, lds1); e != hipSuccess) return (int)e;
     static LdsLimit lim_b1s;
     if (hipError_t e = lim_b1s.ensure((const void *)tbwd1_kernel<NS, F16, true>, lds1); e != hipSuccess) return (int)e;
-    if constexpr (NS == 2)
-        if (hipError_t e = lim_b2.ensure((const void *)tbwd2_kernel<NS, F16, true>, lds2); e != hipSuccess) return (int)e;
     // r04: the column sums of the layer above's pass-2 partials ride in this launch (ColsumJob) instead of a tcolsum launch
     // of their own between the two layers; DPF_TRAIN_FUSE_COLSUM=0 keeps the separate launch
     static const int fuse_env = getenv("DPF_TRAIN_FUSE_COLSUM") ? atoi(getenv("DPF_TRAIN_FUSE_COLSUM")) : 1;
@@ -2153,21 +2277,40 @@ static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb
     const bool split2 = NS == 3 || (split_env >= 0 ? split_env != 0 : nblk <= 128);
     const bool split1 = split_env >= 0 ? split_env != 0 : nblk <= 64;      // (B = 16: tbwd1 15.7 us unsplit, 18.1 split)
     grid1.z = split1 ? 2 : 1;
+    // Who finishes pass 1 -- per-cloud totals, FiLM gradients, dW2 / db2, the BN1-backward means?  Pass 2 needs a CU per workgroup
+    // (158 KB of LDS): role workgroups at the front of its grid (MeansJob) cost nothing where CUs are idle and a whole round of
+    // late workgroups where they are not.  So: roles while the ordinary workgroups + MJ_ROLES fit the chip's CUs, else pass 1's
+    // per-cloud ticket and a recomputation of the means by every workgroup of pass 2 (r02-r04).  DPF_TRAIN_ROLES=0/1 forces either.
+    static const int roles_env = getenv("DPF_TRAIN_ROLES") ? atoi(getenv("DPF_TRAIN_ROLES")) : -1;
+    static const int n_cu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    const int wg2 = nblk * (split2 ? 2 : 1);
+    // (the role form is built for the one-branch-per-workgroup kernel only: that is the form small batches run)
+    const bool roles = split2 && (roles_env >= 0 ? roles_env != 0 : wg2 + MJ_ROLES <= n_cu);
     { KScope ks(4, s);
+    unsigned *tk = roles ? nullptr : w.tickets;
     if (split1)
-        hipLaunchKernelGGL((tbwd1_kernel<NS, F16, true>), grid1, dim3(TW * 64), lds1, s, a, g_p, g_p2, g_mu, g_lv, mu_l, lv_l, dp_in, w.dout, w.part1, *pv,
-                           w.tickets, w.pc, dfm_l, cs);
+        hipLaunchKernelGGL((tbwd1_kernel<NS, F16, true>), grid1, dim3(TW * 64), lds1, s, a, g_p, g_p2, g_mu, g_lv, mu_l, lv_l, dp_in, w.dout, w.part1, *pv, tk, w.pc, dfm_l, cs);
     else
-        hipLaunchKernelGGL((tbwd1_kernel<NS, F16>), grid1, dim3(TW * 64), lds1, s, a, g_p, g_p2, g_mu, g_lv, mu_l, lv_l, dp_in, w.dout, w.part1, *pv,
-                           w.tickets, w.pc, dfm_l, cs); }
-    static LdsLimit lim_b2s;
-    if (split2)
-        if (hipError_t e = lim_b2s.ensure((const void *)tbwd2_kernel<NS, F16, false>, lds2); e != hipSuccess) return (int)e;
-    { KScope ks(5, s);
-    if (split2)      // one branch per workgroup, a tile per wave
-        hipLaunchKernelGGL((tbwd2_kernel<NS, F16, false>), dim3(grid.x, grid.y, 2), dim3(TW * 64), lds2, s, a, w.pc, count, dcanon_l, w.dout, w.ubuf, w.part2);
-    else if constexpr (NS == 2)      // one branch per wave, two tiles per wave
-        hipLaunchKernelGGL((tbwd2_kernel<NS, F16, true>), grid, dim3(TW * 64), lds2, s, a, w.pc, count, dcanon_l, w.dout, w.ubuf, w.part2); }
+        hipLaunchKernelGGL((tbwd1_kernel<NS, F16>), grid1, dim3(TW * 64), lds1, s, a, g_p, g_p2, g_mu, g_lv, mu_l, lv_l, dp_in, w.dout, w.part1, *pv, tk, w.pc, dfm_l, cs); }
+    MeansJob mj;
+    mj.part1 = w.part1; mj.pc = w.pc; mj.dfm_l = dfm_l; mj.s12 = w.s12; mj.flag = w.tickets + B + 1; mj.nb = (int)grid.x;
+    mj.target = 0; mj.rows = 0;
+    if (roles) {
+        mj.target = (unsigned)MJ_ROLES * (unsigned)(++*pass2_launches);
+        mj.rows = (MJ_ROLES + (int)grid.x - 1) / (int)grid.x;
+    }
+    const dim3 grid2(grid.x, mj.rows + grid.y, split2 ? 2 : 1);
+    // split2: one branch per workgroup, a tile per wave; else (two-part precisions): one branch per wave, two tiles per wave
+#define DPF_P2(PAIRV, ROLESV, LDSV)                                                                                                  \
+    {                                                                                                                               \
+        static LdsLimit lim;                                                                                                        \
+        if (hipError_t e = lim.ensure((const void *)tbwd2_kernel<NS, F16, PAIRV, ROLESV>, LDSV); e != hipSuccess) return (int)e;    \
+        KScope ks(5, s);                                                                                                            \
+        hipLaunchKernelGGL((tbwd2_kernel<NS, F16, PAIRV, ROLESV>), grid2, dim3(TW * 64), LDSV, s, a, mj, count, dcanon_l, w.dout, w.ubuf, w.part2); \
+    }
+    if (split2) { if (roles) DPF_P2(false, true, lds2) else DPF_P2(false, false, lds2) }
+    else if constexpr (NS == 2) DPF_P2(true, false, lds2)
+#undef DPF_P2
     const float *ubuf2 = w.ubuf + (size_t)B * 2 * N;                      // u_k comes in two planes (one per branch) either way
     if (!fuse_env || last) {              // (fused: the next backward layer's pass 1 sums these partials; the last layer has none)
         KScope ks(6, s);
@@ -2201,6 +2344,7 @@ static int backward_stack(int n_layers, int B, int N, int mode, int precision, c
     if (!ns || B > 65535) return DPF_ENOSUP;
     const size_t lst = (size_t)B * 3 * N, fls = dpf_flow_train_film_floats(B), fms = (size_t)4 * B * DPF_FLOW_F;
     const float *chain = nullptr;
+    int pass2_launches = 0;          // pass-2 launches of this call that carried role workgroups so far (their counter is monotonic over the call)
     PrevLayer pv = {};
     {   // no layer above the first one (has = 0), but pointers its pass 1 can load from unconditionally
         TWork w0;
@@ -2209,7 +2353,7 @@ static int backward_stack(int n_layers, int B, int N, int mode, int precision, c
         pv.tot = w0.tot2; pv.tcanon_l = tcanon + (size_t)l0 * T_LAYER; pv.stats_l = stats + (size_t)l0 * ST_LAYER;
         pv.ka = 0; pv.kb = -1;
     }
-    {   // pass 1's per-cloud arrival tickets start at zero (every layer leaves them there).  A fill KERNEL: as a captured
+    {   // the role workgroups' arrival counters start at zero (they are monotonic over the call).  A fill KERNEL: as a captured
         // memset node the clear was not reliably ordered before the first pass-1 kernel of a replay (zero_fill.h)
         TWork w;
         carve(workspace, B, N, &w);
@@ -2225,7 +2369,7 @@ static int backward_stack(int n_layers, int B, int N, int mode, int precision, c
     backward_layer<NSV, ##__VA_ARGS__>(B, N, mode, m[0], m[1], m[2], m[3], tcanon + (size_t)l * T_LAYER,                \
                         (const uint8_t *)packed + (size_t)l * pt_bytes(NSV), film + l * fls, stats + (size_t)l * ST_LAYER, pin, \
                         mus + l * lst, logvars + l * lst, grad_of(0, l), chain, grad_of(1, l), grad_of(2, l), out,       \
-                        dcanon + (size_t)l * T_LAYER, dfm + l * fms, flow_eps, workspace, (hipStream_t)stream, &pv, step == 0)
+                        dcanon + (size_t)l * T_LAYER, dfm + l * fms, flow_eps, workspace, (hipStream_t)stream, &pv, &pass2_launches, step == 0)
         const int rc = precision == DPF_PREC_F16X3 ? DPF_BWD(2, true) : (ns == 2 ? DPF_BWD(2) : DPF_BWD(3));
 #undef DPF_BWD
         if (rc) return rc;
@@ -2329,11 +2473,13 @@ extern "C" int dpf_flow_train_update_running(int n_layers, double momentum, cons
     return (int)hipGetLastError();
 }
 
-// workgroups of pass 1 that gave up waiting for the fused column sums and summed the critical columns themselves (process-wide)
+// workgroups that gave up waiting for role workgroups of their own launch (pass 1: the column sums of the layer above; pass 2: the
+// BN1-backward means) and did the sums themselves -- process-wide; 0 as long as the role workgroups are dispatched first
 extern "C" long dpf_train_colsum_fallbacks(void) {
-    unsigned v = 0;
+    unsigned v = 0, m = 0;
     if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_colsum_fallbacks), sizeof(v)) != hipSuccess) return -1;
-    return (long)v;
+    if (hipMemcpyFromSymbol(&m, HIP_SYMBOL(g_means_fallbacks), sizeof(m)) != hipSuccess) return -1;
+    return (long)v + (long)m;
 }
 
 extern "C" long dpf_train_graph_replays(void) { return dpf_graph_stats().replays.load(); }

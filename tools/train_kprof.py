@@ -33,10 +33,10 @@ t = np.median(np.stack(rows), axis=0)
 names = {0: ("tstats_h1", ["entry", "prologue issued (bn0_fold, loads)", "first barrier passed", "both branches done", "exit"]),
          5: ("tstats_h1 prologue (stamps 0, 5, 6, 7, 1 of kernel 0)", None),
          1: ("tbwd1", ["entry", "prologue issued (coefs of pass 3, loads)", "first barrier passed", "main part done", "row published, ticket taken"]),
-         2: ("tbwd2", ["entry", "prologue done (BN1-backward means)", "exit"]),
-         3: ("tbwd2 prologue", ["address setup done", "DMA pieces issued", "cf table / point loads / w2s issued", "means: loads back, sums done",
-                                "partials in LDS", "barrier passed"]),
-         4: ("tbwd2, branch 0, dh0 phase", ["dh1 transposed back (8 identity MFMAs)", "symmetric split (bg)", "W1^T chain (24 MFMAs)", "relu mask + u_k"])}
+         2: ("tbwd2 (r05)", ["entry", "prologue done (staging, first recompute, means from the role workgroups, dh1 fragments)", "both tiles done", "exit (reduction)"]),
+         6: ("tbwd2 role workgroup 1 (r05; same clock as the ordinary workgroup above: compare ABSOLUTE stamps below)", ["entry", "rows loaded and summed", "barrier", "means stored, left the CU", "counter raised"]),
+         3: ("tbwd2 prologue (r05)", ["address setup done", "weight loads issued", "tables in LDS", "staged, barrier passed", "first tile recomputed", "means arrived"])}
+print("absolute stamps: tbwd2 ordinary", [int(v - t[2, 0]) for v in t[3, :6]], "exit", int(t[2, 3] - t[2, 0]), " role", [int(v - t[2, 0]) for v in t[6, :5]])
 for kid, (name, labels) in names.items():
     print(name)
     if labels is None:
