@@ -1665,7 +1665,30 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, MeansJob mj, do
     stage_store(wregs_t, smem + L_PACK + pt_a1t(NS), wave, lane);
     stage_store(fregs, smem + L_FILM, wave, lane);
     stage_store(fbregs, smem + L_FILMB, wave, lane);
-    if constexpr (ROLES) means_wait(a, mj, count, s12s, (int *)uns + 16);  // the BN1-backward means: from the role workgroups at the front of this launch
+    static_assert(!ROLES || !PAIR, "the role form serves the one-tile-per-wave kernel");
+    // ---- forward of a tile: h0 (lane = point) -> fragments; pre = h1 + D in the SWAPPED orientation (lane = feature 32 t + pl,
+    // register r = point (r & 3) + 8 (r >> 2) + 4 h): per-feature constants become per-lane, sums over the points in-lane
+    auto recompute = [&](u32x4 b0, f32x16 (&pre)[2]) {
+        f32x16 h0a[2];
+        u32x4 bf[NS][4];
+        input_mfma(smem + L_PACK + pt_a0(NS), br, lane, b0, h0a);          // gamma*h0n + beta
+        split_fragment<true, NS, false, F16>(h0a, bf, a.negone);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float dsh = film[br * FILM_BR_FLOATS + 32 * t + pl];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pre[t][r] = dsh;
+        }
+        chain_mfma_swapped<NS, F16>(smem + L_PACK + PT_A1, br, lane, bf, pre);   // same products in the same order as the forward kernel
+    };
+    f32x16 pre[2];
+    if constexpr (ROLES) {
+        // the wave's one tile is recomputed HERE: it needs nothing from pass 1, and the role workgroups at the front of this
+        // launch need ~1 us longer for the BN1-backward means than the staging above takes (same box: pass 2 16.3 -> 14.3 us at B = 8)
+        __syncthreads();                                                   // weights, FiLM blocks, tables: in LDS
+        recompute(input_fragment(h ? xb_t[0] : xa_t[0], h), pre);
+        means_wait(a, mj, count, s12s, (int *)uns + 16);
+    }
     __syncthreads();                                                       // weights, FiLM blocks, means, tables: all in LDS
     // BN1 backward per element:  dh1 = rstd1 (a dh2a - m1 - h1n m2) = C1 pa + ([pa > 0] ? G : C0),  C1 = -rstd1^2 m2,
     //   G[f][pt] = K1[f] do_a[pt] + K2[f] do_b[pt] + C0[f],  K_w = rstd1 a W2[w],  C0 = rstd1 (c/a m2 - m1)
@@ -1720,22 +1743,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, MeansJob mj, do
         TP(1)
         // the centred inputs every lane needs in the swapped orientation (registers = points)
         if (!h) { pts[pl] = xa - ea; pts[32 + pl] = xb - eb; }
-        // ---- forward: h0 (lane = point) -> fragments; pre = h1 + D in the SWAPPED orientation (lane = feature 32 t + pl,
-        // register r = point (r & 3) + 8 (r >> 2) + 4 h): per-feature constants become per-lane, sums over the points in-lane
-        f32x16 pre[2];
-        {
-            f32x16 h0a[2];
-            u32x4 bf[NS][4];
-            input_mfma(smem + L_PACK + pt_a0(NS), br, lane, b0, h0a);      // gamma*h0n + beta
-            split_fragment<true, NS, false, F16>(h0a, bf, a.negone);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const float dsh = film[br * FILM_BR_FLOATS + 32 * t + pl];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) pre[t][r] = dsh;
-            }
-            chain_mfma_swapped<NS, F16>(smem + L_PACK + PT_A1, br, lane, bf, pre);   // same products in the same order as the forward kernel
-        }
+        if constexpr (!ROLES) recompute(b0, pre);
         TP(2)
         // ---- dh1 (in place), then as K = points fragments [feature tile][k-step]
         u32x4 xh[2][2], xl[2][2];
