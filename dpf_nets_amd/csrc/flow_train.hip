@@ -1398,7 +1398,7 @@ __device__ __forceinline__ void means_wait(const TArgs &a, const MeansJob &mj, d
 
 #ifdef DPF_PROFILE
 __device__ unsigned long long *g_tprof = nullptr;
-#define TP(i) { __builtin_amdgcn_sched_barrier(0); if (ti == 0) tt[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#define TP(i) { __builtin_amdgcn_sched_barrier(0); if (ti == 0) tt[i] = __builtin_amdgcn_s_memtime(); else if ((i) == 0 || (i) == 6) tt[(i) == 0 ? 7 : 8] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
 #else
 // (the phase boundaries fence the instruction scheduler in every build: left free it starts a phase's loads and conversions
 // inside the previous one, and the kernel -- at the 256 registers two waves per SIMD may have -- spills)
@@ -1729,11 +1729,6 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, MeansJob mj, do
 #pragma unroll 1
     for (int ti = 0; ti < NT; ++ti) {
         TP(0)
-        if constexpr (PAIR) {
-            // the older wave of a SIMD wins the issue arbitration (r04 stamps: 10 K against 13 K ticks per tile): the first tile
-            // is the older four's, the second the younger four's -- both halves of the workgroup reach the reduction together
-            if (ti) { if (wave >> 2) __builtin_amdgcn_s_setprio(1); }
-        }
         const int tile = PAIR ? (wave & 3) + 4 * ti : wave;
         const int tile0 = (blockIdx.x * TW + tile) * TILE;
         // (selects, not xa_t[ti]: a run-time index puts the array in scratch memory)
@@ -1803,6 +1798,11 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, MeansJob mj, do
                 kfrags_from_swapped<false>(pre, xh, xl);
             }
         }
+        // The older wave of a SIMD wins the issue arbitration (r05 stamps: 9.8 K against 15.8 K ticks for the first tile): the
+        // younger four get priority from the middle of their first tile on -- measured against the flip at the tile boundary
+        // (+0.5 us) and earlier ones (+0.3 .. 0.5), tools/train_ab_prof.sh -- so that both halves of the workgroup reach the
+        // reduction together
+        if constexpr (PAIR) { if (ti == 0 && (wave >> 2)) __builtin_amdgcn_s_setprio(1); }
         TP(3)
         // ---- dh1 back to lane = point (an MFMA against the identity: hi + lo is exact) as the A fragments of dh0 = W1^T dh1
         u32x4 bg[2][4];
@@ -1931,7 +1931,12 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, MeansJob mj, do
         for (int k = 0; k < 3; ++k) rs[t][k] = half_sum(rs[t][k]);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-        __syncthreads();                                                   // every wave is through with its scratch / the previous round has been read
+        // (lds_barrier, not __syncthreads: that one waits for every outstanding vector-memory operation, i.e. for the PREVIOUS round's
+        // 16 global stores per thread -- r05 stamps: 6 K ticks from the last tile to the exit, most of them two store round trips)
+        lds_barrier();                                                       // every wave is through with its scratch / the previous round has been read
+#ifdef DPF_PROFILE
+        if (mt == 0) { __builtin_amdgcn_sched_barrier(0); tt[9] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#endif
         f32x4 *slot = (f32x4 *)(redw + wave * 2048) + lane;                // quad (g, lane) at [g * 64 + lane]
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -1940,7 +1945,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, MeansJob mj, do
                 const f32x4 v = {dw[mt][nt][4 * g + 0], dw[mt][nt][4 * g + 1], dw[mt][nt][4 * g + 2], dw[mt][nt][4 * g + 3]};
                 slot[(4 * nt + g) * 64] = v;
             }
-        __syncthreads();
+        lds_barrier();    
         const int e = threadIdx.x;                                         // quad index: (nt, g, lane)
         const int ln = e & 63, g = (e >> 6) & 3, nt = e >> 8;
         const int fo = 32 * mt + 8 * g + 4 * (ln >> 5), fi = 32 * nt + (ln & 31);
@@ -1966,14 +1971,17 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, MeansJob mj, do
             o[(fo + 3) * 64 + fi] = t.w;
         }
     }
-    __syncthreads();
+    lds_barrier();
+#ifdef DPF_PROFILE
+    { __builtin_amdgcn_sched_barrier(0); tt[10] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#endif
     if (!h) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int k = 0; k < 3; ++k) redw[wave * 256 + k * 64 + 32 * t + pl] = rs[t][k];
     }
-    __syncthreads();
+    lds_barrier();    
     if (threadIdx.x < NB * 192) {
         const int b = threadIdx.x / 192, i = threadIdx.x - 192 * b, w0 = PAIR ? 4 * b : 0;
         float t = 0.f;

@@ -35,7 +35,7 @@ names = {0: ("tstats_h1", ["entry", "prologue issued (bn0_fold, loads)", "first 
          1: ("tbwd1", ["entry", "prologue issued (coefs of pass 3, loads)", "first barrier passed", "main part done", "row published, ticket taken"]),
          2: ("tbwd2 (r05)", ["entry", "prologue done (staging, first recompute, means from the role workgroups, dh1 fragments)", "both tiles done", "exit (reduction)"]),
          6: ("tbwd2 role workgroup 1 (r05; same clock as the ordinary workgroup above: compare ABSOLUTE stamps below)", ["entry", "rows loaded and summed", "barrier", "means stored, left the CU", "counter raised"]),
-         3: ("tbwd2 prologue (r05)", ["address setup done", "weight loads issued", "tables in LDS", "staged, barrier passed", "first tile recomputed", "means arrived"])}
+         3: ("tbwd2 prologue (r05, large-batch form)", ["address setup done", "weight loads issued", "tables in LDS", "means: loads back, sums done", "partials in LDS", "barrier passed"])}
 print("absolute stamps: tbwd2 ordinary", [int(v - t[2, 0]) for v in t[3, :6]], "exit", int(t[2, 3] - t[2, 0]), " role", [int(v - t[2, 0]) for v in t[6, :5]])
 for kid, (name, labels) in names.items():
     print(name)

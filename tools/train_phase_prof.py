@@ -29,6 +29,10 @@ for prec in ("f16x3",):
     print(prec, "kernel entry -> after the prologue:", np.median(t[:, 11] - t[:, 12]), " prologue end -> loop:", np.median(t[:, 0] - t[:, 11]),
           " first tile:", np.median(t[:, 6] - t[:, 0]), " first tile done -> exit (second tile + reduction):", np.median(t[:, 13] - t[:, 6]),
           " whole kernel (this wave):", np.median(t[:, 13] - t[:, 12]))
+    print("   second tile (stamps 7, 8):", "median %.0f" % np.median(t[:, 8] - t[:, 7]), " per wave of workgroup 0:", " ".join("%5d" % v for v in (t[:8, 8] - t[:8, 7])),
+          "\n   second tile done -> exit (reduction, incl. the wait for the slowest wave):", " ".join("%5d" % v for v in (t[:8, 13] - t[:8, 8])),
+          "\n      of which: arrival at the reduction's first barrier", " ".join("%5d" % v for v in (t[:8, 9] - t[:8, 8])), "| two dW1 rounds", " ".join("%5d" % v for v in (t[:8, 10] - t[:8, 9])), "| sums round + exit", " ".join("%5d" % v for v in (t[:8, 13] - t[:8, 10])),
+          "\n   entry -> exit per wave:", " ".join("%5d" % v for v in (t[:8, 13] - t[:8, 12])))
     for i in range(6):
         print("   %-16s median %8.0f  min %8.0f  max %8.0f   per wave of workgroup 0: %s" % (names[i + 1], np.median(d[:, i]), d[:, i].min(), d[:, i].max(), " ".join("%5d" % v for v in d[:8, i])))
     print("   arrival at the phase boundaries relative to the workgroup's first wave (workgroup 0):")
