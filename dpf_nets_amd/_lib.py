@@ -64,6 +64,7 @@ SIGNATURES = {
     "dpf_encoder_pack": (_i, [_i, _vp, _vp, _vp]),
     "dpf_encoder_forward": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dpf_train_graph_replays": (_l, []),
+    "dpf_train_colsum_fallbacks": (_l, []),
     "dpf_train_graph_stats": (None, [_vp]),
     "dpf_train_graph_set_enabled": (_i, [_i]),
     "dpf_train_kernel_times": (_i, [_i, _vp, _vp]),

@@ -391,6 +391,10 @@ int dpf_encoder_train_backward(int B, int N, const float *canon, const float *x,
  * {replays, eager calls, recordings, evictions, keys that could not be captured} -- evictions growing while replays stand
  * still means the loop presents more than 8 live pointer sets per entry point, or its allocator does not settle. */
 long dpf_train_graph_replays(void);
+/* Workgroups of the training backward pass that gave up waiting for role workgroups of their own launch (pass 1: the column sums
+ * of the layer above; pass 2, small batches: the per-cloud totals and BatchNorm-backward means of pass 1) and did the sums
+ * themselves -- process-wide.  0 as long as the role workgroups, placed first in the grid, are dispatched first. */
+long dpf_train_colsum_fallbacks(void);
 void dpf_train_graph_stats(long *out);
 int dpf_train_graph_set_enabled(int on);
 /* Diagnostics: per-kernel time of the training stack's launches.  (1, NULL, NULL) starts collecting -- every launch of the

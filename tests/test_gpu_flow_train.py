@@ -49,6 +49,7 @@ KINK = 4.0
 # CONTRACTIONS is what test_training_stack_error_budget_vs_float64 holds to 3 x the fp32 path's own error; this test holds
 # every shape (ragged tiles, > 32 clouds, tiny batches) to what a flipped ReLU allows.
 KINK_SUM = 32.0
+KINK_CAP, KINK_SUM_CAP = 2e-3, 5e-3
 
 
 def _gpu():
@@ -186,8 +187,11 @@ def test_training_hip_vs_tensor_op_path(B, N, mode, prec):
         pytest.skip("2 112 points: the cancelling bias sums (|sum| ~ 1e-3 of the magnitudes) sit below bf16x3's 1e-5 per-term error")
     kf, loose = (5e-4, 1.0) if prec in ("bf16x6", "f16x3") else (1e-2, 10.0)
     STACK_OUT_REL, STACK_GRAD_REL = STACK_TOL[prec]
-    STACK_GRAD_REL = max(STACK_GRAD_REL, KINK / (B * N))
-    PARAM_REL = max(2 * loose * STACK_TOL[prec][1], KINK_SUM / (B * N))
+    # (r05, ADVICE r04: the floors are capped -- at (2, 40) they had grown to 5e-2 / 0.4 and checked nothing; what the tiny and
+    # ragged shapes' kernel forms compute is pinned much tighter by test_training_kernel_forms_agree below, where every form
+    # sees the same ReLU masks)
+    STACK_GRAD_REL = max(STACK_GRAD_REL, min(KINK / (B * N), KINK_CAP))
+    PARAM_REL = max(2 * loose * STACK_TOL[prec][1], min(KINK_SUM / (B * N), KINK_SUM_CAP))
     n_flows, G, seed = 2, 128, 31
     sd = FO.to_torch(FO.make_decoder_state(seed, n_flows, 64, G))
     tgt, z, g = FO.synthetic_inputs(seed, B, N, G)
@@ -256,6 +260,77 @@ def test_training_path_uses_hip_and_repeats(monkeypatch):
         outs.append((ps[0].detach().clone(), tp.grad.clone(), dec.flows[0].nvp1.T_mu_0[3].weight.grad.clone()))
     for a, b in zip(*outs):
         assert torch.equal(a, b)       # per-wave slots, per-workgroup partials, fixed-order column sums: no atomics
+
+
+FORMS_SHAPES = [(2, 40, "inverse"), (33, 64, "direct"), (3, 1000, "inverse"), (8, 2048, "direct"), (20, 2048, "inverse")]
+FORMS_CODE = """
+import sys, json, numpy as np, torch
+sys.path.insert(0, %r)
+from dpf_nets_amd import networks as nets
+from oracle import flow_oracle as FO
+out = {}
+for B, N, mode in %r:
+    sd = FO.to_torch(FO.make_decoder_state(31, 2, 64, 128))
+    tgt, z, g = FO.synthetic_inputs(31, B, N, 128)
+    dec = nets.LocalCondRNVPDecoder(2, 64, 128, weight_std=0.01)
+    dec.load_state_dict(sd, strict=True)
+    dec = dec.cuda().train()
+    tp = torch.from_numpy((tgt if mode == "inverse" else z).copy()).cuda().requires_grad_(True)
+    tg = torch.from_numpy(g.copy()).cuda().requires_grad_(True)
+    ps, mus, lvs = dec(tp, tg, mode=mode)
+    pm, pl = torch.zeros(B, 3, N).cuda(), torch.full((B, 3, N), -3.6).cuda()
+    smp = ps + [tp] if mode == "inverse" else [tp] + ps
+    loss = nets.PointFlowNLL()(smp, [pm] + mus, [pl] + lvs) + 0.1 * (ps[2] * mus[4]).mean()
+    loss.backward()
+    key = "%%d_%%d" %% (B, N)
+    out[key + "/gp"] = tp.grad.cpu().numpy(); out[key + "/gg"] = tg.grad.cpu().numpy()
+    for k, v in dec.named_parameters():
+        if v.grad is not None: out[key + "/" + k] = v.grad.cpu().numpy()
+from dpf_nets_amd._lib import lib
+out["fallbacks"] = np.array([int(lib().dpf_train_colsum_fallbacks())])
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_training_kernel_forms_agree(tmp_path):
+    """The backward kernels come in several forms chosen by batch size -- pass 2 with a branch per WAVE (two tiles per wave) or
+    per WORKGROUP, pass 1 split by branch or not, pass 1 finished by its per-cloud ticket or by role workgroups of pass 2, the
+    column sums of a layer as role workgroups of the next pass 1 or as their own launch.  Every form runs the same forward
+    pass, hence the same ReLU masks: their gradients may differ by rounding only.  Small and ragged shapes (where the float64
+    comparison above has to allow for a flipped ReLU) are pinned here at 2e-5 of each gradient's scale across all forms, and the
+    two column-sum forms bit for bit (same sums in the same order).  Each form needs its own process: the switches are read once."""
+    import subprocess
+    import sys
+    _gpu()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = FORMS_CODE % (root, FORMS_SHAPES)
+    forms = {"default": {}, "pair": {"DPF_TRAIN_SPLIT": "0"}, "split": {"DPF_TRAIN_SPLIT": "1"}, "ticket": {"DPF_TRAIN_ROLES": "0"},
+             "split+roles": {"DPF_TRAIN_SPLIT": "1", "DPF_TRAIN_ROLES": "1"}, "colsum launch": {"DPF_TRAIN_FUSE_COLSUM": "0"}}
+    res = {}
+    for name, env in forms.items():
+        f = str(tmp_path / (name.replace(" ", "_").replace("+", "_") + ".npz"))
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        res[name] = dict(np.load(f))
+    base = res["default"]
+    for name, got in res.items():
+        # the role workgroups were dispatched in front of the workgroups that wait for them: nobody gave up polling
+        assert int(got["fallbacks"][0]) == 0, (name, int(got["fallbacks"][0]))
+        assert set(got) == set(base), name
+        for k in base:
+            if k == "fallbacks":
+                continue
+            if name == "colsum launch":
+                assert np.array_equal(got[k], base[k]), (name, k)
+                continue
+            scale = float(np.abs(base[k]).max())
+            if scale == 0.0:
+                assert float(np.abs(got[k]).max()) == 0.0, (name, k)
+                continue
+            err = float(np.abs(got[k].astype(np.float64) - base[k]).max()) / scale
+            # a heavily cancelling sum (a bias of the later layers) amplifies the forms' different summation orders: those are
+            # held to 2e-4 -- still 25 x below what a flipped ReLU would move them by
+            assert err <= (2e-4 if k.endswith(".bias") else 2e-5), (name, k, err)
 
 
 def test_training_graph_replay_is_bitwise_the_eager_call():
