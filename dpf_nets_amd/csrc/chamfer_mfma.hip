@@ -11,8 +11,18 @@
 // split of the candidate (cx,cy,cz) against the hi/lo split of -2q (4 product
 // terms per coordinate) and a 3-way split of |c|^2 against 1.  s differs from
 // the true distance by at most E = 2^-14 * R2 (R2 = largest squared norm of the
-// two clouds; derivation in docs/DESIGN_history_r01_r03.md 4.3), so the fp32-exact minimiser -- and
-// every exact tie -- has s <= s_min + tau with tau = 2^-12 * R2.  ONE sweep over
+// two clouds, after centring), so the fp32-exact minimiser -- and every exact tie --
+// has s <= s_min + tau with tau = 2^-12 * R2 = 4 E.  Where E comes from: a coordinate
+// is hi + lo with hi its top 8 bits (truncated: |x - hi| < 2^-7 |x|) and lo the
+// bf16 nearest to the remainder (|x - hi - lo| <= 2^-9 * 2^-7 |x| = 2^-16 |x|), on
+// both sides; of the four products of (qh + ql)(ch + cl) all four are in the K slots,
+// so what is lost per coordinate is the split's own remainder, <= 2 * 2^-16 |q_k||c_k|
+// up to second order, i.e. <= 2^-14 |q.c|-bound per pair on the -2 q.c term:
+// 2 * sum_k 2^-15 |q_k||c_k| <= 2^-14 |q||c| <= 2^-14 R2.  |c|^2 is a 3-way split
+// (24 bits: exact) and the fp32 accumulation of the 15 products adds a few 2^-24 R2.
+// tests/test_gpu_chamfer.py::test_filter_surrogate_error_bound MEASURES |s - (d - |q|^2)|
+// against E on the adversarial distributions through dpf_debug_nn_surrogate (below).
+// The centring rounds c - mu to 2^-24 of itself: < 2^-21 R2 more, inside tau's slack.  ONE sweep over
 // the candidate tiles: per tile one MFMA and a v_min3 tree over the accumulator
 // fragment (0.5 VALU op per pair).  Since r04 the sweep keeps no queue: a chunk of
 // 32 tiles leaves its surrogate minima in registers, then every tile within tau of
@@ -511,7 +521,59 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
     }
 }
 
+// ---- the filter's surrogate, read back (tests/test_gpu_chamfer.py::test_filter_surrogate_error_bound) -------------------------
+// One wave per (query tile, candidate tile) of ONE pair of clouds: the same centring, the same fragments and the same MFMA as
+// nnm_kernel, and the 32 x 32 surrogates go to s[query][candidate] instead of into a minimum.  out3[0..2] = mu, out3[3] = R2 as
+// nnm_kernel takes it (over all candidates and all queries; nnm_kernel's per-workgroup R2 is <= that).
+__global__ __launch_bounds__(64) void nnm_surrogate_kernel(const float *__restrict__ q, int nq, const float *__restrict__ c, int nc,
+                                                           float *__restrict__ s, float *__restrict__ out3) {
+    __shared__ uint4 frag[64];
+    const int lane = threadIdx.x, h = lane >> 5, i = lane & 31, qt = blockIdx.x, ct = blockIdx.y;
+    float mux, muy, muz;
+    {
+        const float *src = c + (size_t)min(lane, nc - 1) * 3;
+        mux = src[0]; muy = src[1]; muz = src[2];
+        for (int d = 32; d > 0; d >>= 1) { mux += __shfl_xor(mux, d); muy += __shfl_xor(muy, d); muz += __shfl_xor(muz, d); }
+        mux *= 0.015625f; muy *= 0.015625f; muz *= 0.015625f;
+    }
+    const int j = qt * 32 + i, p = ct * 32 + i;
+    const float *qsrc = q + (size_t)min(j, nq - 1) * 3;
+    const uint4 bq = query_fragment(qsrc[0] - mux, qsrc[1] - muy, qsrc[2] - muz, h);
+    if (h == 0) {
+        const bool live = p < nc;
+        const float *src = c + (size_t)min(p, nc - 1) * 3;
+        uint4 f0, f1;
+        cand_fragment(live ? src[0] - mux : 0.f, live ? src[1] - muy : 0.f, live ? src[2] - muz : 0.f, live, f0, f1);
+        frag[i] = f0; frag[32 + i] = f1;
+    }
+    __syncthreads();
+    const f32x16 a = mfma(frag[lane], bq);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k = ct * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+        if (j < nq && k < nc) s[(size_t)j * nc + k] = a[r];
+    }
+    if (qt == 0 && ct == 0) {          // R2 and mu, by one wave
+        float r2 = 0.f;
+        for (int t = lane; t < nq + nc; t += 64) {
+            const float *src = t < nq ? q + (size_t)t * 3 : c + (size_t)(t - nq) * 3;
+            const float x = src[0] - mux, y = src[1] - muy, z = src[2] - muz;
+            r2 = fmaxf(r2, (x * x + y * y) + z * z);
+        }
+        for (int d = 32; d > 0; d >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, d));
+        if (lane == 0) { out3[0] = mux; out3[1] = muy; out3[2] = muz; out3[3] = r2; }
+    }
+}
+
 }  // namespace
+
+// Test hook: the matrix-core filter's surrogate s(q, c) = |c - mu|^2 - 2 (q - mu).(c - mu) for every pair of ONE pair of clouds
+// ((nq, 3) queries, (nc, 3) candidates), exactly as nnm_kernel forms it; s is (nq, nc), out4 = {mu_x, mu_y, mu_z, R2}.
+extern "C" int dpf_debug_nn_surrogate(int nq, const float *q, int nc, const float *c, float *s, float *out4, dpf_stream_t stream) {
+    if (nq <= 0 || nc <= 0 || !q || !c || !s || !out4) return DPF_EINVAL;
+    hipLaunchKernelGGL(nnm_surrogate_kernel, dim3(tiles_of(nq), tiles_of(nc)), dim3(64), 0, (hipStream_t)stream, q, nq, c, nc, s, out4);
+    return (int)hipGetLastError();
+}
 
 extern "C" size_t dpf_nndistance_mfma_workspace_bytes(int b, int n, int m) {
     (void)b; (void)n; (void)m;

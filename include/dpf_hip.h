@@ -390,6 +390,10 @@ int dpf_encoder_train_backward(int B, int N, const float *canon, const float *x,
  * the previous state.  dpf_train_graph_replays(): calls served by a replay so far.  dpf_train_graph_stats(out[5]):
  * {replays, eager calls, recordings, evictions, keys that could not be captured} -- evictions growing while replays stand
  * still means the loop presents more than 8 live pointer sets per entry point, or its allocator does not settle. */
+/* Test hook of the matrix-core Chamfer filter (csrc/chamfer_mfma.hip): the surrogate s(q, c) = |c - mu|^2 - 2 (q - mu).(c - mu)
+ * of every pair of ONE pair of clouds ((nq, 3) queries, (nc, 3) candidates), formed exactly as the filter forms it; s is
+ * (nq, nc) floats, out4 = {mu_x, mu_y, mu_z, R2}.  The filter's exactness rests on |s - exact| <= 2^-14 R2. */
+int dpf_debug_nn_surrogate(int nq, const float *q, int nc, const float *c, float *s, float *out4, dpf_stream_t stream);
 long dpf_train_graph_replays(void);
 /* Workgroups of the training backward pass that gave up waiting for role workgroups of their own launch (pass 1: the column sums
  * of the layer above; pass 2, small batches: the per-cloud totals and BatchNorm-backward means of pass 1) and did the sums

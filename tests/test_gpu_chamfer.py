@@ -91,6 +91,120 @@ def test_pruned_search_adversarial_distributions(kind, impl):
     _assert_bit_exact(_run(BK, a, b, impl), S.nndistance(a, b), kind)
 
 
+def _adversarial(kind, a, b):
+    """the distributions of test_pruned_search_adversarial_distributions, in place on copies"""
+    a, b = a.copy(), b.copy()
+    m = b.shape[1]
+    if kind == "same_x":
+        a[..., 0] = 0.125; b[..., 0] = 0.125
+    elif kind == "two_planes":
+        a[..., 0] = np.where(a[..., 0] > 0, 0.25, -0.25); b[..., 0] = np.where(b[..., 0] > 0, 0.25, -0.25)
+        b[:, m // 2:m // 2 + 100] = b[:, 100:200]
+    elif kind == "line":
+        a[..., 1:] = 0; b[..., 1:] = 0
+    elif kind == "clustered":
+        a = (np.round(a * 4) / 4 + a * 0.01).astype(np.float32); b = (np.round(b * 4) / 4 + b * 0.01).astype(np.float32)
+    elif kind == "surface":
+        a[..., 2] = np.sin(a[..., 0] * 9) * 0.1; b[..., 2] = np.sin(b[..., 0] * 9) * 0.1
+    elif kind == "far_offset":
+        a += np.float32(37.0); b += np.float32(37.0)
+    elif kind == "all_equal":
+        b[:] = b[:, :1]
+    elif kind == "big_coords":
+        a *= np.float32(1000.0); b *= np.float32(1000.0)
+    elif kind == "tiny_coords":
+        a *= np.float32(1e-6); b *= np.float32(1e-6)
+    return a, b
+
+
+@pytest.mark.parametrize("kind", ["uniform", "same_x", "two_planes", "line", "clustered", "surface", "far_offset", "all_equal",
+                                  "big_coords", "tiny_coords"])
+def test_filter_surrogate_error_bound(kind):
+    """the matrix-core filter is exact BECAUSE its surrogate s = |c|^2 - 2 q.c (on centred coordinates, bf16 hi/lo
+    operands, one MFMA per 32 x 32 pairs) stays within E = 2^-14 R2 of the value it stands for, d - |q|^2: the tile filter keeps
+    everything within tau = 4 E of the running minimum.  The bound is derived in csrc/chamfer_mfma.hip's header; here it is
+    MEASURED: dpf_debug_nn_surrogate forms s with the kernel's own centring, fragments and MFMA for every pair of a cloud pair,
+    and float64 says what it should have been."""
+    _gpu()
+    from dpf_nets_amd._lib import lib, current_stream
+    n, m = 700, 1100
+    a, b = chamfer_inputs(2000 + len(kind), 1, n, m)
+    a, b = _adversarial(kind, a, b)
+    for q, c in ((a[0], b[0]), (b[0], a[0])):                       # both directions of the pair
+        tq, tc = torch.from_numpy(np.ascontiguousarray(q)).cuda(), torch.from_numpy(np.ascontiguousarray(c)).cuda()
+        s = torch.empty((q.shape[0], c.shape[0]), device="cuda")
+        out4 = torch.empty(4, device="cuda")
+        rc = lib().dpf_debug_nn_surrogate(q.shape[0], tq.data_ptr(), c.shape[0], tc.data_ptr(), s.data_ptr(), out4.data_ptr(), current_stream())
+        assert rc == 0
+        torch.cuda.synchronize()
+        mu, r2 = out4[:3].cpu().numpy(), float(out4[3])
+        qc = (q - mu).astype(np.float32).astype(np.float64)         # fl(q - mu), as the kernel centres
+        cc = (c - mu).astype(np.float32).astype(np.float64)
+        assert r2 >= max((qc * qc).sum(1).max(), (cc * cc).sum(1).max()) * (1 - 1e-6)
+        exact = (cc * cc).sum(1)[None, :] - 2.0 * qc @ cc.T         # d - |q|^2 on the centred coordinates
+        err = float(np.abs(s.cpu().numpy().astype(np.float64) - exact).max())
+        E = 2.0 ** -14 * r2
+        # (+ 2^-20 R2: the fp32 rounding of |c|^2 and of the MFMA's accumulation, which the derivation leaves to tau's slack)
+        assert err <= E + 2.0 ** -20 * r2, (kind, err / E if E > 0 else err)
+        # the centring itself: fl(c - mu) against the real difference moves d - |q|^2 by < 2^-21 R2
+        true = ((c.astype(np.float64) - mu) ** 2).sum(1)[None, :] - 2.0 * (q.astype(np.float64) - mu) @ (c.astype(np.float64) - mu).T
+        assert float(np.abs(exact - true).max()) <= 2.0 ** -21 * r2 + 1e-300, kind
+
+
+FUZZ_N = [1, 7, 31, 32, 33, 64, 100, 257, 500, 1000, 1024, 2047, 2048, 2049, 2080, 2500, 3000, 4100]
+FUZZ_M = [1, 5, 32, 63, 65, 300, 777, 1024, 2048, 2111, 2500, 4096, 5000]
+
+
+def test_nndistance_fuzz_all_kernels_vs_oracle():
+    """a seeded, time-boxed run of tools/nn_fuzz.py inside the suite.  Random batch sizes, ragged tile counts, clouds
+    that spill into a second pass of fragments, lattices (exact ties), duplicates, far offsets, 1e-6 .. 1e6 scales: the matrix-core
+    filter, the SGPR-fed scan and the LDS-staged scan must return the CPU oracle's bits on every case it can afford (<= 4e7
+    pair evaluations: nine cases in ten) and each other's on the rest."""
+    BK = _gpu()
+    import time
+    rng = np.random.default_rng(20260501)
+    S.set_threads(8)
+    t0, cases, pinned, budget, want = time.time(), 0, 0, 100.0, 6000
+    try:
+        while cases < want and time.time() - t0 < budget:
+            B = int(rng.integers(1, 9))
+            n, m = int(rng.choice(FUZZ_N)), int(rng.choice(FUZZ_M))
+            if cases % 2:                                            # half of them small: cheap for the oracle
+                n, m = min(n, 500), min(m, 1024)
+            kind = str(rng.choice(["uniform", "normal", "lattice", "dups", "offset", "line", "tiny", "huge"]))
+            a = rng.random((B, n, 3), dtype=np.float32) - 0.5
+            b = rng.random((B, m, 3), dtype=np.float32) - 0.5
+            if kind == "normal":
+                a = rng.standard_normal((B, n, 3)).astype(np.float32) * 0.2; b = rng.standard_normal((B, m, 3)).astype(np.float32) * 0.2
+            elif kind == "lattice":
+                a = np.round(a * 8) / 8; b = np.round(b * 8) / 8
+            elif kind == "dups":
+                b[:, m // 2:] = b[:, :m - m // 2]
+                a[:, ::3] = b[:, :1]
+            elif kind == "offset":
+                a += np.float32(11.0); b += np.float32(11.0)
+            elif kind == "line":
+                a[..., 1:] = 0; b[..., 1:] = 0
+            elif kind == "tiny":
+                a *= np.float32(1e-6); b *= np.float32(1e-6)
+            elif kind == "huge":
+                a *= np.float32(1e6); b *= np.float32(1e6)
+            a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+            tag = (cases, B, n, m, kind)
+            ref = _run(BK, a, b, "brute")
+            if B * n * m <= 4e7:
+                _assert_bit_exact(ref, S.nndistance(a, b), tag)
+                pinned += 1
+            _assert_bit_exact(_run(BK, a, b, "mfma"), ref, tag + ("mfma",))
+            if max(n, m) <= 8192:
+                _assert_bit_exact(_run(BK, a, b, "small"), ref, tag + ("small",))
+            cases += 1
+    finally:
+        S.set_threads(1)
+    print("nndistance fuzz: %d cases in %.0f s, %d of them pinned on the CPU oracle" % (cases, time.time() - t0, pinned))
+    assert cases >= 1500 and pinned >= 1000, (cases, pinned)          # (a fresh box runs all 6000 in a fraction of the budget)
+
+
 def _assert_same_with_nans(got, ref, tag):
     """bit-exact where the reference value is a number; NaN where it is NaN (the payload / sign of a NaN differs between
     x86 and gfx950 arithmetic, its position does not)"""
