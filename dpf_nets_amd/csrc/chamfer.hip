@@ -398,13 +398,19 @@ __global__ __launch_bounds__(KSW * 64) void nn_small_kernel(NNArgs args) {
             if (d0 < best) { best = d0; bc = k; }
         }
     }
-    // the FIRST index inside the winning chunk (descending scan, last hit wins); padding never matches a finite minimum
+    // the FIRST index inside the winning chunk (descending scan, last hit wins); padding never matches a finite minimum.
+    // (r05: the chunk comes back as six 16-byte reads, not 24 scalar ones -- the lanes' chunks differ, and 4-byte reads at
+    // multiples of 8 floats use 8 of the 64 banks: r04 counters, SQ_LDS_BANK_CONFLICT = 0.21 of SQ_LDS_IDX_ACTIVE)
     int i0 = bc;
+    {
+        f4 w[6];
+        load_chunk(bc, w);
 #pragma unroll
-    for (int u = CH - 1; u >= 0; --u) {
-        const int kk = bc + u;
-        const float d0 = one_dist(cx[kk], cy[kk], cz[kk], qx, qy, qz);
-        if (d0 == best && kk < nc) i0 = kk;
+        for (int u = CH - 1; u >= 0; --u) {
+            const int kk = bc + u;
+            const float d0 = one_dist(w[u >> 2][u & 3], w[2 + (u >> 2)][u & 3], w[4 + (u >> 2)][u & 3], qx, qy, qz);
+            if (d0 == best && kk < nc) i0 = kk;
+        }
     }
     sd[ks][lane] = best;
     si[ks][lane] = i0;
@@ -418,7 +424,7 @@ __global__ __launch_bounds__(KSW * 64) void nn_small_kernel(NNArgs args) {
         const float e0 = sd[s2][lane];
         if (e0 < best) { best = e0; i0 = si[s2][lane]; }
     }
-    if (anybad || nn_not_finite(best)) nn_reference_scan(c, nc, qx, qy, qz, best, i0);
+    if (anybad || nn_not_finite(best) || nn_query_far(qx, qy, qz)) nn_reference_scan(c, nc, qx, qy, qz, best, i0);
     if (j < nq) { A.dist[(size_t)bi * nq + j] = best; A.idx[(size_t)bi * nq + j] = i0; }
     if (args.part != nullptr) publish(j < nq ? best : 0.f);
 }

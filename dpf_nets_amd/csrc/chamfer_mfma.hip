@@ -55,10 +55,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // waves per workgroup (32 queries each): template parameter QW = 16, or 8 when that is what fills the chip
-constexpr int CT = 64;           // candidate tiles resident in LDS at a time (64 KiB of fragments + 32 KiB of points)
+constexpr int CT = 64;           // candidate tiles resident in LDS at a time (64 KiB of fragments + 33 KiB of points)
+// points of a tile in LDS: 32 + 1 float4.  The exact evaluations read the tiles their lanes' survivors name -- any tiles -- at the
+// same offset inside the tile: with rows of 32 float4 (512 B) every one of those reads fell on the same four banks (r04 counters:
+// SQ_LDS_BANK_CONFLICT = a third of SQ_LDS_IDX_ACTIVE); one float4 of padding per row spreads tiles t, t + 1, ... over all banks
+constexpr int PROW = 33;
 constexpr int SCH = 32;          // tiles per sweep chunk: their surrogate minima stay in registers until the chunk's threshold is known
 constexpr int WCAP = SCH * 64 / 8;   // work items of a wave per chunk: their 8-byte results reuse the survivor lists' 2 KiB
-__host__ __device__ constexpr int nnm_lds_bytes(int qw) { return CT * 1536 + qw * SCH * 64 + qw * WCAP * 2; }    // fragments + points + survivor lists / results + work lists
+constexpr int NNM_PTS = CT * 1024, NNM_LISTS = NNM_PTS + CT * PROW * 16;      // byte offsets: fragments | points | survivor lists / results | work lists
+__host__ __device__ constexpr int nnm_lds_bytes(int qw) { return NNM_LISTS + qw * SCH * 64 + qw * WCAP * 2; }
 
 __device__ __forceinline__ uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
 __device__ __forceinline__ float u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
@@ -160,7 +165,7 @@ __device__ __forceinline__ void exact_tile(P cp, int nc, int t, int tl, int h, f
     for (int g = 0; g < 4; ++g) {                       // four points at a time: few live registers
         float4 v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = cp[(size_t)tl * 32 + 8 * g + 4 * h + e];    // padded: always in range
+        for (int e = 0; e < 4; ++e) v[e] = cp[(size_t)tl * PROW + 8 * g + 4 * h + e];    // padded: always in range
 #pragma unroll
         for (int e = 0; e < 4; ++e) d[4 * g + e] = dist3(v[e].x, v[e].y, v[e].z, qx, qy, qz);
     }
@@ -192,7 +197,7 @@ __device__ __forceinline__ void exact_tile_mk(P cp, int nc, int t, int tl, int h
     for (int g = 0; g < 4; ++g) {
         float4 v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = cp[(size_t)tl * 32 + 8 * g + 4 * h + e];
+        for (int e = 0; e < 4; ++e) v[e] = cp[(size_t)tl * PROW + 8 * g + 4 * h + e];
 #pragma unroll
         for (int e = 0; e < 4; e += 2) {     // two candidates per packed instruction; every operation rounded on its own, as dist3
             const f2 dx = f2{v[e].x, v[e + 1].x} - qx2, dy = f2{v[e].y, v[e + 1].y} - qy2, dz = f2{v[e].z, v[e + 1].z} - qz2;
@@ -223,8 +228,8 @@ template <int QW>
 __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint4 *sfrag = (uint4 *)lds;                                  // [CT][64]
-    float4 *spts = (float4 *)(lds + CT * 1024);                    // [CT][32]
-    unsigned char *qtile = (unsigned char *)(lds + CT * 1536);     // [QW][WCAP] 8-byte results of the wave-wide work list
+    float4 *spts = (float4 *)(lds + NNM_PTS);                      // [CT][PROW]
+    unsigned char *qtile = (unsigned char *)(lds + NNM_LISTS);     // [QW][WCAP] 8-byte results of the wave-wide work list
     __shared__ float s_r2[QW];
     const bool pairwise = args.pn2 > 0;
     const int dir = pairwise ? (int)(blockIdx.z & 1) : (int)blockIdx.z;
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
     float tau = 0.f;
     bool slow = false;
 
-    unsigned short *wl = (unsigned short *)(lds + CT * 1536 + QW * SCH * 64) + (size_t)wave * WCAP;      // (source lane << 8) | tile
+    unsigned short *wl = (unsigned short *)(lds + NNM_LISTS + QW * SCH * 64) + (size_t)wave * WCAP;      // (source lane << 8) | tile
     uint2 *res = (uint2 *)(qtile + (size_t)wave * SCH * 64);       // (distance bits, index) per work item of the wave
     float smin = __builtin_inff();
     float best = __builtin_inff();
@@ -328,7 +333,7 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
                 sfrag[t * 64 + i] = f0;
                 sfrag[t * 64 + 32 + i] = f1;
                 // original coordinates for the exact evaluation; padding far away (its distance is +inf)
-                spts[t * 32 + i] = live ? make_float4(x, y, z, 0.f) : make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
+                spts[t * PROW + i] = live ? make_float4(x, y, z, 0.f) : make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
                 if (pass == 0) {
                     const float cn = (cx * cx + cy * cy) + cz * cz;
                     r2 = nn_not_finite(cn) ? INF_ : fmaxf(r2, cn);
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
                         }
                     }
                 } else {
-                    // (a ragged last chunk repeats its last tile: a repeated survivor is evaluated twice, which changes nothing)
+                    // (a ragged last chunk repeats its last tile in the slots past it; their survivor bits are cleared below)
                     auto frag = [&](int u) { return sfrag[(c0 + min(u, cn - 1)) * 64 + lane]; };
                     f32x16 a = mfma(frag(0), bq);
 #pragma unroll
@@ -425,6 +430,8 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
                 for (int u = 0; u < SCH; ++u)          // smask = 2 smask + (mt[u] <= thr): a compare and an add-with-carry (the compiler's
                                                        // own form is compare, select, shift, or)
                     asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(smask) : "v"(mt[u]), "v"(thr) : "vcc");
+                // (a ragged last chunk repeated its last tile in slots cn .. SCH - 1: those bits name tiles that are not there)
+                if (cn < SCH) smask &= ~0u << (SCH - cn);
                 const int nsurv = __builtin_popcount(smask);
                 int smax = nsurv;
                 for (int d = 32; d > 0; d >>= 1) smax = max(smax, __shfl_xor(smax, d));

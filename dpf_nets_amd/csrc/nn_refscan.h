@@ -42,6 +42,12 @@ __device__ __forceinline__ void nn_reference_scan(const float *__restrict__ c, i
 
 // true for NaN, +-Inf and anything whose square would overflow the sums the kernels form
 __device__ __forceinline__ bool nn_not_finite(float v) { return !(v <= 3.0e38f); }
+// true for a query the LDS-staged kernels cannot serve: their padding candidates sit at (3e38, 3e38, 3e38) "so far away that
+// the distance is +inf" -- which holds for every query whose coordinates are below ~1e19 in magnitude (the difference then
+// squares to +inf) and fails for a finite query out there, next to the padding: such a query takes the reference's scan too
+__device__ __forceinline__ bool nn_query_far(float x, float y, float z) {
+    return !(fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z)) <= 1.0e18f);
+}
 
 }  // namespace
 #endif

@@ -218,6 +218,19 @@ def _assert_same_with_nans(got, ref, tag):
             assert np.array_equal(g, r), (tag, name, int((g != r).sum()), np.argwhere(g != r)[:4].tolist())
 
 
+@pytest.mark.parametrize("impl", IMPLS)
+def test_finite_query_out_where_the_padding_sits(impl):
+    """the LDS-staged kernels pad their candidate tiles with points at (3e38, 3e38, 3e38), "so far away that the
+    distance is +inf" -- true unless a FINITE query sits out there too (distance 0 to the padding).  Every squared distance of
+    such a query overflows; the reference answers (inf, 0) and so must every kernel."""
+    BK = _gpu()
+    B, n, m = 4, 300, 1100                      # 1100 candidates: a ragged last tile, i.e. padding
+    a, b = chamfer_inputs(77, B, n, m)
+    a[0, 5] = np.float32(3.0e38); a[1, 7] = (np.float32(2.9e38), np.float32(-3.0e38), np.float32(3.0e38))
+    a[2, 0] = (np.float32(3.0e38), np.float32(0.0), np.float32(0.0)); b[3, 1099] = np.float32(-3.0e38)
+    _assert_same_with_nans(_run(BK, a, b, impl), S.nndistance(a, b), impl)
+
+
 NONFINITE_SHAPES = [(8, 700, 1100), (12, 2048, 2048), (8, 2500, 4100), (9, 100, 37)]
 
 
