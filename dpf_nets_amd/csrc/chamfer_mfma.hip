@@ -55,14 +55,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // waves per workgroup (32 queries each): template parameter QW = 16, or 8 when that is what fills the chip
-constexpr int CT = 64;           // candidate tiles resident in LDS at a time (64 KiB of fragments + 33 KiB of points)
-// points of a tile in LDS: 32 + 1 float4.  The exact evaluations read the tiles their lanes' survivors name -- any tiles -- at the
-// same offset inside the tile: with rows of 32 float4 (512 B) every one of those reads fell on the same four banks (r04 counters:
-// SQ_LDS_BANK_CONFLICT = a third of SQ_LDS_IDX_ACTIVE); one float4 of padding per row spreads tiles t, t + 1, ... over all banks
-constexpr int PROW = 33;
+constexpr int CT = 64;           // candidate tiles resident in LDS at a time (64 KiB of fragments + 25 KiB of points)
+// points of a tile in LDS: x[32] | y[32] | z[32] | 4 floats of padding.  The exact evaluations read the tiles their lanes'
+// survivors name -- any tiles -- at the same offset inside the tile: r04's rows of 32 float4 (512 B apart) put every one of
+// those reads on the same four banks (counters: SQ_LDS_BANK_CONFLICT = a third of SQ_LDS_IDX_ACTIVE).  r05: rows of 100
+// floats spread consecutive tiles over all banks (18.5 -> 17.7 us at cfg-2 with padded float4 rows; same box), and the
+// structure-of-arrays form makes a lane's 16 candidates 12 quad reads instead of 16.
+constexpr int PROW = 100;        // floats
 constexpr int SCH = 32;          // tiles per sweep chunk: their surrogate minima stay in registers until the chunk's threshold is known
 constexpr int WCAP = SCH * 64 / 8;   // work items of a wave per chunk: their 8-byte results reuse the survivor lists' 2 KiB
-constexpr int NNM_PTS = CT * 1024, NNM_LISTS = NNM_PTS + CT * PROW * 16;      // byte offsets: fragments | points | survivor lists / results | work lists
+constexpr int NNM_PTS = CT * 1024, NNM_LISTS = NNM_PTS + CT * PROW * 4;       // byte offsets: fragments | points | survivor lists / results | work lists
 __host__ __device__ constexpr int nnm_lds_bytes(int qw) { return NNM_LISTS + qw * SCH * 64 + qw * WCAP * 2; }
 
 __device__ __forceinline__ uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
@@ -163,11 +165,10 @@ __device__ __forceinline__ void exact_tile(P cp, int nc, int t, int tl, int h, f
     float d[16];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {                       // four points at a time: few live registers
-        float4 v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = cp[(size_t)tl * PROW + 8 * g + 4 * h + e];    // padded: always in range
-#pragma unroll
-        for (int e = 0; e < 4; ++e) d[4 * g + e] = dist3(v[e].x, v[e].y, v[e].z, qx, qy, qz);
+        const float *row = cp + (size_t)tl * PROW + 8 * g + 4 * h;               // padded: always in range
+        const float4 vx = *(const float4 *)row, vy = *(const float4 *)(row + 32), vz = *(const float4 *)(row + 64);
+        d[4 * g + 0] = dist3(vx.x, vy.x, vz.x, qx, qy, qz); d[4 * g + 1] = dist3(vx.y, vy.y, vz.y, qx, qy, qz);
+        d[4 * g + 2] = dist3(vx.z, vy.z, vz.z, qx, qy, qz); d[4 * g + 3] = dist3(vx.w, vy.w, vz.w, qx, qy, qz);
     }
     float m = fminf(fminf(d[0], d[1]), d[2]);
 #pragma unroll
@@ -195,14 +196,17 @@ __device__ __forceinline__ void exact_tile_mk(P cp, int nc, int t, int tl, int h
     const f2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        float4 v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = cp[(size_t)tl * PROW + 8 * g + 4 * h + e];
-#pragma unroll
-        for (int e = 0; e < 4; e += 2) {     // two candidates per packed instruction; every operation rounded on its own, as dist3
-            const f2 dx = f2{v[e].x, v[e + 1].x} - qx2, dy = f2{v[e].y, v[e + 1].y} - qy2, dz = f2{v[e].z, v[e + 1].z} - qz2;
+        const float *row = cp + (size_t)tl * PROW + 8 * g + 4 * h;
+        const float4 vx = *(const float4 *)row, vy = *(const float4 *)(row + 32), vz = *(const float4 *)(row + 64);
+        {   // two candidates per packed instruction; every operation rounded on its own, as dist3
+            const f2 dx = f2{vx.x, vx.y} - qx2, dy = f2{vy.x, vy.y} - qy2, dz = f2{vz.x, vz.y} - qz2;
             const f2 dd = (dx * dx + dy * dy) + dz * dz;
-            d[4 * g + e] = dd.x; d[4 * g + e + 1] = dd.y;
+            d[4 * g + 0] = dd.x; d[4 * g + 1] = dd.y;
+        }
+        {
+            const f2 dx = f2{vx.z, vx.w} - qx2, dy = f2{vy.z, vy.w} - qy2, dz = f2{vz.z, vz.w} - qz2;
+            const f2 dd = (dx * dx + dy * dy) + dz * dz;
+            d[4 * g + 2] = dd.x; d[4 * g + 3] = dd.y;
         }
     }
     m = fminf(fminf(d[0], d[1]), d[2]);
@@ -228,7 +232,7 @@ template <int QW>
 __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint4 *sfrag = (uint4 *)lds;                                  // [CT][64]
-    float4 *spts = (float4 *)(lds + NNM_PTS);                      // [CT][PROW]
+    float *spts = (float *)(lds + NNM_PTS);                        // [CT][PROW]
     unsigned char *qtile = (unsigned char *)(lds + NNM_LISTS);     // [QW][WCAP] 8-byte results of the wave-wide work list
     __shared__ float s_r2[QW];
     const bool pairwise = args.pn2 > 0;
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(QW * 64) void nnm_kernel(MArgs args) {
                 sfrag[t * 64 + i] = f0;
                 sfrag[t * 64 + 32 + i] = f1;
                 // original coordinates for the exact evaluation; padding far away (its distance is +inf)
-                spts[t * PROW + i] = live ? make_float4(x, y, z, 0.f) : make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
+                spts[t * PROW + i] = live ? x : 3.0e38f; spts[t * PROW + 32 + i] = live ? y : 3.0e38f; spts[t * PROW + 64 + i] = live ? z : 3.0e38f;
                 if (pass == 0) {
                     const float cn = (cx * cx + cy * cy) + cz * cz;
                     r2 = nn_not_finite(cn) ? INF_ : fmaxf(r2, cn);
