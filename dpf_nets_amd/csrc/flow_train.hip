@@ -792,13 +792,19 @@ __device__ __forceinline__ float dh2a_of(float pre, float w2a, float w2b, float 
 // the dW1 totals are converted by whoever comes first (grid-stride).  Ends with a workgroup barrier.
 struct CoefLoads { double S, Sa, Sb; float ea, eb, caa, cbb, cab, wa, wb, gamma, rstd0; };
 // the loads of bwd3_coefs (threads < 128), to be issued BEFORE the caller's weight loads
+// (two halves: what does not come from the column sums -- the layer's statistics and weights -- and the three totals)
+__device__ __forceinline__ void bwd3_loads_const(CoefLoads &L, int nk, const float *__restrict__ tcanon_l, const float *__restrict__ stats_l) {
+    const int q = threadIdx.x & 127, br = q >> 6, f = q & 63;
+    const float *cb = tcanon_l + br * T_BR;
+    const float *m = stats_l + ST_MOM;
+    L.ea = m[0]; L.eb = m[1]; L.caa = m[2]; L.cbb = m[3]; L.cab = m[4];
+    L.wa = cb[T_W0 + f * nk]; L.wb = nk == 2 ? cb[T_W0 + f * 2 + 1] : 0.f; L.gamma = cb[T_G0 + f];
+    L.rstd0 = stats_l[br * ST_BR + 64 + f];
+}
 template <bool AGENT = false>
-__device__ __forceinline__ CoefLoads bwd3_loads(int nk, const double *__restrict__ tot, const float *__restrict__ tcanon_l,
-                                                const float *__restrict__ stats_l) {
-    CoefLoads L;
+__device__ __forceinline__ void bwd3_loads_totals(CoefLoads &L, const double *__restrict__ tot) {
     const int q = threadIdx.x & 127, br = q >> 6, f = q & 63;
     const double *t = tot + (size_t)br * P2_J;
-    const float *cb = tcanon_l + br * T_BR;
     if (AGENT) {       // written by other workgroups of THIS launch (colsum_role): past this CU's L1 and the XCD's L2
         L.S = __hip_atomic_load(&t[P2_S + f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         L.Sa = __hip_atomic_load(&t[P2_A + f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -806,10 +812,13 @@ __device__ __forceinline__ CoefLoads bwd3_loads(int nk, const double *__restrict
     } else {
         L.S = t[P2_S + f]; L.Sa = t[P2_A + f]; L.Sb = t[P2_B + f];
     }
-    const float *m = stats_l + ST_MOM;
-    L.ea = m[0]; L.eb = m[1]; L.caa = m[2]; L.cbb = m[3]; L.cab = m[4];
-    L.wa = cb[T_W0 + f * nk]; L.wb = nk == 2 ? cb[T_W0 + f * 2 + 1] : 0.f; L.gamma = cb[T_G0 + f];
-    L.rstd0 = stats_l[br * ST_BR + 64 + f];
+}
+template <bool AGENT = false>
+__device__ __forceinline__ CoefLoads bwd3_loads(int nk, const double *__restrict__ tot, const float *__restrict__ tcanon_l,
+                                                const float *__restrict__ stats_l) {
+    CoefLoads L;
+    bwd3_loads_totals<AGENT>(L, tot);
+    bwd3_loads_const(L, nk, tcanon_l, stats_l);
     return L;
 }
 __device__ __forceinline__ void bwd3_coefs(const CoefLoads &L, int blk, int nk, double count, float *__restrict__ dcanon_l,
@@ -883,7 +892,7 @@ struct PrevLayer {
 
 // r04: the column sums of the layer ABOVE's pass-2 partials (the former tcolsum launch between two backward layers) ride in
 // this launch as extra workgroups -- blockIdx.y < cs.rows, dispatched first -- so that the launch boundary
-// tbwd2 -> tcolsum -> tbwd1 becomes tbwd2 -> tbwd1.  The 12 of them that own the 384 totals pass 1 needs (sum dh0a and the
+// tbwd2 -> tcolsum -> tbwd1 becomes tbwd2 -> tbwd1.  The 24 of them that own the 384 totals pass 1 needs (sum dh0a and the
 // two centred input sums per branch and feature: P2_S, P2_A, P2_B) come first, publish their totals with agent-scope stores and
 // raise a counter; the ordinary workgroups recompute the layer's pre-activations first (that needs nothing from above),
 // then wait for the counter (one lane polls; see colsum_wait for the ordering), read the totals past
@@ -897,35 +906,44 @@ struct ColsumJob {
     unsigned target;             // value of *flag once this launch's 16 have arrived
     int nrows, rows;             // partial rows; rows of the grid taken by the column workgroups (0 = none in this launch)
 };
-constexpr int CS_CRIT = 12;      // column workgroups (32 columns each) that own the totals pass 1 waits for: P2_S, P2_A, P2_B of both branches
-// column block of column workgroup `id`: the critical ones first
-__device__ __forceinline__ int cs_block_of(int id) {
-    constexpr int PB = P2_J / 32;                      // 134 blocks per branch: 2 (P2_S) + 128 (dW1) + 4 (P2_A, P2_B)
-    if (id < CS_CRIT) { const int b = id / 6, k = id - 6 * b; return b * PB + (k < 2 ? k : PB - 6 + k); }
+// column workgroups that own the totals pass 1 waits for (P2_S, P2_A, P2_B of both branches: 384 columns): 24 of them with 16
+// columns each -- a thread then has one round of eight row loads instead of two (r05: pass 1 waited ~1 us for them)
+constexpr int CS_CRIT = 24;
+// first column of column workgroup `id`: the critical ones (16 columns) first, then the others (32 columns)
+__device__ __forceinline__ int cs_first_column(int id) {
+    constexpr int PB = P2_J / 32;                      // 134 blocks of 32 per branch: 2 (P2_S) + 128 (dW1) + 4 (P2_A, P2_B)
+    if (id < CS_CRIT) { const int b = id / 12, k = id - 12 * b, k2 = k >> 1; return (b * PB + (k2 < 2 ? k2 : PB - 6 + k2)) * 32 + 16 * (k & 1); }
     int r = id - CS_CRIT;                              // the others in ascending order, skipping those
     const int b = r >= PB - 6, q = r - b * (PB - 6);
-    return b * PB + 2 + q;
+    return (b * PB + 2 + q) * 32;
 }
 // one column of the partials, summed exactly as tcolsum_kernel does: 32 row groups (row r in group r & 31, ascending), then
 // the groups in order
+__device__ __forceinline__ double colsum_group(const ColsumJob &cs, int rg, int j) {      // row group rg of column j
+    const int J = 2 * P2_J;
+    double s = 0;
+    int r = rg;
+    for (; r + 224 < cs.nrows; r += 256) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = cs.part2[(size_t)(r + 32 * k) * J + j];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[k];
+    }
+    for (; r < cs.nrows; r += 32) s += cs.part2[(size_t)r * J + j];
+    return s;
+}
 __device__ __forceinline__ void colsum_role(const ColsumJob &cs, int id, uint8_t *smem) {
     double (*acc)[33] = (double (*)[33])smem;
-    const int J = 2 * P2_J, c = threadIdx.x & 31, rg0 = threadIdx.x >> 5;       // 512 threads: row groups rg0 and rg0 + 16
-    const int j = cs_block_of(id) * 32 + c;
+    const bool crit = id < CS_CRIT;                                            // (workgroup-uniform)
+    // 512 threads: 32 columns x row groups rg0 and rg0 + 16, or (critical) 16 columns x all 32 row groups
+    const int c = crit ? threadIdx.x & 15 : threadIdx.x & 31, rg0 = crit ? threadIdx.x >> 4 : threadIdx.x >> 5;
+    const int j = cs_first_column(id) + c;
+    if (crit) {
+        acc[rg0][c] = colsum_group(cs, rg0, j);
+    } else {
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int rg = rg0 + 16 * half;
-        double s = 0;
-        int r = rg;
-        for (; r + 224 < cs.nrows; r += 256) {
-            float v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = cs.part2[(size_t)(r + 32 * k) * J + j];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) s += v[k];
-        }
-        for (; r < cs.nrows; r += 32) s += cs.part2[(size_t)r * J + j];
-        acc[rg][c] = s;
+        for (int half = 0; half < 2; ++half) acc[rg0 + 16 * half][c] = colsum_group(cs, rg0 + 16 * half, j);
     }
     __syncthreads();
     if (rg0 == 0) {
@@ -936,9 +954,9 @@ __device__ __forceinline__ void colsum_role(const ColsumJob &cs, int id, uint8_t
         const int b2 = j / P2_J, jj = j - b2 * P2_J;
         if (jj >= P2_W && jj < P2_W + 4096) cs.dcanon_prev[b2 * T_BR + T_W1 + jj - P2_W] = (float)t;
     }
-    if (id < CS_CRIT) {
+    if (crit) {
+        // (the threads that stored are the first 16: one wave -- its own vmcnt(0) covers them all, no barrier)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the totals have left this CU before the counter moves
-        __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_fetch_add(cs.flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -990,7 +1008,7 @@ __device__ __forceinline__ void colsum_wait(const ColsumJob &cs, int *lds_word) 
 //   partial sums per workgroup: part1[blk][br][k][64], k = 0 dW2a, 1 dW2b, 2 da, 3 dc;  part1[blk][512 + br*2 + w] = db2
 // the gradient w.r.t. p_out is g_p + g_p2 (either may be NULL = zero, like g_mu and g_lv)
 // (min 4 waves per SIMD = two workgroups per CU: the column workgroups of ColsumJob must find room BESIDE the ordinary ones;
-// the branch-split form serves B * N / 256 <= 64 only -- 128 ordinary + 16 critical column workgroups have a CU each -- and
+// the branch-split form serves B * N / 256 <= 64 only -- 128 ordinary + 24 critical column workgroups have a CU each -- and
 // is one register short at 128)
 template <int NS, bool F16 = false, bool BSPLIT = false>
 __global__ __launch_bounds__(TW * 64, BSPLIT ? 2 : 4) void tbwd1_kernel(TArgs a, const float *__restrict__ g_p, const float *__restrict__ g_p2,
@@ -1001,7 +1019,7 @@ __global__ __launch_bounds__(TW * 64, BSPLIT ? 2 : 4) void tbwd1_kernel(TArgs a,
                                                            float *__restrict__ pc, float *__restrict__ dfm_l, ColsumJob cs) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int L_FILM = pt_a0n(NS), L_FILMB = L_FILM + 2048, L_RED = L_FILMB + 2048;
-    // grid rows [0, cs.rows): the 16 critical column workgroups (dispatched first); rows [cs.rows, cs.rows + B): the clouds;
+    // grid rows [0, cs.rows): the 24 critical column workgroups (dispatched first); rows [cs.rows, cs.rows + B): the clouds;
     // rows behind them: the other column workgroups (dW1 totals: nobody in this launch waits for them)
     // BSPLIT (gridDim.z == 2), small batches: one conditioner branch per workgroup (blockIdx.z), as tbwd2_kernel
     const int br_lo = BSPLIT ? (int)blockIdx.z : 0, br_hi = BSPLIT ? (int)blockIdx.z + 1 : 2;
@@ -1010,7 +1028,7 @@ __global__ __launch_bounds__(TW * 64, BSPLIT ? 2 : 4) void tbwd1_kernel(TArgs a,
         const int id = (int)blockIdx.y < cs.rows ? (int)(blockIdx.y * gridDim.x + blockIdx.x)
                                                  : CS_CRIT + (int)((blockIdx.y - cs.rows - a.B) * gridDim.x + blockIdx.x);
         const bool crit_row = (int)blockIdx.y < cs.rows;
-        if ((crit_row && id < CS_CRIT) || (!crit_row && id < 2 * P2_J / 32)) colsum_role(cs, id, smem);
+        if ((crit_row && id < CS_CRIT) || (!crit_row && id < 2 * P2_J / 32 + CS_CRIT / 2)) colsum_role(cs, id, smem);
         return;
     }
     float *red = (float *)(smem + L_RED);                                  // per wave [2 br][4][64] + [2][2] (+4 pad)
@@ -1117,10 +1135,15 @@ __global__ __launch_bounds__(TW * 64, BSPLIT ? 2 : 4) void tbwd1_kernel(TArgs a,
         // the first branch's recomputation first: by the time it is done the critical column workgroups of this launch have
         // long published their totals (they read 512 columns of the partials; this is ~1 400 instructions)
         recompute_pre(br_lo, pre0);
+        KP(7, 0)
         load_prev();
+        CoefLoads c3;
+        bwd3_loads_const(c3, pv.kb >= 0 ? 2 : 1, pv.tcanon_l, pv.stats_l);    // (requested in front of the wait: only the three totals come from the column sums)
         colsum_wait(cs, (int *)(pcoef + 12));
-        const CoefLoads c3 = bwd3_loads<true>(pv.kb >= 0 ? 2 : 1, pv.tot, pv.tcanon_l, pv.stats_l);
+        KP(7, 1)
+        bwd3_loads_totals<true>(c3, pv.tot);
         finish_gp(c3);
+        KP(7, 2)
     }
     // ---- coupling transform and its derivative (flows.py:96-115)
     const bool inverse = a.mode == DPF_MODE_INVERSE;
@@ -1212,7 +1235,9 @@ __global__ __launch_bounds__(TW * 64, BSPLIT ? 2 : 4) void tbwd1_kernel(TArgs a,
     if constexpr (BSPLIT) {
         branch_sums((int)blockIdx.z);
     } else {
+        KP(7, 3)
         branch_sums(0);
+        KP(7, 4)
         branch_sums(1);
     }
     KP(1, 3)
@@ -2285,7 +2310,7 @@ static int backward_layer(int B, int N, int mode, int ka, int kb, int wa, int wb
         cs.part2 = w.part2; cs.tot = w.tot2; cs.dcanon_prev = pv->dcanon_l; cs.flag = w.tickets + B; cs.nrows = nblk;
         cs.target = (unsigned)CS_CRIT * (unsigned)(++pv->fused_launches);
         cs.rows = (CS_CRIT + (int)grid.x - 1) / (int)grid.x;
-        grid1.y = cs.rows + B + (2 * P2_J / 32 - CS_CRIT + grid.x - 1) / grid.x;
+        grid1.y = cs.rows + B + (2 * P2_J / 32 - CS_CRIT / 2 + grid.x - 1) / grid.x;
     }
     // small batches: the two branches of passes 1 and 2 in two workgroups each (at most half a workgroup per CU otherwise)
     static const int split_env = getenv("DPF_TRAIN_SPLIT") ? atoi(getenv("DPF_TRAIN_SPLIT")) : -1;

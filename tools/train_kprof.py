@@ -33,6 +33,7 @@ t = np.median(np.stack(rows), axis=0)
 names = {0: ("tstats_h1", ["entry", "prologue issued (bn0_fold, loads)", "first barrier passed", "both branches done", "exit"]),
          5: ("tstats_h1 prologue (stamps 0, 5, 6, 7, 1 of kernel 0)", None),
          1: ("tbwd1", ["entry", "prologue issued (coefs of pass 3, loads)", "first barrier passed", "main part done", "row published, ticket taken"]),
+         7: ("tbwd1 main part (fused column sums)", ["first branch recomputed", "column sums' counter seen", "pass-3 totals loaded, coefficients, gradient finished", "coupling transform, stores", "first branch's sums", ]),
          2: ("tbwd2 (r05)", ["entry", "prologue done (staging, first recompute, means from the role workgroups, dh1 fragments)", "both tiles done", "exit (reduction)"]),
          6: ("tbwd2 role workgroup 1 (r05; same clock as the ordinary workgroup above: compare ABSOLUTE stamps below)", ["entry", "rows loaded and summed", "barrier", "means stored, left the CU", "counter raised"]),
          3: ("tbwd2 prologue (r05, large-batch form)", ["address setup done", "weight loads issued", "tables in LDS", "means: loads back, sums done", "partials in LDS", "barrier passed"])}
