@@ -163,11 +163,40 @@ def init_ranks(args):
     # a collective nobody else joins must end the job in minutes, not after the default half hour
     pg_timeout = datetime.timedelta(seconds=int(os.environ.get("DPF_BENCH_PG_TIMEOUT", "300")))
     if backend == "nccl":
+        # RCCL's own account of what it built (transports, channels, rings / trees) goes to a per-rank file and its first lines into
+        # `extra.rccl` of rank 0's line, so that the first real multi-GPU run explains itself.  INIT lines only by default (nothing is
+        # printed per collective); DPF_BENCH_RCCL_TUNING=1 adds the per-call algorithm / protocol choice (a host-side print per step).
+        if os.environ.get("DPF_BENCH_RCCL_LOG", "1") != "0":
+            os.environ.setdefault("NCCL_DEBUG", "INFO")
+            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,TUNING" if os.environ.get("DPF_BENCH_RCCL_TUNING") == "1" else "INIT,GRAPH")
+            os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/dpf_bench_rccl_%h_%p.log")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=pg_timeout)
     else:
         dist.init_process_group(backend, timeout=pg_timeout)
     return rank, local_rank, world, dist
+
+
+def rccl_log_excerpt(max_lines=24):
+    """The informative lines of this process's RCCL log (NCCL_DEBUG_FILE, see init_ranks) or None."""
+    import glob
+    import re
+    pat = os.environ.get("NCCL_DEBUG_FILE", "")
+    if not pat:
+        return None
+    try:
+        files = [f for f in glob.glob(pat.replace("%h", "*").replace("%p", "*")) if f.endswith("_%d.log" % os.getpid())]
+        keep = re.compile(r"(Channel \d+/\d+|Ring \d+|Tree|via |P2P|XGMI|xGMI|NET/|Connected all|comm 0x|nRanks|Algo|Proto|algo|proto|threadThresholds|RCCL version|NCCL version)")
+        out = []
+        for f in files:
+            for l in open(f, errors="replace"):
+                if keep.search(l):
+                    out.append(l.strip()[-220:])
+                    if len(out) >= max_lines:
+                        return out
+        return out or None
+    except Exception as e:       # noqa: BLE001
+        return ["(could not read the RCCL log: %r)" % (e,)]
 
 
 def timed_region(run_steps, args, dist, device):
@@ -897,7 +926,8 @@ def train_step_leg(args, rank, world, dist, device, batch, layers, steps, warmup
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    ar_us = float(np.median([a.elapsed_time(b) for a, b in ev])) * 1e3
+    ar_all = sorted(float(a.elapsed_time(b)) * 1e3 for a, b in ev)
+    ar_us = float(np.median(ar_all))
     nbytes = arena.nbytes()
     gstats = (ctypes.c_long * 5)()
     _lib_handle().dpf_train_graph_stats(gstats)          # of the timed region: read before the eager per-kernel pass below
@@ -958,7 +988,11 @@ def train_step_leg(args, rank, world, dist, device, batch, layers, steps, warmup
         info["error"] = "graph replay and eager launches disagree: no value reported"
     if world > 1:
         bus = 2.0 * (world - 1) / world * nbytes / (ar_us * 1e-6) / 1e9
-        info["allreduce"] = {"us": ar_us, "elements": int(nred), "bus_GBps": bus, "backend": dist.get_backend(),
+        info["allreduce"] = {"us": ar_us, "us_min": ar_all[0], "us_max": ar_all[-1], "us_p10": ar_all[len(ar_all) // 10],
+                             "us_p90": ar_all[(9 * len(ar_all)) // 10], "steps_timed": len(ar_all),
+                             "frac_of_step": ar_us * 1e-3 / (elapsed / steps * 1e3),
+                             "rccl": rccl_log_excerpt() if dist.get_backend() == "nccl" else None,
+                             "elements": int(nred), "bus_GBps": bus, "backend": dist.get_backend(),
                              "xgmi_budget_GBps": 7 * XGMI_LINK_GBS, "frac_of_xgmi_budget": bus / (7 * XGMI_LINK_GBS),
                              "note": "HIP events on the compute stream around dist.all_reduce(arena.buf) (includes the wait for the "
                                      "collective's stream); bus = 2(n-1)/n * bytes / time"}
@@ -1070,6 +1104,16 @@ def per_rank_proxy(args, device):
             "replay_equals_eager": info.get("replay_equals_eager"),
             "kernels_us_per_layer": {k: v.get("us_per_layer") for k, v in (info.get("kernels") or {}).items() if isinstance(v, dict)},
             "allreduce_model_ms": {"ring_one_link": ring * 1e3, "all_links": direct * 1e3},
+            "allreduce": {"range_ms": [direct * 1e3, ring * 1e3],
+                          "source": "MODELLED, never measured on RCCL (no multi-GPU node in the builder's pool): low = reduce-scatter + all-gather over "
+                                    "all 7 xGMI links at %.0f GB/s each, high = a ring bound by one link; the whole term is the projection's "
+                                    "error bar" % XGMI_LINK_GBS,
+                          "functional_only": "two ranks SHARING one GPU over gloo run the same code path end to end "
+                                             "(profiles/r04_bench_2ranks_sharing_one_gpu_gloo.json, tests/test_gpu_multi.py): correctness of the "
+                                             "one-collective step, no statement about RCCL / xGMI time",
+                          "measured_when_available": "bench.py --leg train --gpus N > 1 reports extra-free: allreduce.us (median) / us_min / "
+                                                     "us_p10 / us_p90 / us_max per step, frac_of_step, bus_GBps and RCCL's own INIT / GRAPH "
+                                                     "lines (allreduce.rccl)"},
             "projected_8gpu_points_per_s": {"ring_one_link": 64 * args.points / (t + ring), "all_links": 64 * args.points / (t + direct)},
             "global_batch": 64, "collectives": 1}
     except Exception as e:       # noqa: BLE001

@@ -17,22 +17,26 @@ def parse(path):
     return out
 
 
-def main(pmc_dir, tag, out_json):
+def main(pmc_dir, tag, out_json, source=None):
     vals = {}
     for f in sorted(os.listdir(pmc_dir)):
         if f.endswith(".txt"):
             vals.update(parse(os.path.join(pmc_dir, f)))
     res = json.load(open(out_json)) if os.path.exists(out_json) else {}
-    names = {"flow_kernel": "flow_kernel", "nnm_kernel": "nnm_kernel", "nn_kernel": "nn_kernel", "film_kernel": "film_kernel"}
+    # (longest name first: "flow16s_kernel" also contains "flow16_kernel"-like prefixes of nothing, but "nn_small_kernel" / "nn_kernel" do overlap)
+    names = ["flow16s_kernel", "flow16_kernel", "flow_kernel", "nnm_kernel", "nn_small_kernel", "nn_kernel", "film_kernel"]
     for (k, c), v in vals.items():
         for short in names:
-            if short in k and "pack_" not in k:
+            if short in k and "pack" not in k:
                 e = res.setdefault("%s/%s" % (short, tag), {})
+                if source:
+                    e["source"] = source
                 if c == "FETCH_SIZE":
                     e["fetch_bytes_raw"] = v * 1024
                     e["fetch_bytes"] = v * 1024 * 2          # gfx950: 128-B requests tallied at 64 B
                 else:
                     e["write_bytes"] = v * 1024
+                break
     for e in res.values():
         if isinstance(e, dict) and "fetch_bytes" in e and "write_bytes" in e:
             e["hbm_bytes"] = e["fetch_bytes"] + e["write_bytes"]
@@ -41,4 +45,4 @@ def main(pmc_dir, tag, out_json):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3])
+    main(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None)

@@ -16,7 +16,7 @@ rm -rf $OUT/kt
 cd $GRAFT_REPO_ROOT
 bash tools/pmc_run.sh ${TAG}_prof/pmc > /dev/null 2>&1
 cp profiles/traffic.json $OUT/traffic.json 2>/dev/null
-python3 tools/pmc_traffic.py $OUT/pmc B32_N2048_L14_f16x3 $OUT/traffic.json > /dev/null 2>&1
+python3 tools/pmc_traffic.py $OUT/pmc B32_N2048_L14_f16x3 $OUT/traffic.json "profiles/${TAG}_pmc_pass4.txt + ${TAG}_pmc_pass5.txt" > /dev/null 2>&1
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python3 bench.py --layers 63 --no-extra --no-cpu-baseline > $OUT/bench_L63.json 2>> $OUT/bench_default.err
 python3 bench.py --layers 15 --no-extra --no-cpu-baseline > $OUT/bench_L15.json 2>> $OUT/bench_default.err
@@ -30,4 +30,10 @@ ls -la $OUT $OUT/train
 # passes of the 16-point-tile stack (csrc/flow16.hip) and the small-batch Chamfer scan
 bash tools/kt_run.sh ${TAG}_prof/kernel_trace_stats_b4 --batch 4 --no-cpu-baseline --no-extra --pipelined 0 --steps 300 --warmup 50 --settle 100 > /dev/null 2>&1
 bash tools/pmc_run.sh ${TAG}_prof/pmc_b4 --batch 4 > /dev/null 2>&1
+python3 tools/pmc_traffic.py $OUT/pmc_b4 B4_N2048_L14_f16x3 $OUT/traffic.json "profiles/${TAG}_pmc_b4_pass4.txt + ${TAG}_pmc_b4_pass5.txt" > /dev/null 2>&1
+# r05: the rank-sized training step (B = 8, G = 512) and the phase stamps of the training kernels
+python3 bench.py --leg train --batch 8 --latent 512 --steps 40 --warmup 12 > $OUT/bench_train_B8_G512.json 2>> $OUT/bench_default.err
+(cd dpf_nets_amd/csrc && make -s prof > /dev/null 2>&1)
+python3 tools/train_kprof.py > $OUT/train_kprof.txt 2>&1
+python3 tools/train_phase_prof.py > $OUT/train_phase_prof.txt 2>&1
 ls -la $OUT
