@@ -13,7 +13,7 @@ in one more launch; the EMD entry point needs a dense batch, so only that operan
 is no CPU or tensor-op fallback in this package, so both values of the flag run the exact HIP Chamfer."""
 import torch
 
-from ..networks.utils import distChamferCUDA, emd_approx, chamfer_per_cloud  # noqa: F401
+from ..networks.utils import distChamferCUDA, emd_approx, chamfer_per_cloud, chamfer_cd_per_cloud  # noqa: F401
 from .._lib import lib, check, current_stream
 
 
@@ -23,8 +23,12 @@ def EMD_CD(sample_pcs, ref_pcs, batch_size, accelerated_cd=False, reduced=True):
     cd_lst = []
     for b_start in range(0, N_sample, batch_size):
         b_end = min(N_sample, b_start + batch_size)
-        dl, dr = distChamferCUDA(sample_pcs[b_start:b_end].contiguous(), ref_pcs[b_start:b_end].contiguous())
-        cd_lst.append(chamfer_per_cloud(dl, dr))                       # dl.mean(1) + dr.mean(1), one launch
+        smp, ref = sample_pcs[b_start:b_end].contiguous(), ref_pcs[b_start:b_end].contiguous()
+        if smp.is_cuda and smp.dtype == torch.float32 and ref.dtype == torch.float32 and not (torch.is_grad_enabled() and (smp.requires_grad or ref.requires_grad)):
+            cd_lst.append(chamfer_cd_per_cloud(smp, ref))              # search + dl.mean(1) + dr.mean(1): ONE launch (ChamferEvaluator)
+        else:
+            dl, dr = distChamferCUDA(smp, ref)
+            cd_lst.append(chamfer_per_cloud(dl, dr))                   # dl.mean(1) + dr.mean(1), one more launch
     cd = torch.cat(cd_lst).mean() if reduced else torch.cat(cd_lst)
     return {"MMD-CD": cd}
 

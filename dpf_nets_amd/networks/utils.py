@@ -29,6 +29,43 @@ def chamfer_per_cloud(dl, dr):
     return cd
 
 
+class ChamferEvaluator:
+    """The evaluation loop's Chamfer call (evaluating.py:110-113: `nn_distance` both ways, then `dl.mean(1) + dr.mean(1)`) as
+    ONE launch per batch: distances, indices and the per-cloud CD from the search kernel's own workgroups (NNDistanceCD).  The
+    evaluator OWNS the scratch that call needs -- one CDWorkspace per (batch shape, device, stream), created outside any stream
+    capture, as the interface's ownership rule asks (StructuralLossesBackend.CDWorkspace) -- so a caller that keeps one
+    evaluator per evaluation loop gets the single-launch path with nothing cached behind its back.  r05: the
+    package's own evaluation helpers (metrics.evaluation_metrics.EMD_CD, chamfer_cd_per_cloud) and bench.py's step go through
+    this class; before, only the benchmark created a workspace."""
+
+    def __init__(self):
+        self._ws = {}
+
+    def __call__(self, pred, true):
+        """(B, n, 3), (B, m, 3) contiguous CUDA tensors -> dist1, idx1, dist2, idx2, cd (B,)"""
+        from ..metrics.StructuralLosses import StructuralLossesBackend as BK
+        key = (pred.shape[0], pred.shape[1], true.shape[1], pred.device, torch.cuda.current_stream(pred.device).cuda_stream)
+        ws = self._ws.get(key)
+        if ws is None and not torch.cuda.is_current_stream_capturing():
+            ws = self._ws[key] = BK.CDWorkspace(key[0], key[1], key[2], pred.device)
+        return BK.NNDistanceCD(pred, true, ws)        # (no workspace while capturing a first call: fresh scratch, tickets cleared in-call)
+
+    def cd(self, pred, true):
+        return self(pred, true)[4]
+
+
+_default_evaluator = None
+
+
+def chamfer_cd_per_cloud(pred, true):
+    """(B,) Chamfer distance of each pair of clouds, cd[b] = dist1[b].mean() + dist2[b].mean(), in one launch (no autograd:
+    the evaluation path).  Uses a process-wide ChamferEvaluator; loops that run on several streams should keep their own."""
+    global _default_evaluator
+    if _default_evaluator is None:
+        _default_evaluator = ChamferEvaluator()
+    return _default_evaluator.cd(pred, true)
+
+
 def f_score(predicted_clouds, true_clouds, threshold=0.001):
     """lib/networks/utils.py:38-42.  Without autograd the thresholds, means and the F1 formula are one launch over the two
     distance rows (dpf_fscore_reduce: integer counts, the float arithmetic in the reference's order)."""

@@ -470,6 +470,31 @@ def test_nndistance_cd_fused_reduction():
         BK.NNDistanceCD(ta, tb, BK.CDWorkspace(B + 1, n, m, ta.device))
 
 
+def test_package_evaluation_path_is_the_single_launch_cd():
+    """the fused search + CD call must be what the package's own evaluation helpers run, not a benchmark-only path.
+    networks.utils.ChamferEvaluator owns a CDWorkspace per (shape, stream); metrics.evaluation_metrics.EMD_CD and
+    chamfer_cd_per_cloud go through it and return the bits of an explicit NNDistanceCD call with a caller-owned workspace."""
+    BK = _gpu()
+    from dpf_nets_amd.networks.utils import ChamferEvaluator, chamfer_cd_per_cloud
+    from dpf_nets_amd.metrics.evaluation_metrics import EMD_CD
+    B, n, m = 12, 2048, 2048
+    a, b = chamfer_inputs(4242, B, n, m)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    want = BK.NNDistanceCD(ta, tb, BK.CDWorkspace(B, n, m, ta.device))
+    ev = ChamferEvaluator()
+    for _ in range(3):
+        got = ev(ta, tb)
+        for x, y in zip(got, want):
+            assert torch.equal(x, y)
+    (ws,) = ev._ws.values()                                               # one workspace for the one (shape, stream), reused
+    assert ws.shape == (B, n, m) and not ws.dirty and int(ws.tickets().abs().sum()) == 0
+    assert torch.equal(chamfer_cd_per_cloud(ta, tb), want[4])
+    res = EMD_CD(ta, tb, batch_size=B, reduced=False)["MMD-CD"]
+    assert torch.equal(res, want[4])
+    res2 = EMD_CD(ta, tb, batch_size=5, reduced=False)["MMD-CD"]           # ragged batches: three shapes, three workspaces
+    assert torch.allclose(res2, want[4], rtol=2e-6, atol=0)
+
+
 @pytest.mark.parametrize("B", [32, 4])
 def test_nndistance_cd_ticket_finish_under_load(B):
     """The in-kernel finish of dpf_nndistance_cd reads other workgroups' sums (other CUs, other XCDs, lines that held the
