@@ -72,6 +72,12 @@ __global__ __launch_bounds__(256) void pack_kernel(int G, const float *__restric
     const float *cl = canon + (size_t)l * c_layer_floats(G);
     uint8_t *out = packed + (size_t)l * p_layer_bytes(NS);
     uint16_t *o16 = (uint16_t *)out;
+    __shared__ float scratch[256];
+    float wsc[2] = {1.0f, 1.0f};                  // F16: the power of two of each branch's W1 (flow_common.h: w1_pow2_scale)
+    if (F16) {
+        wsc[0] = w1_pow2_scale(cl + 0 * c_branch_floats(G) + C_W1, scratch);
+        wsc[1] = w1_pow2_scale(cl + 1 * c_branch_floats(G) + C_W1, scratch);
+    }
     // A1: W1 in fragment order.  Element j of lane (i, h), k-step s, M-tile t':
     //   W1[32t'+i][feat(s, j, h)],  feat = 32*(s>>1) + (r&3) + 8*(r>>2) + 4h,  r = 8*(s&1) + j
     // -- the feature a lane of the h0 accumulator fragment holds in register r of tile s>>1.
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(256) void pack_kernel(int G, const float *__restric
         const int i = lane & 31, h = lane >> 5;
         const int r = 8 * (s & 1) + j;
         const int fi = 32 * (s >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float w = cl[br * c_branch_floats(G) + C_W1 + (32 * tp + i) * 64 + fi];
+        const float w = cl[br * c_branch_floats(G) + C_W1 + (32 * tp + i) * 64 + fi] * (br ? wsc[1] : wsc[0]);
         if (F16) {                     // fp16 hi (RNE) + fp16 of the exact remainder: 22 significant bits
             const _Float16 wh = (_Float16)w;
             const _Float16 wl = (_Float16)(w - (float)wh);
@@ -127,9 +133,12 @@ __global__ __launch_bounds__(256) void pack_kernel(int G, const float *__restric
 __host__ __device__ constexpr int fw_sub_floats(int G) { return 64 * G + 128 + 4096 + 64; }
 __host__ __device__ constexpr size_t fw_total_floats(int L, int G) { return (size_t)L * 4 * fw_sub_floats(G) + (size_t)L * 2 * 320; }
 
-__global__ __launch_bounds__(256) void pack_film_kernel(int L, int G, const float *__restrict__ canon, float *__restrict__ fw) {
+__global__ __launch_bounds__(256) void pack_film_kernel(int L, int G, const float *__restrict__ canon, float *__restrict__ fw, int f16) {
     const int l = blockIdx.x >> 2, br = (blockIdx.x >> 1) & 1, sub = blockIdx.x & 1;
     const float *cb = canon + (size_t)l * c_layer_floats(G) + br * c_branch_floats(G);
+    __shared__ float scratch[256];
+    // f16x3: the branch's W1 is packed times 2^k (pack_kernel) -- the output SharedDot's rows carry 2^-k from here on, D gets 2^k in film_kernel
+    const float wsc = (f16 && sub == 0) ? w1_pow2_scale(cb + C_W1, scratch) : 1.0f;
     const float *cf = cb + C_FILM + sub * c_film_floats(G);
     const float *Wf0 = cf, *bnf = cf + 64 * G, *Wf1 = bnf + 256, *bf1 = Wf1 + 4096;
     float *o = fw + (size_t)blockIdx.x * fw_sub_floats(G);
@@ -149,9 +158,10 @@ __global__ __launch_bounds__(256) void pack_film_kernel(int L, int G, const floa
         const float s1 = 1.0f / sqrtf(cb[C_BN1 + 64 + f] + BN_EPS);
         c[f] = s1;
         c[64 + f] = -cb[C_BN1 + f] * s1;
-        c[128 + f] = cb[C_W2 + f];
-        c[192 + f] = cb[C_W2 + 64 + f];
+        c[128 + f] = cb[C_W2 + f] * (1.0f / wsc);
+        c[192 + f] = cb[C_W2 + 64 + f] * (1.0f / wsc);
         if (f < 2) c[256 + f] = cb[C_B2 + f];
+        if (f == 2) c[258] = wsc;
     }
 }
 
@@ -182,6 +192,7 @@ __global__ __launch_bounds__(512) void film_kernel(int L, int B, int G, const fl
     const float *cst = fw + (size_t)L * 4 * fw_sub_floats(G) + (size_t)(l * 2 + br) * 320;
     const float bn_a = sc[f], bn_d = sh[f], bias1 = bf1[f];
     const float s1 = cst[f], t1 = cst[64 + f], w2a = cst[128 + f], w2b = cst[192 + f], b2v = cst[256 + (f & 1)];
+    const float wsc = cst[258];                  // f16x3: 2^k of this branch's packed W1 (1 otherwise); w2a / w2b already carry 2^-k
     float acc[FILM_CLOUDS];
 #pragma unroll
     for (int c = 0; c < FILM_CLOUDS; ++c) acc[c] = 0.f;
@@ -261,7 +272,7 @@ __global__ __launch_bounds__(512) void film_kernel(int L, int B, int G, const fl
         const float a = flow_eps + expf(v[cc]);
         const float FA = a * s1, FC = a * t1 + cbx[c * 64 + f];
         float *o = film + ((size_t)l * B + b) * (FILM_BYTES / 4) + br * FILM_BR_FLOATS;
-        o[f] = FC / FA;
+        o[f] = (FC / FA) * wsc;
         o[64 + f] = w2a * FA;
         o[128 + f] = w2b * FA;
         if (f < 2) film[((size_t)l * B + b) * (FILM_BYTES / 4) + FILM_B2_OFF + br * 2 + f] = b2v;
@@ -996,7 +1007,7 @@ extern "C" int dpf_flow_pack(int n_layers, int G, int precision, const float *ca
     if (precision == DPF_PREC_F16X3)
         if (int rc = flow16_pack(n_layers, G, canon, (uint8_t *)packed + (size_t)n_layers * p_layer_bytes(ns), s)) return rc;
     float *fw = (float *)((uint8_t *)packed + packed_frag_bytes(n_layers, precision));
-    hipLaunchKernelGGL(pack_film_kernel, dim3(n_layers * 4), dim3(256), 0, s, n_layers, G, canon, fw);
+    hipLaunchKernelGGL(pack_film_kernel, dim3(n_layers * 4), dim3(256), 0, s, n_layers, G, canon, fw, precision == DPF_PREC_F16X3 ? 1 : 0);
     return (int)hipGetLastError();
 }
 

@@ -54,11 +54,15 @@ __global__ __launch_bounds__(256) void pack16_kernel(int G, const float *__restr
     const int l = blockIdx.x;
     const float *cl = canon + (size_t)l * c16_layer_floats(G);
     uint16_t *o16 = (uint16_t *)(packed16 + (size_t)l * P16_LAYER);
+    __shared__ float scratch[256];
+    // the power of two of each branch's W1, as pack_kernel<2, true> (flow_common.h: w1_pow2_scale; the FiLM block carries its inverse)
+    const float wsc0 = w1_pow2_scale(cl + 0 * c16_branch_floats(G) + C16_W1, scratch);
+    const float wsc1 = w1_pow2_scale(cl + 1 * c16_branch_floats(G) + C16_W1, scratch);
     for (int idx = threadIdx.x; idx < 2 * 4 * 2 * 64 * 8; idx += blockDim.x) {       // [br][t'][s][lane][j]
         const int j = idx & 7, lane = (idx >> 3) & 63, s = (idx >> 9) & 1, tp = (idx >> 10) & 3, br = idx >> 12;
         const int i = lane & 15, g = lane >> 4;
         const int fi = 16 * (2 * s + (j >> 2)) + 4 * g + (j & 3);
-        const float w = cl[br * c16_branch_floats(G) + C16_W1 + (16 * tp + i) * 64 + fi];
+        const float w = cl[br * c16_branch_floats(G) + C16_W1 + (16 * tp + i) * 64 + fi] * (br ? wsc1 : wsc0);
         const _Float16 wh = (_Float16)w;                       // fp16 hi (RNE) + fp16 of the exact remainder, as pack_kernel<2, true>
         const _Float16 wl = (_Float16)(w - (float)wh);
         o16[idx] = __builtin_bit_cast(uint16_t, wh);

@@ -98,6 +98,26 @@ template <> struct Terms<3> {
     static constexpr int A[6] = {1, 2, 0, 1, 0, 0}, B[6] = {1, 0, 2, 0, 1, 0};
 };
 
+// r05: f16x3 packs W1 as fp16 hi + fp16 lo.  At the reference's init scale (|W1| ~ 0.04) the lo parts are fp16
+// SUBNORMALS (17-19 significant bits instead of 22), and a branch whose weights are small altogether loses the hi part too.
+// W1 is therefore packed times a power of two per (layer, branch) that puts its largest entry into [2^13, 2^14): hi AND lo of
+// every entry within 2^-11 of the largest are normal numbers.  The contraction then yields 2^k (h1 + D) -- the FiLM block
+// carries D 2^k and W2' 2^-k (exact scalings, made where the block is made: film_kernel / tfold_kernel) -- so the eval
+// kernels do not change, and the training kernels unscale where they take sums of the pre-activation.
+// Block-wide: every thread of a 256-thread block calls it with the same W1 (4096 floats); returns the scale in all threads.
+__device__ __forceinline__ float w1_pow2_scale(const float *__restrict__ W1, float *scratch /* 256 floats of LDS */) {
+    float m = 0.f;
+    for (int i = threadIdx.x; i < 4096; i += 256) m = fmaxf(m, fabsf(W1[i]));
+    __syncthreads();                               // (scratch may still be read from a previous call)
+    scratch[threadIdx.x] = m;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < 256; ++i) t = fmaxf(t, scratch[i]);        // every thread the same maximum
+    const int e = (int)((f2u(t) >> 23) & 0xFFu) - 127;             // t in [2^e, 2^(e+1))
+    const bool ok = t > 0.f && e > -100 && e < 100;                // (all zeros, denormal-tiny, Inf / NaN: no scaling)
+    return ok ? u2f((uint32_t)(127 + 13 - e) << 23) : 1.0f;
+}
+
 // One conditioner branch (logvar or mu) of one layer for one 32-point tile:
 // returns the two pre-activation outputs o_a, o_b of the branch (sum over this
 // lane-half's 32 features; the caller adds the other half).
