@@ -137,9 +137,12 @@ __global__ __launch_bounds__(256) void tpack_kernel(const float *__restrict__ tc
         const float *W1 = cl + br * T_BR + T_W1;
         float r1, r2;
         const float w = W1[(32 * tp + i) * 64 + fk];                // forward: rows = out feature, K = in feature
-        if (F16) {                     // fp16 hi (RNE) + fp16 of the exact remainder, as csrc/flow.hip pack_kernel<2, true>
-            const _Float16 wh = (_Float16)w;
-            const _Float16 wl = (_Float16)(w - (float)wh);
+        if (F16) {                     // fp16 hi (RNE) + fp16 of the exact remainder of W1 * 2^kw, as csrc/flow.hip pack_kernel<2, true> (r05: the
+            // forward fragments carry the same power of two as the W1^T fragments below; tfold_kernel puts D 2^kw and W2' 2^-kw
+            // into the layer's FiLM block, the statistics and pass 1 unscale their sums of the pre-activation, pass 2 its C1)
+            const float wsf = w * wscale[br];
+            const _Float16 wh = (_Float16)wsf;
+            const _Float16 wl = (_Float16)(wsf - (float)wh);
             o1[idx] = __builtin_bit_cast(uint16_t, wh);
             o1[P_A1_PART / 2 + idx] = __builtin_bit_cast(uint16_t, wl);
         } else if (NS == 2) {
@@ -635,6 +638,8 @@ __global__ __launch_bounds__(TW * 64) void tstats_h1_kernel(TArgs a, float *__re
     const int nc = valid ? n : N - 1;
     const float xa = pc[(size_t)a.ka * N + nc], xb = a.kb >= 0 ? pc[(size_t)a.kb * N + nc] : 0.f;
     asm volatile("" ::: "memory");
+    // f16x3: 2^-kw of each branch's packed W1 (the sums below are of 2^kw h1)
+    const float wsinv0 = F16 ? *(const float *)(a.packed_l + pt_tail(NS)) : 1.0f, wsinv1 = F16 ? *(const float *)(a.packed_l + pt_tail(NS) + 4) : 1.0f;
     const StageRegs<NS * P_A1_PART> wregs = stage_load<NS * P_A1_PART>(a.packed_l, wave, lane);   // A1; the A0 fragments are folded right here
 #pragma unroll
     for (int k = 0; k < 4; ++k)                                           // pin the consumers of the moment rows BEHIND the weight loads' issue
@@ -675,6 +680,7 @@ __global__ __launch_bounds__(TW * 64) void tstats_h1_kernel(TArgs a, float *__re
             }
             s1 += __shfl_xor(s1, 32);
             s2 += __shfl_xor(s2, 32);
+            if constexpr (F16) { const float u = br ? wsinv1 : wsinv0; s1 *= u; s2 *= u * u; }      // back to h1's scale (exact)
             if (!h) {
                 acc_s[wave][br][0][32 * t + pl] = s1;
                 acc_s[wave][br][1][32 * t + pl] = s2;
@@ -699,10 +705,13 @@ __global__ __launch_bounds__(TW * 64) void tstats_h1_kernel(TArgs a, float *__re
 // One launch instead of a column-sum launch + a fold launch (a dependent tiny launch costs ~4.5 us): workgroup k owns 16
 // features of one branch -- its 32 columns (sum, sum of squares) are summed exactly as tcolsum_kernel does (32 row groups,
 // then the groups in order, doubles), then its threads fold (cloud, feature) items for all B clouds.
+// wtail (f16x3; else NULL): [br] 2^-kw of the layer's packed W1 -- the eval block then carries D 2^kw and W2' 2^-kw, and the sums of
+// tstats_h1 arrive already unscaled
 __global__ __launch_bounds__(1024) void tfold_kernel(double count, int nrows, const float *__restrict__ part,
                                                      const float *__restrict__ tcanon_l, const float *__restrict__ fm_l,
                                                      int B, float eps, float *__restrict__ stats_l,
-                                                     float *__restrict__ film_l, float *__restrict__ filmb_l) {
+                                                     float *__restrict__ film_l, float *__restrict__ filmb_l,
+                                                     const float *__restrict__ wtail) {
     __shared__ double acc[32][33];
     __shared__ double tot[32];
     const int br = blockIdx.x >> 2, f0 = (blockIdx.x & 3) * 16;
@@ -710,6 +719,7 @@ __global__ __launch_bounds__(1024) void tfold_kernel(double count, int nrows, co
     // r03: the fold's own operands (this step's FiLM vectors, W2 rows) do not depend on the column sums: requested first, so
     // that the kernel is ONE global round trip deep instead of two
     float pre_cw = 0.f, pre_cb = 0.f, pre_w2a = 0.f, pre_w2b = 0.f;
+    const float wsinv = wtail != nullptr ? wtail[br] : 1.0f, wsc = 1.0f / wsinv;      // (powers of two: exact)
     if ((int)threadIdx.x < B * 16) {
         const int b = threadIdx.x >> 4, f = f0 + (threadIdx.x & 15);
         pre_cw = fm_l[((size_t)(br * 2 + 0) * B + b) * 64 + f]; pre_cb = fm_l[((size_t)(br * 2 + 1) * B + b) * 64 + f];
@@ -757,9 +767,9 @@ __global__ __launch_bounds__(1024) void tfold_kernel(double count, int nrows, co
         const float av = eps + expf(cw);
         const float FA = av * rstd, FC = -av * (float)mean * rstd + cb;
         float *o = film_l + (size_t)b * (FILM_BYTES / 4) + br * FILM_BR_FLOATS;
-        o[f] = FC / FA;
-        o[64 + f] = w2a_v * FA;
-        o[128 + f] = w2b_v * FA;
+        o[f] = (FC / FA) * wsc;
+        o[64 + f] = (w2a_v * FA) * wsinv;
+        o[128 + f] = (w2b_v * FA) * wsinv;
         if (f < 2) film_l[(size_t)b * (FILM_BYTES / 4) + FILM_B2_OFF + br * 2 + f] = cbp[T_B2 + f];
         float *ob = filmb_l + (size_t)b * FB_CLOUD + br * FB_BR;
         ob[0 * 64 + f] = av;
@@ -1044,6 +1054,8 @@ __global__ __launch_bounds__(TW * 64, BSPLIT ? 2 : 4) void tbwd1_kernel(TArgs a,
     // every load of the prologue is requested here, in the order its consumer comes: the pass-3 totals (above), this thread's
     // point (inputs, the layer's stored outputs, the gradients that reach it), then the weights -- one in-order stream
     const float w2_v = threadIdx.x < 256 ? a.tcanon_l[(threadIdx.x >> 7) * T_BR + T_W2 + (threadIdx.x & 127)] : 0.f;
+    // f16x3: 2^-kw of each branch's packed W1 (the recomputed pre-activations below are 2^kw (h1 + D))
+    const float wsinv0 = F16 ? *(const float *)(a.packed_l + pt_tail(NS)) : 1.0f, wsinv1 = F16 ? *(const float *)(a.packed_l + pt_tail(NS) + 4) : 1.0f;
     const int N = a.N, n = (blockIdx.x * TW + wave) * TILE + pl;
     const bool valid = n < N;
     const int nc = valid ? n : N - 1;
@@ -1216,6 +1228,7 @@ __global__ __launch_bounds__(TW * 64, BSPLIT ? 2 : 4) void tbwd1_kernel(TArgs a,
                 s1 = __builtin_fmaf(db, rp, s1);
                 s3 += dh2a_of(pre[t][r], w2a, w2b, da, db);                                    // dc = sum dh2a,  dh2a = [pa > 0] sum_w W2[w]*do_w
             }
+            if constexpr (F16) { const float u = br ? wsinv1 : wsinv0; s0 *= u; s1 *= u; }     // sums of do * relu(2^kw pa): back to pa's scale (exact)
             float s2 = rstd1 * (w2a * s0 + w2b * s1) - ca * s3;                                // da = sum dh2a * h1n,  h1n = pa * rstd1 - c/a
             s0 *= fa; s1 *= fa;
             s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32); s3 += __shfl_xor(s3, 32);
@@ -1776,7 +1789,7 @@ __global__ __launch_bounds__(TW * 64) void tbwd2_kernel(TArgs a, MeansJob mj, do
                 const int fo = 32 * t + pl;                                 // this lane's feature (swapped orientation)
                 const float rstd1 = filmb[br * FB_BR + 2 * 64 + fo], ca = filmb[br * FB_BR + 3 * 64 + fo];
                 const float m1 = s12s[br * 128 + fo], m2 = s12s[br * 128 + 64 + fo];
-                const float C1 = -(rstd1 * rstd1) * m2, C0 = rstd1 * (ca * m2 - m1);
+                const float C1 = -(rstd1 * rstd1) * m2 * winv, C0 = rstd1 * (ca * m2 - m1);     // (pre is 2^kw pa for f16x3: C1 carries 2^-kw)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) pre[t][r] = __builtin_fmaf(pre[t][r], C1, pre[t][r] > 0.f ? G[r] : C0);
             }
@@ -2209,7 +2222,7 @@ static int prepare_layer(int B, int N, int ka, int kb, const float *tcanon_l, vo
                        (uint8_t *)packed_l + pt_a0(NS)); }
     { KScope ks(2, s);
     hipLaunchKernelGGL(tfold_kernel, dim3(8), dim3(1024), 0, s, count, (int)(grid.x * grid.y), w.part1, tcanon_l, fm_l, B, flow_eps,
-                       stats_l, film_l, film_l + (size_t)B * 512); }
+                       stats_l, film_l, film_l + (size_t)B * 512, F16 ? (const float *)((const uint8_t *)packed_l + pt_tail(NS)) : nullptr); }
     return (int)hipGetLastError();
 }
 
