@@ -29,6 +29,7 @@ SIGNATURES = {
     "dpf_nndistancegrad": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dpf_approxmatch": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dpf_approxmatch_workspace_bytes": (_sz, [_i, _i, _i]),
+    "dpf_emd_set_matrix_path": (_i, [_i]),
     "dpf_approxmatch_ws": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpf_approxmatch_cost_ws": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpf_matchcost": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -15,6 +15,7 @@
 // without reading, which replaces the reference's zero-fill, approxmatch.cu:16-17).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "dpf_hip.h"
@@ -25,6 +26,7 @@
 namespace {
 
 constexpr int MAXS = 16;   // max inner-loop slices (waves) per workgroup
+constexpr int NLEVEL = 9;  // annealing levels j = 7 .. -1 (approxmatch.cu:24)
 
 // Explicit fma / rn intrinsics: the read-modify-write and the deferred paths of approxmatch
 // must produce the same bits, so nothing here is left to the compiler's contraction heuristics.
@@ -193,7 +195,17 @@ __device__ __forceinline__ void stream_records(const u64 *__restrict__ C, int jb
 constexpr int PPW = 128;   // points per wave in the deferred kernels
 
 // (xyz2, multiR) records for the first ratio pass
-__global__ void emd_pack_init_kernel(int m, float multiR, const float *__restrict__ xyz2, float4 *__restrict__ c2a, size_t pstride) {
+// `gate`: the deferred path comes in two families -- these packed-VALU kernels (difference-form d^2, bit-identical to the
+// read-modify-write path) and the matrix-core passes further down (expanded-form d^2).  Which one runs is decided ON THE DEVICE
+// (emd_mfma_prep_kernel looks at the coordinates' range), so both families are launched and every kernel of the family that is
+// not wanted returns at once: gate == nullptr -> always run, else run iff *gate == want.
+__device__ __forceinline__ bool gate_closed(const unsigned *gate, unsigned want) {
+    return gate != nullptr && __builtin_nontemporal_load(gate) != want;
+}
+
+__global__ void emd_pack_init_kernel(int m, float multiR, const float *__restrict__ xyz2, float4 *__restrict__ c2a, size_t pstride,
+                                     const unsigned *gate) {
+    if (gate_closed(gate, 1u)) return;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
     const float *q = xyz2 + ((size_t)blockIdx.y * m + j) * 3;
@@ -201,7 +213,8 @@ __global__ void emd_pack_init_kernel(int m, float multiR, const float *__restric
 }
 
 // remainL = multiL, remainR = multiR                       approxmatch.cu:6-12,18-21
-__global__ void emd_init_kernel(int n, int m, float multiL, float multiR, float *__restrict__ temp) {
+__global__ void emd_init_kernel(int n, int m, float multiL, float multiR, float *__restrict__ temp, unsigned *flag) {
+    if (flag != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *flag = 0u;
     float *t = temp + (size_t)blockIdx.y * (n + m) * 2;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n + m; i += gridDim.x * blockDim.x)
         t[i] = i < n ? multiL : multiR;
@@ -298,7 +311,6 @@ __global__ __launch_bounds__(1024) void emd_match_kernel(int n, int m, float lvl
 // association equals the reference's repeated `match += w`, approxmatch.cu:155) of
 // exp(level*d^2) * ratioL_level[k] * ratioR_level[l].  One 4-byte write per pair instead of a
 // read-modify-write per level: HBM traffic 4*n*m instead of 68*n*m bytes per cloud.
-constexpr int NLEVEL = 9;
 struct Levels { float lvl2[NLEVEL]; };
 
 // ---- the deferred path's kernels (two points per lane; see the note above bsub) -------------------------------
@@ -308,8 +320,9 @@ struct Levels { float lvl2[NLEVEL]; };
 template <int PASS>
 __global__ __launch_bounds__(1024) void emd_ratio2_kernel(int n, int m, float lvl2, const float *__restrict__ xyz1,
                                                           const float *__restrict__ xyz2, float *temp, float *rbase,
-                                                          size_t rstride, float4 *pk, size_t pstride) {
+                                                          size_t rstride, float4 *pk, size_t pstride, const unsigned *gate) {
     __shared__ float part[MAXS][PPW];
+    if (gate_closed(gate, 1u)) return;
     const int bi = blockIdx.y;
     const int lane = threadIdx.x, slice = __builtin_amdgcn_readfirstlane(threadIdx.y), S = blockDim.y;
     float *t = temp + (size_t)bi * (n + m) * 2;
@@ -357,8 +370,9 @@ __global__ __launch_bounds__(1024) void emd_ratio2_kernel(int n, int m, float lv
 
 __global__ __launch_bounds__(1024) void emd_match2_kernel(int n, int m, float lvl2, const float *__restrict__ xyz1,
                                                           float *temp, const float *rbase, size_t rstride,
-                                                          const float4 *pk, size_t pstride) {
+                                                          const float4 *pk, size_t pstride, const unsigned *gate) {
     __shared__ float part[MAXS][PPW];
+    if (gate_closed(gate, 1u)) return;
     const int bi = blockIdx.y;
     const int lane = threadIdx.x, slice = __builtin_amdgcn_readfirstlane(threadIdx.y), S = blockDim.y;
     float *remainL = temp + (size_t)bi * (n + m) * 2;
@@ -389,9 +403,451 @@ __global__ __launch_bounds__(1024) void emd_match2_kernel(int n, int m, float lv
     }
 }
 
+
+// ---- the deferred path on the matrix cores (r05) -----------------------------------------------------------------------
+// Six of the eight packed instructions per candidate above are the squared distance.  Expanded,
+//     -4^j log2(e) |q - p|^2  =  -4^j |q'|^2 - 4^j |p'|^2 + 2 * 4^j q'.p',      q' = sqrt(log2 e) (q - c),
+// it is a K = 15 contraction and ONE v_mfma_f32_32x32x16_f16 hands a wave the exp2 arguments of 32 x 32 pairs:
+//   slots 0..8    per coordinate (Qh, Qh, Ql) x (Ph, Pl, Ph): fp16 hi + lo of 512 q' and of 64 p' (22 bits each; lo*lo dropped)
+//   slots 9..11   three fp16 parts of -128 |q'|^2  x  128          (the norms are formed in double: exact to fp32 and beyond)
+//   slots 12..14  -128  x  three fp16 parts of 128 |p'|^2
+// The records are level-independent and carry the STEEPEST level's scale (4^7: every lo part a normal fp16 number where the
+// exponent's absolute error matters most); level j's 4^(j-7) is a power of two <= 1 and goes onto the candidates' fragment
+// with four exact v_pk_mul_f16 (down to 2^-14, the rest onto the own points' fragments once per kernel) -- lo parts that
+// fall into the subnormals there cost < 2e-6 absolute in the exponent.  c is cloud 1's centroid (the expanded form's cancellation error grows with |q'|^2; centring keeps it at the
+// cloud's own radius).  What is left per pair is exp2 and one FMA with the candidate's weight -- 32 VALU instructions per 1024
+// pairs where the packed form issues 80.  Pass 3 of level j and pass 1 of level j-1 walk the same pairs (cloud 1's points past
+// cloud 2's) and are ONE launch -- 20 launches for the 27 passes.
+// Accuracy (tests/diag/emd_expanded_form_error.py, CPU, same auction with only d^2 exchanged; n = m = 1024, centred and
+// uncentred clouds, uniform and near-pair): cost within 2.4e-6 of the difference form's (contract 1e-4), matching entries
+// within 8.5e-4 of their maximum 1.0 (the auction amplifies any last-bit change that much: the fp32-exact expanded form
+// measures the same as the fp16 hi/lo one).  The results are NOT bit-identical to the read-modify-write path; the packed-VALU
+// family above still is and stays the path for coordinates outside the fp16 range (|q'|^2 > 500 after centring, or not
+// finite), chosen per call on the device (gate), and for dpf_emd_set_matrix_path(0).
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16acc __attribute__((ext_vector_type(16)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+constexpr int MT = 4;            // 32-point tiles per wave
+constexpr int MPW = 32 * MT;     // points per wave / workgroup
+constexpr int MSL = 8;           // max candidate slices (waves) per workgroup
+constexpr float EMD_MFMA_R2MAX = 500.f;   // |q'|^2 bound: 128 * 500 = 64 000 < 65 504 (and 512 |q'| < 11 500)
+
+__device__ __forceinline__ int round_up(int v, int q) { return (v + q - 1) / q * q; }
+
+// One workgroup per cloud: cloud 1's centroid (fixed-order sums) and whether every centred, scaled point of both clouds fits
+__global__ __launch_bounds__(1024) void emd_mfma_prep_kernel(int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+                                                             float *__restrict__ meta, unsigned *flag) {
+    __shared__ float red[3][1024];
+    const int bi = blockIdx.x, tid = threadIdx.x;
+    const float *p1 = xyz1 + (size_t)bi * n * 3, *p2 = xyz2 + (size_t)bi * m * 3;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int i = tid; i < n; i += 1024) { sx += p1[i * 3 + 0]; sy += p1[i * 3 + 1]; sz += p1[i * 3 + 2]; }
+    red[0][tid] = sx; red[1][tid] = sy; red[2][tid] = sz;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; red[2][tid] += red[2][tid + o]; }
+        __syncthreads();
+    }
+    const float cx = red[0][0] / (float)n, cy = red[1][0] / (float)n, cz = red[2][0] / (float)n;
+    int bad = 0;
+    for (int i = tid; i < n + m; i += 1024) {
+        const float *q = i < n ? p1 + i * 3 : p2 + (i - n) * 3;
+        const float dx = q[0] - cx, dy = q[1] - cy, dz = q[2] - cz;
+        const float r2 = 1.44269504f * (dx * dx + dy * dy + dz * dz);
+        bad |= !(r2 <= EMD_MFMA_R2MAX);                 // also catches NaN / inf
+    }
+    bad = __syncthreads_or(bad);
+    if (tid == 0) {
+        meta[bi * 4 + 0] = cx; meta[bi * 4 + 1] = cy; meta[bi * 4 + 2] = cz; meta[bi * 4 + 3] = (float)bad;
+        if (bad) atomicOr(flag, 1u);
+    }
+}
+
+__device__ __forceinline__ void split2(double v, _Float16 &h, _Float16 &l) {
+    h = (_Float16)(float)v;
+    l = (_Float16)(float)(v - (double)(float)h);
+}
+__device__ __forceinline__ void split3(double v, _Float16 &h, _Float16 &mid, _Float16 &l) {
+    h = (_Float16)(float)v;
+    const double r = v - (double)(float)h;
+    mid = (_Float16)(float)r;
+    l = (_Float16)(float)(r - (double)(float)mid);
+}
+
+// Records of both roles for every point of both clouds, per cloud [cloud 1: NP | cloud 2: MP] (padded to whole 128-point
+// groups with zero records), the padded weight vectors per cloud [remainR (MP) | ratioL (NP)], zeros in every level's padded
+// ratioR vector rrpad[level][cloud][MP], and cloud 2's coordinates as planes c2soa[cloud][3][MP] (the materialisation's cost)
+__global__ void emd_mfma_pack_kernel(int n, int m, int NP, int MP, float multiR, const float *__restrict__ xyz1,
+                                     const float *__restrict__ xyz2, const float *__restrict__ meta, u4 *__restrict__ recA,
+                                     u4 *__restrict__ recB, float *__restrict__ wpad, float *__restrict__ rrpad,
+                                     float *__restrict__ c2soa, const unsigned *gate) {
+    if (gate_closed(gate, 0u)) return;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x, bi = blockIdx.y;
+    if (idx >= NP + MP) return;
+    const bool first = idx < NP;
+    const int k = first ? idx : idx - NP;
+    const bool live = k < (first ? n : m);
+    float *w = wpad + (size_t)bi * (NP + (size_t)MP);
+    if (first) w[MP + k] = 0.f;                                   // ratioL
+    else {
+        w[k] = live ? multiR : 0.f;                               // remainR
+        for (int j = 0; j < NLEVEL; ++j) rrpad[((size_t)j * gridDim.y + bi) * MP + k] = 0.f;      // every level's ratioR
+        const float *q = xyz2 + ((size_t)bi * m + (live ? k : 0)) * 3;
+        for (int u = 0; u < 3; ++u) c2soa[((size_t)bi * 3 + u) * MP + k] = live ? q[u] : 0.f;
+    }
+    _Float16 a[16], b[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { a[u] = (_Float16)0.f; b[u] = (_Float16)0.f; }
+    if (live) {
+        const float *q = (first ? xyz1 + ((size_t)bi * n + k) * 3 : xyz2 + ((size_t)bi * m + k) * 3);
+        const double S = 1.2011224087864498;                      // sqrt(log2 e)
+        double c[3], n2 = 0.0;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) { c[u] = ((double)q[u] - (double)meta[bi * 4 + u]) * S; n2 += c[u] * c[u]; }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            _Float16 h, l;
+            split2(c[u] * 512.0, h, l);
+            a[3 * u + 0] = h; a[3 * u + 1] = h; a[3 * u + 2] = l;
+            split2(c[u] * 64.0, h, l);
+            b[3 * u + 0] = h; b[3 * u + 1] = l; b[3 * u + 2] = h;
+        }
+        split3(-n2 * 128.0, a[9], a[10], a[11]);
+        b[9] = b[10] = b[11] = (_Float16)128.f;
+        a[12] = a[13] = a[14] = (_Float16)(-128.f);
+        split3(n2 * 128.0, b[12], b[13], b[14]);
+    }
+    u4 *oa = recA + ((size_t)bi * (NP + MP) + idx) * 2, *ob = recB + ((size_t)bi * (NP + MP) + idx) * 2;
+    u4 va[2], vb[2];
+    __builtin_memcpy(va, a, 32);
+    __builtin_memcpy(vb, b, 32);
+    oa[0] = va[0]; oa[1] = va[1];
+    ob[0] = vb[0]; ob[1] = vb[1];
+}
+
+struct MfmaArgs {
+    int n, m, NP, MP;
+    const u4 *recA, *recB;
+    float *temp, *wpad;
+    size_t rstride;          // per-cloud stride of a level's ratio slot [ratioL (n) | ratioR (m)]
+    const unsigned *gate;
+};
+
+// The three passes of a level must see THE SAME weight for a pair: pass 1 divides remainL by sum_l w remainR, pass 3 takes
+// sum_l w ratioL ratioR back off remainL -- for a point the level consumes entirely the two cancel, and what is left
+// (rounding) is divided by the next level's, possibly tiny, sum.  With weights that agree to 1e-7 that residue is harmless
+// (the packed-VALU kernels compute bit-identical d^2 in all passes); with weights that differ by the expanded form's 1e-3 at
+// the steep levels it grew to O(0.3) changes of the matching (measured, r05: a first version ran pass 2 with the clouds'
+// operand roles exchanged and pass 3 with (exp2 of the next level's exponent)^4).  Hence: cloud 2 is ALWAYS the A operand
+// (rows) and cloud 1 ALWAYS the B operand (columns), every pass of level j scales them by the same (fa_j, fb_j), and every
+// weight is exp2 of that MFMA's result -- the same bits in passes 1, 2 and 3.
+
+// fragments' accumulator register r of lane (half, col): row 8 (r / 4) + 4 half + r % 4, column col
+__device__ __forceinline__ float pick4(const float4 (&w)[4], int r) {
+    return r % 4 == 0 ? w[r / 4].x : r % 4 == 1 ? w[r / 4].y : r % 4 == 2 ? w[r / 4].z : w[r / 4].w;
+}
+__device__ __forceinline__ h8 scale8(u4 v, float f) {
+    const _Float16 fh = (_Float16)f;
+    return __builtin_bit_cast(h8, v) * h8{fh, fh, fh, fh, fh, fh, fh, fh};
+}
+__device__ __forceinline__ f16acc pair_exponents(h8 rows, h8 cols) {
+    const f16acc zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(rows, cols, zero, 0, 0, 0);
+}
+
+// Passes over cloud 1's points (columns; cloud 2's points stream past as row tiles with their weights):
+// MODE 0: pass 1          s_k = sum_l w remainR[l];                     ratioL[k] = remainL[k] / (1e-9 + s_k)
+// MODE 3: pass 3          s_k = sum_l w ratioR[l];                      remainL[k] = max(0, remainL[k] - ratioL[k] s_k)
+// MODE 2: pass 3 of level j, then pass 1 of level j-1 on the new remainL (two MFMAs and two exp2 per pair: saves a launch
+//         and the operand traffic, not arithmetic); (fa, fb) of level j, (fa2, fb) of level j-1
+// rb_cur / rb_next: the ratio slots of level j / j-1.
+template <int MODE>
+__global__ __launch_bounds__(64 * MSL) void emd_mfma_cols_kernel(MfmaArgs a, float fa, float fa2, float fb, float *rb_cur, float *rb_next,
+                                                                 const float *rrlev) {
+    __shared__ float part[MODE == 2 ? 2 : 1][MSL][MPW];
+    if (gate_closed(a.gate, 0u)) return;
+    const int bi = blockIdx.y, lane = threadIdx.x, slice = __builtin_amdgcn_readfirstlane(threadIdx.y), S = blockDim.y;
+    const int half = lane >> 5, col = lane & 31;
+    const size_t cloud = (size_t)bi * (a.NP + a.MP);
+    const u4 *ownrec = a.recB + (cloud + blockIdx.x * MPW) * 2;
+    const u4 *candrec = a.recA + (cloud + a.NP + col) * 2 + half;
+    float *wp = a.wpad + (size_t)bi * (a.NP + (size_t)a.MP);
+    float *remainR_p = wp, *ratioL_p = wp + a.MP;
+    const float *w0 = (MODE == 0 ? remainR_p : rrlev + (size_t)bi * a.MP) + 4 * half;   // rrlev: level j's padded ratioR
+    const float *w1 = remainR_p + 4 * half;                       // MODE 2's second weight
+    h8 bf[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) bf[t] = scale8(ownrec[(t * 32 + col) * 2 + half], fb);
+    const int tiles = round_up(a.m, 32) / 32;
+    const int tb = (int)((long)tiles * slice / S), te = (int)((long)tiles * (slice + 1) / S);
+    float sa[MT], sb[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) { sa[t] = 0.f; sb[t] = 0.f; }
+    if (tb < te) {
+        u4 af = candrec[(size_t)tb * 64];
+        float4 wa[4], wb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            wa[i] = *(const float4 *)(w0 + tb * 32 + 8 * i);
+            if (MODE == 2) wb[i] = *(const float4 *)(w1 + tb * 32 + 8 * i);
+        }
+        for (int ct = tb; ct < te; ++ct) {
+            const int nx = min(ct + 1, te - 1);
+            const u4 afn = candrec[(size_t)nx * 64];
+            float4 wan[4], wbn[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                wan[i] = *(const float4 *)(w0 + nx * 32 + 8 * i);
+                if (MODE == 2) wbn[i] = *(const float4 *)(w1 + nx * 32 + 8 * i);
+            }
+            const h8 as = scale8(af, fa), as2 = scale8(af, fa2);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const f16acc acc = pair_exponents(as, bf[t]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sa[t] = __builtin_fmaf(fast_exp2(acc[r]), pick4(wa, r), sa[t]);
+                if (MODE == 2) {
+                    const f16acc acc2 = pair_exponents(as2, bf[t]);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sb[t] = __builtin_fmaf(fast_exp2(acc2[r]), pick4(wb, r), sb[t]);
+                }
+            }
+            af = afn;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { wa[i] = wan[i]; if (MODE == 2) wb[i] = wbn[i]; }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        sa[t] += __shfl_xor(sa[t], 32);
+        if (MODE == 2) sb[t] += __shfl_xor(sb[t], 32);
+        if (half == 0) {
+            part[0][slice][t * 32 + col] = sa[t];
+            if (MODE == 2) part[MODE == 2 ? 1 : 0][slice][t * 32 + col] = sb[t];
+        }
+    }
+    __syncthreads();
+    float *remainL = a.temp + (size_t)bi * (a.n + a.m) * 2;
+    float *ratioL = rb_cur + (size_t)bi * a.rstride;
+    for (int tid = slice * 64 + lane; tid < MPW; tid += 64 * S) {
+        const int k = blockIdx.x * MPW + tid;
+        if (k >= a.n) continue;
+        float tot = 0.f, tot2 = 0.f;
+        for (int u = 0; u < S; ++u) {
+            tot += part[0][u][tid];
+            if (MODE == 2) tot2 += part[MODE == 2 ? 1 : 0][u][tid];
+        }
+        if (MODE == 0) {
+            const float r = remainL[k] / (1e-9f + tot);
+            ratioL[k] = r;
+            ratioL_p[k] = r;
+        } else {
+            const float rem = fmaxf(0.0f, remainL[k] - ratioL[k] * tot);
+            remainL[k] = rem;
+            if (MODE == 2) {
+                const float r = rem / (1e-9f + tot2);
+                rb_next[(size_t)bi * a.rstride + k] = r;
+                ratioL_p[k] = r;
+            }
+        }
+    }
+}
+
+// sum of v over the 32 lanes of the lane's half (every lane gets it)
+__device__ __forceinline__ float half_wave_sum(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16);
+    return v;
+}
+
+// Pass 2, over cloud 2's points -- which stay the ROWS: a wave owns MT row tiles (their A fragments), cloud 1's points stream
+// past as column tiles with ratioL (one weight per lane), the sums run along the accumulators' columns, i.e. across lanes:
+// per-lane partial sums for every (tile, register) and one butterfly per such sum at the end (~10 % of the loop at n = 8192).
+//   sumr = remainR[l] * sum_k w ratioL[k];  ratioR[l] = min(remainR[l] / (sumr + 1e-9), 1) * remainR[l];
+//   remainR[l] = max(0, remainR[l] - sumr)
+__global__ __launch_bounds__(64 * MSL) void emd_mfma_rows_kernel(MfmaArgs a, float fa, float fb, float *rb_cur, float *rrlev) {
+    __shared__ float part[MSL][MPW];
+    if (gate_closed(a.gate, 0u)) return;
+    const int bi = blockIdx.y, lane = threadIdx.x, slice = __builtin_amdgcn_readfirstlane(threadIdx.y), S = blockDim.y;
+    const int half = lane >> 5, col = lane & 31;
+    const size_t cloud = (size_t)bi * (a.NP + a.MP);
+    const u4 *ownrec = a.recA + (cloud + a.NP + blockIdx.x * MPW) * 2;
+    const u4 *candrec = a.recB + (cloud + col) * 2 + half;
+    float *wp = a.wpad + (size_t)bi * (a.NP + (size_t)a.MP);
+    float *remainR_p = wp, *ratioL_p = wp + a.MP, *ratioR_p = rrlev + (size_t)bi * a.MP;
+    h8 af[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) af[t] = scale8(ownrec[(t * 32 + col) * 2 + half], fa);
+    const int tiles = round_up(a.n, 32) / 32;
+    const int tb = (int)((long)tiles * slice / S), te = (int)((long)tiles * (slice + 1) / S);
+    float s[MT][16];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+    if (tb < te) {
+        u4 bfr = candrec[(size_t)tb * 64];
+        float w = ratioL_p[tb * 32 + col];
+        for (int ct = tb; ct < te; ++ct) {
+            const int nx = min(ct + 1, te - 1);
+            const u4 bfn = candrec[(size_t)nx * 64];
+            const float wn = ratioL_p[nx * 32 + col];
+            const h8 bs = scale8(bfr, fb);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const f16acc acc = pair_exponents(af[t], bs);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[t][r] = __builtin_fmaf(fast_exp2(acc[r]), w, s[t][r]);
+            }
+            bfr = bfn;
+            w = wn;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float tot = half_wave_sum(s[t][r]);
+            if (col == r) part[slice][t * 32 + 8 * (r / 4) + 4 * half + r % 4] = tot;
+        }
+    __syncthreads();
+    float *remainR = a.temp + (size_t)bi * (a.n + a.m) * 2 + a.n;
+    float *ratioR = rb_cur + (size_t)bi * a.rstride + a.n;
+    for (int tid = slice * 64 + lane; tid < MPW; tid += 64 * S) {
+        const int l = blockIdx.x * MPW + tid;
+        if (l >= a.m) continue;
+        float tot = 0.f;
+        for (int u = 0; u < S; ++u) tot += part[u][tid];
+        const float rr = remainR[l];
+        const float sumr = tot * rr;
+        const float consumption = fminf(rr / (sumr + 1e-9f), 1.0f);
+        const float r = consumption * rr, rem = fmaxf(0.0f, rr - sumr);
+        ratioR[l] = r;
+        ratioR_p[l] = r;
+        remainR[l] = rem;
+        remainR_p[l] = rem;
+    }
+}
+
+struct LevelScales { float fa[NLEVEL], fb[NLEVEL]; };
+
+// match[l][k] = sum over the levels, in level order, of w_j(l, k) ratioL_j[k] ratioR_j[l] with the SAME w_j the passes saw (the
+// same MFMA on the same operands) -- with the difference form's weights here the rows and columns of `match` summed to 1 +- 4e-3
+// (the expanded form's error at the steep levels) instead of 1 +- 1e-6.  A wave owns two 32-column tiles of cloud 1 and walks
+// its slice of cloud 2's row tiles; per (pair, level): exp2, two multiplications, one add.  The accumulator layout writes
+// 128 contiguous bytes of a `match` row per register and half-wave.
+// COST: sum match * |x1 - x2| with the distance in the difference form (cloud 2's coordinates by planes), partial sums per
+// (cloud, workgroup, slice) for emd_cost_sum_kernel -- fixed order, deterministic.
+constexpr int MTM = 2;
+template <bool COST>
+__global__ __launch_bounds__(64 * MSL) void emd_mfma_materialize_kernel(MfmaArgs a, LevelScales ls, const float *__restrict__ xyz1,
+                                                                        const float *__restrict__ ws, size_t lstride,
+                                                                        const float *__restrict__ rrpad, const float *__restrict__ c2soa,
+                                                                        float *__restrict__ match, float *__restrict__ costpart) {
+    if (gate_closed(a.gate, 0u)) return;
+    const int bi = blockIdx.y, nb = gridDim.y, lane = threadIdx.x, slice = __builtin_amdgcn_readfirstlane(threadIdx.y), S = blockDim.y;
+    const int half = lane >> 5, col = lane & 31;
+    const size_t cloud = (size_t)bi * (a.NP + a.MP);
+    const u4 *ownrec = a.recB + (cloud + blockIdx.x * (32 * MTM)) * 2;
+    const u4 *candrec = a.recA + (cloud + a.NP + col) * 2 + half;
+    float *__restrict__ mt = match + (size_t)bi * a.n * a.m;
+    __shared__ float rl_s[MSL][NLEVEL][32 * MTM];     // ratioL of the wave's columns, by level (a register array would be indexed
+    __shared__ float ls_s[2 * NLEVEL];                //   dynamically by the level loop -- scratch -- or unrolled nine times -- spills)
+    u4 bfraw[MTM];
+    float px[MTM], py[MTM], pz[MTM];
+    int kk[MTM];
+    if (slice == 0 && lane < 2 * NLEVEL) ls_s[lane] = lane < NLEVEL ? ls.fa[lane] : ls.fb[lane - NLEVEL];
+#pragma unroll
+    for (int t = 0; t < MTM; ++t) {
+        bfraw[t] = ownrec[(t * 32 + col) * 2 + half];
+        kk[t] = blockIdx.x * (32 * MTM) + t * 32 + col;
+        const int kc = min(kk[t], a.n - 1);
+        if (half == 0)
+#pragma unroll
+            for (int j = 0; j < NLEVEL; ++j) rl_s[slice][j][t * 32 + col] = ws[j * lstride + (size_t)bi * a.rstride + kc];
+        if (COST) {
+            const float *p = xyz1 + ((size_t)bi * a.n + kc) * 3;
+            px[t] = p[0]; py[t] = p[1]; pz[t] = p[2];
+        }
+    }
+    __syncthreads();
+    const int tiles = round_up(a.m, 32) / 32;
+    const int tb = (int)((long)tiles * slice / S), te = (int)((long)tiles * (slice + 1) / S);
+    float cost = 0.f;
+    for (int ct = tb; ct < te; ++ct) {
+        const u4 af = candrec[(size_t)ct * 64];
+        f16acc mm[MTM];
+#pragma unroll
+        for (int t = 0; t < MTM; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mm[t][r] = 0.f;
+#pragma unroll 1
+        for (int j = 0; j < NLEVEL; ++j) {
+            float4 rr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rr[i] = *(const float4 *)(rrpad + ((size_t)j * nb + bi) * a.MP + ct * 32 + 8 * i + 4 * half);
+            const h8 as = scale8(af, ls_s[j]);
+            const float fb = ls_s[NLEVEL + j];
+#pragma unroll
+            for (int t = 0; t < MTM; ++t) {
+                const float rlj = rl_s[slice][j][t * 32 + col];
+                const f16acc acc = pair_exponents(as, scale8(bfraw[t], fb));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mm[t][r] = __builtin_fmaf(fmul(fast_exp2(acc[r]), rlj), pick4(rr, r), mm[t][r]);
+            }
+        }
+        // register 4 i + jj of lane (half, col): row ct 32 + 8 i + 4 half + jj, columns kk[0] and kk[0] + 32
+        const bool full = ct * 32 + 32 <= a.m && (int)blockIdx.x * (32 * MTM) + 32 * MTM <= a.n;      // wave-uniform: no masks inside
+        float *row = mt + (size_t)(ct * 32 + 4 * half) * a.n + kk[0];
+        const size_t n4 = (size_t)a.n * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i, row += n4) {
+            float4 qx, qy, qz;
+            if (COST) {
+                const float *c = c2soa + (size_t)bi * 3 * a.MP + ct * 32 + 8 * i + 4 * half;
+                qx = *(const float4 *)c; qy = *(const float4 *)(c + a.MP); qz = *(const float4 *)(c + 2 * (size_t)a.MP);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj, row += a.n) {
+                const bool rowok = full || ct * 32 + 8 * i + 4 * half + jj < a.m;
+                const float cx = jj == 0 ? qx.x : jj == 1 ? qx.y : jj == 2 ? qx.z : qx.w;
+                const float cy = jj == 0 ? qy.x : jj == 1 ? qy.y : jj == 2 ? qy.z : qy.w;
+                const float cz = jj == 0 ? qz.x : jj == 1 ? qz.y : jj == 2 ? qz.z : qz.w;
+#pragma unroll
+                for (int t = 0; t < MTM; ++t) {
+                    const float v = mm[t][4 * i + jj];
+                    if (full || (rowok && kk[t] < a.n)) {
+                        row[32 * t] = v;
+                        if (COST) cost = __builtin_fmaf(v, __builtin_amdgcn_sqrtf(sqdist(px[t], py[t], pz[t], cx, cy, cz)), cost);
+                    }
+                }
+            }
+        }
+    }
+    if (COST) {
+        for (int o = 32; o > 0; o >>= 1) cost += __shfl_xor(cost, o);
+        if (lane == 0) costpart[((size_t)bi * gridDim.x + blockIdx.x) * S + slice] = cost;
+    }
+}
+
+int pick_mfma_slices(int b, int npoints, int ninner) {
+    const long groups = (long)b * ((npoints + MPW - 1) / MPW);
+    const int tiles = (ninner + 31) / 32;
+    int s = 1;
+    while (s < MSL && groups * s < 4096 && tiles / (2 * s) >= 4) s *= 2;
+    return s;
+}
+
+bool g_matrix_path = true;
+
 // (xyz2_l, ratioR_level0..8[l]) records of 12 floats for the materialisation
 __global__ void emd_pack_levels_kernel(int n, int m, const float *__restrict__ xyz2, const float *__restrict__ ws,
-                                       size_t lstride, size_t rstride, float *__restrict__ rec) {
+                                       size_t lstride, size_t rstride, float *__restrict__ rec, const unsigned *gate) {
+    if (gate_closed(gate, 1u)) return;
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= m) return;
     const int bi = blockIdx.y;
@@ -426,7 +882,8 @@ template <bool COST>
 __global__ __launch_bounds__(1024) void emd_materialize2_kernel(int n, int m, LevelPairs lv, const float *__restrict__ xyz1,
                                                                 const float *__restrict__ rec, float *__restrict__ match,
                                                                 const float *__restrict__ ws, size_t lstride, size_t rstride,
-                                                                float *__restrict__ costpart) {
+                                                                float *__restrict__ costpart, const unsigned *gate) {
+    if (gate_closed(gate, 1u)) return;
     const int bi = blockIdx.y;
     const int lane = threadIdx.x, slice = __builtin_amdgcn_readfirstlane(threadIdx.y), S = blockDim.y;
     const float *__restrict__ P = xyz1 + (size_t)bi * n * 3;
@@ -458,8 +915,10 @@ __global__ __launch_bounds__(1024) void emd_materialize2_kernel(int n, int m, Le
 }
 
 // out[b] = the cloud's partial costs, added in a fixed order
-__global__ __launch_bounds__(256) void emd_cost_sum_kernel(int nper, const float *__restrict__ costpart, float *__restrict__ out) {
+__global__ __launch_bounds__(256) void emd_cost_sum_kernel(int nper, const float *__restrict__ costpart, float *__restrict__ out,
+                                                           const unsigned *gate, unsigned want) {
     __shared__ float red[4];
+    if (gate != nullptr && __builtin_nontemporal_load(gate) != want) return;
     const float *cp = costpart + (size_t)blockIdx.x * nper;
     float c = 0.f;
     for (int i = threadIdx.x; i < nper; i += 256) c += cp[i];
@@ -675,11 +1134,31 @@ int pick_slices(int b, int npoints, int ninner) {
 
 }  // namespace
 
-extern "C" size_t dpf_approxmatch_workspace_bytes(int b, int n, int m) {
-    if (b <= 0 || n <= 0 || m <= 0) return 0;
+// bytes of the deferred path's own regions (ratio slots, packed-VALU records, materialisation records, cost partials)
+static size_t deferred_bytes(int b, int n, int m) {
     // NLEVEL ratio slots | 16 B alignment slack | (x,y,z,w) records of the passes | 12-float records of the materialisation
     return (size_t)b * NLEVEL * ((size_t)n + m) * sizeof(float) + 16 + (size_t)b * ((size_t)n + 2 * (size_t)m) * sizeof(float4) +
            (size_t)b * m * 12 * sizeof(float) + (size_t)b * ((n + PPW - 1) / PPW) * MAXS * sizeof(float);
+}
+// ... and of the matrix-core passes behind them: 64 B slack | flag (16 B) | meta (16 B per cloud) | A and B records (32 B per
+// padded point each) | padded remainR, ratioL | every level's padded ratioR | cloud 2's coordinate planes
+static size_t mfma_bytes(int b, int n, int m) {
+    const size_t NP = (size_t)(n + MPW - 1) / MPW * MPW, MP = (size_t)(m + MPW - 1) / MPW * MPW;
+    return 64 + 16 + (size_t)b * 16 + 2 * (size_t)b * (NP + MP) * 32 + (size_t)b * (NP + MP) * sizeof(float) +
+           (size_t)NLEVEL * b * MP * sizeof(float) + 3 * (size_t)b * MP * sizeof(float);
+}
+
+extern "C" size_t dpf_approxmatch_workspace_bytes(int b, int n, int m) {
+    if (b <= 0 || n <= 0 || m <= 0) return 0;
+    return deferred_bytes(b, n, m) + mfma_bytes(b, n, m);
+}
+
+// 1 (default): the deferred path's passes run on the matrix cores when the coordinates allow it; 0: always the packed-VALU
+// kernels (bit-identical to the read-modify-write path).  Returns the previous setting.  Env DPF_EMD_MATRIX=0 sets the default.
+extern "C" int dpf_emd_set_matrix_path(int on) {
+    const int prev = g_matrix_path ? 1 : 0;
+    g_matrix_path = on != 0;
+    return prev;
 }
 
 static int approxmatch_impl(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp, float *cost,
@@ -693,7 +1172,17 @@ static int approxmatch_impl(int b, int n, int m, const float *xyz1, const float 
     float multiL, multiR;
     if (n >= m) { multiL = 1; multiR = (float)(n / m); }   // integer division, approxmatch.cu:6-12
     else        { multiL = (float)(m / n); multiR = 1; }
-    hipLaunchKernelGGL(emd_init_kernel, dim3((n + m + 255) / 256, b), dim3(256), 0, s, n, m, multiL, multiR, temp);
+    static const bool env_matrix = [] { const char *e = getenv("DPF_EMD_MATRIX"); return !(e && e[0] == '0'); }();
+    const bool matrix = deferred && g_matrix_path && env_matrix;
+    // regions of the matrix-core passes (behind the deferred path's own)
+    const int NP = (n + MPW - 1) / MPW * MPW, MP = (m + MPW - 1) / MPW * MPW;
+    uint8_t *mbase = deferred ? (uint8_t *)(((uintptr_t)workspace + deferred_bytes(b, n, m) + 63) & ~(uintptr_t)63) : nullptr;
+    unsigned *flag = matrix ? (unsigned *)mbase : nullptr;
+    float *meta = (float *)(mbase + 16);
+    u4 *recA = (u4 *)(mbase + 16 + (size_t)b * 16), *recB = recA + (size_t)b * (NP + MP) * 2;
+    float *wpad = (float *)(recB + (size_t)b * (NP + MP) * 2);
+    float *rrpad = wpad + (size_t)b * (NP + MP), *c2soa = rrpad + (size_t)NLEVEL * b * MP;
+    hipLaunchKernelGGL(emd_init_kernel, dim3((n + m + 255) / 256, b), dim3(256), 0, s, n, m, multiL, multiR, temp, flag);
     const int s1 = pick_match_slices(b, n, m), s2 = pick_match_slices(b, m, n);
     const dim3 g1((n + 63) / 64, b), g2((m + 63) / 64, b);
     const dim3 h1((n + PPW - 1) / PPW, b), h2((m + PPW - 1) / PPW, b);               // deferred kernels: 128 points per wave
@@ -703,8 +1192,50 @@ static int approxmatch_impl(int b, int n, int m, const float *xyz1, const float 
     const size_t pstride = (size_t)n + 2 * (size_t)m;
     float4 *pk = deferred ? (float4 *)(((uintptr_t)((float *)workspace + NLEVEL * lstride) + 15) & ~(uintptr_t)15) : nullptr;
     float *rec = deferred ? (float *)(pk + (size_t)b * pstride) : nullptr;
+    // (the range check first: every kernel of either family looks at its verdict)
+    if (matrix) hipLaunchKernelGGL(emd_mfma_prep_kernel, dim3(b), dim3(1024), 0, s, n, m, xyz1, xyz2, meta, flag);
     if (deferred)
-        hipLaunchKernelGGL(emd_pack_init_kernel, dim3((m + 255) / 256, b), dim3(256), 0, s, m, multiR, xyz2, pk + n, pstride);
+        hipLaunchKernelGGL(emd_pack_init_kernel, dim3((m + 255) / 256, b), dim3(256), 0, s, m, multiR, xyz2, pk + n, pstride,
+                           (const unsigned *)flag);
+    int mfma_cost_parts = 0;
+    if (matrix) {
+        // the matrix-core family: gate 0.  P1(7) | P2(j), P3(j)+P1(j-1) for j = 7 .. 1 | P2(0), P3(0), P1(-1) | P2(-1), P3(-1)
+        hipLaunchKernelGGL(emd_mfma_pack_kernel, dim3((NP + MP + 255) / 256, b), dim3(256), 0, s, n, m, NP, MP, multiR, xyz1, xyz2,
+                           (const float *)meta, recA, recB, wpad, rrpad, c2soa, (const unsigned *)flag);
+        MfmaArgs ma{n, m, NP, MP, recA, recB, temp, wpad, rstride, flag};
+        const int m1 = pick_mfma_slices(b, n, m), m2 = pick_mfma_slices(b, m, n);
+        const dim3 q1(NP / MPW, b), q2(MP / MPW, b);
+        float *ws = (float *)workspace;
+        // level j's 4^(j-7): on the rows' fragments down to 2^-14 (a normal fp16 number), the rest on the columns'
+        auto fa_of = [](int j) { const float f = powf(4.0f, (float)(j - 7)); return f < 6.103515625e-5f ? 6.103515625e-5f : f; };
+        auto fb_of = [&](int j) { return powf(4.0f, (float)(j - 7)) / fa_of(j); };
+        hipLaunchKernelGGL(emd_mfma_cols_kernel<0>, q1, dim3(64, m1), 0, s, ma, fa_of(7), 0.f, fb_of(7), ws, ws, (const float *)rrpad);
+        int lj = 0;
+        for (int j = 7; j > -2; --j, ++lj) {
+            float *rb = ws + lj * lstride, *rrl = rrpad + (size_t)lj * b * MP;
+            hipLaunchKernelGGL(emd_mfma_rows_kernel, q2, dim3(64, m2), 0, s, ma, fa_of(j), fb_of(j), rb, rrl);
+            if (j > -1 && fb_of(j) == fb_of(j - 1)) {
+                hipLaunchKernelGGL(emd_mfma_cols_kernel<2>, q1, dim3(64, m1), 0, s, ma, fa_of(j), fa_of(j - 1), fb_of(j), rb, rb + lstride,
+                                   (const float *)rrl);
+            } else {
+                hipLaunchKernelGGL(emd_mfma_cols_kernel<3>, q1, dim3(64, m1), 0, s, ma, fa_of(j), 0.f, fb_of(j), rb, rb, (const float *)rrl);
+                if (j > -1)
+                    hipLaunchKernelGGL(emd_mfma_cols_kernel<0>, q1, dim3(64, m1), 0, s, ma, fa_of(j - 1), 0.f, fb_of(j - 1), rb + lstride,
+                                       rb + lstride, (const float *)rrl);
+            }
+        }
+        LevelScales ls;
+        for (int j = 7, q = 0; j > -2; --j, ++q) { ls.fa[q] = fa_of(j); ls.fb[q] = fb_of(j); }
+        const dim3 qm(NP / (32 * MTM), b);
+        float *costpart_m = rec + (size_t)b * m * 12;
+        if (cost)
+            hipLaunchKernelGGL(emd_mfma_materialize_kernel<true>, qm, dim3(64, m1), 0, s, ma, ls, xyz1, (const float *)ws, lstride,
+                               (const float *)rrpad, (const float *)c2soa, match, costpart_m);
+        else
+            hipLaunchKernelGGL(emd_mfma_materialize_kernel<false>, qm, dim3(64, m1), 0, s, ma, ls, xyz1, (const float *)ws, lstride,
+                               (const float *)rrpad, (const float *)c2soa, match, costpart_m);
+        mfma_cost_parts = (int)qm.x * m1;
+    }
     Levels lv;
     int li = 0;
     for (int j = 7; j > -2; --j, ++li) {                    // approxmatch.cu:24 (the j==-2 branch is dead)
@@ -713,9 +1244,13 @@ static int approxmatch_impl(int b, int n, int m, const float *xyz1, const float 
         lv.lvl2[li] = lvl2;
         float *rb = deferred ? (float *)workspace + li * lstride : temp + (size_t)(n + m);
         if (deferred) {
-            hipLaunchKernelGGL(emd_ratio2_kernel<1>, h1, dim3(64, s1), 0, s, n, m, lvl2, xyz1, xyz2, temp, rb, rstride, pk, pstride);
-            hipLaunchKernelGGL(emd_ratio2_kernel<2>, h2, dim3(64, s2), 0, s, n, m, lvl2, xyz1, xyz2, temp, rb, rstride, pk, pstride);
-            hipLaunchKernelGGL(emd_match2_kernel, h1, dim3(64, s1), 0, s, n, m, lvl2, xyz1, temp, rb, rstride, (const float4 *)pk, pstride);
+            // the packed-VALU family: gate 1 (always when the matrix path is off: flag == nullptr)
+            hipLaunchKernelGGL(emd_ratio2_kernel<1>, h1, dim3(64, s1), 0, s, n, m, lvl2, xyz1, xyz2, temp, rb, rstride, pk, pstride,
+                               (const unsigned *)flag);
+            hipLaunchKernelGGL(emd_ratio2_kernel<2>, h2, dim3(64, s2), 0, s, n, m, lvl2, xyz1, xyz2, temp, rb, rstride, pk, pstride,
+                               (const unsigned *)flag);
+            hipLaunchKernelGGL(emd_match2_kernel, h1, dim3(64, s1), 0, s, n, m, lvl2, xyz1, temp, rb, rstride, (const float4 *)pk, pstride,
+                               (const unsigned *)flag);
             continue;
         }
         hipLaunchKernelGGL(emd_ratio_kernel<1>, g1, dim3(64, s1), 0, s, n, m, lvl2, xyz1, xyz2, temp, rb, rstride);
@@ -734,15 +1269,19 @@ static int approxmatch_impl(int b, int n, int m, const float *xyz1, const float 
             lp.p[i] = (u64)lo | ((u64)hi << 32);
         }
         hipLaunchKernelGGL(emd_pack_levels_kernel, dim3((m + 255) / 256, b), dim3(256), 0, s, n, m, xyz2,
-                           (const float *)workspace, lstride, rstride, rec);
+                           (const float *)workspace, lstride, rstride, rec, (const unsigned *)flag);
         float *costpart = rec + (size_t)b * m * 12;
         if (cost) {
             hipLaunchKernelGGL(emd_materialize2_kernel<true>, h1, dim3(64, s1), 0, s, n, m, lp, xyz1, (const float *)rec, match,
-                               (const float *)workspace, lstride, rstride, costpart);
-            hipLaunchKernelGGL(emd_cost_sum_kernel, dim3(b), dim3(256), 0, s, (int)h1.x * s1, (const float *)costpart, cost);
+                               (const float *)workspace, lstride, rstride, costpart, (const unsigned *)flag);
+            hipLaunchKernelGGL(emd_cost_sum_kernel, dim3(b), dim3(256), 0, s, (int)h1.x * s1, (const float *)costpart, cost,
+                               (const unsigned *)flag, 1u);
+            if (matrix)
+                hipLaunchKernelGGL(emd_cost_sum_kernel, dim3(b), dim3(256), 0, s, mfma_cost_parts, (const float *)costpart, cost,
+                                   (const unsigned *)flag, 0u);
         } else {
             hipLaunchKernelGGL(emd_materialize2_kernel<false>, h1, dim3(64, s1), 0, s, n, m, lp, xyz1, (const float *)rec, match,
-                               (const float *)workspace, lstride, rstride, costpart);
+                               (const float *)workspace, lstride, rstride, costpart, (const unsigned *)flag);
         }
     }
     return (int)hipGetLastError();

@@ -107,6 +107,12 @@ int dpf_approxmatch(int b, int n, int m, const float *xyz1, const float *xyz2,
  * 68*n*m bytes of HBM traffic per cloud).  NULL / short workspace -> the
  * read-modify-write path. */
 size_t dpf_approxmatch_workspace_bytes(int b, int n, int m);
+/* r05: with a workspace the 27 level passes run on the matrix cores (expanded-form squared distance, one MFMA per 32 x 32
+ * pairs; csrc/emd.hip) when every coordinate, centred on cloud 1's centroid, fits the fp16 operands (|x - c|^2 <= 346, all
+ * finite) -- decided per call on the device; otherwise, and after dpf_emd_set_matrix_path(0), the packed-VALU kernels run,
+ * whose results are bit-identical to dpf_approxmatch.  The matrix-core results are within the tolerance contract (cost
+ * 1e-4), not bit-identical.  Returns the previous setting. */
+int dpf_emd_set_matrix_path(int on);
 int dpf_approxmatch_ws(int b, int n, int m, const float *xyz1, const float *xyz2,
                        float *match, float *temp, void *workspace, size_t workspace_bytes,
                        dpf_stream_t stream);
