@@ -475,36 +475,40 @@ __device__ __forceinline__ void split3(double v, _Float16 &h, _Float16 &mid, _Fl
     l = (_Float16)(float)(r - (double)(float)mid);
 }
 
-// Records of both roles for every point of both clouds, per cloud [cloud 1: NP | cloud 2: MP] (padded to whole 128-point
-// groups with zero records), the padded weight vectors per cloud [remainR (MP) | ratioL (NP)], zeros in every level's padded
-// ratioR vector rrpad[level][cloud][MP], and cloud 2's coordinates as planes c2soa[cloud][3][MP] (the materialisation's cost)
-__global__ void emd_mfma_pack_kernel(int n, int m, int NP, int MP, float multiR, const float *__restrict__ xyz1,
-                                     const float *__restrict__ xyz2, const float *__restrict__ meta, u4 *__restrict__ recA,
-                                     u4 *__restrict__ recB, float *__restrict__ wpad, float *__restrict__ rrpad,
-                                     float *__restrict__ c2soa, const unsigned *gate) {
-    if (gate_closed(gate, 0u)) return;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x, bi = blockIdx.y;
-    if (idx >= NP + MP) return;
-    const bool first = idx < NP;
-    const int k = first ? idx : idx - NP;
-    const bool live = k < (first ? n : m);
-    float *w = wpad + (size_t)bi * (NP + (size_t)MP);
-    if (first) w[MP + k] = 0.f;                                   // ratioL
-    else {
-        w[k] = live ? multiR : 0.f;                               // remainR
-        for (int j = 0; j < NLEVEL; ++j) rrpad[((size_t)j * gridDim.y + bi) * MP + k] = 0.f;      // every level's ratioR
-        const float *q = xyz2 + ((size_t)bi * m + (live ? k : 0)) * 3;
-        for (int u = 0; u < 3; ++u) c2soa[((size_t)bi * 3 + u) * MP + k] = live ? q[u] : 0.f;
-    }
+// Sparsity (r05, tests/diag/emd_level_zeros.py): a point of cloud 2 whose remainR has reached 0 stays at 0 -- its weight in
+// pass 1 (remainR) and pass 3 (ratioR) is exactly 0 and pass 2 has nothing to compute for it.  On bench.py's cfg5 clouds the
+// live fraction per level is 1, 0.58, 0.31, 0.13, 0.05, 0.02, 0.007, 0.001, 0 (independent clouds: 1, 0.59, 0.35, 0.20,
+// 0.11, 0.07, 0.03, 0.007, 0.002): 2.1 - 2.4 level-passes' worth of pairs instead of 9.  The passes therefore walk a COMPACTED
+// list of cloud 2's live points (A records, original indices, remainR; ping-pong buffers, one stable compaction per level:
+// exact zeros dropped, so the sums lose only terms that are +0), and the compaction files every point it drops into `order`
+// behind the points that outlive it: in that order every level's list is a prefix, and the materialisation gives row tile T
+// only the levels whose list reaches it.
+struct MfmaState {
+    int n, m, NP, MP, nb;
+    const u4 *recB1;        // [nb][NP] B records of cloud 1 (dense, padded with zero records)
+    u4 *recA2[2];           // [nb][MP] A records of cloud 2's live points
+    int *idx2[2];           //          their original indices
+    float *remainR_c[2];    //          their remainR
+    float *ratioR_c;        // [nb][MP] their ratioR of the current level
+    float *ratioL_p;        // [nb][NP] cloud 1's ratioL of the current level
+    int *count;             // [nb] length of the current list
+    int *counts;            // [NLEVEL][nb] length of every level's list
+    int *order;             // [nb][MP] cloud 2's points, longest-lived first
+    float *temp;            // reference layout: remainL (n) | remainR (m) | ...
+    size_t rstride;         // per-cloud stride of a level's ratio slot [ratioL (n) | ratioR (m)]
+    const unsigned *gate;
+};
+
+// fp16 operand records of a point (file header of this section); c = centred, scaled coordinates
+__device__ __forceinline__ void point_records(const float *q, const float *centre, bool live, u4 (&ra)[2], u4 (&rb)[2]) {
     _Float16 a[16], b[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) { a[u] = (_Float16)0.f; b[u] = (_Float16)0.f; }
     if (live) {
-        const float *q = (first ? xyz1 + ((size_t)bi * n + k) * 3 : xyz2 + ((size_t)bi * m + k) * 3);
         const double S = 1.2011224087864498;                      // sqrt(log2 e)
         double c[3], n2 = 0.0;
 #pragma unroll
-        for (int u = 0; u < 3; ++u) { c[u] = ((double)q[u] - (double)meta[bi * 4 + u]) * S; n2 += c[u] * c[u]; }
+        for (int u = 0; u < 3; ++u) { c[u] = ((double)q[u] - (double)centre[u]) * S; n2 += c[u] * c[u]; }
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             _Float16 h, l;
@@ -518,21 +522,39 @@ __global__ void emd_mfma_pack_kernel(int n, int m, int NP, int MP, float multiR,
         a[12] = a[13] = a[14] = (_Float16)(-128.f);
         split3(n2 * 128.0, b[12], b[13], b[14]);
     }
-    u4 *oa = recA + ((size_t)bi * (NP + MP) + idx) * 2, *ob = recB + ((size_t)bi * (NP + MP) + idx) * 2;
-    u4 va[2], vb[2];
-    __builtin_memcpy(va, a, 32);
-    __builtin_memcpy(vb, b, 32);
-    oa[0] = va[0]; oa[1] = va[1];
-    ob[0] = vb[0]; ob[1] = vb[1];
+    __builtin_memcpy(ra, a, 32);
+    __builtin_memcpy(rb, b, 32);
 }
 
-struct MfmaArgs {
-    int n, m, NP, MP;
-    const u4 *recA, *recB;
-    float *temp, *wpad;
-    size_t rstride;          // per-cloud stride of a level's ratio slot [ratioL (n) | ratioR (m)]
-    const unsigned *gate;
-};
+// B records of cloud 1, A records of cloud 2 (dense copy + the first list: every point, in order), zeros in the padding,
+// zeros in every level's ratioR slot of the workspace (a point that has left the auction is not written again)
+__global__ void emd_mfma_pack_kernel(MfmaState st, float multiR, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+                                     const float *__restrict__ meta, u4 *__restrict__ recA2_dense, float *__restrict__ ws, size_t lstride) {
+    if (gate_closed(st.gate, 0u)) return;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x, bi = blockIdx.y;
+    if (idx >= st.NP + st.MP) return;
+    const bool first = idx < st.NP;
+    const int k = first ? idx : idx - st.NP;
+    const bool live = k < (first ? st.n : st.m);
+    const float *q = first ? xyz1 + ((size_t)bi * st.n + (live ? k : 0)) * 3 : xyz2 + ((size_t)bi * st.m + (live ? k : 0)) * 3;
+    u4 ra[2], rb[2];
+    point_records(q, meta + bi * 4, live, ra, rb);
+    if (first) {
+        u4 *o = const_cast<u4 *>(st.recB1) + ((size_t)bi * st.NP + k) * 2;
+        o[0] = rb[0]; o[1] = rb[1];
+        st.ratioL_p[(size_t)bi * st.NP + k] = 0.f;
+    } else {
+        const size_t at = (size_t)bi * st.MP + k;
+        recA2_dense[at * 2] = ra[0]; recA2_dense[at * 2 + 1] = ra[1];
+        st.recA2[0][at * 2] = ra[0]; st.recA2[0][at * 2 + 1] = ra[1];
+        st.idx2[0][at] = k;
+        st.remainR_c[0][at] = live ? multiR : 0.f;
+        st.ratioR_c[at] = 0.f;
+        if (live)
+            for (int qv = 0; qv < NLEVEL; ++qv) ws[qv * lstride + (size_t)bi * st.rstride + st.n + k] = 0.f;
+        if (k == 0) st.count[bi] = st.m;
+    }
+}
 
 // The three passes of a level must see THE SAME weight for a pair: pass 1 divides remainL by sum_l w remainR, pass 3 takes
 // sum_l w ratioL ratioR back off remainL -- for a point the level consumes entirely the two cancel, and what is left
@@ -541,10 +563,13 @@ struct MfmaArgs {
 // the steep levels it grew to O(0.3) changes of the matching (measured, r05: a first version ran pass 2 with the clouds'
 // operand roles exchanged and pass 3 with (exp2 of the next level's exponent)^4).  Hence: cloud 2 is ALWAYS the A operand
 // (rows) and cloud 1 ALWAYS the B operand (columns), every pass of level j scales them by the same (fa_j, fb_j), and every
-// weight is exp2 of that MFMA's result -- the same bits in passes 1, 2 and 3.
+// weight is exp2 of that MFMA's result -- the same bits in passes 1, 2, 3 and in the materialisation.
 
 // fragments' accumulator register r of lane (half, col): row 8 (r / 4) + 4 half + r % 4, column col
 __device__ __forceinline__ float pick4(const float4 (&w)[4], int r) {
+    return r % 4 == 0 ? w[r / 4].x : r % 4 == 1 ? w[r / 4].y : r % 4 == 2 ? w[r / 4].z : w[r / 4].w;
+}
+__device__ __forceinline__ int pick4i(const int4 (&w)[4], int r) {
     return r % 4 == 0 ? w[r / 4].x : r % 4 == 1 ? w[r / 4].y : r % 4 == 2 ? w[r / 4].z : w[r / 4].w;
 }
 __device__ __forceinline__ h8 scale8(u4 v, float f) {
@@ -556,100 +581,69 @@ __device__ __forceinline__ f16acc pair_exponents(h8 rows, h8 cols) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(rows, cols, zero, 0, 0, 0);
 }
 
-// Passes over cloud 1's points (columns; cloud 2's points stream past as row tiles with their weights):
+// Passes over cloud 1's points (columns; cloud 2's LIVE points stream past as row tiles with their weights):
 // MODE 0: pass 1          s_k = sum_l w remainR[l];                     ratioL[k] = remainL[k] / (1e-9 + s_k)
 // MODE 3: pass 3          s_k = sum_l w ratioR[l];                      remainL[k] = max(0, remainL[k] - ratioL[k] s_k)
-// MODE 2: pass 3 of level j, then pass 1 of level j-1 on the new remainL (two MFMAs and two exp2 per pair: saves a launch
-//         and the operand traffic, not arithmetic); (fa, fb) of level j, (fa2, fb) of level j-1
-// rb_cur / rb_next: the ratio slots of level j / j-1.
+// (fa, fb): level j's 4^(j-7), split between the rows' and the columns' fragments.  rb_cur: the ratio slot of level j.
 template <int MODE>
-__global__ __launch_bounds__(64 * MSL) void emd_mfma_cols_kernel(MfmaArgs a, float fa, float fa2, float fb, float *rb_cur, float *rb_next,
-                                                                 const float *rrlev) {
-    __shared__ float part[MODE == 2 ? 2 : 1][MSL][MPW];
-    if (gate_closed(a.gate, 0u)) return;
+__global__ __launch_bounds__(64 * MSL) void emd_mfma_cols_kernel(MfmaState st, int cur, float fa, float fb, float *rb_cur) {
+    __shared__ float part[MSL][MPW];
+    if (gate_closed(st.gate, 0u)) return;
     const int bi = blockIdx.y, lane = threadIdx.x, slice = __builtin_amdgcn_readfirstlane(threadIdx.y), S = blockDim.y;
     const int half = lane >> 5, col = lane & 31;
-    const size_t cloud = (size_t)bi * (a.NP + a.MP);
-    const u4 *ownrec = a.recB + (cloud + blockIdx.x * MPW) * 2;
-    const u4 *candrec = a.recA + (cloud + a.NP + col) * 2 + half;
-    float *wp = a.wpad + (size_t)bi * (a.NP + (size_t)a.MP);
-    float *remainR_p = wp, *ratioL_p = wp + a.MP;
-    const float *w0 = (MODE == 0 ? remainR_p : rrlev + (size_t)bi * a.MP) + 4 * half;   // rrlev: level j's padded ratioR
-    const float *w1 = remainR_p + 4 * half;                       // MODE 2's second weight
+    const u4 *ownrec = st.recB1 + ((size_t)bi * st.NP + blockIdx.x * MPW) * 2;
+    const u4 *candrec = st.recA2[cur] + ((size_t)bi * st.MP + col) * 2 + half;
+    const float *w0 = (MODE == 0 ? st.remainR_c[cur] : st.ratioR_c) + (size_t)bi * st.MP + 4 * half;
     h8 bf[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) bf[t] = scale8(ownrec[(t * 32 + col) * 2 + half], fb);
-    const int tiles = round_up(a.m, 32) / 32;
+    const int tiles = (st.count[bi] + 31) / 32;
     const int tb = (int)((long)tiles * slice / S), te = (int)((long)tiles * (slice + 1) / S);
-    float sa[MT], sb[MT];
+    float sa[MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) { sa[t] = 0.f; sb[t] = 0.f; }
+    for (int t = 0; t < MT; ++t) sa[t] = 0.f;
     if (tb < te) {
         u4 af = candrec[(size_t)tb * 64];
-        float4 wa[4], wb[4];
+        float4 wa[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            wa[i] = *(const float4 *)(w0 + tb * 32 + 8 * i);
-            if (MODE == 2) wb[i] = *(const float4 *)(w1 + tb * 32 + 8 * i);
-        }
+        for (int i = 0; i < 4; ++i) wa[i] = *(const float4 *)(w0 + tb * 32 + 8 * i);
         for (int ct = tb; ct < te; ++ct) {
             const int nx = min(ct + 1, te - 1);
             const u4 afn = candrec[(size_t)nx * 64];
-            float4 wan[4], wbn[4];
+            float4 wan[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                wan[i] = *(const float4 *)(w0 + nx * 32 + 8 * i);
-                if (MODE == 2) wbn[i] = *(const float4 *)(w1 + nx * 32 + 8 * i);
-            }
-            const h8 as = scale8(af, fa), as2 = scale8(af, fa2);
+            for (int i = 0; i < 4; ++i) wan[i] = *(const float4 *)(w0 + nx * 32 + 8 * i);
+            const h8 as = scale8(af, fa);
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
                 const f16acc acc = pair_exponents(as, bf[t]);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sa[t] = __builtin_fmaf(fast_exp2(acc[r]), pick4(wa, r), sa[t]);
-                if (MODE == 2) {
-                    const f16acc acc2 = pair_exponents(as2, bf[t]);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sb[t] = __builtin_fmaf(fast_exp2(acc2[r]), pick4(wb, r), sb[t]);
-                }
             }
             af = afn;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { wa[i] = wan[i]; if (MODE == 2) wb[i] = wbn[i]; }
+            for (int i = 0; i < 4; ++i) wa[i] = wan[i];
         }
     }
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         sa[t] += __shfl_xor(sa[t], 32);
-        if (MODE == 2) sb[t] += __shfl_xor(sb[t], 32);
-        if (half == 0) {
-            part[0][slice][t * 32 + col] = sa[t];
-            if (MODE == 2) part[MODE == 2 ? 1 : 0][slice][t * 32 + col] = sb[t];
-        }
+        if (half == 0) part[slice][t * 32 + col] = sa[t];
     }
     __syncthreads();
-    float *remainL = a.temp + (size_t)bi * (a.n + a.m) * 2;
-    float *ratioL = rb_cur + (size_t)bi * a.rstride;
+    float *remainL = st.temp + (size_t)bi * (st.n + st.m) * 2;
+    float *ratioL = rb_cur + (size_t)bi * st.rstride;
     for (int tid = slice * 64 + lane; tid < MPW; tid += 64 * S) {
         const int k = blockIdx.x * MPW + tid;
-        if (k >= a.n) continue;
-        float tot = 0.f, tot2 = 0.f;
-        for (int u = 0; u < S; ++u) {
-            tot += part[0][u][tid];
-            if (MODE == 2) tot2 += part[MODE == 2 ? 1 : 0][u][tid];
-        }
+        if (k >= st.n) continue;
+        float tot = 0.f;
+        for (int u = 0; u < S; ++u) tot += part[u][tid];
         if (MODE == 0) {
             const float r = remainL[k] / (1e-9f + tot);
             ratioL[k] = r;
-            ratioL_p[k] = r;
+            st.ratioL_p[(size_t)bi * st.NP + k] = r;
         } else {
-            const float rem = fmaxf(0.0f, remainL[k] - ratioL[k] * tot);
-            remainL[k] = rem;
-            if (MODE == 2) {
-                const float r = rem / (1e-9f + tot2);
-                rb_next[(size_t)bi * a.rstride + k] = r;
-                ratioL_p[k] = r;
-            }
+            remainL[k] = fmaxf(0.0f, remainL[k] - ratioL[k] * tot);
         }
     }
 }
@@ -664,25 +658,25 @@ __device__ __forceinline__ float half_wave_sum(float v) {
     return v;
 }
 
-// Pass 2, over cloud 2's points -- which stay the ROWS: a wave owns MT row tiles (their A fragments), cloud 1's points stream
-// past as column tiles with ratioL (one weight per lane), the sums run along the accumulators' columns, i.e. across lanes:
-// per-lane partial sums for every (tile, register) and one butterfly per such sum at the end (~10 % of the loop at n = 8192).
+// Pass 2, over cloud 2's live points -- which stay the ROWS: a wave owns MT row tiles (their A fragments), cloud 1's points
+// stream past as column tiles with ratioL (one weight per lane), the sums run along the accumulators' columns, i.e. across
+// lanes: per-lane partial sums for every (tile, register) and one butterfly per such sum at the end.
 //   sumr = remainR[l] * sum_k w ratioL[k];  ratioR[l] = min(remainR[l] / (sumr + 1e-9), 1) * remainR[l];
 //   remainR[l] = max(0, remainR[l] - sumr)
-__global__ __launch_bounds__(64 * MSL) void emd_mfma_rows_kernel(MfmaArgs a, float fa, float fb, float *rb_cur, float *rrlev) {
+__global__ __launch_bounds__(64 * MSL) void emd_mfma_rows_kernel(MfmaState st, int cur, float fa, float fb, float *rb_cur) {
     __shared__ float part[MSL][MPW];
-    if (gate_closed(a.gate, 0u)) return;
+    if (gate_closed(st.gate, 0u)) return;
     const int bi = blockIdx.y, lane = threadIdx.x, slice = __builtin_amdgcn_readfirstlane(threadIdx.y), S = blockDim.y;
+    const int cnt = st.count[bi];
+    if ((int)blockIdx.x * MPW >= cnt) return;                       // (whole workgroup)
     const int half = lane >> 5, col = lane & 31;
-    const size_t cloud = (size_t)bi * (a.NP + a.MP);
-    const u4 *ownrec = a.recA + (cloud + a.NP + blockIdx.x * MPW) * 2;
-    const u4 *candrec = a.recB + (cloud + col) * 2 + half;
-    float *wp = a.wpad + (size_t)bi * (a.NP + (size_t)a.MP);
-    float *remainR_p = wp, *ratioL_p = wp + a.MP, *ratioR_p = rrlev + (size_t)bi * a.MP;
+    const u4 *ownrec = st.recA2[cur] + ((size_t)bi * st.MP + blockIdx.x * MPW) * 2;
+    const u4 *candrec = st.recB1 + ((size_t)bi * st.NP + col) * 2 + half;
+    const float *wl = st.ratioL_p + (size_t)bi * st.NP;
     h8 af[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) af[t] = scale8(ownrec[(t * 32 + col) * 2 + half], fa);
-    const int tiles = round_up(a.n, 32) / 32;
+    const int tiles = round_up(st.n, 32) / 32;
     const int tb = (int)((long)tiles * slice / S), te = (int)((long)tiles * (slice + 1) / S);
     float s[MT][16];
 #pragma unroll
@@ -691,11 +685,11 @@ __global__ __launch_bounds__(64 * MSL) void emd_mfma_rows_kernel(MfmaArgs a, flo
         for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
     if (tb < te) {
         u4 bfr = candrec[(size_t)tb * 64];
-        float w = ratioL_p[tb * 32 + col];
+        float w = wl[tb * 32 + col];
         for (int ct = tb; ct < te; ++ct) {
             const int nx = min(ct + 1, te - 1);
             const u4 bfn = candrec[(size_t)nx * 64];
-            const float wn = ratioL_p[nx * 32 + col];
+            const float wn = wl[nx * 32 + col];
             const h8 bs = scale8(bfr, fb);
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
@@ -715,70 +709,157 @@ __global__ __launch_bounds__(64 * MSL) void emd_mfma_rows_kernel(MfmaArgs a, flo
             if (col == r) part[slice][t * 32 + 8 * (r / 4) + 4 * half + r % 4] = tot;
         }
     __syncthreads();
-    float *remainR = a.temp + (size_t)bi * (a.n + a.m) * 2 + a.n;
-    float *ratioR = rb_cur + (size_t)bi * a.rstride + a.n;
+    float *remainR = st.temp + (size_t)bi * (st.n + st.m) * 2 + st.n;
+    float *ratioR = rb_cur + (size_t)bi * st.rstride + st.n;
     for (int tid = slice * 64 + lane; tid < MPW; tid += 64 * S) {
-        const int l = blockIdx.x * MPW + tid;
-        if (l >= a.m) continue;
+        const int pos = blockIdx.x * MPW + tid;
+        if (pos >= cnt) continue;
+        const size_t at = (size_t)bi * st.MP + pos;
+        const int l = st.idx2[cur][at];
         float tot = 0.f;
         for (int u = 0; u < S; ++u) tot += part[u][tid];
-        const float rr = remainR[l];
+        const float rr = st.remainR_c[cur][at];
         const float sumr = tot * rr;
         const float consumption = fminf(rr / (sumr + 1e-9f), 1.0f);
         const float r = consumption * rr, rem = fmaxf(0.0f, rr - sumr);
         ratioR[l] = r;
-        ratioR_p[l] = r;
+        st.ratioR_c[at] = r;
         remainR[l] = rem;
-        remainR_p[l] = rem;
+        st.remainR_c[cur][at] = rem;
     }
+}
+
+// After a level's three passes: the points whose remainR is still nonzero move to the other buffer, in order; the others take
+// the places [kept, cnt) of `order` (LAST: every point of the last list takes [0, cnt)).  One workgroup per cloud.
+template <bool LAST>
+__global__ __launch_bounds__(1024) void emd_mfma_compact_kernel(MfmaState st, int cur, int q) {
+    __shared__ int wsum[2][16];
+    __shared__ int total;
+    if (gate_closed(st.gate, 0u)) return;
+    const int bi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nxt = cur ^ 1;
+    const int cnt = st.count[bi];
+    const size_t base = (size_t)bi * st.MP;
+    if (tid == 0) { st.counts[q * st.nb + bi] = cnt; total = 0; }
+    __syncthreads();
+    int kept_total = 0;
+    if (!LAST) {
+        int c = 0;
+        for (int pos = tid; pos < cnt; pos += 1024) c += st.remainR_c[cur][base + pos] != 0.f;
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        if (lane == 0) atomicAdd(&total, c);                       // (integer: order-independent)
+        __syncthreads();
+        kept_total = total;
+    }
+    int kbase = 0, dbase = kept_total;
+    for (int c0 = 0; c0 < cnt; c0 += 1024) {
+        const int pos = c0 + tid;
+        const bool valid = pos < cnt;
+        const bool keep = !LAST && valid && st.remainR_c[cur][base + (valid ? pos : 0)] != 0.f;
+        const bool drop = valid && !keep;
+        const unsigned long long bk = __ballot(keep), bd = __ballot(drop);
+        const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+        const int pk = __popcll(bk & below), pd = __popcll(bd & below);
+        if (lane == 0) { wsum[0][wave] = __popcll(bk); wsum[1][wave] = __popcll(bd); }
+        __syncthreads();
+        int wk = 0, wd = 0, ck = 0, cd = 0;
+        for (int u = 0; u < 16; ++u) {
+            if (u < wave) { wk += wsum[0][u]; wd += wsum[1][u]; }
+            ck += wsum[0][u]; cd += wsum[1][u];
+        }
+        if (keep) {
+            const size_t from = base + pos, to = base + kbase + wk + pk;
+            st.recA2[nxt][to * 2] = st.recA2[cur][from * 2];
+            st.recA2[nxt][to * 2 + 1] = st.recA2[cur][from * 2 + 1];
+            st.idx2[nxt][to] = st.idx2[cur][from];
+            st.remainR_c[nxt][to] = st.remainR_c[cur][from];
+        } else if (drop) {
+            st.order[base + dbase + wd + pd] = st.idx2[cur][base + pos];
+        }
+        kbase += ck; dbase += cd;
+        __syncthreads();
+    }
+    if (!LAST) {
+        // the next list's last tile: zero weights behind its end, records that are numbers
+        const int pad_end = min(round_up(kept_total, 32), st.MP);
+        for (int pos = kept_total + tid; pos < pad_end; pos += 1024) {
+            const u4 z = {0u, 0u, 0u, 0u};
+            st.recA2[nxt][(base + pos) * 2] = z; st.recA2[nxt][(base + pos) * 2 + 1] = z;
+            st.remainR_c[nxt][base + pos] = 0.f;
+        }
+        for (int pos = kept_total + tid; pos < min(round_up(cnt, 32), st.MP); pos += 1024) st.ratioR_c[base + pos] = 0.f;
+        if (tid == 0) st.count[bi] = kept_total;
+    }
+}
+
+// Cloud 2 in `order`: A records, every level's ratioR, coordinates (by planes, for the cost) and original row numbers (-1 in
+// the padding)
+__global__ void emd_mfma_gather_kernel(MfmaState st, const u4 *__restrict__ recA2_dense, const float *__restrict__ xyz2,
+                                       const float *__restrict__ ws, size_t lstride, u4 *__restrict__ recA_s,
+                                       float *__restrict__ rr_s, float *__restrict__ c2soa_s, int *__restrict__ l_s) {
+    if (gate_closed(st.gate, 0u)) return;
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x, bi = blockIdx.y;
+    if (pos >= st.MP) return;
+    const bool valid = pos < st.m;
+    const size_t at = (size_t)bi * st.MP + pos;
+    const int l = valid ? st.order[at] : 0;
+    const u4 z = {0u, 0u, 0u, 0u};
+    recA_s[at * 2] = valid ? recA2_dense[((size_t)bi * st.MP + l) * 2] : z;
+    recA_s[at * 2 + 1] = valid ? recA2_dense[((size_t)bi * st.MP + l) * 2 + 1] : z;
+    for (int qv = 0; qv < NLEVEL; ++qv)
+        rr_s[((size_t)qv * st.nb + bi) * st.MP + pos] = valid ? ws[qv * lstride + (size_t)bi * st.rstride + st.n + l] : 0.f;
+    const float *p = xyz2 + ((size_t)bi * st.m + l) * 3;
+    for (int u = 0; u < 3; ++u) c2soa_s[((size_t)bi * 3 + u) * st.MP + pos] = valid ? p[u] : 0.f;
+    l_s[at] = valid ? l : -1;
 }
 
 struct LevelScales { float fa[NLEVEL], fb[NLEVEL]; };
 
 // match[l][k] = sum over the levels, in level order, of w_j(l, k) ratioL_j[k] ratioR_j[l] with the SAME w_j the passes saw (the
 // same MFMA on the same operands) -- with the difference form's weights here the rows and columns of `match` summed to 1 +- 4e-3
-// (the expanded form's error at the steep levels) instead of 1 +- 1e-6.  A wave owns two 32-column tiles of cloud 1 and walks
-// its slice of cloud 2's row tiles; per (pair, level): exp2, two multiplications, one add.  The accumulator layout writes
-// 128 contiguous bytes of a `match` row per register and half-wave.
-// COST: sum match * |x1 - x2| with the distance in the difference form (cloud 2's coordinates by planes), partial sums per
-// (cloud, workgroup, slice) for emd_cost_sum_kernel -- fixed order, deterministic.
+// (the expanded form's error at the steep levels) instead of 1 +- 1e-6.  A wave owns two 32-column tiles of cloud 1 and takes
+// every S-th 32-row tile of cloud 2 IN `order`: tile T gets the levels whose list is longer than 32 T (the others' ratioR are
+// all zero there) -- per (pair, live level): exp2, a multiplication, an FMA.  The accumulator layout writes 128 contiguous
+// bytes of a `match` row per register and half-wave.
+// COST: sum match * |x1 - x2| with the distance in the difference form, partial sums per (cloud, workgroup, slice) for
+// emd_cost_sum_kernel -- fixed order, deterministic.
 constexpr int MTM = 2;
 template <bool COST>
-__global__ __launch_bounds__(64 * MSL) void emd_mfma_materialize_kernel(MfmaArgs a, LevelScales ls, const float *__restrict__ xyz1,
+__global__ __launch_bounds__(64 * MSL) void emd_mfma_materialize_kernel(MfmaState st, LevelScales ls, const float *__restrict__ xyz1,
                                                                         const float *__restrict__ ws, size_t lstride,
-                                                                        const float *__restrict__ rrpad, const float *__restrict__ c2soa,
+                                                                        const u4 *__restrict__ recA_s, const float *__restrict__ rr_s,
+                                                                        const float *__restrict__ c2soa_s, const int *__restrict__ l_s,
                                                                         float *__restrict__ match, float *__restrict__ costpart) {
-    if (gate_closed(a.gate, 0u)) return;
-    const int bi = blockIdx.y, nb = gridDim.y, lane = threadIdx.x, slice = __builtin_amdgcn_readfirstlane(threadIdx.y), S = blockDim.y;
-    const int half = lane >> 5, col = lane & 31;
-    const size_t cloud = (size_t)bi * (a.NP + a.MP);
-    const u4 *ownrec = a.recB + (cloud + blockIdx.x * (32 * MTM)) * 2;
-    const u4 *candrec = a.recA + (cloud + a.NP + col) * 2 + half;
-    float *__restrict__ mt = match + (size_t)bi * a.n * a.m;
     __shared__ float rl_s[MSL][NLEVEL][32 * MTM];     // ratioL of the wave's columns, by level (a register array would be indexed
     __shared__ float ls_s[2 * NLEVEL];                //   dynamically by the level loop -- scratch -- or unrolled nine times -- spills)
+    __shared__ int cnt_s[NLEVEL];
+    if (gate_closed(st.gate, 0u)) return;
+    const int bi = blockIdx.y, nb = gridDim.y, lane = threadIdx.x, slice = __builtin_amdgcn_readfirstlane(threadIdx.y), S = blockDim.y;
+    const int half = lane >> 5, col = lane & 31;
+    const u4 *ownrec = st.recB1 + ((size_t)bi * st.NP + blockIdx.x * (32 * MTM)) * 2;
+    const u4 *candrec = recA_s + ((size_t)bi * st.MP + col) * 2 + half;
+    float *__restrict__ mt = match + (size_t)bi * st.n * st.m;
     u4 bfraw[MTM];
     float px[MTM], py[MTM], pz[MTM];
     int kk[MTM];
     if (slice == 0 && lane < 2 * NLEVEL) ls_s[lane] = lane < NLEVEL ? ls.fa[lane] : ls.fb[lane - NLEVEL];
+    if (slice == 0 && lane < NLEVEL) cnt_s[lane] = st.counts[lane * nb + bi];
 #pragma unroll
     for (int t = 0; t < MTM; ++t) {
         bfraw[t] = ownrec[(t * 32 + col) * 2 + half];
         kk[t] = blockIdx.x * (32 * MTM) + t * 32 + col;
-        const int kc = min(kk[t], a.n - 1);
+        const int kc = min(kk[t], st.n - 1);
         if (half == 0)
 #pragma unroll
-            for (int j = 0; j < NLEVEL; ++j) rl_s[slice][j][t * 32 + col] = ws[j * lstride + (size_t)bi * a.rstride + kc];
+            for (int j = 0; j < NLEVEL; ++j) rl_s[slice][j][t * 32 + col] = ws[j * lstride + (size_t)bi * st.rstride + kc];
         if (COST) {
-            const float *p = xyz1 + ((size_t)bi * a.n + kc) * 3;
+            const float *p = xyz1 + ((size_t)bi * st.n + kc) * 3;
             px[t] = p[0]; py[t] = p[1]; pz[t] = p[2];
         }
     }
     __syncthreads();
-    const int tiles = round_up(a.m, 32) / 32;
-    const int tb = (int)((long)tiles * slice / S), te = (int)((long)tiles * (slice + 1) / S);
+    const int tiles = round_up(st.m, 32) / 32;
     float cost = 0.f;
-    for (int ct = tb; ct < te; ++ct) {
+    for (int ct = slice; ct < tiles; ct += S) {
         const u4 af = candrec[(size_t)ct * 64];
         f16acc mm[MTM];
 #pragma unroll
@@ -786,10 +867,10 @@ __global__ __launch_bounds__(64 * MSL) void emd_mfma_materialize_kernel(MfmaArgs
 #pragma unroll
             for (int r = 0; r < 16; ++r) mm[t][r] = 0.f;
 #pragma unroll 1
-        for (int j = 0; j < NLEVEL; ++j) {
+        for (int j = 0; j < NLEVEL && cnt_s[j] > ct * 32; ++j) {
             float4 rr[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rr[i] = *(const float4 *)(rrpad + ((size_t)j * nb + bi) * a.MP + ct * 32 + 8 * i + 4 * half);
+            for (int i = 0; i < 4; ++i) rr[i] = *(const float4 *)(rr_s + ((size_t)j * nb + bi) * st.MP + ct * 32 + 8 * i + 4 * half);
             const h8 as = scale8(af, ls_s[j]);
             const float fb = ls_s[NLEVEL + j];
 #pragma unroll
@@ -800,27 +881,27 @@ __global__ __launch_bounds__(64 * MSL) void emd_mfma_materialize_kernel(MfmaArgs
                 for (int r = 0; r < 16; ++r) mm[t][r] = __builtin_fmaf(fmul(fast_exp2(acc[r]), rlj), pick4(rr, r), mm[t][r]);
             }
         }
-        // register 4 i + jj of lane (half, col): row ct 32 + 8 i + 4 half + jj, columns kk[0] and kk[0] + 32
-        const bool full = ct * 32 + 32 <= a.m && (int)blockIdx.x * (32 * MTM) + 32 * MTM <= a.n;      // wave-uniform: no masks inside
-        float *row = mt + (size_t)(ct * 32 + 4 * half) * a.n + kk[0];
-        const size_t n4 = (size_t)a.n * 4;
+        // register 4 i + jj of lane (half, col): the row at place ct 32 + 8 i + 4 half + jj of `order`, columns kk[0] and kk[0] + 32
+        const bool full = ct * 32 + 32 <= st.m && (int)blockIdx.x * (32 * MTM) + 32 * MTM <= st.n;      // wave-uniform: no masks inside
 #pragma unroll
-        for (int i = 0; i < 4; ++i, row += n4) {
+        for (int i = 0; i < 4; ++i) {
+            const int4 l4 = *(const int4 *)(l_s + (size_t)bi * st.MP + ct * 32 + 8 * i + 4 * half);
             float4 qx, qy, qz;
             if (COST) {
-                const float *c = c2soa + (size_t)bi * 3 * a.MP + ct * 32 + 8 * i + 4 * half;
-                qx = *(const float4 *)c; qy = *(const float4 *)(c + a.MP); qz = *(const float4 *)(c + 2 * (size_t)a.MP);
+                const float *c = c2soa_s + (size_t)bi * 3 * st.MP + ct * 32 + 8 * i + 4 * half;
+                qx = *(const float4 *)c; qy = *(const float4 *)(c + st.MP); qz = *(const float4 *)(c + 2 * (size_t)st.MP);
             }
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj, row += a.n) {
-                const bool rowok = full || ct * 32 + 8 * i + 4 * half + jj < a.m;
+            for (int jj = 0; jj < 4; ++jj) {
+                const int l = jj == 0 ? l4.x : jj == 1 ? l4.y : jj == 2 ? l4.z : l4.w;
+                float *row = mt + (size_t)(l < 0 ? 0 : l) * st.n + kk[0];
                 const float cx = jj == 0 ? qx.x : jj == 1 ? qx.y : jj == 2 ? qx.z : qx.w;
                 const float cy = jj == 0 ? qy.x : jj == 1 ? qy.y : jj == 2 ? qy.z : qy.w;
                 const float cz = jj == 0 ? qz.x : jj == 1 ? qz.y : jj == 2 ? qz.z : qz.w;
 #pragma unroll
                 for (int t = 0; t < MTM; ++t) {
                     const float v = mm[t][4 * i + jj];
-                    if (full || (rowok && kk[t] < a.n)) {
+                    if (full || (l >= 0 && kk[t] < st.n)) {
                         row[32 * t] = v;
                         if (COST) cost = __builtin_fmaf(v, __builtin_amdgcn_sqrtf(sqdist(px[t], py[t], pz[t], cx, cy, cz)), cost);
                     }
@@ -1140,13 +1221,24 @@ static size_t deferred_bytes(int b, int n, int m) {
     return (size_t)b * NLEVEL * ((size_t)n + m) * sizeof(float) + 16 + (size_t)b * ((size_t)n + 2 * (size_t)m) * sizeof(float4) +
            (size_t)b * m * 12 * sizeof(float) + (size_t)b * ((n + PPW - 1) / PPW) * MAXS * sizeof(float);
 }
-// ... and of the matrix-core passes behind them: 64 B slack | flag (16 B) | meta (16 B per cloud) | A and B records (32 B per
-// padded point each) | padded remainR, ratioL | every level's padded ratioR | cloud 2's coordinate planes
-static size_t mfma_bytes(int b, int n, int m) {
-    const size_t NP = (size_t)(n + MPW - 1) / MPW * MPW, MP = (size_t)(m + MPW - 1) / MPW * MPW;
-    return 64 + 16 + (size_t)b * 16 + 2 * (size_t)b * (NP + MP) * 32 + (size_t)b * (NP + MP) * sizeof(float) +
-           (size_t)NLEVEL * b * MP * sizeof(float) + 3 * (size_t)b * MP * sizeof(float);
+// ... and of the matrix-core passes behind them (MfmaRegions below lays them out; every region 64-byte aligned)
+struct MfmaRegions {
+    size_t flag, meta, count, counts, recB1, recA2d, recA2[2], idx2[2], remR[2], ratioR, ratioL, order, recAs, rrs, c2s, ls, end;
+};
+static MfmaRegions mfma_regions(int b, int n, int m) {
+    const size_t NP = (size_t)(n + MPW - 1) / MPW * MPW, MP = (size_t)(m + MPW - 1) / MPW * MPW, B = (size_t)b;
+    MfmaRegions r;
+    size_t at = 0;
+    auto take = [&](size_t bytes) { const size_t here = at; at += (bytes + 63) & ~(size_t)63; return here; };
+    r.flag = take(16); r.meta = take(B * 16); r.count = take(B * 4); r.counts = take(NLEVEL * B * 4);
+    r.recB1 = take(B * NP * 32); r.recA2d = take(B * MP * 32);
+    for (int u = 0; u < 2; ++u) { r.recA2[u] = take(B * MP * 32); r.idx2[u] = take(B * MP * 4); r.remR[u] = take(B * MP * 4); }
+    r.ratioR = take(B * MP * 4); r.ratioL = take(B * NP * 4); r.order = take(B * MP * 4);
+    r.recAs = take(B * MP * 32); r.rrs = take(NLEVEL * B * MP * 4); r.c2s = take(3 * B * MP * 4); r.ls = take(B * MP * 4);
+    r.end = at;
+    return r;
 }
+static size_t mfma_bytes(int b, int n, int m) { return 64 + mfma_regions(b, n, m).end; }
 
 extern "C" size_t dpf_approxmatch_workspace_bytes(int b, int n, int m) {
     if (b <= 0 || n <= 0 || m <= 0) return 0;
@@ -1177,11 +1269,9 @@ static int approxmatch_impl(int b, int n, int m, const float *xyz1, const float 
     // regions of the matrix-core passes (behind the deferred path's own)
     const int NP = (n + MPW - 1) / MPW * MPW, MP = (m + MPW - 1) / MPW * MPW;
     uint8_t *mbase = deferred ? (uint8_t *)(((uintptr_t)workspace + deferred_bytes(b, n, m) + 63) & ~(uintptr_t)63) : nullptr;
-    unsigned *flag = matrix ? (unsigned *)mbase : nullptr;
-    float *meta = (float *)(mbase + 16);
-    u4 *recA = (u4 *)(mbase + 16 + (size_t)b * 16), *recB = recA + (size_t)b * (NP + MP) * 2;
-    float *wpad = (float *)(recB + (size_t)b * (NP + MP) * 2);
-    float *rrpad = wpad + (size_t)b * (NP + MP), *c2soa = rrpad + (size_t)NLEVEL * b * MP;
+    const MfmaRegions mr = mfma_regions(b, n, m);
+    unsigned *flag = matrix ? (unsigned *)(mbase + mr.flag) : nullptr;
+    float *meta = (float *)(mbase + mr.meta);
     hipLaunchKernelGGL(emd_init_kernel, dim3((n + m + 255) / 256, b), dim3(256), 0, s, n, m, multiL, multiR, temp, flag);
     const int s1 = pick_match_slices(b, n, m), s2 = pick_match_slices(b, m, n);
     const dim3 g1((n + 63) / 64, b), g2((m + 63) / 64, b);
@@ -1199,41 +1289,52 @@ static int approxmatch_impl(int b, int n, int m, const float *xyz1, const float 
                            (const unsigned *)flag);
     int mfma_cost_parts = 0;
     if (matrix) {
-        // the matrix-core family: gate 0.  P1(7) | P2(j), P3(j)+P1(j-1) for j = 7 .. 1 | P2(0), P3(0), P1(-1) | P2(-1), P3(-1)
-        hipLaunchKernelGGL(emd_mfma_pack_kernel, dim3((NP + MP + 255) / 256, b), dim3(256), 0, s, n, m, NP, MP, multiR, xyz1, xyz2,
-                           (const float *)meta, recA, recB, wpad, rrpad, c2soa, (const unsigned *)flag);
-        MfmaArgs ma{n, m, NP, MP, recA, recB, temp, wpad, rstride, flag};
+        // the matrix-core family: gate 0.  Per level: pass 1, pass 2, pass 3 over the live list, then its compaction
+        MfmaState st{};
+        st.n = n; st.m = m; st.NP = NP; st.MP = MP; st.nb = b;
+        st.recB1 = (const u4 *)(mbase + mr.recB1);
+        for (int u = 0; u < 2; ++u) {
+            st.recA2[u] = (u4 *)(mbase + mr.recA2[u]); st.idx2[u] = (int *)(mbase + mr.idx2[u]); st.remainR_c[u] = (float *)(mbase + mr.remR[u]);
+        }
+        st.ratioR_c = (float *)(mbase + mr.ratioR); st.ratioL_p = (float *)(mbase + mr.ratioL);
+        st.count = (int *)(mbase + mr.count); st.counts = (int *)(mbase + mr.counts); st.order = (int *)(mbase + mr.order);
+        st.temp = temp; st.rstride = rstride; st.gate = flag;
+        u4 *recA2_dense = (u4 *)(mbase + mr.recA2d), *recA_s = (u4 *)(mbase + mr.recAs);
+        float *rr_s = (float *)(mbase + mr.rrs), *c2soa_s = (float *)(mbase + mr.c2s);
+        int *l_s = (int *)(mbase + mr.ls);
+        float *ws = (float *)workspace;
+        hipLaunchKernelGGL(emd_mfma_pack_kernel, dim3((NP + MP + 255) / 256, b), dim3(256), 0, s, st, multiR, xyz1, xyz2,
+                           (const float *)meta, recA2_dense, ws, lstride);
         const int m1 = pick_mfma_slices(b, n, m), m2 = pick_mfma_slices(b, m, n);
         const dim3 q1(NP / MPW, b), q2(MP / MPW, b);
-        float *ws = (float *)workspace;
         // level j's 4^(j-7): on the rows' fragments down to 2^-14 (a normal fp16 number), the rest on the columns'
         auto fa_of = [](int j) { const float f = powf(4.0f, (float)(j - 7)); return f < 6.103515625e-5f ? 6.103515625e-5f : f; };
         auto fb_of = [&](int j) { return powf(4.0f, (float)(j - 7)) / fa_of(j); };
-        hipLaunchKernelGGL(emd_mfma_cols_kernel<0>, q1, dim3(64, m1), 0, s, ma, fa_of(7), 0.f, fb_of(7), ws, ws, (const float *)rrpad);
-        int lj = 0;
+        LevelScales ls;
+        int cur = 0, lj = 0;
         for (int j = 7; j > -2; --j, ++lj) {
-            float *rb = ws + lj * lstride, *rrl = rrpad + (size_t)lj * b * MP;
-            hipLaunchKernelGGL(emd_mfma_rows_kernel, q2, dim3(64, m2), 0, s, ma, fa_of(j), fb_of(j), rb, rrl);
-            if (j > -1 && fb_of(j) == fb_of(j - 1)) {
-                hipLaunchKernelGGL(emd_mfma_cols_kernel<2>, q1, dim3(64, m1), 0, s, ma, fa_of(j), fa_of(j - 1), fb_of(j), rb, rb + lstride,
-                                   (const float *)rrl);
+            float *rb = ws + lj * lstride;
+            ls.fa[lj] = fa_of(j); ls.fb[lj] = fb_of(j);
+            hipLaunchKernelGGL(emd_mfma_cols_kernel<0>, q1, dim3(64, m1), 0, s, st, cur, fa_of(j), fb_of(j), rb);
+            hipLaunchKernelGGL(emd_mfma_rows_kernel, q2, dim3(64, m2), 0, s, st, cur, fa_of(j), fb_of(j), rb);
+            hipLaunchKernelGGL(emd_mfma_cols_kernel<3>, q1, dim3(64, m1), 0, s, st, cur, fa_of(j), fb_of(j), rb);
+            if (j > -1) {
+                hipLaunchKernelGGL(emd_mfma_compact_kernel<false>, dim3(b), dim3(1024), 0, s, st, cur, lj);
+                cur ^= 1;
             } else {
-                hipLaunchKernelGGL(emd_mfma_cols_kernel<3>, q1, dim3(64, m1), 0, s, ma, fa_of(j), 0.f, fb_of(j), rb, rb, (const float *)rrl);
-                if (j > -1)
-                    hipLaunchKernelGGL(emd_mfma_cols_kernel<0>, q1, dim3(64, m1), 0, s, ma, fa_of(j - 1), 0.f, fb_of(j - 1), rb + lstride,
-                                       rb + lstride, (const float *)rrl);
+                hipLaunchKernelGGL(emd_mfma_compact_kernel<true>, dim3(b), dim3(1024), 0, s, st, cur, lj);
             }
         }
-        LevelScales ls;
-        for (int j = 7, q = 0; j > -2; --j, ++q) { ls.fa[q] = fa_of(j); ls.fb[q] = fb_of(j); }
+        hipLaunchKernelGGL(emd_mfma_gather_kernel, dim3((MP + 255) / 256, b), dim3(256), 0, s, st, (const u4 *)recA2_dense, xyz2,
+                           (const float *)ws, lstride, recA_s, rr_s, c2soa_s, l_s);
         const dim3 qm(NP / (32 * MTM), b);
         float *costpart_m = rec + (size_t)b * m * 12;
         if (cost)
-            hipLaunchKernelGGL(emd_mfma_materialize_kernel<true>, qm, dim3(64, m1), 0, s, ma, ls, xyz1, (const float *)ws, lstride,
-                               (const float *)rrpad, (const float *)c2soa, match, costpart_m);
+            hipLaunchKernelGGL(emd_mfma_materialize_kernel<true>, qm, dim3(64, m1), 0, s, st, ls, xyz1, (const float *)ws, lstride,
+                               (const u4 *)recA_s, (const float *)rr_s, (const float *)c2soa_s, (const int *)l_s, match, costpart_m);
         else
-            hipLaunchKernelGGL(emd_mfma_materialize_kernel<false>, qm, dim3(64, m1), 0, s, ma, ls, xyz1, (const float *)ws, lstride,
-                               (const float *)rrpad, (const float *)c2soa, match, costpart_m);
+            hipLaunchKernelGGL(emd_mfma_materialize_kernel<false>, qm, dim3(64, m1), 0, s, st, ls, xyz1, (const float *)ws, lstride,
+                               (const u4 *)recA_s, (const float *)rr_s, (const float *)c2soa_s, (const int *)l_s, match, costpart_m);
         mfma_cost_parts = (int)qm.x * m1;
     }
     Levels lv;
