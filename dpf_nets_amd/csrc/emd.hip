@@ -576,9 +576,23 @@ __device__ __forceinline__ h8 scale8(u4 v, float f) {
     const _Float16 fh = (_Float16)f;
     return __builtin_bit_cast(h8, v) * h8{fh, fh, fh, fh, fh, fh, fh, fh};
 }
+// The MFMA as inline assembly: early-clobber destination, wait states written out (2 in front: a source just written by the
+// VALU; 19 behind: an 8-pass result read by the VALU -- the compiler does not know this asm is an MFMA; other waves issue
+// meanwhile, the passes' times did not move).  Why: r05, measured on MI355X -- with __builtin_amdgcn_mfma_f32_32x32x16_f16 the
+// sparse-regime pass 2 (four column tiles per register set, one wave per SIMD) returned a few sums per million that differed
+// from run to run (tests/diag/emd_repeat.py: first at the level where that regime starts, then everywhere through the auction).
+// In the builds that did so the compiler had put the MFMA's destination on the registers of its dying source B
+// ("v_mfma_f32_32x32x16_f16 v[2:17], v[70:73], v[2:5], 0") with several MFMAs and their v_exp_f32 readers interleaved; builds
+// without that allocation, and this serialised form, are bit-stable over every repeat tried.  The overlap ALONE is not the
+// cause: tools/ubench/mfma_overlap.hip runs 2e7 isolated MFMAs per overlap pattern (A or B, head or middle of the
+// destination, 11 or 19 wait states, 1 or 2 waves per SIMD) without one differing result -- so it is something in the
+// compiler's interleaved schedule around such an instruction, which this form takes out of its hands.
+// tools/mfma_overlap_check.py lists the overlapping MFMAs of any .s (the flow / Chamfer / encoder kernels have some, all
+// first-of-chain with C = 0; their bit-exact and replay-equals-eager tests have never flickered).
 __device__ __forceinline__ f16acc pair_exponents(h8 rows, h8 cols) {
-    const f16acc zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(rows, cols, zero, 0, 0, 0);
+    f16acc acc;
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0\n\ts_nop 15\n\ts_nop 2" : "=&v"(acc) : "v"(rows), "v"(cols));
+    return acc;
 }
 
 // Passes over cloud 1's points (columns; cloud 2's LIVE points stream past as row tiles with their weights):
@@ -603,16 +617,14 @@ __global__ __launch_bounds__(64 * MSL) void emd_mfma_cols_kernel(MfmaState st, i
 #pragma unroll
     for (int t = 0; t < MT; ++t) sa[t] = 0.f;
     if (tb < te) {
-        u4 af = candrec[(size_t)tb * 64];
-        float4 wa[4];
+        // two register sets A / B, each loaded one tile before its use and first touched after the other tile's arithmetic
+        // (a rotating copy made the compiler wait for the load it had just issued -- a full memory round trip per tile
+        // whenever few waves share the SIMD)
+        u4 afA = candrec[(size_t)tb * 64], afB;
+        float4 waA[4], waB[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wa[i] = *(const float4 *)(w0 + tb * 32 + 8 * i);
-        for (int ct = tb; ct < te; ++ct) {
-            const int nx = min(ct + 1, te - 1);
-            const u4 afn = candrec[(size_t)nx * 64];
-            float4 wan[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) wan[i] = *(const float4 *)(w0 + nx * 32 + 8 * i);
+        for (int i = 0; i < 4; ++i) waA[i] = *(const float4 *)(w0 + tb * 32 + 8 * i);
+        auto tile = [&](u4 af, const float4 (&wa)[4]) {
             const h8 as = scale8(af, fa);
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
@@ -620,9 +632,19 @@ __global__ __launch_bounds__(64 * MSL) void emd_mfma_cols_kernel(MfmaState st, i
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sa[t] = __builtin_fmaf(fast_exp2(acc[r]), pick4(wa, r), sa[t]);
             }
-            af = afn;
+        };
+        for (int ct = tb; ct < te; ct += 2) {
+            const int n1 = min(ct + 1, te - 1), n2 = min(ct + 2, te - 1);
+            afB = candrec[(size_t)n1 * 64];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wa[i] = wan[i];
+            for (int i = 0; i < 4; ++i) waB[i] = *(const float4 *)(w0 + n1 * 32 + 8 * i);
+            asm volatile("" ::: "memory");
+            tile(afA, waA);
+            afA = candrec[(size_t)n2 * 64];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) waA[i] = *(const float4 *)(w0 + n2 * 32 + 8 * i);
+            asm volatile("" ::: "memory");
+            if (ct + 1 < te) tile(afB, waB);
         }
     }
 #pragma unroll
@@ -661,48 +683,72 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 // Pass 2, over cloud 2's live points -- which stay the ROWS: a wave owns MT row tiles (their A fragments), cloud 1's points
 // stream past as column tiles with ratioL (one weight per lane), the sums run along the accumulators' columns, i.e. across
 // lanes: per-lane partial sums for every (tile, register) and one butterfly per such sum at the end.
+// RT row tiles per wave: 4 while more than half of cloud 2 is live (regime 1); 1 below that (regime 2: a workgroup's waves then
+// walk 32 x RT x n / S pairs in a row with nobody else on their SIMD -- with RT = 4 a sparse level took the same 100 us as the
+// dense one).  Both are launched from the second level on; the one whose regime it is not returns at once.
 //   sumr = remainR[l] * sum_k w ratioL[k];  ratioR[l] = min(remainR[l] / (sumr + 1e-9), 1) * remainR[l];
 //   remainR[l] = max(0, remainR[l] - sumr)
-__global__ __launch_bounds__(64 * MSL) void emd_mfma_rows_kernel(MfmaState st, int cur, float fa, float fb, float *rb_cur) {
-    __shared__ float part[MSL][MPW];
+template <int RT>
+__global__ __launch_bounds__(64 * MSL) void emd_mfma_rows_kernel(MfmaState st, int cur, float fa, float fb, float *rb_cur, int regime) {
+    constexpr int RPW = 32 * RT;                                    // rows per workgroup
+    __shared__ float part[MSL][RPW];
     if (gate_closed(st.gate, 0u)) return;
     const int bi = blockIdx.y, lane = threadIdx.x, slice = __builtin_amdgcn_readfirstlane(threadIdx.y), S = blockDim.y;
     const int cnt = st.count[bi];
-    if ((int)blockIdx.x * MPW >= cnt) return;                       // (whole workgroup)
+    if ((int)blockIdx.x * RPW >= cnt) return;                       // (whole workgroup)
+    if (regime == 1 ? 2 * cnt <= st.m : regime == 2 ? 2 * cnt > st.m : false) return;
     const int half = lane >> 5, col = lane & 31;
-    const u4 *ownrec = st.recA2[cur] + ((size_t)bi * st.MP + blockIdx.x * MPW) * 2;
+    const u4 *ownrec = st.recA2[cur] + ((size_t)bi * st.MP + blockIdx.x * RPW) * 2;
     const u4 *candrec = st.recB1 + ((size_t)bi * st.NP + col) * 2 + half;
     const float *wl = st.ratioL_p + (size_t)bi * st.NP;
-    h8 af[MT];
+    h8 af[RT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) af[t] = scale8(ownrec[(t * 32 + col) * 2 + half], fa);
+    for (int t = 0; t < RT; ++t) af[t] = scale8(ownrec[(t * 32 + col) * 2 + half], fa);
     const int tiles = round_up(st.n, 32) / 32;
     const int tb = (int)((long)tiles * slice / S), te = (int)((long)tiles * (slice + 1) / S);
-    float s[MT][16];
+    float s[RT][16];
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
     if (tb < te) {
-        u4 bfr = candrec[(size_t)tb * 64];
-        float w = wl[tb * 32 + col];
-        for (int ct = tb; ct < te; ++ct) {
-            const int nx = min(ct + 1, te - 1);
-            const u4 bfn = candrec[(size_t)nx * 64];
-            const float wn = wl[nx * 32 + col];
-            const h8 bs = scale8(bfr, fb);
+        // register sets A / B as in emd_mfma_cols_kernel, NB column tiles each: in the sparse regime a wave is alone on its SIMD
+        // and a tile's arithmetic (~400 cycles) is far shorter than the loads' round trip -- four tiles per set there
+        constexpr int NB = RT == 1 ? 4 : 1;
+        u4 bfA[NB], bfB[NB];
+        float wA[NB], wB[NB];
+        auto load = [&](int c0, u4 (&bfr)[NB], float (&w)[NB]) {
 #pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                const f16acc acc = pair_exponents(af[t], bs);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[t][r] = __builtin_fmaf(fast_exp2(acc[r]), w, s[t][r]);
+            for (int u = 0; u < NB; ++u) {
+                const int c = min(c0 + u, te - 1);
+                bfr[u] = candrec[(size_t)c * 64];
+                w[u] = c0 + u < te ? wl[c * 32 + col] : 0.f;          // (a repeated last tile weighs nothing)
             }
-            bfr = bfn;
-            w = wn;
+        };
+        auto tiles_of = [&](const u4 (&bfr)[NB], const float (&w)[NB]) {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const h8 bs = scale8(bfr[u], fb);
+#pragma unroll
+                for (int t = 0; t < RT; ++t) {
+                    const f16acc acc = pair_exponents(af[t], bs);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[t][r] = __builtin_fmaf(fast_exp2(acc[r]), w[u], s[t][r]);
+                }
+            }
+        };
+        load(tb, bfA, wA);
+        for (int ct = tb; ct < te; ct += 2 * NB) {
+            load(ct + NB, bfB, wB);
+            asm volatile("" ::: "memory");
+            tiles_of(bfA, wA);
+            load(ct + 2 * NB, bfA, wA);
+            asm volatile("" ::: "memory");
+            if (ct + NB < te) tiles_of(bfB, wB);
         }
     }
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float tot = half_wave_sum(s[t][r]);
@@ -711,8 +757,8 @@ __global__ __launch_bounds__(64 * MSL) void emd_mfma_rows_kernel(MfmaState st, i
     __syncthreads();
     float *remainR = st.temp + (size_t)bi * (st.n + st.m) * 2 + st.n;
     float *ratioR = rb_cur + (size_t)bi * st.rstride + st.n;
-    for (int tid = slice * 64 + lane; tid < MPW; tid += 64 * S) {
-        const int pos = blockIdx.x * MPW + tid;
+    for (int tid = slice * 64 + lane; tid < RPW; tid += 64 * S) {
+        const int pos = blockIdx.x * RPW + tid;
         if (pos >= cnt) continue;
         const size_t at = (size_t)bi * st.MP + pos;
         const int l = st.idx2[cur][at];
@@ -901,9 +947,12 @@ __global__ __launch_bounds__(64 * MSL) void emd_mfma_materialize_kernel(MfmaStat
 #pragma unroll
                 for (int t = 0; t < MTM; ++t) {
                     const float v = mm[t][4 * i + jj];
-                    if (full || (l >= 0 && kk[t] < st.n)) {
-                        row[32 * t] = v;
-                        if (COST) cost = __builtin_fmaf(v, __builtin_amdgcn_sqrtf(sqdist(px[t], py[t], pz[t], cx, cy, cz)), cost);
+                    const bool live = full || (l >= 0 && kk[t] < st.n);
+                    if (live) row[32 * t] = v;
+                    // the distance only where some entry of the wave's 2 x 32 is worth it: almost every pair's weight is below 1e-12
+                    // of a matched pair's (what is skipped sums to < 1e-6 of the cost)
+                    if (COST && __ballot(live && v > 1e-12f) != 0ull) {
+                        if (live) cost = __builtin_fmaf(v, __builtin_amdgcn_sqrtf(sqdist(px[t], py[t], pz[t], cx, cy, cz)), cost);
                     }
                 }
             }
@@ -1316,7 +1365,12 @@ static int approxmatch_impl(int b, int n, int m, const float *xyz1, const float 
             float *rb = ws + lj * lstride;
             ls.fa[lj] = fa_of(j); ls.fb[lj] = fb_of(j);
             hipLaunchKernelGGL(emd_mfma_cols_kernel<0>, q1, dim3(64, m1), 0, s, st, cur, fa_of(j), fb_of(j), rb);
-            hipLaunchKernelGGL(emd_mfma_rows_kernel, q2, dim3(64, m2), 0, s, st, cur, fa_of(j), fb_of(j), rb);
+            if (j == 7) {
+                hipLaunchKernelGGL(emd_mfma_rows_kernel<4>, q2, dim3(64, m2), 0, s, st, cur, fa_of(j), fb_of(j), rb, 0);
+            } else {
+                hipLaunchKernelGGL(emd_mfma_rows_kernel<4>, q2, dim3(64, m2), 0, s, st, cur, fa_of(j), fb_of(j), rb, 1);
+                hipLaunchKernelGGL(emd_mfma_rows_kernel<1>, dim3(MP / 32, b), dim3(64, MSL), 0, s, st, cur, fa_of(j), fb_of(j), rb, 2);
+            }
             hipLaunchKernelGGL(emd_mfma_cols_kernel<3>, q1, dim3(64, m1), 0, s, st, cur, fa_of(j), fb_of(j), rb);
             if (j > -1) {
                 hipLaunchKernelGGL(emd_mfma_compact_kernel<false>, dim3(b), dim3(1024), 0, s, st, cur, lj);

@@ -109,6 +109,33 @@ def test_matrix_core_passes_against_the_difference_form(shape):
     np.testing.assert_allclose(c_mx.cpu().numpy(), S.matchcost(a, b, m_mx.cpu().numpy()), rtol=2e-5)
 
 
+def test_matrix_core_passes_repeat_bit_for_bit():
+    """Six calls on the same clouds: the same bits in every level's ratio vectors (read out of the workspace) and in `match`.
+    (r05: with the compiler-scheduled MFMA builtin the sparse-regime pass 2 returned a few different sums per million from run
+    to run -- csrc/emd.hip, pair_exponents; this is the check that found it, tests/diag/emd_repeat.py.)"""
+    _gpu()
+    from dpf_nets_amd._lib import lib, check, current_stream
+    L = lib()
+    for (B, n, m) in ((2, 2048, 2048), (3, 1500, 900)):
+        a, b = chamfer_inputs(700 + n, B, n, m)
+        ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+        first = None
+        for it in range(6):
+            match = torch.empty((B, m, n), device="cuda")
+            temp = torch.empty((B, (n + m) * 2), device="cuda")
+            nbytes = L.dpf_approxmatch_workspace_bytes(B, n, m)
+            ws = torch.zeros((nbytes,), dtype=torch.uint8, device="cuda")
+            check(L.dpf_approxmatch_ws(B, n, m, ta.data_ptr(), tb.data_ptr(), match.data_ptr(), temp.data_ptr(), ws.data_ptr(),
+                                       nbytes, current_stream()), "approxmatch_ws")
+            torch.cuda.synchronize()
+            got = (ws[:9 * B * (n + m) * 4].clone(), match.view(torch.int32).clone())
+            if first is None:
+                first = got
+            else:
+                assert torch.equal(got[0], first[0]), it
+                assert torch.equal(got[1], first[1]), it
+
+
 @pytest.mark.parametrize("kind", ["scale", "offset", "inf", "nan"])
 def test_matrix_core_passes_leave_out_of_range_clouds_to_the_valu_kernels(kind):
     """The fp16 operands hold |x - c|^2 <= 346 (c = cloud 1's centroid); a call with any coordinate beyond that, or not finite,
