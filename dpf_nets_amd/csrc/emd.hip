@@ -18,6 +18,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "dpf_hip.h"
 #include "zero_fill.h"
 
@@ -927,36 +929,43 @@ __global__ __launch_bounds__(64 * MSL) void emd_mfma_materialize_kernel(MfmaStat
                 for (int r = 0; r < 16; ++r) mm[t][r] = __builtin_fmaf(fmul(fast_exp2(acc[r]), rlj), pick4(rr, r), mm[t][r]);
             }
         }
-        // register 4 i + jj of lane (half, col): the row at place ct 32 + 8 i + 4 half + jj of `order`, columns kk[0] and kk[0] + 32
-        const bool full = ct * 32 + 32 <= st.m && (int)blockIdx.x * (32 * MTM) + 32 * MTM <= st.n;      // wave-uniform: no masks inside
+        // register 4 i + jj of lane (half, col): the row at place ct 32 + 8 i + 4 half + jj of `order`, columns kk[0] and kk[0] + 32.
+        // FULL (wave-uniform, all but the last tiles): no lane masks anywhere -- the masked form of this stage was 1 200
+        // instructions per row tile, twice the level loop
+        auto emit = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int4 l4 = *(const int4 *)(l_s + (size_t)bi * st.MP + ct * 32 + 8 * i + 4 * half);
-            float4 qx, qy, qz;
-            if (COST) {
-                const float *c = c2soa_s + (size_t)bi * 3 * st.MP + ct * 32 + 8 * i + 4 * half;
-                qx = *(const float4 *)c; qy = *(const float4 *)(c + st.MP); qz = *(const float4 *)(c + 2 * (size_t)st.MP);
-            }
+            for (int i = 0; i < 4; ++i) {
+                const int4 l4 = *(const int4 *)(l_s + (size_t)bi * st.MP + ct * 32 + 8 * i + 4 * half);
+                float4 qx, qy, qz;
+                if (COST) {
+                    const float *c = c2soa_s + (size_t)bi * 3 * st.MP + ct * 32 + 8 * i + 4 * half;
+                    qx = *(const float4 *)c; qy = *(const float4 *)(c + st.MP); qz = *(const float4 *)(c + 2 * (size_t)st.MP);
+                }
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int l = jj == 0 ? l4.x : jj == 1 ? l4.y : jj == 2 ? l4.z : l4.w;
-                float *row = mt + (size_t)(l < 0 ? 0 : l) * st.n + kk[0];
-                const float cx = jj == 0 ? qx.x : jj == 1 ? qx.y : jj == 2 ? qx.z : qx.w;
-                const float cy = jj == 0 ? qy.x : jj == 1 ? qy.y : jj == 2 ? qy.z : qy.w;
-                const float cz = jj == 0 ? qz.x : jj == 1 ? qz.y : jj == 2 ? qz.z : qz.w;
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int l = jj == 0 ? l4.x : jj == 1 ? l4.y : jj == 2 ? l4.z : l4.w;
+                    float *row = mt + (size_t)(FULL ? l : max(l, 0)) * st.n + kk[0];
+                    const float cx = jj == 0 ? qx.x : jj == 1 ? qx.y : jj == 2 ? qx.z : qx.w;
+                    const float cy = jj == 0 ? qy.x : jj == 1 ? qy.y : jj == 2 ? qy.z : qy.w;
+                    const float cz = jj == 0 ? qz.x : jj == 1 ? qz.y : jj == 2 ? qz.z : qz.w;
 #pragma unroll
-                for (int t = 0; t < MTM; ++t) {
-                    const float v = mm[t][4 * i + jj];
-                    const bool live = full || (l >= 0 && kk[t] < st.n);
-                    if (live) row[32 * t] = v;
-                    // the distance only where some entry of the wave's 2 x 32 is worth it: almost every pair's weight is below 1e-12
-                    // of a matched pair's (what is skipped sums to < 1e-6 of the cost)
-                    if (COST && __ballot(live && v > 1e-12f) != 0ull) {
-                        if (live) cost = __builtin_fmaf(v, __builtin_amdgcn_sqrtf(sqdist(px[t], py[t], pz[t], cx, cy, cz)), cost);
+                    for (int t = 0; t < MTM; ++t) {
+                        const float v = mm[t][4 * i + jj];
+                        const bool live = FULL || (l >= 0 && kk[t] < st.n);
+                        if (live) row[32 * t] = v;
+                        // the distance only where some entry of the wave's 2 x 32 is worth it: almost every pair's weight is below
+                        // 1e-12 of a matched pair's (what is skipped sums to < 1e-6 of the cost)
+                        if (COST && __ballot(live && v > 1e-12f) != 0ull) {
+                            const float d = __builtin_amdgcn_sqrtf(sqdist(px[t], py[t], pz[t], cx, cy, cz));
+                            cost = __builtin_fmaf(live ? v : 0.f, d, cost);
+                        }
                     }
                 }
             }
-        }
+        };
+        if (ct * 32 + 32 <= st.m && (int)blockIdx.x * (32 * MTM) + 32 * MTM <= st.n) emit(std::true_type{});
+        else emit(std::false_type{});
     }
     if (COST) {
         for (int o = 32; o > 0; o >>= 1) cost += __shfl_xor(cost, o);
