@@ -13,6 +13,11 @@
 // needs between passes.  The (B, m, n) `match` tensor is the only large
 // object: pass 3 read-modify-writes it once per level (the first level writes
 // without reading, which replaces the reference's zero-fill, approxmatch.cu:16-17).
+//
+// Three forms, same entry points: (1) read-modify-write (no workspace): the reference's data flow, one launch per pass;
+// (2) deferred, packed VALU (workspace): level state in the workspace, `match` written once, bit-identical to (1);
+// (3) deferred, matrix cores (workspace, default since r05; further down): squared distances by MFMA, the passes over the
+// LIVE points of cloud 2 only, tolerance parity with (1) / (2) -- which of (2) and (3) runs is decided per call on the device.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -416,10 +421,9 @@ __global__ __launch_bounds__(1024) void emd_match2_kernel(int n, int m, float lv
 // The records are level-independent and carry the STEEPEST level's scale (4^7: every lo part a normal fp16 number where the
 // exponent's absolute error matters most); level j's 4^(j-7) is a power of two <= 1 and goes onto the candidates' fragment
 // with four exact v_pk_mul_f16 (down to 2^-14, the rest onto the own points' fragments once per kernel) -- lo parts that
-// fall into the subnormals there cost < 2e-6 absolute in the exponent.  c is cloud 1's centroid (the expanded form's cancellation error grows with |q'|^2; centring keeps it at the
-// cloud's own radius).  What is left per pair is exp2 and one FMA with the candidate's weight -- 32 VALU instructions per 1024
-// pairs where the packed form issues 80.  Pass 3 of level j and pass 1 of level j-1 walk the same pairs (cloud 1's points past
-// cloud 2's) and are ONE launch -- 20 launches for the 27 passes.
+// fall into the subnormals there cost < 2e-6 absolute in the exponent.  c is cloud 1's centroid (the expanded form's
+// cancellation error grows with |q'|^2; centring keeps it at the cloud's own radius).  What is left per pair is exp2 and one
+// FMA with the candidate's weight -- 32 VALU instructions per 1024 pairs where the packed form issues 80.
 // Accuracy (tests/diag/emd_expanded_form_error.py, CPU, same auction with only d^2 exchanged; n = m = 1024, centred and
 // uncentred clouds, uniform and near-pair): cost within 2.4e-6 of the difference form's (contract 1e-4), matching entries
 // within 8.5e-4 of their maximum 1.0 (the auction amplifies any last-bit change that much: the fp32-exact expanded form
@@ -864,12 +868,14 @@ struct LevelScales { float fa[NLEVEL], fb[NLEVEL]; };
 
 // match[l][k] = sum over the levels, in level order, of w_j(l, k) ratioL_j[k] ratioR_j[l] with the SAME w_j the passes saw (the
 // same MFMA on the same operands) -- with the difference form's weights here the rows and columns of `match` summed to 1 +- 4e-3
-// (the expanded form's error at the steep levels) instead of 1 +- 1e-6.  A wave owns two 32-column tiles of cloud 1 and takes
+// (the expanded form's error at the steep levels) instead of 1 +- 1e-6.  A wave owns MTM 32-column tiles of cloud 1 and takes
 // every S-th 32-row tile of cloud 2 IN `order`: tile T gets the levels whose list is longer than 32 T (the others' ratioR are
 // all zero there) -- per (pair, live level): exp2, a multiplication, an FMA.  The accumulator layout writes 128 contiguous
 // bytes of a `match` row per register and half-wave.
 // COST: sum match * |x1 - x2| with the distance in the difference form, partial sums per (cloud, workgroup, slice) for
 // emd_cost_sum_kernel -- fixed order, deterministic.
+// Measured (cfg5, 16 x 8192^2): 1.18 ms = `match` written at 3.6 TB/s; MTM = 4 (512 contiguous bytes per row and wave) and the
+// unmasked store path moved it by < 10 %: it is the write that bounds it, not the instruction count.
 constexpr int MTM = 2;
 template <bool COST>
 __global__ __launch_bounds__(64 * MSL) void emd_mfma_materialize_kernel(MfmaState st, LevelScales ls, const float *__restrict__ xyz1,
