@@ -1,6 +1,6 @@
 """profiles/traffic.json entry "approxmatch_cost/B<b>_N<n>": HBM bytes of ONE ApproxMatchCost call (all of its emd_* launches) from
 the FETCH_SIZE / WRITE_SIZE passes of tools/pmc_cfg5.sh, corrected as MI355X_MICROARCH.md prescribes (both counters in KiB;
-FETCH_SIZE tallies 128-B requests at 64 B on gfx950 -> x2).   usage: pmc_traffic_emd.py <pmc dir> <B> <N> <traffic.json>"""
+FETCH_SIZE tallies 128-B requests at 64 B on gfx950 -> x2).   usage: pmc_traffic_emd.py <pmc dir> <B> <N> <traffic.json> [source note]"""
 import json
 import os
 import re
@@ -19,7 +19,7 @@ def parse(path):
     return calls, vals
 
 
-def main(d, B, N, out_json):
+def main(d, B, N, out_json, source="profiles/r03_pmc_cfg5_pass1.txt + _pass2.txt"):
     tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
     ncalls = None
     per_kernel = {}
@@ -37,7 +37,7 @@ def main(d, B, N, out_json):
                 ncalls = disp if ncalls is None else min(ncalls, disp)
     ncalls = ncalls or 1
     e = {"fetch_bytes_raw": tot["FETCH_SIZE"] * 1024 / ncalls, "fetch_bytes": tot["FETCH_SIZE"] * 1024 * 2 / ncalls,
-         "write_bytes": tot["WRITE_SIZE"] * 1024 / ncalls, "calls": ncalls, "source": "profiles/r03_pmc_cfg5_pass1.txt + _pass2.txt",
+         "write_bytes": tot["WRITE_SIZE"] * 1024 / ncalls, "calls": ncalls, "source": source,
          "per_kernel_KiB_per_dispatch": per_kernel}
     e["hbm_bytes"] = e["fetch_bytes"] + e["write_bytes"]
     res = json.load(open(out_json)) if os.path.exists(out_json) else {}
@@ -47,4 +47,4 @@ def main(d, B, N, out_json):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:6])

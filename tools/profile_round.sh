@@ -31,6 +31,10 @@ ls -la $OUT $OUT/train
 bash tools/kt_run.sh ${TAG}_prof/kernel_trace_stats_b4 --batch 4 --no-cpu-baseline --no-extra --pipelined 0 --steps 300 --warmup 50 --settle 100 > /dev/null 2>&1
 bash tools/pmc_run.sh ${TAG}_prof/pmc_b4 --batch 4 > /dev/null 2>&1
 python3 tools/pmc_traffic.py $OUT/pmc_b4 B4_N2048_L14_f16x3 $OUT/traffic.json "profiles/${TAG}_pmc_b4_pass4.txt + ${TAG}_pmc_b4_pass5.txt" > /dev/null 2>&1
+# r05: approx-EMD at cfg5 -- kernel trace and the two HBM counter passes of the matrix-core path
+bash tools/kt_run.sh ${TAG}_prof/emd_kernel_trace --config cfg5 --no-cpu-baseline --no-extra --steps 5 --warmup 2 > /dev/null 2>&1
+bash tools/pmc_cfg5.sh ${TAG}_prof/pmc_cfg5 > /dev/null 2>&1
+python3 tools/pmc_traffic_emd.py $OUT/pmc_cfg5 16 8192 $OUT/traffic.json "profiles/${TAG}_pmc_cfg5_pass1.txt + _pass2.txt" > /dev/null 2>&1
 # r05: the rank-sized training step (B = 8, G = 512) and the phase stamps of the training kernels
 python3 bench.py --leg train --batch 8 --latent 512 --steps 40 --warmup 12 > $OUT/bench_train_B8_G512.json 2>> $OUT/bench_default.err
 (cd dpf_nets_amd/csrc && make -s prof > /dev/null 2>&1)
