@@ -962,7 +962,7 @@ def train_step_leg(args, rank, world, dist, device, batch, layers, steps, warmup
         kernels["sum_us_per_layer"] = per_layer
         kernels["note"] = ("HIP events around every launch of the stack's kernels, %d eager steps (dpf_train_kernel_times): event to "
                            "event, i.e. kernel duration + the ~1.5 us launch gap of an eager launch -- the rocprofv3 kernel durations of "
-                           "the same command are in profiles/r03_train_kernel_trace.txt; gflop = "
+                           "the same command are in profiles/r05_train_kernel_trace.txt; gflop = "
                            "what the kernel executes per launch incl. the recomputation of the conditioner; tfold / tcolsum / "
                            "tstats_x / tbwd3f are reductions (latency-bound, no matrix work)" % ksteps)
     except Exception as e:       # noqa: BLE001
