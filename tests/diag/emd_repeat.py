@@ -6,8 +6,10 @@ sys.path.insert(0, root)
 from dpf_nets_amd._lib import lib, check, current_stream
 from oracle.gen_golden import chamfer_inputs
 L = lib()
-B, n, m = 2, 2048, 2048
+B, n, m = (2, int(sys.argv[1]), int(sys.argv[1])) if len(sys.argv) > 1 else (2, 2048, 2048)
 a, b = chamfer_inputs(700 + n, B, n, m)
+if len(sys.argv) > 2:
+    a, b = chamfer_inputs(4242, 2, n, n); b = (a[:, ::-1] + 0.03 * b).astype(np.float32).copy()
 ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
 runs = []
 for it in range(6):

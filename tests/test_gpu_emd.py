@@ -110,21 +110,24 @@ def test_matrix_core_passes_against_the_difference_form(shape):
 
 
 def test_matrix_core_passes_repeat_bit_for_bit():
-    """Six calls on the same clouds: the same bits in every level's ratio vectors (read out of the workspace) and in `match`.
-    (r05: with the compiler-scheduled MFMA builtin the sparse-regime pass 2 returned a few different sums per million from run
-    to run -- csrc/emd.hip, pair_exponents; this is the check that found it, tests/diag/emd_repeat.py.)"""
+    """Repeated calls on the same clouds: the same bits in every level's ratio vectors (read out of the workspace) and in
+    `match`.  r05 history (csrc/emd.hip, pair_exponents): with the literal-zero C operand the sparse-regime pass 2 returned a few
+    different sums per million from run to run at 2048^2; the inline-asm MFMA that cured that flickered itself at 8192^2 with two
+    or more waves per SIMD (~1 sum per call at B = 2, ~50 at B = 16).  These are the sizes and regimes that showed it."""
     _gpu()
     from dpf_nets_amd._lib import lib, check, current_stream
     L = lib()
-    for (B, n, m) in ((2, 2048, 2048), (3, 1500, 900)):
+    for (B, n, m, reps) in ((2, 2048, 2048, 6), (3, 1500, 900, 6), (2, 8192, 8192, 5), (6, 8192, 8192, 3)):
         a, b = chamfer_inputs(700 + n, B, n, m)
+        if n == 8192:
+            b = (a[:, ::-1] + 0.03 * b).astype(np.float32).copy()       # the matching of the specified-size test
         ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+        match = torch.empty((B, m, n), device="cuda")
+        temp = torch.empty((B, (n + m) * 2), device="cuda")
+        nbytes = L.dpf_approxmatch_workspace_bytes(B, n, m)
+        ws = torch.zeros((nbytes,), dtype=torch.uint8, device="cuda")
         first = None
-        for it in range(6):
-            match = torch.empty((B, m, n), device="cuda")
-            temp = torch.empty((B, (n + m) * 2), device="cuda")
-            nbytes = L.dpf_approxmatch_workspace_bytes(B, n, m)
-            ws = torch.zeros((nbytes,), dtype=torch.uint8, device="cuda")
+        for it in range(reps):
             check(L.dpf_approxmatch_ws(B, n, m, ta.data_ptr(), tb.data_ptr(), match.data_ptr(), temp.data_ptr(), ws.data_ptr(),
                                        nbytes, current_stream()), "approxmatch_ws")
             torch.cuda.synchronize()
@@ -132,8 +135,10 @@ def test_matrix_core_passes_repeat_bit_for_bit():
             if first is None:
                 first = got
             else:
-                assert torch.equal(got[0], first[0]), it
-                assert torch.equal(got[1], first[1]), it
+                assert torch.equal(got[0], first[0]), (B, n, it)
+                assert torch.equal(got[1], first[1]), (B, n, it)
+        del match, ws, first, got
+        torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("kind", ["scale", "offset", "inf", "nan"])

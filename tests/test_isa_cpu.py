@@ -120,17 +120,14 @@ def test_skewed_eval_kernel_waits_for_its_weight_dma_inside_the_layer_loop(isa_f
         assert any(len(lines) // 4 < w < loop_dma[0] for w in waits), "no vmcnt(0) between the loop's top and its DMA issue"
 
 
-def test_emd_matrix_passes_issue_their_mfma_with_an_early_clobber_destination(tmp_path_factory):
-    """csrc/emd.hip, pair_exponents (r05): with the compiler-scheduled builtin the sparse-regime pass 2 returned sums that
-    differed from run to run on MI355X; in those builds the MFMA's destination sat on the registers of its source B.  The
-    kernels issue the instruction as inline asm with an early-clobber destination and written-out wait states -- checked
-    here on the ISA: every MFMA of emd.hip keeps its destination apart from both sources (tools/mfma_overlap_check.py) and
-    is followed by its wait states, and the source holds no MFMA builtin."""
+def test_emd_matrix_passes_keep_the_mfma_destination_apart(tmp_path_factory):
+    """csrc/emd.hip, pair_exponents (r05): with a literal-zero C operand the compiler gives the MFMA's destination the registers
+    of a dying source, and in the builds where it did a pass returned sums that differed from run to run on MI355X; with C in
+    registers (an opaque zero) it uses the early-clobber form.  Checked on the ISA: every MFMA of emd.hip has a register C and
+    a destination apart from both sources (tools/mfma_overlap_check.py)."""
     import sys
     if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
         pytest.skip("no hipcc")
-    src = open(os.path.join(CSRC, "emd.hip")).read()
-    assert "__builtin_amdgcn_mfma" not in re.sub(r"//[^\n]*", "", src)
     out = tmp_path_factory.mktemp("isa") / "emd.s"
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-ffp-contract=off",
            "-S", "--cuda-device-only", "-o", str(out), os.path.join(CSRC, "emd.hip")]
@@ -140,7 +137,6 @@ def test_emd_matrix_passes_issue_their_mfma_with_an_early_clobber_destination(tm
     import mfma_overlap_check as chk
     total, bad = chk.scan(str(out))
     assert total >= 20 and not bad, (total, bad[:3])
-    lines = out.read_text().splitlines()
-    for i, ln in enumerate(lines):
+    for ln in out.read_text().splitlines():
         if "v_mfma_" in ln:
-            assert "s_nop 15" in lines[i + 1] and "s_nop 2" in lines[i + 2], (ln, lines[i + 1:i + 3])
+            assert re.search(r",\s*v\[\d+:\d+\]\s*$", ln), ln          # C is a register tuple, not the literal 0
