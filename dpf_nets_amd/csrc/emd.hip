@@ -1376,8 +1376,7 @@ static int approxmatch_impl(int b, int n, int m, const float *xyz1, const float 
         float *ws = (float *)workspace;
         hipLaunchKernelGGL(emd_mfma_pack_kernel, dim3((NP + MP + 255) / 256, b), dim3(256), 0, s, st, multiR, xyz1, xyz2,
                            (const float *)meta, recA2_dense, ws, lstride);
-        int m1 = pick_mfma_slices(b, n, m), m2 = pick_mfma_slices(b, m, n);
-        if (const char *e = getenv("DPF_EMD_DBG_S")) m1 = m2 = atoi(e);             // (tests/diag/emd_flake_rate.py: slices per workgroup)
+        const int m1 = pick_mfma_slices(b, n, m), m2 = pick_mfma_slices(b, m, n);
         const dim3 q1(NP / MPW, b), q2(MP / MPW, b);
         // level j's 4^(j-7): on the rows' fragments down to 2^-14 (a normal fp16 number), the rest on the columns'
         auto fa_of = [](int j) { const float f = powf(4.0f, (float)(j - 7)); return f < 6.103515625e-5f ? 6.103515625e-5f : f; };
@@ -1388,7 +1387,6 @@ static int approxmatch_impl(int b, int n, int m, const float *xyz1, const float 
             float *rb = ws + lj * lstride;
             ls.fa[lj] = fa_of(j); ls.fb[lj] = fb_of(j);
             hipLaunchKernelGGL(emd_mfma_cols_kernel<0>, q1, dim3(64, m1), 0, s, st, cur, fa_of(j), fb_of(j), rb);
-            if (getenv("DPF_EMD_DBG_STOP")) return (int)hipGetLastError();      // (tests/diag/emd_flake_rate.py: nothing behind the first pass)
             if (j == 7) {
                 hipLaunchKernelGGL(emd_mfma_rows_kernel<4>, q2, dim3(64, m2), 0, s, st, cur, fa_of(j), fb_of(j), rb, 0);
             } else {

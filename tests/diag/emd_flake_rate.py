@@ -1,5 +1,7 @@
 """Diagnostic: how often the first level's passes of the matrix-core approx-EMD return different bits on the same input.
-40 calls; the first level's ratioL (pass 1) and ratioR (pass 2) of every call against the most common result."""
+N calls; the first level's ratioL (pass 1) and ratioR (pass 2) of every call against call 0's.  (During the r05 hunt the library
+had two debug switches, since removed: DPF_EMD_DBG_STOP -- return behind the first pass, which showed pass 1 alone flickering --
+and DPF_EMD_DBG_S -- slices per workgroup, which showed it needs two waves per SIMD.)   FB=<clouds> emd_flake_rate.py [n] [calls]"""
 import os, sys, collections
 import numpy as np, torch
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
