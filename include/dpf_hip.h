@@ -99,13 +99,11 @@ int dpf_nndistancegrad(int b, int n, const float *xyz1, int m, const float *xyz2
 int dpf_approxmatch(int b, int n, int m, const float *xyz1, const float *xyz2,
                     float *match, float *temp, dpf_stream_t stream);
 
-/* Same results as dpf_approxmatch, bit for bit, with `match` written ONCE: the
- * nine levels' ratio vectors and the packed (x, y, z, weight) candidate records
- * the passes stream through scalar loads are kept in `workspace`
- * (dpf_approxmatch_workspace_bytes = 36*(n+m) + 16*(n+2m) + 48*m + n/2 (+16)
- * bytes per cloud) and the matching is materialised by a final pass (4*n*m instead of
- * 68*n*m bytes of HBM traffic per cloud).  NULL / short workspace -> the
- * read-modify-write path. */
+/* dpf_approxmatch with `match` written ONCE: the nine levels' ratio vectors and the passes' operand records are kept in
+ * `workspace` and the matching is materialised by a final pass (4*n*m instead of 68*n*m bytes of HBM traffic per
+ * cloud).  dpf_approxmatch_workspace_bytes covers both kernel families below: ~ 36*(n+m) + 16*(n+2m) + 48*m + n/2 bytes
+ * per cloud for the packed-VALU one (bit-identical to dpf_approxmatch) + ~ 32*n + 220*m for the matrix-core one.
+ * NULL / short workspace -> the read-modify-write path. */
 size_t dpf_approxmatch_workspace_bytes(int b, int n, int m);
 /* r05: with a workspace the 27 level passes run on the matrix cores (expanded-form squared distance, one MFMA per 32 x 32
  * pairs; csrc/emd.hip) when every coordinate, centred on cloud 1's centroid, fits the fp16 operands (|x - c|^2 <= 346, all
