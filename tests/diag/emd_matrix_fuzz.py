@@ -9,6 +9,7 @@ from dpf_nets_amd.metrics.StructuralLosses import StructuralLossesBackend as BK
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 worst = dict(cost=0.0, match=0.0, mass=0.0)
+rows = []
 for it in range(cases):
     B = int(rng.integers(1, 5))
     n = int(rng.choice([1, 3, 31, 32, 33, 64, 100, 127, 128, 129, 255, 300, 500, 777, 1024, 1500, 2048, 3000]))
@@ -37,6 +38,9 @@ for it in range(cases):
     ce = float(((c1 - c0).abs() / (c0.abs() + 1e-12)).max()); me = float((m1 - m0).abs().max())
     ma = float(max((m1.sum(1) - m0.sum(1)).abs().max(), (m1.sum(2) - m0.sum(2)).abs().max()))
     worst = dict(cost=max(worst["cost"], ce), match=max(worst["match"], me), mass=max(worst["mass"], ma))
+    rows.append((ce, me, ma, it, B, n, m, str(kind), float(c0.abs().min())))
     flag = "" if (ce <= 1e-5 and me <= 2e-3 and ma <= 1e-4) else "   <-- outside the test bars"
     print("%3d B=%d n=%4d m=%4d %-9s cost rel %.1e  match %.1e  mass %.1e%s" % (it, B, n, m, kind, ce, me, ma, flag))
 print("worst:", worst)
+for r in sorted(rows, reverse=True)[:6]:
+    print("largest cost difference: %.2e (match %.1e, mass %.1e) case %d B=%d n=%d m=%d %s, smallest cost in the batch %.3g" % r)
