@@ -65,6 +65,7 @@ SIGNATURES = {
     "dpf_encoder_pack": (_i, [_i, _vp, _vp, _vp]),
     "dpf_encoder_forward": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dpf_debug_nn_surrogate": (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "dpf_debug_emd_exponents": (_i, [_i, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "dpf_train_graph_replays": (_l, []),
     "dpf_train_colsum_fallbacks": (_l, []),
     "dpf_train_graph_stats": (None, [_vp]),

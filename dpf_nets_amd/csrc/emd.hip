@@ -411,25 +411,40 @@ __global__ __launch_bounds__(1024) void emd_match2_kernel(int n, int m, float lv
 }
 
 
-// ---- the deferred path on the matrix cores (r05) -----------------------------------------------------------------------
-// Six of the eight packed instructions per candidate above are the squared distance.  Expanded,
-//     -4^j log2(e) |q - p|^2  =  -4^j |q'|^2 - 4^j |p'|^2 + 2 * 4^j q'.p',      q' = sqrt(log2 e) (q - c),
-// it is a K = 15 contraction and ONE v_mfma_f32_32x32x16_f16 hands a wave the exp2 arguments of 32 x 32 pairs:
-//   slots 0..8    per coordinate (Qh, Qh, Ql) x (Ph, Pl, Ph): fp16 hi + lo of 512 q' and of 64 p' (22 bits each; lo*lo dropped)
-//   slots 9..11   three fp16 parts of -128 |q'|^2  x  128          (the norms are formed in double: exact to fp32 and beyond)
-//   slots 12..14  -128  x  three fp16 parts of 128 |p'|^2
-// The records are level-independent and carry the STEEPEST level's scale (4^7: every lo part a normal fp16 number where the
-// exponent's absolute error matters most); level j's 4^(j-7) is a power of two <= 1 and goes onto the candidates' fragment
-// with four exact v_pk_mul_f16 (down to 2^-14, the rest onto the own points' fragments once per kernel) -- lo parts that
-// fall into the subnormals there cost < 2e-6 absolute in the exponent.  c is cloud 1's centroid (the expanded form's
-// cancellation error grows with |q'|^2; centring keeps it at the cloud's own radius).  What is left per pair is exp2 and one
-// FMA with the candidate's weight -- 32 VALU instructions per 1024 pairs where the packed form issues 80.
-// Accuracy (tests/diag/emd_expanded_form_error.py, CPU, same auction with only d^2 exchanged; n = m = 1024, centred and
-// uncentred clouds, uniform and near-pair): cost within 2.4e-6 of the difference form's (contract 1e-4), matching entries
-// within 8.5e-4 of their maximum 1.0 (the auction amplifies any last-bit change that much: the fp32-exact expanded form
-// measures the same as the fp16 hi/lo one).  The results are NOT bit-identical to the read-modify-write path; the packed-VALU
-// family above still is and stays the path for coordinates outside the fp16 range (|q'|^2 > 500 after centring, or not
-// finite), chosen per call on the device (gate), and for dpf_emd_set_matrix_path(0).
+// ---- the deferred path on the matrix cores (r05; operand format r06) ------------------------------------------------------
+// Six of the eight packed instructions per candidate above are the squared distance.  Expanded, -4^j log2(e) |q - p|^2 is a
+// contraction over K slots and the matrix cores hand a wave the exp2 arguments of 32 x 32 pairs at once; what is left per pair
+// is exp2 and one FMA with the candidate's weight -- 32 VALU instructions per 1024 pairs where the packed form issues 80.
+//
+// r06 -- the operand format (the r05 format, fp16 hi + lo of the coordinates against fp16 parts of the squared
+// norms in ONE MFMA, left the exponent with an rms error of 5e-4 and a worst case of 4e-3 at the steepest level: the three
+// large terms -s|q|^2 - s|p|^2 + 2s q.p, each in the thousands, cancel INSIDE the fp32 accumulator, which aligns every 9-input
+// partial sum to its largest term (profiles/r05_mfma_tree.txt, r05_mfma_accum.txt).  The auction averages that out on generic
+// clouds -- cost within 2e-5 of the difference form -- but not on degenerate ones: 1.15e-4 on collinear points,
+// tests/diag/emd_collinear_case.py, outside the 1e-4 contract).  Now the large terms are EXACT:
+//   q' = sqrt(log2 e) (q - c) 2^g = a + alpha,   a = rint(q') an integer vector with |a_u| <= 1000, |alpha_u| <= 1/2
+// (c: cloud 1's centroid; g per cloud pair from the clouds' extent, <= 11), likewise p' = b + beta for cloud 1, and
+//   -|q' - p'|^2 = [ -|a|^2 - |b|^2 + 2 a.b ]  +  [ -R_q - C_p + 2 a.beta + 2 alpha.b ]  +  2 alpha.beta,
+//   R_q = 2 a.alpha + |alpha|^2,  C_p = 2 b.beta + |beta|^2.
+// The first bracket is integer arithmetic on numbers below 2^22: fp16 holds every operand exactly (|a|^2 as two 11-bit pieces),
+// fp32 accumulation is exact whatever the order -- and the instruction adds the products of K slots 0..7 (with C) BEFORE those
+// of slots 8..15 (the tree test above), so the integers go into slots 0..7 of the first MFMA and have cancelled to
+// -|a - b|^2 (small for every pair whose weight matters) before anything inexact is added.  The second bracket -- terms up to
+// 3000 that cancel to 2 (a - b).(alpha - beta) -- takes slots 8..15 with the hi parts of R, C, alpha, beta and, in a second
+// MFMA chained through C, the lo parts (fp16 hi + lo = 22 bits) and alpha_h.beta_h.  Per 32 x 32 pairs: two MFMAs (the matrix
+// pipe was a tenth busy), the same 32 VALU instructions.  Exponent error at the steepest level on unit-size clouds: max
+// 1e-5, rms 2e-6 -- the class of the fp32 difference form's own rounding (5e-6); measured on the device by
+// test_matrix_core_exponent_error_bound through dpf_debug_emd_exponents, emulated on the CPU by tests/diag/emd_grid_emulation.py.
+// Scales: the records carry the steepest level's 4^7 2^-2g = 2^T (T = 14 - 2g in [-8, 0]) split per slot so that an INTEGER
+// operand is never below fp16's smallest normal number (integers lost to a flush would break the exact cancellation) and a
+// small operand's hi part never is; lo parts may underflow -- gradually where the hardware honours fp16 subnormals, to zero
+// where it does not: either way below 8e-6 of the exponent (slot table at point_records).  Level j's 4^(j-7) goes onto the
+// fragments as a per-slot vector of powers of two (level_vectors): onto the integers of an all-integer slot, onto the small
+// operand of a mixed one -- 4 exact v_pk_mul_f16 per fragment, as before.
+// The results are NOT bit-identical to the read-modify-write path (tolerance parity; the same weight bits in all three passes of
+// a level and in the materialisation, below); the packed-VALU family above still is and stays the path for clouds whose extent
+// puts the second bracket's rounding above 1e-4 (log2(e) |x - c|^2 > 16 for some point, or not finite), chosen per call on
+// the device (gate), and for dpf_emd_set_matrix_path(0).
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f16acc __attribute__((ext_vector_type(16)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
@@ -437,11 +452,16 @@ typedef unsigned u4 __attribute__((ext_vector_type(4)));
 constexpr int MT = 4;            // 32-point tiles per wave
 constexpr int MPW = 32 * MT;     // points per wave / workgroup
 constexpr int MSL = 8;           // max candidate slices (waves) per workgroup
-constexpr float EMD_MFMA_R2MAX = 500.f;   // |q'|^2 bound: 128 * 500 = 64 000 < 65 504 (and 512 |q'| < 11 500)
+constexpr float EMD_MFMA_R2MAX = 16.f;    // log2(e) |x - c|^2 bound: g >= 7, T <= 0, the mixed terms' rounding <= 2e-4 at level 7
+constexpr float EMD_AMAX = 1000.f;        // bound of the integer parts (2 a and |a|^2 / 2048 stay 11-bit integers)
+constexpr int EMD_GMAX = 11;              // finest grid 2^-11: T >= -8
+constexpr int RECQ = 4;                   // 16-byte quarters per point record: [MFMA 1: K 0..7 | K 8..15 | MFMA 2: K 0..7 | K 8..15]
+constexpr int METAF = 8;                  // floats of per-cloud meta: centroid (3), out-of-range flag, 2^g, T
 
 __device__ __forceinline__ int round_up(int v, int q) { return (v + q - 1) / q * q; }
 
-// One workgroup per cloud: cloud 1's centroid (fixed-order sums) and whether every centred, scaled point of both clouds fits
+// One workgroup per cloud: cloud 1's centroid (fixed-order sums), the grid exponent g from the largest centred, scaled
+// coordinate of either cloud, and whether every point of both clouds is in range
 __global__ __launch_bounds__(1024) void emd_mfma_prep_kernel(int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
                                                              float *__restrict__ meta, unsigned *flag) {
     __shared__ float red[3][1024];
@@ -456,16 +476,31 @@ __global__ __launch_bounds__(1024) void emd_mfma_prep_kernel(int n, int m, const
         __syncthreads();
     }
     const float cx = red[0][0] / (float)n, cy = red[1][0] / (float)n, cz = red[2][0] / (float)n;
+    __syncthreads();
     int bad = 0;
+    float mx = 0.f;
     for (int i = tid; i < n + m; i += 1024) {
         const float *q = i < n ? p1 + i * 3 : p2 + (i - n) * 3;
         const float dx = q[0] - cx, dy = q[1] - cy, dz = q[2] - cz;
         const float r2 = 1.44269504f * (dx * dx + dy * dy + dz * dz);
         bad |= !(r2 <= EMD_MFMA_R2MAX);                 // also catches NaN / inf
+        mx = fmaxf(mx, fmaxf(fabsf(dx), fmaxf(fabsf(dy), fabsf(dz))));     // (fmaxf drops a NaN: `bad` has it)
     }
+    red[0][tid] = mx;
     bad = __syncthreads_or(bad);
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) red[0][tid] = fmaxf(red[0][tid], red[0][tid + o]);
+        __syncthreads();
+    }
     if (tid == 0) {
-        meta[bi * 4 + 0] = cx; meta[bi * 4 + 1] = cy; meta[bi * 4 + 2] = cz; meta[bi * 4 + 3] = (float)bad;
+        // 2^g: the largest power of two with 1.2012 mx 2^g <= 1000 (1.2012 > sqrt(log2 e): the records' double arithmetic stays
+        // inside); clouds of no extent take the finest grid
+        const float lim = EMD_AMAX / (1.2012f * fmaxf(red[0][0], 1e-30f));
+        int g = bad ? 7 : (lim >= 4096.f ? EMD_GMAX : min(EMD_GMAX, (int)floorf(log2f(lim))));
+        while (g > 0 && ldexpf(1.2012f * red[0][0], g) > EMD_AMAX) --g;              // (log2f's last bit)
+        float *mt = meta + (size_t)bi * METAF;
+        mt[0] = cx; mt[1] = cy; mt[2] = cz; mt[3] = (float)bad; mt[4] = ldexpf(1.f, g); mt[5] = (float)(14 - 2 * g);
+        mt[6] = 0.f; mt[7] = 0.f;
         if (bad) atomicOr(flag, 1u);
     }
 }
@@ -473,12 +508,6 @@ __global__ __launch_bounds__(1024) void emd_mfma_prep_kernel(int n, int m, const
 __device__ __forceinline__ void split2(double v, _Float16 &h, _Float16 &l) {
     h = (_Float16)(float)v;
     l = (_Float16)(float)(v - (double)(float)h);
-}
-__device__ __forceinline__ void split3(double v, _Float16 &h, _Float16 &mid, _Float16 &l) {
-    h = (_Float16)(float)v;
-    const double r = v - (double)(float)h;
-    mid = (_Float16)(float)r;
-    l = (_Float16)(float)(r - (double)(float)mid);
 }
 
 // Sparsity (r05, tests/diag/emd_level_zeros.py): a point of cloud 2 whose remainR has reached 0 stays at 0 -- its weight in
@@ -505,31 +534,72 @@ struct MfmaState {
     const unsigned *gate;
 };
 
-// fp16 operand records of a point (file header of this section); c = centred, scaled coordinates
-__device__ __forceinline__ void point_records(const float *q, const float *centre, bool live, u4 (&ra)[2], u4 (&rb)[2]) {
-    _Float16 a[16], b[16];
+// fp16 operand records of a point (header of this section).  In grid units q' = a + alpha (rows: cloud 2, the A operand),
+// p' = b + beta (columns: cloud 1, the B operand); every product below times 2^T 4^(j-7) sums to -4^j log2(e) |q - p|^2.
+//   slot            A operand (x its scale)              B operand (x its scale)            level factor goes onto
+//   MFMA 1, K 0..7  -N_hi, -N_lo, -2048, -1, 2 a_u  (2^4)  2048, 1, N_hi, N_lo, b_u (2^(T-4))   A (integers stay >= 2^-12)
+//   MFMA 1, K 8     -hi(8 R_q)                            2^(T-3)                              A
+//           K 9     -2^(T-3)                              hi(8 C_p)                            B
+//           K 10-12 2 a_u            (2^-14)              hi(beta_u 2^(T+14))                  B
+//           K 13-15 hi(alpha_u 2^(T+14))                  2 b_u            (2^-14)             A
+//   MFMA 2, K 0..7  the same eight slots with the lo parts of R_q, C_p, beta_u, alpha_u
+//   MFMA 2, K 8-10  2 alpha_u 2^(T/2)                     beta_u 2^(T/2)                       both (2^(j-7) each)
+// |a|^2 = 2048 N_hi + N_lo (both below 2048).  An integer operand is >= 2^-14 (normal) at every level but one corner (a_u = 1 at
+// the last level, a term below 2e-5); a lo part underflows where it is below 2^-14 of its slot's scale: < 8e-6 of the exponent.
+__device__ __forceinline__ void point_records(const float *q, const float *mt, bool live, u4 (&ra)[RECQ], u4 (&rb)[RECQ]) {
+    _Float16 a[32], b[32];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) { a[u] = (_Float16)0.f; b[u] = (_Float16)0.f; }
+    for (int u = 0; u < 32; ++u) { a[u] = (_Float16)0.f; b[u] = (_Float16)0.f; }
     if (live) {
         const double S = 1.2011224087864498;                      // sqrt(log2 e)
-        double c[3], n2 = 0.0;
-#pragma unroll
-        for (int u = 0; u < 3; ++u) { c[u] = ((double)q[u] - (double)centre[u]) * S; n2 += c[u] * c[u]; }
+        const double G = (double)mt[4];
+        const int T = (int)mt[5];
+        const double sI = ldexp(1.0, T - 4), sC = ldexp(1.0, T - 3), sS = ldexp(1.0, T + 14), sH = ldexp(1.0, T / 2);
+        double ip[3], fp[3], N = 0.0, R = 0.0;
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
-            _Float16 h, l;
-            split2(c[u] * 512.0, h, l);
-            a[3 * u + 0] = h; a[3 * u + 1] = h; a[3 * u + 2] = l;
-            split2(c[u] * 64.0, h, l);
-            b[3 * u + 0] = h; b[3 * u + 1] = l; b[3 * u + 2] = h;
+            const double v = ((double)q[u] - (double)mt[u]) * S * G;
+            ip[u] = rint(v); fp[u] = v - ip[u];
+            N += ip[u] * ip[u];
+            R += 2.0 * ip[u] * fp[u] + fp[u] * fp[u];
         }
-        split3(-n2 * 128.0, a[9], a[10], a[11]);
-        b[9] = b[10] = b[11] = (_Float16)128.f;
-        a[12] = a[13] = a[14] = (_Float16)(-128.f);
-        split3(n2 * 128.0, b[12], b[13], b[14]);
+        const double Nh = floor(N / 2048.0), Nl = N - 2048.0 * Nh;
+        // rows (A)
+        a[0] = (_Float16)(float)(-16.0 * Nh); a[1] = (_Float16)(float)(-16.0 * Nl); a[2] = (_Float16)(-32768.f); a[3] = (_Float16)(-16.f);
+        split2(-8.0 * R, a[8], a[16]);
+        a[9] = a[17] = (_Float16)(float)(-sC);
+        // columns (B)
+        b[0] = (_Float16)(float)(2048.0 * sI); b[1] = (_Float16)(float)sI; b[2] = (_Float16)(float)(Nh * sI); b[3] = (_Float16)(float)(Nl * sI);
+        b[8] = b[16] = (_Float16)(float)sC;
+        split2(8.0 * R, b[9], b[17]);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            a[4 + u] = (_Float16)(float)(32.0 * ip[u]);
+            a[10 + u] = a[18 + u] = (_Float16)(float)ldexp(2.0 * ip[u], -14);
+            split2(fp[u] * sS, a[13 + u], a[21 + u]);
+            a[24 + u] = (_Float16)(float)(2.0 * fp[u] * sH);
+            b[4 + u] = (_Float16)(float)(ip[u] * sI);
+            split2(fp[u] * sS, b[10 + u], b[18 + u]);
+            b[13 + u] = b[21 + u] = (_Float16)(float)ldexp(2.0 * ip[u], -14);
+            b[24 + u] = (_Float16)(float)(fp[u] * sH);
+        }
     }
-    __builtin_memcpy(ra, a, 32);
-    __builtin_memcpy(rb, b, 32);
+    __builtin_memcpy(ra, a, 64);
+    __builtin_memcpy(rb, b, 64);
+}
+
+// Level j's 4^(j-7) as per-slot powers of two.  F = max(4^(j-7), 2^-14) goes onto the operand the table above names, f = 4^(j-7) / F
+// (1 but for the last level's 2^-2) onto the other, h = 2^(j-7) onto both operands of the alpha.beta slots.  fp16 bit patterns.
+struct LevelFac { unsigned F, f, h; };
+__device__ __forceinline__ unsigned pk2(unsigned lo, unsigned hi) { return lo | (hi << 16); }
+// the two quarters a lane of half `half` multiplies its fragments by: [0] MFMA 1, [1] MFMA 2
+__device__ __forceinline__ void level_vectors(LevelFac lf, int half, bool rows, u4 (&v)[2]) {
+    const unsigned own = rows ? lf.F : lf.f, oth = rows ? lf.f : lf.F;     // `own`: this side's factor where A takes the level
+    const u4 ints = {pk2(own, own), pk2(own, own), pk2(own, own), pk2(own, own)};
+    const u4 mixed = {pk2(own, oth), pk2(oth, oth), pk2(oth, own), pk2(own, own)};
+    const u4 both = {pk2(lf.h, lf.h), pk2(lf.h, lf.h), pk2(lf.h, lf.h), pk2(lf.h, lf.h)};
+    v[0] = half == 0 ? ints : mixed;
+    v[1] = half == 0 ? mixed : both;
 }
 
 // B records of cloud 1, A records of cloud 2 (dense copy + the first list: every point, in order), zeros in the padding,
@@ -543,16 +613,17 @@ __global__ void emd_mfma_pack_kernel(MfmaState st, float multiR, const float *__
     const int k = first ? idx : idx - st.NP;
     const bool live = k < (first ? st.n : st.m);
     const float *q = first ? xyz1 + ((size_t)bi * st.n + (live ? k : 0)) * 3 : xyz2 + ((size_t)bi * st.m + (live ? k : 0)) * 3;
-    u4 ra[2], rb[2];
-    point_records(q, meta + bi * 4, live, ra, rb);
+    u4 ra[RECQ], rb[RECQ];
+    point_records(q, meta + (size_t)bi * METAF, live, ra, rb);
     if (first) {
-        u4 *o = const_cast<u4 *>(st.recB1) + ((size_t)bi * st.NP + k) * 2;
-        o[0] = rb[0]; o[1] = rb[1];
+        u4 *o = const_cast<u4 *>(st.recB1) + ((size_t)bi * st.NP + k) * RECQ;
+#pragma unroll
+        for (int u = 0; u < RECQ; ++u) o[u] = rb[u];
         st.ratioL_p[(size_t)bi * st.NP + k] = 0.f;
     } else {
         const size_t at = (size_t)bi * st.MP + k;
-        recA2_dense[at * 2] = ra[0]; recA2_dense[at * 2 + 1] = ra[1];
-        st.recA2[0][at * 2] = ra[0]; st.recA2[0][at * 2 + 1] = ra[1];
+#pragma unroll
+        for (int u = 0; u < RECQ; ++u) { recA2_dense[at * RECQ + u] = ra[u]; st.recA2[0][at * RECQ + u] = ra[u]; }
         st.idx2[0][at] = k;
         st.remainR_c[0][at] = live ? multiR : 0.f;
         st.ratioR_c[at] = 0.f;
@@ -578,10 +649,11 @@ __device__ __forceinline__ float pick4(const float4 (&w)[4], int r) {
 __device__ __forceinline__ int pick4i(const int4 (&w)[4], int r) {
     return r % 4 == 0 ? w[r / 4].x : r % 4 == 1 ? w[r / 4].y : r % 4 == 2 ? w[r / 4].z : w[r / 4].w;
 }
-__device__ __forceinline__ h8 scale8(u4 v, float f) {
-    const _Float16 fh = (_Float16)f;
-    return __builtin_bit_cast(h8, v) * h8{fh, fh, fh, fh, fh, fh, fh, fh};
+__device__ __forceinline__ h8 scale8(u4 v, u4 sv) {          // four exact v_pk_mul_f16 (powers of two)
+    return __builtin_bit_cast(h8, v) * __builtin_bit_cast(h8, sv);
 }
+struct Frag { h8 q1, q2; };                                    // a lane's operands of the two MFMAs of a tile
+__device__ __forceinline__ Frag scale_frag(u4 r1, u4 r2, const u4 (&sv)[2]) { return Frag{scale8(r1, sv[0]), scale8(r2, sv[1])}; }
 // The MFMA of a tile: the builtin with a REGISTER zero as its C operand (`zacc`, sixteen VGPRs made opaque to the compiler).
 // Why not the literal 0 -- r05, measured on MI355X (tests/diag/emd_repeat.py, emd_flake_rate.py): with C = 0 the compiler
 // selects the instruction form whose destination may share registers with a dying source ("v_mfma_f32_32x32x16_f16 v[2:17],
@@ -600,27 +672,94 @@ __device__ __forceinline__ f16acc opaque_zero() {
     asm volatile("" : "+v"(z));
     return z;
 }
-__device__ __forceinline__ f16acc pair_exponents(h8 rows, h8 cols, const f16acc &zacc) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(rows, cols, zacc, 0, 0, 0);
+__device__ unsigned g_emd_dbg_n;
+__device__ float g_emd_dbg[16 * 8];
+#ifndef EMD_DBG
+#define EMD_DBG 0          // timing experiments of r06 (tests/diag/emd_rows_probe.py): 1 wait behind the chain, 2 no chaining, 4 tiles serialised
+#endif
+__device__ __forceinline__ f16acc pair_exponents(const Frag &rows, const Frag &cols, const f16acc &zacc) {
+#if EMD_DBG & 8
+    {   // chained against unchained, mismatches recorded
+        const f16acc i1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(rows.q1, cols.q1, zacc, 0, 0, 0);
+        const f16acc ch = __builtin_amdgcn_mfma_f32_32x32x16_f16(rows.q2, cols.q2, i1, 0, 0, 0);
+        const f16acc i2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(rows.q1, cols.q1, zacc, 0, 0, 0);
+        const f16acc rs = __builtin_amdgcn_mfma_f32_32x32x16_f16(rows.q2, cols.q2, zacc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float alt = i2[r] + rs[r];
+            if (!(fabsf(alt - ch[r]) <= 1e-2f + 1e-4f * fabsf(alt))) {
+                const unsigned slot = atomicAdd(&g_emd_dbg_n, 1u);
+                if (slot < 16) {
+                    g_emd_dbg[slot * 8 + 0] = ch[r]; g_emd_dbg[slot * 8 + 1] = alt; g_emd_dbg[slot * 8 + 2] = i2[r]; g_emd_dbg[slot * 8 + 3] = rs[r];
+                    g_emd_dbg[slot * 8 + 4] = (float)threadIdx.x; g_emd_dbg[slot * 8 + 5] = (float)r;
+                    g_emd_dbg[slot * 8 + 6] = (float)blockIdx.x; g_emd_dbg[slot * 8 + 7] = (float)blockIdx.y;
+                }
+            }
+        }
+        return ch;
+    }
+#elif EMD_DBG & 2
+    f16acc ints = __builtin_amdgcn_mfma_f32_32x32x16_f16(rows.q1, cols.q1, zacc, 0, 0, 0);
+    f16acc rest = __builtin_amdgcn_mfma_f32_32x32x16_f16(rows.q2, cols.q2, zacc, 0, 0, 0);
+    return ints + rest;
+#else
+    const f16acc ints = __builtin_amdgcn_mfma_f32_32x32x16_f16(rows.q1, cols.q1, zacc, 0, 0, 0);
+    f16acc acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(rows.q2, cols.q2, ints, 0, 0, 0);
+#if EMD_DBG & 1
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc));
+#endif
+#if EMD_DBG & 4
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    return acc;
+#endif
+}
+
+// The next tile's prefetch must not be ISSUED before this tile's MFMAs have finished (r06; EMD_PIN_LOADS).  The compiler counts a
+// register dead once its last reader has issued and hands the scaled fragment's registers to the prefetch ("v_mfma ... v[122:125]
+// ...; global_load_dwordx4 v[122:125]" right behind four queued MFMAs that read v[122:125]); see DESIGN 4.6 for what
+// tools/ubench/mfma_war.hip measured about that pattern.  Taking the tile's sums through an empty asm with a memory clobber
+// keeps every later load behind the VALU instructions that consumed the MFMAs' results.
+#ifndef EMD_PIN_LOADS
+#define EMD_PIN_LOADS 1
+#endif
+// ... and the MFMAs of the tile that follows a prefetch must not be moved IN FRONT of it (an MFMA is no memory operation: the
+// scheduler hoists it over a plain memory barrier): the tile's raw fragments pass through the barrier
+__device__ __forceinline__ void mfmas_stay_behind(u4 &r) {
+#if EMD_PIN_LOADS
+    asm volatile("" : "+v"(r) : : "memory");
+#else
+    asm volatile("" ::: "memory");
+#endif
+}
+template <int N>
+__device__ __forceinline__ void loads_stay_behind(float (&v)[N]) {
+#if EMD_PIN_LOADS
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]) : : "memory");
+#endif
 }
 
 // Passes over cloud 1's points (columns; cloud 2's LIVE points stream past as row tiles with their weights):
 // MODE 0: pass 1          s_k = sum_l w remainR[l];                     ratioL[k] = remainL[k] / (1e-9 + s_k)
 // MODE 3: pass 3          s_k = sum_l w ratioR[l];                      remainL[k] = max(0, remainL[k] - ratioL[k] s_k)
-// (fa, fb): level j's 4^(j-7), split between the rows' and the columns' fragments.  rb_cur: the ratio slot of level j.
+// lf: level j's 4^(j-7) as the per-slot factors of level_vectors.  rb_cur: the ratio slot of level j.
 template <int MODE>
-__global__ __launch_bounds__(64 * MSL) void emd_mfma_cols_kernel(MfmaState st, int cur, float fa, float fb, float *rb_cur) {
+__global__ __launch_bounds__(64 * MSL) void emd_mfma_cols_kernel(MfmaState st, int cur, LevelFac lf, float *rb_cur) {
     __shared__ float part[MSL][MPW];
     if (gate_closed(st.gate, 0u)) return;
     const f16acc zacc = opaque_zero();
     const int bi = blockIdx.y, lane = threadIdx.x, slice = __builtin_amdgcn_readfirstlane(threadIdx.y), S = blockDim.y;
     const int half = lane >> 5, col = lane & 31;
-    const u4 *ownrec = st.recB1 + ((size_t)bi * st.NP + blockIdx.x * MPW) * 2;
-    const u4 *candrec = st.recA2[cur] + ((size_t)bi * st.MP + col) * 2 + half;
+    const u4 *ownrec = st.recB1 + ((size_t)bi * st.NP + blockIdx.x * MPW) * RECQ;
+    const u4 *candrec = st.recA2[cur] + ((size_t)bi * st.MP + col) * RECQ + half;
     const float *w0 = (MODE == 0 ? st.remainR_c[cur] : st.ratioR_c) + (size_t)bi * st.MP + 4 * half;
-    h8 bf[MT];
+    u4 svr[2], svc[2];
+    level_vectors(lf, half, true, svr);
+    level_vectors(lf, half, false, svc);
+    Frag bf[MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) bf[t] = scale8(ownrec[(t * 32 + col) * 2 + half], fb);
+    for (int t = 0; t < MT; ++t) bf[t] = scale_frag(ownrec[(t * 32 + col) * RECQ + half], ownrec[(t * 32 + col) * RECQ + 2 + half], svc);
     const int tiles = (st.count[bi] + 31) / 32;
     const int tb = (int)((long)tiles * slice / S), te = (int)((long)tiles * (slice + 1) / S);
     float sa[MT];
@@ -630,12 +769,13 @@ __global__ __launch_bounds__(64 * MSL) void emd_mfma_cols_kernel(MfmaState st, i
         // two register sets A / B, each loaded one tile before its use and first touched after the other tile's arithmetic
         // (a rotating copy made the compiler wait for the load it had just issued -- a full memory round trip per tile
         // whenever few waves share the SIMD)
-        u4 afA = candrec[(size_t)tb * 64], afB;
+        constexpr size_t TQ = 32 * RECQ;                         // quarters per tile of records
+        u4 afA[2] = {candrec[(size_t)tb * TQ], candrec[(size_t)tb * TQ + 2]}, afB[2];
         float4 waA[4], waB[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) waA[i] = *(const float4 *)(w0 + tb * 32 + 8 * i);
-        auto tile = [&](u4 af, const float4 (&wa)[4]) {
-            const h8 as = scale8(af, fa);
+        auto tile = [&](const u4 (&af)[2], const float4 (&wa)[4]) {
+            const Frag as = scale_frag(af[0], af[1], svr);
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
                 const f16acc acc = pair_exponents(as, bf[t], zacc);
@@ -645,16 +785,18 @@ __global__ __launch_bounds__(64 * MSL) void emd_mfma_cols_kernel(MfmaState st, i
         };
         for (int ct = tb; ct < te; ct += 2) {
             const int n1 = min(ct + 1, te - 1), n2 = min(ct + 2, te - 1);
-            afB = candrec[(size_t)n1 * 64];
+            afB[0] = candrec[(size_t)n1 * TQ]; afB[1] = candrec[(size_t)n1 * TQ + 2];
 #pragma unroll
             for (int i = 0; i < 4; ++i) waB[i] = *(const float4 *)(w0 + n1 * 32 + 8 * i);
-            asm volatile("" ::: "memory");
+            mfmas_stay_behind(afA[0]); mfmas_stay_behind(afA[1]);
             tile(afA, waA);
-            afA = candrec[(size_t)n2 * 64];
+            loads_stay_behind(sa);
+            afA[0] = candrec[(size_t)n2 * TQ]; afA[1] = candrec[(size_t)n2 * TQ + 2];
 #pragma unroll
             for (int i = 0; i < 4; ++i) waA[i] = *(const float4 *)(w0 + n2 * 32 + 8 * i);
-            asm volatile("" ::: "memory");
+            mfmas_stay_behind(afB[0]); mfmas_stay_behind(afB[1]);
             if (ct + 1 < te) tile(afB, waB);
+            loads_stay_behind(sa);
         }
     }
 #pragma unroll
@@ -699,7 +841,7 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 //   sumr = remainR[l] * sum_k w ratioL[k];  ratioR[l] = min(remainR[l] / (sumr + 1e-9), 1) * remainR[l];
 //   remainR[l] = max(0, remainR[l] - sumr)
 template <int RT>
-__global__ __launch_bounds__(64 * MSL) void emd_mfma_rows_kernel(MfmaState st, int cur, float fa, float fb, float *rb_cur, int regime) {
+__global__ __launch_bounds__(64 * MSL) void emd_mfma_rows_kernel(MfmaState st, int cur, LevelFac lf, float *rb_cur, int regime) {
     constexpr int RPW = 32 * RT;                                    // rows per workgroup
     __shared__ float part[MSL][RPW];
     if (gate_closed(st.gate, 0u)) return;
@@ -709,12 +851,15 @@ __global__ __launch_bounds__(64 * MSL) void emd_mfma_rows_kernel(MfmaState st, i
     if ((int)blockIdx.x * RPW >= cnt) return;                       // (whole workgroup)
     if (regime == 1 ? 2 * cnt <= st.m : regime == 2 ? 2 * cnt > st.m : false) return;
     const int half = lane >> 5, col = lane & 31;
-    const u4 *ownrec = st.recA2[cur] + ((size_t)bi * st.MP + blockIdx.x * RPW) * 2;
-    const u4 *candrec = st.recB1 + ((size_t)bi * st.NP + col) * 2 + half;
+    const u4 *ownrec = st.recA2[cur] + ((size_t)bi * st.MP + blockIdx.x * RPW) * RECQ;
+    const u4 *candrec = st.recB1 + ((size_t)bi * st.NP + col) * RECQ + half;
     const float *wl = st.ratioL_p + (size_t)bi * st.NP;
-    h8 af[RT];
+    u4 svr[2], svc[2];
+    level_vectors(lf, half, true, svr);
+    level_vectors(lf, half, false, svc);
+    Frag af[RT];
 #pragma unroll
-    for (int t = 0; t < RT; ++t) af[t] = scale8(ownrec[(t * 32 + col) * 2 + half], fa);
+    for (int t = 0; t < RT; ++t) af[t] = scale_frag(ownrec[(t * 32 + col) * RECQ + half], ownrec[(t * 32 + col) * RECQ + 2 + half], svr);
     const int tiles = round_up(st.n, 32) / 32;
     const int tb = (int)((long)tiles * slice / S), te = (int)((long)tiles * (slice + 1) / S);
     float s[RT][16];
@@ -726,20 +871,21 @@ __global__ __launch_bounds__(64 * MSL) void emd_mfma_rows_kernel(MfmaState st, i
         // register sets A / B as in emd_mfma_cols_kernel, NB column tiles each: in the sparse regime a wave is alone on its SIMD
         // and a tile's arithmetic (~400 cycles) is far shorter than the loads' round trip -- four tiles per set there
         constexpr int NB = RT == 1 ? 4 : 1;
-        u4 bfA[NB], bfB[NB];
+        constexpr size_t TQ = 32 * RECQ;
+        u4 bfA[NB][2], bfB[NB][2];
         float wA[NB], wB[NB];
-        auto load = [&](int c0, u4 (&bfr)[NB], float (&w)[NB]) {
+        auto load = [&](int c0, u4 (&bfr)[NB][2], float (&w)[NB]) {
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
                 const int c = min(c0 + u, te - 1);
-                bfr[u] = candrec[(size_t)c * 64];
+                bfr[u][0] = candrec[(size_t)c * TQ]; bfr[u][1] = candrec[(size_t)c * TQ + 2];
                 w[u] = c0 + u < te ? wl[c * 32 + col] : 0.f;          // (a repeated last tile weighs nothing)
             }
         };
-        auto tiles_of = [&](const u4 (&bfr)[NB], const float (&w)[NB]) {
+        auto tiles_of = [&](const u4 (&bfr)[NB][2], const float (&w)[NB]) {
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
-                const h8 bs = scale8(bfr[u], fb);
+                const Frag bs = scale_frag(bfr[u][0], bfr[u][1], svc);
 #pragma unroll
                 for (int t = 0; t < RT; ++t) {
                     const f16acc acc = pair_exponents(af[t], bs, zacc);
@@ -748,14 +894,28 @@ __global__ __launch_bounds__(64 * MSL) void emd_mfma_rows_kernel(MfmaState st, i
                 }
             }
         };
+        auto fence = [&](u4 (&bfr)[NB][2]) {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) { mfmas_stay_behind(bfr[u][0]); mfmas_stay_behind(bfr[u][1]); }
+        };
+        auto pin = [&]() {                       // (one sum per row tile: each depends on that tile's last MFMA)
+            float last[RT];
+#pragma unroll
+            for (int t = 0; t < RT; ++t) last[t] = s[t][15];
+            loads_stay_behind(last);
+#pragma unroll
+            for (int t = 0; t < RT; ++t) s[t][15] = last[t];
+        };
         load(tb, bfA, wA);
         for (int ct = tb; ct < te; ct += 2 * NB) {
             load(ct + NB, bfB, wB);
-            asm volatile("" ::: "memory");
+            fence(bfA);
             tiles_of(bfA, wA);
+            pin();
             load(ct + 2 * NB, bfA, wA);
-            asm volatile("" ::: "memory");
+            fence(bfB);
             if (ct + NB < te) tiles_of(bfB, wB);
+            pin();
         }
     }
 #pragma unroll
@@ -825,8 +985,8 @@ __global__ __launch_bounds__(1024) void emd_mfma_compact_kernel(MfmaState st, in
         }
         if (keep) {
             const size_t from = base + pos, to = base + kbase + wk + pk;
-            st.recA2[nxt][to * 2] = st.recA2[cur][from * 2];
-            st.recA2[nxt][to * 2 + 1] = st.recA2[cur][from * 2 + 1];
+#pragma unroll
+            for (int u = 0; u < RECQ; ++u) st.recA2[nxt][to * RECQ + u] = st.recA2[cur][from * RECQ + u];
             st.idx2[nxt][to] = st.idx2[cur][from];
             st.remainR_c[nxt][to] = st.remainR_c[cur][from];
         } else if (drop) {
@@ -840,7 +1000,8 @@ __global__ __launch_bounds__(1024) void emd_mfma_compact_kernel(MfmaState st, in
         const int pad_end = min(round_up(kept_total, 32), st.MP);
         for (int pos = kept_total + tid; pos < pad_end; pos += 1024) {
             const u4 z = {0u, 0u, 0u, 0u};
-            st.recA2[nxt][(base + pos) * 2] = z; st.recA2[nxt][(base + pos) * 2 + 1] = z;
+#pragma unroll
+            for (int u = 0; u < RECQ; ++u) st.recA2[nxt][(base + pos) * RECQ + u] = z;
             st.remainR_c[nxt][base + pos] = 0.f;
         }
         for (int pos = kept_total + tid; pos < min(round_up(cnt, 32), st.MP); pos += 1024) st.ratioR_c[base + pos] = 0.f;
@@ -860,8 +1021,8 @@ __global__ void emd_mfma_gather_kernel(MfmaState st, const u4 *__restrict__ recA
     const size_t at = (size_t)bi * st.MP + pos;
     const int l = valid ? st.order[at] : 0;
     const u4 z = {0u, 0u, 0u, 0u};
-    recA_s[at * 2] = valid ? recA2_dense[((size_t)bi * st.MP + l) * 2] : z;
-    recA_s[at * 2 + 1] = valid ? recA2_dense[((size_t)bi * st.MP + l) * 2 + 1] : z;
+#pragma unroll
+    for (int u = 0; u < RECQ; ++u) recA_s[at * RECQ + u] = valid ? recA2_dense[((size_t)bi * st.MP + l) * RECQ + u] : z;
     for (int qv = 0; qv < NLEVEL; ++qv)
         rr_s[((size_t)qv * st.nb + bi) * st.MP + pos] = valid ? ws[qv * lstride + (size_t)bi * st.rstride + st.n + l] : 0.f;
     const float *p = xyz2 + ((size_t)bi * st.m + l) * 3;
@@ -869,7 +1030,7 @@ __global__ void emd_mfma_gather_kernel(MfmaState st, const u4 *__restrict__ recA
     l_s[at] = valid ? l : -1;
 }
 
-struct LevelScales { float fa[NLEVEL], fb[NLEVEL]; };
+struct LevelScales { LevelFac lf[NLEVEL]; };
 
 // match[l][k] = sum over the levels, in level order, of w_j(l, k) ratioL_j[k] ratioR_j[l] with the SAME w_j the passes saw (the
 // same MFMA on the same operands) -- with the difference form's weights here the rows and columns of `match` summed to 1 +- 4e-3
@@ -883,29 +1044,39 @@ struct LevelScales { float fa[NLEVEL], fb[NLEVEL]; };
 // unmasked store path moved it by < 10 %: it is the write that bounds it, not the instruction count.
 constexpr int MTM = 2;
 template <bool COST>
-__global__ __launch_bounds__(64 * MSL) void emd_mfma_materialize_kernel(MfmaState st, LevelScales ls, const float *__restrict__ xyz1,
-                                                                        const float *__restrict__ ws, size_t lstride,
-                                                                        const u4 *__restrict__ recA_s, const float *__restrict__ rr_s,
-                                                                        const float *__restrict__ c2soa_s, const int *__restrict__ l_s,
-                                                                        float *__restrict__ match, float *__restrict__ costpart) {
+// (no __restrict__ on what the loop loads: a load from memory the compiler knows nobody writes may cross the asm barriers that
+// keep loads and MFMAs apart -- loads_stay_behind / mfmas_stay_behind -- and r06's first build sank the last ratioR load of a
+// level behind that level's MFMAs, into the registers of a fragment they read)
+__global__ __launch_bounds__(64 * MSL) void emd_mfma_materialize_kernel(MfmaState st, LevelScales ls, const float *xyz1,
+                                                                        const float *ws, size_t lstride,
+                                                                        const u4 *recA_s, const float *rr_s,
+                                                                        const float *c2soa_s, const int *l_s,
+                                                                        float *match, float *costpart) {
     __shared__ float rl_s[MSL][NLEVEL][32 * MTM];     // ratioL of the wave's columns, by level (a register array would be indexed
-    __shared__ float ls_s[2 * NLEVEL];                //   dynamically by the level loop -- scratch -- or unrolled nine times -- spills)
+    __shared__ u4 sv_s[NLEVEL][2][2][2];              //   dynamically by the level loop -- scratch -- or unrolled nine times -- spills)
+                                                      // sv_s[level][rows | columns][half][MFMA]: level_vectors
     __shared__ int cnt_s[NLEVEL];
     if (gate_closed(st.gate, 0u)) return;
     const f16acc zacc = opaque_zero();
     const int bi = blockIdx.y, nb = gridDim.y, lane = threadIdx.x, slice = __builtin_amdgcn_readfirstlane(threadIdx.y), S = blockDim.y;
     const int half = lane >> 5, col = lane & 31;
-    const u4 *ownrec = st.recB1 + ((size_t)bi * st.NP + blockIdx.x * (32 * MTM)) * 2;
-    const u4 *candrec = recA_s + ((size_t)bi * st.MP + col) * 2 + half;
-    float *__restrict__ mt = match + (size_t)bi * st.n * st.m;
-    u4 bfraw[MTM];
+    const u4 *ownrec = st.recB1 + ((size_t)bi * st.NP + blockIdx.x * (32 * MTM)) * RECQ;
+    const u4 *candrec = recA_s + ((size_t)bi * st.MP + col) * RECQ + half;
+    float *mt = match + (size_t)bi * st.n * st.m;
+    u4 bfraw[MTM][2];
     float px[MTM], py[MTM], pz[MTM];
     int kk[MTM];
-    if (slice == 0 && lane < 2 * NLEVEL) ls_s[lane] = lane < NLEVEL ? ls.fa[lane] : ls.fb[lane - NLEVEL];
+    if (slice == 0 && lane < 4 * NLEVEL) {             // (level, side, half) -> its two vectors
+        u4 v[2];
+        level_vectors(ls.lf[lane >> 2], lane & 1, (lane & 2) == 0, v);
+        sv_s[lane >> 2][(lane >> 1) & 1][lane & 1][0] = v[0];
+        sv_s[lane >> 2][(lane >> 1) & 1][lane & 1][1] = v[1];
+    }
     if (slice == 0 && lane < NLEVEL) cnt_s[lane] = st.counts[lane * nb + bi];
 #pragma unroll
     for (int t = 0; t < MTM; ++t) {
-        bfraw[t] = ownrec[(t * 32 + col) * 2 + half];
+        bfraw[t][0] = ownrec[(t * 32 + col) * RECQ + half];
+        bfraw[t][1] = ownrec[(t * 32 + col) * RECQ + 2 + half];
         kk[t] = blockIdx.x * (32 * MTM) + t * 32 + col;
         const int kc = min(kk[t], st.n - 1);
         if (half == 0)
@@ -920,7 +1091,7 @@ __global__ __launch_bounds__(64 * MSL) void emd_mfma_materialize_kernel(MfmaStat
     const int tiles = round_up(st.m, 32) / 32;
     float cost = 0.f;
     for (int ct = slice; ct < tiles; ct += S) {
-        const u4 af = candrec[(size_t)ct * 64];
+        const u4 af[2] = {candrec[(size_t)ct * (32 * RECQ)], candrec[(size_t)ct * (32 * RECQ) + 2]};
         f16acc mm[MTM];
 #pragma unroll
         for (int t = 0; t < MTM; ++t)
@@ -931,14 +1102,28 @@ __global__ __launch_bounds__(64 * MSL) void emd_mfma_materialize_kernel(MfmaStat
             float4 rr[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) rr[i] = *(const float4 *)(rr_s + ((size_t)j * nb + bi) * st.MP + ct * 32 + 8 * i + 4 * half);
-            const h8 as = scale8(af, ls_s[j]);
-            const float fb = ls_s[NLEVEL + j];
+            const u4 svr[2] = {sv_s[j][0][half][0], sv_s[j][0][half][1]}, svc[2] = {sv_s[j][1][half][0], sv_s[j][1][half][1]};
+            float rlj[MTM];
+#pragma unroll
+            for (int t = 0; t < MTM; ++t) rlj[t] = rl_s[slice][j][t * 32 + col];
+            // every load of this level is issued in front of its first MFMA (the raw row fragment passes through the barrier
+            // the MFMAs' operands are made behind), none before its last MFMA has been consumed (below): mfmas_stay_behind
+            u4 afj[2] = {af[0], af[1]};
+            mfmas_stay_behind(afj[0]); mfmas_stay_behind(afj[1]);
+            const Frag as = scale_frag(afj[0], afj[1], svr);
 #pragma unroll
             for (int t = 0; t < MTM; ++t) {
-                const float rlj = rl_s[slice][j][t * 32 + col];
-                const f16acc acc = pair_exponents(as, scale8(bfraw[t], fb), zacc);
+                const f16acc acc = pair_exponents(as, scale_frag(bfraw[t][0], bfraw[t][1], svc), zacc);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mm[t][r] = __builtin_fmaf(fmul(fast_exp2(acc[r]), rlj), pick4(rr, r), mm[t][r]);
+                for (int r = 0; r < 16; ++r) mm[t][r] = __builtin_fmaf(fmul(fast_exp2(acc[r]), rlj[t]), pick4(rr, r), mm[t][r]);
+            }
+            {   // the next level's loads stay behind this level's MFMAs (loads_stay_behind)
+                float last[MTM];
+#pragma unroll
+                for (int t = 0; t < MTM; ++t) last[t] = mm[t][15];
+                loads_stay_behind(last);
+#pragma unroll
+                for (int t = 0; t < MTM; ++t) mm[t][15] = last[t];
             }
         }
         // register 4 i + jj of lane (half, col): the row at place ct 32 + 8 i + 4 half + jj of `order`, columns kk[0] and kk[0] + 32.
@@ -982,6 +1167,32 @@ __global__ __launch_bounds__(64 * MSL) void emd_mfma_materialize_kernel(MfmaStat
     if (COST) {
         for (int o = 32; o > 0; o >>= 1) cost += __shfl_xor(cost, o);
         if (lane == 0) costpart[((size_t)bi * gridDim.x + blockIdx.x) * S + slice] = cost;
+    }
+}
+
+// Debug / test: the exp2 arguments of every pair of one cloud pair at one level, exactly as the passes form them (same records,
+// same level vectors, same two MFMAs): out[l * n + k], l a point of cloud 2, k of cloud 1.  One 32 x 32 tile per wave.
+__global__ __launch_bounds__(64) void emd_mfma_debug_exponents_kernel(MfmaState st, LevelFac lf, const u4 *__restrict__ recA2_dense,
+                                                                      float *__restrict__ out, unsigned slot_mask) {
+    if (gate_closed(st.gate, 0u)) return;
+    const f16acc zacc = opaque_zero();
+    const int lane = threadIdx.x, half = lane >> 5, col = lane & 31;
+    u4 svr[2], svc[2];
+    level_vectors(lf, half, true, svr);
+    level_vectors(lf, half, false, svc);
+    const u4 *rb = st.recB1 + ((size_t)blockIdx.x * 32 + col) * RECQ, *ra = recA2_dense + ((size_t)blockIdx.y * 32 + col) * RECQ;
+    Frag fr = scale_frag(ra[half], ra[2 + half], svr);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                                   // (slot_mask: bit k = K slot k of MFMA 1, bit 16 + k of MFMA 2)
+        if (!((slot_mask >> (8 * half + i)) & 1u)) fr.q1[i] = (_Float16)0.f;
+        if (!((slot_mask >> (16 + 8 * half + i)) & 1u)) fr.q2[i] = (_Float16)0.f;
+    }
+    const f16acc acc = pair_exponents(fr, scale_frag(rb[half], rb[2 + half], svc), zacc);
+    const int k = blockIdx.x * 32 + col;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int l = blockIdx.y * 32 + 8 * (r / 4) + 4 * half + r % 4;
+        if (l < st.m && k < st.n) out[(size_t)l * st.n + k] = acc[r];
     }
 }
 
@@ -1301,11 +1512,12 @@ static MfmaRegions mfma_regions(int b, int n, int m) {
     MfmaRegions r;
     size_t at = 0;
     auto take = [&](size_t bytes) { const size_t here = at; at += (bytes + 63) & ~(size_t)63; return here; };
-    r.flag = take(16); r.meta = take(B * 16); r.count = take(B * 4); r.counts = take(NLEVEL * B * 4);
-    r.recB1 = take(B * NP * 32); r.recA2d = take(B * MP * 32);
-    for (int u = 0; u < 2; ++u) { r.recA2[u] = take(B * MP * 32); r.idx2[u] = take(B * MP * 4); r.remR[u] = take(B * MP * 4); }
+    constexpr size_t RB = 16 * RECQ;                                             // bytes of a point record
+    r.flag = take(16); r.meta = take(B * METAF * 4); r.count = take(B * 4); r.counts = take(NLEVEL * B * 4);
+    r.recB1 = take(B * NP * RB); r.recA2d = take(B * MP * RB);
+    for (int u = 0; u < 2; ++u) { r.recA2[u] = take(B * MP * RB); r.idx2[u] = take(B * MP * 4); r.remR[u] = take(B * MP * 4); }
     r.ratioR = take(B * MP * 4); r.ratioL = take(B * NP * 4); r.order = take(B * MP * 4);
-    r.recAs = take(B * MP * 32); r.rrs = take(NLEVEL * B * MP * 4); r.c2s = take(3 * B * MP * 4); r.ls = take(B * MP * 4);
+    r.recAs = take(B * MP * RB); r.rrs = take(NLEVEL * B * MP * 4); r.c2s = take(3 * B * MP * 4); r.ls = take(B * MP * 4);
     r.end = at;
     return r;
 }
@@ -1361,6 +1573,10 @@ static int approxmatch_impl(int b, int n, int m, const float *xyz1, const float 
     int mfma_cost_parts = 0;
     if (matrix) {
         // the matrix-core family: gate 0.  Per level: pass 1, pass 2, pass 3 over the live list, then its compaction
+        // debug (tests/diag/emd_bisect.py): DPF_EMD_STOP_AFTER=k returns behind the k-th launch of this family
+        const char *stop_env = getenv("DPF_EMD_STOP_AFTER");
+        int stop_left = stop_env ? atoi(stop_env) : -1;
+#define EMD_STOP_CHECK() do { if (stop_left > 0 && --stop_left == 0) return (int)hipGetLastError(); } while (0)
         MfmaState st{};
         st.n = n; st.m = m; st.NP = NP; st.MP = MP; st.nb = b;
         st.recB1 = (const u4 *)(mbase + mr.recB1);
@@ -1376,33 +1592,42 @@ static int approxmatch_impl(int b, int n, int m, const float *xyz1, const float 
         float *ws = (float *)workspace;
         hipLaunchKernelGGL(emd_mfma_pack_kernel, dim3((NP + MP + 255) / 256, b), dim3(256), 0, s, st, multiR, xyz1, xyz2,
                            (const float *)meta, recA2_dense, ws, lstride);
+        EMD_STOP_CHECK();
         const int m1 = pick_mfma_slices(b, n, m), m2 = pick_mfma_slices(b, m, n);
         const dim3 q1(NP / MPW, b), q2(MP / MPW, b);
-        // level j's 4^(j-7): on the rows' fragments down to 2^-14 (a normal fp16 number), the rest on the columns'
-        auto fa_of = [](int j) { const float f = powf(4.0f, (float)(j - 7)); return f < 6.103515625e-5f ? 6.103515625e-5f : f; };
-        auto fb_of = [&](int j) { return powf(4.0f, (float)(j - 7)) / fa_of(j); };
+        // level j's 4^(j-7) as fp16 powers of two (level_vectors): F down to 2^-14 (a normal fp16 number), f the rest, h = 2^(j-7)
+        auto h16 = [](int e) { return (unsigned)((e + 15) << 10); };            // bits of the fp16 number 2^e, -14 <= e <= 15
+        auto fac_of = [&](int j) { const int e = 2 * (j - 7), eF = e < -14 ? -14 : e; return LevelFac{h16(eF), h16(e - eF), h16(j - 7)}; };
         LevelScales ls;
         int cur = 0, lj = 0;
         for (int j = 7; j > -2; --j, ++lj) {
             float *rb = ws + lj * lstride;
-            ls.fa[lj] = fa_of(j); ls.fb[lj] = fb_of(j);
-            hipLaunchKernelGGL(emd_mfma_cols_kernel<0>, q1, dim3(64, m1), 0, s, st, cur, fa_of(j), fb_of(j), rb);
+            ls.lf[lj] = fac_of(j);
+            hipLaunchKernelGGL(emd_mfma_cols_kernel<0>, q1, dim3(64, m1), 0, s, st, cur, fac_of(j), rb);
+        EMD_STOP_CHECK();
             if (j == 7) {
-                hipLaunchKernelGGL(emd_mfma_rows_kernel<4>, q2, dim3(64, m2), 0, s, st, cur, fa_of(j), fb_of(j), rb, 0);
+                hipLaunchKernelGGL(emd_mfma_rows_kernel<4>, q2, dim3(64, m2), 0, s, st, cur, fac_of(j), rb, 0);
+        EMD_STOP_CHECK();
             } else {
-                hipLaunchKernelGGL(emd_mfma_rows_kernel<4>, q2, dim3(64, m2), 0, s, st, cur, fa_of(j), fb_of(j), rb, 1);
-                hipLaunchKernelGGL(emd_mfma_rows_kernel<1>, dim3(MP / 32, b), dim3(64, MSL), 0, s, st, cur, fa_of(j), fb_of(j), rb, 2);
+                hipLaunchKernelGGL(emd_mfma_rows_kernel<4>, q2, dim3(64, m2), 0, s, st, cur, fac_of(j), rb, 1);
+        EMD_STOP_CHECK();
+                hipLaunchKernelGGL(emd_mfma_rows_kernel<1>, dim3(MP / 32, b), dim3(64, MSL), 0, s, st, cur, fac_of(j), rb, 2);
+        EMD_STOP_CHECK();
             }
-            hipLaunchKernelGGL(emd_mfma_cols_kernel<3>, q1, dim3(64, m1), 0, s, st, cur, fa_of(j), fb_of(j), rb);
+            hipLaunchKernelGGL(emd_mfma_cols_kernel<3>, q1, dim3(64, m1), 0, s, st, cur, fac_of(j), rb);
+        EMD_STOP_CHECK();
             if (j > -1) {
                 hipLaunchKernelGGL(emd_mfma_compact_kernel<false>, dim3(b), dim3(1024), 0, s, st, cur, lj);
+        EMD_STOP_CHECK();
                 cur ^= 1;
             } else {
                 hipLaunchKernelGGL(emd_mfma_compact_kernel<true>, dim3(b), dim3(1024), 0, s, st, cur, lj);
+        EMD_STOP_CHECK();
             }
         }
         hipLaunchKernelGGL(emd_mfma_gather_kernel, dim3((MP + 255) / 256, b), dim3(256), 0, s, st, (const u4 *)recA2_dense, xyz2,
                            (const float *)ws, lstride, recA_s, rr_s, c2soa_s, l_s);
+        EMD_STOP_CHECK();
         const dim3 qm(NP / (32 * MTM), b);
         float *costpart_m = rec + (size_t)b * m * 12;
         if (cost)
@@ -1412,6 +1637,7 @@ static int approxmatch_impl(int b, int n, int m, const float *xyz1, const float 
             hipLaunchKernelGGL(emd_mfma_materialize_kernel<false>, qm, dim3(64, m1), 0, s, st, ls, xyz1, (const float *)ws, lstride,
                                (const u4 *)recA_s, (const float *)rr_s, (const float *)c2soa_s, (const int *)l_s, match, costpart_m);
         mfma_cost_parts = (int)qm.x * m1;
+#undef EMD_STOP_CHECK
     }
     Levels lv;
     int li = 0;
@@ -1462,6 +1688,57 @@ static int approxmatch_impl(int b, int n, int m, const float *xyz1, const float 
         }
     }
     return (int)hipGetLastError();
+}
+
+// Test hook (tests/test_gpu_emd.py::test_matrix_core_exponent_error_bound): out (m, n) = the matrix-core passes' exp2 arguments
+// -4^j log2(e) |x2_l - x1_k|^2 of ONE cloud pair at level j (7 .. -1); meta8 (device, 8 floats, may be NULL) receives the
+// centroid, the out-of-range flag (then `out` is left untouched), 2^g and T.  Workspace as for dpf_approxmatch_ws(1, n, m).
+extern "C" int dpf_debug_emd_exponents(int n, int m, const float *xyz1, const float *xyz2, int level_j, float *out, float *meta8,
+                                       void *workspace, size_t workspace_bytes, dpf_stream_t stream) {
+    static const unsigned slot_mask = [] { const char *e = getenv("DPF_EMD_DEBUG_SLOTS"); return e ? (unsigned)strtoul(e, nullptr, 0) : ~0u; }();
+    if (n <= 0 || m <= 0 || level_j < -1 || level_j > 7 || !xyz1 || !xyz2 || !out) return DPF_EINVAL;
+    if (!workspace || workspace_bytes < dpf_approxmatch_workspace_bytes(1, n, m)) return DPF_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int NP = (n + MPW - 1) / MPW * MPW, MP = (m + MPW - 1) / MPW * MPW;
+    uint8_t *mbase = (uint8_t *)(((uintptr_t)workspace + deferred_bytes(1, n, m) + 63) & ~(uintptr_t)63);
+    const MfmaRegions mr = mfma_regions(1, n, m);
+    unsigned *flag = (unsigned *)(mbase + mr.flag);
+    float *meta = (float *)(mbase + mr.meta);
+    hipError_t e = dpf_zero_async(flag, 16, s);
+    if (e != hipSuccess) return (int)e;
+    MfmaState st{};
+    st.n = n; st.m = m; st.NP = NP; st.MP = MP; st.nb = 1;
+    st.recB1 = (const u4 *)(mbase + mr.recB1);
+    for (int u = 0; u < 2; ++u) {
+        st.recA2[u] = (u4 *)(mbase + mr.recA2[u]); st.idx2[u] = (int *)(mbase + mr.idx2[u]); st.remainR_c[u] = (float *)(mbase + mr.remR[u]);
+    }
+    st.ratioR_c = (float *)(mbase + mr.ratioR); st.ratioL_p = (float *)(mbase + mr.ratioL);
+    st.count = (int *)(mbase + mr.count); st.counts = (int *)(mbase + mr.counts); st.order = (int *)(mbase + mr.order);
+    st.temp = nullptr; st.rstride = (size_t)(n + m); st.gate = flag;
+    u4 *recA2_dense = (u4 *)(mbase + mr.recA2d);
+    hipLaunchKernelGGL(emd_mfma_prep_kernel, dim3(1), dim3(1024), 0, s, n, m, xyz1, xyz2, meta, flag);
+    hipLaunchKernelGGL(emd_mfma_pack_kernel, dim3((NP + MP + 255) / 256, 1), dim3(256), 0, s, st, 1.0f, xyz1, xyz2, (const float *)meta,
+                       recA2_dense, (float *)workspace, (size_t)(n + m));
+    const int ex = 2 * (level_j - 7), eF = ex < -14 ? -14 : ex;
+    const LevelFac lf{(unsigned)((eF + 15) << 10), (unsigned)((ex - eF + 15) << 10), (unsigned)((level_j - 7 + 15) << 10)};
+    hipLaunchKernelGGL(emd_mfma_debug_exponents_kernel, dim3(NP / 32, MP / 32), dim3(64), 0, s, st, lf, (const u4 *)recA2_dense, out, slot_mask);
+    if (meta8) {
+        e = hipMemcpyAsync(meta8, meta, METAF * sizeof(float), hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int dpf_debug_emd_mismatches(float *out129) {     // EMD_DBG & 8 builds: [count, 16 x 8 records]; resets the count
+    unsigned n = 0;
+    float rec[128];
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_emd_dbg_n), 4) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(rec, HIP_SYMBOL(g_emd_dbg), sizeof(rec)) != hipSuccess) return -1;
+    out129[0] = (float)n;
+    memcpy(out129 + 1, rec, sizeof(rec));
+    n = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_emd_dbg_n), &n, 4);
+    return 0;
 }
 
 extern "C" int dpf_approxmatch_ws(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,

@@ -102,14 +102,19 @@ int dpf_approxmatch(int b, int n, int m, const float *xyz1, const float *xyz2,
 /* dpf_approxmatch with `match` written ONCE: the nine levels' ratio vectors and the passes' operand records are kept in
  * `workspace` and the matching is materialised by a final pass (4*n*m instead of 68*n*m bytes of HBM traffic per
  * cloud).  dpf_approxmatch_workspace_bytes covers both kernel families below: ~ 36*(n+m) + 16*(n+2m) + 48*m + n/2 bytes
- * per cloud for the packed-VALU one (bit-identical to dpf_approxmatch) + ~ 32*n + 220*m for the matrix-core one.
+ * per cloud for the packed-VALU one (bit-identical to dpf_approxmatch) + ~ 64*n + 350*m for the matrix-core one.
  * NULL / short workspace -> the read-modify-write path. */
 size_t dpf_approxmatch_workspace_bytes(int b, int n, int m);
-/* r05: with a workspace the 27 level passes run on the matrix cores (expanded-form squared distance, one MFMA per 32 x 32
- * pairs; csrc/emd.hip) when every coordinate, centred on cloud 1's centroid, fits the fp16 operands (|x - c|^2 <= 346, all
- * finite) -- decided per call on the device; otherwise, and after dpf_emd_set_matrix_path(0), the packed-VALU kernels run,
- * whose results are bit-identical to dpf_approxmatch.  The matrix-core results are within the tolerance contract (cost
- * 1e-4), not bit-identical.  Returns the previous setting. */
+/* r05 / r06: with a workspace the 27 level passes run on the matrix cores (expanded-form squared distance, two chained MFMAs
+ * per 32 x 32 pairs whose large terms are exact integer arithmetic on a per-call grid; csrc/emd.hip) when every point of
+ * both clouds, centred on cloud 1's centroid c, has log2(e) |x - c|^2 <= 16 and is finite -- decided per call on the device;
+ * otherwise, and after dpf_emd_set_matrix_path(0), the packed-VALU kernels run, whose results are bit-identical to
+ * dpf_approxmatch.  The matrix-core results are within the tolerance contract (cost 1e-4; the exp2 arguments within 2e-5 of
+ * float64 at the steepest level on unit-size clouds, measured by dpf_debug_emd_exponents), not bit-identical.  DETERMINISM of
+ * the matrix-core kernels is a property of the compiled code, not of the source: two builds of r05 returned run-to-run
+ * differing bits (csrc/emd.hip, opaque_zero); the Makefile therefore refuses to link an emd.o whose MFMAs do not have the
+ * properties of the build that repeats (tools/mfma_overlap_check.py --require-register-c), and tests/test_gpu_emd.py holds the
+ * repeat tests.  Returns the previous setting. */
 int dpf_emd_set_matrix_path(int on);
 int dpf_approxmatch_ws(int b, int n, int m, const float *xyz1, const float *xyz2,
                        float *match, float *temp, void *workspace, size_t workspace_bytes,
@@ -398,6 +403,12 @@ int dpf_encoder_train_backward(int B, int N, const float *canon, const float *x,
  * of every pair of ONE pair of clouds ((nq, 3) queries, (nc, 3) candidates), formed exactly as the filter forms it; s is
  * (nq, nc) floats, out4 = {mu_x, mu_y, mu_z, R2}.  The filter's exactness rests on |s - exact| <= 2^-14 R2. */
 int dpf_debug_nn_surrogate(int nq, const float *q, int nc, const float *c, float *s, float *out4, dpf_stream_t stream);
+/* Test hook of the matrix-core approx-EMD passes (csrc/emd.hip): out (m, n) = the exp2 arguments -4^j log2(e) |xyz2_l - xyz1_k|^2
+ * of ONE cloud pair at annealing level j (7 .. -1), formed exactly as the passes form them (same records, level vectors and
+ * MFMAs); meta8 (8 device floats or NULL) = {centroid xyz, out-of-range flag (then `out` is untouched), 2^g, T, 0, 0}.
+ * Workspace as for dpf_approxmatch_ws(1, n, m). */
+int dpf_debug_emd_exponents(int n, int m, const float *xyz1, const float *xyz2, int level_j, float *out, float *meta8,
+                            void *workspace, size_t workspace_bytes, dpf_stream_t stream);
 long dpf_train_graph_replays(void);
 /* Workgroups of the training backward pass that gave up waiting for role workgroups of their own launch (pass 1: the column sums
  * of the layer above; pass 2, small batches: the per-cloud totals and BatchNorm-backward means of pass 1) and did the sums

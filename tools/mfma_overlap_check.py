@@ -4,7 +4,20 @@ r05: such an instruction ("v_mfma_f32_32x32x16_f16 v[2:17], v[70:73], v[2:5], 0"
 a source that dies there) produced results that differed from run to run on MI355X (csrc/emd.hip, pair_exponents).  A destination
 identical to source C is the normal accumulate form and is not reported.
 
-    python tools/mfma_overlap_check.py file.s [...]     -> one line per offending instruction; exit status 1 if any
+    python tools/mfma_overlap_check.py [--require-register-c] [--no-scratch PREFIX] file.s [...]
+        -> one line per offending instruction; exit status 1 if any
+    --require-register-c   also report MFMAs whose C operand is not a register tuple (the literal-0 form is the one the compiler
+                           pairs with an overlapping destination)
+    --no-scratch PREFIX    also fail if a kernel whose name contains PREFIX touches scratch memory (a spilled build of the
+                           approx-EMD passes flickered too)
+    --no-packed-f32 PREFIX r06: also fail if a kernel whose name contains PREFIX holds v_pk_{fma,mul,add}_f32 (the SLP vectoriser's
+                           packed consumers of v_exp_f32 results: the root cause of r05's run-to-run differences)
+    --war                  r06: also report a VMEM / LDS / scratch LOAD whose destination registers are the A or B source of an
+                           MFMA that was issued before it and whose result nothing has read yet (the MFMA may still be queued in
+                           the matrix pipe; tools/ubench/mfma_war.hip, DESIGN 4.6: this pattern is the root cause of r05's
+                           run-to-run differences)
+csrc/Makefile runs it on emd.s with all three options before emd.o may be linked: determinism of those kernels is a property of the
+compiled code (include/dpf_hip.h at dpf_emd_set_matrix_path).
 """
 import re
 import sys
@@ -25,7 +38,7 @@ def overlaps(a, b):
     return a is not None and b is not None and a[0] == b[0] and a[1] <= b[2] and b[1] <= a[2]
 
 
-def scan(path):
+def scan(path, require_register_c=False, no_scratch=None, no_packed=None):
     bad, kernel, total = [], None, 0
     for line in open(path):
         m = re.match(r"^(\S+):\s", line)
@@ -41,13 +54,89 @@ def scan(path):
         dst, a, b = regs(ops[0]), regs(ops[1]), regs(ops[2])
         if overlaps(dst, a) or overlaps(dst, b):
             bad.append((kernel, line.strip()))
+        elif require_register_c and regs(ops[3].split()[0] if len(ops) > 3 else "") is None:
+            bad.append((kernel, line.strip() + "    ; C is not a register tuple"))
+    if no_packed:
+        kernel = None
+        for line in open(path):
+            m = re.match(r"^(\S+):\s", line)
+            if m and not m.group(1).startswith("."):
+                kernel = m.group(1)
+            if kernel and no_packed in kernel and re.search(r"\bv_pk_(fma|mul|add)_f32\b", line):
+                bad.append((kernel, line.strip() + "    ; packed fp32 VALU in a kernel that must not have any"))
+    if no_scratch:
+        kernel = None
+        for line in open(path):
+            m = re.match(r"^(\S+):\s", line)
+            if m and not m.group(1).startswith("."):
+                kernel = m.group(1)
+            if kernel and no_scratch in kernel and re.search(r"\bscratch_(load|store)", line):
+                bad.append((kernel, line.strip() + "    ; scratch in a kernel that must not spill"))
+                break
     return total, bad
 
 
-def main(paths):
+LOADS = re.compile(r"\s*(global_load_\S+|buffer_load_\S+|scratch_load_\S+|flat_load_\S+|ds_read\S*|ds_load\S*)\s+(.*)")
+ANYREG = re.compile(r"\b([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b")
+
+
+def scan_war(path):
+    """[(kernel, load line, mfma line)]: loads into the A / B registers of an MFMA nobody has consumed yet"""
+    out, kernel, pending = [], None, []
+    for line in open(path):
+        m = re.match(r"^(\S+):\s", line)
+        if m and not m.group(1).startswith("."):
+            kernel, pending = m.group(1), []
+        body = line.split(";")[0]
+        mm = re.match(r"\s*(v_mfma_\S+|v_smfmac_\S+)\s+(.*)", body)
+        if mm:
+            ops = [o.strip() for o in mm.group(2).split(",")]
+            if len(ops) >= 4:
+                c = regs(ops[3].split()[0])
+                # an MFMA that accumulates onto an earlier result does not prove that one finished: keep both pending
+                pending.append((regs(ops[0]), regs(ops[1]), regs(ops[2]), body.strip()))
+            continue
+        ml = LOADS.match(body)
+        if ml:
+            dst = regs(ml.group(2).split(",")[0].strip())
+            for (d, a, b, txt) in pending:
+                if overlaps(dst, a) or overlaps(dst, b):
+                    out.append((kernel, body.strip(), txt))
+                    break
+        if not pending or not body.strip() or body.strip().startswith((".", "s_", ";")):
+            continue
+        # any other instruction that READS a pending MFMA's destination waits for it (and for every MFMA before it)
+        toks = body.split(None, 1)
+        srcs = toks[1].split(",")[1:] if len(toks) > 1 and not ml else (toks[1].split(",")[1:] if len(toks) > 1 else [])
+        if toks and toks[0].startswith(("global_store", "buffer_store", "scratch_store", "flat_store", "ds_write", "ds_store")):
+            srcs = toks[1].split(",")
+        used = []
+        for sx in srcs:
+            for t in ANYREG.finditer(sx):
+                used.append((t.group(1) or t.group(4), int(t.group(2) or t.group(5)), int(t.group(3) or t.group(5))))
+        last = -1
+        for i, (d, a, b, txt) in enumerate(pending):
+            if any(overlaps(d, u) for u in used):
+                last = i
+        if last >= 0:
+            pending = pending[last + 1:]
+    return out
+
+
+def main(argv):
     rc = 0
+    req = "--require-register-c" in argv
+    nos = argv[argv.index("--no-scratch") + 1] if "--no-scratch" in argv else None
+    nop = argv[argv.index("--no-packed-f32") + 1] if "--no-packed-f32" in argv else None
+    paths = [a for i, a in enumerate(argv) if not a.startswith("--") and (i == 0 or argv[i - 1] not in ("--no-scratch", "--no-packed-f32"))]
     for p in paths:
-        total, bad = scan(p)
+        total, bad = scan(p, req, nos, nop)
+        if "--war" in argv:
+            war = scan_war(p)
+            print("%s: %d loads into the A / B registers of an MFMA still in flight" % (p, len(war)))
+            for k, l, mf in war:
+                print("   %s: %s    <- after %s" % ((k or "?")[:50], l, mf))
+                rc = 1
         print("%s: %d MFMA instructions, %d with the destination on a source's registers" % (p, total, len(bad)))
         for k, l in bad:
             print("   %s: %s" % (k[:60], l))
