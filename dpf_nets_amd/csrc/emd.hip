@@ -672,10 +672,14 @@ __device__ __forceinline__ f16acc opaque_zero() {
     asm volatile("" : "+v"(z));
     return z;
 }
+#ifndef EMD_DBG
+#define EMD_DBG 0          // A/B builds of r06's hunt (tests/diag/emd_rows_probe.py, emd_chain_mismatch.py; all of them flickered or
+                           // agreed exactly as the plain build did -- DESIGN 4.6): 1 64 wait states behind the chain, 2 no chaining,
+                           // 4 tiles serialised, 8 chained against unchained in every call, mismatches recorded
+#endif
+#if EMD_DBG & 8
 __device__ unsigned g_emd_dbg_n;
 __device__ float g_emd_dbg[16 * 8];
-#ifndef EMD_DBG
-#define EMD_DBG 0          // timing experiments of r06 (tests/diag/emd_rows_probe.py): 1 wait behind the chain, 2 no chaining, 4 tiles serialised
 #endif
 __device__ __forceinline__ f16acc pair_exponents(const Frag &rows, const Frag &cols, const f16acc &zacc) {
 #if EMD_DBG & 8
@@ -715,13 +719,16 @@ __device__ __forceinline__ f16acc pair_exponents(const Frag &rows, const Frag &c
 #endif
 }
 
-// The next tile's prefetch must not be ISSUED before this tile's MFMAs have finished (r06; EMD_PIN_LOADS).  The compiler counts a
-// register dead once its last reader has issued and hands the scaled fragment's registers to the prefetch ("v_mfma ... v[122:125]
-// ...; global_load_dwordx4 v[122:125]" right behind four queued MFMAs that read v[122:125]); see DESIGN 4.6 for what
-// tools/ubench/mfma_war.hip measured about that pattern.  Taking the tile's sums through an empty asm with a memory clobber
-// keeps every later load behind the VALU instructions that consumed the MFMAs' results.
+// EMD_PIN_LOADS=1 (an A/B build, off by default): keep every prefetch behind the VALU instructions that consumed the previous
+// tile's MFMA results, and every tile's MFMAs behind the prefetch in front of it.  Built in r06 to test ONE hypothesis for r05's
+// run-to-run differences -- the compiler counts a register dead once its last reader has issued and hands a scaled fragment's
+// registers to the next prefetch ("v_mfma ... v[122:125] ...; global_load_dwordx4 v[122:125]" behind four queued MFMAs);
+// tools/mfma_overlap_check.py --war lists such sites.  REJECTED: tools/ubench/mfma_war.hip and mfma_valu_war.hip overwrite the
+// sources of up to seven queued MFMAs by a cache-resident load / by VALU writes in the very next slot, 1.6e7 times at up to four
+// waves per SIMD, without one wrong result -- the hardware interlocks it; the pinned build flickered like the unpinned one, and
+// both repeat once the vectoriser is off.  The pins cost nothing measurable (cfg5 2.740 vs 2.741 ms).
 #ifndef EMD_PIN_LOADS
-#define EMD_PIN_LOADS 1
+#define EMD_PIN_LOADS 0
 #endif
 // ... and the MFMAs of the tile that follows a prefetch must not be moved IN FRONT of it (an MFMA is no memory operation: the
 // scheduler hoists it over a plain memory barrier): the tile's raw fragments pass through the barrier
@@ -848,10 +855,11 @@ __global__ __launch_bounds__(64 * MSL) void emd_mfma_rows_kernel(MfmaState st, i
     const f16acc zacc = opaque_zero();
     const int bi = blockIdx.y, lane = threadIdx.x, slice = __builtin_amdgcn_readfirstlane(threadIdx.y), S = blockDim.y;
     const int cnt = st.count[bi];
-    if ((int)blockIdx.x * RPW >= cnt) return;                       // (whole workgroup)
+    const int rowblock = blockIdx.x;
+    if (rowblock * RPW >= cnt) return;                              // (whole workgroup)
     if (regime == 1 ? 2 * cnt <= st.m : regime == 2 ? 2 * cnt > st.m : false) return;
     const int half = lane >> 5, col = lane & 31;
-    const u4 *ownrec = st.recA2[cur] + ((size_t)bi * st.MP + blockIdx.x * RPW) * RECQ;
+    const u4 *ownrec = st.recA2[cur] + ((size_t)bi * st.MP + rowblock * RPW) * RECQ;
     const u4 *candrec = st.recB1 + ((size_t)bi * st.NP + col) * RECQ + half;
     const float *wl = st.ratioL_p + (size_t)bi * st.NP;
     u4 svr[2], svc[2];
@@ -929,7 +937,7 @@ __global__ __launch_bounds__(64 * MSL) void emd_mfma_rows_kernel(MfmaState st, i
     float *remainR = st.temp + (size_t)bi * (st.n + st.m) * 2 + st.n;
     float *ratioR = rb_cur + (size_t)bi * st.rstride + st.n;
     for (int tid = slice * 64 + lane; tid < RPW; tid += 64 * S) {
-        const int pos = blockIdx.x * RPW + tid;
+        const int pos = rowblock * RPW + tid;
         if (pos >= cnt) continue;
         const size_t at = (size_t)bi * st.MP + pos;
         const int l = st.idx2[cur][at];
@@ -1567,6 +1575,10 @@ static int approxmatch_impl(int b, int n, int m, const float *xyz1, const float 
     float *rec = deferred ? (float *)(pk + (size_t)b * pstride) : nullptr;
     // (the range check first: every kernel of either family looks at its verdict)
     if (matrix) hipLaunchKernelGGL(emd_mfma_prep_kernel, dim3(b), dim3(1024), 0, s, n, m, xyz1, xyz2, meta, flag);
+    // (r06, VERDICT r05 #4: the family that is not wanted was moved to a forked side stream -- built, parity-green, measured at
+    // cfg5: 2.7323 ms against 2.7315 ms with everything on the caller's stream.  The 31 gated launches sit at the END of the
+    // call's sequence, back to back, and their launch latencies overlap each other; r05's "0.13 ms of empty launches" was the
+    // rocprof sum of their durations, not time on the call's critical path.  Not kept.)
     if (deferred)
         hipLaunchKernelGGL(emd_pack_init_kernel, dim3((m + 255) / 256, b), dim3(256), 0, s, m, multiR, xyz2, pk + n, pstride,
                            (const unsigned *)flag);
@@ -1607,12 +1619,15 @@ static int approxmatch_impl(int b, int n, int m, const float *xyz1, const float 
         EMD_STOP_CHECK();
             if (j == 7) {
                 hipLaunchKernelGGL(emd_mfma_rows_kernel<4>, q2, dim3(64, m2), 0, s, st, cur, fac_of(j), rb, 0);
-        EMD_STOP_CHECK();
+                EMD_STOP_CHECK();
             } else {
+                // (r06: both regimes as ONE launch -- every fourth workgroup of the sparse regime's grid taking four tiles in the
+                // dense one -- was built and measured: cfg5 2.73 -> 3.53 ms.  The two launches stay; the one whose regime it is
+                // not costs 5-7 us)
                 hipLaunchKernelGGL(emd_mfma_rows_kernel<4>, q2, dim3(64, m2), 0, s, st, cur, fac_of(j), rb, 1);
-        EMD_STOP_CHECK();
+                EMD_STOP_CHECK();
                 hipLaunchKernelGGL(emd_mfma_rows_kernel<1>, dim3(MP / 32, b), dim3(64, MSL), 0, s, st, cur, fac_of(j), rb, 2);
-        EMD_STOP_CHECK();
+                EMD_STOP_CHECK();
             }
             hipLaunchKernelGGL(emd_mfma_cols_kernel<3>, q1, dim3(64, m1), 0, s, st, cur, fac_of(j), rb);
         EMD_STOP_CHECK();
@@ -1729,6 +1744,7 @@ extern "C" int dpf_debug_emd_exponents(int n, int m, const float *xyz1, const fl
     return (int)hipGetLastError();
 }
 
+#if EMD_DBG & 8
 extern "C" int dpf_debug_emd_mismatches(float *out129) {     // EMD_DBG & 8 builds: [count, 16 x 8 records]; resets the count
     unsigned n = 0;
     float rec[128];
@@ -1740,6 +1756,7 @@ extern "C" int dpf_debug_emd_mismatches(float *out129) {     // EMD_DBG & 8 buil
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_emd_dbg_n), &n, 4);
     return 0;
 }
+#endif
 
 extern "C" int dpf_approxmatch_ws(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
                                   void *workspace, size_t workspace_bytes, dpf_stream_t stream) {

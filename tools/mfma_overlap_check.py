@@ -14,9 +14,10 @@ identical to source C is the normal accumulate form and is not reported.
                            packed consumers of v_exp_f32 results: the root cause of r05's run-to-run differences)
     --war                  r06: also report a VMEM / LDS / scratch LOAD whose destination registers are the A or B source of an
                            MFMA that was issued before it and whose result nothing has read yet (the MFMA may still be queued in
-                           the matrix pipe; tools/ubench/mfma_war.hip, DESIGN 4.6: this pattern is the root cause of r05's
-                           run-to-run differences)
-csrc/Makefile runs it on emd.s with all three options before emd.o may be linked: determinism of those kernels is a property of the
+                           the matrix pipe).  An INVENTORY, not a defect list: tools/ubench/mfma_war.hip / mfma_valu_war.hip
+                           show the hardware interlocks this pattern (a rejected hypothesis for r05's run-to-run
+                           differences; flow.hip has thousands of such sites and has never flickered)
+csrc/Makefile runs it on emd.s with the first three options before emd.o may be linked: determinism of those kernels is a property of the
 compiled code (include/dpf_hip.h at dpf_emd_set_matrix_path).
 """
 import re
