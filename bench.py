@@ -132,6 +132,57 @@ def _free_port():
     return p
 
 
+class Watchdog:
+    """Turns a rank that stops making progress into a diagnosis (profiles/README.md r05: one of seven two-rank runs
+    hung in its first all-reduce -- one rank's step never reached the collective -- and nothing in the output could say where).
+    Every rank runs one: the legs call beat(stage) at every step and either side of every collective; a daemon thread that sees
+    no beat for DPF_BENCH_WATCHDOG_S seconds (default 240; 0 = off) prints ONE JSON line on stderr -- rank, the last stage, seconds
+    without progress, the training engine's counters (graph replays / eager calls / recordings / evictions / uncapturable keys,
+    workgroups that gave up waiting for their launch's role workgroups) -- and ends THIS process with status 86.  It never
+    re-executes anything: torchrun (or launch_ranks below, the parent, which has not touched the GPU) then tears the other
+    ranks down and the job exits non-zero with that line in its log."""
+    _one = None
+
+    def __init__(self, rank, seconds):
+        import threading
+        self.rank, self.seconds, self.stage, self.t, self.beats = rank, seconds, "start", time.monotonic(), 0
+        self.lib_handle = None
+        if seconds > 0:
+            threading.Thread(target=self._watch, name="bench-watchdog", daemon=True).start()
+
+    @classmethod
+    def start(cls, rank):
+        cls._one = cls(rank, float(os.environ.get("DPF_BENCH_WATCHDOG_S", "240")))
+        return cls._one
+
+    @classmethod
+    def beat(cls, stage):
+        w = cls._one
+        if w is not None:
+            w.stage, w.t, w.beats = stage, time.monotonic(), w.beats + 1
+
+    def _watch(self):
+        while True:
+            time.sleep(min(1.0, self.seconds / 4))
+            idle = time.monotonic() - self.t
+            if idle > self.seconds:
+                dump = {"watchdog": "no progress", "rank": self.rank, "last_stage": self.stage, "beats": self.beats,
+                        "seconds_without_progress": round(idle, 1), "pid": os.getpid()}
+                try:                                          # host-side counters only: no GPU call from this thread
+                    h = self.lib_handle
+                    if h is not None:
+                        st = (ctypes.c_long * 5)()
+                        h.dpf_train_graph_stats(st)
+                        dump["train_graph_stats"] = dict(zip(("replays", "eager", "recordings", "evictions", "uncapturable"), list(st)))
+                        h.dpf_train_colsum_fallbacks.restype = ctypes.c_long
+                        dump["colsum_fallbacks"] = int(h.dpf_train_colsum_fallbacks())
+                except Exception as e:       # noqa: BLE001
+                    dump["counters_error"] = repr(e)
+                sys.stderr.write(json.dumps(dump) + "\n")
+                sys.stderr.flush()
+                os._exit(86)
+
+
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` outside torchrun: start the N ranks as children of THIS process, which has not touched the
     GPU (no HIP call so far: torch.cuda.device_count() does not initialise it), wait, and exit with their code."""
@@ -143,7 +194,34 @@ def launch_ranks(args, argv):
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this driver
-    return subprocess.call(cmd, env=env)
+    # the ranks police themselves (Watchdog: status 86 + one JSON line); the parent adds the outer bound: a job that is still
+    # there after DPF_BENCH_LAUNCH_TIMEOUT_S (default 3600) has its whole process group killed -- by this process, which has never
+    # initialised the GPU -- and the launcher exits non-zero
+    limit = float(os.environ.get("DPF_BENCH_LAUNCH_TIMEOUT_S", "3600"))
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return proc.wait(timeout=limit if limit > 0 else None)
+    except subprocess.TimeoutExpired:
+        import signal
+        sys.stderr.write(json.dumps({"launcher": "timeout", "seconds": limit, "action": "killing the ranks (exact PIDs: the tree below "
+                                     "the launcher's child)"}) + "\n")
+        victims = []
+        try:                                   # torchrun gives its workers their own process groups: walk the tree
+            import psutil
+            victims = psutil.Process(proc.pid).children(recursive=True)
+        except Exception:       # noqa: BLE001
+            pass
+        for v in victims:
+            try:
+                v.kill()
+            except Exception:       # noqa: BLE001
+                pass
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        proc.wait()
+        return 124
 
 
 def init_ranks(args):
@@ -210,7 +288,9 @@ def timed_region(run_steps, args, dist, device, launch_streams=None):
     path's (VERDICT r05 weak #2; tools/headline_window.py measures what an idle gap in front of the window costs)."""
     import gc
     streams = list(launch_streams) if launch_streams else [torch.cuda.current_stream()]
+    Watchdog.beat("timed region: warm-up")
     run_steps(args.warmup)
+    Watchdog.beat("timed region: barrier in front of the timed steps")
     if dist is not None:
         dist.barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -226,6 +306,7 @@ def timed_region(run_steps, args, dist, device, launch_streams=None):
         ev1.record(streams[0])
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
+        Watchdog.beat("timed region: timed steps done")
     finally:
         if gc_was:
             gc.enable()
@@ -922,10 +1003,17 @@ def train_step_leg(args, rank, world, dist, device, batch, layers, steps, warmup
     ev = []
     counted = []
 
+    nstep = [0]
+    if Watchdog._one is not None:
+        Watchdog._one.lib_handle = _lib_handle()          # (the training engine's host-side counters, for a stall's dump)
+
     def step(record=False):
+        nstep[0] += 1
+        Watchdog.beat("train step %d: forward / backward" % nstep[0])
         arena.zero_grad()                                            # training.py:54 (one fill)
         loss = compute()                                             # training.py:37,42
         loss.backward()                                              # training.py:55
+        Watchdog.beat("train step %d: the gradient all-reduce" % nstep[0])
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -1158,6 +1246,9 @@ def selftest_ranks(args, rank, world, dist):
     started N ranks which see each other (gloo), and that the max-over-ranks reduction and the flat all-reduce work."""
     t = torch.tensor([float(rank + 1)])
     flat = torch.arange(8, dtype=torch.float32) * (rank + 1)
+    Watchdog.beat("selftest: before the first all-reduce")
+    if os.environ.get("DPF_BENCH_SELFTEST_STALL_RANK") == str(rank):      # (the watchdog's own test: this rank never arrives)
+        time.sleep(3600)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(flat)
@@ -1173,6 +1264,7 @@ def main(argv=None):
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args, argv))
     rank, local_rank, world, dist = init_ranks(args)
+    wd = Watchdog.start(rank)
     if os.environ.get("DPF_BENCH_SELFTEST") == "1":
         selftest_ranks(args, rank, world, dist)
         if dist is not None:
@@ -1185,6 +1277,7 @@ def main(argv=None):
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
+    Watchdog.beat("leg %s / %s" % (args.leg, args.config))
     if args.leg == "train":
         line, extra = leg_train(args, rank, world, dist, device)
     elif args.config == "cfg5":
@@ -1193,6 +1286,7 @@ def main(argv=None):
         line, extra = leg_eval(args, rank, world, dist, device)
         if not args.no_extra and args.config == "cfg2" and args.layers == 14 and not args.no_configs:
             try:
+                Watchdog.beat("extra: the other configs")
                 extra["configs"] = extra_config_legs(args, rank, world, device)
             except Exception as e:       # noqa: BLE001
                 extra["configs_error"] = repr(e)
@@ -1200,12 +1294,14 @@ def main(argv=None):
             # the training step with its single gradient all-reduce, on the default run too: at N > 1 this is where RCCL carries
             # the 40 / 52 MB flat gradient over xGMI (every rank takes part; reported by rank 0)
             try:
+                Watchdog.beat("extra: training step leg")
                 batch, _ = clouds_of_rank(args, rank, world)
                 extra["train_step"] = train_step_leg(args, rank, world, dist, device, batch, 63, args.train_steps, 16)
             except Exception as e:       # noqa: BLE001 -- never lose the headline line to an extra
                 extra["train_step_error"] = repr(e)
         if not args.no_extra and not args.no_proxy and world == 1 and args.config == "cfg2" and args.layers == 14 and args.batch is None:
             try:                                         # rank-local, no collective: the single-GPU run only
+                Watchdog.beat("extra: per-rank proxies")
                 extra["per_rank_proxy"] = per_rank_proxy(args, device)
             except Exception as e:       # noqa: BLE001
                 extra["per_rank_proxy_error"] = repr(e)

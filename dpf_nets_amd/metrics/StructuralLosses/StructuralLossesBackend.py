@@ -145,7 +145,9 @@ def ApproxMatch(set_d, set_q):
         if EMD_RMW:
             check(lib().dpf_approxmatch(b, n, m, set_d.data_ptr(), set_q.data_ptr(), match.data_ptr(),
                                         temp.data_ptr(), current_stream()), "approxmatch")
-        else:   # bit-identical, `match` written once (scratch for the per-level ratio vectors is caller-owned)
+        else:   # `match` written once (scratch for the per-level ratio vectors is caller-owned).  Within the 1e-4 cost contract of
+                # the read-modify-write path, NOT bit-identical to it since r05: in range the passes run on the matrix cores
+                # (include/dpf_hip.h at dpf_emd_set_matrix_path; dpf_emd_set_matrix_path(0) selects the bit-identical kernels)
             nbytes = lib().dpf_approxmatch_workspace_bytes(b, n, m)
             ws = torch.empty((nbytes,), dtype=torch.uint8, device=set_d.device)
             check(lib().dpf_approxmatch_ws(b, n, m, set_d.data_ptr(), set_q.data_ptr(), match.data_ptr(),

@@ -51,8 +51,24 @@ def train_stack(owner, layers, p, g, mode, allow_flat=False):
     return run_training_stack(spec, p, g, mode)
 
 
+class EvalModeAutogradWarning(RuntimeWarning):
+    """An eval()-mode module was called under autograd: the call is served by PyTorch tensor operations, not by the HIP kernels."""
+
+
 def _needs_autograd(*tensors):
-    return torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
+    """True when an eval()-mode call must stay differentiable with respect to its INPUTS (the reference's
+    CondRealNVPFlow3D.forward is: flows.py:95-117).  The fused HIP stacks have a backward pass for training-mode BatchNorm only
+    (csrc/flow_train.hip); an eval-mode call under autograd therefore runs the reference's op sequence on ATen (~30 kernels per
+    layer) -- correct, differentiable, and some 50x slower than the fused stack.  That is a SECOND backend behind forward(), so it
+    is loud: one EvalModeAutogradWarning per call site.  The reference's own loops never take it
+    (evaluating.py:58-59 runs under no_grad; training.py:37-56 in train() mode)."""
+    need = torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
+    if need:
+        import warnings
+        warnings.warn("eval()-mode flow called with inputs that require grad: served by PyTorch tensor operations (differentiable, "
+                      "~30 ATen kernels per coupling layer), not by the fused HIP stack; call under torch.no_grad() for the HIP "
+                      "path, or in train() mode for the HIP training kernels", EvalModeAutogradWarning, stacklevel=3)
+    return need
 
 
 class CondRealNVPFlow3D(nn.Module):

@@ -24,7 +24,8 @@ from .._lib import lib, check, current_stream, MODE
 
 
 def _needs_autograd(*tensors):
-    return torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
+    from .flows import _needs_autograd as point_flow_rule          # (one rule, one warning class: flows.EvalModeAutogradWarning)
+    return point_flow_rule(*tensors)
 
 
 def pattern_code(warp_inds, G):

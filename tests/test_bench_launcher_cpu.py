@@ -33,6 +33,25 @@ def test_world_size_mismatch_is_an_error():
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
 
 
+def test_a_stalled_rank_ends_the_job_with_a_diagnosis():
+    """rank 1 never reaches the first all-reduce; its watchdog prints where it stands and ends it (status 86),
+    the launcher tears the job down and exits non-zero -- in seconds, not after the process group's timeout."""
+    import time
+    t0 = time.time()
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1"], {"DPF_BENCH_SELFTEST": "1", "DPF_BENCH_BACKEND": "gloo",
+                                                               "DPF_BENCH_SELFTEST_STALL_RANK": "1", "DPF_BENCH_WATCHDOG_S": "4"})
+    assert r.returncode != 0
+    dumps = [json.loads(ln) for ln in r.stderr.splitlines() if ln.startswith("{") and "watchdog" in ln]
+    assert dumps and any(d["rank"] == 1 and "before the first all-reduce" in d["last_stage"] for d in dumps), r.stderr[-1500:]
+    assert time.time() - t0 < 120
+
+
+def test_the_launcher_bounds_the_whole_job():
+    r = _run(["--gpus", "2"], {"DPF_BENCH_SELFTEST": "1", "DPF_BENCH_BACKEND": "gloo", "DPF_BENCH_SELFTEST_STALL_RANK": "0",
+                               "DPF_BENCH_WATCHDOG_S": "0", "DPF_BENCH_LAUNCH_TIMEOUT_S": "20"})
+    assert r.returncode == 124 and '"launcher": "timeout"' in r.stderr
+
+
 def test_single_process_needs_no_launcher():
     r = _run(["--gpus", "1"], {"DPF_BENCH_SELFTEST": "1", "DPF_BENCH_BACKEND": "gloo"})
     assert r.returncode == 0, r.stderr[-2000:]

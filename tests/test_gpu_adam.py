@@ -47,6 +47,43 @@ def test_fused_adam_step_is_bitwise_the_op_sequence(n, amsgrad, wd):
     assert lib().dpf_adam_step(4, p.data_ptr(), p.data_ptr(), p.data_ptr(), p.data_ptr(), None, lr, b1, b2, eps, wd, 0.0, 0.1, None) == -1       # bias correction 0
 
 
+def test_fused_adam_step_on_the_reference_goldens_own_inputs(golden_dir):
+    """the kernel one hop from the reference.  tests/golden/optimizer.npz holds what the REFERENCE's Adam
+    (lib/networks/optimizers.py:15-76, run by oracle/gen_golden.py) leaves after five steps of the cyclic schedule on four
+    parameters (a SharedDot-shaped weight, a vector, a matrix, a scalar) for every AMSGrad / weight-decay case; here dpf_adam_step
+    itself takes the same parameters, gradients, learning rates and betas: weights, both moments and the AMSGrad maximum
+    bit for bit (CPU ATen and the kernel run the same IEEE operations in the same order; 0 ulp measured)."""
+    import numpy as np
+    import os
+    _gpu()
+    from dpf_nets_amd._lib import lib, current_stream
+    from oracle import optimizer_oracle as OO
+    from oracle.gen_golden import OPT_CASES, optimizer_inputs
+    gold = np.load(os.path.join(golden_dir, "optimizer.npz"))
+    for name, (ams, wd) in OPT_CASES.items():
+        shapes = [np.asarray(v).shape for v in optimizer_inputs(5, -1)]
+        ps = [torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).reshape(-1).cuda() for v in optimizer_inputs(5, -1)]
+        # (every parameter in its own 16-byte aligned buffer: the flat store of the training engine aligns them the same way)
+        ms = [torch.zeros_like(p) for p in ps]
+        vs = [torch.zeros_like(p) for p in ps]
+        vmax = [torch.zeros_like(p) for p in ps]
+        for step in range(5):
+            lr, betas = OO.lr_update(4, 3, 1e-4, 2e-3, 0.9, 0.99, 0.999, step // 4, step % 4)
+            np.testing.assert_allclose([lr, betas[1]], gold[name + "_sched"][step], rtol=1e-15)
+            gs = [torch.from_numpy(np.ascontiguousarray(g, dtype=np.float32)).reshape(-1).cuda() for g in optimizer_inputs(5, step)]
+            for p, g, m, v, vm in zip(ps, gs, ms, vs, vmax):
+                rc = lib().dpf_adam_step(p.numel(), p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), vm.data_ptr() if ams else None,
+                                         lr, betas[0], betas[1], 1e-8, wd, 1 - betas[0] ** (step + 1), math.sqrt(1 - betas[1] ** (step + 1)),
+                                         current_stream())
+                assert rc == 0
+        torch.cuda.synchronize()
+        for i, shp in enumerate(shapes):
+            for what, got in (("p", ps[i]), ("m", ms[i]), ("v", vs[i])) + ((("vmax", vmax[i]),) if ams else ()):
+                ref = np.asarray(gold["%s_%s%d" % (name, what, i)], dtype=np.float32).reshape(-1)
+                ulp = np.abs(got.cpu().numpy().view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64))
+                assert int(ulp.max()) <= 1, (name, what, i, int(ulp.max()))
+
+
 def test_optimizer_class_takes_the_fused_path_and_keeps_the_trajectory(monkeypatch):
     """networks.optimizers.Adam on a flattened decoder: with the fused kernel and with DPF_FUSED_ADAM=0 (the op sequence) the
     weights, moments and step counters after 5 steps are bit-identical."""

@@ -389,6 +389,53 @@ def test_module_semantics():
     assert pr.grad is not None and torch.isfinite(pr.grad).all()
 
 
+def test_eval_mode_gradients_vs_reference_golden(golden_dir):
+    """CondRealNVPFlow3D.forward is differentiable in eval() mode in the reference (flows.py:95-117).  The fused
+    HIP stacks have a backward pass for training-mode BatchNorm only, so an eval-mode call whose inputs require grad is served by
+    the reference's op sequence on ATen -- LOUDLY (networks.flows.EvalModeAutogradWarning, once per call site) -- and its outputs
+    and input gradients are the reference's (golden cases bn == "eval": grad_p, grad_g of a fixed linear functional)."""
+    import warnings
+    nets = _gpu()
+    from dpf_nets_amd.networks.flows import EvalModeAutogradWarning
+    from oracle.gen_golden import layer_inputs as li
+    gold, meta = _load(golden_dir, "flow_layer")
+    B, N, F, G = meta["B"], meta["N"], meta["F"], meta["G"]
+    seen = 0
+    for case in meta["cases"]:
+        if case["bn"] != "eval":
+            continue
+        mod = nets.CondRealNVPFlow3D(F, G, warp_inds=case["warp"])
+        mod.load_state_dict(FO.to_torch(FO.make_layer_state(case["seed"], F, G, case["warp"])), strict=True)
+        mod = mod.cuda().eval()
+        p, g, r1, r2, r3 = li(case["seed"], B, N, G)
+        tp = torch.from_numpy(p).cuda().requires_grad_(True)
+        tg = torch.from_numpy(g).cuda().requires_grad_(True)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            po, mu, lv = mod(tp, tg, mode=case["mode"])
+        assert any(issubclass(w.category, EvalModeAutogradWarning) for w in caught), case["tag"]
+        ((po * torch.from_numpy(r1).cuda()).sum() + (lv * torch.from_numpy(r2).cuda()).sum() + (mu * torch.from_numpy(r3).cuda()).sum()).backward()
+        t = case["tag"]
+        for name, got in (("p_out", po), ("mu", mu), ("logvar", lv), ("grad_p", tp.grad), ("grad_g", tg.grad)):
+            assert rel(got, gold[t + "/" + name]) <= 2e-5, (t, name, rel(got, gold[t + "/" + name]))
+        # ... and the same call under no_grad takes the fused stack: no warning, the same outputs at the fused path's precision
+        with warnings.catch_warnings(record=True) as caught, torch.no_grad():
+            warnings.simplefilter("always")
+            po2, _, _ = mod(tp, tg, mode=case["mode"])
+        assert not any(issubclass(w.category, EvalModeAutogradWarning) for w in caught)
+        assert rel(po2, gold[t + "/p_out"]) <= REL["f16x3"]
+        seen += 1
+    assert seen == 12
+    # the decoder (the stack of layers) and the fused sampling entry point follow the same rule
+    dec = nets.LocalCondRNVPDecoder(1, 64, 128).cuda().eval()
+    pr = (torch.randn(2, 3, 64, device="cuda") * 0.3).requires_grad_(True)
+    gg = torch.randn(2, 128, device="cuda")
+    with pytest.warns(EvalModeAutogradWarning):
+        ps, mus, lvs = dec(pr, gg, mode="inverse")
+    ps[0].sum().backward()
+    assert pr.grad is not None and torch.isfinite(pr.grad).all()
+
+
 def test_pointflow_nll_fused_reduction():
     """PointFlowNLL (losses.py:11-15) on the fused stack's lists in evaluation: one pass over the cloud and the kernel's
     sum of log-variances with the base distribution's stride-0 expansions read in place (csrc/nll.hip), against the
