@@ -1,0 +1,88 @@
+"""Bit-stability soak of the matrix-core kernels OUTSIDE approx-EMD: r05 found run-to-run differing bits in the
+approx-EMD passes and could only say that the flow / Chamfer / encoder kernels "never flickered" in tens of repeats.  r06
+bisected the cause to the SLP vectoriser's packed fp32 code -- which the flow stack has been built without since
+r03 and every object since r06 -- and this test makes "never flickered" a number inside the driver's suite: 2 000 repeats of
+the headline evaluation step (fused 14-layer stack + nn_distance, configs[1]: 2 waves per SIMD in flow_kernel, 4 in nnm_kernel),
+600 of the rank-sized step (16-point tiles + the LDS-staged scan), 300 of the encoder and 120 of a training step (forward +
+backward, 315 dependent launches each), every output compared bit for bit with the first.  ~10 s of GPU time."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(ts):
+    return [t.view(torch.int32) if t.dtype == torch.float32 else t for t in ts]
+
+
+def _same(a, b):
+    return all(torch.equal(x, y) for x, y in zip(_bits(a), _bits(b)))
+
+
+def _nets():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from dpf_nets_amd import networks as nets
+    from dpf_nets_amd import synthetic as SY
+    from dpf_nets_amd.metrics.StructuralLosses import StructuralLossesBackend as BK
+    return nets, SY, BK
+
+
+@pytest.mark.parametrize("B,reps", [(32, 2000), (4, 600)])
+def test_eval_step_repeats_bit_for_bit(B, reps):
+    nets, SY, BK = _nets()
+    N, G, L = 2048, 128, 14
+    state = SY.make_decoder_state(0, 5, 64, G)
+    dec = nets.LocalCondRNVPDecoder(5, 64, G)
+    dec.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in state.items()}, strict=True)
+    dec = dec.cuda().eval()
+    tgt, z, g = SY.synthetic_inputs(0, B, N, G)
+    z, g = torch.from_numpy(z).cuda(), torch.from_numpy(g).cuda()
+    tgt_pm = torch.from_numpy(np.ascontiguousarray(tgt.transpose(0, 2, 1))).cuda()
+    stack = dec.stack()
+    first, bad = None, 0
+    with torch.no_grad():
+        for it in range(reps):
+            p_out, sum_lv, _, _, _ = stack.run(z, g, "direct", "f16x3", want_lists=False, n_layers=L, want_pointmajor=True)
+            d1, i1, d2, i2 = BK.NNDistance(stack.last_pointmajor, tgt_pm)
+            got = [p_out.clone(), sum_lv.clone(), d1, i1, d2, i2]
+            if first is None:
+                first = got
+            elif not _same(got, first):
+                bad += 1
+    assert bad == 0, "%d of %d repeats differ (B = %d)" % (bad, reps - 1, B)
+
+
+def test_encoder_and_training_step_repeat_bit_for_bit():
+    nets, SY, BK = _nets()
+    torch.manual_seed(1)
+    enc = nets.PointNetCloudEncoder(3, 64, [128, 256, 512]).cuda().eval()
+    x = torch.randn(32, 3, 2048, device="cuda")
+    first, bad = None, 0
+    with torch.no_grad():
+        for it in range(300):
+            out = enc(x)
+            got = [(out if torch.is_tensor(out) else out[0]).clone()]
+            if first is None:
+                first = got
+            elif not _same(got, first):
+                bad += 1
+    assert bad == 0, "encoder: %d of 299 repeats differ" % bad
+    torch.manual_seed(0)
+    dec = nets.LocalCondRNVPDecoder(21, 64, 128).cuda().train()
+    dec.flatten_parameters()
+    tgt, z, g = SY.synthetic_inputs(7, 8, 2048, 128)
+    tp, tg = torch.from_numpy(tgt).cuda(), torch.from_numpy(g).cuda()
+    first, bad = None, 0
+    for it in range(120):
+        dec.zero_grad(set_to_none=True)
+        tpi = tp.clone().requires_grad_(True)
+        ps, mus, lvs = dec(tpi, tg, mode="inverse")
+        (ps[0].square().mean() + sum(lvs).mean()).backward()
+        got = [ps[0].detach().clone(), tpi.grad.clone()] + [p.grad.clone() for p in dec.parameters() if p.grad is not None]
+        if first is None:
+            first = got
+        elif not _same(got, first):
+            bad += 1
+    assert bad == 0, "training step: %d of 119 repeats differ" % bad

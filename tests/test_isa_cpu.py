@@ -60,6 +60,17 @@ HOT_EVAL = "flow_kernelILi2ELi8ELi1ELb1ELb1ELb1E"          # NS = 2, 8 waves, LP
 HOT_TRAIN = ("tstats_h1_kernel", "tbwd1_kernel", "tbwd2_kernel")
 
 
+def test_makefile_compiles_every_object_without_the_slp_vectoriser():
+    """r06 (DESIGN 4.6): the vectoriser's packed fp32 code is what made the approx-EMD passes return run-to-run differing bits;
+    since r06 it is off for the whole library (FLAGS), not only for the flow stack (FLOWFLAGS, r03: speed)."""
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    flags = [ln for ln in mk.splitlines() if ln.startswith("FLAGS :=")]
+    assert len(flags) == 1 and "-fno-slp-vectorize" in flags[0], flags
+    for ln in mk.splitlines():                      # every compile line goes through $(FLAGS)
+        if "$(HIPCC)" in ln and " -c " in ln:
+            assert "$(FLAGS)" in ln, ln
+
+
 def test_makefile_compiles_the_flow_stack_without_the_slp_vectoriser():
     mk = open(os.path.join(CSRC, "Makefile")).read()
     for target in ("flow.o", "flow_train.o"):
