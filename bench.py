@@ -271,7 +271,11 @@ def rccl_log_excerpt(max_lines=24):
                 if keep.search(l):
                     out.append(l.strip()[-220:])
                     if len(out) >= max_lines:
-                        return out
+                        break
+            try:
+                os.remove(f)                   # (the excerpt is in the line; no per-rank logs left behind in /tmp)
+            except OSError:
+                pass
         return out or None
     except Exception as e:       # noqa: BLE001
         return ["(could not read the RCCL log: %r)" % (e,)]
@@ -1049,6 +1053,8 @@ def train_step_leg(args, rank, world, dist, device, batch, layers, steps, warmup
     nbytes = arena.nbytes()
     gstats = (ctypes.c_long * 5)()
     _lib_handle().dpf_train_graph_stats(gstats)          # of the timed region: read before the eager per-kernel pass below
+    _lib_handle().dpf_train_colsum_fallbacks.restype = ctypes.c_long
+    colsum_fallbacks = int(_lib_handle().dpf_train_colsum_fallbacks())   # (workgroups that gave up waiting for role workgroups)
     # ---- per-kernel durations of the decoder stack (outside the timed region): HIP events around every launch, eager
     kernels = None
     try:
@@ -1097,6 +1103,7 @@ def train_step_leg(args, rank, world, dist, device, batch, layers, steps, warmup
             "collectives_counted": bool(counted),
             "replay_equals_eager": bool(same), "replay_check": "first 6 optimizer steps, hipGraph replay vs eager launches, loss "
                                                                "bytes compared (%d calls of the check were replays)" % check_replays,
+            "colsum_fallbacks": colsum_fallbacks,
             "graph_replays": int(gstats[0]), "graph_stats": {"replays": int(gstats[0]), "eager_calls": int(gstats[1]),
                                                              "recordings": int(gstats[2]), "evictions": int(gstats[3]),
                                                              "uncapturable": int(gstats[4])},

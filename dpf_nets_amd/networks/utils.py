@@ -38,16 +38,30 @@ class ChamferEvaluator:
     package's own evaluation helpers (metrics.evaluation_metrics.EMD_CD, chamfer_cd_per_cloud) and bench.py's step go through
     this class; before, only the benchmark created a workspace."""
 
+    MAX_WORKSPACES = 8          # (ADVICE r05: a ragged last batch and every new shape used to add a buffer for good)
+
     def __init__(self):
-        self._ws = {}
+        import collections
+        import threading
+        self._ws = collections.OrderedDict()            # least recently used first
+        self._lock = threading.Lock()
 
     def __call__(self, pred, true):
         """(B, n, 3), (B, m, 3) contiguous CUDA tensors -> dist1, idx1, dist2, idx2, cd (B,)"""
         from ..metrics.StructuralLosses import StructuralLossesBackend as BK
-        key = (pred.shape[0], pred.shape[1], true.shape[1], pred.device, torch.cuda.current_stream(pred.device).cuda_stream)
-        ws = self._ws.get(key)
-        if ws is None and not torch.cuda.is_current_stream_capturing():
-            ws = self._ws[key] = BK.CDWorkspace(key[0], key[1], key[2], pred.device)
+        # keyed by the stream OBJECT (held alive by the key: its handle cannot be recycled for another stream while the
+        # workspace lives) and the calling thread (two threads on one stream would share tickets)
+        import threading
+        stream = torch.cuda.current_stream(pred.device)
+        key = (pred.shape[0], pred.shape[1], true.shape[1], pred.device, stream, threading.get_ident())
+        with self._lock:
+            ws = self._ws.get(key)
+            if ws is not None:
+                self._ws.move_to_end(key)
+            elif not torch.cuda.is_current_stream_capturing():
+                ws = self._ws[key] = BK.CDWorkspace(key[0], key[1], key[2], pred.device)
+                while len(self._ws) > self.MAX_WORKSPACES:
+                    self._ws.popitem(last=False)
         return BK.NNDistanceCD(pred, true, ws)        # (no workspace while capturing a first call: fresh scratch, tickets cleared in-call)
 
     def cd(self, pred, true):

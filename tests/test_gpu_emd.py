@@ -237,7 +237,7 @@ def test_emd_fuzz_all_kinds_vs_oracle():
     seen, worst = {}, {}
     for it in range(120):
         a, b, kind = emd_fuzz_case(rng)
-        if time.time() - t0 > 150 and all(seen.get(k, 0) >= 2 for k in ("uniform", "gauss", "jitter", "clustered", "offset", "line", "plane", "dup", "grid")):
+        if time.time() - t0 > 60 and all(seen.get(k, 0) >= 2 for k in ("uniform", "gauss", "jitter", "clustered", "offset", "line", "plane", "dup", "grid")):
             break
         seen[kind] = seen.get(kind, 0) + 1
         tag = (it, kind) + a.shape[:2] + b.shape[1:2]

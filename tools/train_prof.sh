@@ -6,7 +6,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python3 $GRAFT_REPO_ROOT/bench.py --leg train --steps 12 --warmup 4 > $OUT/kt.log 2>&1
 for db in $(find $OUT/kt -name "*.db"); do
-  { echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --leg train --steps 12 --warmup 4   (28 optimizer steps in all: 12 of the replay-vs-eager check, 4 + 12 of the leg; + 3 eager steps of the per-kernel event timing)"; python3 $GRAFT_REPO_ROOT/tools/rocprof_summary.py $db; } > $OUT/train_kernel_trace.txt 2>&1
+  { echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --leg train --steps 12 --warmup 4   (28 optimizer steps in all: 12 of the replay-vs-eager check, 4 + 12 of the leg; + 3 eager steps of the per-kernel event timing)"; echo "# the ~10 000 __amd_rocclr_copyBuffer calls below are NOT part of a training step: they are the replay-vs-eager check's saves and restores of the model / optimizer state (bench.py::replay_equals_eager, 12 steps x 2 runs), identical in count since r03"; python3 $GRAFT_REPO_ROOT/tools/rocprof_summary.py $db; } > $OUT/train_kernel_trace.txt 2>&1
 done
 rm -rf $OUT/kt
 cd $GRAFT_REPO_ROOT
