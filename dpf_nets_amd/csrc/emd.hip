@@ -1051,6 +1051,16 @@ struct LevelScales { LevelFac lf[NLEVEL]; };
 // Measured (cfg5, 16 x 8192^2): 1.18 ms = `match` written at 3.6 TB/s; MTM = 4 (512 contiguous bytes per row and wave) and the
 // unmasked store path moved it by < 10 %: it is the write that bounds it, not the instruction count.
 constexpr int MTM = 2;
+#ifndef EMD_NT_STORE
+#define EMD_NT_STORE 1
+#endif
+#if EMD_NT_STORE
+// `match` (4 n m bytes: 4.3 GB at cfg5) is written once and not read again by the call: a streaming store.  r06, measured at cfg5
+// (B = 16, N = 8192): emd_mfma_materialize_kernel 1.31 -> 0.82 ms, the approxmatch + cost call 2.73 -> 2.24 ms
+#define EMD_MATCH_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#else
+#define EMD_MATCH_STORE(v, p) (*(p) = (v))
+#endif
 template <bool COST>
 // (no __restrict__ on what the loop loads: a load from memory the compiler knows nobody writes may cross the asm barriers that
 // keep loads and MFMAs apart -- loads_stay_behind / mfmas_stay_behind -- and r06's first build sank the last ratioR load of a
@@ -1158,7 +1168,7 @@ __global__ __launch_bounds__(64 * MSL) void emd_mfma_materialize_kernel(MfmaStat
                     for (int t = 0; t < MTM; ++t) {
                         const float v = mm[t][4 * i + jj];
                         const bool live = FULL || (l >= 0 && kk[t] < st.n);
-                        if (live) row[32 * t] = v;
+                        if (live) EMD_MATCH_STORE(v, &row[32 * t]);
                         // the distance only where some entry of the wave's 2 x 32 is worth it: almost every pair's weight is below
                         // 1e-12 of a matched pair's (what is skipped sums to < 1e-6 of the cost)
                         if (COST && __ballot(live && v > 1e-12f) != 0ull) {
@@ -1274,8 +1284,8 @@ __global__ __launch_bounds__(1024) void emd_materialize2_kernel(int n, int m, Le
         const f2 d2 = sqdist2(px, py, pz, r[0], r[1]);
         const f2 acc = level_sum<NLEVEL - 1>(lv, r, rl, d2);
         float *row = mt + (size_t)l * n;
-        if (k0 < n) row[k0] = acc.x;
-        if (k1 < n) row[k1] = acc.y;
+        if (k0 < n) EMD_MATCH_STORE(acc.x, &row[k0]);
+        if (k1 < n) EMD_MATCH_STORE(acc.y, &row[k1]);
         if (COST) cost = fma2(acc, f2{__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)}, cost);
     });
     if (COST) {
