@@ -832,7 +832,7 @@ def leg_cfg5(args, rank, world, dist, device):
             "counter_bytes_over_algorithmic": (traffic / must_write) if traffic else None,
             "note": "algorithmic bytes = 4*n*m per cloud: `match` written once (the reference's own RMW form would move 80*n*m, "
                     "SURVEY 8d); achieved = those bytes / the whole approxmatch+cost call.  The materialisation kernel alone "
-                    "writes them at ~3.6 TB/s (profiles/r05_emd_kernel_trace.txt); the level passes before it are bound by "
+                    "streams them out at ~5.1 TB/s (nontemporal stores; profiles/r06_emd_kernel_trace.txt); the level passes before it are bound by "
                     "v_exp_f32 issue on the live pairs",
             "reference_equivalent_exp": {"per_pair": 36, "Gexp_per_s": ach / 1e9, "issue_peak_Gexp_per_s": exp_peak / 1e9,
                                          "note": "36 exp per pair is what the reference's 27 dense passes + materialisation "
@@ -1087,7 +1087,7 @@ def train_step_leg(args, rank, world, dist, device, batch, layers, steps, warmup
         kernels["sum_us_per_layer"] = per_layer
         kernels["note"] = ("HIP events around every launch of the stack's kernels, %d eager steps (dpf_train_kernel_times): event to "
                            "event, i.e. kernel duration + the ~1.5 us launch gap of an eager launch -- the rocprofv3 kernel durations of "
-                           "the same command are in profiles/r05_train_kernel_trace.txt; gflop = "
+                           "the same command are in profiles/r06_train_kernel_trace.txt; gflop = "
                            "what the kernel executes per launch incl. the recomputation of the conditioner; tfold / tcolsum / "
                            "tstats_x / tbwd3f are reductions (latency-bound, no matrix work)" % ksteps)
     except Exception as e:       # noqa: BLE001
