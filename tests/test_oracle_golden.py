@@ -210,6 +210,51 @@ def test_emd_oracle_invariants():
     assert (np.diagonal(match, axis1=1, axis2=2) > 0.9).all()
 
 
+def test_emd_oracle_vs_an_independent_float64_reading():
+    """approx-EMD parity stays UNPINNED by the reference (no CPU path, no vectors: a11-a14 are "partial" for that reason).  What
+    CAN be excluded here is a slip in the restatement: a SECOND reading of approxmatch.cu:3-182, written from the source on its
+    own -- whole passes as float64 matrix expressions instead of the C oracle's loops -- must give the C oracle's matching.
+      level = -4^j, j = 7 .. -1                                                              approxmatch.cu:24-28
+      pass 1  ratioL[k] = remainL[k] / (1e-9 + sum_l exp(level d2) remainR[l])               :29-62
+      pass 2  sumr = remainR[l] sum_k exp(level d2) ratioL[k];  ratioR[l] = min(remainR[l] / (sumr + 1e-9), 1) remainR[l];
+              remainR[l] = max(0, remainR[l] - sumr)                                         :78-111
+      pass 3  w = exp(level d2) ratioL[k] ratioR[l];  match[l][k] += w;  remainL[k] = max(0, remainL[k] - sum_l w)   :130-163
+    with multiL, multiR = (1, n // m) if n >= m else (m // n, 1)                              :6-12"""
+    def reading(a, b):
+        n, m = len(a), len(b)
+        d2 = ((b[:, None, :].astype(np.float64) - a[None, :, :].astype(np.float64)) ** 2).sum(2)        # (m, n)
+        remL = np.full(n, 1.0 if n >= m else float(m // n))
+        remR = np.full(m, float(n // m) if n >= m else 1.0)
+        match = np.zeros((m, n))
+        for j in range(7, -2, -1):
+            e = np.exp(-(4.0 ** j) * d2)
+            ratioL = remL / (1e-9 + remR @ e)
+            sumr = (e @ ratioL) * remR
+            ratioR = np.minimum(remR / (sumr + 1e-9), 1.0) * remR
+            remR = np.maximum(0.0, remR - sumr)
+            w = e * ratioR[:, None] * ratioL[None, :]
+            match += w
+            remL = np.maximum(0.0, remL - w.sum(0))
+        return match
+    rng = np.random.default_rng(8)
+    for (n, m, kind) in ((64, 64, "uniform"), (128, 64, "uniform"), (48, 96, "uniform"), (200, 77, "line"), (90, 90, "jitter")):
+        a = (rng.random((n, 3)) - 0.5).astype(np.float32)
+        b = (rng.random((m, 3)) - 0.5).astype(np.float32)
+        if kind == "line":
+            a[:, 1:] = 0; b[:, 1:] = 0
+        if kind == "jitter":
+            b = (a[rng.permutation(n)[:m]] + 0.02 * rng.standard_normal((m, 3))).astype(np.float32)
+        got, _ = S.approxmatch(a[None], b[None])
+        ref = reading(a, b)
+        # the C oracle is the CUDA code's fp32; the second reading is float64: the auction amplifies the difference at its clamps
+        np.testing.assert_allclose(got[0].sum(0), ref.sum(0), rtol=2e-3, atol=2e-4, err_msg=kind)
+        np.testing.assert_allclose(got[0].sum(1), ref.sum(1), rtol=2e-3, atol=2e-4, err_msg=kind)
+        assert float(np.abs(got[0] - ref).max()) <= 5e-3, (kind, float(np.abs(got[0] - ref).max()))
+        dist = np.sqrt(((b[:, None, :].astype(np.float64) - a[None, :, :]) ** 2).sum(2))
+        c_ref = float((ref * dist).sum())
+        np.testing.assert_allclose(S.matchcost(a[None], b[None], got)[0], c_ref, rtol=2e-5, err_msg=kind)
+
+
 def test_encoder_oracle_vs_reference_golden(golden_dir):
     """oracle/encoder_oracle.py against PointNetCloudEncoder + torch.max captured from the reference
     (encoders.py:9-28, models.py:85): eval and train mode outputs, running statistics, d/dx and every parameter
