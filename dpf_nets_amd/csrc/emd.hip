@@ -524,7 +524,7 @@ struct MfmaState {
     u4 *recA2[2];           // [nb][MP] A records of cloud 2's live points
     int *idx2[2];           //          their original indices
     float *remainR_c[2];    //          their remainR
-    float *ratioR_c;        // [nb][MP] their ratioR of the current level
+    float *ratioR_c;        // [nb][MP] their remainR - ratioR of the current level (pass 3's row weights; r05: ratioR)
     float *ratioL_p;        // [nb][NP] cloud 1's ratioL of the current level
     int *count;             // [nb] length of the current list
     int *counts;            // [NLEVEL][nb] length of every level's list
@@ -749,7 +749,7 @@ __device__ __forceinline__ void loads_stay_behind(float (&v)[N]) {
 
 // Passes over cloud 1's points (columns; cloud 2's LIVE points stream past as row tiles with their weights):
 // MODE 0: pass 1          s_k = sum_l w remainR[l];                     ratioL[k] = remainL[k] / (1e-9 + s_k)
-// MODE 3: pass 3          s_k = sum_l w ratioR[l];                      remainL[k] = max(0, remainL[k] - ratioL[k] s_k)
+// MODE 3: pass 3          s_k = sum_l w (remainR[l] - ratioR[l]);       remainL[k] = max(0, ratioL[k] (1e-9 + s_k))   [= remainL - ratioL sum w ratioR]
 // lf: level j's 4^(j-7) as the per-slot factors of level_vectors.  rb_cur: the ratio slot of level j.
 template <int MODE>
 __global__ __launch_bounds__(64 * MSL) void emd_mfma_cols_kernel(MfmaState st, int cur, LevelFac lf, float *rb_cur) {
@@ -824,7 +824,18 @@ __global__ __launch_bounds__(64 * MSL) void emd_mfma_cols_kernel(MfmaState st, i
             ratioL[k] = r;
             st.ratioL_p[(size_t)bi * st.NP + k] = r;
         } else {
-            remainL[k] = fmaxf(0.0f, remainL[k] - ratioL[k] * tot);
+            // remainL - ratioL sum_l w ratioR  with  ratioL = remainL / (1e-9 + s),  s = pass 1's sum_l w remainR
+            //   = ratioL (1e-9 + sum_l w (remainR[l] - ratioR[l])).
+            // r06: the second form -- pass 3's row weights are the DEFICITS remainR - ratioR that pass 2 leaves (an exact fp32
+            // subtraction of two numbers within a factor of two; 0 for every row the level consumes), so the sum has no negative
+            // term and what is left of a consumed point is remainL 1e-9 / (1e-9 + s) as in exact arithmetic.  The first form
+            // cancels two sums of size s and leaves +-1e-7 remainL of rounding noise, which the next level divides by ITS
+            // (possibly 1e-9-sized) sum: measured on 32 x 32 and 33 x 33 cases of tests/diag/emd_matrix_fuzz.py -- ratioL of a
+            // consumed point 45-120 x off, cost 2-5e-5 off the oracle on exponents that a float64 auction turns into the
+            // oracle's cost to 4e-9 (tests/diag/emd_case_levels.py, emd_fuzz_case_vs_oracle.py).  The reference's loop
+            // (approxmatch.cu:130-163) has that noise with its own realisation (the fp32 oracle sits 1e-8 .. 4e-6 from the
+            // float64 auction); the packed-VALU family reproduces the reference's operations bit for bit.
+            remainL[k] = fmaxf(0.0f, ratioL[k] * (1e-9f + tot));
         }
     }
 }
@@ -948,7 +959,7 @@ __global__ __launch_bounds__(64 * MSL) void emd_mfma_rows_kernel(MfmaState st, i
         const float consumption = fminf(rr / (sumr + 1e-9f), 1.0f);
         const float r = consumption * rr, rem = fmaxf(0.0f, rr - sumr);
         ratioR[l] = r;
-        st.ratioR_c[at] = r;
+        st.ratioR_c[at] = rr - r;                  // pass 3's weight: the deficit (cols kernel, MODE 3)
         remainR[l] = rem;
         st.remainR_c[cur][at] = rem;
     }
