@@ -8,23 +8,30 @@ from dpf_nets_amd._lib import lib
 from dpf_nets_amd.metrics.StructuralLosses import StructuralLossesBackend as BK
 from oracle import structural as S
 seed, index = int(sys.argv[1]), int(sys.argv[2])
-rng = np.random.default_rng(seed)
-for it in range(index + 1):
-    B = int(rng.integers(1, 5))
-    n = int(rng.choice([1, 3, 31, 32, 33, 64, 100, 127, 128, 129, 255, 300, 500, 777, 1024, 1500, 2048, 3000]))
-    m = int(rng.choice([1, 2, 32, 33, 63, 96, 128, 130, 257, 400, 512, 900, 1024, 2048, 2500]))
-    kind = rng.choice(["uniform", "gauss", "jitter", "clustered", "offset", "line"])
-    a = rng.random((B, n, 3), dtype=np.float32) - 0.5
-    if kind == "gauss": a = (0.2 * rng.standard_normal((B, n, 3))).astype(np.float32)
-    if kind == "clustered": a = (a * 0.05 + rng.integers(0, 3, (B, n, 1)) * 0.3).astype(np.float32)
-    if kind == "line": a[:, :, 1:] = 0
-    if kind == "jitter":
-        idx = rng.integers(0, n, m)
-        b = (a[:, idx] + 0.02 * rng.standard_normal((B, m, 3))).astype(np.float32)
-    else:
-        b = (rng.random((B, m, 3), dtype=np.float32) - 0.5) if kind != "gauss" else (0.2 * rng.standard_normal((B, m, 3))).astype(np.float32)
-        if kind == "line": b[:, :, 1:] = 0
-    if kind == "offset": a, b = a + 5.0, b + 5.0
+if os.environ.get("EMD_CASE_GENERATOR") == "suite":      # tests/test_gpu_emd.py::emd_fuzz_case (tools/emd_oracle_fuzz.py's cases)
+    from tests.test_gpu_emd import emd_fuzz_case
+    rng = np.random.default_rng(seed)
+    for it in range(index + 1):
+        a, b, kind = emd_fuzz_case(rng)
+    B, n, m = a.shape[0], a.shape[1], b.shape[1]
+else:
+    rng = np.random.default_rng(seed)
+    for it in range(index + 1):
+        B = int(rng.integers(1, 5))
+        n = int(rng.choice([1, 3, 31, 32, 33, 64, 100, 127, 128, 129, 255, 300, 500, 777, 1024, 1500, 2048, 3000]))
+        m = int(rng.choice([1, 2, 32, 33, 63, 96, 128, 130, 257, 400, 512, 900, 1024, 2048, 2500]))
+        kind = rng.choice(["uniform", "gauss", "jitter", "clustered", "offset", "line"])
+        a = rng.random((B, n, 3), dtype=np.float32) - 0.5
+        if kind == "gauss": a = (0.2 * rng.standard_normal((B, n, 3))).astype(np.float32)
+        if kind == "clustered": a = (a * 0.05 + rng.integers(0, 3, (B, n, 1)) * 0.3).astype(np.float32)
+        if kind == "line": a[:, :, 1:] = 0
+        if kind == "jitter":
+            idx = rng.integers(0, n, m)
+            b = (a[:, idx] + 0.02 * rng.standard_normal((B, m, 3))).astype(np.float32)
+        else:
+            b = (rng.random((B, m, 3), dtype=np.float32) - 0.5) if kind != "gauss" else (0.2 * rng.standard_normal((B, m, 3))).astype(np.float32)
+            if kind == "line": b[:, :, 1:] = 0
+        if kind == "offset": a, b = a + 5.0, b + 5.0
 print("case", index, B, n, m, kind)
 a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
 ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()

@@ -200,6 +200,27 @@ def collinear_case():
     return np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
 
 
+def _auction64(a1, b1):
+    """approxmatch.cu:3-182 + matchcost in float64 (whole passes as matrix expressions; tests/test_oracle_golden.py holds the C
+    oracle to this reading): exact arithmetic for practical purposes -- what the fp32 oracle is compared with to tell how well
+    conditioned an input is."""
+    n, m = len(a1), len(b1)
+    d2 = ((b1[:, None, :].astype(np.float64) - a1[None, :, :].astype(np.float64)) ** 2).sum(2)
+    remL = np.full(n, 1.0 if n >= m else float(m // n))
+    remR = np.full(m, float(n // m) if n >= m else 1.0)
+    match = np.zeros((m, n))
+    for j in range(7, -2, -1):
+        e = np.exp(-(4.0 ** j) * d2)
+        ratioL = remL / (1e-9 + remR @ e)
+        sumr = (e @ ratioL) * remR
+        ratioR = np.minimum(remR / (sumr + 1e-9), 1.0) * remR
+        remR = np.maximum(0.0, remR - sumr)
+        w = e * ratioR[:, None] * ratioL[None, :]
+        match += w
+        remL = np.maximum(0.0, remL - w.sum(0))
+    return float((match * np.sqrt(d2)).sum())
+
+
 def _oracle_bars(BK, a, b, tag):
     """The contract of the module header against the CPU oracle: cost rtol 1e-4, row / column mass 1e-3, finite, repeatable."""
     ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
@@ -211,10 +232,21 @@ def _oracle_bars(BK, a, b, tag):
     rmatch, _ = S.approxmatch(a, b)
     rcost = S.matchcost(a, b, rmatch)
     gm = match.cpu().numpy()
-    np.testing.assert_allclose(cost.cpu().numpy(), rcost, rtol=1e-4, atol=1e-6, err_msg=repr(tag))
+    got = cost.cpu().numpy()
+    err = np.abs(got - rcost) / np.maximum(np.abs(rcost), 1e-6)
+    if (err > 1e-4).any():
+        # Only where the comparison measures parity: the auction divides by (1e-9 + a sum of weights), and fp32 cannot resolve
+        # `remain - consumed` of a size-1 quantity to 1e-9 -- on clouds where some point's neighbours have all been consumed
+        # (exact duplicates, near-duplicates) EVERY fp32 evaluation returns its own rounding noise amplified: the fp32 oracle sits
+        # up to 4e-4 from the same auction in float64 there and both kernel families up to 5e-4 from the oracle
+        # (tools/emd_oracle_fuzz.py, profiles/r06_emd_oracle_fuzz_800.txt: 11 of 1 604 clouds).  The oracle's own distance
+        # from exact arithmetic is the measure of that; a cloud further than 1e-5 gets 1e-4 + 4 x that distance.
+        for i in np.nonzero(err > 1e-4)[0]:
+            cond = abs(float(rcost[i]) - _auction64(a[i], b[i])) / max(abs(float(rcost[i])), 1e-6)
+            assert cond > 1e-5 and err[i] <= 1e-4 + 4.0 * cond, (tag, int(i), float(err[i]), cond)
     np.testing.assert_allclose(gm.sum(1), rmatch.sum(1), rtol=1e-3, atol=1e-3, err_msg=repr(tag))
     np.testing.assert_allclose(gm.sum(2), rmatch.sum(2), rtol=1e-3, atol=1e-3, err_msg=repr(tag))
-    return float(np.max(np.abs(cost.cpu().numpy() - rcost) / np.maximum(np.abs(rcost), 1e-6)))
+    return float(err.max())
 
 
 def test_collinear_clouds_vs_oracle():
