@@ -202,6 +202,55 @@ def test_training_hip_vs_tensor_op_path(B, N, mode, prec):
     nets = _gpu()
     if prec == "bf16x3" and B == 33:
         pytest.skip("2 112 points: the cancelling bias sums (|sum| ~ 1e-3 of the magnitudes) sit below bf16x3's 1e-5 per-term error")
+    _hip_vs_tensor_ops(nets, B, N, mode, prec, 31)
+
+
+def test_training_gradient_errors_over_seeds_are_the_fp32_tensor_ops_own(monkeypatch):
+    """the ReLU-flip floors of the test above (KINK_SUM / P, KINK_CLOUD / N, bias_floor) were re-derived in r05 from what ONE
+    seed drew.  What they stand for is a mechanism, and this test holds the mechanism instead of a constant: training-mode BatchNorm
+    couples all P points, ~10 pre-activations per pass sit within the forward error of zero at ANY seed, and a ReLU that falls the
+    other way than in float64 moves a row of d loss / d g by O(1 / N) and a parameter gradient by O(1 / P) of its scale -- on ANY fp32
+    evaluation, the reference's own tensor ops included (tests/diag/gg_seeds.py, 24 seeds at this shape: d/dg error x N up to 4.9
+    for the HIP stack and up to 6.3 for the fp32 tensor ops; parameter gradients x P up to 476 and 506).  Over eight seeds of weights
+    and inputs at (8, 2048, direct), default precision, both paths against float64: the HIP stack's MEDIAN errors are within 2 x the
+    fp32 tensor ops' and its WORST within 1.5 x (d/dg) / 5 x (parameters: eight draws of a heavy tail -- seed 33 puts 205 / P on one
+    FiLM-net weight of the HIP stack, seed 35 74 / P on the tensor ops'; over 24 seeds both reach ~500 / P unfloored,
+    profiles/r06_gg_seeds.txt).  The two paths draw different ReLUs, so the comparison is of distributions, not per seed."""
+    nets = _gpu()
+    from dpf_nets_amd.networks import train_engine
+    monkeypatch.setattr(train_engine, "TRAIN_PRECISION", "f16x3")
+    B, N, mode, n_flows, G = 8, 2048, "direct", 2, 128
+    rows = []
+    for seed in range(32, 40):
+        sd = FO.to_torch(FO.make_decoder_state(seed, n_flows, 64, G))
+        tgt, z, g = FO.synthetic_inputs(seed, B, N, G)
+        res = {}
+        for impl in ("hip", "torch", "torch64"):
+            dec = nets.LocalCondRNVPDecoder(n_flows, 64, G, weight_std=0.01)
+            dec.load_state_dict(sd, strict=True)
+            dec = dec.cuda().train()
+            tp, tg = torch.from_numpy(z.copy()).cuda(), torch.from_numpy(g.copy()).cuda()
+            if impl == "torch64":
+                dec, tp, tg = dec.double(), tp.double(), tg.double()
+            tp.requires_grad_(True)
+            tg.requires_grad_(True)
+            ps, mus, lvs = dec(tp, tg, mode=mode) if impl == "hip" else dec.forward_torch(tp, tg, mode=mode)
+            pm, pl = torch.zeros(B, 3, N).cuda().to(tp.dtype), torch.full((B, 3, N), -3.6).cuda().to(tp.dtype)
+            (nets.PointFlowNLL()([tp] + ps, [pm] + mus, [pl] + lvs) + 0.1 * (ps[2] * mus[4]).mean()).backward()
+            res[impl] = dict(gg=tg.grad, grads={k: v.grad for k, v in dec.named_parameters() if v.grad is not None})
+        h, t, t32 = res["hip"], res["torch64"], res["torch"]
+        rows.append((rel(h["gg"], t["gg"]) * N, rel(t32["gg"], t["gg"]) * N,
+                     max(rel(h["grads"][k], t["grads"][k], bias_floor(t["grads"], k)) for k in t["grads"]) * B * N,
+                     max(rel(t32["grads"][k], t["grads"][k], bias_floor(t["grads"], k)) for k in t["grads"]) * B * N))
+    a = np.array(rows)
+    print("d/dg error x N (hip, fp32 tensor ops), parameter gradient error x P (hip, fp32): max", a.max(0), "median", np.median(a, 0))
+    assert a[:, 0].max() <= 1.5 * a[:, 1].max() + 0.5, a[:, :2]
+    assert np.median(a[:, 0]) <= 2.0 * np.median(a[:, 1]) + 0.25, a[:, :2]
+    assert a[:, 2].max() <= 5.0 * a[:, 3].max() + 8.0, a[:, 2:]
+    assert np.median(a[:, 2]) <= 2.0 * np.median(a[:, 3]) + 8.0, a[:, 2:]
+
+
+def _hip_vs_tensor_ops(nets, B, N, mode, prec, seed):
     kf, loose = (5e-4, 1.0) if prec in ("bf16x6", "f16x3") else (1e-2, 10.0)
     STACK_OUT_REL, STACK_GRAD_REL = STACK_TOL[prec]
     # (r05, ADVICE r04: the floors are capped -- at (2, 40) they had grown to 5e-2 / 0.4 and checked nothing; what the tiny and
@@ -209,7 +258,7 @@ def test_training_hip_vs_tensor_op_path(B, N, mode, prec):
     # sees the same ReLU masks)
     STACK_GRAD_REL = max(STACK_GRAD_REL, min(KINK / (B * N), KINK_CAP))
     PARAM_REL = max(2 * loose * STACK_TOL[prec][1], min(KINK_SUM / (B * N), KINK_SUM_CAP))
-    n_flows, G, seed = 2, 128, 31
+    n_flows, G = 2, 128
     sd = FO.to_torch(FO.make_decoder_state(seed, n_flows, 64, G))
     tgt, z, g = FO.synthetic_inputs(seed, B, N, G)
     src = tgt if mode == "inverse" else z
