@@ -147,6 +147,7 @@ class Watchdog:
         import threading
         self.rank, self.seconds, self.stage, self.t, self.beats = rank, seconds, "start", time.monotonic(), 0
         self.lib_handle = None
+        self.measured = None      # rank 0's headline line once its leg is done: a stall in an `extra` must not lose it
         if seconds > 0:
             threading.Thread(target=self._watch, name="bench-watchdog", daemon=True).start()
 
@@ -160,6 +161,12 @@ class Watchdog:
         w = cls._one
         if w is not None:
             w.stage, w.t, w.beats = stage, time.monotonic(), w.beats + 1
+
+    @classmethod
+    def keep(cls, line):
+        """rank 0: the line measured so far (None once main() has printed it itself)."""
+        if cls._one is not None:
+            cls._one.measured = line
 
     def _watch(self):
         while True:
@@ -180,6 +187,13 @@ class Watchdog:
                     dump["counters_error"] = repr(e)
                 sys.stderr.write(json.dumps(dump) + "\n")
                 sys.stderr.flush()
+                line, self.measured = self.measured, None
+                if line is not None:       # the headline was measured before the stall: print it, marked, and still exit 86
+                    line = dict(line)
+                    line["extra"] = dict(line.get("extra") or {}, watchdog=dump,
+                                         note="the job stalled in an extra leg AFTER this line's timed region; the later extras are lost")
+                    sys.stdout.write(json.dumps(line) + "\n")
+                    sys.stdout.flush()
                 os._exit(86)
 
 
@@ -1261,8 +1275,13 @@ def selftest_ranks(args, rank, world, dist):
         dist.all_reduce(flat)
         dist.barrier()
     if rank == 0:
-        print(json.dumps({"selftest": True, "n_gpus": world, "max_rank_plus_1": float(t.item()),
-                          "flat_sum_ok": bool(torch.equal(flat, torch.arange(8, dtype=torch.float32) * (world * (world + 1) / 2)))}))
+        line = {"selftest": True, "n_gpus": world, "max_rank_plus_1": float(t.item()),
+                "flat_sum_ok": bool(torch.equal(flat, torch.arange(8, dtype=torch.float32) * (world * (world + 1) / 2)))}
+        if os.environ.get("DPF_BENCH_SELFTEST_STALL_AFTER_LINE") == "1":      # (the watchdog's own test: an `extra` that never returns)
+            Watchdog.keep(line)
+            Watchdog.beat("selftest: an extra leg behind the measured line")
+            time.sleep(3600)
+        print(json.dumps(line))
 
 
 def main(argv=None):
@@ -1291,6 +1310,8 @@ def main(argv=None):
         line, extra = leg_cfg5(args, rank, world, dist, device)
     else:
         line, extra = leg_eval(args, rank, world, dist, device)
+        if rank == 0:
+            Watchdog.keep(dict(line, extra=dict(extra)))      # (a stall in one of the extras below prints this, see Watchdog._watch)
         if not args.no_extra and args.config == "cfg2" and args.layers == 14 and not args.no_configs:
             try:
                 Watchdog.beat("extra: the other configs")
@@ -1313,6 +1334,7 @@ def main(argv=None):
             except Exception as e:       # noqa: BLE001
                 extra["per_rank_proxy_error"] = repr(e)
     if rank == 0:
+        Watchdog.keep(None)
         if extra:
             line["extra"] = extra
         print(json.dumps(line))

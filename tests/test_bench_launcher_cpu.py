@@ -71,3 +71,15 @@ def test_config_defaults():
     assert (a.points, a.steps) == (8192, 10)
     a = bench.parse(["--leg", "train"])
     assert a.layers == 63
+
+
+def test_a_stall_behind_the_measured_line_does_not_lose_it():
+    """The headline is measured before the extra legs: a rank 0 that stalls in one of them still prints its line (marked, with
+    the watchdog's dump inside) and the job still ends with the watchdog's status."""
+    r = _run(["--gpus", "1"], {"DPF_BENCH_SELFTEST": "1", "DPF_BENCH_BACKEND": "gloo", "DPF_BENCH_SELFTEST_STALL_AFTER_LINE": "1",
+                               "DPF_BENCH_WATCHDOG_S": "3"})
+    assert r.returncode == 86, (r.returncode, r.stderr[-1500:])
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and lines[0]["selftest"] and lines[0]["n_gpus"] == 1
+    wd = lines[0]["extra"]["watchdog"]
+    assert wd["rank"] == 0 and "behind the measured line" in wd["last_stage"] and "stalled" in lines[0]["extra"]["note"]
