@@ -431,8 +431,11 @@ def test_training_kernel_forms_agree(tmp_path):
         res[name] = dict(np.load(f))
     base = res["default"]
     for name, got in res.items():
-        # the role workgroups were dispatched in front of the workgroups that wait for them: nobody gave up polling
-        assert int(got["fallbacks"][0]) == 0, (name, int(got["fallbacks"][0]))
+        # the role workgroups were dispatched in front of the workgroups that wait for them: nobody gave up polling.  A workgroup
+        # that does give up produces the same bits itself (the comparisons below hold either way): on a GPU this process has to
+        # itself the count is 0 -- a handful is tolerated so that a time-sliced box cannot fail a performance assumption as a
+        # parity failure; thousands would mean the dispatch-order assumption is gone
+        assert int(got["fallbacks"][0]) <= 16, (name, int(got["fallbacks"][0]))
         assert set(got) == set(base), name
         for k in base:
             if k == "fallbacks":
