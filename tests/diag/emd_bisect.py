@@ -1,6 +1,6 @@
 """Diagnostic: which launch of the matrix-core approx-EMD family first leaves different bytes behind on two runs of the same input?
 DPF_EMD_STOP_AFTER=k makes dpf_approxmatch_ws return behind the family's k-th launch (csrc/emd.hip); for k = 1, 2, ... the call runs
-R times on freshly zeroed buffers and the whole workspace and `temp` are compared byte for byte.   emd_bisect.py B n m seed [R]"""
+R times on freshly zeroed buffers and the whole workspace and `temp` are compared byte for byte.   emd_bisect.py B n m seed [R [K0 [K1]]]"""
 import os, sys
 import numpy as np, torch
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,6 +11,7 @@ L = lib()
 B, n, m, seed = (int(v) for v in sys.argv[1:5])
 R = int(sys.argv[5]) if len(sys.argv) > 5 else 6
 K0 = int(sys.argv[6]) if len(sys.argv) > 6 else 1        # start at launch K0 (and do not stop at the first difference if given)
+K1 = int(sys.argv[7]) if len(sys.argv) > 7 else None     # ... and end behind launch K1
 A, Bc = chamfer_inputs(seed, B, n, m)
 tA, tB = torch.from_numpy(A).cuda(), torch.from_numpy(Bc).cuda()
 nb = L.dpf_approxmatch_workspace_bytes(B, n, m)
@@ -20,7 +21,7 @@ names = ["pack"]
 for j in range(7, -2, -1):
     names += ["L%d pass1" % j, "L%d pass2 (4 tiles)" % j] + (["L%d pass2 (1 tile)" % j] if j < 7 else []) + ["L%d pass3" % j, "L%d compact" % j]
 names += ["gather", "materialise"]
-for k in range(K0, len(names) + 1):
+for k in range(K0, (K1 if K1 is not None else len(names)) + 1):
     os.environ["DPF_EMD_STOP_AFTER"] = str(k)
     snaps = []
     for r in range(R):

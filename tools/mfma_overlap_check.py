@@ -11,7 +11,14 @@ identical to source C is the normal accumulate form and is not reported.
     --no-scratch PREFIX    also fail if a kernel whose name contains PREFIX touches scratch memory (a spilled build of the
                            approx-EMD passes flickered too)
     --no-packed-f32 PREFIX r06: also fail if a kernel whose name contains PREFIX holds v_pk_{fma,mul,add}_f32 (the SLP vectoriser's
-                           packed consumers of v_exp_f32 results: the root cause of r05's run-to-run differences)
+                           packed accumulations: see the next option; the approx-EMD passes keep none at all)
+    --no-packed-before-mfma
+                           r06, the instruction pair tools/asm_bisect found behind r05's / r06's run-to-run differing bits (DESIGN
+                           4.6): a packed fp32 VALU instruction whose NEXT instruction is an MFMA -- in emd_mfma_cols_kernel<0> of
+                           the vectorised build, "v_pk_fma_f32 v[132:133], ...; v_mfma_f32_32x32x16_f16 v[34:49], ..." lost the
+                           packed result in about half of the launches; one s_nop 0, any instruction between the two, or the
+                           two v_fma_f32 the packed one stands for made 48 of 48 launches repeat.  Fails on every such pair in
+                           ANY kernel of the file (csrc/Makefile runs it on every object)
     --war                  r06: also report a VMEM / LDS / scratch LOAD whose destination registers are the A or B source of an
                            MFMA that was issued before it and whose result nothing has read yet (the MFMA may still be queued in
                            the matrix pipe).  An INVENTORY, not a defect list: tools/ubench/mfma_war.hip / mfma_valu_war.hip
@@ -37,6 +44,26 @@ def regs(tok):
 
 def overlaps(a, b):
     return a is not None and b is not None and a[0] == b[0] and a[1] <= b[2] and b[1] <= a[2]
+
+
+PACKED_F32 = re.compile(r"^v_pk_(fma|mul|add)_f32\b")
+
+
+def scan_packed_before_mfma(path):
+    """[(kernel, packed line, mfma line)]: packed fp32 VALU instructions directly followed by an MFMA"""
+    out, kernel, prev = [], None, None
+    for line in open(path):
+        m = re.match(r"^(\S+):\s", line)
+        if m and not m.group(1).startswith("."):
+            kernel, prev = m.group(1), None
+            continue
+        body = line.split(";")[0].strip()
+        if not body or body.startswith((".", "//")) or body.endswith(":"):
+            continue
+        if re.match(r"(v_mfma_|v_smfmac_)", body) and prev is not None and PACKED_F32.match(prev):
+            out.append((kernel, prev, body))
+        prev = body
+    return out
 
 
 def scan(path, require_register_c=False, no_scratch=None, no_packed=None):
@@ -137,6 +164,12 @@ def main(argv):
             print("%s: %d loads into the A / B registers of an MFMA still in flight" % (p, len(war)))
             for k, l, mf in war:
                 print("   %s: %s    <- after %s" % ((k or "?")[:50], l, mf))
+                rc = 1
+        if "--no-packed-before-mfma" in argv:
+            pairs = scan_packed_before_mfma(p)
+            print("%s: %d packed fp32 VALU instructions directly in front of an MFMA" % (p, len(pairs)))
+            for k, a, b in pairs:
+                print("   %s: %s  ->  %s" % ((k or "?")[:50], a, b))
                 rc = 1
         print("%s: %d MFMA instructions, %d with the destination on a source's registers" % (p, total, len(bad)))
         for k, l in bad:

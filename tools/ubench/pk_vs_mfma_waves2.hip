@@ -1,0 +1,152 @@
+// Micro-test (gfx950), r06 -- follow-up of pk_vs_mfma_waves.hip (which reproduced it): WHICH VALU instructions lose results while
+// another wave of the SIMD issues MFMAs with gaps, at WHICH gap, and what the wrong result is.
+//   workgroup = 8 waves (2 per SIMD): waves 0-3 run a chain of 8 instructions of one KIND on random data and compare with the
+//   same arithmetic done before the MFMA waves start (a first pass with the others parked at a barrier is not possible inside one
+//   launch, so: the reference is v_fma_f32 / v_mul_f32 / v_add_f32 code, which KIND 0 shows to be immune);
+//   waves 4-7: "v_mfma; s_nop G" repeated, G fixed per launch (-1: back to back).
+//   KIND 0: v_fma_f32 (scalar control)   1: v_pk_fma_f32   2: v_pk_mul_f32   3: v_pk_add_f32   4: v_pk_fma_f32 with s_nop 1 behind each
+//   build: hipcc --offload-arch=gfx950 -O3 pk_vs_mfma_waves2.hip -o pk_vs_mfma_waves2 ; run: ./pk_vs_mfma_waves2
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+template <int G>
+__device__ __forceinline__ void gap() {
+    if constexpr (G == 0) asm volatile("s_nop 0");
+    if constexpr (G == 1) asm volatile("s_nop 1");
+    if constexpr (G == 2) asm volatile("s_nop 2");
+    if constexpr (G == 3) asm volatile("s_nop 3");
+    if constexpr (G == 4) asm volatile("s_nop 4");
+    if constexpr (G == 5) asm volatile("s_nop 5");
+    if constexpr (G == 6) asm volatile("s_nop 6");
+    if constexpr (G == 7) asm volatile("s_nop 7");
+    if constexpr (G == 11) asm volatile("s_nop 11");
+    if constexpr (G == 15) asm volatile("s_nop 15");
+    if constexpr (G == 31) asm volatile("s_nop 15\n s_nop 15");
+}
+
+template <int KIND, int G>
+__global__ __launch_bounds__(512) void probe(const float *__restrict__ E, int iters, int nset, unsigned long long *bad, float *sink,
+                                             float *examples) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave >= 4) {
+        h8 a, b;
+        for (int u = 0; u < 8; ++u) { a[u] = (_Float16)(0.01f * (lane + u)); b[u] = (_Float16)(0.02f * (lane - u)); }
+        f16v c0 = {0}, c1 = {0};
+        for (int it = 0; it < iters * 3; ++it) {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
+            gap<G>();
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c1, 0, 0, 0);
+            gap<G>();
+        }
+        sink[blockIdx.x * 512 + threadIdx.x] = c0[0] + c1[1];
+        return;
+    }
+    unsigned long long nb = 0, lost = 0;
+    for (int it = 0; it < iters; ++it) {
+        const int set = (it * 5 + blockIdx.x + wave) % nset;
+        const float *e = E + (size_t)set * 20 * 64 + lane;
+        float x[16], w[4];
+        for (int u = 0; u < 16; ++u) x[u] = e[u * 64];
+        for (int u = 0; u < 4; ++u) w[u] = e[(16 + u) * 64];
+        const f2 x01 = {x[0], x[1]}, x23 = {x[2], x[3]}, x45 = {x[4], x[5]}, x67 = {x[6], x[7]}, w01 = {w[0], w[1]}, w23 = {w[2], w[3]};
+        f2 acc = {x[8], x[9]};
+        float r0 = acc.x, r1 = acc.y;
+        if constexpr (KIND == 0) {
+            asm volatile("v_fma_f32 %[d0], %[a0], %[w0], %[d0]\n v_fma_f32 %[d1], %[a1], %[w0], %[d1]\n"
+                         "v_fma_f32 %[d0], %[b0], %[w1], %[d0]\n v_fma_f32 %[d1], %[b1], %[w1], %[d1]\n"
+                         "v_fma_f32 %[d0], %[c0], %[w2], %[d0]\n v_fma_f32 %[d1], %[c1], %[w2], %[d1]\n"
+                         "v_fma_f32 %[d0], %[e0], %[w3], %[d0]\n v_fma_f32 %[d1], %[e1], %[w3], %[d1]\n"
+                         : [d0] "+v"(acc.x), [d1] "+v"(acc.y)
+                         : [a0] "v"(x[0]), [a1] "v"(x[1]), [b0] "v"(x[2]), [b1] "v"(x[3]), [c0] "v"(x[4]), [c1] "v"(x[5]), [e0] "v"(x[6]),
+                           [e1] "v"(x[7]), [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]));
+        }
+        if constexpr (KIND == 1)
+            asm volatile("v_pk_fma_f32 %[d], %[s0], %[w01], %[d] op_sel_hi:[1,0,1]\n v_pk_fma_f32 %[d], %[s1], %[w01], %[d] op_sel:[0,1,0]\n"
+                         "v_pk_fma_f32 %[d], %[s2], %[w23], %[d] op_sel_hi:[1,0,1]\n v_pk_fma_f32 %[d], %[s3], %[w23], %[d] op_sel:[0,1,0]\n"
+                         : [d] "+v"(acc) : [s0] "v"(x01), [s1] "v"(x23), [s2] "v"(x45), [s3] "v"(x67), [w01] "v"(w01), [w23] "v"(w23));
+        if constexpr (KIND == 4)
+            asm volatile("v_pk_fma_f32 %[d], %[s0], %[w01], %[d] op_sel_hi:[1,0,1]\n s_nop 1\n v_pk_fma_f32 %[d], %[s1], %[w01], %[d] op_sel:[0,1,0]\n s_nop 1\n"
+                         "v_pk_fma_f32 %[d], %[s2], %[w23], %[d] op_sel_hi:[1,0,1]\n s_nop 1\n v_pk_fma_f32 %[d], %[s3], %[w23], %[d] op_sel:[0,1,0]\n s_nop 1\n"
+                         : [d] "+v"(acc) : [s0] "v"(x01), [s1] "v"(x23), [s2] "v"(x45), [s3] "v"(x67), [w01] "v"(w01), [w23] "v"(w23));
+        if constexpr (KIND == 0 || KIND == 1 || KIND == 4) {
+            r0 = __builtin_fmaf(x[0], w[0], r0); r1 = __builtin_fmaf(x[1], w[0], r1);
+            r0 = __builtin_fmaf(x[2], w[1], r0); r1 = __builtin_fmaf(x[3], w[1], r1);
+            r0 = __builtin_fmaf(x[4], w[2], r0); r1 = __builtin_fmaf(x[5], w[2], r1);
+            r0 = __builtin_fmaf(x[6], w[3], r0); r1 = __builtin_fmaf(x[7], w[3], r1);
+        }
+        if constexpr (KIND == 2) {      // acc = ((acc * x01) * x23) * (w0, w0) ... products
+            asm volatile("v_pk_mul_f32 %[d], %[d], %[s0]\n v_pk_mul_f32 %[d], %[d], %[w01] op_sel_hi:[1,0]\n"
+                         "v_pk_mul_f32 %[d], %[d], %[s1]\n v_pk_mul_f32 %[d], %[d], %[w23] op_sel:[0,1]\n"
+                         : [d] "+v"(acc) : [s0] "v"(x01), [s1] "v"(x23), [w01] "v"(w01), [w23] "v"(w23));
+            r0 = r0 * x[0]; r1 = r1 * x[1]; r0 = r0 * w[0]; r1 = r1 * w[0]; r0 = r0 * x[2]; r1 = r1 * x[3]; r0 = r0 * w[3]; r1 = r1 * w[3];
+        }
+        if constexpr (KIND == 3) {
+            asm volatile("v_pk_add_f32 %[d], %[d], %[s0]\n v_pk_add_f32 %[d], %[d], %[w01] op_sel_hi:[1,0]\n"
+                         "v_pk_add_f32 %[d], %[d], %[s1]\n v_pk_add_f32 %[d], %[d], %[w23] op_sel:[0,1]\n"
+                         : [d] "+v"(acc) : [s0] "v"(x01), [s1] "v"(x23), [w01] "v"(w01), [w23] "v"(w23));
+            r0 = r0 + x[0]; r1 = r1 + x[1]; r0 = r0 + w[0]; r1 = r1 + w[0]; r0 = r0 + x[2]; r1 = r1 + x[3]; r0 = r0 + w[3]; r1 = r1 + w[3];
+        }
+        const bool b0 = __float_as_uint(r0) != __float_as_uint(acc.x), b1 = __float_as_uint(r1) != __float_as_uint(acc.y);
+        nb += b0 + b1;
+        if ((b0 || b1) && (KIND == 1)) {
+            // is the wrong value the chain with ONE term missing?
+            bool one = false;
+            for (int skip = 0; skip < 4 && !one; ++skip) {
+                float q0 = x[8], q1 = x[9];
+                for (int t = 0; t < 4; ++t) if (t != skip) { q0 = __builtin_fmaf(x[2 * t], w[t], q0); q1 = __builtin_fmaf(x[2 * t + 1], w[t], q1); }
+                one = (b0 && __float_as_uint(q0) == __float_as_uint(acc.x)) || (b1 && __float_as_uint(q1) == __float_as_uint(acc.y));
+            }
+            lost += one;
+            const unsigned long long slot = atomicAdd(bad + 2, 1ull);
+            if (slot < 8) { float *o = examples + slot * 8; o[0] = r0; o[1] = acc.x; o[2] = r1; o[3] = acc.y; o[4] = x[8]; o[5] = x[9]; o[6] = (float)lane; o[7] = one; }
+        }
+    }
+    if (nb) atomicAdd(bad, nb);
+    if (lost) atomicAdd(bad + 1, lost);
+}
+
+static const char *KNAME[] = {"v_fma_f32 (control)", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_pk_fma_f32 + s_nop 1 each"};
+
+template <int KIND, int G>
+void run(const float *E, int nset, unsigned long long *bad, float *sink, float *ex) {
+    hipMemset(bad, 0, 24);
+    const int iters = 20000, blocks = 512;
+    hipLaunchKernelGGL((probe<KIND, G>), dim3(blocks), dim3(512), 0, 0, E, iters, nset, bad, sink, ex);
+    unsigned long long h[3] = {0, 0, 0};
+    hipMemcpy(h, bad, 24, hipMemcpyDeviceToHost);
+    printf("%-30s other wave: v_mfma; s_nop %2d : %.3g chains, wrong results %llu", KNAME[KIND], G, (double)blocks * 256 * iters, h[0]);
+    if (KIND == 1 && h[0]) {
+        float he[64];
+        hipMemcpy(he, ex, sizeof(he), hipMemcpyDeviceToHost);
+        printf("  (chains that equal the chain with ONE term missing: %llu of %llu;  e.g. want %.9g got %.9g | want %.9g got %.9g, lane %g)", h[1], h[2],
+               he[0], he[1], he[2], he[3], he[6]);
+    }
+    printf("\n");
+}
+
+template <int KIND>
+void sweep(const float *E, int nset, unsigned long long *bad, float *sink, float *ex) {
+    run<KIND, -1>(E, nset, bad, sink, ex); run<KIND, 0>(E, nset, bad, sink, ex); run<KIND, 1>(E, nset, bad, sink, ex);
+    run<KIND, 2>(E, nset, bad, sink, ex); run<KIND, 3>(E, nset, bad, sink, ex); run<KIND, 4>(E, nset, bad, sink, ex);
+    run<KIND, 5>(E, nset, bad, sink, ex); run<KIND, 6>(E, nset, bad, sink, ex); run<KIND, 7>(E, nset, bad, sink, ex);
+    run<KIND, 11>(E, nset, bad, sink, ex); run<KIND, 15>(E, nset, bad, sink, ex); run<KIND, 31>(E, nset, bad, sink, ex);
+}
+
+int main() {
+    const int nset = 16;
+    float *E, *sink, *ex; unsigned long long *bad;
+    hipMalloc(&E, nset * 20 * 64 * 4); hipMalloc(&sink, 1024 * 512 * 4); hipMalloc(&bad, 24); hipMalloc(&ex, 64 * 4);
+    float *h = (float *)malloc(nset * 20 * 64 * 4);
+    srand(5);
+    for (int i = 0; i < nset * 20 * 64; ++i) h[i] = ldexpf(0.5f + rand() / (float)RAND_MAX, -(rand() % 6));
+    hipMemcpy(E, h, nset * 20 * 64 * 4, hipMemcpyHostToDevice);
+    sweep<0>(E, nset, bad, sink, ex); sweep<1>(E, nset, bad, sink, ex); sweep<2>(E, nset, bad, sink, ex); sweep<3>(E, nset, bad, sink, ex);
+    sweep<4>(E, nset, bad, sink, ex);
+    return 0;
+}
