@@ -191,23 +191,19 @@ __device__ __forceinline__ void exact_tile(P cp, int nc, int t, int tl, int h, f
 // candidates lane half `h` sees in tile `t`, for the owner to merge under the (d, index) rule (INT_MAX: no candidate)
 template <class P>
 __device__ __forceinline__ void exact_tile_mk(P cp, int nc, int t, int tl, int h, float qx, float qy, float qz, float &m, int &kmin) {
-    typedef float f2 __attribute__((ext_vector_type(2)));
+    // r06: one candidate per instruction.  r04-r05 evaluated two per PACKED fp32 instruction here; on gfx950 a packed fp32 VALU
+    // instruction can lose the low half of its result in lanes 48-63 while another wave of the SIMD issues MFMAs at certain
+    // distances (tools/ubench/pk_vs_mfma_waves2.hip, profiles/r06_packed_f32_vs_mfma.txt; found behind approx-EMD's run-to-run
+    // differing bits) -- and the other fifteen waves of this workgroup are sweeping with MFMAs while this one
+    // evaluates.  Never observed HERE (2 000-repeat soak, 1.3e5 fuzz cases bit for bit), but a kernel that issues MFMAs keeps no
+    // packed fp32: csrc/Makefile gates every object on it (tools/mfma_overlap_check.py --no-packed-with-mfma)
     float d[16];
-    const f2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const float *row = cp + (size_t)tl * PROW + 8 * g + 4 * h;
         const float4 vx = *(const float4 *)row, vy = *(const float4 *)(row + 32), vz = *(const float4 *)(row + 64);
-        {   // two candidates per packed instruction; every operation rounded on its own, as dist3
-            const f2 dx = f2{vx.x, vx.y} - qx2, dy = f2{vy.x, vy.y} - qy2, dz = f2{vz.x, vz.y} - qz2;
-            const f2 dd = (dx * dx + dy * dy) + dz * dz;
-            d[4 * g + 0] = dd.x; d[4 * g + 1] = dd.y;
-        }
-        {
-            const f2 dx = f2{vx.z, vx.w} - qx2, dy = f2{vy.z, vy.w} - qy2, dz = f2{vz.z, vz.w} - qz2;
-            const f2 dd = (dx * dx + dy * dy) + dz * dz;
-            d[4 * g + 2] = dd.x; d[4 * g + 3] = dd.y;
-        }
+        d[4 * g + 0] = dist3(vx.x, vy.x, vz.x, qx, qy, qz); d[4 * g + 1] = dist3(vx.y, vy.y, vz.y, qx, qy, qz);
+        d[4 * g + 2] = dist3(vx.z, vy.z, vz.z, qx, qy, qz); d[4 * g + 3] = dist3(vx.w, vy.w, vz.w, qx, qy, qz);
     }
     m = fminf(fminf(d[0], d[1]), d[2]);
 #pragma unroll
@@ -566,6 +562,7 @@ __global__ __launch_bounds__(64) void nnm_surrogate_kernel(const float *__restri
     }
     if (qt == 0 && ct == 0) {          // R2 and mu, by one wave
         float r2 = 0.f;
+#pragma clang loop vectorize(disable) interleave(disable)      // (no packed fp32 in a kernel that issues MFMAs: exact_tile_mk)
         for (int t = lane; t < nq + nc; t += 64) {
             const float *src = t < nq ? q + (size_t)t * 3 : c + (size_t)(t - nq) * 3;
             const float x = src[0] - mux, y = src[1] - muy, z = src[2] - muz;

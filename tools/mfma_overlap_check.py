@@ -12,6 +12,11 @@ identical to source C is the normal accumulate form and is not reported.
                            approx-EMD passes flickered too)
     --no-packed-f32 PREFIX r06: also fail if a kernel whose name contains PREFIX holds v_pk_{fma,mul,add}_f32 (the SLP vectoriser's
                            packed accumulations: see the next option; the approx-EMD passes keep none at all)
+    --ignore-overlap       count the overlapping destinations but do not fail on them (csrc/Makefile's gate for every object)
+    --no-packed-with-mfma  r06, the isolated form of the same defect (tools/ubench/pk_vs_mfma_waves2.hip, profiles/r06_packed_f32_vs_mfma.txt):
+                           v_pk_{fma,mul,add}_f32 loses the LOW half of its result in lanes 48-63 while ANOTHER wave of the SIMD
+                           issues MFMAs at certain distances -- nothing in the wave's own instruction stream prevents it.  Fails if
+                           any kernel of the file holds both MFMAs and packed fp32 VALU instructions
     --no-packed-before-mfma
                            r06, the instruction pair tools/asm_bisect found behind r05's / r06's run-to-run differing bits (DESIGN
                            4.6): a packed fp32 VALU instruction whose NEXT instruction is an MFMA -- in emd_mfma_cols_kernel<0> of
@@ -24,8 +29,9 @@ identical to source C is the normal accumulate form and is not reported.
                            the matrix pipe).  An INVENTORY, not a defect list: tools/ubench/mfma_war.hip / mfma_valu_war.hip
                            show the hardware interlocks this pattern (a rejected hypothesis for r05's run-to-run
                            differences; flow.hip has thousands of such sites and has never flickered)
-csrc/Makefile runs it on emd.s with the first three options before emd.o may be linked: determinism of those kernels is a property of the
-compiled code (include/dpf_hip.h at dpf_emd_set_matrix_path).
+csrc/Makefile runs it on emd.s with the first three options before emd.o may be linked, and on EVERY object's assembly with
+--no-packed-with-mfma --no-packed-before-mfma: determinism of those kernels is a property of the compiled code (ADVICE r05,
+include/dpf_hip.h at dpf_emd_set_matrix_path).
 """
 import re
 import sys
@@ -64,6 +70,25 @@ def scan_packed_before_mfma(path):
             out.append((kernel, prev, body))
         prev = body
     return out
+
+
+def scan_packed_with_mfma(path):
+    """[(kernel, packed count, mfma count)]: kernels that hold both"""
+    counts, kernel = {}, None
+    for line in open(path):
+        m = re.match(r"^(\S+):\s", line)
+        if m and not m.group(1).startswith("."):
+            kernel = m.group(1)
+            counts[kernel] = [0, 0]
+            continue
+        body = line.split(";")[0].strip()
+        if kernel is None or not body:
+            continue
+        if PACKED_F32.match(body):
+            counts[kernel][0] += 1
+        elif re.match(r"(v_mfma_|v_smfmac_)", body):
+            counts[kernel][1] += 1
+    return [(k, a, b) for k, (a, b) in counts.items() if a and b]
 
 
 def scan(path, require_register_c=False, no_scratch=None, no_packed=None):
@@ -165,6 +190,12 @@ def main(argv):
             for k, l, mf in war:
                 print("   %s: %s    <- after %s" % ((k or "?")[:50], l, mf))
                 rc = 1
+        if "--no-packed-with-mfma" in argv:
+            both = scan_packed_with_mfma(p)
+            print("%s: %d kernels with both MFMAs and packed fp32 VALU instructions" % (p, len(both)))
+            for k, a, b in both:
+                print("   %s: %d packed fp32, %d MFMA" % ((k or "?")[:70], a, b))
+                rc = 1
         if "--no-packed-before-mfma" in argv:
             pairs = scan_packed_before_mfma(p)
             print("%s: %d packed fp32 VALU instructions directly in front of an MFMA" % (p, len(pairs)))
@@ -172,6 +203,8 @@ def main(argv):
                 print("   %s: %s  ->  %s" % ((k or "?")[:50], a, b))
                 rc = 1
         print("%s: %d MFMA instructions, %d with the destination on a source's registers" % (p, total, len(bad)))
+        if "--ignore-overlap" in argv:          # (the library-wide gate: the packed-fp32 rules only)
+            continue
         for k, l in bad:
             print("   %s: %s" % (k[:60], l))
             rc = 1
