@@ -662,8 +662,11 @@ __device__ __forceinline__ Frag scale_frag(u4 r1, u4 r2, const u4 (&sv)[2]) { re
 // keeps its own hazard bookkeeping.  Why not inline asm with an early-clobber output and written-out wait states (the first
 // remedy tried): bit-stable at 2 x 2048^2, but at 8192^2 with two or more waves per SIMD pass 1 itself then returned ~1 (B = 2)
 // to ~50 (B = 16) differing sums per call -- more with more s_nop, none with one wave per SIMD, none with the builtin.  The
-// overlap alone is harmless (tools/ubench/mfma_overlap.hip: 2e7 isolated MFMAs per pattern); the cause inside the scheduled
-// code is not established.  What is established is which forms repeat bit for bit: test_matrix_core_passes_repeat_bit_for_bit
+// overlap alone is harmless (tools/ubench/mfma_overlap.hip: 2e7 isolated MFMAs per pattern).  r06 established the cause inside
+// the scheduled code: every one of those builds was vectorised, the vectoriser's packed accumulations use the form
+// "v_pk_fma_f32 ... op_sel:[0,1,0]", and that form loses its low half in lanes 48-63 while another wave of the SIMD issues MFMAs
+// at certain distances (tools/ubench/pk_vs_mfma_forms.hip) -- "two or more waves per SIMD", "more with more s_nop" and "grew with
+// the kernel's duration" are that condition.  Which forms repeat bit for bit: test_matrix_core_passes_repeat_bit_for_bit
 // runs the sizes and regimes that flickered.  tools/mfma_overlap_check.py lists overlapping MFMAs in any .s
 // (tests/test_isa_cpu.py: none in emd.hip; the flow / Chamfer / encoder kernels have some, all first-of-chain, and their
 // bit-exact and replay-equals-eager tests have never flickered).
@@ -726,7 +729,9 @@ __device__ __forceinline__ f16acc pair_exponents(const Frag &rows, const Frag &c
 // tools/mfma_overlap_check.py --war lists such sites.  REJECTED: tools/ubench/mfma_war.hip and mfma_valu_war.hip overwrite the
 // sources of up to seven queued MFMAs by a cache-resident load / by VALU writes in the very next slot, 1.6e7 times at up to four
 // waves per SIMD, without one wrong result -- the hardware interlocks it; the pinned build flickered like the unpinned one, and
-// both repeat once the vectoriser is off.  The pins cost nothing measurable (cfg5 2.740 vs 2.741 ms).
+// both repeat once the vectoriser is off (what the vectoriser wrote was "v_pk_fma_f32 ... op_sel:[0,1,0]", a packed form
+// that loses its low half in lanes 48-63 beside another wave's MFMAs -- tools/ubench/pk_vs_mfma_forms.hip).  The pins cost nothing
+// measurable (cfg5 2.740 vs 2.741 ms).
 #ifndef EMD_PIN_LOADS
 #define EMD_PIN_LOADS 0
 #endif

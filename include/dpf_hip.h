@@ -112,9 +112,12 @@ size_t dpf_approxmatch_workspace_bytes(int b, int n, int m);
  * dpf_approxmatch.  The matrix-core results are within the tolerance contract (cost 1e-4; the exp2 arguments within 2e-5 of
  * float64 at the steepest level on unit-size clouds, measured by dpf_debug_emd_exponents), not bit-identical.  DETERMINISM of
  * the matrix-core kernels is a property of the compiled code, not of the source: two builds of r05 returned run-to-run
- * differing bits (csrc/emd.hip, opaque_zero); the Makefile therefore refuses to link an emd.o whose MFMAs do not have the
- * properties of the build that repeats (tools/mfma_overlap_check.py --require-register-c), and tests/test_gpu_emd.py holds the
- * repeat tests.  Returns the previous setting. */
+ * differing bits (csrc/emd.hip, opaque_zero).  r06 found why: the compiler's vectoriser had written a packed fp32 instruction form
+ * (low half reading the high word of a VGPR pair) that gfx950 executes wrongly in lanes 48-63 while another wave of the SIMD issues
+ * MFMAs (tools/ubench/pk_vs_mfma_forms.hip).  The Makefile refuses to link ANY object that holds that form, or packed
+ * fp32 beside MFMAs, or an emd.o whose MFMAs do not have the properties of the build that repeats (tools/mfma_overlap_check.py);
+ * tests/test_gpu_emd.py holds the repeat tests, tests/test_gpu_interference.py runs the kernels beside an MFMA-issuing kernel of
+ * another stream.  Returns the previous setting. */
 int dpf_emd_set_matrix_path(int on);
 int dpf_approxmatch_ws(int b, int n, int m, const float *xyz1, const float *xyz2,
                        float *match, float *temp, void *workspace, size_t workspace_bytes,

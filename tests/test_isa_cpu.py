@@ -154,10 +154,79 @@ def test_emd_matrix_passes_keep_the_mfma_destination_apart(tmp_path_factory):
             assert re.search(r",\s*[va]\[\d+:\d+\]\s*$", ln), ln       # C is a register tuple, not the literal 0
     mk = open(os.path.join(CSRC, "Makefile")).read()
     rule = mk.split("emd.o:")[1].split("\n\n")[0]
-    assert "mfma_overlap_check.py --require-register-c --no-scratch emd_mfma_ --no-packed-f32 emd_mfma_ emd.s" in rule
+    assert "mfma_overlap_check.py --require-register-c --no-scratch emd_mfma_ --no-packed-f32 emd_mfma_ " in rule and rule.count(" emd.s") >= 2
     assert rule.count("-fno-slp-vectorize") == 2              # the gated listing and the object are the same build
     # ... and none of the matrix-core kernels spills (r05: a build forced to 128 registers -- 40 to 123 spilled -- failed the
     # parity and repeat tests on the GPU, besides being 2 - 6 x slower)
     for name, body in _kernels(text).items():
         if "emd_mfma_" in name:
             assert "scratch_" not in body, name
+
+
+# ---- r06: the packed-fp32 rules of every object ---------------------------------------------------------------
+def _checker():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mfma_overlap_check", os.path.join(ROOT, "tools", "mfma_overlap_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_the_checker_knows_the_affected_instruction_forms(tmp_path):
+    """tools/ubench/pk_vs_mfma_forms.hip on MI355X: of eight forms only the one whose LOW half reads the HIGH word of a VGPR pair
+    loses results beside another wave's MFMAs.  The checker must flag exactly that form, a packed instruction directly in front of
+    an MFMA, and a kernel that holds both kinds."""
+    chk = _checker()
+    text = """
+kern_a: ; @kern_a
+\tv_pk_fma_f32 v[132:133], v[172:173], v[112:113], v[132:133] op_sel:[0,1,0]
+\tv_mfma_f32_32x32x16_f16 v[34:49], v[142:145], v[78:81], v[34:49]
+\tv_pk_fma_f32 v[2:3], v[4:5], v[6:7], v[2:3] op_sel_hi:[1,0,1]
+\ts_nop 0
+\tv_mfma_f32_32x32x16_f16 v[34:49], v[142:145], v[78:81], v[34:49]
+.Lfunc_end0:
+kern_b: ; @kern_b
+\tv_pk_add_f32 v[2:3], s[4:5], v[6:7] op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]
+\tv_pk_mul_f32 v[2:3], v[2:3], v[6:7]
+\tv_pk_mul_f32 v[2:3], v[2:3], v[6:7] op_sel:[0,1]
+.Lfunc_end1:
+"""
+    p = tmp_path / "t.s"
+    p.write_text(text)
+    low = chk.scan_packed_low_from_high(str(p))
+    assert [(k, l.split()[0], l.split("op_sel:")[1][:7]) for k, l in low] == [("kern_a", "v_pk_fma_f32", "[0,1,0]"), ("kern_b", "v_pk_mul_f32", "[0,1]")]
+    pairs = chk.scan_packed_before_mfma(str(p))
+    assert len(pairs) == 1 and pairs[0][0] == "kern_a" and "op_sel:[0,1,0]" in pairs[0][1]
+    both = chk.scan_packed_with_mfma(str(p))
+    assert both == [("kern_a", 2, 2)]
+    assert chk.main(["--ignore-overlap", "--no-packed-with-mfma", "--no-packed-before-mfma", "--no-packed-low-from-high", str(p)]) == 1
+
+
+def test_makefile_gates_every_object_on_the_packed_fp32_rules():
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    gate = [ln for ln in mk.splitlines() if ln.startswith("GATE :=")]
+    assert len(gate) == 1 and all(o in gate[0] for o in ("--no-packed-with-mfma", "--no-packed-before-mfma", "--no-packed-low-from-high")), gate
+    rules = re.findall(r"^([\w%]+\.o): .*\n((?:\t.*\n)+)", mk, flags=re.M)
+    objs = re.search(r"^OBJS := (.*)$", mk, flags=re.M).group(1).split()
+    named = {t for t, _ in rules}
+    for t, body in rules:
+        if t.endswith(("_prof.o", "_ab.o")) or t not in set(objs) | {"%.o"}:
+            continue                                    # (profiling / ablation builds are scratch: nothing but libdpf_hip.so ships)
+        if t == "emd.o":
+            assert all(o in body for o in ("--no-packed-with-mfma", "--no-packed-before-mfma", "--no-packed-low-from-high")), body
+        else:
+            assert "$(call isa_gate," in body, (t, body)
+    assert "%.o" in named and "emd.o" in named
+
+
+def test_the_built_objects_hold_no_affected_packed_form():
+    """the assembly listings `make` leaves beside the objects (csrc/*.s; __graft_entry__.build() has run make) through the same gate"""
+    chk = _checker()
+    listings = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".s")]
+    fresh = [p for p in listings if os.path.exists(p[:-2] + ".hip") and os.path.getmtime(p) >= os.path.getmtime(p[:-2] + ".hip")]
+    if len(fresh) < 10:
+        pytest.skip("no fresh listings beside the objects (run make -C dpf_nets_amd/csrc)")
+    for p in fresh:
+        assert chk.scan_packed_low_from_high(p) == [], p
+        assert chk.scan_packed_before_mfma(p) == [], p
+        assert chk.scan_packed_with_mfma(p) == [], p
