@@ -4,6 +4,8 @@
 //   3 v_pk_mul_f32 plain            4 v_pk_add_f32 plain                  5 v_pk_mul_f32 op_sel_hi:[1,0]
 //   6 v_pk_add_f32 V, S, V op_sel_hi:[0,1] neg (csrc/chamfer.hip's scan: a candidate pair in SGPRs against two queries)
 //   7 v_pk_add_f32 V, S, V op_sel:[1,0] neg
+//   8 v_fma_mixlo_f16 V, V, S, V op_sel_hi:[1,0,0] clamp  +  v_fma_mixhi_f16 V, V, S, V op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp
+//     (csrc/flow.hip's relu + fp16 split, 768 of each in the headline kernel: op_sel picks the HIGH 16 bits of ONE register)
 //   build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off pk_vs_mfma_forms.hip -o pk_vs_mfma_forms ; run: ./pk_vs_mfma_forms
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -89,6 +91,32 @@ __global__ __launch_bounds__(512) void probe(const float *__restrict__ E, int it
                          "v_pk_add_f32 %[d], %[sp], %[d] op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_add_f32 %[d], %[sp], %[d] op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n" OPS4);
             r0 = s1 - r0; r1 = s1 - r1; r0 = s1 - x[0]; r1 = s1 - x[1]; r0 = s1 - r0; r1 = s1 - r1; r0 = s1 - r0; r1 = s1 - r1;
         }
+        if constexpr (FORM == 8) {
+            // a = two fp16 numbers in one register; d.lo16 = f16(clamp(a.lo16 * s + c)), d.hi16 = f16(clamp(a.hi16 * s + c)), four times
+            uint32_t d = 0;
+            const _Float16 h0 = (_Float16)(x[0] * 0.5f), h1 = (_Float16)(x[1] * 0.5f);
+            const uint32_t a = (uint32_t)__builtin_bit_cast(unsigned short, h0) | ((uint32_t)__builtin_bit_cast(unsigned short, h1) << 16);
+            float c = x[2] - 1.0f;
+            uint32_t dd[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                asm volatile("v_fma_mixlo_f16 %[d], %[a], %[s], %[c] op_sel_hi:[1,0,0] clamp\n v_fma_mixhi_f16 %[d], %[a], %[s], %[c] op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp\n"
+                             : [d] "+v"(d) : [a] "v"(a), [s] "s"(s0), [c] "v"(c));
+                dd[t] = d;
+                c += 0.03125f;
+            }
+            float cc = x[2] - 1.0f;
+            unsigned long long wl = 0, wh = 0;
+            for (int t = 0; t < 4; ++t) {
+                const float lo = fminf(fmaxf(__builtin_fmaf((float)h0, s0, cc), 0.f), 1.f), hi = fminf(fmaxf(__builtin_fmaf((float)h1, s0, cc), 0.f), 1.f);
+                const uint32_t want = (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)lo) | ((uint32_t)__builtin_bit_cast(unsigned short, (_Float16)hi) << 16);
+                wl += (want & 0xffffu) != (dd[t] & 0xffffu);
+                wh += (want >> 16) != (dd[t] >> 16);
+                cc += 0.03125f;
+            }
+            nlo += wl; nhi += wh;
+            continue;
+        }
         nlo += __float_as_uint(r0) != __float_as_uint(acc.x);
         nhi += __float_as_uint(r1) != __float_as_uint(acc.y);
     }
@@ -97,7 +125,8 @@ __global__ __launch_bounds__(512) void probe(const float *__restrict__ E, int it
 }
 
 static const char *NAME[] = {"v_pk_fma_f32 plain", "v_pk_fma_f32 op_sel_hi:[1,0,1]", "v_pk_fma_f32 op_sel:[0,1,0]", "v_pk_mul_f32 plain", "v_pk_add_f32 plain",
-                             "v_pk_mul_f32 op_sel_hi:[1,0]", "v_pk_add_f32 V,S,V op_sel_hi:[0,1] neg", "v_pk_add_f32 V,S,V op_sel:[1,0] neg"};
+                             "v_pk_mul_f32 op_sel_hi:[1,0]", "v_pk_add_f32 V,S,V op_sel_hi:[0,1] neg", "v_pk_add_f32 V,S,V op_sel:[1,0] neg",
+                             "v_fma_mixlo/hi_f16 (flow.hip's split)"};
 
 template <int FORM, int G>
 void run(const float *E, int nset, unsigned long long *bad, float *sink) {
@@ -120,5 +149,6 @@ int main() {
     hipMemcpy(E, h, nset * 20 * 64 * 4, hipMemcpyHostToDevice);
     both<0>(E, nset, bad, sink); both<1>(E, nset, bad, sink); both<2>(E, nset, bad, sink); both<3>(E, nset, bad, sink);
     both<4>(E, nset, bad, sink); both<5>(E, nset, bad, sink); both<6>(E, nset, bad, sink); both<7>(E, nset, bad, sink);
+    both<8>(E, nset, bad, sink);
     return 0;
 }
