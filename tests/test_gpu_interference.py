@@ -192,3 +192,33 @@ def test_flow_stack_and_encoder_beside_an_mfma_neighbour():
             e = enc(tz)
         return [ps[-1], mus[-1], lvs[-1]] + ([e] if torch.is_tensor(e) else [t for t in e if torch.is_tensor(t)])
     _beside(I, run, 10)
+
+
+def test_training_step_beside_an_mfma_neighbour():
+    """forward + backward of the 63-layer training stack (315 dependent launches of flow_train.hip's kernels, BatchNorm statistics,
+    FiLM training kernels) and the latent prior flow's training kernels: outputs, input gradients and every parameter gradient"""
+    I = _interferer()
+    from dpf_nets_amd import networks as nets
+    torch.manual_seed(0)
+    dec = nets.LocalCondRNVPDecoder(21, 64, 128).cuda().train()
+    dec.flatten_parameters()
+    tgt, z, g = FO.synthetic_inputs(7, 8, 2048, 128)
+    tp, tg = torch.from_numpy(tgt).cuda(), torch.from_numpy(g).cuda()
+    prior = nets.GlobalRNVPDecoder(3, 64, 128, weight_std=0.05).cuda().train()
+    gg = torch.from_numpy(GO.gprior_inputs(9, 64, 128)).cuda()
+
+    def run():
+        dec.zero_grad(set_to_none=True)
+        prior.zero_grad(set_to_none=True)
+        tpi = tp.clone().requires_grad_(True)
+        ps, mus, lvs = dec(tpi, tg, mode="inverse")
+        (ps[0].square().mean() + sum(lvs).mean()).backward()
+        out = prior(gg, mode="direct")
+        flat = []
+        for o in out:
+            flat += list(o) if isinstance(o, (list, tuple)) else [o]
+        flat = [t for t in flat if torch.is_tensor(t)]
+        sum(t.square().mean() for t in flat).backward()
+        return [ps[0].detach(), tpi.grad] + [p.grad for p in dec.parameters() if p.grad is not None] + \
+               [t.detach() for t in flat] + [p.grad for p in prior.parameters() if p.grad is not None]
+    _beside(I, run, 4)
